@@ -1,0 +1,150 @@
+/*
+ * libsfd2hip -- C-ABI of the MI355X-native SFD2 extract + match hot path.
+ *
+ * One shared object, plain pointers and sizes, no torch types.  Every entry point
+ * names the reference interface (feixue94/sfd2, file:line) it replaces.  The
+ * Python host side (sfd2_amd/) binds these with ctypes; INTEGRATION.md shows the
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - return value 0 = ok, negative = error; text in sfd2_last_error() (thread local)
+ *   - a context is bound to ONE device and ONE HIP stream; it is not thread-safe;
+ *     use one context per GPU (any number per process)
+ *   - the caller owns every input/output buffer; the library owns the context,
+ *     packed weights and workspace only
+ *   - `*_on_device` flags: 0 = host pointer (pageable ok), 1 = device pointer on the
+ *     context's device
+ *   - all calls are synchronous with respect to the host unless SFD2_FLAG_ASYNC is
+ *     passed (then the caller synchronises the stream from sfd2_get_stream())
+ */
+#ifndef SFD2_HIP_H
+#define SFD2_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sfd2_ctx sfd2_ctx;
+
+#define SFD2_DESC_DIM 128
+#define SFD2_FLAG_ASYNC 1          /* do not synchronise the stream before returning     */
+#define SFD2_FLAG_NO_STABILITY 2   /* use_stability = False (extract_localization.py:31) */
+#define SFD2_FLAG_IMG_NORMALISED 4 /* input already passed through norm_RGB               */
+
+/* One named fp32 tensor of the reference state_dict (torch layout), host memory.
+ * Replaces: model.load_state_dict(torch.load(p)['model'])  extract_localization.py:213-215 */
+typedef struct {
+    const char *name;   /* e.g. "conv1a.0.weight", "conv4.1.bn2.running_var" */
+    const float *data;  /* contiguous fp32                                   */
+    int32_t ndim;
+    int64_t shape[4];
+} sfd2_tensor;
+
+/* matcher flavours */
+#define SFD2_MATCH_HLOC 0       /* hloc/matchers/nearest_neighbor.py:38-57                  */
+#define SFD2_MATCH_ITLOC_NNM 1  /* it_loc/matcher.py:122-130 (+ scores :113)               */
+#define SFD2_MATCH_ITLOC_NNR 2  /* it_loc/matcher.py:165-194                               */
+/* descriptor element types / layouts accepted by the matcher */
+#define SFD2_DT_F32 0
+#define SFD2_DT_F64 1
+#define SFD2_DT_F16 2
+#define SFD2_LAYOUT_ND 0  /* [n][dim]  (it_loc/matcher.py: [N,128])                        */
+#define SFD2_LAYOUT_DN 1  /* [dim][n]  (hloc feature files: [128,N], match_features.py:99) */
+/* similarity arithmetic */
+#define SFD2_SIM_F16 0       /* fp16 operands, fp32 accumulate: |err| < 1e-3 on unit vectors */
+#define SFD2_SIM_F16X2 1     /* hi+lo fp16 split (3 MFMA products): ~fp32 accuracy            */
+
+typedef struct {
+    int32_t flavour;          /* SFD2_MATCH_*                                                */
+    int32_t do_mutual_check;  /* hloc only (default_conf, nearest_neighbor.py:28-32)          */
+    float ratio_threshold;    /* hloc: <=0 means None.  itloc nnr: the Lowe ratio (0.9)       */
+    float distance_threshold; /* hloc: <=0 means None                                         */
+    int32_t sim_mode;         /* SFD2_SIM_*                                                   */
+} sfd2_match_conf;
+
+typedef struct {
+    float ms_total;      /* last sfd2_extract / sfd2_match* call, device time (hip events) */
+    float ms_backbone;   /* conv stack incl. heads                                          */
+    float ms_post;       /* heat map, NMS, selection, descriptor sampling                   */
+    float ms_match;
+    int64_t n_candidates; /* N0 after NMS + threshold + border of the last extract          */
+} sfd2_timings;
+
+int sfd2_version(void);
+const char *sfd2_last_error(void);
+
+int sfd2_ctx_create(int device, sfd2_ctx **out);
+void sfd2_ctx_destroy(sfd2_ctx *ctx);
+/* HIP stream (hipStream_t) all of this context's kernels are launched on. */
+void *sfd2_get_stream(sfd2_ctx *ctx);
+
+/* Folds Conv bias + BatchNorm (eval) into fp32 per-channel scale/shift, converts the
+ * filters to fp16 MFMA-friendly layouts and uploads them.  Unknown names
+ * (num_batches_tracked ...) are ignored; missing ones are an error.
+ * Replaces: ResSegNetV2.__init__ / load_state_dict  (nets/sfd2.py:259-303). */
+int sfd2_load_weights(sfd2_ctx *ctx, const sfd2_tensor *tensors, int n);
+
+/* ResSegNetV2.det (nets/sfd2.py:313-354).  x: [3][H][W] fp32, normalised image
+ * (pass SFD2_FLAG_IMG_NORMALISED) or raw [0,1] RGB (normalised on the fly).
+ * score [8*H8][8*W8], stability [H][W], desc [128][Hc][Wc] (L2-normalised), fp32.
+ * Any output pointer may be NULL.  *hs,*ws receive the score map size. */
+int sfd2_det(sfd2_ctx *ctx, const float *x, int x_on_device, int H, int W, int flags,
+             float *score, float *stability, float *desc, int out_on_device,
+             int *hs, int *ws, int *hc, int *wc);
+
+/* extract_resnet_return, single scale, mask=None (nets/extractor.py:97-338):
+ * img [3][H][W] fp32 in [0,1] -> up to top_k key points sorted by score descending.
+ * kpts_xy [cap][2] (x, y), scores [cap], desc [cap][128] fp32, cap = top_k (>0).
+ * top_k <= 0 keeps every candidate (cap_out entries are then written at most).
+ * nms_radius 4 and border 4 are the reference's constants (:143-144). */
+int sfd2_extract(sfd2_ctx *ctx, const float *img, int img_on_device, int H, int W,
+                 float conf_th, int top_k, int flags,
+                 float *kpts_xy, float *scores, float *desc, int out_on_device,
+                 int64_t cap_out, int *n_out);
+/* After an SFD2_FLAG_ASYNC extract: number of key points, once the stream is idle. */
+int sfd2_extract_count(sfd2_ctx *ctx, int *n_out);
+
+/* Stage entry points (parity tests; each is the device kernel the pipeline uses). */
+/* simple_nms(scores, 4) (nets/extractor.py:20-35): heat [H][W] -> nms [H][W] */
+int sfd2_simple_nms(sfd2_ctx *ctx, const float *heat, int H, int W, int radius, float *nms_out);
+/* NMS + threshold + border + sort + top-K (nets/extractor.py:157-183,322-326) */
+int sfd2_select_keypoints(sfd2_ctx *ctx, const float *heat, int H, int W, float conf_th,
+                          int radius, int border, int top_k,
+                          float *kpts_xy, float *scores, int64_t cap_out, int *n_out);
+/* bilinear descriptor sampling + renormalisation (nets/extractor.py:199-208);
+ * desc_map [128][hc][wc] fp32 (raw or normalised), kpts [n][2] */
+int sfd2_sample_descriptors(sfd2_ctx *ctx, const float *desc_map, int hc, int wc, int nh, int nw,
+                            const float *kpts_xy, int n, float *desc_out);
+/* heat = resize(score) * stability (nets/extractor.py:137-141), with stability from the
+ * 3-class logits sta [3][hc][wc] (nets/sfd2.py:345-347).  score [hs][ws]. sta may be NULL. */
+int sfd2_heatmap(sfd2_ctx *ctx, const float *score, int hs, int ws, const float *sta, int hc, int wc,
+                 int H, int W, float *heat_out);
+/* Reads back an intermediate activation of the last sfd2_det/sfd2_extract as fp32 [c][h][w].
+ * Names: conv1a bn1b conv2a bn2b conv3a bn3b conv4.0.bn1 conv4.0.bn2 conv4.0 conv4.1 conv4.2
+ *        convPa.0 convPa convDa.0 convDa convPb convDb ConvSta */
+int sfd2_debug_activation(sfd2_ctx *ctx, const char *name, float *out, int64_t cap, int *c, int *h, int *w);
+
+/* Nearest-neighbour matcher.  d0 [n0 x dim], d1 [n1 x dim] (dtype/layout as given).
+ * matches0 [n0] int64 (-1 = no match); scores0 [n0] fp32 (hloc: (sim+1)/2 or 0;
+ * itloc: raw row maximum).  Replaces NearestNeighbor._forward
+ * (hloc/matchers/nearest_neighbor.py:38-57) and Matcher.forward (it_loc/matcher.py:91-119). */
+int sfd2_match(sfd2_ctx *ctx, const void *d0, int n0, const void *d1, int n1, int dim,
+               int dtype, int layout, int on_device, const sfd2_match_conf *conf,
+               int64_t *matches0, float *scores0, int out_on_device);
+
+/* One query against k database images (the localiser's inner loop,
+ * it_loc/localize_cv2.py:705-715 -> feature_matching :511-560).  d1s[k], n1s[k];
+ * matches0 [k][n0], scores0 [k][n0].  Device-resident descriptor sets in fp16
+ * ([n][128]) avoid any per-call conversion. */
+int sfd2_match_batch(sfd2_ctx *ctx, const void *d0, int n0, const void *const *d1s, const int *n1s, int k,
+                     int dim, int dtype, int layout, int on_device, const sfd2_match_conf *conf,
+                     int64_t *matches0, float *scores0, int out_on_device, int flags);
+
+int sfd2_get_timings(sfd2_ctx *ctx, sfd2_timings *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFD2_HIP_H */

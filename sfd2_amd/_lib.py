@@ -1,0 +1,171 @@
+"""ctypes binding of libsfd2hip.so (C-ABI in include/sfd2_hip.h).
+
+There is NO fallback: if the shared object is missing or no MI355X is visible the
+product path raises.  (oracle/ is test infrastructure and is never imported here.)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsfd2hip.so")
+
+FLAG_ASYNC = 1
+FLAG_NO_STABILITY = 2
+FLAG_IMG_NORMALISED = 4
+MATCH_HLOC, MATCH_ITLOC_NNM, MATCH_ITLOC_NNR = 0, 1, 2
+DT_F32, DT_F64, DT_F16 = 0, 1, 2
+LAYOUT_ND, LAYOUT_DN = 0, 1
+SIM_F16, SIM_F16X2 = 0, 1
+
+
+class Sfd2Tensor(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.c_void_p), ("ndim", ctypes.c_int32),
+                ("shape", ctypes.c_int64 * 4)]
+
+
+class MatchConf(ctypes.Structure):
+    _fields_ = [("flavour", ctypes.c_int32), ("do_mutual_check", ctypes.c_int32),
+                ("ratio_threshold", ctypes.c_float), ("distance_threshold", ctypes.c_float),
+                ("sim_mode", ctypes.c_int32)]
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [("ms_total", ctypes.c_float), ("ms_backbone", ctypes.c_float), ("ms_post", ctypes.c_float),
+                ("ms_match", ctypes.c_float), ("n_candidates", ctypes.c_int64)]
+
+
+# every symbol include/sfd2_hip.h declares (tests/test_abi.py checks the two lists agree)
+EXPORTS = [
+    "sfd2_version", "sfd2_last_error", "sfd2_ctx_create", "sfd2_ctx_destroy", "sfd2_get_stream",
+    "sfd2_load_weights", "sfd2_det", "sfd2_extract", "sfd2_extract_count", "sfd2_simple_nms",
+    "sfd2_select_keypoints", "sfd2_sample_descriptors", "sfd2_heatmap", "sfd2_debug_activation",
+    "sfd2_match", "sfd2_match_batch", "sfd2_get_timings",
+]
+
+_lib = None
+
+
+def load():
+    """Loads the shared object (does not touch the GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci, cf, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+    pi = ctypes.POINTER(ctypes.c_int)
+    lib.sfd2_version.restype = ci
+    lib.sfd2_last_error.restype = ctypes.c_char_p
+    lib.sfd2_ctx_create.argtypes = [ci, ctypes.POINTER(vp)]
+    lib.sfd2_ctx_destroy.argtypes = [vp]
+    lib.sfd2_ctx_destroy.restype = None
+    lib.sfd2_get_stream.argtypes = [vp]
+    lib.sfd2_get_stream.restype = vp
+    lib.sfd2_load_weights.argtypes = [vp, ctypes.POINTER(Sfd2Tensor), ci]
+    lib.sfd2_det.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, pi, pi, pi, pi]
+    lib.sfd2_extract.argtypes = [vp, vp, ci, ci, ci, cf, ci, ci, vp, vp, vp, ci, i64, pi]
+    lib.sfd2_extract_count.argtypes = [vp, pi]
+    lib.sfd2_simple_nms.argtypes = [vp, vp, ci, ci, ci, vp]
+    lib.sfd2_select_keypoints.argtypes = [vp, vp, ci, ci, cf, ci, ci, ci, vp, vp, i64, pi]
+    lib.sfd2_sample_descriptors.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, vp]
+    lib.sfd2_heatmap.argtypes = [vp, vp, ci, ci, vp, ci, ci, ci, ci, vp]
+    lib.sfd2_debug_activation.argtypes = [vp, ctypes.c_char_p, vp, i64, pi, pi, pi]
+    lib.sfd2_match.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, ctypes.POINTER(MatchConf), vp, vp, ci]
+    lib.sfd2_match_batch.argtypes = [vp, vp, ci, ctypes.POINTER(vp), pi, ci, ci, ci, ci, ci,
+                                     ctypes.POINTER(MatchConf), vp, vp, ci, ci]
+    lib.sfd2_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
+    for name in EXPORTS:
+        getattr(lib, name)  # raises AttributeError if the .so lacks a declared symbol
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libsfd2hip: " + load().sfd2_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a):
+    """Raw address of a numpy array / torch tensor / int / None."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()  # torch tensor
+
+
+class Context:
+    """One sfd2_ctx: one GPU, one HIP stream, one set of packed weights."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = ctypes.c_void_p()
+        check(self.lib.sfd2_ctx_create(int(device), ctypes.byref(h)))
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sfd2_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return self.lib.sfd2_get_stream(self.h)
+
+    def load_weights(self, sd):
+        """sd: {name: array-like}; fp32 tensors of the reference state_dict."""
+        keep, arr = [], (Sfd2Tensor * len(sd))()
+        n = 0
+        for name, v in sd.items():
+            a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            if a.dtype.kind != "f":
+                continue  # num_batches_tracked
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.ndim > 4:
+                continue
+            keep.append(a)
+            arr[n].name = name.encode()
+            arr[n].data = a.ctypes.data
+            arr[n].ndim = a.ndim
+            for i, s in enumerate(a.shape):
+                arr[n].shape[i] = s
+            n += 1
+        check(self.lib.sfd2_load_weights(self.h, arr, n))
+
+    def timings(self):
+        t = Timings()
+        check(self.lib.sfd2_get_timings(self.h, ctypes.byref(t)))
+        return {"ms_total": t.ms_total, "ms_backbone": t.ms_backbone, "ms_post": t.ms_post,
+                "ms_match": t.ms_match, "n_candidates": t.n_candidates}
+
+    def debug_activation(self, name):
+        c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(self.lib.sfd2_debug_activation(self.h, name.encode(), None, 0, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)))
+        out = np.empty((c.value, h.value, w.value), dtype=np.float32)
+        check(self.lib.sfd2_debug_activation(self.h, name.encode(), out.ctypes.data, out.size, ctypes.byref(c),
+                                             ctypes.byref(h), ctypes.byref(w)))
+        return out
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Shared per-device context (used by the matchers)."""
+    d = int(device)
+    if d not in _default_ctx:
+        _default_ctx[d] = Context(d)
+    return _default_ctx[d]

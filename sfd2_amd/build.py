@@ -1,0 +1,42 @@
+"""Builds libsfd2hip.so (hipcc, gfx950) in-tree.  Called by __graft_entry__.build()."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsfd2hip.so")
+SOURCES = ["conv_kernels.hip", "post_kernels.hip", "match_kernels.hip", "sfd2_api.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build_lib(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    deps = [os.path.join(CSRC, "sfd2_internal.h"), os.path.join(HERE, "..", "include", "sfd2_hip.h")]
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(s, o) or any(_newer(d, o) for d in deps):
+            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    if force or procs or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(verbose=True))

@@ -1,0 +1,277 @@
+// Mutual nearest-neighbour descriptor matcher on gfx950: D0 . D1^T on
+// v_mfma_f32_32x32x16_f16 with the row top-2 reduction fused into the GEMM epilogue (the
+// N x M similarity matrix never exists in memory), then ratio / distance / mutual tests.
+//
+// Replaces (file:line in the reference):
+//   hloc/matchers/nearest_neighbor.py:6-16 find_nn, :19-24 mutual_check, :38-57 _forward
+//   it_loc/matcher.py:91-119 Matcher.forward, :122-130 mutual_nn_matcher, :165-194 mutual_nn_ratio_matcher
+//
+// Orientation: the side being REDUCED over ("a": candidates j) is the MFMA A operand (rows),
+// the side being KEPT ("b": queries i) is the B operand (columns).  In the 32x32 C/D layout
+// (col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)) a lane then holds 16 different candidates
+// of ONE query, so the running top-2 is lane-local; one cross-half merge at the end.
+// The reverse direction (column top-2 of the similarity matrix) is the same kernel with the
+// operands swapped.
+#include "sfd2_internal.h"
+#include <math.h>
+
+#define NT 256
+#define KD 128        // descriptor dimension (nets/sfd2.py:260 outdim=128)
+#define TA 64         // candidate rows per LDS stage
+#define APITCH 136    // fp16 per staged row: 128 + 8 pad (272 B)
+
+// ---------------------------------------------------------------- operand preparation
+// hi = fp16(v);  lo = fp16((v - hi) * 2^11)  so that  v ~= hi + lo * 2^-11  to ~2^-22 relative.
+__global__ __launch_bounds__(NT)
+void match_prep_kernel(const void *__restrict__ src, int n, int dim, int dtype, int layout,
+                       half_t *__restrict__ hi, half_t *__restrict__ lo)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * KD) return;
+    const int i = (int)(t / KD), d = (int)(t % KD);
+    double v = 0.0;
+    if (d < dim) {
+        const size_t off = layout == 0 ? (size_t)i * dim + d : (size_t)d * n + i;
+        if (dtype == 0) v = (double)reinterpret_cast<const float *>(src)[off];
+        else if (dtype == 1) v = reinterpret_cast<const double *>(src)[off];
+        else v = (double)(float)reinterpret_cast<const half_t *>(src)[off];
+    }
+    const half_t h = (half_t)(float)v;
+    hi[t] = h;
+    if (lo) lo[t] = (half_t)(float)((v - (double)(float)h) * 2048.0);
+}
+
+void launch_match_prep(hipStream_t st, const void *src, int n, int dim, int dtype, int layout, half_t *hi, half_t *lo)
+{
+    const size_t tot = (size_t)n * KD;
+    if (tot == 0) return;
+    hipLaunchKernelGGL(match_prep_kernel, dim3((unsigned)((tot + NT - 1) / NT)), dim3(NT), 0, st, src, n, dim, dtype,
+                       layout, hi, lo);
+}
+
+// ---------------------------------------------------------------- fused GEMM + top-2
+__device__ __forceinline__ void top2_update(float v, int j, float &b1, float &b2, int &i1)
+{
+    // strict '>' keeps the first (lowest) index among equal maxima, like torch.max / our tie rule
+    b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+    i1 = v > b1 ? j : i1;
+    b1 = fmaxf(b1, v);
+}
+
+template <bool USE_LO>
+__global__ __launch_bounds__(NT, 2)
+void match_top2_kernel(const MatchJob *__restrict__ jobs, int splits)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half_t *As = reinterpret_cast<half_t *>(smem);                 // [2][TA][APITCH] hi
+    half_t *Al = As + 2 * TA * APITCH;                             // [2][TA][APITCH] lo (USE_LO)
+    const MatchJob job = jobs[blockIdx.z];
+    const int na = job.na, nb = job.nb;
+    const int i_base = blockIdx.x * 128;
+    if (i_base >= nb) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lcol = lane & 31, lk = (lane >> 5) * 8;
+
+    // candidate range of this split, multiple of 32 so sub-tiles never straddle splits
+    int chunk = (na + splits - 1) / splits;
+    chunk = (chunk + 31) & ~31;
+    const int ja0 = blockIdx.y * chunk;
+    int ja1 = ja0 + chunk;
+    if (ja1 > na) ja1 = na;
+
+    const int my_i = i_base + wave * 32 + lcol;
+    h8_t bh[8], bl[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        h8_t z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (half_t)0.0f;
+        bh[ks] = z;
+        bl[ks] = z;
+        if (my_i < nb) {
+            bh[ks] = *reinterpret_cast<const h8_t *>(job.b_hi + (size_t)my_i * KD + ks * 16 + lk);
+            if (USE_LO) bl[ks] = *reinterpret_cast<const h8_t *>(job.b_lo + (size_t)my_i * KD + ks * 16 + lk);
+        }
+    }
+
+    float b1 = -INFINITY, b2 = -INFINITY;
+    int i1 = 0;
+
+    if (ja0 < ja1) {
+        const int nst = (ja1 - ja0 + TA - 1) / TA;
+        uint4 rh[4], rl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { rh[i] = make_uint4(0, 0, 0, 0); rl[i] = make_uint4(0, 0, 0, 0); }
+        // piece p (0..1023): row = p >> 4, part = p & 15 (16 bytes each)
+#define LOAD_A(stage_)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+        const int p = tid + i * NT, row = p >> 4, part = p & 15;                                       \
+        const int ja = ja0 + (stage_)*TA + row;                                                        \
+        rh[i] = make_uint4(0, 0, 0, 0);                                                                \
+        rl[i] = make_uint4(0, 0, 0, 0);                                                                \
+        if (ja < ja1) {                                                                                \
+            rh[i] = *reinterpret_cast<const uint4 *>(job.a_hi + (size_t)ja * KD + part * 8);           \
+            if (USE_LO) rl[i] = *reinterpret_cast<const uint4 *>(job.a_lo + (size_t)ja * KD + part * 8); \
+        }                                                                                              \
+    }
+#define STORE_A(buf_)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+        const int p = tid + i * NT, row = p >> 4, part = p & 15;                                       \
+        *reinterpret_cast<uint4 *>(As + ((buf_)*TA + row) * APITCH + part * 8) = rh[i];                \
+        if (USE_LO) *reinterpret_cast<uint4 *>(Al + ((buf_)*TA + row) * APITCH + part * 8) = rl[i];    \
+    }
+        LOAD_A(0)
+        STORE_A(0)
+        __syncthreads();
+        for (int s = 0; s < nst; ++s) {
+            const int buf = s & 1;
+            const bool has_next = s + 1 < nst;
+            if (has_next) { LOAD_A(s + 1) }
+#pragma unroll
+            for (int sub = 0; sub < TA / 32; ++sub) {
+                f32x16_t acc, accx;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; accx[r] = 0.0f; }
+                const half_t *arow = As + (buf * TA + sub * 32 + lcol) * APITCH + lk;
+                const half_t *arow_l = Al + (buf * TA + sub * 32 + lcol) * APITCH + lk;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const h8_t ah = *reinterpret_cast<const h8_t *>(arow + ks * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
+                    if (USE_LO) {
+                        const h8_t al = *reinterpret_cast<const h8_t *>(arow_l + ks * 16);
+                        accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], accx, 0, 0, 0);
+                        accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], accx, 0, 0, 0);
+                    }
+                }
+                const int jbase = ja0 + s * TA + sub * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = jbase + (r & 3) + 8 * (r >> 2);
+                    float v = acc[r];
+                    if (USE_LO) v = v + accx[r] * (1.0f / 2048.0f);
+                    if (j >= ja1) v = -INFINITY;
+                    top2_update(v, j, b1, b2, i1);
+                }
+            }
+            if (has_next) { STORE_A(buf ^ 1) }
+            __syncthreads();
+        }
+#undef LOAD_A
+#undef STORE_A
+    }
+    // merge the two half-waves (same query, interleaved candidate rows)
+    const float c1 = __shfl_xor(b1, 32), c2 = __shfl_xor(b2, 32);
+    const int j1 = __shfl_xor(i1, 32);
+    float n1v, n2v;
+    int n1i;
+    if (c1 > b1 || (c1 == b1 && j1 < i1)) { n1v = c1; n1i = j1; n2v = fmaxf(b1, c2); }
+    else { n1v = b1; n1i = i1; n2v = fmaxf(b2, c1); }
+    if (lane < 32 && my_i < nb) {
+        const size_t o = (size_t)blockIdx.y * nb + my_i;
+        job.part_v1[o] = n1v;
+        job.part_v2[o] = n2v;
+        job.part_i1[o] = n1i;
+    }
+}
+
+void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int max_nb, int splits, int use_lo)
+{
+    if (njobs <= 0 || max_nb <= 0) return;
+    static bool attr_done = false;
+    const size_t lds_hi = (size_t)2 * TA * APITCH * sizeof(half_t);
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_hi));
+        attr_done = true;
+    }
+    const dim3 grid((max_nb + 127) / 128, splits, njobs);
+    if (use_lo) hipLaunchKernelGGL(match_top2_kernel<true>, grid, dim3(NT), 2 * lds_hi, st, jobs_dev, splits);
+    else hipLaunchKernelGGL(match_top2_kernel<false>, grid, dim3(NT), lds_hi, st, jobs_dev, splits);
+}
+
+// ---------------------------------------------------------------- split merge + decisions
+// red[0][i] = best similarity, red[1][i] = second best, red[2][i] = arg best (int bits)
+__global__ __launch_bounds__(NT)
+void match_reduce_kernel(const MatchFinal *__restrict__ fins, int splits)
+{
+    const MatchFinal f = fins[blockIdx.y];
+    const int dir = blockIdx.z;
+    const int n = dir == 0 ? f.n0 : f.n1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *v1 = dir == 0 ? f.f_v1 : f.r_v1;
+    const float *v2 = dir == 0 ? f.f_v2 : f.r_v2;
+    const int *i1 = dir == 0 ? f.f_i1 : f.r_i1;
+    float *red = dir == 0 ? f.red_f : f.red_r;
+    float b1 = -INFINITY, b2 = -INFINITY;
+    int bi = 0;
+    for (int s = 0; s < splits; ++s) {  // splits ascend in candidate index: strict '>' keeps the lowest
+        const float c1 = v1[(size_t)s * n + i], c2 = v2[(size_t)s * n + i];
+        const int ci = i1[(size_t)s * n + i];
+        if (c1 > b1) { b2 = fmaxf(b1, c2); b1 = c1; bi = ci; }
+        else { b2 = fmaxf(b2, c1); }
+    }
+    red[i] = b1;
+    red[(size_t)n + i] = b2;
+    reinterpret_cast<int *>(red)[2 * (size_t)n + i] = bi;
+}
+
+__device__ __forceinline__ bool hloc_pass(float s1, float s2, float ratio, float dist)
+{
+    const float d0 = 2.0f * (1.0f - s1), d1 = 2.0f * (1.0f - s2);     // find_nn: dist_nn = 2 * (1 - sim_nn)
+    bool ok = true;
+    if (ratio > 0.0f) ok = ok && (d0 <= (ratio * ratio) * d1);
+    if (dist > 0.0f) ok = ok && (d0 <= dist * dist);
+    return ok;
+}
+__device__ __forceinline__ float lowe_ratio(float s1, float s2)
+{
+    // it_loc/matcher.py:171-174: sqrt(2 - 2 sim), ratio = d0 / (d1 + 1e-8).  2 - 2 sim is clamped at 0
+    // (the reference yields NaN -> "no match" when rounding pushes a self-similarity above 1).
+    const float d0 = sqrtf(fmaxf(2.0f - 2.0f * s1, 0.0f)), d1 = sqrtf(fmaxf(2.0f - 2.0f * s2, 0.0f));
+    return d0 / (d1 + 1e-8f);
+}
+
+__global__ __launch_bounds__(NT)
+void match_decide_kernel(const MatchFinal *__restrict__ fins, int flavour, int mutual, float ratio, float dist)
+{
+    const MatchFinal f = fins[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= f.n0) return;
+    const float s1 = f.red_f[i], s2 = f.red_f[(size_t)f.n0 + i];
+    const int j = reinterpret_cast<const int *>(f.red_f)[2 * (size_t)f.n0 + i];
+    long long m = -1;
+    float score = 0.0f;
+    if (f.n1 > 0) {
+        const float t1 = f.red_r[j], t2 = f.red_r[(size_t)f.n1 + j];
+        const int back = reinterpret_cast<const int *>(f.red_r)[2 * (size_t)f.n1 + j];
+        if (flavour == 0) {  // hloc NearestNeighbor
+            const bool ok = hloc_pass(s1, s2, ratio, dist);
+            score = ok ? (s1 + 1.0f) / 2.0f : 0.0f;   // scores0 come from the forward direction only
+            m = ok ? j : -1;
+            if (ok && mutual) {
+                const bool ok_back = hloc_pass(t1, t2, ratio, dist);
+                if (!(ok_back && back == i)) m = -1;
+            }
+        } else if (flavour == 1) {  // it_loc nnm
+            score = s1;
+            m = (back == i) ? j : -1;
+        } else {  // it_loc nnr
+            score = s1;
+            const bool ok = (back == i) && lowe_ratio(s1, s2) <= ratio && lowe_ratio(t1, t2) <= ratio;
+            m = ok ? j : -1;
+        }
+    }
+    f.matches0[i] = m;
+    f.scores0[i] = score;
+}
+
+void launch_match_finalize(hipStream_t st, const MatchFinal *fin_dev, int npairs, int max_n, int splits, int flavour,
+                           int mutual, float ratio, float dist)
+{
+    if (npairs <= 0 || max_n <= 0) return;
+    hipLaunchKernelGGL(match_reduce_kernel, dim3((max_n + NT - 1) / NT, npairs, 2), dim3(NT), 0, st, fin_dev, splits);
+    hipLaunchKernelGGL(match_decide_kernel, dim3((max_n + NT - 1) / NT, npairs), dim3(NT), 0, st, fin_dev, flavour,
+                       mutual, ratio, dist);
+}

@@ -1,0 +1,469 @@
+// Heads and key-point selection of the SFD2 extractor on gfx950: detector soft-max +
+// depth-to-space, stability up-sampling + arg-max, heat map, max-pool NMS, threshold /
+// border / top-K selection with a defined tie order, bilinear descriptor sampling.
+// HBM-bound work: coalesced loads, LDS tiling, wave64 reductions.
+//
+// Replaces (file:line in the reference):
+//   nets/sfd2.py:329-337 (detector head)      nets/sfd2.py:305-311,345-347 (stability)
+//   nets/extractor.py:137-141 (heat map)       nets/extractor.py:20-35 (simple_nms)
+//   nets/extractor.py:158-183,322-326 (selection)   nets/extractor.py:199-208 (descriptors)
+#include "sfd2_internal.h"
+#include <math.h>
+
+#define NT 256
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// ---------------------------------------------------------------- detector head
+// One wave per coarse cell: lane c holds channel c (0..63), channel 64 is the dust bin.
+__global__ __launch_bounds__(NT)
+void detector_head_kernel(const float *__restrict__ logits, int pitch, int hc, int wc, float *__restrict__ score)
+{
+    const int lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (cell >= hc * wc) return;
+    const int y = cell / wc, x = cell - y * wc;
+    const float *p = logits + (size_t)cell * pitch;
+    const float e = expf(p[lane]);
+    const float ed = expf(p[64]);
+    const float den = (wave_sum(e) + ed) + 0.00001f;
+    score[(size_t)(8 * y + (lane >> 3)) * (8 * wc) + 8 * x + (lane & 7)] = e / den;
+}
+
+void launch_detector_head(hipStream_t st, const float *logits, int pitch, int hc, int wc, float *score)
+{
+    const int cells = hc * wc;
+    hipLaunchKernelGGL(detector_head_kernel, dim3((cells + 3) / 4), dim3(NT), 0, st, logits, pitch, hc, wc, score);
+}
+
+// ---------------------------------------------------------------- bilinear (torch, align_corners=False)
+// Rounding sequence pinned to torch's CPU kernel (see oracle/orc_post.c orc_resize_bilinear):
+//   src = fma(scale, dst + 0.5, -0.5) clamped at 0;   out = fma(top, ly0, bot*ly1), top = fma(v00, lx0, v01*lx1)
+struct LinCoef { int i0, i1; float l0, l1; };
+__device__ __forceinline__ LinCoef lin_coef(int dst, int in_size, int out_size, float scale)
+{
+    LinCoef c;
+    if (in_size == out_size) { c.i0 = dst; c.i1 = dst; c.l0 = 1.0f; c.l1 = 0.0f; return c; }
+    float src = __fmaf_rn(scale, (float)dst + 0.5f, -0.5f);
+    if (src < 0.0f) src = 0.0f;
+    int a = (int)floorf(src);
+    if (a > in_size - 1) a = in_size - 1;
+    float lam = __fsub_rn(src, (float)a);
+    lam = fminf(fmaxf(lam, 0.0f), 1.0f);
+    c.i0 = a;
+    c.i1 = (a + 1 < in_size) ? a + 1 : in_size - 1;
+    c.l1 = lam;
+    c.l0 = __fsub_rn(1.0f, lam);
+    return c;
+}
+__device__ __forceinline__ float bilerp(const float *__restrict__ p, int w, const LinCoef &cy, const LinCoef &cx)
+{
+    const float v00 = p[(size_t)cy.i0 * w + cx.i0], v01 = p[(size_t)cy.i0 * w + cx.i1];
+    const float v10 = p[(size_t)cy.i1 * w + cx.i0], v11 = p[(size_t)cy.i1 * w + cx.i1];
+    const float top = __fmaf_rn(v00, cx.l0, __fmul_rn(v01, cx.l1));
+    const float bot = __fmaf_rn(v10, cx.l0, __fmul_rn(v11, cx.l1));
+    return __fmaf_rn(top, cy.l0, __fmul_rn(bot, cy.l1));
+}
+
+// heat[y][x] = resize(score)[y][x] * cls_to_value(argmax_c resize(sta_c)[y][x])
+__global__ __launch_bounds__(NT)
+void heatmap_kernel(const float *__restrict__ score, int hs, int ws, float sc_y, float sc_x,
+                    const float *__restrict__ sta, int hc, int wc, float st_y, float st_x,
+                    int H, int W, float *__restrict__ heat, float *__restrict__ stab_out)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    float s;
+    if (hs == H && ws == W) {
+        s = score[(size_t)y * ws + x];
+    } else {
+        const LinCoef cy = lin_coef(y, hs, H, sc_y), cx = lin_coef(x, ws, W, sc_x);
+        s = bilerp(score, ws, cy, cx);
+    }
+    float stab = 1.0f;
+    if (sta) {
+        const LinCoef cy = lin_coef(y, hc, H, st_y), cx = lin_coef(x, wc, W, st_x);
+        const size_t plane = (size_t)hc * wc;
+        const float v0 = bilerp(sta, wc, cy, cx);
+        const float v1 = bilerp(sta + plane, wc, cy, cx);
+        const float v2 = bilerp(sta + 2 * plane, wc, cy, cx);
+        int best = 0;
+        float bv = v0;
+        if (v1 > bv) { bv = v1; best = 1; }
+        if (v2 > bv) { bv = v2; best = 2; }
+        stab = best == 0 ? 0.1f : (best == 1 ? 0.5f : 1.0f);
+        if (stab_out) stab_out[(size_t)y * W + x] = stab;
+    }
+    if (heat) heat[(size_t)y * W + x] = __fmul_rn(s, stab);
+}
+
+void launch_heatmap(hipStream_t st, const float *score, int hs, int ws, const float *sta, int hc, int wc,
+                    int H, int W, float *heat, float *stab_out)
+{
+    const float sc_y = (float)hs / (float)H, sc_x = (float)ws / (float)W;
+    const float st_y = hc > 0 ? (float)hc / (float)H : 1.0f, st_x = wc > 0 ? (float)wc / (float)W : 1.0f;
+    hipLaunchKernelGGL(heatmap_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(NT), 0, st, score, hs, ws, sc_y, sc_x,
+                       sta, hc, wc, st_y, st_x, H, W, heat, stab_out);
+}
+
+// ---------------------------------------------------------------- simple_nms (+ threshold/border/compaction)
+// One block = 32 x 64 output pixels, LDS region = tile + 5*radius halo (radius 4 -> 72 x 104):
+// five chained 9x9 max-pools, each run as a row pass and a column pass over the whole region; a
+// value is exact once it is 4 px further from the region edge than its inputs.
+// Padding semantics of torch.max_pool2d (-inf outside the image) are carried by the data:
+// scores outside the image are -inf, masks outside the image are 0.
+#define NMS_TH 32
+#define NMS_TW 64
+#define NMS_RMAX 4
+#define NMS_RH (NMS_TH + 10 * NMS_RMAX)
+#define NMS_RW (NMS_TW + 10 * NMS_RMAX)
+#define NMS_N (NMS_RH * NMS_RW)
+
+__device__ __forceinline__ void pool_rows(const float *__restrict__ src, float *__restrict__ dst, int r)
+{
+    for (int i = threadIdx.x; i < NMS_N; i += blockDim.x) {
+        const int y = i / NMS_RW, x = i - y * NMS_RW;
+        const int a = x - r < 0 ? 0 : x - r, b = x + r >= NMS_RW ? NMS_RW - 1 : x + r;
+        float m = src[y * NMS_RW + a];
+        for (int t = a + 1; t <= b; ++t) m = fmaxf(m, src[y * NMS_RW + t]);
+        dst[i] = m;
+    }
+}
+__device__ __forceinline__ void pool_cols(const float *__restrict__ src, float *__restrict__ dst, int r)
+{
+    for (int i = threadIdx.x; i < NMS_N; i += blockDim.x) {
+        const int y = i / NMS_RW, x = i - y * NMS_RW;
+        const int a = y - r < 0 ? 0 : y - r, b = y + r >= NMS_RH ? NMS_RH - 1 : y + r;
+        float m = src[a * NMS_RW + x];
+        for (int t = a + 1; t <= b; ++t) m = fmaxf(m, src[t * NMS_RW + x]);
+        dst[i] = m;
+    }
+}
+
+__global__ __launch_bounds__(512)
+void nms_select_kernel(const float *__restrict__ heat, int H, int W, int radius, float conf_th, int border,
+                       float *__restrict__ nms_dense, unsigned long long *__restrict__ cand, int cand_cap,
+                       unsigned int *__restrict__ counters)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *S = reinterpret_cast<float *>(smem);
+    float *A = S + NMS_N;
+    float *B = A + NMS_N;
+    unsigned char *M = reinterpret_cast<unsigned char *>(B + NMS_N);
+    const int halo = 5 * radius;
+    const int gy0 = blockIdx.y * NMS_TH - halo, gx0 = blockIdx.x * NMS_TW - halo;
+    const float NEG = -INFINITY;
+
+    for (int i = threadIdx.x; i < NMS_N; i += blockDim.x) {
+        const int y = i / NMS_RW, x = i - y * NMS_RW;
+        const int gy = gy0 + y, gx = gx0 + x;
+        S[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? heat[(size_t)gy * W + gx] : NEG;
+    }
+    __syncthreads();
+    pool_rows(S, A, radius);
+    __syncthreads();
+    pool_cols(A, B, radius);
+    __syncthreads();
+    for (int i = threadIdx.x; i < NMS_N; i += blockDim.x) {
+        const bool oob = S[i] == NEG;
+        const bool mk = !oob && (S[i] == B[i]);            // max_mask = scores == max_pool(scores)
+        M[i] = mk ? 1 : 0;
+        B[i] = mk ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    for (int it = 0; it < 2; ++it) {
+        pool_rows(B, A, radius);
+        __syncthreads();
+        pool_cols(A, B, radius);                           // B = max_pool(max_mask.float())
+        __syncthreads();
+        for (int i = threadIdx.x; i < NMS_N; i += blockDim.x) {
+            const bool oob = S[i] == NEG;
+            const bool supp = B[i] > 0.0f;                 // supp_mask
+            M[i] = (M[i] & 1) | (supp ? 2 : 0);
+            B[i] = oob ? NEG : (supp ? 0.0f : S[i]);       // supp_scores (padding stays -inf)
+        }
+        __syncthreads();
+        pool_rows(B, A, radius);
+        __syncthreads();
+        pool_cols(A, B, radius);                           // B = max_pool(supp_scores)
+        __syncthreads();
+        for (int i = threadIdx.x; i < NMS_N; i += blockDim.x) {
+            const bool oob = S[i] == NEG;
+            const bool supp = (M[i] & 2) != 0;
+            const float ss = supp ? 0.0f : S[i];
+            const bool new_max = (ss == B[i]);
+            bool mk = (M[i] & 1) != 0;
+            if (!oob && new_max && !supp) mk = true;       // max_mask | (new_max_mask & ~supp_mask)
+            M[i] = mk ? 1 : 0;
+            B[i] = mk ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < NMS_TH * NMS_TW; i += blockDim.x) {
+        const int ty = i / NMS_TW, tx = i - ty * NMS_TW;
+        const int gy = blockIdx.y * NMS_TH + ty, gx = blockIdx.x * NMS_TW + tx;
+        if (gy >= H || gx >= W) continue;
+        const int li = (ty + halo) * NMS_RW + tx + halo;
+        const float v = M[li] ? S[li] : 0.0f;              // where(max_mask, scores, zeros)
+        if (nms_dense) nms_dense[(size_t)gy * W + gx] = v;
+        if (cand && v > conf_th && gx >= border && gx < W - border && gy >= border && gy < H - border) {
+            const unsigned int idx = (unsigned int)(gy * W + gx);
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+            const unsigned int pos = atomicAdd(&counters[0], 1u);
+            if (pos < (unsigned int)cand_cap) cand[pos] = key;
+        }
+    }
+}
+
+void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radius, float conf_th, int border,
+                       float *nms_dense, unsigned long long *cand, int cand_cap, unsigned int *counters)
+{
+    static bool attr_done = false;
+    const size_t lds = (size_t)NMS_N * (3 * sizeof(float) + 1);
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_select_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(nms_select_kernel, dim3((W + NMS_TW - 1) / NMS_TW, (H + NMS_TH - 1) / NMS_TH), dim3(512), lds,
+                       st, heat, H, W, radius, conf_th, border, nms_dense, cand, cand_cap, counters);
+}
+
+// ---------------------------------------------------------------- top-K + sort
+// Keys are unique 64-bit integers: (score bits << 32) | (0xFFFFFFFF - pixel index); descending
+// key order == score descending, then pixel index ascending (the tie rule of DESIGN.md).
+// counters: [0] n_cand (may exceed cap: overflow flag), [1] n_selected, [2] compaction cursor,
+//           [4..5] threshold key.
+__global__ __launch_bounds__(1024)
+void radix_select_kernel(const unsigned long long *__restrict__ cand, int cand_cap, int top_k,
+                         unsigned int *__restrict__ counters)
+{
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long s_prefix, s_mask;
+    __shared__ unsigned int s_remaining;
+    unsigned int n = counters[0];
+    if (n > (unsigned int)cand_cap) n = cand_cap;
+    unsigned int k = (top_k <= 0 || (unsigned int)top_k > n) ? n : (unsigned int)top_k;
+    unsigned long long *thr = reinterpret_cast<unsigned long long *>(counters + 4);
+    if (k == n) {  // keep everything
+        if (threadIdx.x == 0) { *thr = 0ull; counters[1] = n; counters[2] = 0; }
+        return;
+    }
+    if (threadIdx.x == 0) { s_prefix = 0ull; s_mask = 0ull; s_remaining = k; }
+    for (int pass = 7; pass >= 0; --pass) {
+        const int shift = pass * 8;
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix, mask = s_mask;
+        for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned long long key = cand[i];
+            if ((key & mask) == prefix) atomicAdd(&hist[(unsigned int)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int cum = 0, rem = s_remaining;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (cum + hist[d] >= rem) break;
+                cum += hist[d];
+            }
+            s_remaining = rem - cum;
+            s_prefix = prefix | ((unsigned long long)d << shift);
+            s_mask = mask | (0xFFull << shift);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { *thr = s_prefix; counters[1] = k; counters[2] = 0; }
+}
+
+__global__ __launch_bounds__(NT)
+void compact_selected_kernel(const unsigned long long *__restrict__ cand, int cand_cap,
+                             unsigned long long *__restrict__ sel, int sel_cap, unsigned int *__restrict__ counters)
+{
+    unsigned int n = counters[0];
+    if (n > (unsigned int)cand_cap) n = cand_cap;
+    const unsigned long long thr = *reinterpret_cast<const unsigned long long *>(counters + 4);
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long key = cand[i];
+        if (key >= thr) {
+            const unsigned int pos = atomicAdd(&counters[2], 1u);
+            if (pos < (unsigned int)sel_cap) sel[pos] = key;
+        }
+    }
+}
+
+// rank-by-counting sort of the selected keys (unique) into descending order
+__global__ __launch_bounds__(NT)
+void rank_sort_kernel(const unsigned long long *__restrict__ sel, unsigned long long *__restrict__ sorted,
+                      int sel_cap, const unsigned int *__restrict__ counters)
+{
+    __shared__ unsigned long long tile[1024];
+    unsigned int n = counters[1];
+    if (n > (unsigned int)sel_cap) n = sel_cap;
+    if (blockIdx.x * blockDim.x >= n) return;
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long mine = i < n ? sel[i] : 0ull;
+    unsigned int rank = 0;
+    for (unsigned int base = 0; base < n; base += 1024) {
+        for (unsigned int t = threadIdx.x; t < 1024; t += blockDim.x) tile[t] = (base + t < n) ? sel[base + t] : 0ull;
+        __syncthreads();
+        const unsigned int lim = n - base < 1024 ? n - base : 1024;
+        for (unsigned int t = 0; t < lim; ++t) rank += tile[t] > mine ? 1u : 0u;
+        __syncthreads();
+    }
+    if (i < n) sorted[rank] = mine;
+}
+
+void launch_topk_sort(hipStream_t st, const unsigned long long *cand, int cand_cap, int top_k,
+                      unsigned long long *sel, unsigned long long *sorted, int sel_cap, unsigned int *counters)
+{
+    hipLaunchKernelGGL(radix_select_kernel, dim3(1), dim3(1024), 0, st, cand, cand_cap, top_k, counters);
+    int grid = (cand_cap + NT - 1) / NT;
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(compact_selected_kernel, dim3(grid), dim3(NT), 0, st, cand, cand_cap, sel, sel_cap, counters);
+    hipLaunchKernelGGL(rank_sort_kernel, dim3((sel_cap + NT - 1) / NT), dim3(NT), 0, st, sel, sorted, sel_cap, counters);
+}
+
+__global__ __launch_bounds__(NT)
+void keys_to_kpts_kernel(const unsigned long long *__restrict__ sorted, const unsigned int *__restrict__ counters,
+                         int W, float *__restrict__ kpts, float *__restrict__ scores, int cap)
+{
+    unsigned int n = counters[1];
+    if (n > (unsigned int)cap) n = cap;
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = sorted[i];
+    const unsigned int idx = 0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull);
+    kpts[2 * i] = (float)(idx % (unsigned int)W);
+    kpts[2 * i + 1] = (float)(idx / (unsigned int)W);
+    scores[i] = __uint_as_float((unsigned int)(key >> 32));
+}
+
+void launch_keys_to_kpts(hipStream_t st, const unsigned long long *sorted, const unsigned int *counters, int W,
+                         float *kpts, float *scores, int cap)
+{
+    if (cap <= 0) return;
+    hipLaunchKernelGGL(keys_to_kpts_kernel, dim3((cap + NT - 1) / NT), dim3(NT), 0, st, sorted, counters, W, kpts, scores, cap);
+}
+
+// ---------------------------------------------------------------- descriptor sampling
+// One wave per key point, lane l owns channels 2l, 2l+1.  The four taps are L2-normalised on
+// the fly (F.normalize of the dense map, nets/sfd2.py:342, commutes with the gather), blended
+// with torch's grid_sample weights (zeros padding, align_corners=False) and re-normalised.
+__global__ __launch_bounds__(NT)
+void sample_desc_kernel(const float *__restrict__ dmap, int hc, int wc, float half_w, float half_h,
+                        const float *__restrict__ kpts, const unsigned int *__restrict__ count, int n_max,
+                        float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    int n = n_max;
+    if (count) { const unsigned int c = *count; if ((unsigned int)n > c) n = (int)c; }
+    if (i >= n) return;
+    const float gx = __fsub_rn(__fdiv_rn(kpts[2 * i], half_w), 1.0f);
+    const float gy = __fsub_rn(__fdiv_rn(kpts[2 * i + 1], half_h), 1.0f);
+    const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.0f), (float)wc), 1.0f), 2.0f);
+    const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.0f), (float)hc), 1.0f), 2.0f);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float ex = __fsub_rn(__fadd_rn(fx, 1.0f), ix), ey = __fsub_rn(__fadd_rn(fy, 1.0f), iy);
+    const float dx = __fsub_rn(ix, fx), dy = __fsub_rn(iy, fy);
+    const float w_nw = __fmul_rn(ex, ey), w_ne = __fmul_rn(dx, ey), w_sw = __fmul_rn(ex, dy), w_se = __fmul_rn(dx, dy);
+    const bool vx0 = x0 >= 0 && x0 < wc, vx1 = x1 >= 0 && x1 < wc;
+    const bool vy0 = y0 >= 0 && y0 < hc, vy1 = y1 >= 0 && y1 < hc;
+    float a0 = 0.0f, a1 = 0.0f;
+#define SFD2_TAP(valid_, yy_, xx_, wgt_)                                                             \
+    if (valid_) {                                                                                    \
+        const float2 v = *reinterpret_cast<const float2 *>(dmap + ((size_t)(yy_) * wc + (xx_)) * 128 + 2 * lane); \
+        const float nrm = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y)), 1e-12f);                     \
+        a0 += __fdiv_rn(v.x, nrm) * (wgt_);                                                          \
+        a1 += __fdiv_rn(v.y, nrm) * (wgt_);                                                          \
+    }
+    SFD2_TAP(vy0 && vx0, y0, x0, w_nw)
+    SFD2_TAP(vy0 && vx1, y0, x1, w_ne)
+    SFD2_TAP(vy1 && vx0, y1, x0, w_sw)
+    SFD2_TAP(vy1 && vx1, y1, x1, w_se)
+#undef SFD2_TAP
+    const float nrm = sqrtf(wave_sum(a0 * a0 + a1 * a1));
+    *reinterpret_cast<float2 *>(out + (size_t)i * 128 + 2 * lane) = make_float2(__fdiv_rn(a0, nrm), __fdiv_rn(a1, nrm));
+}
+
+void launch_sample_desc(hipStream_t st, const float *dmap, int hc, int wc, int nh, int nw, const float *kpts,
+                        const unsigned int *count, int n_max, float *out)
+{
+    if (n_max <= 0) return;
+    hipLaunchKernelGGL(sample_desc_kernel, dim3((n_max + 3) / 4), dim3(NT), 0, st, dmap, hc, wc, (float)nw / 2.0f,
+                       (float)nh / 2.0f, kpts, count, n_max, out);
+}
+
+// ---------------------------------------------------------------- dense descriptor normalise + NHWC -> NCHW
+__global__ __launch_bounds__(NT)
+void desc_normalise_nchw_kernel(const float *__restrict__ in, int npix, float *__restrict__ out)
+{
+    __shared__ float tile[64][129];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p0 = blockIdx.x * 64;
+    for (int r = wave; r < 64; r += 4) {
+        const int p = p0 + r;
+        float2 v = make_float2(0.0f, 0.0f);
+        if (p < npix) v = *reinterpret_cast<const float2 *>(in + (size_t)p * 128 + 2 * lane);
+        const float nrm = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y)), 1e-12f);
+        tile[r][2 * lane] = __fdiv_rn(v.x, nrm);
+        tile[r][2 * lane + 1] = __fdiv_rn(v.y, nrm);
+    }
+    __syncthreads();
+    for (int c = wave; c < 128; c += 4) {
+        const int p = p0 + lane;
+        if (p < npix) out[(size_t)c * npix + p] = tile[lane][c];
+    }
+}
+
+void launch_desc_normalise_nchw(hipStream_t st, const float *in, int npix, float *out)
+{
+    hipLaunchKernelGGL(desc_normalise_nchw_kernel, dim3((npix + 63) / 64), dim3(NT), 0, st, in, npix, out);
+}
+
+// ---------------------------------------------------------------- layout helpers (parity / debug paths)
+__global__ void nhwc_h_to_nchw_f_kernel(const half_t *__restrict__ in, int npix, int pitch, int c, float *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)npix * c) return;
+    const int ch = (int)(i / npix), p = (int)(i % npix);
+    out[i] = (float)in[(size_t)p * pitch + ch];
+}
+__global__ void nhwc_f_to_nchw_f_kernel(const float *__restrict__ in, int npix, int pitch, int c, float *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)npix * c) return;
+    const int ch = (int)(i / npix), p = (int)(i % npix);
+    out[i] = in[(size_t)p * pitch + ch];
+}
+__global__ void nchw_f_to_nhwc_f_kernel(const float *__restrict__ in, int npix, int c, float *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)npix * c) return;
+    const int p = (int)(i / c), ch = (int)(i % c);
+    out[i] = in[(size_t)ch * npix + p];
+}
+void launch_nhwc_h_to_nchw_f(hipStream_t st, const half_t *in, int npix, int pitch, int c, float *out)
+{
+    const size_t n = (size_t)npix * c;
+    hipLaunchKernelGGL(nhwc_h_to_nchw_f_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, in, npix, pitch, c, out);
+}
+void launch_nhwc_f_to_nchw_f(hipStream_t st, const float *in, int npix, int pitch, int c, float *out)
+{
+    const size_t n = (size_t)npix * c;
+    hipLaunchKernelGGL(nhwc_f_to_nchw_f_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, in, npix, pitch, c, out);
+}
+void launch_nchw_f_to_nhwc_f(hipStream_t st, const float *in, int npix, int c, float *out)
+{
+    const size_t n = (size_t)npix * c;
+    hipLaunchKernelGGL(nchw_f_to_nhwc_f_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, in, npix, c, out);
+}

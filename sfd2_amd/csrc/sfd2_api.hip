@@ -1,0 +1,813 @@
+// libsfd2hip: context, weight folding/packing, pipeline orchestration and the C-ABI
+// declared in include/sfd2_hip.h.  Host C++ only (no kernels here).
+#include "../../include/sfd2_hip.h"
+#include "sfd2_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(const std::string &m)
+{
+    g_err = m;
+    return -1;
+}
+#define HIPCHECK(expr)                                                                           \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct ConvW {                 // one folded + packed layer
+    int cin = 0, cout = 0, cout_pad = 0, ks = 0, stride = 1;
+    DevBuf w, scale, shift;    // fp16 packed filters, fp32 [cout_pad]
+};
+
+struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; };
+
+struct sfd2_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_jobs = nullptr;      // guards reuse of the pinned job descriptors below
+    void *pin_jobs = nullptr;
+    size_t pin_cap = 0;
+    bool weights_loaded = false;
+    // weights
+    ConvW c1a, c1b, c2a, c2b, c3a, c3b, rb1[3], rb2[3], rb3[3], pa0, pa3, da0, da3, pb, db;
+    DevBuf sta_w, sta_b;
+    // geometry of the current workspace
+    int H = 0, W = 0, H2 = 0, W2 = 0, H4 = 0, W4 = 0, H8 = 0, W8 = 0;
+    // activations (NHWC fp16 unless noted)
+    DevBuf img, a1a, a1b, a2a, a2b, a3a, a3b, rt1[3], rt2[3], ro[3], pa0_o, pa_o, da0_o, da_o;
+    DevBuf logits /*f32 [P8][128]*/, draw /*f32 [P4][128]*/, sta /*f32 [3][P4]*/, score /*f32*/, heat /*f32*/;
+    DevBuf stab /*f32 [H][W]*/, desc_nchw, tmp_f32;
+    // selection
+    DevBuf cand, sel, sorted, counters, kpts, kscores, kdesc;
+    int cand_cap = 0;
+    int last_sel_cap = 0;
+    // matcher
+    DevBuf m_stage, m_hi0, m_lo0, m_hi1, m_lo1, m_part_f, m_part_i, m_red, m_jobs, m_fins, m_out_m, m_out_s;
+    sfd2_timings tim = {};
+    std::map<std::string, ActInfo> acts;
+};
+
+// ------------------------------------------------------------------------------------------ basics
+extern "C" int sfd2_version(void) { return 100; }
+extern "C" const char *sfd2_last_error(void) { return g_err.c_str(); }
+
+extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
+{
+    if (!out) return fail("sfd2_ctx_create: out is null");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail("sfd2_ctx_create: no HIP device available (libsfd2hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail("sfd2_ctx_create: bad device index");
+    HIPCHECK(hipSetDevice(device));
+    sfd2_ctx *c = new sfd2_ctx();
+    c->device = device;
+    HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) HIPCHECK(hipEventCreate(&c->ev[i]));
+    HIPCHECK(hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming));
+    *out = c;
+    return 0;
+}
+
+extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
+                      &c->rt1[0], &c->rt1[1], &c->rt1[2], &c->rt2[0], &c->rt2[1], &c->rt2[2], &c->ro[0], &c->ro[1],
+                      &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
+                      &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->sel, &c->sorted, &c->counters,
+                      &c->kpts, &c->kscores, &c->kdesc, &c->m_stage, &c->m_hi0, &c->m_lo0, &c->m_hi1, &c->m_lo1,
+                      &c->m_part_f, &c->m_part_i, &c->m_red, &c->m_jobs, &c->m_fins, &c->m_out_m, &c->m_out_s};
+    for (DevBuf *b : bufs) b->release();
+    ConvW *ws[] = {&c->c1a, &c->c1b, &c->c2a, &c->c2b, &c->c3a, &c->c3b, &c->rb1[0], &c->rb1[1], &c->rb1[2],
+                   &c->rb2[0], &c->rb2[1], &c->rb2[2], &c->rb3[0], &c->rb3[1], &c->rb3[2], &c->pa0, &c->pa3,
+                   &c->da0, &c->da3, &c->pb, &c->db};
+    for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); }
+    for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
+    if (c->pin_jobs) (void)hipHostFree(c->pin_jobs);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void *sfd2_get_stream(sfd2_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------------ weights
+struct TView { const float *d; std::vector<int64_t> shape; size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; } };
+typedef std::map<std::string, TView> TMap;
+
+static const TView *find_t(const TMap &m, const std::string &k)
+{
+    auto it = m.find(k);
+    return it == m.end() ? nullptr : &it->second;
+}
+
+static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st)
+{
+    HIPCHECK(b.ensure(bytes));
+    HIPCHECK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// y = scale * conv_nobias(x) + shift  with conv bias and BatchNorm(eval, eps 1e-5) folded:
+//   BN(affine=False): (x + b - mean) / sqrt(var + eps)                         nets/sfd2.py:58-65
+//   BN(affine):       gamma * (x + b - mean) / sqrt(var + eps) + beta           nets/sfd2.py:286-296, :25-55
+static int fold_scale_shift(const TMap &m, const std::string &conv, const std::string &bn, int cout, int cout_pad,
+                            std::vector<float> &scale, std::vector<float> &shift)
+{
+    scale.assign(cout_pad, 1.0f);
+    shift.assign(cout_pad, 0.0f);
+    const TView *bias = find_t(m, conv + ".bias");
+    if (bias && (int)bias->numel() != cout) return fail("bad bias shape for " + conv);
+    if (bn.empty()) {
+        for (int c = 0; c < cout; ++c) shift[c] = bias ? bias->d[c] : 0.0f;
+        return 0;
+    }
+    const TView *mean = find_t(m, bn + ".running_mean"), *var = find_t(m, bn + ".running_var");
+    const TView *gamma = find_t(m, bn + ".weight"), *beta = find_t(m, bn + ".bias");
+    if (!mean || !var) return fail("missing BatchNorm statistics: " + bn);
+    if ((int)mean->numel() != cout || (int)var->numel() != cout) return fail("bad BatchNorm shape: " + bn);
+    for (int c = 0; c < cout; ++c) {
+        const float inv = 1.0f / std::sqrt(var->d[c] + 1e-5f);
+        const float a = gamma ? gamma->d[c] * inv : inv;
+        const float b = bias ? bias->d[c] : 0.0f;
+        scale[c] = a;
+        shift[c] = (beta ? beta->d[c] : 0.0f) + (b - mean->d[c]) * a;
+    }
+    return 0;
+}
+
+static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &conv, const std::string &bn, int cin,
+                      int cout, int ks, int stride)
+{
+    const TView *w = find_t(m, conv + ".weight");
+    if (!w) return fail("missing tensor: " + conv + ".weight");
+    if (w->shape.size() != 4 || w->shape[0] != cout || w->shape[1] != cin || w->shape[2] != ks || w->shape[3] != ks)
+        return fail("bad shape for " + conv + ".weight");
+    const int cout_pad = (cout + 63) / 64 * 64;
+    L.cin = cin; L.cout = cout; L.cout_pad = cout_pad; L.ks = ks; L.stride = stride;
+    const int T = ks * ks, nch = cin / 32;
+    std::vector<half_t> pk((size_t)nch * T * cout_pad * 32, (half_t)0.0f);
+    for (int ch = 0; ch < nch; ++ch)
+        for (int t = 0; t < T; ++t)
+            for (int oc = 0; oc < cout; ++oc)
+                for (int k = 0; k < 32; ++k) {
+                    const float v = w->d[(((size_t)oc * cin + ch * 32 + k) * ks + t / ks) * ks + t % ks];
+                    pk[(((size_t)ch * T + t) * cout_pad + oc) * 32 + k] = (half_t)v;
+                }
+    std::vector<float> sc, sh;
+    if (fold_scale_shift(m, conv, bn, cout, cout_pad, sc, sh)) return -1;
+    if (upload(L.w, pk.data(), pk.size() * sizeof(half_t), c->stream)) return -1;
+    if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
+    if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+    return 0;
+}
+
+static int pack_conv1a(sfd2_ctx *c, const TMap &m)
+{
+    const TView *w = find_t(m, "conv1a.0.weight");
+    if (!w) return fail("missing tensor: conv1a.0.weight");
+    if (w->shape.size() != 4 || w->shape[0] != 64 || w->shape[1] != 3 || w->shape[2] != 3 || w->shape[3] != 3)
+        return fail("bad shape for conv1a.0.weight");
+    ConvW &L = c->c1a;
+    L.cin = 3; L.cout = 64; L.cout_pad = 64; L.ks = 3; L.stride = 1;
+    // A fragment of mfma_32x32x16: lane l -> row (l & 31), k = (l >> 5) * 8 + j; k = kx * 4 + c within a filter row
+    std::vector<half_t> pk((size_t)2 * 3 * 64 * 8, (half_t)0.0f);
+    for (int ct = 0; ct < 2; ++ct)
+        for (int ky = 0; ky < 3; ++ky)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int oc = ct * 32 + (lane & 31), g = lane >> 5;
+                    const int kx = 2 * g + (j >> 2), ch = j & 3;
+                    float v = 0.0f;
+                    if (kx < 3 && ch < 3) v = w->d[(((size_t)oc * 3 + ch) * 3 + ky) * 3 + kx];
+                    pk[(((size_t)ct * 3 + ky) * 64 + lane) * 8 + j] = (half_t)v;
+                }
+    std::vector<float> sc, sh;
+    if (fold_scale_shift(m, "conv1a.0", "conv1a.1", 64, 64, sc, sh)) return -1;
+    if (upload(L.w, pk.data(), pk.size() * sizeof(half_t), c->stream)) return -1;
+    if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
+    if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+    return 0;
+}
+
+static int pack_gconv(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &conv, const std::string &bn)
+{
+    const TView *w = find_t(m, conv + ".weight");
+    if (!w) return fail("missing tensor: " + conv + ".weight");
+    if (w->shape.size() != 4 || w->shape[0] != 256 || w->shape[1] != 8 || w->shape[2] != 3 || w->shape[3] != 3)
+        return fail("bad shape for " + conv + ".weight (expected [256,8,3,3], groups=32)");
+    L.cin = 256; L.cout = 256; L.cout_pad = 256; L.ks = 3; L.stride = 1;
+    // A fragment of mfma_16x16x32: lane l -> row i = l & 15 (output channel of the pair), k = (l >> 4) * 8 + j;
+    // k step s covers taps 2s, 2s+1: k = (tap - 2s) * 16 + (input channel of the pair)
+    std::vector<half_t> pk((size_t)16 * 5 * 64 * 8, (half_t)0.0f);
+    for (int pair = 0; pair < 16; ++pair)
+        for (int s = 0; s < 5; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int i = lane & 15, g = lane >> 4;
+                    const int tap = 2 * s + (g >> 1);
+                    const int oc = pair * 16 + i;
+                    float v = 0.0f;
+                    if (tap <= 8 && (i >> 3) == (g & 1)) v = w->d[(((size_t)oc * 8 + j) * 3 + tap / 3) * 3 + tap % 3];
+                    pk[(((size_t)pair * 5 + s) * 64 + lane) * 8 + j] = (half_t)v;
+                }
+    std::vector<float> sc, sh;
+    if (fold_scale_shift(m, conv, bn, 256, 256, sc, sh)) return -1;
+    if (upload(L.w, pk.data(), pk.size() * sizeof(half_t), c->stream)) return -1;
+    if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
+    if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+    return 0;
+}
+
+extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
+{
+    if (!c || !tensors) return fail("sfd2_load_weights: null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    TMap m;
+    for (int i = 0; i < n; ++i) {
+        if (!tensors[i].name || !tensors[i].data) continue;
+        TView v;
+        v.d = tensors[i].data;
+        for (int d = 0; d < tensors[i].ndim && d < 4; ++d) v.shape.push_back(tensors[i].shape[d]);
+        m[tensors[i].name] = v;
+    }
+    if (pack_conv1a(c, m)) return -1;
+    if (pack_igemm(c, m, c->c1b, "conv1b.0", "bn1b.0", 64, 64, 3, 2)) return -1;
+    if (pack_igemm(c, m, c->c2a, "conv2a.0", "conv2a.1", 64, 128, 3, 1)) return -1;
+    if (pack_igemm(c, m, c->c2b, "conv2b.0", "bn2b.0", 128, 128, 3, 2)) return -1;
+    if (pack_igemm(c, m, c->c3a, "conv3a.0", "conv3a.1", 128, 256, 3, 1)) return -1;
+    if (pack_igemm(c, m, c->c3b, "conv3b.0", "bn3b.0", 256, 256, 3, 1)) return -1;
+    for (int b = 0; b < 3; ++b) {
+        const std::string p = "conv4." + std::to_string(b) + ".";
+        if (pack_igemm(c, m, c->rb1[b], p + "conv1", p + "bn1", 256, 256, 1, 1)) return -1;
+        if (pack_gconv(c, m, c->rb2[b], p + "conv2", p + "bn2")) return -1;
+        if (pack_igemm(c, m, c->rb3[b], p + "conv3", p + "bn3", 256, 256, 1, 1)) return -1;
+    }
+    if (pack_igemm(c, m, c->pa0, "convPa.0", "convPa.1", 256, 256, 3, 2)) return -1;
+    if (pack_igemm(c, m, c->pa3, "convPa.3", "", 256, 256, 3, 1)) return -1;
+    if (pack_igemm(c, m, c->da0, "convDa.0", "convDa.1", 256, 256, 3, 1)) return -1;
+    if (pack_igemm(c, m, c->da3, "convDa.3", "", 256, 256, 3, 1)) return -1;
+    if (pack_igemm(c, m, c->pb, "convPb", "", 256, 65, 1, 1)) return -1;
+    if (pack_igemm(c, m, c->db, "convDb", "", 256, 128, 1, 1)) return -1;
+    const TView *sw = find_t(m, "ConvSta.weight"), *sb = find_t(m, "ConvSta.bias");
+    if (!sw || !sb) return fail("missing tensor: ConvSta.{weight,bias}");
+    if (sw->numel() != 3 * 256 || sb->numel() != 3) return fail("bad shape for ConvSta");
+    if (upload(c->sta_w, sw->d, 3 * 256 * sizeof(float), c->stream)) return -1;
+    if (upload(c->sta_b, sb->d, 3 * sizeof(float), c->stream)) return -1;
+    c->weights_loaded = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ workspace
+static int down2(int n) { return (n - 1) / 2 + 1; }  // 3x3 stride 2 pad 1
+
+static int ensure_workspace(sfd2_ctx *c, int H, int W)
+{
+    if (H < 8 || W < 8) return fail("image too small (need H, W >= 8)");
+    if ((long long)H * W > (1ll << 30)) return fail("image too large");
+    c->H = H; c->W = W;
+    c->H2 = down2(H); c->W2 = down2(W);
+    c->H4 = down2(c->H2); c->W4 = down2(c->W2);
+    c->H8 = down2(c->H4); c->W8 = down2(c->W4);
+    const size_t P1 = (size_t)H * W, P2 = (size_t)c->H2 * c->W2, P4 = (size_t)c->H4 * c->W4, P8 = (size_t)c->H8 * c->W8;
+    const size_t hb = sizeof(half_t);
+    HIPCHECK(c->a1a.ensure(P1 * 64 * hb));
+    HIPCHECK(c->a1b.ensure(P2 * 64 * hb));
+    HIPCHECK(c->a2a.ensure(P2 * 128 * hb));
+    HIPCHECK(c->a2b.ensure(P4 * 128 * hb));
+    HIPCHECK(c->a3a.ensure(P4 * 256 * hb));
+    HIPCHECK(c->a3b.ensure(P4 * 256 * hb));
+    for (int b = 0; b < 3; ++b) {
+        HIPCHECK(c->rt1[b].ensure(P4 * 256 * hb));
+        HIPCHECK(c->rt2[b].ensure(P4 * 256 * hb));
+        HIPCHECK(c->ro[b].ensure(P4 * 256 * hb));
+    }
+    HIPCHECK(c->pa0_o.ensure(P8 * 256 * hb));
+    HIPCHECK(c->pa_o.ensure(P8 * 256 * hb));
+    HIPCHECK(c->da0_o.ensure(P4 * 256 * hb));
+    HIPCHECK(c->da_o.ensure(P4 * 256 * hb));
+    HIPCHECK(c->logits.ensure(P8 * 128 * sizeof(float)));
+    HIPCHECK(c->draw.ensure(P4 * 128 * sizeof(float)));
+    HIPCHECK(c->sta.ensure(P4 * 3 * sizeof(float)));
+    HIPCHECK(c->score.ensure(P8 * 64 * sizeof(float)));
+    HIPCHECK(c->heat.ensure(P1 * sizeof(float)));
+    size_t cap = std::max<size_t>(65536, P1 / 8);
+    cap = std::min(cap, P1);
+    c->cand_cap = (int)cap;
+    HIPCHECK(c->cand.ensure(cap * 8));
+    HIPCHECK(c->counters.ensure(64));
+    c->acts.clear();
+    auto reg = [&](const char *nm, const DevBuf &b, int f32, int planar, int ch, int pitch, int h, int w) {
+        c->acts[nm] = ActInfo{b.p, f32, planar, ch, pitch, h, w};
+    };
+    reg("conv1a", c->a1a, 0, 0, 64, 64, H, W);
+    reg("bn1b", c->a1b, 0, 0, 64, 64, c->H2, c->W2);
+    reg("conv2a", c->a2a, 0, 0, 128, 128, c->H2, c->W2);
+    reg("bn2b", c->a2b, 0, 0, 128, 128, c->H4, c->W4);
+    reg("conv3a", c->a3a, 0, 0, 256, 256, c->H4, c->W4);
+    reg("bn3b", c->a3b, 0, 0, 256, 256, c->H4, c->W4);
+    static const char *n1[3] = {"conv4.0.bn1", "conv4.1.bn1", "conv4.2.bn1"};
+    static const char *n2[3] = {"conv4.0.bn2", "conv4.1.bn2", "conv4.2.bn2"};
+    static const char *n3[3] = {"conv4.0", "conv4.1", "conv4.2"};
+    for (int b = 0; b < 3; ++b) {
+        reg(n1[b], c->rt1[b], 0, 0, 256, 256, c->H4, c->W4);
+        reg(n2[b], c->rt2[b], 0, 0, 256, 256, c->H4, c->W4);
+        reg(n3[b], c->ro[b], 0, 0, 256, 256, c->H4, c->W4);
+    }
+    reg("convPa.0", c->pa0_o, 0, 0, 256, 256, c->H8, c->W8);
+    reg("convPa", c->pa_o, 0, 0, 256, 256, c->H8, c->W8);
+    reg("convDa.0", c->da0_o, 0, 0, 256, 256, c->H4, c->W4);
+    reg("convDa", c->da_o, 0, 0, 256, 256, c->H4, c->W4);
+    reg("convPb", c->logits, 1, 0, 65, 128, c->H8, c->W8);
+    reg("convDb", c->draw, 1, 0, 128, 128, c->H4, c->W4);
+    reg("ConvSta", c->sta, 1, 1, 3, 0, c->H4, c->W4);
+    return 0;
+}
+
+static void conv(sfd2_ctx *c, const ConvW &L, const DevBuf &in, int H, int W, const DevBuf &out, int Ho, int Wo,
+                 int relu, const half_t *res = nullptr, int out_f32 = 0)
+{
+    launch_conv_igemm(c->stream, in.as<half_t>(), H, W, L.cin, L.w.as<half_t>(), L.scale.as<float>(),
+                      L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu, res, out.p, out_f32, Ho, Wo);
+}
+
+// ResSegNetV2.det up to the three head outputs (nets/sfd2.py:314-328, :340-345)
+static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
+{
+    hipStream_t st = c->stream;
+    const int H = c->H, W = c->W, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
+    launch_conv1a(st, img_dev, H, W, normalise, c->c1a.w.as<half_t>(), c->c1a.scale.as<float>(),
+                  c->c1a.shift.as<float>(), c->a1a.as<half_t>());
+    conv(c, c->c1b, c->a1a, H, W, c->a1b, H2, W2, 1);
+    conv(c, c->c2a, c->a1b, H2, W2, c->a2a, H2, W2, 1);
+    conv(c, c->c2b, c->a2a, H2, W2, c->a2b, H4, W4, 1);
+    conv(c, c->c3a, c->a2b, H4, W4, c->a3a, H4, W4, 1);
+    conv(c, c->c3b, c->a3a, H4, W4, c->a3b, H4, W4, 1);
+    const DevBuf *x = &c->a3b;
+    for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
+        conv(c, c->rb1[b], *x, H4, W4, c->rt1[b], H4, W4, 1);
+        launch_gconv3x3_g8(st, c->rt1[b].as<half_t>(), H4, W4, c->rb2[b].w.as<half_t>(), c->rb2[b].scale.as<float>(),
+                           c->rb2[b].shift.as<float>(), c->rt2[b].as<half_t>());
+        conv(c, c->rb3[b], c->rt2[b], H4, W4, c->ro[b], H4, W4, 1, x->as<half_t>());
+        x = &c->ro[b];
+    }
+    conv(c, c->pa0, *x, H4, W4, c->pa0_o, H8, W8, 1);
+    conv(c, c->pa3, c->pa0_o, H8, W8, c->pa_o, H8, W8, 0);
+    conv(c, c->pb, c->pa_o, H8, W8, c->logits, H8, W8, 0, nullptr, 1);
+    conv(c, c->da0, *x, H4, W4, c->da0_o, H4, W4, 1);
+    conv(c, c->da3, c->da0_o, H4, W4, c->da_o, H4, W4, 0);
+    conv(c, c->db, c->da_o, H4, W4, c->draw, H4, W4, 0, nullptr, 1);
+    launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
+    launch_detector_head(st, c->logits.as<float>(), 128, H8, W8, c->score.as<float>());
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+static int stage_image(sfd2_ctx *c, const float *x, int on_device, int H, int W, const float **dev)
+{
+    if (on_device) { *dev = x; return 0; }
+    const size_t bytes = (size_t)3 * H * W * sizeof(float);
+    HIPCHECK(c->img.ensure(bytes));
+    HIPCHECK(hipMemcpyAsync(c->img.p, x, bytes, hipMemcpyHostToDevice, c->stream));
+    *dev = c->img.as<float>();
+    return 0;
+}
+
+static int copy_out(sfd2_ctx *c, void *dst, const void *src_dev, size_t bytes, int dst_on_device)
+{
+    if (!dst || bytes == 0) return 0;
+    HIPCHECK(hipMemcpyAsync(dst, src_dev, bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+extern "C" int sfd2_det(sfd2_ctx *c, const float *x, int x_on_device, int H, int W, int flags, float *score,
+                        float *stability, float *desc, int out_on_device, int *hs, int *ws, int *hc, int *wc)
+{
+    if (!c || !x) return fail("sfd2_det: null argument");
+    if (!c->weights_loaded) return fail("sfd2_det: weights not loaded");
+    HIPCHECK(hipSetDevice(c->device));
+    if (ensure_workspace(c, H, W)) return -1;
+    const float *img = nullptr;
+    if (stage_image(c, x, x_on_device, H, W, &img)) return -1;
+    if (run_network(c, img, (flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1)) return -1;
+    const int HS = 8 * c->H8, WS = 8 * c->W8;
+    if (hs) *hs = HS;
+    if (ws) *ws = WS;
+    if (hc) *hc = c->H4;
+    if (wc) *wc = c->W4;
+    if (copy_out(c, score, c->score.p, (size_t)HS * WS * sizeof(float), out_on_device)) return -1;
+    if (stability) {
+        HIPCHECK(c->stab.ensure((size_t)H * W * sizeof(float)));
+        launch_heatmap(c->stream, c->score.as<float>(), HS, WS, c->sta.as<float>(), c->H4, c->W4, H, W, nullptr,
+                       c->stab.as<float>());
+        if (copy_out(c, stability, c->stab.p, (size_t)H * W * sizeof(float), out_on_device)) return -1;
+    }
+    if (desc) {
+        const size_t n = (size_t)c->H4 * c->W4;
+        HIPCHECK(c->desc_nchw.ensure(n * 128 * sizeof(float)));
+        launch_desc_normalise_nchw(c->stream, c->draw.as<float>(), (int)n, c->desc_nchw.as<float>());
+        if (copy_out(c, desc, c->desc_nchw.p, n * 128 * sizeof(float), out_on_device)) return -1;
+    }
+    HIPCHECK(hipGetLastError());
+    if (!(flags & SFD2_FLAG_ASYNC)) HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// NMS + selection on c->heat; results in c->kpts / c->kscores, count in counters[1]
+static int run_selection(sfd2_ctx *c, const float *heat_dev, int H, int W, float conf_th, int radius, int border,
+                         int top_k, float *nms_dense)
+{
+    if (radius < 0 || radius > 4) return fail("nms radius must be in [0,4] (reference uses 4)");
+    const int sel_cap = top_k > 0 ? std::min(top_k, c->cand_cap) : c->cand_cap;
+    c->last_sel_cap = sel_cap;
+    HIPCHECK(c->sel.ensure((size_t)sel_cap * 8));
+    HIPCHECK(c->sorted.ensure((size_t)sel_cap * 8));
+    HIPCHECK(c->kpts.ensure((size_t)sel_cap * 2 * sizeof(float)));
+    HIPCHECK(c->kscores.ensure((size_t)sel_cap * sizeof(float)));
+    HIPCHECK(hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+    launch_nms_select(c->stream, heat_dev, H, W, radius, conf_th, border, nms_dense, c->cand.as<unsigned long long>(),
+                      c->cand_cap, c->counters.as<unsigned int>());
+    launch_topk_sort(c->stream, c->cand.as<unsigned long long>(), c->cand_cap, top_k, c->sel.as<unsigned long long>(),
+                     c->sorted.as<unsigned long long>(), sel_cap, c->counters.as<unsigned int>());
+    launch_keys_to_kpts(c->stream, c->sorted.as<unsigned long long>(), c->counters.as<unsigned int>(), W,
+                        c->kpts.as<float>(), c->kscores.as<float>(), sel_cap);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+static int read_counts(sfd2_ctx *c, int64_t cap_out, int *n_out)
+{
+    unsigned int cnt[4] = {0, 0, 0, 0};
+    HIPCHECK(hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    c->tim.n_candidates = cnt[0];
+    if (cnt[0] > (unsigned int)c->cand_cap)
+        return fail("candidate buffer overflow: " + std::to_string(cnt[0]) + " NMS survivors > capacity " +
+                    std::to_string(c->cand_cap));
+    int64_t n = cnt[1];
+    if (n > c->last_sel_cap) n = c->last_sel_cap;
+    if (cap_out >= 0 && n > cap_out) n = cap_out;
+    if (n_out) *n_out = (int)n;
+    return 0;
+}
+
+extern "C" int sfd2_extract(sfd2_ctx *c, const float *img, int img_on_device, int H, int W, float conf_th, int top_k,
+                            int flags, float *kpts_xy, float *scores, float *desc, int out_on_device, int64_t cap_out,
+                            int *n_out)
+{
+    if (!c || !img) return fail("sfd2_extract: null argument");
+    if (!c->weights_loaded) return fail("sfd2_extract: weights not loaded");
+    HIPCHECK(hipSetDevice(c->device));
+    if (ensure_workspace(c, H, W)) return -1;
+    const float *img_dev = nullptr;
+    if (stage_image(c, img, img_on_device, H, W, &img_dev)) return -1;
+    HIPCHECK(hipEventRecord(c->ev[0], c->stream));
+    if (run_network(c, img_dev, (flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1)) return -1;
+    HIPCHECK(hipEventRecord(c->ev[1], c->stream));
+    const int HS = 8 * c->H8, WS = 8 * c->W8;
+    launch_heatmap(c->stream, c->score.as<float>(), HS, WS, (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(),
+                   c->H4, c->W4, H, W, c->heat.as<float>(), nullptr);
+    if (run_selection(c, c->heat.as<float>(), H, W, conf_th, 4, 4, top_k, nullptr)) return -1;
+    const int sel_cap = c->last_sel_cap;
+    int64_t ncopy = sel_cap;
+    if (cap_out >= 0 && ncopy > cap_out) ncopy = cap_out;
+    float *desc_dst = nullptr;
+    if (desc) {
+        if (out_on_device && cap_out >= sel_cap) {
+            desc_dst = desc;  // sample straight into the caller's buffer
+        } else {
+            HIPCHECK(c->kdesc.ensure((size_t)sel_cap * 128 * sizeof(float)));
+            desc_dst = c->kdesc.as<float>();
+        }
+        launch_sample_desc(c->stream, c->draw.as<float>(), c->H4, c->W4, H, W, c->kpts.as<float>(),
+                           c->counters.as<unsigned int>() + 1, sel_cap, desc_dst);
+    }
+    HIPCHECK(hipEventRecord(c->ev[2], c->stream));
+    HIPCHECK(hipGetLastError());
+    if (flags & SFD2_FLAG_ASYNC) {
+        // device-resident outputs only: copy the fixed-capacity arrays, the count stays on the device
+        if (!out_on_device) return fail("SFD2_FLAG_ASYNC needs device output buffers");
+        if (copy_out(c, kpts_xy, c->kpts.p, (size_t)ncopy * 2 * sizeof(float), 1)) return -1;
+        if (copy_out(c, scores, c->kscores.p, (size_t)ncopy * sizeof(float), 1)) return -1;
+        if (desc && desc_dst != desc && copy_out(c, desc, desc_dst, (size_t)ncopy * 128 * sizeof(float), 1)) return -1;
+        if (n_out) *n_out = -1;
+        return 0;
+    }
+    int n = 0;
+    if (read_counts(c, cap_out, &n)) return -1;
+    if (copy_out(c, kpts_xy, c->kpts.p, (size_t)n * 2 * sizeof(float), out_on_device)) return -1;
+    if (copy_out(c, scores, c->kscores.p, (size_t)n * sizeof(float), out_on_device)) return -1;
+    if (desc && desc_dst != desc && copy_out(c, desc, desc_dst, (size_t)n * 128 * sizeof(float), out_on_device)) return -1;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[2]) == hipSuccess) c->tim.ms_total = ms;
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->tim.ms_backbone = ms;
+    if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->tim.ms_post = ms;
+    if (n_out) *n_out = n;
+    return 0;
+}
+
+extern "C" int sfd2_extract_count(sfd2_ctx *c, int *n_out)
+{
+    if (!c) return fail("sfd2_extract_count: null ctx");
+    HIPCHECK(hipSetDevice(c->device));
+    return read_counts(c, -1, n_out);
+}
+
+// ------------------------------------------------------------------------------------------ stage entry points
+static int heat_to_device(sfd2_ctx *c, const float *heat, int H, int W)
+{
+    const size_t bytes = (size_t)H * W * sizeof(float);
+    HIPCHECK(c->heat.ensure(bytes));
+    HIPCHECK(hipMemcpyAsync(c->heat.p, heat, bytes, hipMemcpyHostToDevice, c->stream));
+    size_t cap = std::max<size_t>(65536, (size_t)H * W / 8);
+    cap = std::min(cap, (size_t)H * W);
+    c->cand_cap = (int)cap;
+    HIPCHECK(c->cand.ensure(cap * 8));
+    HIPCHECK(c->counters.ensure(64));
+    return 0;
+}
+
+extern "C" int sfd2_simple_nms(sfd2_ctx *c, const float *heat, int H, int W, int radius, float *nms_out)
+{
+    if (!c || !heat || !nms_out) return fail("sfd2_simple_nms: null argument");
+    if (radius < 0 || radius > 4) return fail("nms radius must be in [0,4]");
+    HIPCHECK(hipSetDevice(c->device));
+    if (heat_to_device(c, heat, H, W)) return -1;
+    HIPCHECK(c->tmp_f32.ensure((size_t)H * W * sizeof(float)));
+    HIPCHECK(hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+    launch_nms_select(c->stream, c->heat.as<float>(), H, W, radius, 0.0f, 0, c->tmp_f32.as<float>(), nullptr, 0,
+                      c->counters.as<unsigned int>());
+    HIPCHECK(hipGetLastError());
+    if (copy_out(c, nms_out, c->tmp_f32.p, (size_t)H * W * sizeof(float), 0)) return -1;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int sfd2_select_keypoints(sfd2_ctx *c, const float *heat, int H, int W, float conf_th, int radius, int border,
+                                     int top_k, float *kpts_xy, float *scores, int64_t cap_out, int *n_out)
+{
+    if (!c || !heat) return fail("sfd2_select_keypoints: null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    if (heat_to_device(c, heat, H, W)) return -1;
+    if (run_selection(c, c->heat.as<float>(), H, W, conf_th, radius, border, top_k, nullptr)) return -1;
+    int n = 0;
+    if (read_counts(c, cap_out, &n)) return -1;
+    if (copy_out(c, kpts_xy, c->kpts.p, (size_t)n * 2 * sizeof(float), 0)) return -1;
+    if (copy_out(c, scores, c->kscores.p, (size_t)n * sizeof(float), 0)) return -1;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (n_out) *n_out = n;
+    return 0;
+}
+
+extern "C" int sfd2_sample_descriptors(sfd2_ctx *c, const float *desc_map, int hc, int wc, int nh, int nw,
+                                       const float *kpts_xy, int n, float *desc_out)
+{
+    if (!c || !desc_map || !kpts_xy || !desc_out) return fail("sfd2_sample_descriptors: null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    const size_t np = (size_t)hc * wc;
+    HIPCHECK(c->tmp_f32.ensure(np * 128 * sizeof(float)));
+    HIPCHECK(c->draw.ensure(np * 128 * sizeof(float)));
+    HIPCHECK(c->kpts.ensure((size_t)std::max(n, 1) * 2 * sizeof(float)));
+    HIPCHECK(c->kdesc.ensure((size_t)std::max(n, 1) * 128 * sizeof(float)));
+    HIPCHECK(hipMemcpyAsync(c->tmp_f32.p, desc_map, np * 128 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->kpts.p, kpts_xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    launch_nchw_f_to_nhwc_f(c->stream, c->tmp_f32.as<float>(), (int)np, 128, c->draw.as<float>());
+    launch_sample_desc(c->stream, c->draw.as<float>(), hc, wc, nh, nw, c->kpts.as<float>(), nullptr, n, c->kdesc.as<float>());
+    HIPCHECK(hipGetLastError());
+    if (copy_out(c, desc_out, c->kdesc.p, (size_t)n * 128 * sizeof(float), 0)) return -1;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int sfd2_heatmap(sfd2_ctx *c, const float *score, int hs, int ws, const float *sta, int hc, int wc, int H,
+                            int W, float *heat_out)
+{
+    if (!c || !score || !heat_out) return fail("sfd2_heatmap: null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(c->score.ensure((size_t)hs * ws * sizeof(float)));
+    HIPCHECK(c->heat.ensure((size_t)H * W * sizeof(float)));
+    HIPCHECK(hipMemcpyAsync(c->score.p, score, (size_t)hs * ws * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (sta) {
+        HIPCHECK(c->sta.ensure((size_t)3 * hc * wc * sizeof(float)));
+        HIPCHECK(hipMemcpyAsync(c->sta.p, sta, (size_t)3 * hc * wc * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    launch_heatmap(c->stream, c->score.as<float>(), hs, ws, sta ? c->sta.as<float>() : nullptr, hc, wc, H, W,
+                   c->heat.as<float>(), nullptr);
+    HIPCHECK(hipGetLastError());
+    if (copy_out(c, heat_out, c->heat.p, (size_t)H * W * sizeof(float), 0)) return -1;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int sfd2_debug_activation(sfd2_ctx *c, const char *name, float *out, int64_t cap, int *ch, int *h, int *w)
+{
+    if (!c || !name) return fail("sfd2_debug_activation: null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    auto it = c->acts.find(name);
+    if (it == c->acts.end()) return fail(std::string("unknown activation: ") + name);
+    const ActInfo &a = it->second;
+    if (ch) *ch = a.c;
+    if (h) *h = a.h;
+    if (w) *w = a.w;
+    if (!out) return 0;
+    const size_t n = (size_t)a.c * a.h * a.w;
+    if ((int64_t)n > cap) return fail("sfd2_debug_activation: output buffer too small");
+    const int np = a.h * a.w;
+    if (a.planar) {
+        if (copy_out(c, out, a.p, n * sizeof(float), 0)) return -1;
+    } else {
+        HIPCHECK(c->tmp_f32.ensure(n * sizeof(float)));
+        if (a.f32) launch_nhwc_f_to_nchw_f(c->stream, reinterpret_cast<const float *>(a.p), np, a.pitch, a.c, c->tmp_f32.as<float>());
+        else launch_nhwc_h_to_nchw_f(c->stream, reinterpret_cast<const half_t *>(a.p), np, a.pitch, a.c, c->tmp_f32.as<float>());
+        if (copy_out(c, out, c->tmp_f32.p, n * sizeof(float), 0)) return -1;
+    }
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ matcher
+static size_t elt_size(int dtype) { return dtype == SFD2_DT_F64 ? 8 : (dtype == SFD2_DT_F16 ? 2 : 4); }
+
+// Makes a device fp16 [n][128] view (hi, optional lo) of one descriptor set.
+static int prep_set(sfd2_ctx *c, const void *src, int n, int dim, int dtype, int layout, int on_device, int need_lo,
+                    DevBuf &stage, size_t &stage_off, half_t *hi_dst, half_t *lo_dst, const half_t **hi, const half_t **lo)
+{
+    if (dtype == SFD2_DT_F16 && layout == SFD2_LAYOUT_ND && on_device && dim == 128 && !need_lo) {
+        *hi = reinterpret_cast<const half_t *>(src);
+        *lo = nullptr;
+        return 0;
+    }
+    const void *dev_src = src;
+    if (!on_device) {
+        const size_t bytes = (size_t)n * dim * elt_size(dtype);
+        void *dst = reinterpret_cast<char *>(stage.p) + stage_off;
+        HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        dev_src = dst;
+        stage_off += (bytes + 255) & ~(size_t)255;
+    }
+    launch_match_prep(c->stream, dev_src, n, dim, dtype, layout, hi_dst, need_lo ? lo_dst : nullptr);
+    *hi = hi_dst;
+    *lo = need_lo ? lo_dst : nullptr;
+    return 0;
+}
+
+extern "C" int sfd2_match_batch(sfd2_ctx *c, const void *d0, int n0, const void *const *d1s, const int *n1s, int k,
+                                int dim, int dtype, int layout, int on_device, const sfd2_match_conf *conf,
+                                int64_t *matches0, float *scores0, int out_on_device, int flags)
+{
+    if (!c || !conf || (k > 0 && (!d1s || !n1s))) return fail("sfd2_match_batch: null argument");
+    if (dim <= 0 || dim > 128) return fail("descriptor dimension must be in [1,128]");
+    if (n0 < 0 || k < 0) return fail("negative size");
+    if (k == 0 || n0 == 0) return 0;
+    HIPCHECK(hipSetDevice(c->device));
+    const int need_lo = conf->sim_mode == SFD2_SIM_F16X2;
+    int max_n1 = 0;
+    size_t tot_n1 = 0, stage_bytes = 0;
+    for (int i = 0; i < k; ++i) {
+        if (n1s[i] < 0) return fail("negative n1");
+        max_n1 = std::max(max_n1, n1s[i]);
+        tot_n1 += (size_t)n1s[i];
+        if (!on_device) stage_bytes += (((size_t)n1s[i] * dim * elt_size(dtype)) + 255) & ~(size_t)255;
+    }
+    if (!on_device) stage_bytes += (((size_t)n0 * dim * elt_size(dtype)) + 255) & ~(size_t)255;
+    const int max_n = std::max(n0, max_n1);
+    // splits: enough blocks to fill 256 CUs twice, never finer than 32 candidates
+    const int blocks_per_job = (max_n + 127) / 128;
+    int splits = (512 + 2 * k * blocks_per_job - 1) / (2 * k * blocks_per_job);
+    splits = std::max(1, std::min(splits, 16));
+    const int min_n = std::max(1, std::min(n0, max_n1 > 0 ? max_n1 : 1));
+    splits = std::min(splits, std::max(1, (min_n + 31) / 32));
+
+    HIPCHECK(c->m_stage.ensure(std::max<size_t>(stage_bytes, 256)));
+    HIPCHECK(c->m_hi0.ensure((size_t)n0 * 128 * 2));
+    if (need_lo) HIPCHECK(c->m_lo0.ensure((size_t)n0 * 128 * 2));
+    HIPCHECK(c->m_hi1.ensure(std::max<size_t>(tot_n1, 1) * 128 * 2));
+    if (need_lo) HIPCHECK(c->m_lo1.ensure(std::max<size_t>(tot_n1, 1) * 128 * 2));
+    // partials: per pair forward [splits][n0] and reverse [splits][n1], 2 float arrays + 1 int array
+    const size_t per_pair_f = (size_t)splits * n0, tot_part = (size_t)k * per_pair_f + (size_t)splits * tot_n1;
+    HIPCHECK(c->m_part_f.ensure(std::max<size_t>(tot_part, 1) * 2 * sizeof(float)));
+    HIPCHECK(c->m_part_i.ensure(std::max<size_t>(tot_part, 1) * sizeof(int)));
+    HIPCHECK(c->m_red.ensure(((size_t)k * n0 + tot_n1 + 1) * 3 * sizeof(float)));
+    HIPCHECK(c->m_jobs.ensure((size_t)2 * k * sizeof(MatchJob)));
+    HIPCHECK(c->m_fins.ensure((size_t)k * sizeof(MatchFinal)));
+    HIPCHECK(c->m_out_m.ensure((size_t)k * n0 * sizeof(long long)));
+    HIPCHECK(c->m_out_s.ensure((size_t)k * n0 * sizeof(float)));
+
+    HIPCHECK(hipEventRecord(c->ev[0], c->stream));
+    size_t stage_off = 0;
+    const half_t *q_hi = nullptr, *q_lo = nullptr;
+    if (prep_set(c, d0, n0, dim, dtype, layout, on_device, need_lo, c->m_stage, stage_off, c->m_hi0.as<half_t>(),
+                 c->m_lo0.as<half_t>(), &q_hi, &q_lo)) return -1;
+    // job descriptors live in pinned host memory owned by the context; the event makes sure the
+    // previous call's async copies have consumed them before they are rewritten
+    const size_t jobs_bytes = 2 * (size_t)k * sizeof(MatchJob), fins_bytes = (size_t)k * sizeof(MatchFinal);
+    HIPCHECK(hipEventSynchronize(c->ev_jobs));
+    if (jobs_bytes + fins_bytes > c->pin_cap) {
+        if (c->pin_jobs) (void)hipHostFree(c->pin_jobs);
+        c->pin_jobs = nullptr;
+        c->pin_cap = 0;
+        HIPCHECK(hipHostMalloc(&c->pin_jobs, jobs_bytes + fins_bytes, hipHostMallocDefault));
+        c->pin_cap = jobs_bytes + fins_bytes;
+    }
+    MatchJob *jobs = reinterpret_cast<MatchJob *>(c->pin_jobs);
+    MatchFinal *fins = reinterpret_cast<MatchFinal *>(reinterpret_cast<char *>(c->pin_jobs) + jobs_bytes);
+    float *pf = c->m_part_f.as<float>();
+    int *pi = c->m_part_i.as<int>();
+    float *red = c->m_red.as<float>();
+    size_t off1 = 0, poff = 0, roff = 0;
+    for (int i = 0; i < k; ++i) {
+        const int n1 = n1s[i];
+        const half_t *h = nullptr, *l = nullptr;
+        if (n1 > 0) {
+            if (prep_set(c, d1s[i], n1, dim, dtype, layout, on_device, need_lo, c->m_stage, stage_off,
+                         c->m_hi1.as<half_t>() + off1 * 128, need_lo ? c->m_lo1.as<half_t>() + off1 * 128 : nullptr, &h, &l))
+                return -1;
+        }
+        off1 += (size_t)n1;
+        MatchJob &f = jobs[2 * i], &r = jobs[2 * i + 1];
+        // forward: keep queries (d0), reduce over d1
+        f.a_hi = h; f.a_lo = l; f.b_hi = q_hi; f.b_lo = q_lo; f.na = n1; f.nb = n0;
+        f.part_v1 = pf + 2 * poff; f.part_v2 = pf + 2 * poff + (size_t)splits * n0; f.part_i1 = pi + poff;
+        poff += (size_t)splits * n0;
+        // reverse: keep d1 rows, reduce over queries
+        r.a_hi = q_hi; r.a_lo = q_lo; r.b_hi = h; r.b_lo = l; r.na = n0; r.nb = n1;
+        r.part_v1 = pf + 2 * poff; r.part_v2 = pf + 2 * poff + (size_t)splits * n1; r.part_i1 = pi + poff;
+        poff += (size_t)splits * n1;
+        MatchFinal &fn = fins[i];
+        fn.f_v1 = f.part_v1; fn.f_v2 = f.part_v2; fn.f_i1 = f.part_i1;
+        fn.r_v1 = r.part_v1; fn.r_v2 = r.part_v2; fn.r_i1 = r.part_i1;
+        fn.n0 = n0; fn.n1 = n1;
+        fn.matches0 = c->m_out_m.as<long long>() + (size_t)i * n0;
+        fn.scores0 = c->m_out_s.as<float>() + (size_t)i * n0;
+        fn.red_f = red + 3 * roff; roff += (size_t)n0;
+        fn.red_r = red + 3 * roff; roff += (size_t)n1;
+    }
+    HIPCHECK(hipMemcpyAsync(c->m_jobs.p, jobs, jobs_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->m_fins.p, fins, fins_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipEventRecord(c->ev_jobs, c->stream));
+    launch_match_top2(c->stream, c->m_jobs.as<MatchJob>(), 2 * k, max_n, splits, need_lo);
+    launch_match_finalize(c->stream, c->m_fins.as<MatchFinal>(), k, max_n, splits, conf->flavour, conf->do_mutual_check,
+                          conf->ratio_threshold, conf->distance_threshold);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipEventRecord(c->ev[3], c->stream));
+    if (copy_out(c, matches0, c->m_out_m.p, (size_t)k * n0 * sizeof(long long), out_on_device)) return -1;
+    if (copy_out(c, scores0, c->m_out_s.p, (size_t)k * n0 * sizeof(float), out_on_device)) return -1;
+    if (!(flags & SFD2_FLAG_ASYNC)) {
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) c->tim.ms_match = ms;
+    }
+    return 0;
+}
+
+extern "C" int sfd2_match(sfd2_ctx *c, const void *d0, int n0, const void *d1, int n1, int dim, int dtype, int layout,
+                          int on_device, const sfd2_match_conf *conf, int64_t *matches0, float *scores0, int out_on_device)
+{
+    const void *d1s[1] = {d1};
+    const int n1s[1] = {n1};
+    return sfd2_match_batch(c, d0, n0, d1s, n1s, 1, dim, dtype, layout, on_device, conf, matches0, scores0, out_on_device, 0);
+}
+
+extern "C" int sfd2_get_timings(sfd2_ctx *c, sfd2_timings *out)
+{
+    if (!c || !out) return fail("sfd2_get_timings: null argument");
+    *out = c->tim;
+    return 0;
+}

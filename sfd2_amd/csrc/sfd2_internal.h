@@ -1,0 +1,90 @@
+// Internal declarations shared by the HIP translation units of libsfd2hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ conv stack
+// Activations live in HBM as NHWC fp16 (channel pitch = padded Cout of the producer).
+
+// conv1a: fp32 CHW image (+ optional norm_RGB) -> 3x3 conv 3->64 + folded BN + ReLU -> NHWC fp16
+void launch_conv1a(hipStream_t st, const float *img_chw, int H, int W, int normalise,
+                   const half_t *wpk /*[2][3][64][8]*/, const float *scale, const float *shift,
+                   half_t *out /*[H][W][64]*/);
+
+// Implicit-GEMM conv on MFMA (3x3 or 1x1, stride 1 or 2, Cin % 32 == 0, Cout_pad % 64 == 0).
+//   in  [H][W][Cin] fp16,  wpk [Cin/32][ks*ks][Cout_pad][32] fp16,  scale/shift [Cout_pad]
+//   out [Ho][Wo][Cout_pad] fp16 (relu / residual optional) or fp32 (out_f32)
+void launch_conv_igemm(hipStream_t st, const half_t *in, int H, int W, int Cin,
+                       const half_t *wpk, const float *scale, const float *shift, int Cout_pad,
+                       int ks, int stride, int relu, const half_t *residual,
+                       void *out, int out_f32, int Ho, int Wo);
+
+// Grouped 3x3 conv, 256 channels, 32 groups of 8 (ResBlock.conv2) + folded BN + ReLU.
+//   wpk [16 pairs][5 steps][64 lanes][8] fp16 (block-diagonal 16x16 MFMA A fragments)
+void launch_gconv3x3_g8(hipStream_t st, const half_t *in, int H, int W, const half_t *wpk,
+                        const float *scale, const float *shift, half_t *out);
+
+// 1x1 conv 256 -> 3 (ConvSta), fp32 planar output [3][H][W]
+void launch_convsta(hipStream_t st, const half_t *in, int npix, const float *w /*[3][256]*/, const float *b,
+                    float *out /*[3][npix]*/);
+
+// ------------------------------------------------------------------ heads / post
+// logits [P][pitch] fp32 (65 used) -> score [8*hc][8*wc]
+void launch_detector_head(hipStream_t st, const float *logits, int pitch, int hc, int wc, float *score);
+// heat[H][W] = resize(score[hs][ws]) * stability(sta[3][hc][wc])   (sta may be null)
+void launch_heatmap(hipStream_t st, const float *score, int hs, int ws, const float *sta, int hc, int wc,
+                    int H, int W, float *heat, float *stab_out /*may be null*/);
+// simple_nms + threshold + border; appends (score,idx) keys; optional dense output
+void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radius, float conf_th, int border,
+                       float *nms_dense /*may be null*/, unsigned long long *cand_keys, int cand_cap,
+                       unsigned int *counters /*[0]=n_cand*/);
+// top-K of the candidate keys, sorted descending -> sorted_keys[0..n_sel), counters[1]=n_sel
+void launch_topk_sort(hipStream_t st, const unsigned long long *cand_keys, int cand_cap, int top_k,
+                      unsigned long long *sel_keys, unsigned long long *sorted_keys, int sel_cap,
+                      unsigned int *counters);
+// keys -> kpts (x,y), scores
+void launch_keys_to_kpts(hipStream_t st, const unsigned long long *sorted_keys, const unsigned int *counters,
+                         int W, float *kpts_xy, float *scores, int cap);
+// bilinear sampling of desc_raw [hc][wc][128] fp32 NHWC at kpts + per-tap and final L2 normalisation
+void launch_sample_desc(hipStream_t st, const float *desc_nhwc, int hc, int wc, int nh, int nw,
+                        const float *kpts_xy, const unsigned int *count /*device, may be null*/, int n_max,
+                        float *out);
+// desc_raw NHWC [P][128] -> normalised NCHW [128][P]
+void launch_desc_normalise_nchw(hipStream_t st, const float *desc_nhwc, int npix, float *out_nchw);
+// layout helpers
+void launch_nhwc_h_to_nchw_f(hipStream_t st, const half_t *in, int npix, int c_pitch, int c, float *out);
+void launch_nhwc_f_to_nchw_f(hipStream_t st, const float *in, int npix, int c_pitch, int c, float *out);
+void launch_nchw_f_to_nhwc_f(hipStream_t st, const float *in, int npix, int c, float *out);
+
+// ------------------------------------------------------------------ matcher
+// convert descriptors to fp16 [n][128] (hi) and optional scaled residual (lo)
+void launch_match_prep(hipStream_t st, const void *src, int n, int dim, int dtype, int layout,
+                       half_t *hi, half_t *lo /*may be null*/);
+struct MatchJob {          // one direction of one pair
+    const half_t *a_hi;    // reduced side ("columns" j), [na][128]
+    const half_t *a_lo;
+    const half_t *b_hi;    // kept side ("rows" i), [nb][128]
+    const half_t *b_lo;
+    int na, nb;
+    float *part_v1;        // [splits][nb]
+    float *part_v2;
+    int *part_i1;
+};
+void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int max_nb, int splits, int use_lo);
+struct MatchFinal {
+    const float *f_v1, *f_v2; const int *f_i1;   // forward partials [splits][n0]
+    const float *r_v1, *r_v2; const int *r_i1;   // reverse partials [splits][n1]
+    int n0, n1;
+    long long *matches0; float *scores0;
+    float *red_f;  // scratch [3*n0]
+    float *red_r;  // scratch [3*n1]
+};
+void launch_match_finalize(hipStream_t st, const MatchFinal *fin_dev, int npairs, int max_n, int splits,
+                           int flavour, int mutual, float ratio, float dist);

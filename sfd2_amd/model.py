@@ -1,0 +1,126 @@
+"""Host-side mirror of the reference model object (nets/sfd2.py:259-425 ResSegNetV2).
+
+Same constructor arguments, same .eval()/.cuda()/.to()/.load_state_dict()/.det()
+surface as the reference nn.Module, but there is no torch graph behind it: the
+forward pass is the hand-written HIP conv stack in libsfd2hip (sfd2_det/sfd2_extract).
+torch is used only to hold device memory for inputs/outputs.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+try:  # torch is plumbing (tensor holder); numpy-only use works without it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_torch(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+class ResSegNetV2:
+    """Drop-in for nets.sfd2.ResSegNetV2 on the inference path (det)."""
+
+    def __init__(self, outdim=128, require_feature=False, require_stability=False, ms_detector=True):
+        if outdim != 128:
+            raise ValueError("the HIP path implements outdim=128 (extract_localization.py:213)")
+        self.outdim = outdim
+        self.require_feature = require_feature
+        self.require_stability = require_stability
+        self.ms_detector = ms_detector
+        self.training = False
+        self._sd = None
+        self._ctx = None
+        self._device = 0
+
+    # -- nn.Module-like plumbing the reference drivers call (extract_localization.py:208-226)
+    def eval(self):
+        self.training = False
+        return self
+
+    def cuda(self, device=None):
+        if device is not None:
+            self._device = int(device.index if hasattr(device, "index") and device.index is not None else device) \
+                if not isinstance(device, int) else device
+        self._ensure_ctx()
+        return self
+
+    def to(self, device):
+        if isinstance(device, str):
+            if not device.startswith("cuda"):
+                raise RuntimeError("sfd2_amd runs on the MI355X only; there is no CPU path")
+            self._device = int(device.split(":")[1]) if ":" in device else 0
+            return self.cuda()
+        return self.cuda(device)
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts the reference checkpoint's ['model'] dict (torch tensors or numpy).
+        extract_localization.py:213-215 passes strict=False for V2."""
+        sd = state_dict
+        if isinstance(sd, dict) and isinstance(sd.get("model"), dict):  # whole checkpoint {'model': sd, 'epoch': ..}
+            sd = sd["model"]
+        self._sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
+        if self._ctx is not None:
+            self._ctx.load_weights(self._sd)
+        return self
+
+    def state_dict(self):
+        return dict(self._sd or {})
+
+    def _ensure_ctx(self):
+        if self._ctx is None:
+            self._ctx = _lib.Context(self._device)
+            if self._sd is not None:
+                self._ctx.load_weights(self._sd)
+        return self._ctx
+
+    @property
+    def context(self):
+        return self._ensure_ctx()
+
+    # -- the operator (nets/sfd2.py:313-354)
+    def det(self, x):
+        """x: [1,3,H,W] normalised image (torch tensor, cpu or cuda, or numpy).
+        Returns (score [1,1,8*H8,8*W8], stability [1,1,H,W] or None, desc [1,128,H4,W4])
+        as float32 tensors on the device x lives on (numpy in -> numpy out)."""
+        ctx = self._ensure_ctx()
+        if self._sd is None:
+            raise RuntimeError("load_state_dict() first")
+        lib = ctx.lib
+        as_torch = _is_torch(x)
+        on_dev = bool(as_torch and x.is_cuda)
+        if as_torch:
+            xin = x.detach().to(torch.float32).contiguous()
+            if on_dev:
+                torch.cuda.current_stream(xin.device).synchronize()
+        else:
+            xin = np.ascontiguousarray(x, dtype=np.float32)
+        if xin.ndim != 4 or xin.shape[0] != 1 or xin.shape[1] != 3:
+            raise ValueError("det expects [1,3,H,W]")
+        H, W = int(xin.shape[2]), int(xin.shape[3])
+        h2, w2 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        h4, w4 = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+        h8, w8 = (h4 - 1) // 2 + 1, (w4 - 1) // 2 + 1
+
+        def alloc(shape):
+            if on_dev:
+                return torch.empty(shape, dtype=torch.float32, device=xin.device)
+            return np.empty(shape, dtype=np.float32)
+
+        score = alloc((1, 1, 8 * h8, 8 * w8))
+        stab = alloc((1, 1, H, W)) if self.require_stability else None
+        desc = alloc((1, 128, h4, w4))
+        hs, ws, hc, wc = (ctypes.c_int() for _ in range(4))
+        _lib.check(lib.sfd2_det(ctx.h, _lib.ptr(xin), int(on_dev), H, W, _lib.FLAG_IMG_NORMALISED,
+                                _lib.ptr(score), _lib.ptr(stab), _lib.ptr(desc), int(on_dev),
+                                ctypes.byref(hs), ctypes.byref(ws), ctypes.byref(hc), ctypes.byref(wc)))
+        if as_torch and not on_dev:
+            score, desc = torch.from_numpy(score), torch.from_numpy(desc)
+            stab = torch.from_numpy(stab) if stab is not None else None
+        return score, stab, desc
+
+    def __call__(self, *a, **k):
+        raise NotImplementedError("training forward (nets/sfd2.py:397-425) is out of scope; use det()")
