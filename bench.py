@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec extract+match (1600x1200, n4096) on MI355X.
+
+One "step" = one pass of the hot path over one synthetic query image:
+  sfd2_extract (ResSegNetV2 conv stack -> heat map -> NMS -> top-4096 -> descriptors)
+  + sfd2_match_batch of its 4096 descriptors against K=50 resident database sets
+    (the Aachen netvlad-50 unit of BASELINE.json configs[2]).
+Inputs (images, database descriptors) are resident in HBM before the timed region.
+Multi-GPU: one process per GPU, images sharded, no collective on the data path
+("scaling": "weak"); torch.distributed is used for the barrier and the max-over-ranks time only.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, TOPK, K_DB, N_DB = 1200, 1600, 4096, 50, 4096
+PEAK_TFLOPS_F16 = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(sd, n_match_sample=10):
+    """The oracle (a CPU port of the reference algorithm, oracle/) timed on the host cores:
+    one full-size extract + n_match_sample of the 50 matches, scaled to the full unit."""
+    from oracle import oracle as orc
+    from sfd2_amd import synth
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    img = synth.make_image(H, W, 5)
+    t0 = time.time()
+    pred = orc.extract_resnet_return(sd, img, conf_th=0.001, topK=TOPK)
+    t_ext = time.time() - t0
+    d0 = pred["descriptors"].astype(np.float32)
+    t0 = time.time()
+    for i in range(n_match_sample):
+        orc.hloc_nearest_neighbor(d0, synth.make_descriptors(N_DB, seed=100 + i), do_mutual_check=True)
+    t_match = (time.time() - t0) * (K_DB / n_match_sample)
+    return {"value": round(1.0 / (t_ext + t_match), 5), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle (C, OpenMP, fp32): 1 image {W}x{H} top-{TOPK} extract ({t_ext:.1f}s) + "
+                      f"{n_match_sample} of {K_DB} NNM matches 4096x4096x128 scaled x{K_DB // n_match_sample} ({t_match:.1f}s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extract-only", action="store_true", help="configs[1]: extract without matching")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from sfd2_amd import _lib, synth
+    from sfd2_amd.model import ResSegNetV2
+
+    sd = synth.make_state_dict(0)
+    model = ResSegNetV2(outdim=128, require_stability=True).eval()
+    model.load_state_dict(sd)
+    model.cuda(local_rank)
+    ctx = model.context
+    lib = ctx.lib
+
+    # ---- resident inputs: a few distinct query images per rank + K database descriptor sets (fp16)
+    n_img = 4
+    imgs = [torch.from_numpy(synth.make_image(H, W, 100 + rank * n_img + i)).to(dev) for i in range(n_img)]
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    db = []
+    for _ in range(K_DB):
+        d = torch.randn(N_DB, 128, generator=g)
+        db.append((d / d.norm(dim=1, keepdim=True)).to(torch.float16).to(dev).contiguous())
+    kpts = torch.empty((TOPK, 2), dtype=torch.float32, device=dev)
+    scores = torch.empty((TOPK,), dtype=torch.float32, device=dev)
+    desc = torch.empty((TOPK, 128), dtype=torch.float32, device=dev)
+    matches = torch.empty((K_DB, TOPK), dtype=torch.int64, device=dev)
+    mscores = torch.empty((K_DB, TOPK), dtype=torch.float32, device=dev)
+    q = _lib.DescSet(desc.data_ptr(), TOPK, _lib.DT_F32, _lib.LAYOUT_ND, 1)
+    dbs = (_lib.DescSet * K_DB)(*[_lib.DescSet(d.data_ptr(), N_DB, _lib.DT_F16, _lib.LAYOUT_ND, 1) for d in db])
+    mconf = _lib.MatchConf(_lib.MATCH_HLOC, 1, 0.0, 0.0, _lib.SIM_F16)   # NNM (hloc/match_features.py:21-28)
+    n_out = ctypes.c_int(0)
+    torch.cuda.synchronize()
+
+    def step(i):
+        _lib.check(lib.sfd2_extract(ctx.h, imgs[i % n_img].data_ptr(), 1, H, W, 0.001, TOPK, _lib.FLAG_ASYNC,
+                                    kpts.data_ptr(), scores.data_ptr(), desc.data_ptr(), 1, TOPK, ctypes.byref(n_out)))
+        if not args.extract_only:
+            _lib.check(lib.sfd2_match_batch(ctx.h, ctypes.byref(q), dbs, K_DB, 128, ctypes.byref(mconf),
+                                            matches.data_ptr(), mscores.data_ptr(), 1, _lib.FLAG_ASYNC))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.sync()
+    n_kp = ctypes.c_int(0)
+    _lib.check(lib.sfd2_extract_count(ctx.h, ctypes.byref(n_kp)))
+    if n_kp.value != TOPK:
+        raise SystemExit(f"synthetic image yielded {n_kp.value} < {TOPK} key points; the match leg assumes {TOPK}")
+
+    ctx.set_profiling(2 * args.steps + 2)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    layers = ctx.layer_timings()
+    ctx.set_profiling(0)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    n_matched = int((matches >= 0).sum().item()) if not args.extract_only else 0
+
+    if rank == 0:
+        # dominant kernel family = largest summed device time
+        fam = {}
+        for r in layers:
+            f = fam.setdefault(r["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "layers": []})
+            f["ms"] += r["ms_total"]
+            f["flops"] += r["flops"] * r["launches"]
+            f["bytes"] += r["bytes"] * r["launches"]
+            f["launches"] += r["launches"]
+            f["layers"].append(r["name"])
+        dom_name, dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+        is_gemm = dom["flops"] > 0
+        if is_gemm:
+            achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom_name, "layers": dom["layers"], "achieved": round(achieved, 2),
+                    "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS_F16, 4),
+                    "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 5), "launches": dom["launches"],
+                    "traffic": None}
+        else:
+            achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom_name, "layers": dom["layers"], "achieved": round(achieved, 2),
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4),
+                    "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 5), "launches": dom["launches"],
+                    "traffic": None}
+        total_ms = sum(r["ms_total"] for r in layers)
+        breakdown = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+        out = {
+            "metric": "images/sec extract" + ("" if args.extract_only else "+match") + " (1600x1200, n4096)",
+            "value": round(args.steps * world / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": ("aachen_v1.1 day query, extract-only (BASELINE configs[1])" if args.extract_only else
+                                    "aachen_v1.1 query extract + NNM match vs netvlad-50 resident db sets (BASELINE configs[2])"),
+                       "image": f"{W}x{H}", "max_keypoints": TOPK, "db_sets_per_query": 0 if args.extract_only else K_DB,
+                       "db_keypoints": N_DB, "weights": "synthetic seeded ResSegNetV2 (checkpoint not shipped)",
+                       "parallelism": f"images sharded over {world} GPU(s), no collective"},
+            "roofline": roof, "kernel_ms_per_step": breakdown, "device_ms_per_step": round(total_ms / args.steps, 4),
+            "mutual_matches_last_step": n_matched,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

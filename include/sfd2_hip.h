@@ -134,15 +134,42 @@ int sfd2_match(sfd2_ctx *ctx, const void *d0, int n0, const void *d1, int n1, in
                int dtype, int layout, int on_device, const sfd2_match_conf *conf,
                int64_t *matches0, float *scores0, int out_on_device);
 
-/* One query against k database images (the localiser's inner loop,
- * it_loc/localize_cv2.py:705-715 -> feature_matching :511-560).  d1s[k], n1s[k];
- * matches0 [k][n0], scores0 [k][n0].  Device-resident descriptor sets in fp16
- * ([n][128]) avoid any per-call conversion. */
-int sfd2_match_batch(sfd2_ctx *ctx, const void *d0, int n0, const void *const *d1s, const int *n1s, int k,
-                     int dim, int dtype, int layout, int on_device, const sfd2_match_conf *conf,
-                     int64_t *matches0, float *scores0, int out_on_device, int flags);
+/* One descriptor set handed to the batched matcher. */
+typedef struct {
+    const void *data;   /* [n][dim] or [dim][n], see layout                          */
+    int32_t n;
+    int32_t dtype;      /* SFD2_DT_*                                                  */
+    int32_t layout;     /* SFD2_LAYOUT_*                                              */
+    int32_t on_device;  /* 0 host, 1 device                                           */
+} sfd2_desc_set;
+
+/* One query against k database images in one launch (the localiser's inner loop,
+ * it_loc/localize_cv2.py:705-715 -> feature_matching :511-560 -> Matcher.forward).
+ * matches0 [k][q->n] int64, scores0 [k][q->n] fp32.  Device-resident fp16 [n][128] database
+ * sets (SFD2_DT_F16, SFD2_LAYOUT_ND, sim_mode SFD2_SIM_F16) are used in place, no conversion. */
+int sfd2_match_batch(sfd2_ctx *ctx, const sfd2_desc_set *q, const sfd2_desc_set *db, int k, int dim,
+                     const sfd2_match_conf *conf, int64_t *matches0, float *scores0, int out_on_device,
+                     int flags);
 
 int sfd2_get_timings(sfd2_ctx *ctx, sfd2_timings *out);
+
+/* Blocks until every kernel queued on the context's stream has finished. */
+int sfd2_sync(sfd2_ctx *ctx);
+
+/* Per-launch device timing (HIP events recorded on the context's stream around every kernel
+ * launch of sfd2_det / sfd2_extract / sfd2_match*).  The reference only has wall-clock prints
+ * (it_loc/localizer.py:151-156); this is what bench.py's roofline block is computed from.
+ * max_steps = number of extract/match calls that may be in flight before the table is read. */
+typedef struct {
+    char name[32];      /* layer / stage, e.g. "conv3b", "nms_select"                       */
+    char kernel[48];    /* kernel family, e.g. "conv_igemm<3,1,256>"                        */
+    double flops;       /* algorithmic FLOPs of ONE launch (2*MAC; 0 for non-GEMM stages)    */
+    double bytes;       /* algorithmic HBM bytes of ONE launch (each tensor once)            */
+    double ms_total;    /* summed device time of all recorded launches                       */
+    int32_t launches;
+} sfd2_layer_timing;
+int sfd2_set_profiling(sfd2_ctx *ctx, int max_steps /* 0 = off */);
+int sfd2_get_layer_timings(sfd2_ctx *ctx, sfd2_layer_timing *out, int cap, int *n);
 
 #ifdef __cplusplus
 }

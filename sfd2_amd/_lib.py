@@ -36,12 +36,23 @@ class Timings(ctypes.Structure):
                 ("ms_match", ctypes.c_float), ("n_candidates", ctypes.c_int64)]
 
 
+class DescSet(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("n", ctypes.c_int32), ("dtype", ctypes.c_int32),
+                ("layout", ctypes.c_int32), ("on_device", ctypes.c_int32)]
+
+
+class LayerTiming(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 32), ("kernel", ctypes.c_char * 48), ("flops", ctypes.c_double),
+                ("bytes", ctypes.c_double), ("ms_total", ctypes.c_double), ("launches", ctypes.c_int32)]
+
+
 # every symbol include/sfd2_hip.h declares (tests/test_abi.py checks the two lists agree)
 EXPORTS = [
     "sfd2_version", "sfd2_last_error", "sfd2_ctx_create", "sfd2_ctx_destroy", "sfd2_get_stream",
     "sfd2_load_weights", "sfd2_det", "sfd2_extract", "sfd2_extract_count", "sfd2_simple_nms",
     "sfd2_select_keypoints", "sfd2_sample_descriptors", "sfd2_heatmap", "sfd2_debug_activation",
-    "sfd2_match", "sfd2_match_batch", "sfd2_get_timings",
+    "sfd2_match", "sfd2_match_batch", "sfd2_get_timings", "sfd2_sync", "sfd2_set_profiling",
+    "sfd2_get_layer_timings",
 ]
 
 _lib = None
@@ -75,9 +86,12 @@ def load():
     lib.sfd2_heatmap.argtypes = [vp, vp, ci, ci, vp, ci, ci, ci, ci, vp]
     lib.sfd2_debug_activation.argtypes = [vp, ctypes.c_char_p, vp, i64, pi, pi, pi]
     lib.sfd2_match.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, ctypes.POINTER(MatchConf), vp, vp, ci]
-    lib.sfd2_match_batch.argtypes = [vp, vp, ci, ctypes.POINTER(vp), pi, ci, ci, ci, ci, ci,
+    lib.sfd2_match_batch.argtypes = [vp, ctypes.POINTER(DescSet), ctypes.POINTER(DescSet), ci, ci,
                                      ctypes.POINTER(MatchConf), vp, vp, ci, ci]
     lib.sfd2_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
+    lib.sfd2_sync.argtypes = [vp]
+    lib.sfd2_set_profiling.argtypes = [vp, ci]
+    lib.sfd2_get_layer_timings.argtypes = [vp, ctypes.POINTER(LayerTiming), ci, pi]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the .so lacks a declared symbol
     _lib = lib
@@ -150,6 +164,21 @@ class Context:
         check(self.lib.sfd2_get_timings(self.h, ctypes.byref(t)))
         return {"ms_total": t.ms_total, "ms_backbone": t.ms_backbone, "ms_post": t.ms_post,
                 "ms_match": t.ms_match, "n_candidates": t.n_candidates}
+
+    def sync(self):
+        check(self.lib.sfd2_sync(self.h))
+
+    def set_profiling(self, max_steps):
+        check(self.lib.sfd2_set_profiling(self.h, int(max_steps)))
+
+    def layer_timings(self):
+        """[{name, kernel, flops, bytes, ms_total, launches}] accumulated since set_profiling()."""
+        n = ctypes.c_int(0)
+        arr = (LayerTiming * 64)()
+        check(self.lib.sfd2_get_layer_timings(self.h, arr, 64, ctypes.byref(n)))
+        return [{"name": arr[i].name.decode(), "kernel": arr[i].kernel.decode(), "flops": arr[i].flops,
+                 "bytes": arr[i].bytes, "ms_total": arr[i].ms_total, "launches": arr[i].launches}
+                for i in range(min(n.value, 64))]
 
     def debug_activation(self, name):
         c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

@@ -78,7 +78,48 @@ struct sfd2_ctx {
     DevBuf m_stage, m_hi0, m_lo0, m_hi1, m_lo1, m_part_f, m_part_i, m_red, m_jobs, m_fins, m_out_m, m_out_s;
     sfd2_timings tim = {};
     std::map<std::string, ActInfo> acts;
+    // per-launch profiling (sfd2_set_profiling)
+    int prof_max_steps = 0, prof_step = 0, prof_slot = 0;
+    std::vector<hipEvent_t> prof_ev;          // [max_steps][PROF_SLOTS][2]
+    std::vector<sfd2_layer_timing> prof_tab;  // slot -> descriptor + accumulators
+    std::vector<int> prof_used;               // [max_steps] slots recorded in that step
+    std::vector<int> prof_row;                // [max_steps][PROF_SLOTS] -> row of prof_tab
 };
+
+#define PROF_SLOTS 48
+struct ProfScope {   // records an event pair around one launch when profiling is on
+    sfd2_ctx *c; int slot;
+    ProfScope(sfd2_ctx *c_, const char *name, const char *kernel, double flops, double bytes) : c(c_), slot(-1)
+    {
+        if (c->prof_max_steps <= 0 || c->prof_step >= c->prof_max_steps || c->prof_slot >= PROF_SLOTS) return;
+        slot = c->prof_slot++;
+        int row = -1;  // table rows are keyed by stage name (extract and match steps interleave)
+        for (size_t i = 0; i < c->prof_tab.size(); ++i)
+            if (strncmp(c->prof_tab[i].name, name, sizeof(c->prof_tab[i].name) - 1) == 0) { row = (int)i; break; }
+        if (row < 0) {
+            c->prof_tab.push_back(sfd2_layer_timing{});
+            row = (int)c->prof_tab.size() - 1;
+            snprintf(c->prof_tab[row].name, sizeof(c->prof_tab[row].name), "%s", name);
+            snprintf(c->prof_tab[row].kernel, sizeof(c->prof_tab[row].kernel), "%s", kernel);
+        }
+        c->prof_tab[row].flops = flops;
+        c->prof_tab[row].bytes = bytes;
+        c->prof_row[(size_t)c->prof_step * PROF_SLOTS + slot] = row;
+        (void)hipEventRecord(c->prof_ev[((size_t)c->prof_step * PROF_SLOTS + slot) * 2], c->stream);
+    }
+    ~ProfScope()
+    {
+        if (slot >= 0) (void)hipEventRecord(c->prof_ev[((size_t)c->prof_step * PROF_SLOTS + slot) * 2 + 1], c->stream);
+    }
+};
+static void prof_step_begin(sfd2_ctx *c) { c->prof_slot = 0; }
+static void prof_step_end(sfd2_ctx *c)
+{
+    if (c->prof_max_steps > 0 && c->prof_step < c->prof_max_steps) {
+        c->prof_used[c->prof_step] = c->prof_slot;
+        c->prof_step++;
+    }
+}
 
 // ------------------------------------------------------------------------------------------ basics
 extern "C" int sfd2_version(void) { return 100; }
@@ -119,6 +160,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); }
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->pin_jobs) (void)hipHostFree(c->pin_jobs);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -360,9 +402,17 @@ static int ensure_workspace(sfd2_ctx *c, int H, int W)
     return 0;
 }
 
-static void conv(sfd2_ctx *c, const ConvW &L, const DevBuf &in, int H, int W, const DevBuf &out, int Ho, int Wo,
-                 int relu, const half_t *res = nullptr, int out_f32 = 0)
+static void conv(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &in, int H, int W, const DevBuf &out,
+                 int Ho, int Wo, int relu, const half_t *res = nullptr, int out_f32 = 0)
 {
+    char kn[48];
+    const int bn = (L.cout_pad % 256 == 0) ? 256 : (L.cout_pad % 128 == 0 ? 128 : 64);
+    snprintf(kn, sizeof(kn), "conv_igemm<%d,%d,%d%s>", L.ks, L.stride, bn, out_f32 ? ",f32" : "");
+    const double px = (double)Ho * Wo;
+    const double flops = 2.0 * px * L.cout * L.cin * L.ks * L.ks;
+    const double bytes = 2.0 * ((double)H * W * L.cin + (double)L.cout * L.cin * L.ks * L.ks) +
+                         px * L.cout_pad * (out_f32 ? 4.0 : 2.0) + (res ? px * L.cout_pad * 2.0 : 0.0);
+    ProfScope ps(c, name, kn, flops, bytes);
     launch_conv_igemm(c->stream, in.as<half_t>(), H, W, L.cin, L.w.as<half_t>(), L.scale.as<float>(),
                       L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu, res, out.p, out_f32, Ho, Wo);
 }
@@ -372,29 +422,45 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
 {
     hipStream_t st = c->stream;
     const int H = c->H, W = c->W, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
-    launch_conv1a(st, img_dev, H, W, normalise, c->c1a.w.as<half_t>(), c->c1a.scale.as<float>(),
-                  c->c1a.shift.as<float>(), c->a1a.as<half_t>());
-    conv(c, c->c1b, c->a1a, H, W, c->a1b, H2, W2, 1);
-    conv(c, c->c2a, c->a1b, H2, W2, c->a2a, H2, W2, 1);
-    conv(c, c->c2b, c->a2a, H2, W2, c->a2b, H4, W4, 1);
-    conv(c, c->c3a, c->a2b, H4, W4, c->a3a, H4, W4, 1);
-    conv(c, c->c3b, c->a3a, H4, W4, c->a3b, H4, W4, 1);
+    const double P1 = (double)H * W, P4 = (double)H4 * W4, P8 = (double)H8 * W8;
+    {
+        ProfScope ps(c, "conv1a", "conv1a_kernel", 2.0 * P1 * 64 * 27, P1 * (12 + 128));
+        launch_conv1a(st, img_dev, H, W, normalise, c->c1a.w.as<half_t>(), c->c1a.scale.as<float>(),
+                      c->c1a.shift.as<float>(), c->a1a.as<half_t>());
+    }
+    conv(c, "conv1b", c->c1b, c->a1a, H, W, c->a1b, H2, W2, 1);
+    conv(c, "conv2a", c->c2a, c->a1b, H2, W2, c->a2a, H2, W2, 1);
+    conv(c, "conv2b", c->c2b, c->a2a, H2, W2, c->a2b, H4, W4, 1);
+    conv(c, "conv3a", c->c3a, c->a2b, H4, W4, c->a3a, H4, W4, 1);
+    conv(c, "conv3b", c->c3b, c->a3a, H4, W4, c->a3b, H4, W4, 1);
     const DevBuf *x = &c->a3b;
+    static const char *nm1[3] = {"conv4.0.conv1", "conv4.1.conv1", "conv4.2.conv1"};
+    static const char *nm2[3] = {"conv4.0.conv2", "conv4.1.conv2", "conv4.2.conv2"};
+    static const char *nm3[3] = {"conv4.0.conv3", "conv4.1.conv3", "conv4.2.conv3"};
     for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
-        conv(c, c->rb1[b], *x, H4, W4, c->rt1[b], H4, W4, 1);
-        launch_gconv3x3_g8(st, c->rt1[b].as<half_t>(), H4, W4, c->rb2[b].w.as<half_t>(), c->rb2[b].scale.as<float>(),
-                           c->rb2[b].shift.as<float>(), c->rt2[b].as<half_t>());
-        conv(c, c->rb3[b], c->rt2[b], H4, W4, c->ro[b], H4, W4, 1, x->as<half_t>());
+        conv(c, nm1[b], c->rb1[b], *x, H4, W4, c->rt1[b], H4, W4, 1);
+        {
+            ProfScope ps(c, nm2[b], "gconv3x3_g8_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 4);
+            launch_gconv3x3_g8(st, c->rt1[b].as<half_t>(), H4, W4, c->rb2[b].w.as<half_t>(),
+                               c->rb2[b].scale.as<float>(), c->rb2[b].shift.as<float>(), c->rt2[b].as<half_t>());
+        }
+        conv(c, nm3[b], c->rb3[b], c->rt2[b], H4, W4, c->ro[b], H4, W4, 1, x->as<half_t>());
         x = &c->ro[b];
     }
-    conv(c, c->pa0, *x, H4, W4, c->pa0_o, H8, W8, 1);
-    conv(c, c->pa3, c->pa0_o, H8, W8, c->pa_o, H8, W8, 0);
-    conv(c, c->pb, c->pa_o, H8, W8, c->logits, H8, W8, 0, nullptr, 1);
-    conv(c, c->da0, *x, H4, W4, c->da0_o, H4, W4, 1);
-    conv(c, c->da3, c->da0_o, H4, W4, c->da_o, H4, W4, 0);
-    conv(c, c->db, c->da_o, H4, W4, c->draw, H4, W4, 0, nullptr, 1);
-    launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
-    launch_detector_head(st, c->logits.as<float>(), 128, H8, W8, c->score.as<float>());
+    conv(c, "convPa.0", c->pa0, *x, H4, W4, c->pa0_o, H8, W8, 1);
+    conv(c, "convPa.3", c->pa3, c->pa0_o, H8, W8, c->pa_o, H8, W8, 0);
+    conv(c, "convPb", c->pb, c->pa_o, H8, W8, c->logits, H8, W8, 0, nullptr, 1);
+    conv(c, "convDa.0", c->da0, *x, H4, W4, c->da0_o, H4, W4, 1);
+    conv(c, "convDa.3", c->da3, c->da0_o, H4, W4, c->da_o, H4, W4, 0);
+    conv(c, "convDb", c->db, c->da_o, H4, W4, c->draw, H4, W4, 0, nullptr, 1);
+    {
+        ProfScope ps(c, "ConvSta", "convsta_kernel", 2.0 * P4 * 3 * 256, P4 * (512 + 12));
+        launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
+    }
+    {
+        ProfScope ps(c, "detector_head", "detector_head_kernel", 0.0, P8 * (65 * 4 + 256));
+        launch_detector_head(st, c->logits.as<float>(), 128, H8, W8, c->score.as<float>());
+    }
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -425,7 +491,9 @@ extern "C" int sfd2_det(sfd2_ctx *c, const float *x, int x_on_device, int H, int
     if (ensure_workspace(c, H, W)) return -1;
     const float *img = nullptr;
     if (stage_image(c, x, x_on_device, H, W, &img)) return -1;
+    prof_step_begin(c);
     if (run_network(c, img, (flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1)) return -1;
+    prof_step_end(c);
     const int HS = 8 * c->H8, WS = 8 * c->W8;
     if (hs) *hs = HS;
     if (ws) *ws = WS;
@@ -461,12 +529,19 @@ static int run_selection(sfd2_ctx *c, const float *heat_dev, int H, int W, float
     HIPCHECK(c->kpts.ensure((size_t)sel_cap * 2 * sizeof(float)));
     HIPCHECK(c->kscores.ensure((size_t)sel_cap * sizeof(float)));
     HIPCHECK(hipMemsetAsync(c->counters.p, 0, 64, c->stream));
-    launch_nms_select(c->stream, heat_dev, H, W, radius, conf_th, border, nms_dense, c->cand.as<unsigned long long>(),
-                      c->cand_cap, c->counters.as<unsigned int>());
-    launch_topk_sort(c->stream, c->cand.as<unsigned long long>(), c->cand_cap, top_k, c->sel.as<unsigned long long>(),
-                     c->sorted.as<unsigned long long>(), sel_cap, c->counters.as<unsigned int>());
-    launch_keys_to_kpts(c->stream, c->sorted.as<unsigned long long>(), c->counters.as<unsigned int>(), W,
-                        c->kpts.as<float>(), c->kscores.as<float>(), sel_cap);
+    {
+        ProfScope ps(c, "nms_select", "nms_select_kernel", 0.0, (double)H * W * 4);
+        launch_nms_select(c->stream, heat_dev, H, W, radius, conf_th, border, nms_dense,
+                          c->cand.as<unsigned long long>(), c->cand_cap, c->counters.as<unsigned int>());
+    }
+    {
+        ProfScope ps(c, "topk_sort", "radix_select+compact+rank_sort", 0.0, (double)sel_cap * 24);
+        launch_topk_sort(c->stream, c->cand.as<unsigned long long>(), c->cand_cap, top_k,
+                         c->sel.as<unsigned long long>(), c->sorted.as<unsigned long long>(), sel_cap,
+                         c->counters.as<unsigned int>());
+        launch_keys_to_kpts(c->stream, c->sorted.as<unsigned long long>(), c->counters.as<unsigned int>(), W,
+                            c->kpts.as<float>(), c->kscores.as<float>(), sel_cap);
+    }
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -498,11 +573,16 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const float *img, int img_on_device, in
     const float *img_dev = nullptr;
     if (stage_image(c, img, img_on_device, H, W, &img_dev)) return -1;
     HIPCHECK(hipEventRecord(c->ev[0], c->stream));
+    prof_step_begin(c);
     if (run_network(c, img_dev, (flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1)) return -1;
     HIPCHECK(hipEventRecord(c->ev[1], c->stream));
     const int HS = 8 * c->H8, WS = 8 * c->W8;
-    launch_heatmap(c->stream, c->score.as<float>(), HS, WS, (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(),
-                   c->H4, c->W4, H, W, c->heat.as<float>(), nullptr);
+    {
+        ProfScope ps(c, "heatmap", "heatmap_kernel", 0.0, (double)H * W * 8);
+        launch_heatmap(c->stream, c->score.as<float>(), HS, WS,
+                       (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(), c->H4, c->W4, H, W,
+                       c->heat.as<float>(), nullptr);
+    }
     if (run_selection(c, c->heat.as<float>(), H, W, conf_th, 4, 4, top_k, nullptr)) return -1;
     const int sel_cap = c->last_sel_cap;
     int64_t ncopy = sel_cap;
@@ -515,9 +595,11 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const float *img, int img_on_device, in
             HIPCHECK(c->kdesc.ensure((size_t)sel_cap * 128 * sizeof(float)));
             desc_dst = c->kdesc.as<float>();
         }
+        ProfScope ps(c, "sample_desc", "sample_desc_kernel", 0.0, (double)sel_cap * 128 * 4 * 5);
         launch_sample_desc(c->stream, c->draw.as<float>(), c->H4, c->W4, H, W, c->kpts.as<float>(),
                            c->counters.as<unsigned int>() + 1, sel_cap, desc_dst);
     }
+    prof_step_end(c);
     HIPCHECK(hipEventRecord(c->ev[2], c->stream));
     HIPCHECK(hipGetLastError());
     if (flags & SFD2_FLAG_ASYNC) {
@@ -688,25 +770,28 @@ static int prep_set(sfd2_ctx *c, const void *src, int n, int dim, int dtype, int
     return 0;
 }
 
-extern "C" int sfd2_match_batch(sfd2_ctx *c, const void *d0, int n0, const void *const *d1s, const int *n1s, int k,
-                                int dim, int dtype, int layout, int on_device, const sfd2_match_conf *conf,
-                                int64_t *matches0, float *scores0, int out_on_device, int flags)
+extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_desc_set *db, int k, int dim,
+                                const sfd2_match_conf *conf, int64_t *matches0, float *scores0, int out_on_device,
+                                int flags)
 {
-    if (!c || !conf || (k > 0 && (!d1s || !n1s))) return fail("sfd2_match_batch: null argument");
+    if (!c || !conf || !q || (k > 0 && !db)) return fail("sfd2_match_batch: null argument");
     if (dim <= 0 || dim > 128) return fail("descriptor dimension must be in [1,128]");
+    const int n0 = q->n;
     if (n0 < 0 || k < 0) return fail("negative size");
     if (k == 0 || n0 == 0) return 0;
+    if (!q->data) return fail("sfd2_match_batch: null query descriptors");
     HIPCHECK(hipSetDevice(c->device));
     const int need_lo = conf->sim_mode == SFD2_SIM_F16X2;
     int max_n1 = 0;
     size_t tot_n1 = 0, stage_bytes = 0;
     for (int i = 0; i < k; ++i) {
-        if (n1s[i] < 0) return fail("negative n1");
-        max_n1 = std::max(max_n1, n1s[i]);
-        tot_n1 += (size_t)n1s[i];
-        if (!on_device) stage_bytes += (((size_t)n1s[i] * dim * elt_size(dtype)) + 255) & ~(size_t)255;
+        if (db[i].n < 0) return fail("negative n1");
+        if (db[i].n > 0 && !db[i].data) return fail("sfd2_match_batch: null database descriptors");
+        max_n1 = std::max(max_n1, db[i].n);
+        tot_n1 += (size_t)db[i].n;
+        if (!db[i].on_device) stage_bytes += (((size_t)db[i].n * dim * elt_size(db[i].dtype)) + 255) & ~(size_t)255;
     }
-    if (!on_device) stage_bytes += (((size_t)n0 * dim * elt_size(dtype)) + 255) & ~(size_t)255;
+    if (!q->on_device) stage_bytes += (((size_t)n0 * dim * elt_size(q->dtype)) + 255) & ~(size_t)255;
     const int max_n = std::max(n0, max_n1);
     // splits: enough blocks to fill 256 CUs twice, never finer than 32 candidates
     const int blocks_per_job = (max_n + 127) / 128;
@@ -731,10 +816,11 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const void *d0, int n0, const void 
     HIPCHECK(c->m_out_s.ensure((size_t)k * n0 * sizeof(float)));
 
     HIPCHECK(hipEventRecord(c->ev[0], c->stream));
+    prof_step_begin(c);
     size_t stage_off = 0;
     const half_t *q_hi = nullptr, *q_lo = nullptr;
-    if (prep_set(c, d0, n0, dim, dtype, layout, on_device, need_lo, c->m_stage, stage_off, c->m_hi0.as<half_t>(),
-                 c->m_lo0.as<half_t>(), &q_hi, &q_lo)) return -1;
+    if (prep_set(c, q->data, n0, dim, q->dtype, q->layout, q->on_device, need_lo, c->m_stage, stage_off,
+                 c->m_hi0.as<half_t>(), c->m_lo0.as<half_t>(), &q_hi, &q_lo)) return -1;
     // job descriptors live in pinned host memory owned by the context; the event makes sure the
     // previous call's async copies have consumed them before they are rewritten
     const size_t jobs_bytes = 2 * (size_t)k * sizeof(MatchJob), fins_bytes = (size_t)k * sizeof(MatchFinal);
@@ -753,10 +839,10 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const void *d0, int n0, const void 
     float *red = c->m_red.as<float>();
     size_t off1 = 0, poff = 0, roff = 0;
     for (int i = 0; i < k; ++i) {
-        const int n1 = n1s[i];
+        const int n1 = db[i].n;
         const half_t *h = nullptr, *l = nullptr;
         if (n1 > 0) {
-            if (prep_set(c, d1s[i], n1, dim, dtype, layout, on_device, need_lo, c->m_stage, stage_off,
+            if (prep_set(c, db[i].data, n1, dim, db[i].dtype, db[i].layout, db[i].on_device, need_lo, c->m_stage, stage_off,
                          c->m_hi1.as<half_t>() + off1 * 128, need_lo ? c->m_lo1.as<half_t>() + off1 * 128 : nullptr, &h, &l))
                 return -1;
         }
@@ -782,9 +868,19 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const void *d0, int n0, const void 
     HIPCHECK(hipMemcpyAsync(c->m_jobs.p, jobs, jobs_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(c->m_fins.p, fins, fins_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipEventRecord(c->ev_jobs, c->stream));
-    launch_match_top2(c->stream, c->m_jobs.as<MatchJob>(), 2 * k, max_n, splits, need_lo);
-    launch_match_finalize(c->stream, c->m_fins.as<MatchFinal>(), k, max_n, splits, conf->flavour, conf->do_mutual_check,
-                          conf->ratio_threshold, conf->distance_threshold);
+    {
+        // both directions: 2 GEMMs of n0 x n1 x 128 per pair (x3 products in the hi+lo mode)
+        ProfScope ps(c, "match_top2", need_lo ? "match_top2_kernel<x2>" : "match_top2_kernel",
+                     2.0 * 2.0 * (double)n0 * (double)tot_n1 * 128.0 * (need_lo ? 3.0 : 1.0),
+                     2.0 * 2.0 * ((double)k * n0 + (double)tot_n1) * 128.0);
+        launch_match_top2(c->stream, c->m_jobs.as<MatchJob>(), 2 * k, max_n, splits, need_lo);
+    }
+    {
+        ProfScope ps(c, "match_finalize", "match_reduce+decide", 0.0, (double)tot_part * 12);
+        launch_match_finalize(c->stream, c->m_fins.as<MatchFinal>(), k, max_n, splits, conf->flavour,
+                              conf->do_mutual_check, conf->ratio_threshold, conf->distance_threshold);
+    }
+    prof_step_end(c);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventRecord(c->ev[3], c->stream));
     if (copy_out(c, matches0, c->m_out_m.p, (size_t)k * n0 * sizeof(long long), out_on_device)) return -1;
@@ -800,9 +896,60 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const void *d0, int n0, const void 
 extern "C" int sfd2_match(sfd2_ctx *c, const void *d0, int n0, const void *d1, int n1, int dim, int dtype, int layout,
                           int on_device, const sfd2_match_conf *conf, int64_t *matches0, float *scores0, int out_on_device)
 {
-    const void *d1s[1] = {d1};
-    const int n1s[1] = {n1};
-    return sfd2_match_batch(c, d0, n0, d1s, n1s, 1, dim, dtype, layout, on_device, conf, matches0, scores0, out_on_device, 0);
+    const sfd2_desc_set q = {d0, n0, dtype, layout, on_device};
+    const sfd2_desc_set db = {d1, n1, dtype, layout, on_device};
+    return sfd2_match_batch(c, &q, &db, 1, dim, conf, matches0, scores0, out_on_device, 0);
+}
+
+extern "C" int sfd2_sync(sfd2_ctx *c)
+{
+    if (!c) return fail("sfd2_sync: null ctx");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int sfd2_set_profiling(sfd2_ctx *c, int max_steps)
+{
+    if (!c) return fail("sfd2_set_profiling: null ctx");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (max_steps < 0 || max_steps > 4096) return fail("sfd2_set_profiling: max_steps out of range");
+    const size_t need = (size_t)max_steps * PROF_SLOTS * 2;
+    while (c->prof_ev.size() < need) {
+        hipEvent_t e;
+        HIPCHECK(hipEventCreate(&e));
+        c->prof_ev.push_back(e);
+    }
+    c->prof_max_steps = max_steps;
+    c->prof_step = 0;
+    c->prof_slot = 0;
+    c->prof_used.assign(max_steps, 0);
+    c->prof_row.assign((size_t)max_steps * PROF_SLOTS, 0);
+    c->prof_tab.clear();
+    return 0;
+}
+
+extern "C" int sfd2_get_layer_timings(sfd2_ctx *c, sfd2_layer_timing *out, int cap, int *n)
+{
+    if (!c || !n) return fail("sfd2_get_layer_timings: null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    for (int st = 0; st < c->prof_step; ++st)
+        for (int sl = 0; sl < c->prof_used[st]; ++sl) {
+            float ms = 0.0f;
+            const size_t e = ((size_t)st * PROF_SLOTS + sl) * 2;
+            const int row = c->prof_row[(size_t)st * PROF_SLOTS + sl];
+            if (hipEventElapsedTime(&ms, c->prof_ev[e], c->prof_ev[e + 1]) == hipSuccess) {
+                c->prof_tab[row].ms_total += ms;
+                c->prof_tab[row].launches += 1;
+            }
+        }
+    c->prof_step = 0;  // events consumed; the table keeps accumulating until sfd2_set_profiling resets it
+    *n = (int)c->prof_tab.size();
+    if (out)
+        for (int i = 0; i < *n && i < cap; ++i) out[i] = c->prof_tab[i];
+    return 0;
 }
 
 extern "C" int sfd2_get_timings(sfd2_ctx *c, sfd2_timings *out)

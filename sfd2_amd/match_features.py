@@ -1,0 +1,50 @@
+"""Host driver pieces mirroring hloc/match_features.py (reference): confs (:20-45), pair
+naming and de-duplication (:87-97), the per-pair call (:99-119) with the int16 / fp16 casts
+of the stored results.  HDF5 I/O (h5py) is outside the hot path."""
+import numpy as np
+
+from . import matchers
+from .base_model import dynamic_load
+
+confs = {
+    'NNM': {'output': 'NNM', 'model': {'name': 'nearest_neighbor', 'do_mutual_check': True, 'distance_threshold': None}},
+    'ONN': {'output': 'ONN', 'model': {'name': 'nearest_neighbor', 'do_mutual_check': False, 'distance_threshold': None}},
+    'NNR': {'output': 'NNR', 'model': {'name': 'nearest_neighbor', 'do_mutual_check': True, 'distance_threshold': 0.9}},
+}
+
+
+def names_to_pair(name0, name1):  # hloc/utils/parsers.py:66-67
+    return '_'.join((name0.replace('/', '-'), name1.replace('/', '-')))
+
+
+def unique_pairs(pair_list):
+    """hloc/match_features.py:87-97: skip (a,b) when (a,b) or (b,a) was already matched."""
+    matched, out = set(), []
+    for pair in pair_list:
+        name0, name1 = pair.split(' ')
+        if len({(name0, name1), (name1, name0)} & matched):
+            continue
+        out.append((name0, name1))
+        matched |= {(name0, name1), (name1, name0)}
+    return out
+
+
+def cast_for_storage(matches0, scores0):
+    """hloc/match_features.py:114,118: matches0 -> int16 (torch .short(): wraps), scores -> fp16."""
+    m = np.asarray(matches0).astype(np.int64).astype(np.int16)
+    s = np.asarray(scores0).astype(np.float32).astype(np.float16)
+    return m, s
+
+
+def match_pair(model, feats0, feats1):
+    """feats*: the per-image groups of the feature file ('descriptors' [128,N], ...).
+    Returns (matches0 int16 [N], matching_scores0 fp16 [N]) as the reference stores them."""
+    data = {'descriptors0': np.asarray(feats0['descriptors'], dtype=np.float32)[None],
+            'descriptors1': np.asarray(feats1['descriptors'], dtype=np.float32)[None]}
+    pred = model(data)
+    return cast_for_storage(pred['matches0'][0], pred['matching_scores0'][0])
+
+
+def load_matcher(conf):
+    Model = dynamic_load(matchers, conf['model']['name'])   # hloc/match_features.py:77-79
+    return Model(conf['model']).eval().to('cuda')

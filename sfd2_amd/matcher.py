@@ -67,11 +67,11 @@ class Matcher:
         ds = [np.ascontiguousarray(d, dtype=np.float32) for d in d1_list]
         k, n0 = len(ds), d0.shape[0]
         ctx = _lib.default_context(self._device)
-        ptrs = (ctypes.c_void_p * k)(*[d.ctypes.data for d in ds])
-        n1s = (ctypes.c_int * k)(*[d.shape[0] for d in ds])
+        q = _lib.DescSet(d0.ctypes.data, n0, _lib.DT_F32, _lib.LAYOUT_ND, 0)
+        db = (_lib.DescSet * k)(*[_lib.DescSet(d.ctypes.data, d.shape[0], _lib.DT_F32, _lib.LAYOUT_ND, 0) for d in ds])
         m = np.empty((k, n0), dtype=np.int64)
         s = np.empty((k, n0), dtype=np.float32)
         conf = self._conf()
-        _lib.check(ctx.lib.sfd2_match_batch(ctx.h, d0.ctypes.data, n0, ptrs, n1s, k, d0.shape[1], _lib.DT_F32,
-                                            _lib.LAYOUT_ND, 0, ctypes.byref(conf), m.ctypes.data, s.ctypes.data, 0, 0))
+        _lib.check(ctx.lib.sfd2_match_batch(ctx.h, ctypes.byref(q), db, k, d0.shape[1], ctypes.byref(conf),
+                                            m.ctypes.data, s.ctypes.data, 0, 0))
         return m, s

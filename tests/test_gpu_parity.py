@@ -1,0 +1,417 @@
+"""GPU parity tests (pytest -m gpu): every call goes through the C-ABI of libsfd2hip.so and is
+compared with the CPU oracle on the same seeded inputs, with the committed reference goldens,
+and -- at BASELINE.json's full sizes -- directly (the oracle needs seconds) plus through
+size-independent properties.
+
+Tolerances (fp16 MFMA operands, fp32 accumulate; measured worst cases in DESIGN.md):
+  * integer / index / compare-only stages (heat map, NMS, threshold, border, sort, top-K,
+    mutual check given identical similarities): BIT-EXACT
+  * conv-stack activations: |err| <= 1.5e-2 * max|layer|   (fp16 rounding through 22 layers)
+  * detector score: |err| <= 8e-2 * score + 1e-4           (exp() of logits known to ~6e-2)
+  * descriptors (dense and sampled): |err| <= 3e-3 abs on unit vectors; norms 1 +- 1e-5
+  * key points end-to-end: set IoU >= 0.95 vs the fp32 oracle (selection is a cascade of
+    discontinuities: exactness is claimed per stage, not across the fp16 conv stack)
+  * matcher: fp16 operands: similarities within 1e-3, matches identical wherever the
+    top-1/top-2 gap exceeds 1e-3; hi+lo split mode ('f16x2'): within 1e-6 / identical.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402  (tests may use the oracle; the product never does)
+from sfd2_amd import _lib, synth  # noqa: E402
+
+
+def _gpu_ok():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="module")
+def model(synth_sd):
+    if not _gpu_ok():
+        pytest.fail("no MI355X visible: GPU tests cannot run (there is no CPU fallback)")
+    from sfd2_amd.model import ResSegNetV2
+    m = ResSegNetV2(outdim=128, require_stability=True).eval()
+    m.load_state_dict(synth_sd)
+    m.cuda(0)
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(model):
+    return model.context
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _kp_index(kp):
+    return {(int(x), int(y)): i for i, (x, y) in enumerate(kp)}
+
+
+def _compare_extract(got, want, min_iou, desc_tol):
+    a, b = _kp_index(got["keypoints"]), _kp_index(want["keypoints"])
+    common = sorted(set(a) & set(b))
+    iou = len(common) / max(1, len(set(a) | set(b)))
+    assert iou >= min_iou, iou
+    ia = np.array([a[k] for k in common]); ib = np.array([b[k] for k in common])
+    ds = np.abs(got["scores"][ia] - want["scores"][ib])
+    assert (ds <= 8e-2 * want["scores"][ib] + 1e-4).all(), ds.max()
+    dd = np.abs(got["descriptors"][ia] - np.asarray(want["descriptors"], dtype=np.float64)[ib]).max()
+    assert dd <= desc_tol, dd
+    return iou
+
+
+# ------------------------------------------------------------------ conv stack / det
+@pytest.mark.parametrize("h,w,seed", [(64, 96, 11), (100, 130, 12), (37, 53, 13)])
+def test_det_vs_oracle(model, ctx, synth_sd, h, w, seed):
+    img = synth.make_image(h, w, seed)
+    x = orc.norm_rgb(img)
+    taps = {}
+    o_score, o_stab, o_desc = orc.det(synth_sd, x, taps)
+    score, stab, desc = model.det(x[None])
+    assert score.shape == (1, 1) + o_score.shape and desc.shape == (1,) + o_desc.shape and stab.shape == (1, 1, h, w)
+    for name, want in taps.items():
+        got = ctx.debug_activation(name)
+        assert got.shape == want.shape, name
+        err = np.abs(got - want).max()
+        assert err <= 1.5e-2 * np.abs(want).max(), (name, err)
+    assert (np.abs(score[0, 0] - o_score) <= 8e-2 * o_score + 1e-4).all()
+    assert np.abs(desc[0] - o_desc).max() <= 3e-3
+    np.testing.assert_allclose(np.linalg.norm(desc[0], axis=0), 1.0, atol=1e-5)
+    assert (stab[0, 0] != o_stab).mean() < 0.01          # 3-class arg-max flips only at near-ties
+    assert set(np.unique(stab)) <= {np.float32(0.1), np.float32(0.5), np.float32(1.0)}
+
+
+@pytest.mark.parametrize("tag", ["64x96", "100x130"])
+def test_det_vs_reference_golden(model, golden_dir, tag):
+    g = _load(golden_dir, f"det_{tag}.npz")
+    img = synth.make_image(int(g["h"]), int(g["w"]), int(g["seed"]))
+    score, stab, desc = model.det(orc.norm_rgb(img)[None])
+    assert (np.abs(score[0, 0] - g["score"]) <= 8e-2 * g["score"] + 1e-4).all()
+    assert np.abs(desc[0] - g["desc"]).max() <= 3e-3
+    assert (stab[0, 0] != g["stability"]).mean() < 0.01
+
+
+def test_det_torch_cuda_tensors(model, synth_sd):
+    import torch
+    x = torch.from_numpy(orc.norm_rgb(synth.make_image(64, 96, 11)))[None].cuda()
+    score, stab, desc = model.det(x)
+    assert score.is_cuda and desc.is_cuda and stab.is_cuda
+    s2, st2, d2 = model.det(x.cpu().numpy())
+    np.testing.assert_array_equal(score.cpu().numpy(), s2)
+    np.testing.assert_array_equal(desc.cpu().numpy(), d2)
+    np.testing.assert_array_equal(stab.cpu().numpy(), st2)
+
+
+# ------------------------------------------------------------------ exact stages
+def _heat_hip(ctx, score, sta, h, w):
+    score = np.ascontiguousarray(score, dtype=np.float32)
+    out = np.empty((h, w), dtype=np.float32)
+    sp = None
+    hc = wc = 0
+    if sta is not None:
+        sta = np.ascontiguousarray(sta, dtype=np.float32)
+        sp, hc, wc = sta.ctypes.data, sta.shape[1], sta.shape[2]
+    _lib.check(ctx.lib.sfd2_heatmap(ctx.h, score.ctypes.data, score.shape[0], score.shape[1], sp, hc, wc, h, w, out.ctypes.data))
+    return out
+
+
+@pytest.mark.parametrize("h,w,hs,ws,hc,wc", [(64, 96, 64, 96, 16, 24), (100, 130, 104, 136, 25, 33),
+                                              (1063, 1600, 1064, 1600, 266, 400), (1200, 1600, 1200, 1600, 300, 400)])
+def test_heatmap_bit_exact(ctx, h, w, hs, ws, hc, wc):
+    rs = np.random.RandomState(h + w)
+    score = rs.random_sample((hs, ws)).astype(np.float32)
+    sta = rs.standard_normal((3, hc, wc)).astype(np.float32)
+    want = orc.heatmap(score, orc.cls_to_value(orc.resize_bilinear(sta, h, w)), h, w)
+    np.testing.assert_array_equal(_heat_hip(ctx, score, sta, h, w), want)
+    want_ns = orc.heatmap(score, None, h, w)
+    np.testing.assert_array_equal(_heat_hip(ctx, score, None, h, w), want_ns)
+
+
+def _nms_hip(ctx, m, r=4):
+    m = np.ascontiguousarray(m, dtype=np.float32)
+    out = np.empty_like(m)
+    _lib.check(ctx.lib.sfd2_simple_nms(ctx.h, m.ctypes.data, m.shape[0], m.shape[1], r, out.ctypes.data))
+    return out
+
+
+def _select_hip(ctx, m, conf_th, border, topk):
+    m = np.ascontiguousarray(m, dtype=np.float32)
+    cap = m.size
+    kp = np.empty((cap, 2), dtype=np.float32)
+    sc = np.empty((cap,), dtype=np.float32)
+    n = ctypes.c_int()
+    _lib.check(ctx.lib.sfd2_select_keypoints(ctx.h, m.ctypes.data, m.shape[0], m.shape[1], conf_th, 4, border, topk,
+                                             kp.ctypes.data, sc.ctypes.data, cap, ctypes.byref(n)))
+    return kp[:n.value], sc[:n.value]
+
+
+@pytest.mark.parametrize("case", ["rand_61x83", "rand_128x160", "plateau_64x64", "sparse_70x90", "tiny_5x7"])
+def test_nms_vs_reference_golden_bit_exact(ctx, golden_dir, case):
+    g = _load(golden_dir, "nms.npz")
+    out = _nms_hip(ctx, g[case + "/in"])
+    idx = np.flatnonzero(out)
+    np.testing.assert_array_equal(idx, g[case + "/idx"])
+    np.testing.assert_array_equal(out.reshape(-1)[idx], g[case + "/val"])
+
+
+@pytest.mark.parametrize("h,w,kind", [(33, 65, "rand"), (200, 333, "rand"), (64, 64, "plateau"), (97, 131, "sparse"),
+                                       (8, 9, "rand"), (1200, 1600, "rand"), (1063, 1600, "smooth"), (64, 64, "const")])
+def test_nms_and_selection_bit_exact(ctx, h, w, kind):
+    rs = np.random.RandomState(h * 7 + w)
+    m = rs.random_sample((h, w))
+    if kind == "plateau":
+        m = np.floor(m * 4) / 4
+    elif kind == "sparse":
+        m = np.where(m > 0.97, rs.random_sample((h, w)), 0)
+    elif kind == "smooth":   # heat-map like: peaky, mostly tiny values
+        m = m ** 12
+    elif kind == "const":
+        m = np.full((h, w), 0.25)
+    m = m.astype(np.float32)
+    want = orc.simple_nms(m, 4)
+    np.testing.assert_array_equal(_nms_hip(ctx, m), want)
+    for topk in (64, 4096, -1):
+        if kind in ("plateau", "const") and topk > 0:
+            continue   # equal scores straddling the top-K cut: order fixed by our tie rule, checked with -1
+        kp_w, sc_w, _ = orc.select_keypoints(want, 0.001, 4, topk)
+        kp, sc = _select_hip(ctx, m, 0.001, 4, topk)
+        np.testing.assert_array_equal(kp, kp_w)
+        np.testing.assert_array_equal(sc, sc_w)
+        assert (np.diff(sc) <= 0).all()
+        if len(kp):
+            assert kp[:, 0].min() >= 4 and kp[:, 0].max() < w - 4 and kp[:, 1].min() >= 4 and kp[:, 1].max() < h - 4
+
+
+def test_selection_vs_reference_golden_bit_exact(ctx, golden_dir):
+    """Reference NMS output (candidates) -> threshold / border / sort / top-K identical to the
+    reference's key points and scores (nets/extractor.py:158-183,322-326)."""
+    g = _load(golden_dir, "extract_480x640_k1024.npz")
+    h, w, topk = int(g["h"]), int(g["w"]), int(g["topk"])
+    nms = np.zeros((h * w,), dtype=np.float32)
+    nms[g["cand_idx"]] = g["cand_val"]
+    # the NMS of an already-suppressed map keeps isolated maxima, so feeding the reference's NMS
+    # output through the full stage reproduces the reference's selection
+    kp, sc = _select_hip(ctx, nms.reshape(h, w), 0.001, 4, topk)
+    np.testing.assert_array_equal(kp, g["keypoints"])
+    np.testing.assert_array_equal(sc, g["scores"])
+
+
+def test_nms_radius_argument(ctx):
+    m = np.random.RandomState(1).random_sample((50, 60)).astype(np.float32)
+    for r in (0, 1, 2, 3):
+        np.testing.assert_array_equal(_nms_hip(ctx, m, r), orc.simple_nms(m, r))
+    with pytest.raises(RuntimeError):
+        _nms_hip(ctx, m, 5)
+
+
+def test_sample_descriptors_vs_oracle(ctx):
+    rs = np.random.RandomState(5)
+    for (hc, wc, nh, nw) in ((25, 33, 100, 130), (300, 400, 1200, 1600), (16, 24, 64, 96)):
+        dm = orc.l2norm_channels(rs.standard_normal((128, hc, wc)).astype(np.float32))
+        n = 500
+        kp = np.stack([rs.randint(0, nw, n), rs.randint(0, nh, n)], axis=1).astype(np.float32)
+        kp[:4] = [[0, 0], [nw - 1, nh - 1], [0, nh - 1], [nw - 1, 0]]          # zero-padded border taps
+        want = orc.sample_descriptors(dm, kp, nh, nw)
+        got = np.empty_like(want)
+        _lib.check(ctx.lib.sfd2_sample_descriptors(ctx.h, dm.ctypes.data, hc, wc, nh, nw, kp.ctypes.data, n, got.ctypes.data))
+        np.testing.assert_allclose(got, want, atol=2e-6)
+        np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+
+
+# ------------------------------------------------------------------ end to end
+@pytest.mark.parametrize("h,w,seed,topk", [(96, 128, 21, 200), (100, 130, 22, -1), (480, 640, 0, 1024)])
+def test_extract_vs_oracle_and_golden(model, synth_sd, golden_dir, h, w, seed, topk):
+    from sfd2_amd.extractor import extract_resnet_return
+    img = synth.make_image(h, w, seed)
+    got = extract_resnet_return(model, img[None], conf_th=0.001, topK=topk, scales=[1.0])
+    assert got["keypoints"].dtype == np.float64 and got["descriptors"].dtype == np.float64 and got["scores"].dtype == np.float64
+    assert got["descriptors"].shape == (len(got["scores"]), 128)
+    assert (np.diff(got["scores"]) <= 0).all()
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk)
+    _compare_extract(got, want, 0.95, 3e-3)
+    tag = {(96, 128): "96x128_k200", (100, 130): "100x130_all", (480, 640): "480x640_k1024"}[(h, w)]
+    g = _load(golden_dir, f"extract_{tag}.npz")
+    ref = {"keypoints": g["keypoints"], "scores": g["scores"].astype(np.float64), "descriptors": g["descriptors"].astype(np.float64)}
+    _compare_extract(got, ref, 0.95, 4e-3)   # fixture descriptors are stored as fp16
+
+
+def test_extract_full_size_1600x1200(model, synth_sd):
+    """BASELINE.json configs[1] geometry: direct comparison with the oracle + invariants."""
+    from sfd2_amd.extractor import extract_resnet_return
+    import torch
+    img = synth.make_image(1200, 1600, 5)
+    got = extract_resnet_return(model, torch.from_numpy(img)[None].cuda(), conf_th=0.001, topK=4096, scales=[1.0])
+    n = len(got["scores"])
+    assert n == 4096
+    kp = got["keypoints"]
+    assert len({(int(x), int(y)) for x, y in kp}) == n
+    assert kp[:, 0].min() >= 4 and kp[:, 0].max() < 1600 - 4 and kp[:, 1].min() >= 4 and kp[:, 1].max() < 1200 - 4
+    assert (np.diff(got["scores"]) <= 0).all() and got["scores"].min() > 0.001
+    np.testing.assert_allclose(np.linalg.norm(got["descriptors"], axis=1), 1.0, atol=1e-5)
+    # NMS radius: no two key points within Chebyshev distance 4 unless they tie exactly
+    order = np.lexsort((kp[:, 0], kp[:, 1]))
+    pts = kp[order]
+    for i in range(0, n - 1):
+        j = i + 1
+        while j < n and pts[j, 1] - pts[i, 1] <= 4:
+            if abs(pts[j, 0] - pts[i, 0]) <= 4:
+                assert got["scores"][order[i]] == got["scores"][order[j]]
+            j += 1
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=4096)
+    _compare_extract(got, want, 0.93, 3e-3)
+
+
+def test_extract_async_device_outputs_equal_sync(model):
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    ctx = model.context
+    img = torch.from_numpy(synth.make_image(240, 320, 3)).cuda()
+    sync = extract_resnet_return(model, img[None], conf_th=0.001, topK=512, scales=[1.0])
+    kp = torch.zeros((512, 2), device="cuda"); sc = torch.zeros((512,), device="cuda"); de = torch.zeros((512, 128), device="cuda")
+    n = ctypes.c_int()
+    torch.cuda.synchronize()
+    _lib.check(ctx.lib.sfd2_extract(ctx.h, img.data_ptr(), 1, 240, 320, 0.001, 512, _lib.FLAG_ASYNC, kp.data_ptr(),
+                                    sc.data_ptr(), de.data_ptr(), 1, 512, ctypes.byref(n)))
+    assert n.value == -1
+    ctx.sync()
+    _lib.check(ctx.lib.sfd2_extract_count(ctx.h, ctypes.byref(n)))
+    k = n.value
+    assert k == len(sync["scores"])
+    np.testing.assert_array_equal(kp[:k].cpu().numpy().astype(np.float64), sync["keypoints"])
+    np.testing.assert_array_equal(sc[:k].cpu().numpy().astype(np.float64), sync["scores"])
+    np.testing.assert_array_equal(de[:k].cpu().numpy().astype(np.float64), sync["descriptors"])
+
+
+def test_no_stability_and_empty_result(synth_sd):
+    from sfd2_amd.extractor import extract_resnet_return
+    from sfd2_amd.model import ResSegNetV2
+    m = ResSegNetV2(outdim=128, require_stability=False).eval()
+    m.load_state_dict(synth_sd)
+    m.cuda(0)
+    img = synth.make_image(96, 128, 21)
+    got = extract_resnet_return(m, img[None], conf_th=0.001, topK=100, scales=[1.0])
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=100, use_stability=False)
+    _compare_extract(got, want, 0.9, 3e-3)
+    score, stab, desc = m.det(orc.norm_rgb(img)[None])
+    assert stab is None
+    none = extract_resnet_return(m, img[None], conf_th=2.0, topK=100, scales=[1.0])   # nothing above threshold
+    assert none["keypoints"].shape == (0, 2) and none["descriptors"].shape == (0, 128) and none["scores"].shape == (0,)
+
+
+# ------------------------------------------------------------------ matchers
+HLOC_CONFS = {
+    "NNM": dict(do_mutual_check=True),
+    "ONN": dict(do_mutual_check=False),
+    "NNR": dict(do_mutual_check=True, distance_threshold=0.9),
+    "RATIO": dict(do_mutual_check=True, ratio_threshold=0.8),
+    "RATIO_DIST": dict(do_mutual_check=False, ratio_threshold=0.9, distance_threshold=0.7),
+}
+
+
+def _hloc(d0, d1, conf, sim_mode):
+    from sfd2_amd.matchers.nearest_neighbor import NearestNeighbor
+    p = NearestNeighbor({**conf, "sim_mode": sim_mode})({"descriptors0": d0.T[None].copy(), "descriptors1": d1.T[None].copy()})
+    return p["matches0"][0], p["matching_scores0"][0]
+
+
+def _gaps(d0, d1):
+    sim = d0.astype(np.float64) @ d1.astype(np.float64).T
+    r = np.sort(sim, axis=1)
+    c = np.sort(sim, axis=0)
+    return r[:, -1] - r[:, -2], c[-1] - c[-2], sim
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_matchers_vs_reference_golden(golden_dir, tag):
+    from sfd2_amd.matcher import Matcher, confs as mconfs
+    g = _load(golden_dir, "matchers.npz")
+    d0, d1 = g[f"{tag}/d0"], g[f"{tag}/d1"]
+    for name, conf in HLOC_CONFS.items():
+        gm, gs = g[f"{tag}/hloc/{name}/matches0"], g[f"{tag}/hloc/{name}/scores0"]
+        m, s = _hloc(d0, d1, conf, "f16x2")
+        assert (m != gm).mean() <= 0.003, name            # threshold tests on ~1e-7-different sums
+        np.testing.assert_allclose(s[m == gm], gs[m == gm], atol=2e-6)
+        m, s = _hloc(d0, d1, conf, "f16")
+        assert (m != gm).mean() <= 0.02, name
+        np.testing.assert_allclose(s[m == gm], gs[m == gm], atol=1e-3)
+    for name in ("NNM", "NNR"):
+        gm, gs = g[f"{tag}/itloc/{name}/matches0"], g[f"{tag}/itloc/{name}/scores0"]
+        for sim_mode, tol_m, tol_s in (("f16x2", 0.003, 2e-6), ("f16", 0.02, 1e-3)):
+            mc = {"output": name, "model": {**mconfs[name]["model"], "sim_mode": sim_mode}}
+            p = Matcher(mc).eval().cuda()({"descriptors0": d0.astype(np.float64), "descriptors1": d1.astype(np.float64)})
+            assert p["matches0"].dtype == np.int64 and p["matching_scores0"].dtype == np.float64
+            assert (p["matches0"] != gm).mean() <= tol_m, (name, sim_mode)
+            np.testing.assert_allclose(p["matching_scores0"], gs, atol=tol_s)
+
+
+@pytest.mark.parametrize("n0,n1", [(4096, 4096), (1000, 37), (33, 1025), (1, 3), (5, 1), (128, 128)])
+def test_matcher_vs_oracle_sizes(n0, n1):
+    d0 = synth.make_descriptors(n0, seed=n0 + 7)
+    d1 = synth.make_descriptors(n1, seed=n1 + 8)
+    k = min(n0, n1) // 2
+    if k:
+        rs = np.random.RandomState(9)
+        src, dst = rs.permutation(n0)[:k], rs.permutation(n1)[:k]
+        noisy = d0[src] + (0.02 + 0.1 * rs.random_sample((k, 1))).astype(np.float32) * rs.standard_normal((k, 128)).astype(np.float32)
+        d1[dst] = noisy / np.linalg.norm(noisy, axis=1, keepdims=True)
+    rg, cg, sim = _gaps(d0, d1) if n1 > 1 and n0 > 1 else (np.ones(n0), np.ones(n1), d0.astype(np.float64) @ d1.astype(np.float64).T)
+    for name, conf in (("NNM", HLOC_CONFS["NNM"]), ("ONN", HLOC_CONFS["ONN"])):
+        want = orc.hloc_nearest_neighbor(d0, d1, **conf)
+        for sim_mode, gap, tol in (("f16", 1e-3, 1e-3), ("f16x2", 1e-5, 2e-6)):
+            m, s = _hloc(d0, d1, conf, sim_mode)
+            # rows whose own arg-max and whose partner's arg-max are unambiguous at this precision
+            safe = rg > gap
+            if conf["do_mutual_check"]:
+                j = np.argmax(sim, axis=1)
+                safe &= cg[j] > gap
+            np.testing.assert_array_equal(m[safe], want["matches0"][safe])
+            same = m == want["matches0"]
+            np.testing.assert_allclose(s[same], want["matching_scores0"][same], atol=tol)
+            if conf["do_mutual_check"]:      # mutual matches are a partial bijection
+                mm = m[m >= 0]
+                assert len(np.unique(mm)) == len(mm)
+
+
+def test_matcher_batch_equals_single_and_handles_empty():
+    from sfd2_amd.matcher import Matcher, confs as mconfs
+    mt = Matcher(mconfs["NNM"])
+    d0 = synth.make_descriptors(700, seed=1)
+    dbs = [synth.make_descriptors(n, seed=10 + i) for i, n in enumerate((512, 100, 0, 900, 33))]
+    m, s = mt.match_batch(d0, dbs)
+    assert m.shape == (5, 700)
+    for i, d1 in enumerate(dbs):
+        if len(d1) == 0:
+            assert (m[i] == -1).all()
+            continue
+        p = mt({"descriptors0": d0, "descriptors1": d1})
+        np.testing.assert_array_equal(m[i], p["matches0"])
+        np.testing.assert_allclose(s[i], p["matching_scores0"], atol=0)
+
+
+def test_hloc_plugin_with_cuda_tensors():
+    import torch
+    from sfd2_amd import matchers
+    from sfd2_amd.base_model import dynamic_load
+    Model = dynamic_load(matchers, "nearest_neighbor")
+    model = Model({"do_mutual_check": True, "distance_threshold": 0.9}).eval().to("cuda")
+    d0 = torch.from_numpy(synth.make_descriptors(600, seed=3).T.copy())[None].cuda()
+    d1 = torch.from_numpy(synth.make_descriptors(500, seed=4).T.copy())[None].cuda()
+    pred = model({"descriptors0": d0, "descriptors1": d1})
+    assert pred["matches0"].is_cuda and pred["matches0"].dtype == torch.int64 and pred["matches0"].shape == (1, 600)
+    assert pred["matching_scores0"].dtype == torch.float32
+    cpu = model({"descriptors0": d0.cpu(), "descriptors1": d1.cpu()})
+    assert torch.equal(pred["matches0"].cpu(), cpu["matches0"]) and torch.equal(pred["matching_scores0"].cpu(), cpu["matching_scores0"])
+    from sfd2_amd.match_features import cast_for_storage
+    m16, s16 = cast_for_storage(cpu["matches0"][0].numpy(), cpu["matching_scores0"][0].numpy())
+    assert m16.dtype == np.int16 and s16.dtype == np.float16
