@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extract-only", action="store_true", help="configs[1]: extract without matching")
+    ap.add_argument("--dump-layers", action="store_true", help="per-layer device times to stderr")
     args = ap.parse_args()
 
     import torch
@@ -166,6 +167,13 @@ def main():
                     "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 5), "launches": dom["launches"],
                     "traffic": None}
         total_ms = sum(r["ms_total"] for r in layers)
+        if args.dump_layers:
+            for r in layers:
+                ms = r["ms_total"] / max(1, r["launches"])
+                tf = r["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0
+                gb = r["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0
+                print(f"{r['name']:16s} {r['kernel']:34s} {ms*1e3:9.1f} us  {r['flops']/1e9:8.2f} GF {tf:8.1f} TF/s  "
+                      f"{r['bytes']/1e6:8.1f} MB {gb:8.0f} GB/s", file=sys.stderr)
         breakdown = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         out = {
             "metric": "images/sec extract" + ("" if args.extract_only else "+match") + " (1600x1200, n4096)",

@@ -222,9 +222,228 @@ void nms_select_kernel(const float *__restrict__ heat, int H, int W, int radius,
     }
 }
 
+// ---------------------------------------------------------------- fast path, radius 4
+// Same algorithm, restructured for the LDS: region 64 x 128 (tile 24 x 88 + 20-px halo), only two
+// float planes (scores S, row-pass result A).  Each max-pool is a register-blocked row pass
+// (8 outputs from 16 loaded values: suffix/prefix maxima) and a column pass whose result is
+// compared in registers and turned into bit masks with wave ballots; the two mask dilations
+// (supp_mask = max_pool(max_mask) > 0) are bit operations on 128-bit rows.  The suppressed score
+// map (where(supp, 0, scores)) is formed on the fly from S and the supp bits.
+#define N2_TH 24
+#define N2_TW 88
+#define N2_HALO 20
+#define N2_RH 64
+#define N2_RW 128
+#define N2_SP 136   // S row pitch: 4 pad floats (-inf) on either side
+#define N2_AR (N2_RH + 8)
+
+__device__ __forceinline__ void pool8(const float (&v)[16], float (&o)[8])
+{
+    // o[j] = max(v[j .. j+8]) = max(suffix max of v[0..7] at j, prefix max of v[8..15] at j)
+    float suf[8], pre[8];
+    suf[7] = v[7];
+#pragma unroll
+    for (int j = 6; j >= 0; --j) suf[j] = fmaxf(v[j], suf[j + 1]);
+    pre[0] = v[8];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) pre[j] = fmaxf(pre[j - 1], v[8 + j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = fmaxf(suf[j], pre[j]);
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void n2_row_pass(const float *__restrict__ S, float *__restrict__ A,
+                                            const unsigned long long *__restrict__ supp)
+{
+    const float NEG = -INFINITY;
+    for (int u = threadIdx.x; u < N2_RH * 16; u += blockDim.x) {
+        const int y = u >> 4, x0 = (u & 15) * 8;
+        float v[16];
+        const float4 *src = reinterpret_cast<const float4 *>(S + y * N2_SP + x0);   // region cols x0-4 .. x0+11
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t = src[q];
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        if (MASKED) {
+            // bits of region cols x0-4 .. x0+11, taken from the row mask shifted left by 4
+            const unsigned long long w0 = supp[2 * y], w1 = supp[2 * y + 1];
+            const unsigned long long lo = w0 << 4, hi = (w1 << 4) | (w0 >> 60), top = w1 >> 60;
+            unsigned long long bits;
+            if (x0 < 64) bits = (lo >> x0) | (x0 ? (hi << (64 - x0)) : 0ull);
+            else { const int sft = x0 - 64; bits = (hi >> sft) | (sft ? (top << (64 - sft)) : 0ull); }
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (((bits >> i) & 1ull) && v[i] != NEG) v[i] = 0.0f;   // padding stays -inf
+        }
+        float o[8];
+        pool8(v, o);
+        float4 *dst = reinterpret_cast<float4 *>(A + (y + 4) * N2_RW + x0);
+        dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+// column pass + compare; MASKED: new = old | (ss == pool(ss) & ~supp), else new = (s == pool(s))
+template <bool MASKED>
+__device__ __forceinline__ void n2_col_pass(const float *__restrict__ S, const float *__restrict__ A,
+                                            const unsigned long long *__restrict__ supp,
+                                            unsigned long long *__restrict__ mask)
+{
+    const float NEG = -INFINITY;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int u = wave; u < (N2_RH / 8) * 2; u += nw) {
+        const int k = u >> 1, h = u & 1, x = h * 64 + lane;
+        float a[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = A[(8 * k + i) * N2_RW + x];
+        float o[8];
+        pool8(a, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int y = 8 * k + j;
+            const float sv = S[y * N2_SP + 4 + x];
+            bool cond;
+            if (MASKED) {
+                const bool sb = (supp[2 * y + h] >> lane) & 1ull;
+                const float ss = (sb && sv != NEG) ? 0.0f : sv;
+                cond = (ss == o[j]) && sv != NEG && !sb;
+            } else {
+                cond = (sv == o[j]) && sv != NEG;
+            }
+            const unsigned long long word = __ballot(cond);
+            if (lane == 0) mask[2 * y + h] = MASKED ? (mask[2 * y + h] | word) : word;
+        }
+    }
+}
+
+__device__ __forceinline__ void n2_dilate(const unsigned long long *__restrict__ m, unsigned long long *__restrict__ tmp,
+                                          unsigned long long *__restrict__ supp)
+{
+    for (int u = threadIdx.x; u < N2_RH; u += blockDim.x) {
+        const unsigned long long w0 = m[2 * u], w1 = m[2 * u + 1];
+        unsigned long long d0 = w0, d1 = w1;
+#pragma unroll
+        for (int sft = 1; sft <= 4; ++sft) {
+            d0 |= (w0 << sft) | (w0 >> sft) | (w1 << (64 - sft));
+            d1 |= (w1 << sft) | (w1 >> sft) | (w0 >> (64 - sft));
+        }
+        tmp[2 * u] = d0;
+        tmp[2 * u + 1] = d1;
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < N2_RH * 2; u += blockDim.x) {
+        const int y = u >> 1, h = u & 1;
+        unsigned long long d = 0ull;
+#pragma unroll
+        for (int dy = -4; dy <= 4; ++dy)
+            if (y + dy >= 0 && y + dy < N2_RH) d |= tmp[2 * (y + dy) + h];
+        supp[u] = d;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(512)
+void nms4_select_kernel(const float *__restrict__ heat, int H, int W, float conf_th, int border,
+                        float *__restrict__ nms_dense, unsigned long long *__restrict__ cand, int cand_cap,
+                        unsigned int *__restrict__ counters, unsigned int *__restrict__ hist)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *S = reinterpret_cast<float *>(smem);                         // [RH][SP]
+    float *A = S + N2_RH * N2_SP;                                       // [RH + 8][RW]
+    unsigned long long *M = reinterpret_cast<unsigned long long *>(A + N2_AR * N2_RW);   // [RH][2]
+    unsigned long long *SU = M + 2 * N2_RH;
+    unsigned long long *TM = SU + 2 * N2_RH;
+    const float NEG = -INFINITY;
+    const int gy0 = blockIdx.y * N2_TH - N2_HALO, gx0 = blockIdx.x * N2_TW - N2_HALO;
+
+    for (int i = threadIdx.x; i < N2_RH * N2_SP; i += blockDim.x) {
+        const int y = i / N2_SP, xs = i - y * N2_SP;
+        const int gy = gy0 + y, gx = gx0 + xs - 4;
+        const bool in = xs >= 4 && xs < 4 + N2_RW && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        S[i] = in ? heat[(size_t)gy * W + gx] : NEG;
+    }
+    for (int i = threadIdx.x; i < 4 * N2_RW; i += blockDim.x) {          // -inf rows above / below A
+        A[i] = NEG;
+        A[(N2_RH + 4) * N2_RW + i] = NEG;
+    }
+    __syncthreads();
+    n2_row_pass<false>(S, A, nullptr);
+    __syncthreads();
+    n2_col_pass<false>(S, A, nullptr, M);                                // max_mask = scores == max_pool(scores)
+    __syncthreads();
+    for (int it = 0; it < 2; ++it) {
+        n2_dilate(M, TM, SU);                                            // supp_mask = max_pool(max_mask) > 0
+        n2_row_pass<true>(S, A, SU);
+        __syncthreads();
+        n2_col_pass<true>(S, A, SU, M);                                  // max_mask |= new_max_mask & ~supp_mask
+        __syncthreads();
+    }
+    // Candidates are first gathered per block in LDS (the A plane is free now) so that the global
+    // cursor sees ONE atomic per block: tens of thousands of same-address atomics (~12 ns each at
+    // the L2) were the whole cost of this kernel.
+    unsigned long long *lkeys = reinterpret_cast<unsigned long long *>(A);   // <= 24*88 keys = 16.5 KB
+    // (all LDS stays in the one dynamic array: a static __shared__ would shift its 16-byte base)
+    unsigned int &l_cnt = reinterpret_cast<unsigned int *>(TM + 2 * N2_RH)[0];
+    unsigned int &l_base = reinterpret_cast<unsigned int *>(TM + 2 * N2_RH)[1];
+    if (threadIdx.x == 0) l_cnt = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < N2_TH * N2_TW; i += blockDim.x) {
+        const int ty = i / N2_TW, tx = i - ty * N2_TW;
+        const int gy = blockIdx.y * N2_TH + ty, gx = blockIdx.x * N2_TW + tx;
+        if (gy >= H || gx >= W) continue;
+        const int ry = ty + N2_HALO, rx = tx + N2_HALO;
+        const bool mk = (M[2 * ry + (rx >> 6)] >> (rx & 63)) & 1ull;
+        const float v = mk ? S[ry * N2_SP + 4 + rx] : 0.0f;              // where(max_mask, scores, zeros)
+        if (nms_dense) nms_dense[(size_t)gy * W + gx] = v;
+        if (cand && v > conf_th && gx >= border && gx < W - border && gy >= border && gy < H - border) {
+            const unsigned int idx = (unsigned int)(gy * W + gx);
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+            lkeys[atomicAdd(&l_cnt, 1u)] = key;
+        }
+    }
+    __syncthreads();
+    if (!cand || l_cnt == 0) return;
+    if (threadIdx.x == 0) l_base = atomicAdd(&counters[0], l_cnt);
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < l_cnt; i += blockDim.x) {
+        const unsigned int pos = l_base + i;
+        if (pos < (unsigned int)cand_cap) {
+            const unsigned long long key = lkeys[i];
+            cand[pos] = key;
+            atomicAdd(&hist[(unsigned int)(key >> 47) & 0xFFFFu], 1u);
+        }
+    }
+}
+
+// generic-radius kernel also feeds the histogram (same key -> bin map)
+__global__ __launch_bounds__(NT)
+void hist_from_cand_kernel(const unsigned long long *__restrict__ cand, int cand_cap,
+                           const unsigned int *__restrict__ counters, unsigned int *__restrict__ hist)
+{
+    unsigned int n = counters[0];
+    if (n > (unsigned int)cand_cap) n = cand_cap;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        atomicAdd(&hist[(unsigned int)(cand[i] >> 47) & 0xFFFFu], 1u);
+}
+
 void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radius, float conf_th, int border,
                        float *nms_dense, unsigned long long *cand, int cand_cap, unsigned int *counters)
 {
+    unsigned int *hist = counters + 16;   // counters[0..15], then 65536 histogram bins
+    if (radius == 4) {
+        static bool attr4 = false;
+        const size_t lds4 = (size_t)(N2_RH * N2_SP + N2_AR * N2_RW) * sizeof(float) + 3 * 2 * N2_RH * sizeof(unsigned long long) + 16;
+        if (!attr4) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms4_select_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+            attr4 = true;
+        }
+        hipLaunchKernelGGL(nms4_select_kernel, dim3((W + N2_TW - 1) / N2_TW, (H + N2_TH - 1) / N2_TH), dim3(512), lds4,
+                           st, heat, H, W, conf_th, border, nms_dense, cand, cand_cap, counters, hist);
+        return;
+    }
     static bool attr_done = false;
     const size_t lds = (size_t)NMS_N * (3 * sizeof(float) + 1);
     if (!attr_done) {
@@ -234,101 +453,143 @@ void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radi
     }
     hipLaunchKernelGGL(nms_select_kernel, dim3((W + NMS_TW - 1) / NMS_TW, (H + NMS_TH - 1) / NMS_TH), dim3(512), lds,
                        st, heat, H, W, radius, conf_th, border, nms_dense, cand, cand_cap, counters);
+    if (cand) hipLaunchKernelGGL(hist_from_cand_kernel, dim3(64), dim3(NT), 0, st, cand, cand_cap, counters, hist);
 }
 
 // ---------------------------------------------------------------- top-K + sort
 // Keys are unique 64-bit integers: (score bits << 32) | (0xFFFFFFFF - pixel index); descending
 // key order == score descending, then pixel index ascending (the tie rule of DESIGN.md).
-// counters: [0] n_cand (may exceed cap: overflow flag), [1] n_selected, [2] compaction cursor,
-//           [4..5] threshold key.
+// counters: [0] n_cand (may exceed cap: overflow flag), [1] n_selected (K), [2] cursor of keys above
+//           the boundary bin, [3] boundary-list cursor, [4] boundary bin b*, [5] keys still needed
+//           from bin b*, [6] select-all flag; counters[16 ..] = 65536-bin histogram of score bits >> 15
+//           (filled by the NMS kernel while it appends candidates).
 __global__ __launch_bounds__(1024)
-void radix_select_kernel(const unsigned long long *__restrict__ cand, int cand_cap, int top_k,
-                         unsigned int *__restrict__ counters)
+void select_threshold_kernel(int cand_cap, int top_k, unsigned int *__restrict__ counters)
 {
-    __shared__ unsigned int hist[256];
-    __shared__ unsigned long long s_prefix, s_mask;
-    __shared__ unsigned int s_remaining;
+    __shared__ unsigned int tsum[1024];
+    __shared__ unsigned int s_t, s_above;
+    const unsigned int *hist = counters + 16;
     unsigned int n = counters[0];
     if (n > (unsigned int)cand_cap) n = cand_cap;
-    unsigned int k = (top_k <= 0 || (unsigned int)top_k > n) ? n : (unsigned int)top_k;
-    unsigned long long *thr = reinterpret_cast<unsigned long long *>(counters + 4);
-    if (k == n) {  // keep everything
-        if (threadIdx.x == 0) { *thr = 0ull; counters[1] = n; counters[2] = 0; }
+    const unsigned int k = (top_k <= 0 || (unsigned int)top_k > n) ? n : (unsigned int)top_k;
+    if (k == n) {
+        if (threadIdx.x == 0) { counters[1] = n; counters[2] = 0; counters[3] = 0; counters[4] = 0; counters[5] = 0; counters[6] = 1; }
         return;
     }
-    if (threadIdx.x == 0) { s_prefix = 0ull; s_mask = 0ull; s_remaining = k; }
-    for (int pass = 7; pass >= 0; --pass) {
-        const int shift = pass * 8;
-        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
-        __syncthreads();
-        const unsigned long long prefix = s_prefix, mask = s_mask;
-        for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) {
-            const unsigned long long key = cand[i];
-            if ((key & mask) == prefix) atomicAdd(&hist[(unsigned int)(key >> shift) & 255u], 1u);
+    const int t = threadIdx.x;
+    unsigned int sum = 0;
+    for (int b = 0; b < 64; ++b) sum += hist[64 * t + b];
+    tsum[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        unsigned int cum = 0;
+        int tt = 1023;
+        for (; tt > 0; --tt) {
+            if (cum + tsum[tt] >= k) break;
+            cum += tsum[tt];
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned int cum = 0, rem = s_remaining;
-            int d = 255;
-            for (; d > 0; --d) {
-                if (cum + hist[d] >= rem) break;
-                cum += hist[d];
-            }
-            s_remaining = rem - cum;
-            s_prefix = prefix | ((unsigned long long)d << shift);
-            s_mask = mask | (0xFFull << shift);
-        }
-        __syncthreads();
+        s_t = tt;
+        s_above = cum;
     }
-    if (threadIdx.x == 0) { *thr = s_prefix; counters[1] = k; counters[2] = 0; }
+    __syncthreads();
+    if (t == 0) {
+        unsigned int cum = s_above;
+        int b = 64 * (int)s_t + 63;
+        for (; b > 64 * (int)s_t; --b) {
+            if (cum + hist[b] >= k) break;
+            cum += hist[b];
+        }
+        counters[1] = k; counters[2] = 0; counters[3] = 0;
+        counters[4] = (unsigned int)b;     // boundary bin
+        counters[5] = k - cum;             // how many of its keys are selected
+        counters[6] = 0;
+    }
 }
 
 __global__ __launch_bounds__(NT)
 void compact_selected_kernel(const unsigned long long *__restrict__ cand, int cand_cap,
-                             unsigned long long *__restrict__ sel, int sel_cap, unsigned int *__restrict__ counters)
+                             unsigned long long *__restrict__ sel, int sel_cap,
+                             unsigned long long *__restrict__ bnd, unsigned int *__restrict__ counters)
 {
     unsigned int n = counters[0];
     if (n > (unsigned int)cand_cap) n = cand_cap;
-    const unsigned long long thr = *reinterpret_cast<const unsigned long long *>(counters + 4);
+    const unsigned int bstar = counters[4], all = counters[6];
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const unsigned long long key = cand[i];
-        if (key >= thr) {
+        const unsigned int bin = (unsigned int)(key >> 47) & 0xFFFFu;
+        if (all || bin > bstar) {
             const unsigned int pos = atomicAdd(&counters[2], 1u);
             if (pos < (unsigned int)sel_cap) sel[pos] = key;
+        } else if (bin == bstar) {
+            const unsigned int pos = atomicAdd(&counters[3], 1u);
+            bnd[pos] = key;   // bnd has cand_cap entries
         }
     }
 }
 
-// rank-by-counting sort of the selected keys (unique) into descending order
+// the boundary bin: rank its keys by counting and keep the `need` largest
+__global__ __launch_bounds__(1024)
+void boundary_kernel(const unsigned long long *__restrict__ bnd, unsigned long long *__restrict__ sel, int sel_cap,
+                     const unsigned int *__restrict__ counters)
+{
+    __shared__ unsigned long long tile[1024];
+    const unsigned int nb = counters[3], need = counters[5], k = counters[1];
+    if (counters[6] || need == 0) return;
+    const unsigned int base_out = k - need;
+    for (unsigned int i0 = 0; i0 < nb; i0 += blockDim.x) {
+        const unsigned int i = i0 + threadIdx.x;
+        const unsigned long long mine = i < nb ? bnd[i] : 0ull;
+        unsigned int rank = 0;
+        for (unsigned int b = 0; b < nb; b += 1024) {
+            tile[threadIdx.x] = (b + threadIdx.x < nb) ? bnd[b + threadIdx.x] : 0ull;
+            __syncthreads();
+            const unsigned int lim = nb - b < 1024 ? nb - b : 1024;
+            for (unsigned int t = 0; t < lim; ++t) rank += tile[t] > mine ? 1u : 0u;
+            __syncthreads();
+        }
+        if (i < nb && rank < need && base_out + rank < (unsigned int)sel_cap) sel[base_out + rank] = mine;
+    }
+}
+
+// rank-by-counting sort of the selected keys (unique) into descending order.
+// block = 64 keys x 4 quarters of the comparison range.
 __global__ __launch_bounds__(NT)
 void rank_sort_kernel(const unsigned long long *__restrict__ sel, unsigned long long *__restrict__ sorted,
                       int sel_cap, const unsigned int *__restrict__ counters)
 {
-    __shared__ unsigned long long tile[1024];
+    __shared__ unsigned long long tile[4][256];
+    __shared__ unsigned int part[4][64];
     unsigned int n = counters[1];
     if (n > (unsigned int)sel_cap) n = sel_cap;
-    if (blockIdx.x * blockDim.x >= n) return;
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * 64u >= n) return;
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const unsigned int i = blockIdx.x * 64 + li;
     const unsigned long long mine = i < n ? sel[i] : 0ull;
+    const unsigned int qlen = (n + 3) / 4, j0 = q * qlen;
+    const unsigned int j1 = j0 + qlen < n ? j0 + qlen : n;
     unsigned int rank = 0;
-    for (unsigned int base = 0; base < n; base += 1024) {
-        for (unsigned int t = threadIdx.x; t < 1024; t += blockDim.x) tile[t] = (base + t < n) ? sel[base + t] : 0ull;
+    for (unsigned int b = 0; b < qlen; b += 256) {           // same trip count for all four waves
+        for (int t = li; t < 256; t += 64) tile[q][t] = (j0 + b + t < j1) ? sel[j0 + b + t] : 0ull;
         __syncthreads();
-        const unsigned int lim = n - base < 1024 ? n - base : 1024;
-        for (unsigned int t = 0; t < lim; ++t) rank += tile[t] > mine ? 1u : 0u;
+#pragma unroll 8
+        for (int t = 0; t < 256; ++t) rank += tile[q][t] > mine ? 1u : 0u;
         __syncthreads();
     }
-    if (i < n) sorted[rank] = mine;
+    part[q][li] = rank;
+    __syncthreads();
+    if (q == 0 && i < n) sorted[part[0][li] + part[1][li] + part[2][li] + part[3][li]] = mine;
 }
 
 void launch_topk_sort(hipStream_t st, const unsigned long long *cand, int cand_cap, int top_k,
-                      unsigned long long *sel, unsigned long long *sorted, int sel_cap, unsigned int *counters)
+                      unsigned long long *sel, unsigned long long *sorted, int sel_cap, unsigned int *counters,
+                      unsigned long long *bnd)
 {
-    hipLaunchKernelGGL(radix_select_kernel, dim3(1), dim3(1024), 0, st, cand, cand_cap, top_k, counters);
+    hipLaunchKernelGGL(select_threshold_kernel, dim3(1), dim3(1024), 0, st, cand_cap, top_k, counters);
     int grid = (cand_cap + NT - 1) / NT;
-    if (grid > 512) grid = 512;
-    hipLaunchKernelGGL(compact_selected_kernel, dim3(grid), dim3(NT), 0, st, cand, cand_cap, sel, sel_cap, counters);
-    hipLaunchKernelGGL(rank_sort_kernel, dim3((sel_cap + NT - 1) / NT), dim3(NT), 0, st, sel, sorted, sel_cap, counters);
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL(compact_selected_kernel, dim3(grid), dim3(NT), 0, st, cand, cand_cap, sel, sel_cap, bnd, counters);
+    hipLaunchKernelGGL(boundary_kernel, dim3(1), dim3(1024), 0, st, bnd, sel, sel_cap, counters);
+    hipLaunchKernelGGL(rank_sort_kernel, dim3((sel_cap + 63) / 64), dim3(NT), 0, st, sel, sorted, sel_cap, counters);
 }
 
 __global__ __launch_bounds__(NT)

@@ -71,7 +71,7 @@ struct sfd2_ctx {
     DevBuf logits /*f32 [P8][128]*/, draw /*f32 [P4][128]*/, sta /*f32 [3][P4]*/, score /*f32*/, heat /*f32*/;
     DevBuf stab /*f32 [H][W]*/, desc_nchw, tmp_f32;
     // selection
-    DevBuf cand, sel, sorted, counters, kpts, kscores, kdesc;
+    DevBuf cand, bnd, sel, sorted, counters, kpts, kscores, kdesc;
     int cand_cap = 0;
     int last_sel_cap = 0;
     // matcher
@@ -150,7 +150,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
                       &c->rt1[0], &c->rt1[1], &c->rt1[2], &c->rt2[0], &c->rt2[1], &c->rt2[2], &c->ro[0], &c->ro[1],
                       &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
-                      &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->sel, &c->sorted, &c->counters,
+                      &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->bnd, &c->sel, &c->sorted, &c->counters,
                       &c->kpts, &c->kscores, &c->kdesc, &c->m_stage, &c->m_hi0, &c->m_lo0, &c->m_hi1, &c->m_lo1,
                       &c->m_part_f, &c->m_part_i, &c->m_red, &c->m_jobs, &c->m_fins, &c->m_out_m, &c->m_out_s};
     for (DevBuf *b : bufs) b->release();
@@ -373,7 +373,8 @@ static int ensure_workspace(sfd2_ctx *c, int H, int W)
     cap = std::min(cap, P1);
     c->cand_cap = (int)cap;
     HIPCHECK(c->cand.ensure(cap * 8));
-    HIPCHECK(c->counters.ensure(64));
+    HIPCHECK(c->bnd.ensure(cap * 8));
+    HIPCHECK(c->counters.ensure(SFD2_COUNTER_BYTES));
     c->acts.clear();
     auto reg = [&](const char *nm, const DevBuf &b, int f32, int planar, int ch, int pitch, int h, int w) {
         c->acts[nm] = ActInfo{b.p, f32, planar, ch, pitch, h, w};
@@ -528,17 +529,17 @@ static int run_selection(sfd2_ctx *c, const float *heat_dev, int H, int W, float
     HIPCHECK(c->sorted.ensure((size_t)sel_cap * 8));
     HIPCHECK(c->kpts.ensure((size_t)sel_cap * 2 * sizeof(float)));
     HIPCHECK(c->kscores.ensure((size_t)sel_cap * sizeof(float)));
-    HIPCHECK(hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+    HIPCHECK(hipMemsetAsync(c->counters.p, 0, SFD2_COUNTER_BYTES, c->stream));
     {
         ProfScope ps(c, "nms_select", "nms_select_kernel", 0.0, (double)H * W * 4);
         launch_nms_select(c->stream, heat_dev, H, W, radius, conf_th, border, nms_dense,
                           c->cand.as<unsigned long long>(), c->cand_cap, c->counters.as<unsigned int>());
     }
     {
-        ProfScope ps(c, "topk_sort", "radix_select+compact+rank_sort", 0.0, (double)sel_cap * 24);
+        ProfScope ps(c, "topk_sort", "hist_select+compact+rank_sort", 0.0, (double)sel_cap * 24);
         launch_topk_sort(c->stream, c->cand.as<unsigned long long>(), c->cand_cap, top_k,
                          c->sel.as<unsigned long long>(), c->sorted.as<unsigned long long>(), sel_cap,
-                         c->counters.as<unsigned int>());
+                         c->counters.as<unsigned int>(), c->bnd.as<unsigned long long>());
         launch_keys_to_kpts(c->stream, c->sorted.as<unsigned long long>(), c->counters.as<unsigned int>(), W,
                             c->kpts.as<float>(), c->kscores.as<float>(), sel_cap);
     }
@@ -642,7 +643,8 @@ static int heat_to_device(sfd2_ctx *c, const float *heat, int H, int W)
     cap = std::min(cap, (size_t)H * W);
     c->cand_cap = (int)cap;
     HIPCHECK(c->cand.ensure(cap * 8));
-    HIPCHECK(c->counters.ensure(64));
+    HIPCHECK(c->bnd.ensure(cap * 8));
+    HIPCHECK(c->counters.ensure(SFD2_COUNTER_BYTES));
     return 0;
 }
 
@@ -653,7 +655,7 @@ extern "C" int sfd2_simple_nms(sfd2_ctx *c, const float *heat, int H, int W, int
     HIPCHECK(hipSetDevice(c->device));
     if (heat_to_device(c, heat, H, W)) return -1;
     HIPCHECK(c->tmp_f32.ensure((size_t)H * W * sizeof(float)));
-    HIPCHECK(hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+    HIPCHECK(hipMemsetAsync(c->counters.p, 0, SFD2_COUNTER_BYTES, c->stream));
     launch_nms_select(c->stream, c->heat.as<float>(), H, W, radius, 0.0f, 0, c->tmp_f32.as<float>(), nullptr, 0,
                       c->counters.as<unsigned int>());
     HIPCHECK(hipGetLastError());

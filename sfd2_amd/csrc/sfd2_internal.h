@@ -48,7 +48,8 @@ void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radi
 // top-K of the candidate keys, sorted descending -> sorted_keys[0..n_sel), counters[1]=n_sel
 void launch_topk_sort(hipStream_t st, const unsigned long long *cand_keys, int cand_cap, int top_k,
                       unsigned long long *sel_keys, unsigned long long *sorted_keys, int sel_cap,
-                      unsigned int *counters);
+                      unsigned int *counters, unsigned long long *boundary_keys /*[cand_cap]*/);
+#define SFD2_COUNTER_BYTES (64 + 65536 * 4)   // 16 counters + score histogram
 // keys -> kpts (x,y), scores
 void launch_keys_to_kpts(hipStream_t st, const unsigned long long *sorted_keys, const unsigned int *counters,
                          int W, float *kpts_xy, float *scores, int cap);
