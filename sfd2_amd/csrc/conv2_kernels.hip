@@ -1,0 +1,258 @@
+// conv_igemm2: second-generation implicit-GEMM conv for the stride-1 layers that carry most of
+// the FLOPs (3x3 and 1x1, Cout tile 128 or 256).  Same GEMM orientation and epilogue as
+// conv_kernels.hip; what changes is the staging:
+//   * block = 512 threads = 8 waves, output tile 8 x 32 pixels x BN channels (the [BN][32] filter
+//     tile of a K step is shared by twice as many pixels -> half the filter traffic per FLOP)
+//   * global -> LDS copies are direct (global_load_lds_dwordx4): no VGPR round trip, no ds_write.
+//     The LDS image is lane-linear (64-byte records), bank conflicts are avoided by an XOR swizzle of
+//     the 16-byte slot index with ((record >> 2) & 3), applied to the per-lane SOURCE address when
+//     staging and to the read address when forming fragments (same involution on both sides).
+//   * out-of-image pixels (zero padding) read from a zero page instead of being predicated off,
+//     because a masked lane would leave stale bytes in LDS.
+// Replaces nets/sfd2.py Conv2d+BatchNorm2d+ReLU modules: conv2a, conv3a, conv3b (:272-278), the
+// ResBlock 1x1 convs (:30-35), convPa.3 / convDa.0 / convDa.3 (:286-297), convPb / convDb (:299-300).
+#include "sfd2_internal.h"
+
+#define TW 32
+#define TH2 8
+#define CC 32
+#define NT2 512
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __forceinline__ int xcd_swizzle2(int bid, int nblk)
+{
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+__device__ __forceinline__ h4_t cvt4b(float a, float b, float c, float d)
+{
+    h4_t r;
+    r[0] = (half_t)a; r[1] = (half_t)b; r[2] = (half_t)c; r[3] = (half_t)d;
+    return r;
+}
+
+template <int KS, int BN, bool OUT_F32, bool HAS_RES>
+__global__ __launch_bounds__(NT2, 2)
+void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
+                        const half_t *__restrict__ wpk, const float *__restrict__ scale,
+                        const float *__restrict__ shift, int CoutP, int relu,
+                        const half_t *__restrict__ res, void *__restrict__ outv,
+                        int Ho, int Wo, int tiles_x, const half_t *__restrict__ zero_page)
+{
+    constexpr int T = KS * KS;
+    constexpr int PAD = KS / 2;
+    constexpr int PH = TH2 - 1 + KS, PW = TW - 1 + KS;
+    constexpr int NPIX = PH * PW;
+    constexpr int XCH = (NPIX + 15) / 16;              // 1 KB chunks (16 pixel records) of one patch
+    constexpr int XPW = (XCH + 7) / 8;                 // chunks per wave
+    constexpr int WCH = BN / 16;                       // 1 KB chunks of one filter tile
+    constexpr int WPW = WCH / 8;                       // per wave (BN 128 -> 1, 256 -> 2)
+    constexpr int XBYTES = XCH * 1024, WBYTES = BN * 64;
+    constexpr int WAVES_CH = 2, WAVES_PX = 4;
+    constexpr int CH_T = BN / WAVES_CH / 32;           // 2 or 4
+    constexpr int PX_T = TH2 / WAVES_PX;               // 2 image rows per wave
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Xs = smem;                          // [2][XBYTES]
+    unsigned char *Ws = smem + 2 * XBYTES;             // [2][WBYTES]
+    float *SS = reinterpret_cast<float *>(Ws + 2 * WBYTES);   // scale[BN], shift[BN] of this channel tile
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wch = (wave % WAVES_CH) * (CH_T * 32);
+    const int wrow = (wave / WAVES_CH) * PX_T;
+
+    const int n_tiles_n = CoutP / BN;
+    const int swz = xcd_swizzle2(blockIdx.x, gridDim.x);
+    const int tn = swz % n_tiles_n;
+    const int tsp = swz / n_tiles_n;
+    const int tx = tsp % tiles_x, ty = tsp / tiles_x;
+    const int oy0 = ty * TH2, ox0 = tx * TW, n0 = tn * BN;
+
+    // ---- per-lane staging sources (element offsets into `in`; -1 = zero page)
+    int xoff[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int chunk = wave + 8 * i;
+        const int q = chunk * 16 + (lane >> 2);
+        const int slot = (lane & 3) ^ ((q >> 2) & 3);  // logical 16-byte slot this lane's bytes hold
+        int off = -1;
+        if (chunk < XCH && q < NPIX) {
+            const int py = q / PW, px = q - py * PW;
+            const int iy = oy0 - PAD + py, ix = ox0 - PAD + px;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) off = (iy * W + ix) * Cin + slot * 8;
+        }
+        xoff[i] = off;
+    }
+    int woff[WPW];
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int r = (wave * WPW + i) * 16 + (lane >> 2);
+        const int slot = (lane & 3) ^ ((r >> 2) & 3);
+        woff[i] = (n0 + r) * CC + slot * 8;
+    }
+
+#define ISSUE_X(chunk_, buf_)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < XPW; ++i) {                                                  \
+        if (wave + 8 * i < XCH) {                                                                      \
+            const half_t *src = xoff[i] >= 0 ? in + (size_t)xoff[i] + (chunk_)*CC : zero_page + (lane & 3) * 8; \
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                        \
+                                             (lds_void_t *)(Xs + (buf_)*XBYTES + (wave + 8 * i) * 1024), 16, 0, 0); \
+        }                                                                                              \
+    }
+#define ISSUE_W(step_, buf_)                                                                           \
+    _Pragma("unroll") for (int i = 0; i < WPW; ++i) {                                                  \
+        const half_t *src = wpk + (size_t)(step_)*CoutP * CC + woff[i];                                \
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                            \
+                                         (lds_void_t *)(Ws + (buf_)*WBYTES + (wave * WPW + i) * 1024), 16, 0, 0); \
+    }
+
+    f32x16_t acc[CH_T][PX_T];
+#pragma unroll
+    for (int a = 0; a < CH_T; ++a)
+#pragma unroll
+        for (int b = 0; b < PX_T; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int NS = (Cin / CC) * T;
+    ISSUE_X(0, 0)
+    ISSUE_W(0, 0)
+    if (tid < BN) { SS[tid] = scale[n0 + tid]; SS[BN + tid] = shift[n0 + tid]; }
+    __syncthreads();   // hipcc drains vmcnt(0) before the barrier while LDS-DMA is in flight
+
+    const int lrow = lane & 31, lhi = lane >> 5;
+    // fragment read offsets that do not depend on the step
+    int a_off[CH_T];   // bytes: row * 64, plus the row's swizzle term kept separately
+    int a_sw[CH_T];
+#pragma unroll
+    for (int ct = 0; ct < CH_T; ++ct) {
+        const int r = wch + ct * 32 + lrow;
+        a_off[ct] = r * 64;
+        a_sw[ct] = (r >> 2) & 3;
+    }
+
+    int chunk = 0, tap = 0;
+    for (int s = 0; s < NS; ++s) {
+        const int wb = s & 1, xb = chunk & 1;
+        int ntap = tap + 1, nchunk = chunk;
+        if (ntap == T) { ntap = 0; ++nchunk; }
+        const bool has_next = (s + 1 < NS);
+        const bool new_chunk = has_next && (ntap == 0);
+        if (has_next) { ISSUE_W(s + 1, wb ^ 1) }
+        if (new_chunk) { ISSUE_X(nchunk, xb ^ 1) }
+
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const unsigned char *xs = Xs + xb * XBYTES;
+        const unsigned char *ws = Ws + wb * WBYTES;
+        int b_off[PX_T], b_sw[PX_T];
+#pragma unroll
+        for (int pr = 0; pr < PX_T; ++pr) {
+            const int q = (wrow + pr + ky) * PW + lrow + kx;
+            b_off[pr] = q * 64;
+            b_sw[pr] = (q >> 2) & 3;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int slot = kk * 2 + lhi;
+            h8_t a[CH_T], b[PX_T];
+#pragma unroll
+            for (int ct = 0; ct < CH_T; ++ct)
+                a[ct] = *reinterpret_cast<const h8_t *>(ws + a_off[ct] + ((slot ^ a_sw[ct]) << 4));
+#pragma unroll
+            for (int pr = 0; pr < PX_T; ++pr)
+                b[pr] = *reinterpret_cast<const h8_t *>(xs + b_off[pr] + ((slot ^ b_sw[pr]) << 4));
+#pragma unroll
+            for (int ct = 0; ct < CH_T; ++ct)
+#pragma unroll
+                for (int pr = 0; pr < PX_T; ++pr)
+                    acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ct], b[pr], acc[ct][pr], 0, 0, 0);
+        }
+        __syncthreads();
+        tap = ntap;
+        chunk = nchunk;
+    }
+#undef ISSUE_X
+#undef ISSUE_W
+
+    // epilogue: scale/shift come from LDS, the residual quads of one 32-channel block are fetched
+    // together (4 loads in flight) before they are used.
+#pragma unroll
+    for (int pr = 0; pr < PX_T; ++pr) {
+        const int oy = oy0 + wrow + pr, ox = ox0 + lrow;
+        if (oy < Ho && ox < Wo) {
+            const size_t pix = (size_t)oy * Wo + ox;
+#pragma unroll
+            for (int ct = 0; ct < CH_T; ++ct) {
+                const int cl = wch + ct * 32 + 4 * lhi;        // channel within the tile, + 8q
+                h4_t rq[4];
+                if (HAS_RES) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        rq[q] = *reinterpret_cast<const h4_t *>(res + pix * CoutP + n0 + cl + 8 * q);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 sc = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
+                    const float4 sh = *reinterpret_cast<const float4 *>(SS + BN + cl + 8 * q);
+                    float v0 = acc[ct][pr][4 * q + 0] * sc.x + sh.x;
+                    float v1 = acc[ct][pr][4 * q + 1] * sc.y + sh.y;
+                    float v2 = acc[ct][pr][4 * q + 2] * sc.z + sh.z;
+                    float v3 = acc[ct][pr][4 * q + 3] * sc.w + sh.w;
+                    if (HAS_RES) {
+                        v0 += (float)rq[q][0]; v1 += (float)rq[q][1]; v2 += (float)rq[q][2]; v3 += (float)rq[q][3];
+                    }
+                    if (relu) {
+                        v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
+                    }
+                    const size_t o = pix * CoutP + n0 + cl + 8 * q;
+                    if (OUT_F32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(outv) + o) = make_float4(v0, v1, v2, v3);
+                    else *reinterpret_cast<h4_t *>(reinterpret_cast<half_t *>(outv) + o) = cvt4b(v0, v1, v2, v3);
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int BN, bool OUT_F32, bool HAS_RES>
+static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
+                            const float *scale, const float *shift, int CoutP, int relu, const half_t *res,
+                            void *out, int Ho, int Wo, const half_t *zero_page)
+{
+    constexpr int PH = TH2 - 1 + KS, PW = TW - 1 + KS;
+    constexpr int XCH = (PH * PW + 15) / 16;
+    constexpr size_t lds = (size_t)2 * XCH * 1024 + (size_t)2 * BN * 64 + (size_t)2 * BN * sizeof(float);
+    static bool attr_done = false;
+    auto kern = conv_igemm2_kernel<KS, BN, OUT_F32, HAS_RES>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH2 - 1) / TH2;
+    const int grid = tiles_x * tiles_y * (CoutP / BN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT2), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, res, out,
+                       Ho, Wo, tiles_x, zero_page);
+}
+
+// returns false when the (ks, Cout tile) combination has no v2 instantiation
+bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
+                        const float *scale, const float *shift, int CoutP, int ks, int relu,
+                        const half_t *residual, void *out, int out_f32, int Ho, int Wo, const half_t *zero_page)
+{
+#define SFD2_IG2(KS_, BN_, F32_)                                                                                        \
+    do {                                                                                                                \
+        if (residual) launch_igemm2_t<KS_, BN_, F32_, true>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); \
+        else launch_igemm2_t<KS_, BN_, F32_, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);         \
+    } while (0)
+    const int bn = (CoutP % 256 == 0) ? 256 : (CoutP % 128 == 0 ? 128 : 64);
+    if (bn == 64) return false;
+    if (ks == 3 && !out_f32) { if (bn == 256) SFD2_IG2(3, 256, false); else SFD2_IG2(3, 128, false); return true; }
+    if (ks == 1 && !out_f32) { if (bn == 256) SFD2_IG2(1, 256, false); else SFD2_IG2(1, 128, false); return true; }
+    if (ks == 1 && out_f32) { if (bn == 256) SFD2_IG2(1, 256, true); else SFD2_IG2(1, 128, true); return true; }
+#undef SFD2_IG2
+    return false;
+}

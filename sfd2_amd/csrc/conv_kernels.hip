@@ -14,6 +14,7 @@
 // a lane then owns 4 consecutive output channels of one pixel per register quad, i.e.
 // 8-byte NHWC stores.
 #include "sfd2_internal.h"
+#include <stdlib.h>
 
 #define TW 32     // output tile width  (one 32-wide MFMA column block = 32 consecutive pixels of a row)
 #define TH 4      // output tile height
@@ -43,7 +44,7 @@ __device__ __forceinline__ h4_t cvt4(float a, float b, float c, float d)
 // and re-used by all KS*KS taps; one [BN][32] filter tile is staged per (chunk, tap) step.
 // Both are double-buffered through registers (global loads issued before the MFMAs of the
 // current step, LDS stores after), one barrier per step.
-template <int KS, int STRIDE, int BN, bool OUT_F32>
+template <int KS, int STRIDE, int BN, bool OUT_F32, bool HAS_RES>
 __global__ __launch_bounds__(NT, (STRIDE == 1 ? 2 : 1))
 void conv_igemm_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                        const half_t *__restrict__ wpk, const float *__restrict__ scale,
@@ -67,6 +68,7 @@ void conv_igemm_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half_t *Xs = reinterpret_cast<half_t *>(smem);     // [2][NPIX][PIXP]
     half_t *Ws = Xs + 2 * NPIX * PIXP;                 // [2][BN][PIXP]
+    float *SS = reinterpret_cast<float *>(Ws + 2 * BN * PIXP);   // scale[BN], shift[BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wch = (wave % WAVES_CH) * (CH_T * 32);
@@ -132,6 +134,7 @@ void conv_igemm_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     LOAD_W(0)
     STORE_X(0)
     STORE_W(0)
+    if (tid < BN) { SS[tid] = scale[n0 + tid]; SS[BN + tid] = shift[n0 + tid]; }
     __syncthreads();
 
     const int lrow = lane & 31, lk = (lane >> 5) * 8;
@@ -178,51 +181,54 @@ void conv_igemm_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #undef STORE_W
 
     // epilogue: y = acc * scale[c] + shift[c] (+ residual) (ReLU); lane owns pixel (lane&31) and, per
-    // register quad q, channels 8q + 4*(lane>>5) .. +3 of each 32-channel block.
+    // register quad q, channels 8q + 4*(lane>>5) .. +3 of each 32-channel block.  scale/shift come
+    // from LDS; the residual quads of one block are fetched together before use.
 #pragma unroll
     for (int pr = 0; pr < PX_T; ++pr) {
         const int oy = oy0 + wrow + pr, ox = ox0 + lrow;
         if (oy < Ho && ox < Wo) {
             const size_t pix = (size_t)oy * Wo + ox;
 #pragma unroll
-            for (int ct = 0; ct < CH_T; ++ct)
+            for (int ct = 0; ct < CH_T; ++ct) {
+                const int cl = wch + ct * 32 + 4 * (lane >> 5);
+                h4_t rq[4];
+                if (HAS_RES) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        rq[q] = *reinterpret_cast<const h4_t *>(res + pix * CoutP + n0 + cl + 8 * q);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int c0 = n0 + wch + ct * 32 + 8 * q + 4 * (lane >> 5);
-                    const float4 sc = *reinterpret_cast<const float4 *>(scale + c0);
-                    const float4 sh = *reinterpret_cast<const float4 *>(shift + c0);
+                    const float4 sc = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
+                    const float4 sh = *reinterpret_cast<const float4 *>(SS + BN + cl + 8 * q);
                     float v0 = acc[ct][pr][4 * q + 0] * sc.x + sh.x;
                     float v1 = acc[ct][pr][4 * q + 1] * sc.y + sh.y;
                     float v2 = acc[ct][pr][4 * q + 2] * sc.z + sh.z;
                     float v3 = acc[ct][pr][4 * q + 3] * sc.w + sh.w;
-                    if (res) {
-                        const h4_t r = *reinterpret_cast<const h4_t *>(res + pix * CoutP + c0);
-                        v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+                    if (HAS_RES) {
+                        v0 += (float)rq[q][0]; v1 += (float)rq[q][1]; v2 += (float)rq[q][2]; v3 += (float)rq[q][3];
                     }
                     if (relu) {
                         v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
                     }
-                    if (OUT_F32) {
-                        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(outv) + pix * CoutP + c0) =
-                            make_float4(v0, v1, v2, v3);
-                    } else {
-                        *reinterpret_cast<h4_t *>(reinterpret_cast<half_t *>(outv) + pix * CoutP + c0) =
-                            cvt4(v0, v1, v2, v3);
-                    }
+                    const size_t o = pix * CoutP + n0 + cl + 8 * q;
+                    if (OUT_F32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(outv) + o) = make_float4(v0, v1, v2, v3);
+                    else *reinterpret_cast<h4_t *>(reinterpret_cast<half_t *>(outv) + o) = cvt4(v0, v1, v2, v3);
                 }
+            }
         }
     }
 }
 
-template <int KS, int STRIDE, int BN, bool OUT_F32>
+template <int KS, int STRIDE, int BN, bool OUT_F32, bool HAS_RES>
 static void launch_igemm_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                            const float *scale, const float *shift, int CoutP, int relu, const half_t *res,
                            void *out, int Ho, int Wo)
 {
     constexpr int PH = (TH - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
-    constexpr size_t lds = (size_t)(2 * PH * PW + 2 * BN) * PIXP * sizeof(half_t);
+    constexpr size_t lds = (size_t)(2 * PH * PW + 2 * BN) * PIXP * sizeof(half_t) + (size_t)2 * BN * sizeof(float);
     static bool attr_done = false;
-    auto kern = conv_igemm_kernel<KS, STRIDE, BN, OUT_F32>;
+    auto kern = conv_igemm_kernel<KS, STRIDE, BN, OUT_F32, HAS_RES>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
@@ -233,12 +239,24 @@ static void launch_igemm_t(hipStream_t st, const half_t *in, int H, int W, int C
                        Ho, Wo, tiles_x);
 }
 
+bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
+                        const float *scale, const float *shift, int CoutP, int ks, int relu,
+                        const half_t *residual, void *out, int out_f32, int Ho, int Wo, const half_t *zero_page);
+
 void launch_conv_igemm(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                        const float *scale, const float *shift, int CoutP, int ks, int stride, int relu,
-                       const half_t *residual, void *out, int out_f32, int Ho, int Wo)
+                       const half_t *residual, void *out, int out_f32, int Ho, int Wo, const half_t *zero_page)
 {
-#define SFD2_IGEMM(KS_, ST_, BN_, F32_) \
-    launch_igemm_t<KS_, ST_, BN_, F32_>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo)
+    // second-generation kernel (conv2_kernels.hip) for the stride-1 layers; SFD2_CONV_V1=1 forces the first
+    static const bool force_v1 = getenv("SFD2_CONV_V1") != nullptr;
+    if (!force_v1 && stride == 1 && zero_page &&
+        launch_conv_igemm2(st, in, H, W, Cin, wpk, scale, shift, CoutP, ks, relu, residual, out, out_f32, Ho, Wo, zero_page))
+        return;
+#define SFD2_IGEMM(KS_, ST_, BN_, F32_)                                                                               \
+    do {                                                                                                              \
+        if (residual) launch_igemm_t<KS_, ST_, BN_, F32_, true>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo); \
+        else launch_igemm_t<KS_, ST_, BN_, F32_, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo);         \
+    } while (0)
     const int bn = (CoutP % 256 == 0) ? 256 : (CoutP % 128 == 0 ? 128 : 64);
     if (ks == 3 && stride == 1 && !out_f32) {
         if (bn == 256) SFD2_IGEMM(3, 1, 256, false);

@@ -63,7 +63,7 @@ struct sfd2_ctx {
     bool weights_loaded = false;
     // weights
     ConvW c1a, c1b, c2a, c2b, c3a, c3b, rb1[3], rb2[3], rb3[3], pa0, pa3, da0, da3, pb, db;
-    DevBuf sta_w, sta_b;
+    DevBuf sta_w, sta_b, zero_page;
     // geometry of the current workspace
     int H = 0, W = 0, H2 = 0, W2 = 0, H4 = 0, W4 = 0, H8 = 0, W8 = 0;
     // activations (NHWC fp16 unless noted)
@@ -138,6 +138,8 @@ extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
     HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; ++i) HIPCHECK(hipEventCreate(&c->ev[i]));
     HIPCHECK(hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming));
+    HIPCHECK(c->zero_page.ensure(256));
+    HIPCHECK(hipMemset(c->zero_page.p, 0, 256));
     *out = c;
     return 0;
 }
@@ -147,7 +149,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
+    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
                       &c->rt1[0], &c->rt1[1], &c->rt1[2], &c->rt2[0], &c->rt2[1], &c->rt2[2], &c->ro[0], &c->ro[1],
                       &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
                       &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->bnd, &c->sel, &c->sorted, &c->counters,
@@ -415,7 +417,8 @@ static void conv(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &in
                          px * L.cout_pad * (out_f32 ? 4.0 : 2.0) + (res ? px * L.cout_pad * 2.0 : 0.0);
     ProfScope ps(c, name, kn, flops, bytes);
     launch_conv_igemm(c->stream, in.as<half_t>(), H, W, L.cin, L.w.as<half_t>(), L.scale.as<float>(),
-                      L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu, res, out.p, out_f32, Ho, Wo);
+                      L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu, res, out.p, out_f32, Ho, Wo,
+                      c->zero_page.as<half_t>());
 }
 
 // ResSegNetV2.det up to the three head outputs (nets/sfd2.py:314-328, :340-345)

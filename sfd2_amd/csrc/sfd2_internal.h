@@ -24,7 +24,7 @@ void launch_conv1a(hipStream_t st, const float *img_chw, int H, int W, int norma
 void launch_conv_igemm(hipStream_t st, const half_t *in, int H, int W, int Cin,
                        const half_t *wpk, const float *scale, const float *shift, int Cout_pad,
                        int ks, int stride, int relu, const half_t *residual,
-                       void *out, int out_f32, int Ho, int Wo);
+                       void *out, int out_f32, int Ho, int Wo, const half_t *zero_page /*>= 64 B of zeros*/);
 
 // Grouped 3x3 conv, 256 channels, 32 groups of 8 (ResBlock.conv2) + folded BN + ReLU.
 //   wpk [16 pairs][5 steps][64 lanes][8] fp16 (block-diagonal 16x16 MFMA A fragments)
