@@ -15,7 +15,6 @@
 
 #define TW 32
 #define TH2 8
-#define CC 32
 #define NT2 512
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -35,7 +34,7 @@ __device__ __forceinline__ h4_t cvt4b(float a, float b, float c, float d)
     return r;
 }
 
-template <int KS, int BN, bool OUT_F32, bool HAS_RES>
+template <int KS, int BN, int CC, bool OUT_F32, bool HAS_RES>
 __global__ __launch_bounds__(NT2, 2)
 void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                         const half_t *__restrict__ wpk, const float *__restrict__ scale,
@@ -47,11 +46,15 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     constexpr int PAD = KS / 2;
     constexpr int PH = TH2 - 1 + KS, PW = TW - 1 + KS;
     constexpr int NPIX = PH * PW;
-    constexpr int XCH = (NPIX + 15) / 16;              // 1 KB chunks (16 pixel records) of one patch
+    constexpr int RB = CC * 2;                         // bytes per record (one pixel / one filter row of a K chunk)
+    constexpr int RPC = 1024 / RB;                     // records per 1 KB LDS-DMA chunk (16 or 8)
+    constexpr int SPR = RB / 16;                       // 16-byte slots per record (4 or 8)
+    constexpr int SWS = (CC == 32) ? 2 : 1;            // swizzle: slot ^= (record >> SWS) & (SPR - 1)
+    constexpr int XCH = (NPIX + RPC - 1) / RPC;        // 1 KB chunks of one patch
     constexpr int XPW = (XCH + 7) / 8;                 // chunks per wave
-    constexpr int WCH = BN / 16;                       // 1 KB chunks of one filter tile
-    constexpr int WPW = WCH / 8;                       // per wave (BN 128 -> 1, 256 -> 2)
-    constexpr int XBYTES = XCH * 1024, WBYTES = BN * 64;
+    constexpr int WCH = BN / RPC;                      // 1 KB chunks of one filter tile
+    constexpr int WPW = WCH / 8;                       // per wave
+    constexpr int XBYTES = XCH * 1024, WBYTES = BN * RB;
     constexpr int WAVES_CH = 2, WAVES_PX = 4;
     constexpr int CH_T = BN / WAVES_CH / 32;           // 2 or 4
     constexpr int PX_T = TH2 / WAVES_PX;               // 2 image rows per wave
@@ -78,8 +81,8 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
     for (int i = 0; i < XPW; ++i) {
         const int chunk = wave + 8 * i;
-        const int q = chunk * 16 + (lane >> 2);
-        const int slot = (lane & 3) ^ ((q >> 2) & 3);  // logical 16-byte slot this lane's bytes hold
+        const int q = chunk * RPC + lane / SPR;
+        const int slot = (lane % SPR) ^ ((q >> SWS) & (SPR - 1));  // logical 16-byte slot this lane's bytes hold
         int off = -1;
         if (chunk < XCH && q < NPIX) {
             const int py = q / PW, px = q - py * PW;
@@ -91,15 +94,15 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     int woff[WPW];
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-        const int r = (wave * WPW + i) * 16 + (lane >> 2);
-        const int slot = (lane & 3) ^ ((r >> 2) & 3);
+        const int r = (wave * WPW + i) * RPC + lane / SPR;
+        const int slot = (lane % SPR) ^ ((r >> SWS) & (SPR - 1));
         woff[i] = (n0 + r) * CC + slot * 8;
     }
 
 #define ISSUE_X(chunk_, buf_)                                                                          \
     _Pragma("unroll") for (int i = 0; i < XPW; ++i) {                                                  \
         if (wave + 8 * i < XCH) {                                                                      \
-            const half_t *src = xoff[i] >= 0 ? in + (size_t)xoff[i] + (chunk_)*CC : zero_page + (lane & 3) * 8; \
+            const half_t *src = xoff[i] >= 0 ? in + (size_t)xoff[i] + (chunk_)*CC : zero_page + (lane % SPR) * 8; \
             __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                        \
                                              (lds_void_t *)(Xs + (buf_)*XBYTES + (wave + 8 * i) * 1024), 16, 0, 0); \
         }                                                                                              \
@@ -132,8 +135,8 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
     for (int ct = 0; ct < CH_T; ++ct) {
         const int r = wch + ct * 32 + lrow;
-        a_off[ct] = r * 64;
-        a_sw[ct] = (r >> 2) & 3;
+        a_off[ct] = r * RB;
+        a_sw[ct] = (r >> SWS) & (SPR - 1);
     }
 
     int chunk = 0, tap = 0;
@@ -153,24 +156,41 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
         for (int pr = 0; pr < PX_T; ++pr) {
             const int q = (wrow + pr + ky) * PW + lrow + kx;
-            b_off[pr] = q * 64;
-            b_sw[pr] = (q >> 2) & 3;
+            b_off[pr] = q * RB;
+            b_sw[pr] = (q >> SWS) & (SPR - 1);
         }
+        // software-pipelined fragment reads: the ds_reads of k-slice kk+1 are in flight while the
+        // MFMAs of slice kk issue (two register sets, static indices)
+        constexpr int NK = CC / 16;
+        h8_t fa[2][CH_T], fb[2][PX_T];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int slot = kk * 2 + lhi;
-            h8_t a[CH_T], b[PX_T];
+        for (int ct = 0; ct < CH_T; ++ct)
+            fa[0][ct] = *reinterpret_cast<const h8_t *>(ws + a_off[ct] + ((lhi ^ a_sw[ct]) << 4));
 #pragma unroll
-            for (int ct = 0; ct < CH_T; ++ct)
-                a[ct] = *reinterpret_cast<const h8_t *>(ws + a_off[ct] + ((slot ^ a_sw[ct]) << 4));
+        for (int pr = 0; pr < PX_T; ++pr)
+            fb[0][pr] = *reinterpret_cast<const h8_t *>(xs + b_off[pr] + ((lhi ^ b_sw[pr]) << 4));
+        // pin the issue order (hipcc otherwise sinks every read next to its first use and waits
+        // lgkmcnt(0) in front of each MFMA group): reads of slice kk+1, then the MFMAs of slice kk
+        __builtin_amdgcn_sched_group_barrier(0x100, CH_T + PX_T, 0);
 #pragma unroll
-            for (int pr = 0; pr < PX_T; ++pr)
-                b[pr] = *reinterpret_cast<const h8_t *>(xs + b_off[pr] + ((slot ^ b_sw[pr]) << 4));
+        for (int kk = 0; kk < NK; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < NK) {
+                const int slot = (kk + 1) * 2 + lhi;
+#pragma unroll
+                for (int ct = 0; ct < CH_T; ++ct)
+                    fa[nxt][ct] = *reinterpret_cast<const h8_t *>(ws + a_off[ct] + ((slot ^ a_sw[ct]) << 4));
+#pragma unroll
+                for (int pr = 0; pr < PX_T; ++pr)
+                    fb[nxt][pr] = *reinterpret_cast<const h8_t *>(xs + b_off[pr] + ((slot ^ b_sw[pr]) << 4));
+            }
 #pragma unroll
             for (int ct = 0; ct < CH_T; ++ct)
 #pragma unroll
                 for (int pr = 0; pr < PX_T; ++pr)
-                    acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ct], b[pr], acc[ct][pr], 0, 0, 0);
+                    acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][ct], fb[cur][pr], acc[ct][pr], 0, 0, 0);
+            if (kk + 1 < NK) __builtin_amdgcn_sched_group_barrier(0x100, CH_T + PX_T, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, CH_T * PX_T, 0);
         }
         __syncthreads();
         tap = ntap;
@@ -218,16 +238,17 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     }
 }
 
-template <int KS, int BN, bool OUT_F32, bool HAS_RES>
+template <int KS, int BN, int CC, bool OUT_F32, bool HAS_RES>
 static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                             const float *scale, const float *shift, int CoutP, int relu, const half_t *res,
                             void *out, int Ho, int Wo, const half_t *zero_page)
 {
     constexpr int PH = TH2 - 1 + KS, PW = TW - 1 + KS;
-    constexpr int XCH = (PH * PW + 15) / 16;
-    constexpr size_t lds = (size_t)2 * XCH * 1024 + (size_t)2 * BN * 64 + (size_t)2 * BN * sizeof(float);
+    constexpr int RPC = 1024 / (CC * 2);
+    constexpr int XCH = (PH * PW + RPC - 1) / RPC;
+    constexpr size_t lds = (size_t)2 * XCH * 1024 + (size_t)2 * BN * CC * 2 + (size_t)2 * BN * sizeof(float);
     static bool attr_done = false;
-    auto kern = conv_igemm2_kernel<KS, BN, OUT_F32, HAS_RES>;
+    auto kern = conv_igemm2_kernel<KS, BN, CC, OUT_F32, HAS_RES>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
@@ -238,21 +259,39 @@ static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int 
                        Ho, Wo, tiles_x, zero_page);
 }
 
+// K-chunk width the v2 kernel wants the filters packed with (0 = layer is not served by v2)
+int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin)
+{
+    if (stride != 1 || CoutP % 128 != 0) return 0;
+    (void)ks;
+    // 256-channel tiles: 64-wide K chunks (one block per CU either way, half the barriers);
+    // 128-channel tiles: 32-wide chunks keep the LDS footprint at 60 KB -> two blocks per CU
+    if (CoutP % 256 == 0) return (Cin % 64 == 0) ? 64 : 32;
+    return 32;
+}
+
 // returns false when the (ks, Cout tile) combination has no v2 instantiation
 bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                         const float *scale, const float *shift, int CoutP, int ks, int relu,
                         const half_t *residual, void *out, int out_f32, int Ho, int Wo, const half_t *zero_page)
 {
-#define SFD2_IG2(KS_, BN_, F32_)                                                                                        \
+#define SFD2_IG2B(KS_, BN_, CC_, F32_)                                                                                   \
     do {                                                                                                                \
-        if (residual) launch_igemm2_t<KS_, BN_, F32_, true>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); \
-        else launch_igemm2_t<KS_, BN_, F32_, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);         \
+        if (residual) launch_igemm2_t<KS_, BN_, CC_, F32_, true>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); \
+        else launch_igemm2_t<KS_, BN_, CC_, F32_, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);         \
     } while (0)
-    const int bn = (CoutP % 256 == 0) ? 256 : (CoutP % 128 == 0 ? 128 : 64);
-    if (bn == 64) return false;
+#define SFD2_IG2(KS_, BN_, F32_)                                         \
+    do {                                                                 \
+        if (cc == 64) SFD2_IG2B(KS_, BN_, 64, F32_);                     \
+        else SFD2_IG2B(KS_, BN_, 32, F32_);                              \
+    } while (0)
+    const int cc = conv_igemm2_chunk(ks, 1, CoutP, Cin);
+    if (cc == 0) return false;
+    const int bn = (CoutP % 256 == 0) ? 256 : 128;
     if (ks == 3 && !out_f32) { if (bn == 256) SFD2_IG2(3, 256, false); else SFD2_IG2(3, 128, false); return true; }
     if (ks == 1 && !out_f32) { if (bn == 256) SFD2_IG2(1, 256, false); else SFD2_IG2(1, 128, false); return true; }
     if (ks == 1 && out_f32) { if (bn == 256) SFD2_IG2(1, 256, true); else SFD2_IG2(1, 128, true); return true; }
 #undef SFD2_IG2
+#undef SFD2_IG2B
     return false;
 }

@@ -225,14 +225,15 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
         return fail("bad shape for " + conv + ".weight");
     const int cout_pad = (cout + 63) / 64 * 64;
     L.cin = cin; L.cout = cout; L.cout_pad = cout_pad; L.ks = ks; L.stride = stride;
-    const int T = ks * ks, nch = cin / 32;
-    std::vector<half_t> pk((size_t)nch * T * cout_pad * 32, (half_t)0.0f);
+    const int cc = conv_igemm_chunk(ks, stride, cout_pad, cin);   // 32 or 64 input channels per packed tile
+    const int T = ks * ks, nch = cin / cc;
+    std::vector<half_t> pk((size_t)nch * T * cout_pad * cc, (half_t)0.0f);
     for (int ch = 0; ch < nch; ++ch)
         for (int t = 0; t < T; ++t)
             for (int oc = 0; oc < cout; ++oc)
-                for (int k = 0; k < 32; ++k) {
-                    const float v = w->d[(((size_t)oc * cin + ch * 32 + k) * ks + t / ks) * ks + t % ks];
-                    pk[(((size_t)ch * T + t) * cout_pad + oc) * 32 + k] = (half_t)v;
+                for (int k = 0; k < cc; ++k) {
+                    const float v = w->d[(((size_t)oc * cin + ch * cc + k) * ks + t / ks) * ks + t % ks];
+                    pk[(((size_t)ch * T + t) * cout_pad + oc) * cc + k] = (half_t)v;
                 }
     std::vector<float> sc, sh;
     if (fold_scale_shift(m, conv, bn, cout, cout_pad, sc, sh)) return -1;

@@ -19,12 +19,15 @@ void launch_conv1a(hipStream_t st, const float *img_chw, int H, int W, int norma
                    half_t *out /*[H][W][64]*/);
 
 // Implicit-GEMM conv on MFMA (3x3 or 1x1, stride 1 or 2, Cin % 32 == 0, Cout_pad % 64 == 0).
-//   in  [H][W][Cin] fp16,  wpk [Cin/32][ks*ks][Cout_pad][32] fp16,  scale/shift [Cout_pad]
+//   in  [H][W][Cin] fp16,  wpk [Cin/cc][ks*ks][Cout_pad][cc] fp16 (cc = conv_igemm_chunk),  scale/shift [Cout_pad]
 //   out [Ho][Wo][Cout_pad] fp16 (relu / residual optional) or fp32 (out_f32)
 void launch_conv_igemm(hipStream_t st, const half_t *in, int H, int W, int Cin,
                        const half_t *wpk, const float *scale, const float *shift, int Cout_pad,
                        int ks, int stride, int relu, const half_t *residual,
                        void *out, int out_f32, int Ho, int Wo, const half_t *zero_page /*>= 64 B of zeros*/);
+
+// input channels per packed filter tile for this layer: wpk is [Cin/cc][ks*ks][Cout_pad][cc]
+int conv_igemm_chunk(int ks, int stride, int Cout_pad, int Cin);
 
 // Grouped 3x3 conv, 256 channels, 32 groups of 8 (ResBlock.conv2) + folded BN + ReLU.
 //   wpk [16 pairs][5 steps][64 lanes][8] fp16 (block-diagonal 16x16 MFMA A fragments)

@@ -64,8 +64,15 @@ def _compare_extract(got, want, min_iou, desc_tol):
     iou = len(common) / max(1, len(set(a) | set(b)))
     assert iou >= min_iou, iou
     ia = np.array([a[k] for k in common]); ib = np.array([b[k] for k in common])
-    ds = np.abs(got["scores"][ia] - want["scores"][ib])
-    assert (ds <= 8e-2 * want["scores"][ib] + 1e-4).all(), ds.max()
+    gs, ws = got["scores"][ia], want["scores"][ib]
+    bad = np.abs(gs - ws) > 8e-2 * ws + 1e-4
+    # score = detector score x stability in {0.1, 0.5, 1.0}: an fp16-level arg-max flip of the 3-class
+    # stability head changes a key point's score by exactly one of these ratios -- rare, and the
+    # only admissible cause of a large score difference
+    assert bad.mean() <= 0.01, bad.mean()
+    ratio = gs[bad] / ws[bad]
+    flips = np.array([0.1, 0.2, 0.5, 2.0, 5.0, 10.0])
+    assert all(np.min(np.abs(r / flips - 1.0)) < 0.09 for r in ratio), ratio
     dd = np.abs(got["descriptors"][ia] - np.asarray(want["descriptors"], dtype=np.float64)[ib]).max()
     assert dd <= desc_tol, dd
     return iou
