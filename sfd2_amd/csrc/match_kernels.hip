@@ -14,6 +14,7 @@
 // operands swapped.
 #include "sfd2_internal.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define NT 256
 #define KD 128        // descriptor dimension (nets/sfd2.py:260 outdim=128)
@@ -175,7 +176,119 @@ void match_top2_kernel(const MatchJob *__restrict__ jobs, int splits)
     }
 }
 
-void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int max_nb, int splits, int use_lo)
+// ---------------------------------------------------------------- second generation (fp16 operands)
+// 64 queries per wave (each candidate fragment read from LDS feeds two MFMAs), candidates staged by
+// direct-to-LDS copies (global_load_lds_dwordx4) into a lane-linear image of 256-byte rows whose
+// 16-byte slots are XOR-swizzled with (row & 15); top-2 or top-1 tracking chosen at compile time.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <bool NEED2>
+__global__ __launch_bounds__(NT, 2)
+void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const half_t *__restrict__ zero_page)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][TA][256 B]
+    const MatchJob job = jobs[blockIdx.z];
+    const int na = job.na, nb = job.nb;
+    const int i_base = blockIdx.x * 256;
+    if (i_base >= nb) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lcol = lane & 31, lhi = lane >> 5;
+
+    int chunk = (na + splits - 1) / splits;
+    chunk = (chunk + 31) & ~31;
+    const int ja0 = blockIdx.y * chunk;
+    int ja1 = ja0 + chunk;
+    if (ja1 > na) ja1 = na;
+
+    h8_t bq[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int qi = i_base + wave * 64 + t * 32 + lcol;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            h8_t z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (half_t)0.0f;
+            bq[t][ks] = z;
+            if (qi < nb) bq[t][ks] = *reinterpret_cast<const h8_t *>(job.b_hi + (size_t)qi * KD + ks * 16 + lhi * 8);
+        }
+    }
+    float b1[2] = {-INFINITY, -INFINITY}, b2[2] = {-INFINITY, -INFINITY};
+    int i1[2] = {0, 0};
+
+    if (ja0 < ja1) {
+        const int nst = (ja1 - ja0 + TA - 1) / TA;
+        // staging: 16 one-KB chunks (4 rows each) per stage, 4 per wave
+        const int srow = lane >> 4;                                  // row within the chunk
+#define ISSUE_A(stage_, buf_)                                                                            \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                      \
+        const int row = (wave * 4 + c) * 4 + srow;                                                       \
+        const int slot = (lane & 15) ^ (row & 15);                                                       \
+        const int ja = ja0 + (stage_)*TA + row;                                                          \
+        const half_t *src = ja < ja1 ? job.a_hi + (size_t)ja * KD + slot * 8 : zero_page + (lane & 3) * 8; \
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                              \
+                                         (lds_void_t *)(smem + (buf_)*TA * 256 + (wave * 4 + c) * 1024), 16, 0, 0); \
+    }
+        ISSUE_A(0, 0)
+        __syncthreads();
+        for (int s = 0; s < nst; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nst) { ISSUE_A(s + 1, buf ^ 1) }
+#pragma unroll
+            for (int sub = 0; sub < TA / 32; ++sub) {
+                f32x16_t acc0, acc1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+                const int row = sub * 32 + lcol;
+                const unsigned char *arow = smem + (buf * TA + row) * 256;
+                const int sw = row & 15;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const h8_t a = *reinterpret_cast<const h8_t *>(arow + (((ks * 2 + lhi) ^ sw) << 4));
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[0][ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[1][ks], acc1, 0, 0, 0);
+                }
+                const int jbase = ja0 + s * TA + sub * 32 + 4 * lhi;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = jbase + (r & 3) + 8 * (r >> 2);
+                    const bool in = j < ja1;
+                    const float v0 = in ? acc0[r] : -INFINITY, v1 = in ? acc1[r] : -INFINITY;
+                    if (NEED2) {
+                        top2_update(v0, j, b1[0], b2[0], i1[0]);
+                        top2_update(v1, j, b1[1], b2[1], i1[1]);
+                    } else {
+                        i1[0] = v0 > b1[0] ? j : i1[0]; b1[0] = fmaxf(b1[0], v0);
+                        i1[1] = v1 > b1[1] ? j : i1[1]; b1[1] = fmaxf(b1[1], v1);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+#undef ISSUE_A
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float c1 = __shfl_xor(b1[t], 32), c2 = __shfl_xor(b2[t], 32);
+        const int j1 = __shfl_xor(i1[t], 32);
+        float n1v, n2v;
+        int n1i;
+        if (c1 > b1[t] || (c1 == b1[t] && j1 < i1[t])) { n1v = c1; n1i = j1; n2v = fmaxf(b1[t], c2); }
+        else { n1v = b1[t]; n1i = i1[t]; n2v = fmaxf(b2[t], c1); }
+        const int qi = i_base + wave * 64 + t * 32 + lcol;
+        if (lane < 32 && qi < nb) {
+            const size_t o = (size_t)blockIdx.y * nb + qi;
+            job.part_v1[o] = n1v;
+            job.part_v2[o] = NEED2 ? n2v : -INFINITY;
+            job.part_i1[o] = n1i;
+        }
+    }
+}
+
+void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int max_nb, int splits, int use_lo,
+                       int need_top2, const half_t *zero_page)
 {
     if (njobs <= 0 || max_nb <= 0) return;
     static bool attr_done = false;
@@ -184,6 +297,13 @@ void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int 
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_hi));
         attr_done = true;
+    }
+    if (!use_lo && zero_page && getenv("SFD2_MATCH_V1") == nullptr) {
+        const dim3 grid((max_nb + 255) / 256, splits, njobs);
+        const size_t lds = (size_t)2 * TA * 256;
+        if (need_top2) hipLaunchKernelGGL(match_top2_v2_kernel<true>, grid, dim3(NT), lds, st, jobs_dev, splits, zero_page);
+        else hipLaunchKernelGGL(match_top2_v2_kernel<false>, grid, dim3(NT), lds, st, jobs_dev, splits, zero_page);
+        return;
     }
     const dim3 grid((max_nb + 127) / 128, splits, njobs);
     if (use_lo) hipLaunchKernelGGL(match_top2_kernel<true>, grid, dim3(NT), 2 * lds_hi, st, jobs_dev, splits);

@@ -4,6 +4,7 @@
 #include "sfd2_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -800,11 +801,12 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     if (!q->on_device) stage_bytes += (((size_t)n0 * dim * elt_size(q->dtype)) + 255) & ~(size_t)255;
     const int max_n = std::max(n0, max_n1);
     // splits: enough blocks to fill 256 CUs twice, never finer than 32 candidates
-    const int blocks_per_job = (max_n + 127) / 128;
+    const int blocks_per_job = (max_n + 255) / 256;
     int splits = (512 + 2 * k * blocks_per_job - 1) / (2 * k * blocks_per_job);
     splits = std::max(1, std::min(splits, 16));
     const int min_n = std::max(1, std::min(n0, max_n1 > 0 ? max_n1 : 1));
     splits = std::min(splits, std::max(1, (min_n + 31) / 32));
+    if (const char *e = getenv("SFD2_MATCH_SPLITS")) splits = std::max(1, std::min(16, atoi(e)));
 
     HIPCHECK(c->m_stage.ensure(std::max<size_t>(stage_bytes, 256)));
     HIPCHECK(c->m_hi0.ensure((size_t)n0 * 128 * 2));
@@ -879,7 +881,10 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
         ProfScope ps(c, "match_top2", need_lo ? "match_top2_kernel<x2>" : "match_top2_kernel",
                      2.0 * 2.0 * (double)n0 * (double)tot_n1 * 128.0 * (need_lo ? 3.0 : 1.0),
                      2.0 * 2.0 * ((double)k * n0 + (double)tot_n1) * 128.0);
-        launch_match_top2(c->stream, c->m_jobs.as<MatchJob>(), 2 * k, max_n, splits, need_lo);
+        const int need_top2 = (conf->flavour == SFD2_MATCH_ITLOC_NNR) ||
+                              (conf->flavour == SFD2_MATCH_HLOC && conf->ratio_threshold > 0.0f);
+        launch_match_top2(c->stream, c->m_jobs.as<MatchJob>(), 2 * k, max_n, splits, need_lo, need_top2,
+                          c->zero_page.as<half_t>());
     }
     {
         ProfScope ps(c, "match_finalize", "match_reduce+decide", 0.0, (double)tot_part * 12);

@@ -81,7 +81,8 @@ struct MatchJob {          // one direction of one pair
     float *part_v2;
     int *part_i1;
 };
-void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int max_nb, int splits, int use_lo);
+void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int max_nb, int splits, int use_lo,
+                       int need_top2, const half_t *zero_page);
 struct MatchFinal {
     const float *f_v1, *f_v2; const int *f_i1;   // forward partials [splits][n0]
     const float *r_v1, *r_v2; const int *r_i1;   // reverse partials [splits][n1]
