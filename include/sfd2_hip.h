@@ -86,6 +86,13 @@ void *sfd2_get_stream(sfd2_ctx *ctx);
  * Replaces: ResSegNetV2.__init__ / load_state_dict  (nets/sfd2.py:259-303). */
 int sfd2_load_weights(sfd2_ctx *ctx, const sfd2_tensor *tensors, int n);
 
+/* Arithmetic of the conv stack.  SFD2_PREC_F16 (default): fp16 MFMA operands, fp32 accumulate,
+ * fp16 activations -- the throughput mode.  SFD2_PREC_F32: exact fp32 on the f32-input MFMA with
+ * fp32 activations -- the parity mode (differs from the fp32 reference by summation order only). */
+#define SFD2_PREC_F16 0
+#define SFD2_PREC_F32 1
+int sfd2_set_precision(sfd2_ctx *ctx, int mode);
+
 /* ResSegNetV2.det (nets/sfd2.py:313-354).  x: [3][H][W] fp32, normalised image
  * (pass SFD2_FLAG_IMG_NORMALISED) or raw [0,1] RGB (normalised on the fly).
  * score [8*H8][8*W8], stability [H][W], desc [128][Hc][Wc] (L2-normalised), fp32.

@@ -52,7 +52,7 @@ EXPORTS = [
     "sfd2_load_weights", "sfd2_det", "sfd2_extract", "sfd2_extract_count", "sfd2_simple_nms",
     "sfd2_select_keypoints", "sfd2_sample_descriptors", "sfd2_heatmap", "sfd2_debug_activation",
     "sfd2_match", "sfd2_match_batch", "sfd2_get_timings", "sfd2_sync", "sfd2_set_profiling",
-    "sfd2_get_layer_timings",
+    "sfd2_get_layer_timings", "sfd2_set_precision",
 ]
 
 _lib = None
@@ -90,6 +90,7 @@ def load():
                                      ctypes.POINTER(MatchConf), vp, vp, ci, ci]
     lib.sfd2_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
     lib.sfd2_sync.argtypes = [vp]
+    lib.sfd2_set_precision.argtypes = [vp, ci]
     lib.sfd2_set_profiling.argtypes = [vp, ci]
     lib.sfd2_get_layer_timings.argtypes = [vp, ctypes.POINTER(LayerTiming), ci, pi]
     for name in EXPORTS:
@@ -164,6 +165,10 @@ class Context:
         check(self.lib.sfd2_get_timings(self.h, ctypes.byref(t)))
         return {"ms_total": t.ms_total, "ms_backbone": t.ms_backbone, "ms_post": t.ms_post,
                 "ms_match": t.ms_match, "n_candidates": t.n_candidates}
+
+    def set_precision(self, mode):
+        """'f16' (throughput mode, default) or 'f32' (strict parity mode)."""
+        check(self.lib.sfd2_set_precision(self.h, {'f16': 0, 'f32': 1}[mode]))
 
     def sync(self):
         check(self.lib.sfd2_sync(self.h))

@@ -12,6 +12,7 @@
 // Replaces nets/sfd2.py Conv2d+BatchNorm2d+ReLU modules: conv2a, conv3a, conv3b (:272-278), the
 // ResBlock 1x1 convs (:30-35), convPa.3 / convDa.0 / convDa.3 (:286-297), convPb / convDb (:299-300).
 #include "sfd2_internal.h"
+#include <stdlib.h>
 
 #define TW 32
 #define TH2 8
@@ -266,7 +267,8 @@ int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin)
     (void)ks;
     // 256-channel tiles: 64-wide K chunks (one block per CU either way, half the barriers);
     // 128-channel tiles: 32-wide chunks keep the LDS footprint at 60 KB -> two blocks per CU
-    if (CoutP % 256 == 0) return (Cin % 64 == 0) ? 64 : 32;
+    static const bool bn128 = getenv("SFD2_CONV_BN128") != nullptr;   // experiment: 128-channel tiles everywhere
+    if (CoutP % 256 == 0 && !bn128) return (Cin % 64 == 0) ? 64 : 32;
     return 32;
 }
 
@@ -287,7 +289,8 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
     } while (0)
     const int cc = conv_igemm2_chunk(ks, 1, CoutP, Cin);
     if (cc == 0) return false;
-    const int bn = (CoutP % 256 == 0) ? 256 : 128;
+    static const bool bn128 = getenv("SFD2_CONV_BN128") != nullptr;
+    const int bn = (CoutP % 256 == 0 && !bn128) ? 256 : 128;
     if (ks == 3 && !out_f32) { if (bn == 256) SFD2_IG2(3, 256, false); else SFD2_IG2(3, 128, false); return true; }
     if (ks == 1 && !out_f32) { if (bn == 256) SFD2_IG2(1, 256, false); else SFD2_IG2(1, 128, false); return true; }
     if (ks == 1 && out_f32) { if (bn == 256) SFD2_IG2(1, 256, true); else SFD2_IG2(1, 128, true); return true; }

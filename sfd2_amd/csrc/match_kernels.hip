@@ -251,17 +251,40 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[1][ks], acc1, 0, 0, 0);
                 }
                 const int jbase = ja0 + s * TA + sub * 32 + 4 * lhi;
+                const bool full = ja0 + s * TA + sub * 32 + 32 <= ja1;   // wave-uniform: no row of this sub-tile is padding
+                if (!NEED2 && full) {
+                    // top-1 only: one max tree per tile; the per-element index scan runs only in the
+                    // (increasingly rare) case that some lane's running maximum is beaten
+                    float m0 = acc0[0], m1 = acc1[0];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = jbase + (r & 3) + 8 * (r >> 2);
-                    const bool in = j < ja1;
-                    const float v0 = in ? acc0[r] : -INFINITY, v1 = in ? acc1[r] : -INFINITY;
-                    if (NEED2) {
-                        top2_update(v0, j, b1[0], b2[0], i1[0]);
-                        top2_update(v1, j, b1[1], b2[1], i1[1]);
-                    } else {
-                        i1[0] = v0 > b1[0] ? j : i1[0]; b1[0] = fmaxf(b1[0], v0);
-                        i1[1] = v1 > b1[1] ? j : i1[1]; b1[1] = fmaxf(b1[1], v1);
+                    for (int r = 1; r < 16; ++r) { m0 = fmaxf(m0, acc0[r]); m1 = fmaxf(m1, acc1[r]); }
+                    if (__any(m0 > b1[0])) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int j = jbase + (r & 3) + 8 * (r >> 2);
+                            i1[0] = acc0[r] > b1[0] ? j : i1[0]; b1[0] = fmaxf(b1[0], acc0[r]);
+                        }
+                    }
+                    if (__any(m1 > b1[1])) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int j = jbase + (r & 3) + 8 * (r >> 2);
+                            i1[1] = acc1[r] > b1[1] ? j : i1[1]; b1[1] = fmaxf(b1[1], acc1[r]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = jbase + (r & 3) + 8 * (r >> 2);
+                        const bool in = j < ja1;
+                        const float v0 = in ? acc0[r] : -INFINITY, v1 = in ? acc1[r] : -INFINITY;
+                        if (NEED2) {
+                            top2_update(v0, j, b1[0], b2[0], i1[0]);
+                            top2_update(v1, j, b1[1], b2[1], i1[1]);
+                        } else {
+                            i1[0] = v0 > b1[0] ? j : i1[0]; b1[0] = fmaxf(b1[0], v0);
+                            i1[1] = v1 > b1[1] ? j : i1[1]; b1[1] = fmaxf(b1[1], v1);
+                        }
                     }
                 }
             }

@@ -65,6 +65,10 @@ struct sfd2_ctx {
     // weights
     ConvW c1a, c1b, c2a, c2b, c3a, c3b, rb1[3], rb2[3], rb3[3], pa0, pa3, da0, da3, pb, db;
     DevBuf sta_w, sta_b, zero_page;
+    // strict fp32 mode
+    int precision = SFD2_PREC_F16;
+    ConvW f1a, f1b, f2a, f2b, f3a, f3b, frb1[3], frb2[3], frb3[3], fpa0, fpa3, fda0, fda3, fpb, fdb;
+    DevBuf g1a, g1b, g2a, g2b, g3a, g3b, grt1[3], grt2[3], gro[3], gpa0_o, gpa_o, gda0_o, gda_o;   // fp32 NHWC activations
     // geometry of the current workspace
     int H = 0, W = 0, H2 = 0, W2 = 0, H4 = 0, W4 = 0, H8 = 0, W8 = 0;
     // activations (NHWC fp16 unless noted)
@@ -155,11 +159,16 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
                       &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
                       &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->bnd, &c->sel, &c->sorted, &c->counters,
                       &c->kpts, &c->kscores, &c->kdesc, &c->m_stage, &c->m_hi0, &c->m_lo0, &c->m_hi1, &c->m_lo1,
-                      &c->m_part_f, &c->m_part_i, &c->m_red, &c->m_jobs, &c->m_fins, &c->m_out_m, &c->m_out_s};
+                      &c->m_part_f, &c->m_part_i, &c->m_red, &c->m_jobs, &c->m_fins, &c->m_out_m, &c->m_out_s,
+                      &c->g1a, &c->g1b, &c->g2a, &c->g2b, &c->g3a, &c->g3b, &c->grt1[0], &c->grt1[1], &c->grt1[2],
+                      &c->grt2[0], &c->grt2[1], &c->grt2[2], &c->gro[0], &c->gro[1], &c->gro[2], &c->gpa0_o, &c->gpa_o,
+                      &c->gda0_o, &c->gda_o};
     for (DevBuf *b : bufs) b->release();
     ConvW *ws[] = {&c->c1a, &c->c1b, &c->c2a, &c->c2b, &c->c3a, &c->c3b, &c->rb1[0], &c->rb1[1], &c->rb1[2],
                    &c->rb2[0], &c->rb2[1], &c->rb2[2], &c->rb3[0], &c->rb3[1], &c->rb3[2], &c->pa0, &c->pa3,
-                   &c->da0, &c->da3, &c->pb, &c->db};
+                   &c->da0, &c->da3, &c->pb, &c->db, &c->f1a, &c->f1b, &c->f2a, &c->f2b, &c->f3a, &c->f3b, &c->frb1[0],
+                   &c->frb1[1], &c->frb1[2], &c->frb2[0], &c->frb2[1], &c->frb2[2], &c->frb3[0], &c->frb3[1], &c->frb3[2],
+                   &c->fpa0, &c->fpa3, &c->fda0, &c->fda3, &c->fpb, &c->fdb};
     for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); }
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
@@ -301,6 +310,67 @@ static int pack_gconv(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
     return 0;
 }
 
+// ---- strict fp32 mode: the same folding, filters kept in fp32
+static int pack_igemm_f32(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &conv, const std::string &bn, int cin,
+                          int cout, int ks, int stride)
+{
+    const TView *w = find_t(m, conv + ".weight");
+    if (!w) return fail("missing tensor: " + conv + ".weight");
+    const int cout_pad = (cout + 63) / 64 * 64;
+    L.cin = cin; L.cout = cout; L.cout_pad = cout_pad; L.ks = ks; L.stride = stride;
+    const int T = ks * ks, nch = cin / 32;
+    std::vector<float> pk((size_t)nch * T * cout_pad * 32, 0.0f);
+    for (int ch = 0; ch < nch; ++ch)
+        for (int t = 0; t < T; ++t)
+            for (int oc = 0; oc < cout; ++oc)
+                for (int k = 0; k < 32; ++k)
+                    pk[(((size_t)ch * T + t) * cout_pad + oc) * 32 + k] =
+                        w->d[(((size_t)oc * cin + ch * 32 + k) * ks + t / ks) * ks + t % ks];
+    std::vector<float> sc, sh;
+    if (fold_scale_shift(m, conv, bn, cout, cout_pad, sc, sh)) return -1;
+    if (upload(L.w, pk.data(), pk.size() * sizeof(float), c->stream)) return -1;
+    if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
+    if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+    return 0;
+}
+
+static int pack_raw_f32(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &conv, const std::string &bn, int cout,
+                        size_t numel)
+{
+    const TView *w = find_t(m, conv + ".weight");
+    if (!w || w->numel() != numel) return fail("missing or mis-shaped tensor: " + conv + ".weight");
+    L.cout = cout; L.cout_pad = cout;
+    std::vector<float> sc, sh;
+    if (fold_scale_shift(m, conv, bn, cout, cout, sc, sh)) return -1;
+    if (upload(L.w, w->d, numel * sizeof(float), c->stream)) return -1;
+    if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
+    if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+    return 0;
+}
+
+static int pack_all_f32(sfd2_ctx *c, const TMap &m)
+{
+    if (pack_raw_f32(c, m, c->f1a, "conv1a.0", "conv1a.1", 64, 64 * 27)) return -1;
+    if (pack_igemm_f32(c, m, c->f1b, "conv1b.0", "bn1b.0", 64, 64, 3, 2)) return -1;
+    if (pack_igemm_f32(c, m, c->f2a, "conv2a.0", "conv2a.1", 64, 128, 3, 1)) return -1;
+    if (pack_igemm_f32(c, m, c->f2b, "conv2b.0", "bn2b.0", 128, 128, 3, 2)) return -1;
+    if (pack_igemm_f32(c, m, c->f3a, "conv3a.0", "conv3a.1", 128, 256, 3, 1)) return -1;
+    if (pack_igemm_f32(c, m, c->f3b, "conv3b.0", "bn3b.0", 256, 256, 3, 1)) return -1;
+    for (int b = 0; b < 3; ++b) {
+        const std::string p = "conv4." + std::to_string(b) + ".";
+        if (pack_igemm_f32(c, m, c->frb1[b], p + "conv1", p + "bn1", 256, 256, 1, 1)) return -1;
+        if (pack_raw_f32(c, m, c->frb2[b], p + "conv2", p + "bn2", 256, 256 * 72)) return -1;
+        if (pack_igemm_f32(c, m, c->frb3[b], p + "conv3", p + "bn3", 256, 256, 1, 1)) return -1;
+    }
+    if (pack_igemm_f32(c, m, c->fpa0, "convPa.0", "convPa.1", 256, 256, 3, 2)) return -1;
+    if (pack_igemm_f32(c, m, c->fpa3, "convPa.3", "", 256, 256, 3, 1)) return -1;
+    if (pack_igemm_f32(c, m, c->fda0, "convDa.0", "convDa.1", 256, 256, 3, 1)) return -1;
+    if (pack_igemm_f32(c, m, c->fda3, "convDa.3", "", 256, 256, 3, 1)) return -1;
+    if (pack_igemm_f32(c, m, c->fpb, "convPb", "", 256, 65, 1, 1)) return -1;
+    if (pack_igemm_f32(c, m, c->fdb, "convDb", "", 256, 128, 1, 1)) return -1;
+    return 0;
+}
+
 extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
 {
     if (!c || !tensors) return fail("sfd2_load_weights: null argument");
@@ -336,6 +406,7 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
     if (sw->numel() != 3 * 256 || sb->numel() != 3) return fail("bad shape for ConvSta");
     if (upload(c->sta_w, sw->d, 3 * 256 * sizeof(float), c->stream)) return -1;
     if (upload(c->sta_b, sb->d, 3 * sizeof(float), c->stream)) return -1;
+    if (pack_all_f32(c, m)) return -1;
     c->weights_loaded = true;
     return 0;
 }
@@ -383,6 +454,46 @@ static int ensure_workspace(sfd2_ctx *c, int H, int W)
     auto reg = [&](const char *nm, const DevBuf &b, int f32, int planar, int ch, int pitch, int h, int w) {
         c->acts[nm] = ActInfo{b.p, f32, planar, ch, pitch, h, w};
     };
+    if (c->precision == SFD2_PREC_F32) {
+        const size_t fb = sizeof(float);
+        HIPCHECK(c->g1a.ensure(P1 * 64 * fb));
+        HIPCHECK(c->g1b.ensure(P2 * 64 * fb));
+        HIPCHECK(c->g2a.ensure(P2 * 128 * fb));
+        HIPCHECK(c->g2b.ensure(P4 * 128 * fb));
+        HIPCHECK(c->g3a.ensure(P4 * 256 * fb));
+        HIPCHECK(c->g3b.ensure(P4 * 256 * fb));
+        for (int b = 0; b < 3; ++b) {
+            HIPCHECK(c->grt1[b].ensure(P4 * 256 * fb));
+            HIPCHECK(c->grt2[b].ensure(P4 * 256 * fb));
+            HIPCHECK(c->gro[b].ensure(P4 * 256 * fb));
+        }
+        HIPCHECK(c->gpa0_o.ensure(P8 * 256 * fb));
+        HIPCHECK(c->gpa_o.ensure(P8 * 256 * fb));
+        HIPCHECK(c->gda0_o.ensure(P4 * 256 * fb));
+        HIPCHECK(c->gda_o.ensure(P4 * 256 * fb));
+        static const char *fn1[3] = {"conv4.0.bn1", "conv4.1.bn1", "conv4.2.bn1"};
+        static const char *fn2[3] = {"conv4.0.bn2", "conv4.1.bn2", "conv4.2.bn2"};
+        static const char *fn3[3] = {"conv4.0", "conv4.1", "conv4.2"};
+        reg("conv1a", c->g1a, 1, 0, 64, 64, H, W);
+        reg("bn1b", c->g1b, 1, 0, 64, 64, c->H2, c->W2);
+        reg("conv2a", c->g2a, 1, 0, 128, 128, c->H2, c->W2);
+        reg("bn2b", c->g2b, 1, 0, 128, 128, c->H4, c->W4);
+        reg("conv3a", c->g3a, 1, 0, 256, 256, c->H4, c->W4);
+        reg("bn3b", c->g3b, 1, 0, 256, 256, c->H4, c->W4);
+        for (int b = 0; b < 3; ++b) {
+            reg(fn1[b], c->grt1[b], 1, 0, 256, 256, c->H4, c->W4);
+            reg(fn2[b], c->grt2[b], 1, 0, 256, 256, c->H4, c->W4);
+            reg(fn3[b], c->gro[b], 1, 0, 256, 256, c->H4, c->W4);
+        }
+        reg("convPa.0", c->gpa0_o, 1, 0, 256, 256, c->H8, c->W8);
+        reg("convPa", c->gpa_o, 1, 0, 256, 256, c->H8, c->W8);
+        reg("convDa.0", c->gda0_o, 1, 0, 256, 256, c->H4, c->W4);
+        reg("convDa", c->gda_o, 1, 0, 256, 256, c->H4, c->W4);
+        reg("convPb", c->logits, 1, 0, 65, 128, c->H8, c->W8);
+        reg("convDb", c->draw, 1, 0, 128, 128, c->H4, c->W4);
+        reg("ConvSta", c->sta, 1, 1, 3, 0, c->H4, c->W4);
+        return 0;
+    }
     reg("conv1a", c->a1a, 0, 0, 64, 64, H, W);
     reg("bn1b", c->a1b, 0, 0, 64, 64, c->H2, c->W2);
     reg("conv2a", c->a2a, 0, 0, 128, 128, c->H2, c->W2);
@@ -423,9 +534,70 @@ static void conv(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &in
                       c->zero_page.as<half_t>());
 }
 
+static void convf(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &in, int H, int W, const DevBuf &out,
+                  int Ho, int Wo, int relu, const float *res = nullptr)
+{
+    char kn[48];
+    snprintf(kn, sizeof(kn), "conv_igemm_f32<%d,%d,%d>", L.ks, L.stride, (L.cout_pad % 128 == 0) ? 128 : 64);
+    const double px = (double)Ho * Wo;
+    ProfScope ps(c, name, kn, 2.0 * px * L.cout * L.cin * L.ks * L.ks,
+                 4.0 * ((double)H * W * L.cin + (double)L.cout * L.cin * L.ks * L.ks + px * L.cout_pad * (res ? 2 : 1)));
+    launch_conv_igemm_f32(c->stream, in.as<float>(), H, W, L.cin, L.w.as<float>(), L.scale.as<float>(),
+                          L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu, res, out.as<float>(), Ho, Wo);
+}
+
+// strict mode: identical layer sequence on fp32 activations (conv_f32_kernels.hip)
+static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
+{
+    hipStream_t st = c->stream;
+    const int H = c->H, W = c->W, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
+    const double P1 = (double)H * W, P4 = (double)H4 * W4, P8 = (double)H8 * W8;
+    {
+        ProfScope ps(c, "conv1a", "conv1a_f32_kernel", 2.0 * P1 * 64 * 27, P1 * (12 + 256));
+        launch_conv1a_f32(st, img_dev, H, W, normalise, c->f1a.w.as<float>(), c->f1a.scale.as<float>(),
+                          c->f1a.shift.as<float>(), c->g1a.as<float>());
+    }
+    convf(c, "conv1b", c->f1b, c->g1a, H, W, c->g1b, H2, W2, 1);
+    convf(c, "conv2a", c->f2a, c->g1b, H2, W2, c->g2a, H2, W2, 1);
+    convf(c, "conv2b", c->f2b, c->g2a, H2, W2, c->g2b, H4, W4, 1);
+    convf(c, "conv3a", c->f3a, c->g2b, H4, W4, c->g3a, H4, W4, 1);
+    convf(c, "conv3b", c->f3b, c->g3a, H4, W4, c->g3b, H4, W4, 1);
+    const DevBuf *x = &c->g3b;
+    static const char *nm1[3] = {"conv4.0.conv1", "conv4.1.conv1", "conv4.2.conv1"};
+    static const char *nm2[3] = {"conv4.0.conv2", "conv4.1.conv2", "conv4.2.conv2"};
+    static const char *nm3[3] = {"conv4.0.conv3", "conv4.1.conv3", "conv4.2.conv3"};
+    for (int b = 0; b < 3; ++b) {
+        convf(c, nm1[b], c->frb1[b], *x, H4, W4, c->grt1[b], H4, W4, 1);
+        {
+            ProfScope ps(c, nm2[b], "gconv_f32_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 8);
+            launch_gconv_f32(st, c->grt1[b].as<float>(), H4, W4, c->frb2[b].w.as<float>(), c->frb2[b].scale.as<float>(),
+                             c->frb2[b].shift.as<float>(), c->grt2[b].as<float>());
+        }
+        convf(c, nm3[b], c->frb3[b], c->grt2[b], H4, W4, c->gro[b], H4, W4, 1, x->as<float>());
+        x = &c->gro[b];
+    }
+    convf(c, "convPa.0", c->fpa0, *x, H4, W4, c->gpa0_o, H8, W8, 1);
+    convf(c, "convPa.3", c->fpa3, c->gpa0_o, H8, W8, c->gpa_o, H8, W8, 0);
+    convf(c, "convPb", c->fpb, c->gpa_o, H8, W8, c->logits, H8, W8, 0);
+    convf(c, "convDa.0", c->fda0, *x, H4, W4, c->gda0_o, H4, W4, 1);
+    convf(c, "convDa.3", c->fda3, c->gda0_o, H4, W4, c->gda_o, H4, W4, 0);
+    convf(c, "convDb", c->fdb, c->gda_o, H4, W4, c->draw, H4, W4, 0);
+    {
+        ProfScope ps(c, "ConvSta", "convsta_f32_kernel", 2.0 * P4 * 3 * 256, P4 * (1024 + 12));
+        launch_convsta_f32(st, x->as<float>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
+    }
+    {
+        ProfScope ps(c, "detector_head", "detector_head_kernel", 0.0, P8 * (65 * 4 + 256));
+        launch_detector_head(st, c->logits.as<float>(), 128, H8, W8, c->score.as<float>());
+    }
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
 // ResSegNetV2.det up to the three head outputs (nets/sfd2.py:314-328, :340-345)
 static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
 {
+    if (c->precision == SFD2_PREC_F32) return run_network_f32(c, img_dev, normalise);
     hipStream_t st = c->stream;
     const int H = c->H, W = c->W, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
     const double P1 = (double)H * W, P4 = (double)H4 * W4, P8 = (double)H8 * W8;
@@ -910,6 +1082,16 @@ extern "C" int sfd2_match(sfd2_ctx *c, const void *d0, int n0, const void *d1, i
     const sfd2_desc_set q = {d0, n0, dtype, layout, on_device};
     const sfd2_desc_set db = {d1, n1, dtype, layout, on_device};
     return sfd2_match_batch(c, &q, &db, 1, dim, conf, matches0, scores0, out_on_device, 0);
+}
+
+extern "C" int sfd2_set_precision(sfd2_ctx *c, int mode)
+{
+    if (!c) return fail("sfd2_set_precision: null ctx");
+    if (mode != SFD2_PREC_F16 && mode != SFD2_PREC_F32) return fail("sfd2_set_precision: unknown mode");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    c->precision = mode;
+    return 0;
 }
 
 extern "C" int sfd2_sync(sfd2_ctx *c)

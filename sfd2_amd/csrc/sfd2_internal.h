@@ -38,6 +38,17 @@ void launch_gconv3x3_g8(hipStream_t st, const half_t *in, int H, int W, const ha
 void launch_convsta(hipStream_t st, const half_t *in, int npix, const float *w /*[3][256]*/, const float *b,
                     float *out /*[3][npix]*/);
 
+// ---- strict fp32 mode (conv_f32_kernels.hip): fp32 NHWC activations, f32-input MFMA
+//   wpk [Cin/32][ks*ks][Cout_pad][32] fp32
+void launch_conv_igemm_f32(hipStream_t st, const float *in, int H, int W, int Cin, const float *wpk,
+                           const float *scale, const float *shift, int Cout_pad, int ks, int stride, int relu,
+                           const float *residual, float *out, int Ho, int Wo);
+void launch_conv1a_f32(hipStream_t st, const float *img_chw, int H, int W, int normalise, const float *w /*[64][27]*/,
+                       const float *scale, const float *shift, float *out /*[H][W][64]*/);
+void launch_gconv_f32(hipStream_t st, const float *in, int H, int W, const float *w /*[256][72]*/, const float *scale,
+                      const float *shift, float *out);
+void launch_convsta_f32(hipStream_t st, const float *in, int npix, const float *w, const float *b, float *out);
+
 // ------------------------------------------------------------------ heads / post
 // logits [P][pitch] fp32 (65 used) -> score [8*hc][8*wc]
 void launch_detector_head(hipStream_t st, const float *logits, int pitch, int hc, int wc, float *score);

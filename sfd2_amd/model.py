@@ -24,7 +24,12 @@ def _is_torch(x):
 class ResSegNetV2:
     """Drop-in for nets.sfd2.ResSegNetV2 on the inference path (det)."""
 
-    def __init__(self, outdim=128, require_feature=False, require_stability=False, ms_detector=True):
+    def __init__(self, outdim=128, require_feature=False, require_stability=False, ms_detector=True,
+                 precision="f16"):
+        """precision (extension): 'f16' = fp16 MFMA throughput mode, 'f32' = strict fp32 parity mode."""
+        if precision not in ("f16", "f32"):
+            raise ValueError("precision must be 'f16' or 'f32'")
+        self.precision = precision
         if outdim != 128:
             raise ValueError("the HIP path implements outdim=128 (extract_localization.py:213)")
         self.outdim = outdim
@@ -73,6 +78,7 @@ class ResSegNetV2:
     def _ensure_ctx(self):
         if self._ctx is None:
             self._ctx = _lib.Context(self._device)
+            self._ctx.set_precision(self.precision)
             if self._sd is not None:
                 self._ctx.load_weights(self._sd)
         return self._ctx

@@ -422,3 +422,68 @@ def test_hloc_plugin_with_cuda_tensors():
     from sfd2_amd.match_features import cast_for_storage
     m16, s16 = cast_for_storage(cpu["matches0"][0].numpy(), cpu["matching_scores0"][0].numpy())
     assert m16.dtype == np.int16 and s16.dtype == np.float16
+
+
+# ------------------------------------------------------------------ strict fp32 mode
+# precision='f32': the conv stack runs in exact fp32 on the f32-input MFMA.  It differs from the
+# fp32 reference only by summation order, so the tolerances are fp32 round-off and the key-point
+# LIST (not just the set) reproduces the reference's up to swaps of near-equal scores.
+@pytest.fixture(scope="module")
+def model_f32(synth_sd):
+    if not _gpu_ok():
+        pytest.fail("no MI355X visible")
+    from sfd2_amd.model import ResSegNetV2
+    m = ResSegNetV2(outdim=128, require_stability=True, precision="f32").eval()
+    m.load_state_dict(synth_sd)
+    m.cuda(0)
+    return m
+
+
+@pytest.mark.parametrize("h,w,seed", [(64, 96, 11), (100, 130, 12), (37, 53, 13)])
+def test_strict_det_vs_oracle(model_f32, synth_sd, h, w, seed):
+    img = synth.make_image(h, w, seed)
+    x = orc.norm_rgb(img)
+    taps = {}
+    o_score, o_stab, o_desc = orc.det(synth_sd, x, taps)
+    score, stab, desc = model_f32.det(x[None])
+    ctx = model_f32.context
+    for name, want in taps.items():
+        got = ctx.debug_activation(name)
+        np.testing.assert_allclose(got, want, atol=1e-4, rtol=1e-4, err_msg=name)
+    np.testing.assert_allclose(score[0, 0], o_score, atol=1e-6, rtol=2e-4)
+    np.testing.assert_allclose(desc[0], o_desc, atol=2e-5)
+    assert (stab[0, 0] != o_stab).mean() <= 5e-4
+
+
+def _compare_strict(got, want, desc_tol):
+    mine = _kp_index(got["keypoints"])
+    rank = np.array([mine.get((int(x), int(y)), -1) for x, y in want["keypoints"]])
+    found = rank >= 0
+    assert abs(len(got["scores"]) - len(want["scores"])) <= 2
+    assert found.mean() >= 0.995, found.mean()
+    assert np.abs(rank[found] - np.flatnonzero(found)).max() <= 3          # order, up to near-ties
+    np.testing.assert_allclose(got["scores"][rank[found]], np.asarray(want["scores"], dtype=np.float64)[found], atol=1e-5, rtol=2e-4)
+    dd = np.abs(got["descriptors"][rank[found]] - np.asarray(want["descriptors"], dtype=np.float64)[found]).max()
+    assert dd <= desc_tol, dd
+
+
+@pytest.mark.parametrize("h,w,seed,topk", [(96, 128, 21, 200), (100, 130, 22, -1), (480, 640, 0, 1024)])
+def test_strict_extract_vs_oracle_and_reference_golden(model_f32, synth_sd, golden_dir, h, w, seed, topk):
+    from sfd2_amd.extractor import extract_resnet_return
+    img = synth.make_image(h, w, seed)
+    got = extract_resnet_return(model_f32, img[None], conf_th=0.001, topK=topk, scales=[1.0])
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk)
+    _compare_strict(got, want, 2e-5)
+    tag = {(96, 128): "96x128_k200", (100, 130): "100x130_all", (480, 640): "480x640_k1024"}[(h, w)]
+    g = _load(golden_dir, f"extract_{tag}.npz")
+    ref = {"keypoints": g["keypoints"], "scores": g["scores"], "descriptors": g["descriptors"].astype(np.float64)}
+    _compare_strict(got, ref, 2e-3)    # the fixture stores the reference's descriptors as fp16
+
+
+def test_strict_full_size_vs_oracle(model_f32, synth_sd):
+    from sfd2_amd.extractor import extract_resnet_return
+    img = synth.make_image(1200, 1600, 5)
+    got = extract_resnet_return(model_f32, img[None], conf_th=0.001, topK=4096, scales=[1.0])
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=4096)
+    _compare_strict(got, want, 2e-5)
+    print("strict 1600x1200 timings:", model_f32.context.timings())
