@@ -113,6 +113,17 @@ int sfd2_extract(sfd2_ctx *ctx, const float *img, int img_on_device, int H, int 
 /* After an SFD2_FLAG_ASYNC extract: number of key points, once the stream is idle. */
 int sfd2_extract_count(sfd2_ctx *ctx, int *n_out);
 
+/* extract_spp_feats_singlescale (extract.py:205-277), the older SuperPoint-style variant:
+ * candidates heat >= conf_th, greedy grid NMS in score order (nms_fast, extract.py:17-84,
+ * Chebyshev radius 4), border 4, descriptor sampling, NO top-K.  x is the NORMALISED image
+ * (this variant's caller applies norm_RGB, extract.py:280-287).  Also returns, if non-NULL, the
+ * heat map [H][W] and the dense L2-normalised descriptor map [128][Hc][Wc] the reference returns. */
+int sfd2_extract_spp(sfd2_ctx *ctx, const float *x, int x_on_device, int H, int W, float conf_th, int flags,
+                     float *kpts_xy, float *scores, float *desc, int64_t cap_out, int *n_out,
+                     float *heat_out, float *desc_full_out);
+/* nms_fast on a dense map: kept[y][x] = heat if the pixel survives greedy NMS else 0 (host buffers) */
+int sfd2_nms_fast(sfd2_ctx *ctx, const float *heat, int H, int W, float conf_th, int dist, float *kept_out);
+
 /* Stage entry points (parity tests; each is the device kernel the pipeline uses). */
 /* simple_nms(scores, 4) (nets/extractor.py:20-35): heat [H][W] -> nms [H][W] */
 int sfd2_simple_nms(sfd2_ctx *ctx, const float *heat, int H, int W, int radius, float *nms_out);

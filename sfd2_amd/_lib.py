@@ -52,7 +52,7 @@ EXPORTS = [
     "sfd2_load_weights", "sfd2_det", "sfd2_extract", "sfd2_extract_count", "sfd2_simple_nms",
     "sfd2_select_keypoints", "sfd2_sample_descriptors", "sfd2_heatmap", "sfd2_debug_activation",
     "sfd2_match", "sfd2_match_batch", "sfd2_get_timings", "sfd2_sync", "sfd2_set_profiling",
-    "sfd2_get_layer_timings", "sfd2_set_precision",
+    "sfd2_get_layer_timings", "sfd2_set_precision", "sfd2_extract_spp", "sfd2_nms_fast",
 ]
 
 _lib = None
@@ -80,6 +80,8 @@ def load():
     lib.sfd2_det.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, pi, pi, pi, pi]
     lib.sfd2_extract.argtypes = [vp, vp, ci, ci, ci, cf, ci, ci, vp, vp, vp, ci, i64, pi]
     lib.sfd2_extract_count.argtypes = [vp, pi]
+    lib.sfd2_extract_spp.argtypes = [vp, vp, ci, ci, ci, cf, ci, vp, vp, vp, i64, pi, vp, vp]
+    lib.sfd2_nms_fast.argtypes = [vp, vp, ci, ci, cf, ci, vp]
     lib.sfd2_simple_nms.argtypes = [vp, vp, ci, ci, ci, vp]
     lib.sfd2_select_keypoints.argtypes = [vp, vp, ci, ci, cf, ci, ci, ci, vp, vp, i64, pi]
     lib.sfd2_sample_descriptors.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, vp]

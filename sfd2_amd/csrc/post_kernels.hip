@@ -614,6 +614,75 @@ void launch_keys_to_kpts(hipStream_t st, const unsigned long long *sorted, const
     hipLaunchKernelGGL(keys_to_kpts_kernel, dim3((cap + NT - 1) / NT), dim3(NT), 0, st, sorted, counters, W, kpts, scores, cap);
 }
 
+// ---------------------------------------------------------------- greedy grid NMS (extract.py:17-84 nms_fast)
+// The reference visits candidates in score order and keeps one iff no kept candidate lies within
+// Chebyshev distance `dist`.  Exact parallel form: a candidate is KEPT once every higher-priority
+// candidate in its window is SUPPRESSED, SUPPRESSED once any candidate in its window is KEPT;
+// iterate (double-buffered states) to the fixed point -- identical to the sequential result.
+// Priority = 64-bit key (score bits, then lower pixel index first), 0 = not a candidate.
+#define GS_NONE 0
+#define GS_UNDECIDED 1
+#define GS_KEPT 2
+#define GS_SUPPRESSED 3
+__global__ __launch_bounds__(NT)
+void greedy_init_kernel(const float *__restrict__ heat, int n, float conf_th, unsigned long long *__restrict__ keys,
+                        unsigned char *__restrict__ state)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = heat[i];
+    const bool c = v >= conf_th;                      // np.where(heatmap >= conf_thresh)  (extract.py:230)
+    keys[i] = c ? (((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i)) : 0ull;
+    state[i] = c ? GS_UNDECIDED : GS_NONE;
+}
+
+__global__ __launch_bounds__(NT)
+void greedy_iter_kernel(const unsigned long long *__restrict__ keys, const unsigned char *__restrict__ sin,
+                        unsigned char *__restrict__ sout, int H, int W, int dist, unsigned int *__restrict__ undecided)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const int i = y * W + x;
+    const unsigned char st = sin[i];
+    if (st != GS_UNDECIDED) { sout[i] = st; return; }
+    const unsigned long long mine = keys[i];
+    bool any_kept = false, blocked = false;
+    const int y0 = max(0, y - dist), y1 = min(H - 1, y + dist), x0 = max(0, x - dist), x1 = min(W - 1, x + dist);
+    for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) {
+            const int j = yy * W + xx;
+            const unsigned char sj = sin[j];
+            if (sj == GS_KEPT) any_kept = true;
+            else if (sj == GS_UNDECIDED && keys[j] > mine) blocked = true;
+        }
+    unsigned char ns = GS_UNDECIDED;
+    if (any_kept) ns = GS_SUPPRESSED;
+    else if (!blocked) ns = GS_KEPT;
+    sout[i] = ns;
+    if (ns == GS_UNDECIDED) atomicAdd(undecided, 1u);
+}
+
+__global__ __launch_bounds__(NT)
+void greedy_final_kernel(const float *__restrict__ heat, const unsigned char *__restrict__ state, int n, float *__restrict__ kept)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) kept[i] = state[i] == GS_KEPT ? heat[i] : 0.0f;
+}
+
+void launch_greedy_init(hipStream_t st, const float *heat, int n, float conf_th, unsigned long long *keys, unsigned char *state)
+{
+    hipLaunchKernelGGL(greedy_init_kernel, dim3((n + NT - 1) / NT), dim3(NT), 0, st, heat, n, conf_th, keys, state);
+}
+void launch_greedy_iter(hipStream_t st, const unsigned long long *keys, const unsigned char *sin, unsigned char *sout,
+                        int H, int W, int dist, unsigned int *undecided)
+{
+    hipLaunchKernelGGL(greedy_iter_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(NT), 0, st, keys, sin, sout, H, W, dist, undecided);
+}
+void launch_greedy_final(hipStream_t st, const float *heat, const unsigned char *state, int n, float *kept)
+{
+    hipLaunchKernelGGL(greedy_final_kernel, dim3((n + NT - 1) / NT), dim3(NT), 0, st, heat, state, n, kept);
+}
+
 // ---------------------------------------------------------------- descriptor sampling
 // One wave per key point, lane l owns channels 2l, 2l+1.  The four taps are L2-normalised on
 // the fly (F.normalize of the dense map, nets/sfd2.py:342, commutes with the gather), blended

@@ -77,6 +77,7 @@ struct sfd2_ctx {
     DevBuf stab /*f32 [H][W]*/, desc_nchw, tmp_f32;
     // selection
     DevBuf cand, bnd, sel, sorted, counters, kpts, kscores, kdesc;
+    DevBuf g_keys, g_state0, g_state1, g_kept;   // greedy NMS (extract.py variant)
     int cand_cap = 0;
     int last_sel_cap = 0;
     // matcher
@@ -162,7 +163,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
                       &c->m_part_f, &c->m_part_i, &c->m_red, &c->m_jobs, &c->m_fins, &c->m_out_m, &c->m_out_s,
                       &c->g1a, &c->g1b, &c->g2a, &c->g2b, &c->g3a, &c->g3b, &c->grt1[0], &c->grt1[1], &c->grt1[2],
                       &c->grt2[0], &c->grt2[1], &c->grt2[2], &c->gro[0], &c->gro[1], &c->gro[2], &c->gpa0_o, &c->gpa_o,
-                      &c->gda0_o, &c->gda_o};
+                      &c->gda0_o, &c->gda_o, &c->g_keys, &c->g_state0, &c->g_state1, &c->g_kept};
     for (DevBuf *b : bufs) b->release();
     ConvW *ws[] = {&c->c1a, &c->c1b, &c->c2a, &c->c2b, &c->c3a, &c->c3b, &c->rb1[0], &c->rb1[1], &c->rb1[2],
                    &c->rb2[0], &c->rb2[1], &c->rb2[2], &c->rb3[0], &c->rb3[1], &c->rb3[2], &c->pa0, &c->pa3,
@@ -808,6 +809,90 @@ extern "C" int sfd2_extract_count(sfd2_ctx *c, int *n_out)
     if (!c) return fail("sfd2_extract_count: null ctx");
     HIPCHECK(hipSetDevice(c->device));
     return read_counts(c, -1, n_out);
+}
+
+// greedy NMS to the fixed point; result (kept ? heat : 0) in c->g_kept
+static int run_greedy_nms(sfd2_ctx *c, const float *heat_dev, int H, int W, float conf_th, int dist)
+{
+    const int n = H * W;
+    HIPCHECK(c->g_keys.ensure((size_t)n * 8));
+    HIPCHECK(c->g_state0.ensure(n));
+    HIPCHECK(c->g_state1.ensure(n));
+    HIPCHECK(c->g_kept.ensure((size_t)n * sizeof(float)));
+    HIPCHECK(c->counters.ensure(SFD2_COUNTER_BYTES));
+    launch_greedy_init(c->stream, heat_dev, n, conf_th, c->g_keys.as<unsigned long long>(), c->g_state0.as<unsigned char>());
+    unsigned char *sa = c->g_state0.as<unsigned char>(), *sb = c->g_state1.as<unsigned char>();
+    unsigned int *und = c->counters.as<unsigned int>() + 8;   // scratch word, outside the selection counters
+    const int max_iter = 1 << 20;                             // every sweep decides at least the best undecided candidate
+    for (int it = 0; it < max_iter;) {
+        unsigned int left = 0;
+        for (int b = 0; b < 8 && it < max_iter; ++b, ++it) {  // 8 sweeps per host round trip
+            HIPCHECK(hipMemsetAsync(und, 0, 4, c->stream));
+            launch_greedy_iter(c->stream, c->g_keys.as<unsigned long long>(), sa, sb, H, W, dist, und);
+            std::swap(sa, sb);
+        }
+        HIPCHECK(hipMemcpyAsync(&left, und, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        if (left == 0) break;
+        if (it >= max_iter) return fail("greedy NMS did not converge");
+    }
+    launch_greedy_final(c->stream, heat_dev, sa, n, c->g_kept.as<float>());
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sfd2_nms_fast(sfd2_ctx *c, const float *heat, int H, int W, float conf_th, int dist, float *kept_out)
+{
+    if (!c || !heat || !kept_out) return fail("sfd2_nms_fast: null argument");
+    if (dist < 0 || dist > 16) return fail("sfd2_nms_fast: dist out of range");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(c->heat.ensure((size_t)H * W * sizeof(float)));
+    HIPCHECK(hipMemcpyAsync(c->heat.p, heat, (size_t)H * W * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (run_greedy_nms(c, c->heat.as<float>(), H, W, conf_th, dist)) return -1;
+    if (copy_out(c, kept_out, c->g_kept.p, (size_t)H * W * sizeof(float), 0)) return -1;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int sfd2_extract_spp(sfd2_ctx *c, const float *x, int x_on_device, int H, int W, float conf_th, int flags,
+                                float *kpts_xy, float *scores, float *desc, int64_t cap_out, int *n_out,
+                                float *heat_out, float *desc_full_out)
+{
+    if (!c || !x) return fail("sfd2_extract_spp: null argument");
+    if (!c->weights_loaded) return fail("sfd2_extract_spp: weights not loaded");
+    HIPCHECK(hipSetDevice(c->device));
+    if (ensure_workspace(c, H, W)) return -1;
+    const float *img_dev = nullptr;
+    if (stage_image(c, x, x_on_device, H, W, &img_dev)) return -1;
+    prof_step_begin(c);
+    if (run_network(c, img_dev, 0)) return -1;   // the caller normalised the image (extract.py:280-287)
+    const int HS = 8 * c->H8, WS = 8 * c->W8;
+    launch_heatmap(c->stream, c->score.as<float>(), HS, WS, (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(),
+                   c->H4, c->W4, H, W, c->heat.as<float>(), nullptr);
+    if (run_greedy_nms(c, c->heat.as<float>(), H, W, conf_th, 4)) return -1;
+    // kept map -> threshold (> 0: every kept score is >= conf_th > 0), border 4, sort; no top-K (extract.py:236-244)
+    if (run_selection(c, c->g_kept.as<float>(), H, W, 0.0f, 0, 4, 0, nullptr)) return -1;
+    prof_step_end(c);
+    int n = 0;
+    if (read_counts(c, cap_out, &n)) return -1;
+    if (copy_out(c, kpts_xy, c->kpts.p, (size_t)n * 2 * sizeof(float), 0)) return -1;
+    if (copy_out(c, scores, c->kscores.p, (size_t)n * sizeof(float), 0)) return -1;
+    if (desc && n > 0) {
+        HIPCHECK(c->kdesc.ensure((size_t)n * 128 * sizeof(float)));
+        launch_sample_desc(c->stream, c->draw.as<float>(), c->H4, c->W4, H, W, c->kpts.as<float>(), nullptr, n, c->kdesc.as<float>());
+        if (copy_out(c, desc, c->kdesc.p, (size_t)n * 128 * sizeof(float), 0)) return -1;
+    }
+    if (copy_out(c, heat_out, c->heat.p, (size_t)H * W * sizeof(float), 0)) return -1;
+    if (desc_full_out) {
+        const size_t np = (size_t)c->H4 * c->W4;
+        HIPCHECK(c->desc_nchw.ensure(np * 128 * sizeof(float)));
+        launch_desc_normalise_nchw(c->stream, c->draw.as<float>(), (int)np, c->desc_nchw.as<float>());
+        if (copy_out(c, desc_full_out, c->desc_nchw.p, np * 128 * sizeof(float), 0)) return -1;
+    }
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (n_out) *n_out = n;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------ stage entry points

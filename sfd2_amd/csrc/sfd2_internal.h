@@ -64,6 +64,11 @@ void launch_topk_sort(hipStream_t st, const unsigned long long *cand_keys, int c
                       unsigned long long *sel_keys, unsigned long long *sorted_keys, int sel_cap,
                       unsigned int *counters, unsigned long long *boundary_keys /*[cand_cap]*/);
 #define SFD2_COUNTER_BYTES (64 + 65536 * 4)   // 16 counters + score histogram
+// greedy grid NMS of extract.py (nms_fast): init / one relaxation sweep / kept-score map
+void launch_greedy_init(hipStream_t st, const float *heat, int n, float conf_th, unsigned long long *keys, unsigned char *state);
+void launch_greedy_iter(hipStream_t st, const unsigned long long *keys, const unsigned char *sin, unsigned char *sout,
+                        int H, int W, int dist, unsigned int *undecided);
+void launch_greedy_final(hipStream_t st, const float *heat, const unsigned char *state, int n, float *kept);
 // keys -> kpts (x,y), scores
 void launch_keys_to_kpts(hipStream_t st, const unsigned long long *sorted_keys, const unsigned int *counters,
                          int W, float *kpts_xy, float *scores, int cap);

@@ -68,6 +68,15 @@ from it_loc.matcher import Matcher, confs as itloc_confs  # noqa: E402
 
 from sfd2_amd import synth  # noqa: E402
 
+# extract.py imports tools.dataloader (-> datasets, torchvision, ...) only for norm_RGB
+_tools = types.ModuleType("tools")
+_tdl = types.ModuleType("tools.dataloader")
+_tdl.norm_RGB = ref_ext.norm_RGB
+_tools.dataloader = _tdl
+sys.modules["tools"] = _tools
+sys.modules["tools.dataloader"] = _tdl
+import extract as ref_extract  # noqa: E402
+
 torch.set_grad_enabled(False)
 torch.manual_seed(0)
 
@@ -176,6 +185,24 @@ def gen_extract(model, h, w, seed, topk, tag, keep_desc_all=False):
     print(f"extract_{tag}: N={len(sc)} N0={len(cand)} ties={n_ties} min score {sc.min():.5f}")
 
 
+def gen_extract_spp(model, h, w, seed, conf_th, tag):
+    """G5: extract.py nms_fast (:17-84) and extract_spp_feats_singlescale (:205-277)."""
+    img = synth.make_image(h, w, seed)
+    x = norm_rgb(img)
+    pts, desc, scores, desc_full, heat = ref_extract.extract_spp_feats_singlescale(model, x, conf_th=conf_th)
+    out = {"h": h, "w": w, "seed": seed, "conf_th": conf_th, "pts": pts, "desc": desc.astype(np.float16),
+           "n_ties": int((np.diff(pts[:, 2]) == 0).sum()), "heat": heat.astype(np.float32)}
+    # nms_fast alone on random integer corners
+    rs = np.random.RandomState(17)
+    hh, ww, n = 60, 80, 900
+    lin = rs.permutation(hh * ww)[:n]
+    corners = np.stack([lin % ww, lin // ww, rs.random_sample(n) + 0.01]).astype(np.float64)
+    o, inds = ref_extract.nms_fast(corners, hh, ww, 4)
+    out.update({"nf/corners": corners, "nf/h": hh, "nf/w": ww, "nf/out": o, "nf/inds": inds.astype(np.int64)})
+    np.savez_compressed(os.path.join(HERE, f"extract_spp_{tag}.npz"), **out)
+    print(f"extract_spp_{tag}: N={len(pts)} ties={out['n_ties']} nms_fast kept {o.shape[1]} of {n}")
+
+
 def gen_matchers():
     """G6: hloc NearestNeighbor (hloc/matchers/nearest_neighbor.py:27-57) with the
     NNM / ONN / NNR confs (hloc/match_features.py:20-45) + a ratio-test conf, and
@@ -253,5 +280,6 @@ if __name__ == "__main__":
     gen_extract(model, 96, 128, 21, 200, "96x128_k200")
     gen_extract(model, 100, 130, 22, -1, "100x130_all")
     gen_extract(model, 480, 640, 0, 1024, "480x640_k1024")
+    gen_extract_spp(model, 96, 128, 21, 0.02, "96x128")
     gen_matchers()
     gen_host()

@@ -487,3 +487,68 @@ def test_strict_full_size_vs_oracle(model_f32, synth_sd):
     want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=4096)
     _compare_strict(got, want, 2e-5)
     print("strict 1600x1200 timings:", model_f32.context.timings())
+
+
+# ------------------------------------------------------------------ extract.py variant (greedy NMS) and feature_matching
+@pytest.mark.parametrize("h,w,density", [(60, 80, 0.2), (97, 131, 1.0), (300, 400, 0.05), (64, 64, 1.0)])
+def test_nms_fast_vs_oracle_bit_exact(ctx, h, w, density):
+    rs = np.random.RandomState(h + w)
+    heat = rs.random_sample((h, w)).astype(np.float32) + 0.01
+    if (h, w) == (64, 64):      # monotone ramp: the longest dependency chain of the greedy order
+        heat = (np.arange(h * w, dtype=np.float32).reshape(h, w) + 1) / (h * w)
+    heat = np.where(rs.random_sample((h, w)) < density, heat, 0).astype(np.float32)
+    th = 0.005
+    ys, xs = np.where(heat >= th)
+    keep = orc.nms_fast(xs.astype(np.float32), ys.astype(np.float32), heat[ys, xs], h, w, 4)
+    want = np.zeros_like(heat)
+    want[ys[keep], xs[keep]] = heat[ys[keep], xs[keep]]
+    got = np.empty_like(heat)
+    _lib.check(ctx.lib.sfd2_nms_fast(ctx.h, heat.ctypes.data, h, w, th, 4, got.ctypes.data))
+    np.testing.assert_array_equal(got, want)
+
+
+def test_extract_py_api_vs_reference_golden_and_oracle(model, model_f32, synth_sd, golden_dir):
+    from sfd2_amd.extract import extract_spp_return, nms_fast
+    g = _load(golden_dir, "extract_spp_96x128.npz")
+    c = g["nf/corners"]
+    out, inds = nms_fast(c, int(g["nf/h"]), int(g["nf/w"]), 4)
+    np.testing.assert_array_equal(inds, g["nf/inds"])
+    np.testing.assert_array_equal(out, g["nf/out"])
+    h, w, th = int(g["h"]), int(g["w"]), float(g["conf_th"])
+    x = orc.norm_rgb(synth.make_image(h, w, int(g["seed"])))
+    want = orc.extract_spp_feats_singlescale(synth_sd, x, th)
+    for m, tol_pts, tol_desc, min_found in ((model_f32, 1e-5, 2e-5, 0.99), (model, 8e-2, 3e-3, 0.93)):
+        pts, desc, scores, desc_full, heat = extract_spp_return(m, x[None], conf_th=th)
+        assert pts.dtype == np.float64 and desc.dtype == np.float32 and desc_full.shape == want[3].shape and heat.shape == (h, w)
+        for ref_pts, ref_desc, dt in ((want[0], want[1], tol_desc), (g["pts"], g["desc"].astype(np.float32), max(tol_desc, 2e-3))):
+            mine = {(int(a), int(b)): i for i, (a, b, _) in enumerate(pts)}
+            rank = np.array([mine.get((int(a), int(b)), -1) for a, b, _ in ref_pts])
+            ok = rank >= 0
+            assert ok.mean() >= min_found, ok.mean()
+            rel = np.abs(pts[rank[ok], 2] - ref_pts[ok, 2]) / ref_pts[ok, 2]
+            assert np.mean(rel > tol_pts + 1e-4) <= 0.02          # fp16 mode: rare stability-class flips
+            assert np.abs(desc[rank[ok]] - ref_desc[ok]).max() <= dt
+        np.testing.assert_allclose(desc_full, want[3], atol=max(tol_desc, 2e-5))
+    with pytest.raises(NotImplementedError):
+        extract_spp_return(model, x[None], multi_scale=True)
+
+
+def test_feature_matching_mask_and_remap():
+    """it_loc/localize_cv2.py:511-560: only db key points with a 3D point take part; indices map back."""
+    from sfd2_amd.localize import feature_matching
+    from sfd2_amd.matcher import Matcher, confs as mconfs
+    mt = Matcher({"output": "NNM", "model": {**mconfs["NNM"]["model"], "sim_mode": "f16x2"}}).eval().cuda()
+    q = synth.make_descriptors(400, seed=5).astype(np.float64)
+    db = synth.make_descriptors(600, seed=6).astype(np.float64)
+    rs = np.random.RandomState(2)
+    db[rs.permutation(600)[:200]] = q[rs.permutation(400)[:200]]      # exact duplicates -> certain matches
+    ids = np.where(rs.random_sample(600) < 0.6, rs.randint(0, 10000, 600), -1)
+    got = feature_matching(q, db, mt, db_3D_ids=ids)
+    valid = np.flatnonzero(ids != -1)
+    want = orc.itloc_matcher(q, db[valid], "nnm")["matches0"]
+    want = np.where(want >= 0, valid[np.maximum(want, 0)], -1)
+    np.testing.assert_array_equal(got, want)
+    assert (ids[got[got >= 0]] != -1).all()
+    assert (feature_matching(q, db, mt, db_3D_ids=np.full(600, -1)) == -1).all()      # <= 3 valid: early out
+    plain = feature_matching(q, db, mt)
+    np.testing.assert_array_equal(plain, orc.itloc_matcher(q, db, "nnm")["matches0"])

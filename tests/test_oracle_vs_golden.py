@@ -123,3 +123,24 @@ def test_matchers_match_reference(golden_dir, tag):
         p = orc.itloc_matcher(d0.astype(np.float64), d1.astype(np.float64), mode, 0.9)
         np.testing.assert_array_equal(p["matches0"], g[f"{tag}/itloc/{name}/matches0"])
         np.testing.assert_allclose(p["matching_scores0"], g[f"{tag}/itloc/{name}/scores0"], atol=1e-12)
+
+
+def test_nms_fast_and_extract_spp_match_reference(golden_dir, synth_sd):
+    """extract.py variant: greedy nms_fast and extract_spp_feats_singlescale."""
+    g = _load(golden_dir, "extract_spp_96x128.npz")
+    c = g["nf/corners"]
+    keep = orc.nms_fast(c[0], c[1], c[2], int(g["nf/h"]), int(g["nf/w"]), 4)
+    np.testing.assert_array_equal(keep, g["nf/inds"])          # same corners, same (score-descending) order
+    np.testing.assert_array_equal(c[:, keep], g["nf/out"])
+    assert int(g["n_ties"]) == 0
+    h, w = int(g["h"]), int(g["w"])
+    x = orc.norm_rgb(synth.make_image(h, w, int(g["seed"])))
+    pts, desc, scores, desc_full, heat = orc.extract_spp_feats_singlescale(synth_sd, x, float(g["conf_th"]))
+    np.testing.assert_allclose(heat, g["heat"], atol=1e-5, rtol=1e-4)
+    gp = g["pts"]
+    mine = {(int(a), int(b)): i for i, (a, b, _) in enumerate(pts)}
+    rank = np.array([mine.get((int(a), int(b)), -1) for a, b, _ in gp])
+    assert (rank >= 0).mean() >= 0.99 and abs(len(pts) - len(gp)) <= 2
+    ok = rank >= 0
+    np.testing.assert_allclose(pts[rank[ok], 2], gp[ok, 2], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(desc[rank[ok]], g["desc"].astype(np.float32)[ok], atol=2e-3)
