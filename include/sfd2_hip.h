@@ -187,6 +187,9 @@ typedef struct {
     int32_t launches;
 } sfd2_layer_timing;
 int sfd2_set_profiling(sfd2_ctx *ctx, int max_steps /* 0 = off */);
+/* Only launches whose kernel-family label contains `substr` are timed (NULL or "" = all): every
+ * event pair costs ~2-4 us of stream time, so a timed run brackets the kernel it reports on only. */
+int sfd2_set_profile_filter(sfd2_ctx *ctx, const char *substr);
 int sfd2_get_layer_timings(sfd2_ctx *ctx, sfd2_layer_timing *out, int cap, int *n);
 
 #ifdef __cplusplus

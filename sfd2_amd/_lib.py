@@ -53,6 +53,7 @@ EXPORTS = [
     "sfd2_select_keypoints", "sfd2_sample_descriptors", "sfd2_heatmap", "sfd2_debug_activation",
     "sfd2_match", "sfd2_match_batch", "sfd2_get_timings", "sfd2_sync", "sfd2_set_profiling",
     "sfd2_get_layer_timings", "sfd2_set_precision", "sfd2_extract_spp", "sfd2_nms_fast",
+    "sfd2_set_profile_filter",
 ]
 
 _lib = None
@@ -94,6 +95,7 @@ def load():
     lib.sfd2_sync.argtypes = [vp]
     lib.sfd2_set_precision.argtypes = [vp, ci]
     lib.sfd2_set_profiling.argtypes = [vp, ci]
+    lib.sfd2_set_profile_filter.argtypes = [vp, ctypes.c_char_p]
     lib.sfd2_get_layer_timings.argtypes = [vp, ctypes.POINTER(LayerTiming), ci, pi]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the .so lacks a declared symbol
@@ -175,7 +177,8 @@ class Context:
     def sync(self):
         check(self.lib.sfd2_sync(self.h))
 
-    def set_profiling(self, max_steps):
+    def set_profiling(self, max_steps, kernel_filter=None):
+        check(self.lib.sfd2_set_profile_filter(self.h, (kernel_filter or "").encode()))
         check(self.lib.sfd2_set_profiling(self.h, int(max_steps)))
 
     def layer_timings(self):

@@ -1,0 +1,182 @@
+// Fused stem: norm_RGB + conv1a (3->64, 3x3) + BN + ReLU + conv1b (64->64, 3x3, stride 2) + BN + ReLU
+// in one kernel (nets/extractor.py:104, nets/sfd2.py:268-270,314-316).  The 64-channel full-resolution
+// tensor between the two convolutions (245 MB at 1600x1200, written and re-read once) never leaves
+// the CU: each block computes the 9 x 65 conv1a pixels its 4 x 32 conv1b outputs need into LDS
+// (MFMA, K = 48), then runs conv1b from there (MFMA, K = 9 x 64), streaming the 9 filter taps
+// through a double-buffered direct-to-LDS copy.  HBM traffic: image in, H/2 x W/2 x 64 out.
+#include "sfd2_internal.h"
+
+#define NT 512           // 8 waves: wave -> (output row = wave >> 1, 32-channel half = wave & 1)
+#define F_TH 4           // conv1b output rows per block
+#define F_TW 32
+#define F_RH 9           // conv1a rows needed: 2*4 + 1
+#define F_RW 65
+#define F_RP (F_RH * F_RW)        // 585 conv1a pixels
+#define F_IH 11          // image rows needed
+#define F_IW 68          // image cols needed (67) + 1 so the zero-weight kx = 3 slot reads valid bytes
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __forceinline__ h4_t f_cvt4(float a, float b, float c, float d)
+{
+    h4_t r;
+    r[0] = (half_t)a; r[1] = (half_t)b; r[2] = (half_t)c; r[3] = (half_t)d;
+    return r;
+}
+
+__global__ __launch_bounds__(NT)
+void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalise,
+                       const half_t *__restrict__ w1 /*[2][3][64][8] conv1a A fragments*/,
+                       const float *__restrict__ sc1, const float *__restrict__ sh1,
+                       const half_t *__restrict__ w2 /*[9][64 oc][64 ic] conv1b*/,
+                       const float *__restrict__ sc2, const float *__restrict__ sh2,
+                       half_t *__restrict__ out /*[H2][W2][64]*/, int H2, int W2, int tiles_x)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *X1 = smem;                                         // [F_RP][128 B], 16-B slots swizzled with (rec >> 1) & 7
+    unsigned char *Wt = X1 + ((F_RP * 128 + 1023) & ~1023);           // [2][64][128 B], same swizzle
+    half_t *IM = reinterpret_cast<half_t *>(Wt + 2 * 8192);           // [F_IH][F_IW][4]
+    float *SS = reinterpret_cast<float *>(IM + F_IH * F_IW * 4);      // sc1, sh1, sc2, sh2 (64 each)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhi = lane >> 5;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int oy0 = ty * F_TH, ox0 = tx * F_TW;
+    const int ry0 = 2 * oy0 - 1, rx0 = 2 * ox0 - 1;                   // image coords of conv1a region pixel (0, 0)
+    const size_t plane = (size_t)H * W;
+
+    // filter tap t of conv1b -> Wt[buf]: 8 one-KB chunks (8 rows each), 1 per wave
+#define ISSUE_W2(tap_, buf_)                                                                              \
+    {                                                                                                     \
+        const int r = wave * 8 + (lane >> 3);                                                             \
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);                                                     \
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)(w2 + ((size_t)(tap_)*64 + r) * 64 + slot * 8),    \
+                                         (lds_void_t *)(Wt + (buf_)*8192 + wave * 1024), 16, 0, 0);       \
+    }
+    ISSUE_W2(0, 0)
+
+    // ---- image patch (normalised, fp16, 4 halves per pixel) and the four scale/shift vectors
+    for (int p = tid; p < F_IH * F_IW; p += NT) {
+        const int py = p / F_IW, px = p - py * F_IW;
+        const int iy = ry0 - 1 + py, ix = rx0 - 1 + px;
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const size_t o = (size_t)iy * W + ix;
+            r = img[o]; g = img[plane + o]; b = img[2 * plane + o];
+            if (normalise) {
+                r = __fdiv_rn(__fsub_rn(r, 0.485f), 0.229f);
+                g = __fdiv_rn(__fsub_rn(g, 0.456f), 0.224f);
+                b = __fdiv_rn(__fsub_rn(b, 0.406f), 0.225f);
+            }
+        }
+        *reinterpret_cast<h4_t *>(IM + p * 4) = f_cvt4(r, g, b, 0.0f);
+    }
+    if (tid < 64) { SS[tid] = sc1[tid]; SS[64 + tid] = sh1[tid]; SS[128 + tid] = sc2[tid]; SS[192 + tid] = sh2[tid]; }
+    h8_t a1[2][3];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+            a1[ct][ky] = *reinterpret_cast<const h8_t *>(w1 + ((size_t)(ct * 3 + ky) * 64 + lane) * 8);
+    __syncthreads();
+
+    // ---- phase 1: conv1a on the 585 region pixels, 32 per MFMA column block
+    for (int t = wave; t < (F_RP + 31) / 32; t += NT / 64) {
+        const int p = t * 32 + lrow;
+        const int pc = p < F_RP ? p : F_RP - 1;
+        const int ry = pc / F_RW, rx = pc - ry * F_RW;
+        f32x16_t acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int q = (ry + ky) * F_IW + rx + 2 * lhi;
+            const h4_t lo = *reinterpret_cast<const h4_t *>(IM + q * 4);
+            const h4_t hi = *reinterpret_cast<const h4_t *>(IM + (q + 1) * 4);
+            h8_t b;
+            b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3];
+            b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ct][ky], b, acc[ct], 0, 0, 0);
+        }
+        // conv1b zero-pads conv1a's OUTPUT: region pixels outside the image are zeros, not conv1a(0)
+        const int gy = ry0 + ry, gx = rx0 + rx;
+        const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        if (p < F_RP) {
+            const int sw = (p >> 1) & 7;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = ct * 32 + 8 * q + 4 * lhi;
+                    const float4 s = *reinterpret_cast<const float4 *>(SS + c0);
+                    const float4 h = *reinterpret_cast<const float4 *>(SS + 64 + c0);
+                    h4_t v = f_cvt4(0.f, 0.f, 0.f, 0.f);
+                    if (inside)
+                        v = f_cvt4(fmaxf(acc[ct][4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc[ct][4 * q + 1] * s.y + h.y, 0.0f),
+                                   fmaxf(acc[ct][4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc[ct][4 * q + 3] * s.w + h.w, 0.0f));
+                    *reinterpret_cast<h4_t *>(X1 + p * 128 + (((c0 >> 3) ^ sw) << 4) + (c0 & 4) * 2) = v;
+                }
+        }
+    }
+    __syncthreads();   // X1 complete; also drains the tap-0 filter copy
+
+    // ---- phase 2: conv1b (stride 2): wave -> (output row, 32-channel half)
+    const int orow = wave >> 1, cth = wave & 1;
+    f32x16_t acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.0f;
+    const int ar = cth * 32 + lrow;
+    const int a_off = ar * 128, a_sw = (ar >> 1) & 7;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int buf = tap & 1;
+        if (tap + 1 < 9) { ISSUE_W2(tap + 1, buf ^ 1) }
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int q = (2 * orow + ky) * F_RW + 2 * lrow + kx;
+        const unsigned char *xq = X1 + q * 128;
+        const int bsw = (q >> 1) & 7;
+        const unsigned char *wt = Wt + buf * 8192;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int slot = kk * 2 + lhi;
+            const h8_t b = *reinterpret_cast<const h8_t *>(xq + ((slot ^ bsw) << 4));
+            const h8_t a = *reinterpret_cast<const h8_t *>(wt + a_off + ((slot ^ a_sw) << 4));
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#undef ISSUE_W2
+
+    const int oy = oy0 + orow, ox = ox0 + lrow;
+    if (oy < H2 && ox < W2) {
+        half_t *o = out + ((size_t)oy * W2 + ox) * 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = cth * 32 + 8 * q + 4 * lhi;
+            const float4 s = *reinterpret_cast<const float4 *>(SS + 128 + c0);
+            const float4 h = *reinterpret_cast<const float4 *>(SS + 192 + c0);
+            *reinterpret_cast<h4_t *>(o + c0) =
+                f_cvt4(fmaxf(acc2[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc2[4 * q + 1] * s.y + h.y, 0.0f),
+                       fmaxf(acc2[4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc2[4 * q + 3] * s.w + h.w, 0.0f));
+        }
+    }
+}
+
+void launch_fused_stem(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *w1, const float *sc1,
+                       const float *sh1, const half_t *w2, const float *sc2, const float *sh2, half_t *out, int H2, int W2)
+{
+    static bool attr_done = false;
+    const size_t lds = (size_t)((F_RP * 128 + 1023) & ~1023) + 2 * 8192 + (size_t)F_IH * F_IW * 4 * sizeof(half_t) + 256 * sizeof(float);
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int tiles_x = (W2 + F_TW - 1) / F_TW, tiles_y = (H2 + F_TH - 1) / F_TH;
+    hipLaunchKernelGGL(fused_stem_kernel, dim3(tiles_x * tiles_y), dim3(NT), lds, st, img, H, W, normalise, w1, sc1, sh1, w2,
+                       sc2, sh2, out, H2, W2, tiles_x);
+}

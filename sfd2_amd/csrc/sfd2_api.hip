@@ -64,7 +64,9 @@ struct sfd2_ctx {
     bool weights_loaded = false;
     // weights
     ConvW c1a, c1b, c2a, c2b, c3a, c3b, rb1[3], rb2[3], rb3[3], pa0, pa3, da0, da3, pb, db;
-    DevBuf sta_w, sta_b, zero_page;
+    DevBuf sta_w, sta_b, zero_page, w1b_fused;   // w1b_fused: conv1b filters as [9][64][64] for the fused stem
+    int fuse = 1;                                  // fused kernels on the extract path (SFD2_NO_FUSE=1 disables)
+    int fuse_now = 0;                              // set per call: sfd2_det keeps every intermediate readable
     // strict fp32 mode
     int precision = SFD2_PREC_F16;
     ConvW f1a, f1b, f2a, f2b, f3a, f3b, frb1[3], frb2[3], frb3[3], fpa0, fpa3, fda0, fda3, fpb, fdb;
@@ -90,6 +92,7 @@ struct sfd2_ctx {
     std::vector<sfd2_layer_timing> prof_tab;  // slot -> descriptor + accumulators
     std::vector<int> prof_used;               // [max_steps] slots recorded in that step
     std::vector<int> prof_row;                // [max_steps][PROF_SLOTS] -> row of prof_tab
+    std::string prof_filter;                  // only kernel labels containing this are timed
 };
 
 #define PROF_SLOTS 48
@@ -98,6 +101,7 @@ struct ProfScope {   // records an event pair around one launch when profiling i
     ProfScope(sfd2_ctx *c_, const char *name, const char *kernel, double flops, double bytes) : c(c_), slot(-1)
     {
         if (c->prof_max_steps <= 0 || c->prof_step >= c->prof_max_steps || c->prof_slot >= PROF_SLOTS) return;
+        if (!c->prof_filter.empty() && strstr(kernel, c->prof_filter.c_str()) == nullptr) return;
         slot = c->prof_slot++;
         int row = -1;  // table rows are keyed by stage name (extract and match steps interleave)
         for (size_t i = 0; i < c->prof_tab.size(); ++i)
@@ -144,6 +148,7 @@ extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
     HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; ++i) HIPCHECK(hipEventCreate(&c->ev[i]));
     HIPCHECK(hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming));
+    c->fuse = getenv("SFD2_NO_FUSE") ? 0 : 1;
     HIPCHECK(c->zero_page.ensure(256));
     HIPCHECK(hipMemset(c->zero_page.p, 0, 256));
     *out = c;
@@ -155,7 +160,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
+    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
                       &c->rt1[0], &c->rt1[1], &c->rt1[2], &c->rt2[0], &c->rt2[1], &c->rt2[2], &c->ro[0], &c->ro[1],
                       &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
                       &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->bnd, &c->sel, &c->sorted, &c->counters,
@@ -386,6 +391,14 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
     }
     if (pack_conv1a(c, m)) return -1;
     if (pack_igemm(c, m, c->c1b, "conv1b.0", "bn1b.0", 64, 64, 3, 2)) return -1;
+    {   // the same filters as [tap][oc][ic] for the fused stem kernel
+        const TView *w = find_t(m, "conv1b.0.weight");
+        std::vector<half_t> pk((size_t)9 * 64 * 64);
+        for (int t = 0; t < 9; ++t)
+            for (int oc = 0; oc < 64; ++oc)
+                for (int ic = 0; ic < 64; ++ic) pk[((size_t)t * 64 + oc) * 64 + ic] = (half_t)w->d[((size_t)oc * 64 + ic) * 9 + t];
+        if (upload(c->w1b_fused, pk.data(), pk.size() * sizeof(half_t), c->stream)) return -1;
+    }
     if (pack_igemm(c, m, c->c2a, "conv2a.0", "conv2a.1", 64, 128, 3, 1)) return -1;
     if (pack_igemm(c, m, c->c2b, "conv2b.0", "bn2b.0", 128, 128, 3, 2)) return -1;
     if (pack_igemm(c, m, c->c3a, "conv3a.0", "conv3a.1", 128, 256, 3, 1)) return -1;
@@ -602,12 +615,20 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     hipStream_t st = c->stream;
     const int H = c->H, W = c->W, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
     const double P1 = (double)H * W, P4 = (double)H4 * W4, P8 = (double)H8 * W8;
-    {
-        ProfScope ps(c, "conv1a", "conv1a_kernel", 2.0 * P1 * 64 * 27, P1 * (12 + 128));
-        launch_conv1a(st, img_dev, H, W, normalise, c->c1a.w.as<half_t>(), c->c1a.scale.as<float>(),
-                      c->c1a.shift.as<float>(), c->a1a.as<half_t>());
+    if (c->fuse_now) {
+        ProfScope ps(c, "conv1a+conv1b", "fused_stem_kernel", 2.0 * P1 * 64 * 27 + 2.0 * (double)H2 * W2 * 64 * 576,
+                     P1 * 12 + (double)H2 * W2 * 128);
+        launch_fused_stem(st, img_dev, H, W, normalise, c->c1a.w.as<half_t>(), c->c1a.scale.as<float>(),
+                          c->c1a.shift.as<float>(), c->w1b_fused.as<half_t>(), c->c1b.scale.as<float>(),
+                          c->c1b.shift.as<float>(), c->a1b.as<half_t>(), H2, W2);
+    } else {
+        {
+            ProfScope ps(c, "conv1a", "conv1a_kernel", 2.0 * P1 * 64 * 27, P1 * (12 + 128));
+            launch_conv1a(st, img_dev, H, W, normalise, c->c1a.w.as<half_t>(), c->c1a.scale.as<float>(),
+                          c->c1a.shift.as<float>(), c->a1a.as<half_t>());
+        }
+        conv(c, "conv1b", c->c1b, c->a1a, H, W, c->a1b, H2, W2, 1);
     }
-    conv(c, "conv1b", c->c1b, c->a1a, H, W, c->a1b, H2, W2, 1);
     conv(c, "conv2a", c->c2a, c->a1b, H2, W2, c->a2a, H2, W2, 1);
     conv(c, "conv2b", c->c2b, c->a2a, H2, W2, c->a2b, H4, W4, 1);
     conv(c, "conv3a", c->c3a, c->a2b, H4, W4, c->a3a, H4, W4, 1);
@@ -671,6 +692,7 @@ extern "C" int sfd2_det(sfd2_ctx *c, const float *x, int x_on_device, int H, int
     const float *img = nullptr;
     if (stage_image(c, x, x_on_device, H, W, &img)) return -1;
     prof_step_begin(c);
+    c->fuse_now = 0;   // det is the parity entry point: every activation stays readable (sfd2_debug_activation)
     if (run_network(c, img, (flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1)) return -1;
     prof_step_end(c);
     const int HS = 8 * c->H8, WS = 8 * c->W8;
@@ -753,6 +775,7 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const float *img, int img_on_device, in
     if (stage_image(c, img, img_on_device, H, W, &img_dev)) return -1;
     HIPCHECK(hipEventRecord(c->ev[0], c->stream));
     prof_step_begin(c);
+    c->fuse_now = c->fuse && c->precision == SFD2_PREC_F16;
     if (run_network(c, img_dev, (flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1)) return -1;
     HIPCHECK(hipEventRecord(c->ev[1], c->stream));
     const int HS = 8 * c->H8, WS = 8 * c->W8;
@@ -865,6 +888,7 @@ extern "C" int sfd2_extract_spp(sfd2_ctx *c, const float *x, int x_on_device, in
     const float *img_dev = nullptr;
     if (stage_image(c, x, x_on_device, H, W, &img_dev)) return -1;
     prof_step_begin(c);
+    c->fuse_now = c->fuse && c->precision == SFD2_PREC_F16;
     if (run_network(c, img_dev, 0)) return -1;   // the caller normalised the image (extract.py:280-287)
     const int HS = 8 * c->H8, WS = 8 * c->W8;
     launch_heatmap(c->stream, c->score.as<float>(), HS, WS, (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(),
@@ -1205,6 +1229,13 @@ extern "C" int sfd2_set_profiling(sfd2_ctx *c, int max_steps)
     c->prof_used.assign(max_steps, 0);
     c->prof_row.assign((size_t)max_steps * PROF_SLOTS, 0);
     c->prof_tab.clear();
+    return 0;
+}
+
+extern "C" int sfd2_set_profile_filter(sfd2_ctx *c, const char *substr)
+{
+    if (!c) return fail("sfd2_set_profile_filter: null ctx");
+    c->prof_filter = substr ? substr : "";
     return 0;
 }
 

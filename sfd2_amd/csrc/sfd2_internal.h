@@ -18,6 +18,10 @@ void launch_conv1a(hipStream_t st, const float *img_chw, int H, int W, int norma
                    const half_t *wpk /*[2][3][64][8]*/, const float *scale, const float *shift,
                    half_t *out /*[H][W][64]*/);
 
+// Fused stem: norm_RGB + conv1a + BN + ReLU + conv1b (stride 2) + BN + ReLU; w2 = [9][64 oc][64 ic] fp16
+void launch_fused_stem(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *w1, const float *sc1,
+                       const float *sh1, const half_t *w2, const float *sc2, const float *sh2, half_t *out, int H2, int W2);
+
 // Implicit-GEMM conv on MFMA (3x3 or 1x1, stride 1 or 2, Cin % 32 == 0, Cout_pad % 64 == 0).
 //   in  [H][W][Cin] fp16,  wpk [Cin/cc][ks*ks][Cout_pad][cc] fp16 (cc = conv_igemm_chunk),  scale/shift [Cout_pad]
 //   out [Ho][Wo][Cout_pad] fp16 (relu / residual optional) or fp32 (out_f32)
