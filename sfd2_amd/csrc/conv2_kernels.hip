@@ -35,7 +35,7 @@ __device__ __forceinline__ h4_t cvt4b(float a, float b, float c, float d)
     return r;
 }
 
-template <int KS, int BN, int CC, bool OUT_F32, bool HAS_RES>
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES>
 __global__ __launch_bounds__(NT2, 2)
 void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                         const half_t *__restrict__ wpk, const float *__restrict__ scale,
@@ -45,7 +45,8 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 {
     constexpr int T = KS * KS;
     constexpr int PAD = KS / 2;
-    constexpr int PH = TH2 - 1 + KS, PW = TW - 1 + KS;
+ constexpr int THT = (STRIDE == 1) ? TH2 : 4;      // output rows per tile: 8 (stride 1) or 4 (stride 2: the patch is 2x larger)
+    constexpr int PH = (THT - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
     constexpr int NPIX = PH * PW;
     constexpr int RB = CC * 2;                         // bytes per record (one pixel / one filter row of a K chunk)
     constexpr int RPC = 1024 / RB;                     // records per 1 KB LDS-DMA chunk (16 or 8)
@@ -58,7 +59,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     constexpr int XBYTES = XCH * 1024, WBYTES = BN * RB;
     constexpr int WAVES_CH = 2, WAVES_PX = 4;
     constexpr int CH_T = BN / WAVES_CH / 32;           // 2 or 4
-    constexpr int PX_T = TH2 / WAVES_PX;               // 2 image rows per wave
+    constexpr int PX_T = THT / WAVES_PX;               // image rows per wave (2 or 1)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Xs = smem;                          // [2][XBYTES]
@@ -75,7 +76,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     const int tn = swz % n_tiles_n;
     const int tsp = swz / n_tiles_n;
     const int tx = tsp % tiles_x, ty = tsp / tiles_x;
-    const int oy0 = ty * TH2, ox0 = tx * TW, n0 = tn * BN;
+    const int oy0 = ty * THT, ox0 = tx * TW, n0 = tn * BN;
 
     // ---- per-lane staging sources (element offsets into `in`; -1 = zero page)
     int xoff[XPW];
@@ -87,7 +88,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         int off = -1;
         if (chunk < XCH && q < NPIX) {
             const int py = q / PW, px = q - py * PW;
-            const int iy = oy0 - PAD + py, ix = ox0 - PAD + px;
+            const int iy = oy0 * STRIDE - PAD + py, ix = ox0 * STRIDE - PAD + px;
             if (iy >= 0 && iy < H && ix >= 0 && ix < W) off = (iy * W + ix) * Cin + slot * 8;
         }
         xoff[i] = off;
@@ -156,7 +157,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         int b_off[PX_T], b_sw[PX_T];
 #pragma unroll
         for (int pr = 0; pr < PX_T; ++pr) {
-            const int q = (wrow + pr + ky) * PW + lrow + kx;
+            const int q = ((wrow + pr) * STRIDE + ky) * PW + lrow * STRIDE + kx;
             b_off[pr] = q * RB;
             b_sw[pr] = (q >> SWS) & (SPR - 1);
         }
@@ -239,22 +240,23 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     }
 }
 
-template <int KS, int BN, int CC, bool OUT_F32, bool HAS_RES>
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES>
 static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                             const float *scale, const float *shift, int CoutP, int relu, const half_t *res,
                             void *out, int Ho, int Wo, const half_t *zero_page)
 {
-    constexpr int PH = TH2 - 1 + KS, PW = TW - 1 + KS;
+    constexpr int THT = (STRIDE == 1) ? TH2 : 4;
+    constexpr int PH = (THT - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
     constexpr int RPC = 1024 / (CC * 2);
     constexpr int XCH = (PH * PW + RPC - 1) / RPC;
     constexpr size_t lds = (size_t)2 * XCH * 1024 + (size_t)2 * BN * CC * 2 + (size_t)2 * BN * sizeof(float);
     static bool attr_done = false;
-    auto kern = conv_igemm2_kernel<KS, BN, CC, OUT_F32, HAS_RES>;
+    auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH2 - 1) / TH2;
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + THT - 1) / THT;
     const int grid = tiles_x * tiles_y * (CoutP / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT2), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, res, out,
                        Ho, Wo, tiles_x, zero_page);
@@ -263,8 +265,9 @@ static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int 
 // K-chunk width the v2 kernel wants the filters packed with (0 = layer is not served by v2)
 int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin)
 {
-    if (stride != 1 || CoutP % 128 != 0) return 0;
-    (void)ks;
+    if (CoutP % 128 != 0) return 0;
+    if (stride == 2) return (ks == 3) ? 32 : 0;        // stride-2 3x3: 4-row tiles, 32-wide chunks (patch 9 x 65 records)
+    if (stride != 1) return 0;
     // 256-channel tiles: 64-wide K chunks (one block per CU either way, half the barriers);
     // 128-channel tiles: 32-wide chunks keep the LDS footprint at 60 KB -> two blocks per CU
     static const bool bn128 = getenv("SFD2_CONV_BN128") != nullptr;   // experiment: 128-channel tiles everywhere
@@ -274,13 +277,19 @@ int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin)
 
 // returns false when the (ks, Cout tile) combination has no v2 instantiation
 bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
-                        const float *scale, const float *shift, int CoutP, int ks, int relu,
+                        const float *scale, const float *shift, int CoutP, int ks, int stride, int relu,
                         const half_t *residual, void *out, int out_f32, int Ho, int Wo, const half_t *zero_page)
 {
+    if (stride == 2) {
+        if (conv_igemm2_chunk(ks, 2, CoutP, Cin) != 32 || residual || out_f32) return false;
+        if (CoutP % 256 == 0) launch_igemm2_t<3, 2, 256, 32, false, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
+        else launch_igemm2_t<3, 2, 128, 32, false, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
+        return true;
+    }
 #define SFD2_IG2B(KS_, BN_, CC_, F32_)                                                                                   \
     do {                                                                                                                \
-        if (residual) launch_igemm2_t<KS_, BN_, CC_, F32_, true>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); \
-        else launch_igemm2_t<KS_, BN_, CC_, F32_, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);         \
+        if (residual) launch_igemm2_t<KS_, 1, BN_, CC_, F32_, true>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); \
+        else launch_igemm2_t<KS_, 1, BN_, CC_, F32_, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);         \
     } while (0)
 #define SFD2_IG2(KS_, BN_, F32_)                                         \
     do {                                                                 \

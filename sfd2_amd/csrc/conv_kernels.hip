@@ -240,7 +240,7 @@ static void launch_igemm_t(hipStream_t st, const half_t *in, int H, int W, int C
 }
 
 bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
-                        const float *scale, const float *shift, int CoutP, int ks, int relu,
+                        const float *scale, const float *shift, int CoutP, int ks, int stride, int relu,
                         const half_t *residual, void *out, int out_f32, int Ho, int Wo, const half_t *zero_page);
 int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin);
 
@@ -261,8 +261,8 @@ void launch_conv_igemm(hipStream_t st, const half_t *in, int H, int W, int Cin, 
                        const half_t *residual, void *out, int out_f32, int Ho, int Wo, const half_t *zero_page)
 {
     // second-generation kernel (conv2_kernels.hip) for the stride-1 layers; SFD2_CONV_V1=1 forces the first
-    if (getenv("SFD2_CONV_V1") == nullptr && stride == 1 && zero_page &&
-        launch_conv_igemm2(st, in, H, W, Cin, wpk, scale, shift, CoutP, ks, relu, residual, out, out_f32, Ho, Wo, zero_page))
+    if (getenv("SFD2_CONV_V1") == nullptr && zero_page &&
+        launch_conv_igemm2(st, in, H, W, Cin, wpk, scale, shift, CoutP, ks, stride, relu, residual, out, out_f32, Ho, Wo, zero_page))
         return;
 #define SFD2_IGEMM(KS_, ST_, BN_, F32_)                                                                               \
     do {                                                                                                              \

@@ -183,11 +183,12 @@ void match_top2_kernel(const MatchJob *__restrict__ jobs, int splits)
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
+#define TA2 64        // candidate rows per LDS stage in the v2 kernel (16 KB; 128 measured slower: fewer blocks per CU)
 template <bool NEED2>
-__global__ __launch_bounds__(NT, 2)
+__global__ __launch_bounds__(NT, 2)   // 140 VGPRs -> 3 blocks per CU; forcing 4 (128 VGPRs) spills and measured slower
 void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const half_t *__restrict__ zero_page)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][TA][256 B]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][TA2][256 B]
     const MatchJob job = jobs[blockIdx.z];
     const int na = job.na, nb = job.nb;
     const int i_base = blockIdx.x * 256;
@@ -219,17 +220,17 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
     int i1[2] = {0, 0};
 
     if (ja0 < ja1) {
-        const int nst = (ja1 - ja0 + TA - 1) / TA;
-        // staging: 16 one-KB chunks (4 rows each) per stage, 4 per wave
+        const int nst = (ja1 - ja0 + TA2 - 1) / TA2;
+        // staging: TA2/4 one-KB chunks (4 rows each) per stage, TA2/16 per wave
         const int srow = lane >> 4;                                  // row within the chunk
 #define ISSUE_A(stage_, buf_)                                                                            \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                      \
-        const int row = (wave * 4 + c) * 4 + srow;                                                       \
+    _Pragma("unroll") for (int c = 0; c < TA2 / 16; ++c) {                                               \
+        const int row = (wave * (TA2 / 16) + c) * 4 + srow;                                                       \
         const int slot = (lane & 15) ^ (row & 15);                                                       \
-        const int ja = ja0 + (stage_)*TA + row;                                                          \
+        const int ja = ja0 + (stage_)*TA2 + row;                                                          \
         const half_t *src = ja < ja1 ? job.a_hi + (size_t)ja * KD + slot * 8 : zero_page + (lane & 3) * 8; \
         __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                              \
-                                         (lds_void_t *)(smem + (buf_)*TA * 256 + (wave * 4 + c) * 1024), 16, 0, 0); \
+                                         (lds_void_t *)(smem + (buf_)*TA2 * 256 + (wave * (TA2 / 16) + c) * 1024), 16, 0, 0); \
     }
         ISSUE_A(0, 0)
         __syncthreads();
@@ -237,12 +238,12 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
             const int buf = s & 1;
             if (s + 1 < nst) { ISSUE_A(s + 1, buf ^ 1) }
 #pragma unroll
-            for (int sub = 0; sub < TA / 32; ++sub) {
+            for (int sub = 0; sub < TA2 / 32; ++sub) {
                 f32x16_t acc0, acc1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
                 const int row = sub * 32 + lcol;
-                const unsigned char *arow = smem + (buf * TA + row) * 256;
+                const unsigned char *arow = smem + (buf * TA2 + row) * 256;
                 const int sw = row & 15;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
@@ -250,8 +251,8 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[0][ks], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[1][ks], acc1, 0, 0, 0);
                 }
-                const int jbase = ja0 + s * TA + sub * 32 + 4 * lhi;
-                const bool full = ja0 + s * TA + sub * 32 + 32 <= ja1;   // wave-uniform: no row of this sub-tile is padding
+                const int jbase = ja0 + s * TA2 + sub * 32 + 4 * lhi;
+                const bool full = ja0 + s * TA2 + sub * 32 + 32 <= ja1;   // wave-uniform: no row of this sub-tile is padding
                 if (!NEED2 && full) {
                     // top-1 only: one max tree per tile; the per-element index scan runs only in the
                     // (increasingly rare) case that some lane's running maximum is beaten
@@ -323,7 +324,13 @@ void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int 
     }
     if (!use_lo && zero_page && getenv("SFD2_MATCH_V1") == nullptr) {
         const dim3 grid((max_nb + 255) / 256, splits, njobs);
-        const size_t lds = (size_t)2 * TA * 256;
+        const size_t lds = (size_t)2 * TA2 * 256;
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_v2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_v2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr2 = true;
+        }
         if (need_top2) hipLaunchKernelGGL(match_top2_v2_kernel<true>, grid, dim3(NT), lds, st, jobs_dev, splits, zero_page);
         else hipLaunchKernelGGL(match_top2_v2_kernel<false>, grid, dim3(NT), lds, st, jobs_dev, splits, zero_page);
         return;
