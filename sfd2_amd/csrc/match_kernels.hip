@@ -311,6 +311,264 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
     }
 }
 
+// ---------------------------------------------------------------- single-GEMM mutual NN (top-1 both ways)
+// The two directions of the mutual check are the row and the column maxima of ONE similarity matrix.
+// With candidates on the MFMA rows and queries on the columns, the row direction is lane-local (as
+// above).  The column direction (best query per candidate) is reduced here without a second GEMM:
+//   1. element-wise max of the wave's two query tiles               (16 v_max per 32 candidates)
+//   2. max over the 32 lanes of each half-wave with DPP row shifts + one row broadcast
+//      (5 v_max_dpp per register; the result sits in lanes 31 / 63)
+//   3. only if a candidate's running best (kept in LDS) is beaten: recover the winning query from
+//      ballots and publish (value, query) with one 64-bit LDS atomic max.
+// Per block the column results are partial (its 256 queries); the finalize step merges blocks.
+__device__ __forceinline__ unsigned int f32_ord(float v)
+{
+    const unsigned int b = __float_as_uint(v);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);   // order-preserving map float -> uint
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max(float v)
+{
+    const int t = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return fmaxf(v, __int_as_float(t));
+}
+__device__ __forceinline__ float half_wave_max_to_last_lane(float v)
+{
+    v = dpp_max<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_max<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_max<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_max<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every 16-lane row holds the row maximum
+    v = dpp_max<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold the half-wave maximum
+    return v;
+}
+
+#define MF_CHUNK 1024   // candidates per block (LDS column state): 8 KB keys + 4 KB filter values
+
+__global__ __launch_bounds__(NT, 2)
+void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const half_t *__restrict__ zero_page)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *colkey = reinterpret_cast<unsigned long long *>(smem + 2 * TA2 * 256);   // [MF_CHUNK]
+    float *colbest = reinterpret_cast<float *>(colkey + MF_CHUNK);                               // [MF_CHUNK]
+    const MatchJob2 job = jobs[blockIdx.z];
+    const int na = job.n1, nb = job.n0;          // a = database (candidates), b = queries
+    const int i_base = blockIdx.x * 256;
+    if (i_base >= nb) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lcol = lane & 31, lhi = lane >> 5;
+
+    int chunk = (na + splits - 1) / splits;
+    chunk = (chunk + 31) & ~31;
+    const int ja0 = blockIdx.y * chunk;
+    int ja1 = ja0 + chunk;
+    if (ja1 > na) ja1 = na;
+
+    for (int j = tid; j < MF_CHUNK; j += NT) { colkey[j] = 0ull; colbest[j] = -INFINITY; }
+
+    h8_t bq[2][8];
+    float qmask[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int qi = i_base + wave * 64 + t * 32 + lcol;
+        qmask[t] = qi < nb ? 0.0f : -INFINITY;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            h8_t z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (half_t)0.0f;
+            bq[t][ks] = z;
+            if (qi < nb) bq[t][ks] = *reinterpret_cast<const h8_t *>(job.q_hi + (size_t)qi * KD + ks * 16 + lhi * 8);
+        }
+    }
+    const bool partial_q = i_base + wave * 64 + 64 > nb;     // wave-uniform: some query column is padding
+    float b1[2] = {-INFINITY, -INFINITY};
+    int i1[2] = {0, 0};
+
+    if (ja0 < ja1) {
+        const int nst = (ja1 - ja0 + TA2 - 1) / TA2;
+        const int srow = lane >> 4;
+#define ISSUE_A(stage_, buf_)                                                                            \
+    _Pragma("unroll") for (int c = 0; c < TA2 / 16; ++c) {                                               \
+        const int row = (wave * (TA2 / 16) + c) * 4 + srow;                                              \
+        const int slot = (lane & 15) ^ (row & 15);                                                       \
+        const int ja = ja0 + (stage_)*TA2 + row;                                                         \
+        const half_t *src = ja < ja1 ? job.d_hi + (size_t)ja * KD + slot * 8 : zero_page + (lane & 3) * 8; \
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                              \
+                                         (lds_void_t *)(smem + (buf_)*TA2 * 256 + (wave * (TA2 / 16) + c) * 1024), 16, 0, 0); \
+    }
+        ISSUE_A(0, 0)
+        __syncthreads();
+        for (int s = 0; s < nst; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nst) { ISSUE_A(s + 1, buf ^ 1) }
+#pragma unroll
+            for (int sub = 0; sub < TA2 / 32; ++sub) {
+                f32x16_t acc0, acc1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+                const int row = sub * 32 + lcol;
+                const unsigned char *arow = smem + (buf * TA2 + row) * 256;
+                const int sw = row & 15;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const h8_t a = *reinterpret_cast<const h8_t *>(arow + (((ks * 2 + lhi) ^ sw) << 4));
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[0][ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[1][ks], acc1, 0, 0, 0);
+                }
+                const int jloc0 = s * TA2 + sub * 32 + 4 * lhi;          // candidate (within the chunk) of register 0
+                const int jbase = ja0 + jloc0;
+                const bool full = ja0 + s * TA2 + sub * 32 + 32 <= ja1;   // wave-uniform
+                // ---- row direction (best candidate per query): lane-local, lazy index scan
+                if (full) {
+                    float m0 = acc0[0], m1 = acc1[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) { m0 = fmaxf(m0, acc0[r]); m1 = fmaxf(m1, acc1[r]); }
+                    if (__any(m0 > b1[0])) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int j = jbase + (r & 3) + 8 * (r >> 2);
+                            i1[0] = acc0[r] > b1[0] ? j : i1[0]; b1[0] = fmaxf(b1[0], acc0[r]);
+                        }
+                    }
+                    if (__any(m1 > b1[1])) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int j = jbase + (r & 3) + 8 * (r >> 2);
+                            i1[1] = acc1[r] > b1[1] ? j : i1[1]; b1[1] = fmaxf(b1[1], acc1[r]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = jbase + (r & 3) + 8 * (r >> 2);
+                        const float v0 = j < ja1 ? acc0[r] : -INFINITY, v1 = j < ja1 ? acc1[r] : -INFINITY;
+                        i1[0] = v0 > b1[0] ? j : i1[0]; b1[0] = fmaxf(b1[0], v0);
+                        i1[1] = v1 > b1[1] ? j : i1[1]; b1[1] = fmaxf(b1[1], v1);
+                    }
+                }
+                // ---- column direction (best query per candidate)
+                if (partial_q) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc0[r] += qmask[0]; acc1[r] += qmask[1]; }
+                }
+                float red[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[r] = half_wave_max_to_last_lane(fmaxf(acc0[r], acc1[r]));
+                // lanes 31 / 63 compare with the running best of their 16 candidates
+                unsigned int imp = 0;
+                if (lcol == 31) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 cb = *reinterpret_cast<const float4 *>(colbest + jloc0 + 8 * g);
+                        const int jg = jbase + 8 * g;
+                        if (red[4 * g + 0] > cb.x && jg + 0 < ja1) imp |= 1u << (4 * g + 0);
+                        if (red[4 * g + 1] > cb.y && jg + 1 < ja1) imp |= 1u << (4 * g + 1);
+                        if (red[4 * g + 2] > cb.z && jg + 2 < ja1) imp |= 1u << (4 * g + 2);
+                        if (red[4 * g + 3] > cb.w && jg + 3 < ja1) imp |= 1u << (4 * g + 3);
+                    }
+                }
+                const unsigned int imp_lo = __builtin_amdgcn_readlane(imp, 31), imp_hi = __builtin_amdgcn_readlane(imp, 63);
+                if (imp_lo | imp_hi) {                       // rare once the running bests have warmed up
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (((imp_lo | imp_hi) >> r) & 1u) {
+                            const float m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(red[r]), 31));
+                            const float m_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(red[r]), 63));
+                            const float m = lhi ? m_hi : m_lo;
+                            const unsigned long long h0 = __ballot(acc0[r] == m), h1 = __ballot(acc1[r] == m);
+                            const unsigned int my = lhi ? 0xFFFFFFFFu : 0u;   // select this half's 32 ballot bits
+                            const unsigned int b0 = lhi ? (unsigned int)(h0 >> 32) : (unsigned int)h0;
+                            const unsigned int b1m = lhi ? (unsigned int)(h1 >> 32) : (unsigned int)h1;
+                            (void)my;
+                            const bool mine = (((lhi ? imp_hi : imp_lo) >> r) & 1u) != 0;
+                            if (mine && lcol == 31) {
+                                // lowest query index among the maxima: tile 0 first, then the lowest lane
+                                const int qi = b0 ? (__ffs(b0) - 1) : (32 + __ffs(b1m) - 1);
+                                const int i = i_base + wave * 64 + qi;
+                                const int jl = jloc0 + (r & 3) + 8 * (r >> 2);
+                                const unsigned long long key = ((unsigned long long)f32_ord(m) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)i);
+                                atomicMax(&colkey[jl], key);
+                                colbest[jl] = fmaxf(colbest[jl], m);   // a filter only: a stale value just costs one more attempt
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+#undef ISSUE_A
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float c1 = __shfl_xor(b1[t], 32);
+        const int j1 = __shfl_xor(i1[t], 32);
+        float n1v;
+        int n1i;
+        if (c1 > b1[t] || (c1 == b1[t] && j1 < i1[t])) { n1v = c1; n1i = j1; }
+        else { n1v = b1[t]; n1i = i1[t]; }
+        const int qi = i_base + wave * 64 + t * 32 + lcol;
+        if (lane < 32 && qi < nb) {
+            const size_t o = (size_t)blockIdx.y * nb + qi;
+            job.part_v1[o] = n1v;
+            job.part_i1[o] = n1i;
+        }
+    }
+    __syncthreads();
+    // partial column results of this block's queries
+    for (int j = tid; j < ja1 - ja0; j += NT) job.rkeys[(size_t)blockIdx.x * na + ja0 + j] = colkey[j];
+}
+
+// merges the partials: forward [splits][n0] (value, index), reverse [n_iblocks][n1] packed keys
+__global__ __launch_bounds__(NT)
+void match_mutual_reduce_kernel(const MatchJob2 *__restrict__ jobs, const MatchFinal *__restrict__ fins, int splits)
+{
+    const MatchJob2 job = jobs[blockIdx.y];
+    const MatchFinal f = fins[blockIdx.y];
+    const int dir = blockIdx.z;
+    const int n = dir == 0 ? job.n0 : job.n1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float b1 = -INFINITY;
+    int bi = 0;
+    if (dir == 0) {
+        for (int s = 0; s < splits; ++s) {
+            const float c1 = job.part_v1[(size_t)s * n + i];
+            if (c1 > b1) { b1 = c1; bi = job.part_i1[(size_t)s * n + i]; }
+        }
+        f.red_f[i] = b1;
+        f.red_f[(size_t)n + i] = -INFINITY;
+        reinterpret_cast<int *>(f.red_f)[2 * (size_t)n + i] = bi;
+    } else {
+        const int nib = (job.n0 + 255) / 256;
+        unsigned long long best = 0ull;
+        for (int b = 0; b < nib; ++b) {
+            const unsigned long long k = job.rkeys[(size_t)b * n + i];
+            best = k > best ? k : best;
+        }
+        const unsigned int o = (unsigned int)(best >> 32);
+        const unsigned int bits = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;   // inverse of f32_ord
+        f.red_r[i] = best ? __uint_as_float(bits) : -INFINITY;
+        f.red_r[(size_t)n + i] = -INFINITY;
+        reinterpret_cast<int *>(f.red_r)[2 * (size_t)n + i] = best ? (int)(0xFFFFFFFFu - (unsigned int)(best & 0xFFFFFFFFull)) : 0;
+    }
+}
+
+void launch_match_mutual(hipStream_t st, const MatchJob2 *jobs_dev, const MatchFinal *fins_dev, int npairs, int max_n0,
+                         int max_n1, int splits, const half_t *zero_page)
+{
+    if (npairs <= 0 || max_n0 <= 0) return;
+    static bool attr = false;
+    const size_t lds = (size_t)2 * TA2 * 256 + (size_t)MF_CHUNK * 12;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_mutual_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(match_mutual_kernel, dim3((max_n0 + 255) / 256, splits, npairs), dim3(NT), lds, st, jobs_dev, splits, zero_page);
+    const int max_n = max_n0 > max_n1 ? max_n0 : max_n1;
+    hipLaunchKernelGGL(match_mutual_reduce_kernel, dim3((max_n + NT - 1) / NT, npairs, 2), dim3(NT), 0, st, jobs_dev, fins_dev, splits);
+}
+
 void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int max_nb, int splits, int use_lo,
                        int need_top2, const half_t *zero_page)
 {
@@ -415,6 +673,14 @@ void match_decide_kernel(const MatchFinal *__restrict__ fins, int flavour, int m
     }
     f.matches0[i] = m;
     f.scores0[i] = score;
+}
+
+void launch_match_decide(hipStream_t st, const MatchFinal *fin_dev, int npairs, int max_n, int flavour, int mutual,
+                         float ratio, float dist)
+{
+    if (npairs <= 0 || max_n <= 0) return;
+    hipLaunchKernelGGL(match_decide_kernel, dim3((max_n + NT - 1) / NT, npairs), dim3(NT), 0, st, fin_dev, flavour,
+                       mutual, ratio, dist);
 }
 
 void launch_match_finalize(hipStream_t st, const MatchFinal *fin_dev, int npairs, int max_n, int splits, int flavour,

@@ -83,7 +83,7 @@ struct sfd2_ctx {
     int cand_cap = 0;
     int last_sel_cap = 0;
     // matcher
-    DevBuf m_stage, m_hi0, m_lo0, m_hi1, m_lo1, m_part_f, m_part_i, m_red, m_jobs, m_fins, m_out_m, m_out_s;
+    DevBuf m_stage, m_hi0, m_lo0, m_hi1, m_lo1, m_part_f, m_part_i, m_red, m_jobs, m_fins, m_out_m, m_out_s, m_rkeys;
     sfd2_timings tim = {};
     std::map<std::string, ActInfo> acts;
     // per-launch profiling (sfd2_set_profiling)
@@ -168,7 +168,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
                       &c->m_part_f, &c->m_part_i, &c->m_red, &c->m_jobs, &c->m_fins, &c->m_out_m, &c->m_out_s,
                       &c->g1a, &c->g1b, &c->g2a, &c->g2b, &c->g3a, &c->g3b, &c->grt1[0], &c->grt1[1], &c->grt1[2],
                       &c->grt2[0], &c->grt2[1], &c->grt2[2], &c->gro[0], &c->gro[1], &c->gro[2], &c->gpa0_o, &c->gpa_o,
-                      &c->gda0_o, &c->gda_o, &c->g_keys, &c->g_state0, &c->g_state1, &c->g_kept};
+                      &c->gda0_o, &c->gda_o, &c->m_rkeys, &c->g_keys, &c->g_state0, &c->g_state1, &c->g_kept};
     for (DevBuf *b : bufs) b->release();
     ConvW *ws[] = {&c->c1a, &c->c1b, &c->c2a, &c->c2b, &c->c3a, &c->c3b, &c->rb1[0], &c->rb1[1], &c->rb1[2],
                    &c->rb2[0], &c->rb2[1], &c->rb2[2], &c->rb3[0], &c->rb3[1], &c->rb3[2], &c->pa0, &c->pa3,
@@ -1091,6 +1091,15 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     splits = std::min(splits, std::max(1, (min_n + 31) / 32));
     if (const char *e = getenv("SFD2_MATCH_SPLITS")) splits = std::max(1, std::min(16, atoi(e)));
 
+    const int need_top2 = (conf->flavour == SFD2_MATCH_ITLOC_NNR) ||
+                          (conf->flavour == SFD2_MATCH_HLOC && conf->ratio_threshold > 0.0f);
+    // Experiment (off by default, SFD2_MATCH_ONE_GEMM=1): both directions of the top-1 modes from ONE
+    // GEMM with a DPP column reduction (match_mutual_kernel).  Correct, but VALU-bound: measured
+    // 1103 us vs 470 us for the two-GEMM path on 50 x (4096 x 4096), so the second GEMM stays.
+    const bool single_gemm = !need_lo && !need_top2 && getenv("SFD2_MATCH_ONE_GEMM") != nullptr;
+    if (single_gemm) splits = std::max(splits, (max_n1 + 1023) / 1024);   // the kernel keeps <= 1024 candidates of column state
+    const int nib = (n0 + 255) / 256;
+
     HIPCHECK(c->m_stage.ensure(std::max<size_t>(stage_bytes, 256)));
     HIPCHECK(c->m_hi0.ensure((size_t)n0 * 128 * 2));
     if (need_lo) HIPCHECK(c->m_lo0.ensure((size_t)n0 * 128 * 2));
@@ -1100,6 +1109,7 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     const size_t per_pair_f = (size_t)splits * n0, tot_part = (size_t)k * per_pair_f + (size_t)splits * tot_n1;
     HIPCHECK(c->m_part_f.ensure(std::max<size_t>(tot_part, 1) * 2 * sizeof(float)));
     HIPCHECK(c->m_part_i.ensure(std::max<size_t>(tot_part, 1) * sizeof(int)));
+    if (single_gemm) HIPCHECK(c->m_rkeys.ensure(std::max<size_t>((size_t)nib * tot_n1, 1) * 8));
     HIPCHECK(c->m_red.ensure(((size_t)k * n0 + tot_n1 + 1) * 3 * sizeof(float)));
     HIPCHECK(c->m_jobs.ensure((size_t)2 * k * sizeof(MatchJob)));
     HIPCHECK(c->m_fins.ensure((size_t)k * sizeof(MatchFinal)));
@@ -1114,6 +1124,7 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
                  c->m_hi0.as<half_t>(), c->m_lo0.as<half_t>(), &q_hi, &q_lo)) return -1;
     // job descriptors live in pinned host memory owned by the context; the event makes sure the
     // previous call's async copies have consumed them before they are rewritten
+    static_assert(sizeof(MatchJob2) <= 2 * sizeof(MatchJob), "descriptor buffer sizing");
     const size_t jobs_bytes = 2 * (size_t)k * sizeof(MatchJob), fins_bytes = (size_t)k * sizeof(MatchFinal);
     HIPCHECK(hipEventSynchronize(c->ev_jobs));
     if (jobs_bytes + fins_bytes > c->pin_cap) {
@@ -1124,6 +1135,7 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
         c->pin_cap = jobs_bytes + fins_bytes;
     }
     MatchJob *jobs = reinterpret_cast<MatchJob *>(c->pin_jobs);
+    MatchJob2 *jobs2 = reinterpret_cast<MatchJob2 *>(c->pin_jobs);
     MatchFinal *fins = reinterpret_cast<MatchFinal *>(reinterpret_cast<char *>(c->pin_jobs) + jobs_bytes);
     float *pf = c->m_part_f.as<float>();
     int *pi = c->m_part_i.as<int>();
@@ -1137,19 +1149,28 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
                          c->m_hi1.as<half_t>() + off1 * 128, need_lo ? c->m_lo1.as<half_t>() + off1 * 128 : nullptr, &h, &l))
                 return -1;
         }
-        off1 += (size_t)n1;
-        MatchJob &f = jobs[2 * i], &r = jobs[2 * i + 1];
-        // forward: keep queries (d0), reduce over d1
-        f.a_hi = h; f.a_lo = l; f.b_hi = q_hi; f.b_lo = q_lo; f.na = n1; f.nb = n0;
-        f.part_v1 = pf + 2 * poff; f.part_v2 = pf + 2 * poff + (size_t)splits * n0; f.part_i1 = pi + poff;
-        poff += (size_t)splits * n0;
-        // reverse: keep d1 rows, reduce over queries
-        r.a_hi = q_hi; r.a_lo = q_lo; r.b_hi = h; r.b_lo = l; r.na = n0; r.nb = n1;
-        r.part_v1 = pf + 2 * poff; r.part_v2 = pf + 2 * poff + (size_t)splits * n1; r.part_i1 = pi + poff;
-        poff += (size_t)splits * n1;
         MatchFinal &fn = fins[i];
-        fn.f_v1 = f.part_v1; fn.f_v2 = f.part_v2; fn.f_i1 = f.part_i1;
-        fn.r_v1 = r.part_v1; fn.r_v2 = r.part_v2; fn.r_i1 = r.part_i1;
+        if (single_gemm) {
+            MatchJob2 &j2 = jobs2[i];
+            j2.q_hi = q_hi; j2.d_hi = h; j2.n0 = n0; j2.n1 = n1;
+            j2.part_v1 = pf + 2 * poff; j2.part_i1 = pi + poff;
+            j2.rkeys = c->m_rkeys.as<unsigned long long>() + (size_t)nib * off1;
+            poff += (size_t)splits * n0 + (size_t)splits * n1;
+            fn.f_v1 = fn.f_v2 = fn.r_v1 = fn.r_v2 = nullptr; fn.f_i1 = fn.r_i1 = nullptr;
+        } else {
+            MatchJob &f = jobs[2 * i], &r = jobs[2 * i + 1];
+            // forward: keep queries (d0), reduce over d1
+            f.a_hi = h; f.a_lo = l; f.b_hi = q_hi; f.b_lo = q_lo; f.na = n1; f.nb = n0;
+            f.part_v1 = pf + 2 * poff; f.part_v2 = pf + 2 * poff + (size_t)splits * n0; f.part_i1 = pi + poff;
+            poff += (size_t)splits * n0;
+            // reverse: keep d1 rows, reduce over queries
+            r.a_hi = q_hi; r.a_lo = q_lo; r.b_hi = h; r.b_lo = l; r.na = n0; r.nb = n1;
+            r.part_v1 = pf + 2 * poff; r.part_v2 = pf + 2 * poff + (size_t)splits * n1; r.part_i1 = pi + poff;
+            poff += (size_t)splits * n1;
+            fn.f_v1 = f.part_v1; fn.f_v2 = f.part_v2; fn.f_i1 = f.part_i1;
+            fn.r_v1 = r.part_v1; fn.r_v2 = r.part_v2; fn.r_i1 = r.part_i1;
+        }
+        off1 += (size_t)n1;
         fn.n0 = n0; fn.n1 = n1;
         fn.matches0 = c->m_out_m.as<long long>() + (size_t)i * n0;
         fn.scores0 = c->m_out_s.as<float>() + (size_t)i * n0;
@@ -1159,20 +1180,32 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     HIPCHECK(hipMemcpyAsync(c->m_jobs.p, jobs, jobs_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(c->m_fins.p, fins, fins_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipEventRecord(c->ev_jobs, c->stream));
-    {
-        // both directions: 2 GEMMs of n0 x n1 x 128 per pair (x3 products in the hi+lo mode)
-        ProfScope ps(c, "match_top2", need_lo ? "match_top2_kernel<x2>" : "match_top2_kernel",
-                     2.0 * 2.0 * (double)n0 * (double)tot_n1 * 128.0 * (need_lo ? 3.0 : 1.0),
-                     2.0 * 2.0 * ((double)k * n0 + (double)tot_n1) * 128.0);
-        const int need_top2 = (conf->flavour == SFD2_MATCH_ITLOC_NNR) ||
-                              (conf->flavour == SFD2_MATCH_HLOC && conf->ratio_threshold > 0.0f);
-        launch_match_top2(c->stream, c->m_jobs.as<MatchJob>(), 2 * k, max_n, splits, need_lo, need_top2,
-                          c->zero_page.as<half_t>());
-    }
-    {
-        ProfScope ps(c, "match_finalize", "match_reduce+decide", 0.0, (double)tot_part * 12);
-        launch_match_finalize(c->stream, c->m_fins.as<MatchFinal>(), k, max_n, splits, conf->flavour,
-                              conf->do_mutual_check, conf->ratio_threshold, conf->distance_threshold);
+    if (single_gemm) {
+        {
+            ProfScope ps(c, "match_mutual", "match_mutual_kernel", 2.0 * (double)n0 * (double)tot_n1 * 128.0,
+                         2.0 * ((double)k * n0 + (double)tot_n1) * 128.0);
+            launch_match_mutual(c->stream, c->m_jobs.as<MatchJob2>(), c->m_fins.as<MatchFinal>(), k, n0, max_n1, splits,
+                                c->zero_page.as<half_t>());
+        }
+        {
+            ProfScope ps(c, "match_finalize", "match_decide", 0.0, (double)tot_part * 12);
+            launch_match_decide(c->stream, c->m_fins.as<MatchFinal>(), k, max_n, conf->flavour, conf->do_mutual_check,
+                                conf->ratio_threshold, conf->distance_threshold);
+        }
+    } else {
+        {
+            // both directions: 2 GEMMs of n0 x n1 x 128 per pair (x3 products in the hi+lo mode)
+            ProfScope ps(c, "match_top2", need_lo ? "match_top2_kernel<x2>" : "match_top2_kernel",
+                         2.0 * 2.0 * (double)n0 * (double)tot_n1 * 128.0 * (need_lo ? 3.0 : 1.0),
+                         2.0 * 2.0 * ((double)k * n0 + (double)tot_n1) * 128.0);
+            launch_match_top2(c->stream, c->m_jobs.as<MatchJob>(), 2 * k, max_n, splits, need_lo, need_top2,
+                              c->zero_page.as<half_t>());
+        }
+        {
+            ProfScope ps(c, "match_finalize", "match_reduce+decide", 0.0, (double)tot_part * 12);
+            launch_match_finalize(c->stream, c->m_fins.as<MatchFinal>(), k, max_n, splits, conf->flavour,
+                                  conf->do_mutual_check, conf->ratio_threshold, conf->distance_threshold);
+        }
     }
     prof_step_end(c);
     HIPCHECK(hipGetLastError());

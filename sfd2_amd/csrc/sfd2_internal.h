@@ -103,6 +103,19 @@ struct MatchJob {          // one direction of one pair
 };
 void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int max_nb, int splits, int use_lo,
                        int need_top2, const half_t *zero_page);
+struct MatchJob2 {         // one pair, both directions from one GEMM (top-1 modes)
+    const half_t *q_hi;    // queries [n0][128]
+    const half_t *d_hi;    // database [n1][128]
+    int n0, n1;
+    float *part_v1;        // forward partials [splits][n0]
+    int *part_i1;
+    unsigned long long *rkeys;   // reverse partials [ceil(n0/256)][n1] packed (ordered value, ~query)
+};
+struct MatchFinal;
+void launch_match_mutual(hipStream_t st, const MatchJob2 *jobs_dev, const MatchFinal *fins_dev, int npairs, int max_n0,
+                         int max_n1, int splits, const half_t *zero_page);
+void launch_match_decide(hipStream_t st, const MatchFinal *fin_dev, int npairs, int max_n, int flavour, int mutual,
+                         float ratio, float dist);
 struct MatchFinal {
     const float *f_v1, *f_v2; const int *f_i1;   // forward partials [splits][n0]
     const float *r_v1, *r_v2; const int *r_i1;   // reverse partials [splits][n1]
