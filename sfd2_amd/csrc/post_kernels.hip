@@ -466,8 +466,10 @@ void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radi
 __global__ __launch_bounds__(1024)
 void select_threshold_kernel(int cand_cap, int top_k, unsigned int *__restrict__ counters)
 {
-    __shared__ unsigned int tsum[1024];
-    __shared__ unsigned int s_t, s_above;
+    // 65536 bins = 1024 threads x 64 bins.  Parallel: per-thread group sums, suffix scan over the
+    // 1024 groups (wave shuffles + 16 wave totals), then one wave resolves the bin inside the group.
+    __shared__ unsigned int wsum[16];
+    __shared__ unsigned int s_group, s_above;
     const unsigned int *hist = counters + 16;
     unsigned int n = counters[0];
     if (n > (unsigned int)cand_cap) n = cand_cap;
@@ -476,33 +478,43 @@ void select_threshold_kernel(int cand_cap, int top_k, unsigned int *__restrict__
         if (threadIdx.x == 0) { counters[1] = n; counters[2] = 0; counters[3] = 0; counters[4] = 0; counters[5] = 0; counters[6] = 1; }
         return;
     }
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     unsigned int sum = 0;
-    for (int b = 0; b < 64; ++b) sum += hist[64 * t + b];
-    tsum[t] = sum;
-    __syncthreads();
-    if (t == 0) {
-        unsigned int cum = 0;
-        int tt = 1023;
-        for (; tt > 0; --tt) {
-            if (cum + tsum[tt] >= k) break;
-            cum += tsum[tt];
-        }
-        s_t = tt;
-        s_above = cum;
+    const uint4 *h4 = reinterpret_cast<const uint4 *>(hist + 64 * t);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) { const uint4 v = h4[b]; sum += v.x + v.y + v.z + v.w; }
+    // inclusive suffix sum within the wave: suf = sum of groups t .. (wave end)
+    unsigned int suf = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int o = __shfl_down(suf, d);
+        if (lane + d < 64) suf += o;
     }
+    if (lane == 0) wsum[wave] = suf;          // total of this wave's 64 groups
+    if (t == 0) s_group = 0xFFFFFFFFu;
     __syncthreads();
-    if (t == 0) {
-        unsigned int cum = s_above;
-        int b = 64 * (int)s_t + 63;
-        for (; b > 64 * (int)s_t; --b) {
-            if (cum + hist[b] >= k) break;
-            cum += hist[b];
+    unsigned int higher = 0;                   // keys in all groups of higher waves
+    for (int w = wave + 1; w < 16; ++w) higher += wsum[w];
+    const unsigned int above_incl = higher + suf;          // keys in groups >= t
+    const unsigned int above_excl = above_incl - sum;      // keys in groups  > t
+    if (above_excl < k && above_incl >= k) { s_group = t; s_above = above_excl; }   // exactly one thread
+    __syncthreads();
+    if (wave == 0) {
+        const unsigned int g = s_group;
+        const unsigned int hv = hist[64 * g + lane];
+        unsigned int sb = hv;                  // inclusive suffix over the 64 bins of the group
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int o = __shfl_down(sb, d);
+            if (lane + d < 64) sb += o;
         }
-        counters[1] = k; counters[2] = 0; counters[3] = 0;
-        counters[4] = (unsigned int)b;     // boundary bin
-        counters[5] = k - cum;             // how many of its keys are selected
-        counters[6] = 0;
+        const unsigned int incl = s_above + sb, excl = incl - hv;
+        if (excl < k && incl >= k) {
+            counters[1] = k; counters[2] = 0; counters[3] = 0;
+            counters[4] = 64 * g + lane;       // boundary bin
+            counters[5] = k - excl;            // how many of its keys are selected
+            counters[6] = 0;
+        }
     }
 }
 

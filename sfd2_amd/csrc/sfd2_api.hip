@@ -82,6 +82,7 @@ struct sfd2_ctx {
     DevBuf g_keys, g_state0, g_state1, g_kept;   // greedy NMS (extract.py variant)
     int cand_cap = 0;
     int last_sel_cap = 0;
+    float *kpts_cur = nullptr, *kscores_cur = nullptr;   // where the last selection wrote its key points
     // matcher
     DevBuf m_stage, m_hi0, m_lo0, m_hi1, m_lo1, m_part_f, m_part_i, m_red, m_jobs, m_fins, m_out_m, m_out_s, m_rkeys;
     sfd2_timings tim = {};
@@ -720,7 +721,7 @@ extern "C" int sfd2_det(sfd2_ctx *c, const float *x, int x_on_device, int H, int
 
 // NMS + selection on c->heat; results in c->kpts / c->kscores, count in counters[1]
 static int run_selection(sfd2_ctx *c, const float *heat_dev, int H, int W, float conf_th, int radius, int border,
-                         int top_k, float *nms_dense)
+                         int top_k, float *nms_dense, float *kpts_dev = nullptr, float *scores_dev = nullptr)
 {
     if (radius < 0 || radius > 4) return fail("nms radius must be in [0,4] (reference uses 4)");
     const int sel_cap = top_k > 0 ? std::min(top_k, c->cand_cap) : c->cand_cap;
@@ -740,8 +741,10 @@ static int run_selection(sfd2_ctx *c, const float *heat_dev, int H, int W, float
         launch_topk_sort(c->stream, c->cand.as<unsigned long long>(), c->cand_cap, top_k,
                          c->sel.as<unsigned long long>(), c->sorted.as<unsigned long long>(), sel_cap,
                          c->counters.as<unsigned int>(), c->bnd.as<unsigned long long>());
+        c->kpts_cur = kpts_dev ? kpts_dev : c->kpts.as<float>();      // written in place when the caller's buffers are
+        c->kscores_cur = scores_dev ? scores_dev : c->kscores.as<float>();   // device resident: no staging copies
         launch_keys_to_kpts(c->stream, c->sorted.as<unsigned long long>(), c->counters.as<unsigned int>(), W,
-                            c->kpts.as<float>(), c->kscores.as<float>(), sel_cap);
+                            c->kpts_cur, c->kscores_cur, sel_cap);
     }
     HIPCHECK(hipGetLastError());
     return 0;
@@ -785,7 +788,10 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const float *img, int img_on_device, in
                        (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(), c->H4, c->W4, H, W,
                        c->heat.as<float>(), nullptr);
     }
-    if (run_selection(c, c->heat.as<float>(), H, W, conf_th, 4, 4, top_k, nullptr)) return -1;
+    const int sel_guess = top_k > 0 ? std::min(top_k, c->cand_cap) : c->cand_cap;
+    const bool direct = out_on_device && kpts_xy && scores && cap_out >= sel_guess;
+    if (run_selection(c, c->heat.as<float>(), H, W, conf_th, 4, 4, top_k, nullptr, direct ? kpts_xy : nullptr,
+                      direct ? scores : nullptr)) return -1;
     const int sel_cap = c->last_sel_cap;
     int64_t ncopy = sel_cap;
     if (cap_out >= 0 && ncopy > cap_out) ncopy = cap_out;
@@ -798,7 +804,7 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const float *img, int img_on_device, in
             desc_dst = c->kdesc.as<float>();
         }
         ProfScope ps(c, "sample_desc", "sample_desc_kernel", 0.0, (double)sel_cap * 128 * 4 * 5);
-        launch_sample_desc(c->stream, c->draw.as<float>(), c->H4, c->W4, H, W, c->kpts.as<float>(),
+        launch_sample_desc(c->stream, c->draw.as<float>(), c->H4, c->W4, H, W, c->kpts_cur,
                            c->counters.as<unsigned int>() + 1, sel_cap, desc_dst);
     }
     prof_step_end(c);
@@ -807,16 +813,16 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const float *img, int img_on_device, in
     if (flags & SFD2_FLAG_ASYNC) {
         // device-resident outputs only: copy the fixed-capacity arrays, the count stays on the device
         if (!out_on_device) return fail("SFD2_FLAG_ASYNC needs device output buffers");
-        if (copy_out(c, kpts_xy, c->kpts.p, (size_t)ncopy * 2 * sizeof(float), 1)) return -1;
-        if (copy_out(c, scores, c->kscores.p, (size_t)ncopy * sizeof(float), 1)) return -1;
+        if (!direct && copy_out(c, kpts_xy, c->kpts.p, (size_t)ncopy * 2 * sizeof(float), 1)) return -1;
+        if (!direct && copy_out(c, scores, c->kscores.p, (size_t)ncopy * sizeof(float), 1)) return -1;
         if (desc && desc_dst != desc && copy_out(c, desc, desc_dst, (size_t)ncopy * 128 * sizeof(float), 1)) return -1;
         if (n_out) *n_out = -1;
         return 0;
     }
     int n = 0;
     if (read_counts(c, cap_out, &n)) return -1;
-    if (copy_out(c, kpts_xy, c->kpts.p, (size_t)n * 2 * sizeof(float), out_on_device)) return -1;
-    if (copy_out(c, scores, c->kscores.p, (size_t)n * sizeof(float), out_on_device)) return -1;
+    if (!direct && copy_out(c, kpts_xy, c->kpts.p, (size_t)n * 2 * sizeof(float), out_on_device)) return -1;
+    if (!direct && copy_out(c, scores, c->kscores.p, (size_t)n * sizeof(float), out_on_device)) return -1;
     if (desc && desc_dst != desc && copy_out(c, desc, desc_dst, (size_t)n * 128 * sizeof(float), out_on_device)) return -1;
     HIPCHECK(hipStreamSynchronize(c->stream));
     float ms = 0.0f;
@@ -1172,8 +1178,9 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
         }
         off1 += (size_t)n1;
         fn.n0 = n0; fn.n1 = n1;
-        fn.matches0 = c->m_out_m.as<long long>() + (size_t)i * n0;
-        fn.scores0 = c->m_out_s.as<float>() + (size_t)i * n0;
+        const bool direct_out = out_on_device && matches0 && scores0;
+        fn.matches0 = (direct_out ? reinterpret_cast<long long *>(matches0) : c->m_out_m.as<long long>()) + (size_t)i * n0;
+        fn.scores0 = (direct_out ? scores0 : c->m_out_s.as<float>()) + (size_t)i * n0;
         fn.red_f = red + 3 * roff; roff += (size_t)n0;
         fn.red_r = red + 3 * roff; roff += (size_t)n1;
     }
@@ -1210,8 +1217,10 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     prof_step_end(c);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventRecord(c->ev[3], c->stream));
-    if (copy_out(c, matches0, c->m_out_m.p, (size_t)k * n0 * sizeof(long long), out_on_device)) return -1;
-    if (copy_out(c, scores0, c->m_out_s.p, (size_t)k * n0 * sizeof(float), out_on_device)) return -1;
+    if (!(out_on_device && matches0 && scores0)) {
+        if (copy_out(c, matches0, c->m_out_m.p, (size_t)k * n0 * sizeof(long long), out_on_device)) return -1;
+        if (copy_out(c, scores0, c->m_out_s.p, (size_t)k * n0 * sizeof(float), out_on_device)) return -1;
+    }
     if (!(flags & SFD2_FLAG_ASYNC)) {
         HIPCHECK(hipStreamSynchronize(c->stream));
         float ms = 0.0f;
