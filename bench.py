@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extract-only", action="store_true", help="configs[1]: extract without matching")
     ap.add_argument("--dump-layers", action="store_true", help="per-layer device times to stderr")
+    ap.add_argument("--streams", type=int, default=1, help="contexts (HIP streams) per GPU processing different images concurrently")
     ap.add_argument("--no-profile", action="store_true", help="experiment: no per-launch events in the timed region")
     args = ap.parse_args()
 
@@ -81,12 +82,6 @@ def main():
     from sfd2_amd.model import ResSegNetV2
 
     sd = synth.make_state_dict(0)
-    model = ResSegNetV2(outdim=128, require_stability=True).eval()
-    model.load_state_dict(sd)
-    model.cuda(local_rank)
-    ctx = model.context
-    lib = ctx.lib
-
     # ---- resident inputs: a few distinct query images per rank + K database descriptor sets (fp16)
     n_img = 4
     imgs = [torch.from_numpy(synth.make_image(H, W, 100 + rank * n_img + i)).to(dev) for i in range(n_img)]
@@ -95,32 +90,49 @@ def main():
     for _ in range(K_DB):
         d = torch.randn(N_DB, 128, generator=g)
         db.append((d / d.norm(dim=1, keepdim=True)).to(torch.float16).to(dev).contiguous())
-    kpts = torch.empty((TOPK, 2), dtype=torch.float32, device=dev)
-    scores = torch.empty((TOPK,), dtype=torch.float32, device=dev)
-    desc = torch.empty((TOPK, 128), dtype=torch.float32, device=dev)
-    matches = torch.empty((K_DB, TOPK), dtype=torch.int64, device=dev)
-    mscores = torch.empty((K_DB, TOPK), dtype=torch.float32, device=dev)
-    q = _lib.DescSet(desc.data_ptr(), TOPK, _lib.DT_F32, _lib.LAYOUT_ND, 1)
     dbs = (_lib.DescSet * K_DB)(*[_lib.DescSet(d.data_ptr(), N_DB, _lib.DT_F16, _lib.LAYOUT_ND, 1) for d in db])
     mconf = _lib.MatchConf(_lib.MATCH_HLOC, 1, 0.0, 0.0, _lib.SIM_F16)   # NNM (hloc/match_features.py:21-28)
-    n_out = ctypes.c_int(0)
+
+    class Lane:   # one context = one HIP stream, its packed weights, workspace and output buffers
+        def __init__(self):
+            self.model = ResSegNetV2(outdim=128, require_stability=True).eval()
+            self.model.load_state_dict(sd)
+            self.model.cuda(local_rank)
+            self.ctx = self.model.context
+            self.kpts = torch.empty((TOPK, 2), dtype=torch.float32, device=dev)
+            self.scores = torch.empty((TOPK,), dtype=torch.float32, device=dev)
+            self.desc = torch.empty((TOPK, 128), dtype=torch.float32, device=dev)
+            self.matches = torch.empty((K_DB, TOPK), dtype=torch.int64, device=dev)
+            self.mscores = torch.empty((K_DB, TOPK), dtype=torch.float32, device=dev)
+            self.q = _lib.DescSet(self.desc.data_ptr(), TOPK, _lib.DT_F32, _lib.LAYOUT_ND, 1)
+            self.n_out = ctypes.c_int(0)
+
+    lanes = [Lane() for _ in range(max(1, args.streams))]
+    ctx = lanes[0].ctx
+    lib = ctx.lib
+    matches = lanes[0].matches
     torch.cuda.synchronize()
 
     def step(i):
-        _lib.check(lib.sfd2_extract(ctx.h, imgs[i % n_img].data_ptr(), 1, H, W, 0.001, TOPK, _lib.FLAG_ASYNC,
-                                    kpts.data_ptr(), scores.data_ptr(), desc.data_ptr(), 1, TOPK, ctypes.byref(n_out)))
+        ln = lanes[i % len(lanes)]
+        _lib.check(lib.sfd2_extract(ln.ctx.h, imgs[i % n_img].data_ptr(), 1, H, W, 0.001, TOPK, _lib.FLAG_ASYNC,
+                                    ln.kpts.data_ptr(), ln.scores.data_ptr(), ln.desc.data_ptr(), 1, TOPK, ctypes.byref(ln.n_out)))
         if not args.extract_only:
-            _lib.check(lib.sfd2_match_batch(ctx.h, ctypes.byref(q), dbs, K_DB, 128, ctypes.byref(mconf),
-                                            matches.data_ptr(), mscores.data_ptr(), 1, _lib.FLAG_ASYNC))
+            _lib.check(lib.sfd2_match_batch(ln.ctx.h, ctypes.byref(ln.q), dbs, K_DB, 128, ctypes.byref(mconf),
+                                            ln.matches.data_ptr(), ln.mscores.data_ptr(), 1, _lib.FLAG_ASYNC))
+
+    def sync_all():
+        for ln in lanes:
+            ln.ctx.sync()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, len(lanes))):
         step(i)
-    ctx.sync()
+    sync_all()
     n_kp = ctypes.c_int(0)
     _lib.check(lib.sfd2_extract_count(ctx.h, ctypes.byref(n_kp)))
     if n_kp.value != TOPK:
@@ -140,7 +152,7 @@ def main():
     # untimed pre-pass with every launch bracketed: per-kernel breakdown + which family dominates
     ctx.set_profiling(8)
     for i in range(3):
-        step(i)
+        step(0)
     breakdown_rows = ctx.layer_timings()
     fam_all = dominant_family(breakdown_rows)
     dom_name = max(fam_all.items(), key=lambda kv: kv[1]["ms"])[0]
@@ -152,7 +164,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    ctx.sync()
+    sync_all()
     barrier()
     dt = time.perf_counter() - t0
     layers = ctx.layer_timings()
@@ -202,7 +214,7 @@ def main():
                                     "aachen_v1.1 query extract + NNM match vs netvlad-50 resident db sets (BASELINE configs[2])"),
                        "image": f"{W}x{H}", "max_keypoints": TOPK, "db_sets_per_query": 0 if args.extract_only else K_DB,
                        "db_keypoints": N_DB, "weights": "synthetic seeded ResSegNetV2 (checkpoint not shipped)",
-                       "parallelism": f"images sharded over {world} GPU(s), no collective"},
+                       "parallelism": f"images sharded over {world} GPU(s), no collective", "streams_per_gpu": len(lanes)},
             "roofline": roof, "kernel_ms_per_step": breakdown, "device_ms_per_step": round(total_ms, 4),
             "mutual_matches_last_step": n_matched,
         }

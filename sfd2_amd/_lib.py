@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfd2hip.so")
+LIB_PATH = os.environ.get("SFD2_LIB") or os.path.join(_HERE, "libsfd2hip.so")   # SFD2_LIB: kernel A/B experiments
 
 FLAG_ASYNC = 1
 FLAG_NO_STABILITY = 2

@@ -57,7 +57,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     constexpr int WCH = BN / RPC;                      // 1 KB chunks of one filter tile
     constexpr int WPW = WCH / 8;                       // per wave
     constexpr int XBYTES = XCH * 1024, WBYTES = BN * RB;
-    constexpr int WAVES_CH = 2, WAVES_PX = 4;
+    constexpr int WAVES_CH = 2, WAVES_PX = 4;   // (4 x 2 and s_setprio around the MFMA bursts measured no better)
     constexpr int CH_T = BN / WAVES_CH / 32;           // 2 or 4
     constexpr int PX_T = THT / WAVES_PX;               // image rows per wave (2 or 1)
 
