@@ -30,6 +30,18 @@ PEAK_TFLOPS_F16 = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(kernel_label):
+    """HBM-side bytes per launch of a kernel family from the committed PMC profile
+    (profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    bench command, read side doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            e = json.load(f).get(kernel_label)
+            return e["bytes_per_launch"] if e else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(sd, n_match_sample=10):
     """The oracle (a CPU port of the reference algorithm, oracle/) timed on the host cores:
     one full-size extract + n_match_sample of the 50 matches, scaled to the full unit."""
@@ -130,6 +142,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed pre-heat (~1 s: clocks, allocator, lazily created kernels), then the W warm-up steps
+    t_heat = time.perf_counter()
+    while time.perf_counter() - t_heat < 1.0:
+        for i in range(8):
+            step(i)
+        sync_all()
     for i in range(max(args.warmup, len(lanes))):
         step(i)
     sync_all()
@@ -189,13 +207,13 @@ def main():
             roof = {"bound": "mfma", "kernel": dom_name, "layers": dom["layers"], "achieved": round(achieved, 2),
                     "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS_F16, 4),
                     "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 5), "launches": dom["launches"],
-                    "traffic": None}
+                    "traffic": pmc_traffic(dom_name)}
         else:
             achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom_name, "layers": dom["layers"], "achieved": round(achieved, 2),
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4),
                     "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 5), "launches": dom["launches"],
-                    "traffic": None}
+                    "traffic": pmc_traffic(dom_name)}
         total_ms = sum(r["ms_total"] / max(1, r["launches"]) for r in breakdown_rows) * 1.0
         if args.dump_layers:
             for r in breakdown_rows:
