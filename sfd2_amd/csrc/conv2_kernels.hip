@@ -201,22 +201,20 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #undef ISSUE_X
 #undef ISSUE_W
 
-    // epilogue: scale/shift come from LDS, the residual quads of one 32-channel block are fetched
-    // together (4 loads in flight) before they are used.
+    // epilogue: y = acc * scale + shift (+ residual) (ReLU).  A lane owns, per register quad q, channels
+    // 8q + 4*lhi .. +3 of one pixel, i.e. lanes l and l+32 hold the two 8-byte halves of one 16-byte
+    // run.  For the fp16 output a v_permlane32_swap per dword regroups two quads so that lanes 0-31
+    // own the full 16 bytes of quad 2m and lanes 32-63 those of quad 2m+1: half as many stores (and
+    // residual loads), each 16 bytes wide.
 #pragma unroll
     for (int pr = 0; pr < PX_T; ++pr) {
         const int oy = oy0 + wrow + pr, ox = ox0 + lrow;
-        if (oy < Ho && ox < Wo) {
-            const size_t pix = (size_t)oy * Wo + ox;
+        const bool inb = oy < Ho && ox < Wo;
+        const size_t pix = (size_t)(inb ? oy : 0) * Wo + (inb ? ox : 0);
 #pragma unroll
-            for (int ct = 0; ct < CH_T; ++ct) {
-                const int cl = wch + ct * 32 + 4 * lhi;        // channel within the tile, + 8q
-                h4_t rq[4];
-                if (HAS_RES) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        rq[q] = *reinterpret_cast<const h4_t *>(res + pix * CoutP + n0 + cl + 8 * q);
-                }
+        for (int ct = 0; ct < CH_T; ++ct) {
+            const int cl = wch + ct * 32 + 4 * lhi;        // channel within the tile, + 8q
+            if (OUT_F32) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 sc = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
@@ -225,15 +223,53 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                     float v1 = acc[ct][pr][4 * q + 1] * sc.y + sh.y;
                     float v2 = acc[ct][pr][4 * q + 2] * sc.z + sh.z;
                     float v3 = acc[ct][pr][4 * q + 3] * sc.w + sh.w;
-                    if (HAS_RES) {
-                        v0 += (float)rq[q][0]; v1 += (float)rq[q][1]; v2 += (float)rq[q][2]; v3 += (float)rq[q][3];
-                    }
                     if (relu) {
                         v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
                     }
-                    const size_t o = pix * CoutP + n0 + cl + 8 * q;
-                    if (OUT_F32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(outv) + o) = make_float4(v0, v1, v2, v3);
-                    else *reinterpret_cast<h4_t *>(reinterpret_cast<half_t *>(outv) + o) = cvt4b(v0, v1, v2, v3);
+                    if (inb)
+                        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(outv) + pix * CoutP + n0 + cl + 8 * q) =
+                            make_float4(v0, v1, v2, v3);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    // 16-byte column run this lane ends up owning: quad 2m (lanes 0-31) or 2m+1 (lanes 32-63)
+                    const size_t o16 = pix * CoutP + n0 + wch + ct * 32 + 8 * (2 * m + lhi);
+                    uint2 rq[2] = {make_uint2(0, 0), make_uint2(0, 0)};
+                    if (HAS_RES) {
+                        uint4 r16 = make_uint4(0, 0, 0, 0);
+                        if (inb) r16 = *reinterpret_cast<const uint4 *>(res + o16);
+                        // undo the regrouping: afterwards rq[j] is this lane's 8-byte piece of quad 2m+j
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(r16.x, r16.z, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(r16.y, r16.w, false, false);
+                        rq[0] = make_uint2(s0[0], s1[0]);
+                        rq[1] = make_uint2(s0[1], s1[1]);
+                    }
+                    uint2 pk[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int q = 2 * m + j;
+                        const float4 sc = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
+                        const float4 sh = *reinterpret_cast<const float4 *>(SS + BN + cl + 8 * q);
+                        float v0 = acc[ct][pr][4 * q + 0] * sc.x + sh.x;
+                        float v1 = acc[ct][pr][4 * q + 1] * sc.y + sh.y;
+                        float v2 = acc[ct][pr][4 * q + 2] * sc.z + sh.z;
+                        float v3 = acc[ct][pr][4 * q + 3] * sc.w + sh.w;
+                        if (HAS_RES) {
+                            h4_t r;
+                            __builtin_memcpy(&r, &rq[j], 8);
+                            v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+                        }
+                        if (relu) {
+                            v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
+                        }
+                        const h4_t hv = cvt4b(v0, v1, v2, v3);
+                        __builtin_memcpy(&pk[j], &hv, 8);
+                    }
+                    const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                    const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                    if (inb)
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<half_t *>(outv) + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
                 }
             }
         }

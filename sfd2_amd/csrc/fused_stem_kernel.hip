@@ -153,17 +153,26 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
 #undef ISSUE_W2
 
     const int oy = oy0 + orow, ox = ox0 + lrow;
-    if (oy < H2 && ox < W2) {
-        half_t *o = out + ((size_t)oy * W2 + ox) * 64;
+    const bool inb = oy < H2 && ox < W2;
+    half_t *o = out + ((size_t)(inb ? oy : 0) * W2 + (inb ? ox : 0)) * 64;
+    // lanes l and l+32 hold the two 8-byte halves of a 16-byte channel run: regroup two quads with
+    // v_permlane32_swap so every lane issues one 16-byte store per quad pair (as conv_igemm2)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+    for (int m = 0; m < 2; ++m) {
+        uint2 pk[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = 2 * m + j;
             const int c0 = cth * 32 + 8 * q + 4 * lhi;
             const float4 s = *reinterpret_cast<const float4 *>(SS + 128 + c0);
             const float4 h = *reinterpret_cast<const float4 *>(SS + 192 + c0);
-            *reinterpret_cast<h4_t *>(o + c0) =
-                f_cvt4(fmaxf(acc2[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc2[4 * q + 1] * s.y + h.y, 0.0f),
-                       fmaxf(acc2[4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc2[4 * q + 3] * s.w + h.w, 0.0f));
+            const h4_t hv = f_cvt4(fmaxf(acc2[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc2[4 * q + 1] * s.y + h.y, 0.0f),
+                                   fmaxf(acc2[4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc2[4 * q + 3] * s.w + h.w, 0.0f));
+            __builtin_memcpy(&pk[j], &hv, 8);
         }
+        const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+        const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+        if (inb) *reinterpret_cast<uint4 *>(o + cth * 32 + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
     }
 }
 
