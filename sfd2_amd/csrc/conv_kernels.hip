@@ -446,16 +446,27 @@ void gconv3x3_g8_kernel(const half_t *__restrict__ in, int H, int W, const half_
         const int c0 = pair * 16 + g * 4;
         const float4 sc = *reinterpret_cast<const float4 *>(scale + c0);
         const float4 sh = *reinterpret_cast<const float4 *>(shift + c0);
+        // lane groups g and g^1 (16 lanes apart) hold adjacent 8-byte channel runs of the same pixel:
+        // exchange across two pixel tiles so that every lane issues one 16-byte store per tile pair
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int oy = oy0 + (t >> 1), ox = ox0 + (t & 1) * 16 + lcol;
-            if (oy < H && ox < W) {
-                const float v0 = fmaxf(acc[t][0] * sc.x + sh.x, 0.0f);
-                const float v1 = fmaxf(acc[t][1] * sc.y + sh.y, 0.0f);
-                const float v2 = fmaxf(acc[t][2] * sc.z + sh.z, 0.0f);
-                const float v3 = fmaxf(acc[t][3] * sc.w + sh.w, 0.0f);
-                *reinterpret_cast<h4_t *>(out + ((size_t)oy * W + ox) * 256 + c0) = cvt4(v0, v1, v2, v3);
+        for (int t = 0; t < 8; t += 2) {
+            uint2 pk[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const h4_t hv = cvt4(fmaxf(acc[t + j][0] * sc.x + sh.x, 0.0f), fmaxf(acc[t + j][1] * sc.y + sh.y, 0.0f),
+                                     fmaxf(acc[t + j][2] * sc.z + sh.z, 0.0f), fmaxf(acc[t + j][3] * sc.w + sh.w, 0.0f));
+                __builtin_memcpy(&pk[j], &hv, 8);
             }
+            const bool odd = g & 1;
+            const uint2 send = odd ? pk[0] : pk[1];
+            uint2 recv;
+            recv.x = __shfl_xor(send.x, 16);
+            recv.y = __shfl_xor(send.y, 16);
+            const int tt = odd ? t + 1 : t;                         // the tile this lane stores
+            const int oy = oy0 + (tt >> 1), ox = ox0 + (tt & 1) * 16 + lcol;
+            const uint4 v = odd ? make_uint4(recv.x, recv.y, pk[1].x, pk[1].y) : make_uint4(pk[0].x, pk[0].y, recv.x, recv.y);
+            if (oy < H && ox < W)
+                *reinterpret_cast<uint4 *>(out + ((size_t)oy * W + ox) * 256 + pair * 16 + (g & ~1) * 4) = v;
         }
     }
 }

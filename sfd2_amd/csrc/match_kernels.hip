@@ -218,6 +218,13 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
     }
     float b1[2] = {-INFINITY, -INFINITY}, b2[2] = {-INFINITY, -INFINITY};
     int i1[2] = {0, 0};
+    f32x16_t zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+    // top-1 mode: running maximum with the register index (15 - r) packed into the 4 low mantissa
+    // bits (relative perturbation <= 2^-19, far below the fp16-operand error), plus the sub-tile id
+    float bp[2] = {-INFINITY, -INFINITY};
+    int sid[2] = {0, 0};
 
     if (ja0 < ja1) {
         const int nst = (ja1 - ja0 + TA2 - 1) / TA2;
@@ -239,9 +246,7 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
             if (s + 1 < nst) { ISSUE_A(s + 1, buf ^ 1) }
 #pragma unroll
             for (int sub = 0; sub < TA2 / 32; ++sub) {
-                f32x16_t acc0, acc1;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+                f32x16_t acc0 = zero16, acc1 = zero16;
                 const int row = sub * 32 + lcol;
                 const unsigned char *arow = smem + (buf * TA2 + row) * 256;
                 const int sw = row & 15;
@@ -254,25 +259,20 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
                 const int jbase = ja0 + s * TA2 + sub * 32 + 4 * lhi;
                 const bool full = ja0 + s * TA2 + sub * 32 + 32 <= ja1;   // wave-uniform: no row of this sub-tile is padding
                 if (!NEED2 && full) {
-                    // top-1 only: one max tree per tile; the per-element index scan runs only in the
-                    // (increasingly rare) case that some lane's running maximum is beaten
-                    float m0 = acc0[0], m1 = acc1[0];
+                    // one v_and_or per element packs (15 - r) under the value, a max tree then yields the
+                    // maximum AND its register; per-element index scans would make this kernel VALU-bound
+                    // (measured 11.8 VALU instructions per MFMA with them)
+                    const int sub_id = s * (TA2 / 32) + sub;
+                    float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
-                    for (int r = 1; r < 16; ++r) { m0 = fmaxf(m0, acc0[r]); m1 = fmaxf(m1, acc1[r]); }
-                    if (__any(m0 > b1[0])) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int j = jbase + (r & 3) + 8 * (r >> 2);
-                            i1[0] = acc0[r] > b1[0] ? j : i1[0]; b1[0] = fmaxf(b1[0], acc0[r]);
-                        }
+                    for (int r = 0; r < 16; ++r) {
+                        const float p0 = __uint_as_float((__float_as_uint(acc0[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r));
+                        const float p1 = __uint_as_float((__float_as_uint(acc1[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r));
+                        m0 = fmaxf(m0, p0);
+                        m1 = fmaxf(m1, p1);
                     }
-                    if (__any(m1 > b1[1])) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int j = jbase + (r & 3) + 8 * (r >> 2);
-                            i1[1] = acc1[r] > b1[1] ? j : i1[1]; b1[1] = fmaxf(b1[1], acc1[r]);
-                        }
-                    }
+                    sid[0] = m0 > bp[0] ? sub_id : sid[0]; bp[0] = fmaxf(bp[0], m0);
+                    sid[1] = m1 > bp[1] ? sub_id : sid[1]; bp[1] = fmaxf(bp[1], m1);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -292,6 +292,17 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
             __syncthreads();
         }
 #undef ISSUE_A
+    }
+    if (!NEED2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned int bits = __float_as_uint(bp[t]);
+            const float v = __uint_as_float(bits & 0xFFFFFFF0u);
+            const int r = 15 - (int)(bits & 15u);
+            const int j = ja0 + sid[t] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            // the packed path and the masked tail path (b1/i1) both ran: keep the better, lower index on ties
+            if (bp[t] != -INFINITY && (v > b1[t] || (v == b1[t] && j < i1[t]))) { b1[t] = v; i1[t] = j; }
+        }
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -384,6 +395,9 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const h
     const bool partial_q = i_base + wave * 64 + 64 > nb;     // wave-uniform: some query column is padding
     float b1[2] = {-INFINITY, -INFINITY};
     int i1[2] = {0, 0};
+    f32x16_t zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
 
     if (ja0 < ja1) {
         const int nst = (ja1 - ja0 + TA2 - 1) / TA2;
@@ -404,9 +418,7 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const h
             if (s + 1 < nst) { ISSUE_A(s + 1, buf ^ 1) }
 #pragma unroll
             for (int sub = 0; sub < TA2 / 32; ++sub) {
-                f32x16_t acc0, acc1;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+                f32x16_t acc0 = zero16, acc1 = zero16;
                 const int row = sub * 32 + lcol;
                 const unsigned char *arow = smem + (buf * TA2 + row) * 256;
                 const int sw = row & 15;
