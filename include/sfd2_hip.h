@@ -32,6 +32,9 @@ typedef struct sfd2_ctx sfd2_ctx;
 #define SFD2_FLAG_ASYNC 1          /* do not synchronise the stream before returning     */
 #define SFD2_FLAG_NO_STABILITY 2   /* use_stability = False (extract_localization.py:31) */
 #define SFD2_FLAG_IMG_NORMALISED 4 /* input already passed through norm_RGB               */
+#define SFD2_FLAG_IMG_U8_HWC 8     /* sfd2_extract: img is uint8 [H][W][3]; the device does the
+                                    * astype(float32) / 255. of extract_localization.py:168,186 */
+#define SFD2_FLAG_IMG_BGR 16       /* with IMG_U8_HWC: channel order is cv2's BGR (:162-165)    */
 
 /* One named fp32 tensor of the reference state_dict (torch layout), host memory.
  * Replaces: model.load_state_dict(torch.load(p)['model'])  extract_localization.py:213-215 */
@@ -102,14 +105,27 @@ int sfd2_det(sfd2_ctx *ctx, const float *x, int x_on_device, int H, int W, int f
              int *hs, int *ws, int *hc, int *wc);
 
 /* extract_resnet_return, single scale, mask=None (nets/extractor.py:97-338):
- * img [3][H][W] fp32 in [0,1] -> up to top_k key points sorted by score descending.
+ * img [3][H][W] fp32 in [0,1] (or uint8 [H][W][3] with SFD2_FLAG_IMG_U8_HWC: a quarter of the
+ * host->device bytes, converted while conv1a stages its patch) -> up to top_k key points sorted
+ * by score descending.
  * kpts_xy [cap][2] (x, y), scores [cap], desc [cap][128] fp32, cap = top_k (>0).
  * top_k <= 0 keeps every candidate (cap_out entries are then written at most).
  * nms_radius 4 and border 4 are the reference's constants (:143-144). */
-int sfd2_extract(sfd2_ctx *ctx, const float *img, int img_on_device, int H, int W,
+int sfd2_extract(sfd2_ctx *ctx, const void *img, int img_on_device, int H, int W,
                  float conf_th, int top_k, int flags,
                  float *kpts_xy, float *scores, float *desc, int out_on_device,
                  int64_t cap_out, int *n_out);
+/* extract_resnet_return with kwargs scales=[...] (nets/extractor.py:113-124,211-236,322-330):
+ * every pyramid level int(H*s) x int(W*s) is the bilinear resize (align_corners=False) of the
+ * normalised image; levels are merged by score on the device (top_k > 0) or concatenated in
+ * scale order (top_k <= 0).  Key points are returned in original-image coordinates.
+ * Reference behaviour kept: the 4-pixel border is tested against the ORIGINAL W, H in level
+ * coordinates (:181-184).  scales: n_scales (<= 8) doubles.  Synchronous. */
+int sfd2_extract_multiscale(sfd2_ctx *ctx, const void *img, int img_on_device, int H, int W,
+                            const double *scales, int n_scales, float conf_th, int top_k, int flags,
+                            float *kpts_xy, float *scores, float *desc, int out_on_device,
+                            int64_t cap_out, int *n_out);
+
 /* After an SFD2_FLAG_ASYNC extract: number of key points, once the stream is idle. */
 int sfd2_extract_count(sfd2_ctx *ctx, int *n_out);
 

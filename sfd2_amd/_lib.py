@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("SFD2_LIB") or os.path.join(_HERE, "libsfd2hip.so")   
 FLAG_ASYNC = 1
 FLAG_NO_STABILITY = 2
 FLAG_IMG_NORMALISED = 4
+FLAG_IMG_U8_HWC = 8
+FLAG_IMG_BGR = 16
 MATCH_HLOC, MATCH_ITLOC_NNM, MATCH_ITLOC_NNR = 0, 1, 2
 DT_F32, DT_F64, DT_F16 = 0, 1, 2
 LAYOUT_ND, LAYOUT_DN = 0, 1
@@ -53,7 +55,7 @@ EXPORTS = [
     "sfd2_select_keypoints", "sfd2_sample_descriptors", "sfd2_heatmap", "sfd2_debug_activation",
     "sfd2_match", "sfd2_match_batch", "sfd2_get_timings", "sfd2_sync", "sfd2_set_profiling",
     "sfd2_get_layer_timings", "sfd2_set_precision", "sfd2_extract_spp", "sfd2_nms_fast",
-    "sfd2_set_profile_filter",
+    "sfd2_set_profile_filter", "sfd2_extract_multiscale",
 ]
 
 _lib = None
@@ -81,6 +83,7 @@ def load():
     lib.sfd2_det.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, pi, pi, pi, pi]
     lib.sfd2_extract.argtypes = [vp, vp, ci, ci, ci, cf, ci, ci, vp, vp, vp, ci, i64, pi]
     lib.sfd2_extract_count.argtypes = [vp, pi]
+    lib.sfd2_extract_multiscale.argtypes = [vp, vp, ci, ci, ci, vp, ci, cf, ci, ci, vp, vp, vp, ci, i64, pi]
     lib.sfd2_extract_spp.argtypes = [vp, vp, ci, ci, ci, cf, ci, vp, vp, vp, i64, pi, vp, vp]
     lib.sfd2_nms_fast.argtypes = [vp, vp, ci, ci, cf, ci, vp]
     lib.sfd2_simple_nms.argtypes = [vp, vp, ci, ci, ci, vp]

@@ -232,8 +232,13 @@ void conv1a_f32_kernel(const float *__restrict__ img, int H, int W, int normalis
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
         float v = 0.0f;
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-            v = img[c * plane + (size_t)iy * W + ix];
-            if (normalise) {
+            if (normalise & 2) {  // uint8 HWC ingest (extract_localization.py:165-186)
+                const int cs = (normalise & 4) ? 2 - c : c;
+                v = __fdiv_rn((float)reinterpret_cast<const unsigned char *>(img)[((size_t)iy * W + ix) * 3 + cs], 255.0f);
+            } else {
+                v = img[c * plane + (size_t)iy * W + ix];
+            }
+            if (normalise & 1) {
                 const float m = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
                 const float sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
                 v = __fdiv_rn(__fsub_rn(v, m), sd);

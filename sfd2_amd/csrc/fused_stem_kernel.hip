@@ -64,8 +64,14 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
         float r = 0.0f, g = 0.0f, b = 0.0f;
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
             const size_t o = (size_t)iy * W + ix;
-            r = img[o]; g = img[plane + o]; b = img[2 * plane + o];
-            if (normalise) {
+            if (normalise & 2) {  // uint8 HWC ingest: x.astype(float32) / 255. (extract_localization.py:168,186)
+                const unsigned char *u = reinterpret_cast<const unsigned char *>(img) + o * 3;
+                const int sw = (normalise & 4) ? 2 : 0;  // BGR -> RGB (:165)
+                r = __fdiv_rn((float)u[sw], 255.0f); g = __fdiv_rn((float)u[1], 255.0f); b = __fdiv_rn((float)u[2 - sw], 255.0f);
+            } else {
+                r = img[o]; g = img[plane + o]; b = img[2 * plane + o];
+            }
+            if (normalise & 1) {
                 r = __fdiv_rn(__fsub_rn(r, 0.485f), 0.229f);
                 g = __fdiv_rn(__fsub_rn(g, 0.456f), 0.224f);
                 b = __fdiv_rn(__fsub_rn(b, 0.406f), 0.225f);

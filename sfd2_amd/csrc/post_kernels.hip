@@ -147,7 +147,7 @@ __device__ __forceinline__ void pool_cols(const float *__restrict__ src, float *
 }
 
 __global__ __launch_bounds__(512)
-void nms_select_kernel(const float *__restrict__ heat, int H, int W, int radius, float conf_th, int border,
+void nms_select_kernel(const float *__restrict__ heat, int H, int W, int radius, float conf_th, int border, int Hb, int Wb,
                        float *__restrict__ nms_dense, unsigned long long *__restrict__ cand, int cand_cap,
                        unsigned int *__restrict__ counters)
 {
@@ -212,7 +212,7 @@ void nms_select_kernel(const float *__restrict__ heat, int H, int W, int radius,
         const int li = (ty + halo) * NMS_RW + tx + halo;
         const float v = M[li] ? S[li] : 0.0f;              // where(max_mask, scores, zeros)
         if (nms_dense) nms_dense[(size_t)gy * W + gx] = v;
-        if (cand && v > conf_th && gx >= border && gx < W - border && gy >= border && gy < H - border) {
+        if (cand && v > conf_th && gx >= border && gx < Wb - border && gy >= border && gy < Hb - border) {
             const unsigned int idx = (unsigned int)(gy * W + gx);
             const unsigned long long key =
                 ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
@@ -344,7 +344,7 @@ __device__ __forceinline__ void n2_dilate(const unsigned long long *__restrict__
 }
 
 __global__ __launch_bounds__(512)
-void nms4_select_kernel(const float *__restrict__ heat, int H, int W, float conf_th, int border,
+void nms4_select_kernel(const float *__restrict__ heat, int H, int W, float conf_th, int border, int Hb, int Wb,
                         float *__restrict__ nms_dense, unsigned long long *__restrict__ cand, int cand_cap,
                         unsigned int *__restrict__ counters, unsigned int *__restrict__ hist)
 {
@@ -396,7 +396,7 @@ void nms4_select_kernel(const float *__restrict__ heat, int H, int W, float conf
         const bool mk = (M[2 * ry + (rx >> 6)] >> (rx & 63)) & 1ull;
         const float v = mk ? S[ry * N2_SP + 4 + rx] : 0.0f;              // where(max_mask, scores, zeros)
         if (nms_dense) nms_dense[(size_t)gy * W + gx] = v;
-        if (cand && v > conf_th && gx >= border && gx < W - border && gy >= border && gy < H - border) {
+        if (cand && v > conf_th && gx >= border && gx < Wb - border && gy >= border && gy < Hb - border) {
             const unsigned int idx = (unsigned int)(gy * W + gx);
             const unsigned long long key =
                 ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
@@ -428,7 +428,7 @@ void hist_from_cand_kernel(const unsigned long long *__restrict__ cand, int cand
         atomicAdd(&hist[(unsigned int)(cand[i] >> 47) & 0xFFFFu], 1u);
 }
 
-void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radius, float conf_th, int border,
+void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radius, float conf_th, int border, int Hb, int Wb,
                        float *nms_dense, unsigned long long *cand, int cand_cap, unsigned int *counters)
 {
     unsigned int *hist = counters + 16;   // counters[0..15], then 65536 histogram bins
@@ -441,7 +441,7 @@ void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radi
             attr4 = true;
         }
         hipLaunchKernelGGL(nms4_select_kernel, dim3((W + N2_TW - 1) / N2_TW, (H + N2_TH - 1) / N2_TH), dim3(512), lds4,
-                           st, heat, H, W, conf_th, border, nms_dense, cand, cand_cap, counters, hist);
+                           st, heat, H, W, conf_th, border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist);
         return;
     }
     static bool attr_done = false;
@@ -452,7 +452,7 @@ void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radi
         attr_done = true;
     }
     hipLaunchKernelGGL(nms_select_kernel, dim3((W + NMS_TW - 1) / NMS_TW, (H + NMS_TH - 1) / NMS_TH), dim3(512), lds,
-                       st, heat, H, W, radius, conf_th, border, nms_dense, cand, cand_cap, counters);
+                       st, heat, H, W, radius, conf_th, border, Hb, Wb, nms_dense, cand, cand_cap, counters);
     if (cand) hipLaunchKernelGGL(hist_from_cand_kernel, dim3(64), dim3(NT), 0, st, cand, cand_cap, counters, hist);
 }
 
@@ -808,4 +808,148 @@ void launch_nchw_f_to_nhwc_f(hipStream_t st, const float *in, int npix, int c, f
 {
     const size_t n = (size_t)npix * c;
     hipLaunchKernelGGL(nchw_f_to_nhwc_f_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, in, npix, c, out);
+}
+
+// ---------------------------------------------------------------- scale pyramid (nets/extractor.py:118-124,211-236)
+// level image = F.interpolate(norm_RGB(img), (nh, nw), bilinear, align_corners=False): normalise the four taps with
+// norm_RGB's IEEE sub + div, blend with the pinned torch rounding sequence (lin_coef / bilerp above).
+__device__ __forceinline__ float norm_tap(const float *__restrict__ img, int mode, int c, size_t plane, int W, int y, int x)
+{
+    float v;
+    if (mode & 2) {
+        const int cs = (mode & 4) ? 2 - c : c;
+        v = __fdiv_rn((float)reinterpret_cast<const unsigned char *>(img)[((size_t)y * W + x) * 3 + cs], 255.0f);
+    } else {
+        v = img[c * plane + (size_t)y * W + x];
+    }
+    if (mode & 1) {
+        const float m = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
+        const float sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+        v = __fdiv_rn(__fsub_rn(v, m), sd);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(NT)
+void norm_resize_kernel(const float *__restrict__ img, int mode, int H, int W, int nh, int nw, float sc_y, float sc_x,
+                        float *__restrict__ out)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int c = blockIdx.z;
+    if (x >= nw || y >= nh) return;
+    const LinCoef cy = lin_coef(y, H, nh, sc_y), cx = lin_coef(x, W, nw, sc_x);
+    const size_t plane = (size_t)H * W;
+    const float v00 = norm_tap(img, mode, c, plane, W, cy.i0, cx.i0), v01 = norm_tap(img, mode, c, plane, W, cy.i0, cx.i1);
+    const float v10 = norm_tap(img, mode, c, plane, W, cy.i1, cx.i0), v11 = norm_tap(img, mode, c, plane, W, cy.i1, cx.i1);
+    const float top = __fmaf_rn(v00, cx.l0, __fmul_rn(v01, cx.l1));
+    const float bot = __fmaf_rn(v10, cx.l0, __fmul_rn(v11, cx.l1));
+    out[(size_t)c * nh * nw + (size_t)y * nw + x] = __fmaf_rn(top, cy.l0, __fmul_rn(bot, cy.l1));
+}
+
+void launch_norm_resize(hipStream_t st, const float *img, int mode, int H, int W, int nh, int nw, float *out)
+{
+    hipLaunchKernelGGL(norm_resize_kernel, dim3((nw + 63) / 64, (nh + 3) / 4, 3), dim3(NT), 0, st, img, mode, H, W, nh, nw,
+                       (float)H / (float)nh, (float)W / (float)nw, out);
+}
+
+// one pyramid level's selected key points -> the staging arrays: x * W / nw, y * H / nh in fp32 (two roundings each,
+// nets/extractor.py:211-212), scores copied, the level's count recorded.
+__global__ __launch_bounds__(NT)
+void ms_append_kernel(const float *__restrict__ kpts, const float *__restrict__ scores, const unsigned int *__restrict__ count,
+                      int cap, float W, float nw, float H, float nh, float *__restrict__ kp_out, float *__restrict__ sc_out,
+                      unsigned int *__restrict__ level_count)
+{
+    unsigned int n = *count;
+    if (n > (unsigned int)cap) n = cap;
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *level_count = n;
+    if (i >= n) return;
+    kp_out[2 * i] = __fdiv_rn(__fmul_rn(kpts[2 * i], W), nw);
+    kp_out[2 * i + 1] = __fdiv_rn(__fmul_rn(kpts[2 * i + 1], H), nh);
+    sc_out[i] = scores[i];
+}
+
+void launch_ms_append(hipStream_t st, const float *kpts, const float *scores, const unsigned int *count, int cap, int W, int nw,
+                      int H, int nh, float *kp_out, float *sc_out, unsigned int *level_count)
+{
+    hipLaunchKernelGGL(ms_append_kernel, dim3((cap + NT - 1) / NT > 0 ? (cap + NT - 1) / NT : 1), dim3(NT), 0, st, kpts, scores,
+                       count, cap, (float)W, (float)nw, (float)H, (float)nh, kp_out, sc_out, level_count);
+}
+
+// concatenation order position -> 64-bit key (score bits, then earlier position first); ms_counters[1] = total
+struct MsLevels { int n_levels; int offset[8]; };   // staging offset of each level (host-known capacities)
+
+__device__ __forceinline__ void ms_locate(const MsLevels &lv, const unsigned int *__restrict__ level_count, unsigned int pos,
+                                          int *level, unsigned int *idx)
+{
+    unsigned int base = 0;
+    int l = 0;
+    for (; l < lv.n_levels - 1; ++l) {
+        const unsigned int n = level_count[l];
+        if (pos < base + n) break;
+        base += n;
+    }
+    *level = l;
+    *idx = pos - base;
+}
+
+__global__ __launch_bounds__(NT)
+void ms_keys_kernel(MsLevels lv, const unsigned int *__restrict__ level_count, const float *__restrict__ sc_stage,
+                    unsigned long long *__restrict__ keys, int cap_total, unsigned int *__restrict__ ms_counters)
+{
+    unsigned int total = 0;
+    for (int l = 0; l < lv.n_levels; ++l) total += level_count[l];
+    const unsigned int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos == 0) ms_counters[1] = total;
+    if (pos >= total || pos >= (unsigned int)cap_total) return;
+    int l; unsigned int i;
+    ms_locate(lv, level_count, pos, &l, &i);
+    const float s = sc_stage[lv.offset[l] + i];
+    keys[pos] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - pos);
+}
+
+// output row r <- staged key point of sorted[r] (or of position r when sorted == nullptr: top_k <= 0 keeps the
+// concatenation order, nets/extractor.py:322-330).  One wave per key point (128-float descriptor row).
+__global__ __launch_bounds__(NT)
+void ms_gather_kernel(MsLevels lv, const unsigned int *__restrict__ level_count, const unsigned long long *__restrict__ sorted,
+                      const float *__restrict__ kp_stage, const float *__restrict__ sc_stage, const float *__restrict__ de_stage,
+                      int n_max, float *__restrict__ kp_out, float *__restrict__ sc_out, float *__restrict__ de_out,
+                      unsigned int *__restrict__ ms_counters)
+{
+    unsigned int total = 0;
+    for (int l = 0; l < lv.n_levels; ++l) total += level_count[l];
+    unsigned int n = total < (unsigned int)n_max ? total : (unsigned int)n_max;
+    const int lane = threadIdx.x & 63;
+    const unsigned int r = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (r == 0 && lane == 0) ms_counters[2] = n;
+    if (r >= n) return;
+    const unsigned int pos = sorted ? 0xFFFFFFFFu - (unsigned int)(sorted[r] & 0xFFFFFFFFull) : r;
+    int l; unsigned int i;
+    ms_locate(lv, level_count, pos, &l, &i);
+    const size_t src = (size_t)lv.offset[l] + i;
+    if (lane < 2) kp_out[2 * (size_t)r + lane] = kp_stage[2 * src + lane];
+    if (lane == 2) sc_out[r] = sc_stage[src];
+    if (de_out)
+        *reinterpret_cast<float2 *>(de_out + (size_t)r * 128 + 2 * lane) =
+            *reinterpret_cast<const float2 *>(de_stage + src * 128 + 2 * lane);
+}
+
+void launch_ms_merge(hipStream_t st, int n_levels, const int *offsets, const unsigned int *level_count, const float *kp_stage,
+                     const float *sc_stage, const float *de_stage, int cap_total, int top_k, unsigned long long *keys,
+                     unsigned long long *sorted, unsigned int *ms_counters, int n_max, float *kp_out, float *sc_out, float *de_out)
+{
+    MsLevels lv;
+    lv.n_levels = n_levels;
+    for (int l = 0; l < 8; ++l) lv.offset[l] = l < n_levels ? offsets[l] : 0;
+    const unsigned long long *order = nullptr;
+    if (top_k > 0) {
+        hipLaunchKernelGGL(ms_keys_kernel, dim3((cap_total + NT - 1) / NT), dim3(NT), 0, st, lv, level_count, sc_stage, keys,
+                           cap_total, ms_counters);
+        hipLaunchKernelGGL(rank_sort_kernel, dim3((cap_total + 63) / 64), dim3(NT), 0, st, keys, sorted, cap_total, ms_counters);
+        order = sorted;
+    }
+    if (n_max <= 0) return;
+    hipLaunchKernelGGL(ms_gather_kernel, dim3((n_max + 3) / 4), dim3(NT), 0, st, lv, level_count, order, kp_stage, sc_stage,
+                       de_stage, n_max, kp_out, sc_out, de_out, ms_counters);
 }

@@ -83,6 +83,10 @@ struct sfd2_ctx {
     int cand_cap = 0;
     int last_sel_cap = 0;
     float *kpts_cur = nullptr, *kscores_cur = nullptr;   // where the last selection wrote its key points
+    // scale pyramid staging (sfd2_extract_multiscale)
+    DevBuf img_scaled, ms_kp, ms_sc, ms_de, ms_keys, ms_sorted, ms_cnt;
+    unsigned int ms_cand_seen[8] = {};
+    int ms_cand_cap[8] = {};
     // matcher
     DevBuf m_stage, m_hi0, m_lo0, m_hi1, m_lo1, m_part_f, m_part_i, m_red, m_jobs, m_fins, m_out_m, m_out_s, m_rkeys;
     sfd2_timings tim = {};
@@ -169,7 +173,8 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
                       &c->m_part_f, &c->m_part_i, &c->m_red, &c->m_jobs, &c->m_fins, &c->m_out_m, &c->m_out_s,
                       &c->g1a, &c->g1b, &c->g2a, &c->g2b, &c->g3a, &c->g3b, &c->grt1[0], &c->grt1[1], &c->grt1[2],
                       &c->grt2[0], &c->grt2[1], &c->grt2[2], &c->gro[0], &c->gro[1], &c->gro[2], &c->gpa0_o, &c->gpa_o,
-                      &c->gda0_o, &c->gda_o, &c->m_rkeys, &c->g_keys, &c->g_state0, &c->g_state1, &c->g_kept};
+                      &c->gda0_o, &c->gda_o, &c->m_rkeys, &c->g_keys, &c->g_state0, &c->g_state1, &c->g_kept,
+                      &c->img_scaled, &c->ms_kp, &c->ms_sc, &c->ms_de, &c->ms_keys, &c->ms_sorted, &c->ms_cnt};
     for (DevBuf *b : bufs) b->release();
     ConvW *ws[] = {&c->c1a, &c->c1b, &c->c2a, &c->c2b, &c->c3a, &c->c3b, &c->rb1[0], &c->rb1[1], &c->rb1[2],
                    &c->rb2[0], &c->rb2[1], &c->rb2[2], &c->rb3[0], &c->rb3[1], &c->rb3[2], &c->pa0, &c->pa3,
@@ -666,10 +671,10 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     return 0;
 }
 
-static int stage_image(sfd2_ctx *c, const float *x, int on_device, int H, int W, const float **dev)
+static int stage_image(sfd2_ctx *c, const void *x, int on_device, int H, int W, const float **dev, int u8 = 0)
 {
-    if (on_device) { *dev = x; return 0; }
-    const size_t bytes = (size_t)3 * H * W * sizeof(float);
+    if (on_device) { *dev = static_cast<const float *>(x); return 0; }
+    const size_t bytes = (size_t)3 * H * W * (u8 ? 1 : sizeof(float));
     HIPCHECK(c->img.ensure(bytes));
     HIPCHECK(hipMemcpyAsync(c->img.p, x, bytes, hipMemcpyHostToDevice, c->stream));
     *dev = c->img.as<float>();
@@ -721,8 +726,11 @@ extern "C" int sfd2_det(sfd2_ctx *c, const float *x, int x_on_device, int H, int
 
 // NMS + selection on c->heat; results in c->kpts / c->kscores, count in counters[1]
 static int run_selection(sfd2_ctx *c, const float *heat_dev, int H, int W, float conf_th, int radius, int border,
-                         int top_k, float *nms_dense, float *kpts_dev = nullptr, float *scores_dev = nullptr)
+                         int top_k, float *nms_dense, float *kpts_dev = nullptr, float *scores_dev = nullptr,
+                         int Hb = 0, int Wb = 0)
 {
+    if (Hb <= 0) Hb = H;
+    if (Wb <= 0) Wb = W;
     if (radius < 0 || radius > 4) return fail("nms radius must be in [0,4] (reference uses 4)");
     const int sel_cap = top_k > 0 ? std::min(top_k, c->cand_cap) : c->cand_cap;
     c->last_sel_cap = sel_cap;
@@ -733,7 +741,7 @@ static int run_selection(sfd2_ctx *c, const float *heat_dev, int H, int W, float
     HIPCHECK(hipMemsetAsync(c->counters.p, 0, SFD2_COUNTER_BYTES, c->stream));
     {
         ProfScope ps(c, "nms_select", "nms_select_kernel", 0.0, (double)H * W * 4);
-        launch_nms_select(c->stream, heat_dev, H, W, radius, conf_th, border, nms_dense,
+        launch_nms_select(c->stream, heat_dev, H, W, radius, conf_th, border, Hb, Wb, nms_dense,
                           c->cand.as<unsigned long long>(), c->cand_cap, c->counters.as<unsigned int>());
     }
     {
@@ -766,7 +774,7 @@ static int read_counts(sfd2_ctx *c, int64_t cap_out, int *n_out)
     return 0;
 }
 
-extern "C" int sfd2_extract(sfd2_ctx *c, const float *img, int img_on_device, int H, int W, float conf_th, int top_k,
+extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int H, int W, float conf_th, int top_k,
                             int flags, float *kpts_xy, float *scores, float *desc, int out_on_device, int64_t cap_out,
                             int *n_out)
 {
@@ -775,11 +783,15 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const float *img, int img_on_device, in
     HIPCHECK(hipSetDevice(c->device));
     if (ensure_workspace(c, H, W)) return -1;
     const float *img_dev = nullptr;
-    if (stage_image(c, img, img_on_device, H, W, &img_dev)) return -1;
+    const int u8 = (flags & SFD2_FLAG_IMG_U8_HWC) ? 1 : 0;
+    if (u8 && (flags & SFD2_FLAG_IMG_NORMALISED)) return fail("sfd2_extract: a uint8 image cannot be pre-normalised");
+    if ((flags & SFD2_FLAG_IMG_BGR) && !u8) return fail("sfd2_extract: SFD2_FLAG_IMG_BGR needs SFD2_FLAG_IMG_U8_HWC");
+    if (stage_image(c, img, img_on_device, H, W, &img_dev, u8)) return -1;
     HIPCHECK(hipEventRecord(c->ev[0], c->stream));
     prof_step_begin(c);
     c->fuse_now = c->fuse && c->precision == SFD2_PREC_F16;
-    if (run_network(c, img_dev, (flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1)) return -1;
+    const int in_mode = ((flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1) | (u8 ? 2 : 0) | ((flags & SFD2_FLAG_IMG_BGR) ? 4 : 0);
+    if (run_network(c, img_dev, in_mode)) return -1;
     HIPCHECK(hipEventRecord(c->ev[1], c->stream));
     const int HS = 8 * c->H8, WS = 8 * c->W8;
     {
@@ -830,6 +842,112 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const float *img, int img_on_device, in
     if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->tim.ms_backbone = ms;
     if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->tim.ms_post = ms;
     if (n_out) *n_out = n;
+    return 0;
+}
+
+// Scale pyramid (nets/extractor.py:118-236,322-330): every level runs the single-scale pipeline on the bilinearly
+// resized normalised image, keeps its own top_k (the union's top_k is a subset of the levels' top_k), and the levels
+// are merged by score on the device.  Reference quirks kept: the border test uses the ORIGINAL W, H in level
+// coordinates (:181-184); key points are mapped back with x * W / nw in fp32 (:211-212); descriptors are sampled at
+// level coordinates (:199-208); top_k <= 0 returns the plain concatenation, no global sort (:322).
+extern "C" int sfd2_extract_multiscale(sfd2_ctx *c, const void *img, int img_on_device, int H, int W, const double *scales,
+                                       int n_scales, float conf_th, int top_k, int flags, float *kpts_xy, float *scores,
+                                       float *desc, int out_on_device, int64_t cap_out, int *n_out)
+{
+    if (!c || !img || !scales) return fail("sfd2_extract_multiscale: null argument");
+    if (n_scales < 1 || n_scales > 8) return fail("sfd2_extract_multiscale: 1..8 scales");
+    if (!c->weights_loaded) return fail("sfd2_extract_multiscale: weights not loaded");
+    if (flags & SFD2_FLAG_ASYNC) return fail("sfd2_extract_multiscale: SFD2_FLAG_ASYNC is not supported");
+    if (!kpts_xy || !scores) return fail("sfd2_extract_multiscale: kpts_xy and scores are required");
+    HIPCHECK(hipSetDevice(c->device));
+    const int u8 = (flags & SFD2_FLAG_IMG_U8_HWC) ? 1 : 0;
+    if (u8 && (flags & SFD2_FLAG_IMG_NORMALISED)) return fail("sfd2_extract_multiscale: a uint8 image cannot be pre-normalised");
+    if ((flags & SFD2_FLAG_IMG_BGR) && !u8) return fail("sfd2_extract_multiscale: SFD2_FLAG_IMG_BGR needs SFD2_FLAG_IMG_U8_HWC");
+    const int in_mode = ((flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1) | (u8 ? 2 : 0) | ((flags & SFD2_FLAG_IMG_BGR) ? 4 : 0);
+    int nh[8], nw[8], cap[8], off[8];
+    int cap_total = 0;
+    for (int l = 0; l < n_scales; ++l) {
+        nh[l] = scales[l] == 1.0 ? H : (int)((double)H * scales[l]);    // int(H * s), :122-123
+        nw[l] = scales[l] == 1.0 ? W : (int)((double)W * scales[l]);
+        if (nh[l] < 8 || nw[l] < 8) return fail("sfd2_extract_multiscale: a pyramid level is smaller than 8x8");
+        const size_t P1 = (size_t)nh[l] * nw[l];
+        const size_t cc = std::min(std::max<size_t>(65536, P1 / 8), P1);   // ensure_workspace's candidate capacity
+        cap[l] = top_k > 0 ? (int)std::min<size_t>((size_t)top_k, cc) : (int)cc;
+        off[l] = cap_total;
+        cap_total += cap[l];
+    }
+    const float *img_dev = nullptr;
+    if (stage_image(c, img, img_on_device, H, W, &img_dev, u8)) return -1;
+    HIPCHECK(c->ms_kp.ensure((size_t)cap_total * 2 * sizeof(float)));
+    HIPCHECK(c->ms_sc.ensure((size_t)cap_total * sizeof(float)));
+    if (desc) HIPCHECK(c->ms_de.ensure((size_t)cap_total * 128 * sizeof(float)));
+    HIPCHECK(c->ms_keys.ensure((size_t)cap_total * 8));
+    HIPCHECK(c->ms_sorted.ensure((size_t)cap_total * 8));
+    HIPCHECK(c->ms_cnt.ensure(64));
+    HIPCHECK(hipMemsetAsync(c->ms_cnt.p, 0, 64, c->stream));
+    unsigned int *level_count = c->ms_cnt.as<unsigned int>();        // [0..7] level counts, [8..] merge counters
+    unsigned int *ms_counters = level_count + 8;
+    HIPCHECK(hipEventRecord(c->ev[0], c->stream));
+    for (int l = 0; l < n_scales; ++l) {
+        const float *lvl_img = img_dev;
+        int mode = in_mode;
+        if (nh[l] != H || nw[l] != W) {
+            HIPCHECK(c->img_scaled.ensure((size_t)3 * nh[l] * nw[l] * sizeof(float)));
+            launch_norm_resize(c->stream, img_dev, in_mode, H, W, nh[l], nw[l], c->img_scaled.as<float>());
+            lvl_img = c->img_scaled.as<float>();
+            mode = 0;
+        }
+        if (ensure_workspace(c, nh[l], nw[l])) return -1;
+        c->fuse_now = c->fuse && c->precision == SFD2_PREC_F16;
+        if (run_network(c, lvl_img, mode)) return -1;
+        launch_heatmap(c->stream, c->score.as<float>(), 8 * c->H8, 8 * c->W8,
+                       (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(), c->H4, c->W4, nh[l], nw[l],
+                       c->heat.as<float>(), nullptr);
+        if (run_selection(c, c->heat.as<float>(), nh[l], nw[l], conf_th, 4, 4, top_k, nullptr, nullptr, nullptr, H, W)) return -1;
+        if (c->last_sel_cap != cap[l]) return fail("sfd2_extract_multiscale: internal capacity mismatch");
+        if (desc)
+            launch_sample_desc(c->stream, c->draw.as<float>(), c->H4, c->W4, nh[l], nw[l], c->kpts_cur,
+                               c->counters.as<unsigned int>() + 1, cap[l], c->ms_de.as<float>() + (size_t)off[l] * 128);
+        launch_ms_append(c->stream, c->kpts_cur, c->kscores_cur, c->counters.as<unsigned int>() + 1, cap[l], W, nw[l], H, nh[l],
+                         c->ms_kp.as<float>() + (size_t)off[l] * 2, c->ms_sc.as<float>() + off[l], level_count + l);
+        // candidate-buffer overflow of this level is checked after the merge (counters are reused by the next level)
+        HIPCHECK(hipMemcpyAsync(c->ms_cand_seen + l, c->counters.p, 4, hipMemcpyDeviceToHost, c->stream));
+        c->ms_cand_cap[l] = c->cand_cap;
+    }
+    const int64_t want = top_k > 0 ? std::min<int64_t>(top_k, cap_total) : cap_total;
+    const int64_t n_max = cap_out >= 0 ? std::min<int64_t>(want, cap_out) : want;
+    float *kp_dst = kpts_xy, *sc_dst = scores, *de_dst = desc;
+    if (!out_on_device) {
+        HIPCHECK(c->kpts.ensure((size_t)std::max<int64_t>(n_max, 1) * 2 * sizeof(float)));
+        HIPCHECK(c->kscores.ensure((size_t)std::max<int64_t>(n_max, 1) * sizeof(float)));
+        kp_dst = c->kpts.as<float>();
+        sc_dst = c->kscores.as<float>();
+        if (desc) {
+            HIPCHECK(c->kdesc.ensure((size_t)std::max<int64_t>(n_max, 1) * 128 * sizeof(float)));
+            de_dst = c->kdesc.as<float>();
+        }
+    }
+    launch_ms_merge(c->stream, n_scales, off, level_count, c->ms_kp.as<float>(), c->ms_sc.as<float>(),
+                    desc ? c->ms_de.as<float>() : nullptr, cap_total, top_k, c->ms_keys.as<unsigned long long>(),
+                    c->ms_sorted.as<unsigned long long>(), ms_counters, (int)n_max, kp_dst, sc_dst, de_dst);
+    HIPCHECK(hipEventRecord(c->ev[2], c->stream));
+    HIPCHECK(hipGetLastError());
+    unsigned int n_dev = 0;
+    HIPCHECK(hipMemcpyAsync(&n_dev, ms_counters + 2, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    for (int l = 0; l < n_scales; ++l)
+        if (c->ms_cand_seen[l] > (unsigned int)c->ms_cand_cap[l])
+            return fail("candidate buffer overflow at pyramid level " + std::to_string(l));
+    const int64_t n = n_max > 0 ? (int64_t)n_dev : 0;
+    if (!out_on_device) {
+        if (copy_out(c, kpts_xy, kp_dst, (size_t)n * 2 * sizeof(float), 0)) return -1;
+        if (copy_out(c, scores, sc_dst, (size_t)n * sizeof(float), 0)) return -1;
+        if (desc && copy_out(c, desc, de_dst, (size_t)n * 128 * sizeof(float), 0)) return -1;
+        HIPCHECK(hipStreamSynchronize(c->stream));
+    }
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[2]) == hipSuccess) c->tim.ms_total = ms;
+    if (n_out) *n_out = (int)n;
     return 0;
 }
 
@@ -948,7 +1066,7 @@ extern "C" int sfd2_simple_nms(sfd2_ctx *c, const float *heat, int H, int W, int
     if (heat_to_device(c, heat, H, W)) return -1;
     HIPCHECK(c->tmp_f32.ensure((size_t)H * W * sizeof(float)));
     HIPCHECK(hipMemsetAsync(c->counters.p, 0, SFD2_COUNTER_BYTES, c->stream));
-    launch_nms_select(c->stream, c->heat.as<float>(), H, W, radius, 0.0f, 0, c->tmp_f32.as<float>(), nullptr, 0,
+    launch_nms_select(c->stream, c->heat.as<float>(), H, W, radius, 0.0f, 0, H, W, c->tmp_f32.as<float>(), nullptr, 0,
                       c->counters.as<unsigned int>());
     HIPCHECK(hipGetLastError());
     if (copy_out(c, nms_out, c->tmp_f32.p, (size_t)H * W * sizeof(float), 0)) return -1;

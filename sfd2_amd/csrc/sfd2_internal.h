@@ -60,7 +60,9 @@ void launch_detector_head(hipStream_t st, const float *logits, int pitch, int hc
 void launch_heatmap(hipStream_t st, const float *score, int hs, int ws, const float *sta, int hc, int wc,
                     int H, int W, float *heat, float *stab_out /*may be null*/);
 // simple_nms + threshold + border; appends (score,idx) keys; optional dense output
-void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radius, float conf_th, int border,
+// border test: x in [border, Wb-border), y in [border, Hb-border) -- Hb/Wb are the ORIGINAL image dims when the map
+// is a rescaled pyramid level (nets/extractor.py:181-184 tests against W, H, not nw, nh)
+void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radius, float conf_th, int border, int Hb, int Wb,
                        float *nms_dense /*may be null*/, unsigned long long *cand_keys, int cand_cap,
                        unsigned int *counters /*[0]=n_cand*/);
 // top-K of the candidate keys, sorted descending -> sorted_keys[0..n_sel), counters[1]=n_sel
@@ -126,3 +128,11 @@ struct MatchFinal {
 };
 void launch_match_finalize(hipStream_t st, const MatchFinal *fin_dev, int npairs, int max_n, int splits,
                            int flavour, int mutual, float ratio, float dist);
+
+// scale pyramid (nets/extractor.py:118-124,211-236,322-330)
+void launch_norm_resize(hipStream_t st, const float *img, int mode, int H, int W, int nh, int nw, float *out);
+void launch_ms_append(hipStream_t st, const float *kpts, const float *scores, const unsigned int *count, int cap, int W, int nw,
+                      int H, int nh, float *kp_out, float *sc_out, unsigned int *level_count);
+void launch_ms_merge(hipStream_t st, int n_levels, const int *offsets, const unsigned int *level_count, const float *kp_stage,
+                     const float *sc_stage, const float *de_stage, int cap_total, int top_k, unsigned long long *keys,
+                     unsigned long long *sorted, unsigned int *ms_counters, int n_max, float *kp_out, float *sc_out, float *de_out);

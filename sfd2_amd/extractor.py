@@ -47,26 +47,72 @@ def simple_nms(scores, nms_radius: int):
     return torch.from_numpy(out).to(scores.device) if is_t else out
 
 
+def _to_u8_hwc(img):
+    """uint8 [H,W,3] (or [1,H,W,3]) torch / numpy -> (contiguous array-like, on_device, H, W), else None."""
+    if torch is not None and isinstance(img, torch.Tensor):
+        if img.dtype != torch.uint8:
+            return None
+        t = img.detach().reshape(img.shape[-3:]).contiguous()
+        if t.shape[-1] != 3:
+            raise ValueError("uint8 images must be [H, W, 3] (HWC)")
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+            return t, True, int(t.shape[0]), int(t.shape[1])
+        a = t.numpy()
+        return a, False, a.shape[0], a.shape[1]
+    a = np.asarray(img)
+    if a.dtype != np.uint8:
+        return None
+    a = np.ascontiguousarray(a.reshape(a.shape[-3:]))
+    if a.shape[-1] != 3:
+        raise ValueError("uint8 images must be [H, W, 3] (HWC)")
+    return a, False, a.shape[0], a.shape[1]
+
+
 def extract_resnet_return(model, img, conf_th=0.001, mask=None, topK=-1, **kwargs):
-    """nets/extractor.py:97-338.  img: [1,3,H,W] in [0,1] (RGB), cpu or cuda.
+    """nets/extractor.py:97-338.  img: [1,3,H,W] in [0,1] (RGB), cpu or cuda -- or the decoder's
+    uint8 [H,W,3] image as is (kwarg bgr=True for cv2.imread order): the astype(float32) / 255.
+    of extract_localization.py:168,186 then happens on the device and only a quarter of the bytes
+    cross PCIe.  kwarg scales (default [1.0]) is the reference's pyramid (:113-124).
     Returns {'keypoints': [N,2] f64 (x,y), 'descriptors': [N,128] f64, 'scores': [N] f64}
-    sorted by score descending, N <= topK (topK <= 0: all candidates)."""
+    sorted by score descending, N <= topK (topK <= 0: all candidates; with several scales the
+    reference then returns the per-scale lists concatenated, and so does this)."""
     if mask is not None:
         raise NotImplementedError("semantic-mask top-K branch (nets/extractor.py:240-319) is not on the shipped "
                                   "pipelines' path (extract_localization.py:247 passes mask=None)")
-    scales = kwargs.get("scales", [1.0])
-    if list(scales) != [1.0]:
-        raise NotImplementedError("multi-scale extraction (nets/extractor.py:118-124); every shipped conf uses [1.0]")
+    scales = [float(s) for s in kwargs.get("scales", [1.0])]
     ctx = model.context
-    arr, on_dev, H, W = _to_chw(img)
     flags = 0 if getattr(model, "require_stability", True) else _lib.FLAG_NO_STABILITY
-    cap = int(topK) if topK > 0 else max(65536, (H * W) // 8)
-    kp = np.empty((cap, 2), dtype=np.float32)
-    sc = np.empty((cap,), dtype=np.float32)
-    de = np.empty((cap, 128), dtype=np.float32)
+    u8 = _to_u8_hwc(img)
+    if u8 is not None:
+        arr, on_dev, H, W = u8
+        flags |= _lib.FLAG_IMG_U8_HWC | (_lib.FLAG_IMG_BGR if kwargs.get("bgr", False) else 0)
+    else:
+        if kwargs.get("bgr", False):
+            raise ValueError("bgr=True needs a uint8 HWC image")
+        arr, on_dev, H, W = _to_chw(img)
     n = ctypes.c_int(0)
-    _lib.check(ctx.lib.sfd2_extract(ctx.h, _lib.ptr(arr), int(on_dev), H, W, float(conf_th), int(topK), flags,
-                                    kp.ctypes.data, sc.ctypes.data, de.ctypes.data, 0, cap, ctypes.byref(n)))
+    if scales == [1.0]:
+        cap = int(topK) if topK > 0 else max(65536, (H * W) // 8)
+        kp = np.empty((cap, 2), dtype=np.float32)
+        sc = np.empty((cap,), dtype=np.float32)
+        de = np.empty((cap, 128), dtype=np.float32)
+        _lib.check(ctx.lib.sfd2_extract(ctx.h, _lib.ptr(arr), int(on_dev), H, W, float(conf_th), int(topK), flags,
+                                        kp.ctypes.data, sc.ctypes.data, de.ctypes.data, 0, cap, ctypes.byref(n)))
+    else:
+        if not 1 <= len(scales) <= 8:
+            raise ValueError("1..8 scales")
+        if topK > 0:
+            cap = int(topK)
+        else:
+            cap = sum(max(65536, (int(H * s) * int(W * s)) // 8) for s in scales)
+        kp = np.empty((cap, 2), dtype=np.float32)
+        sc = np.empty((cap,), dtype=np.float32)
+        de = np.empty((cap, 128), dtype=np.float32)
+        sarr = (ctypes.c_double * len(scales))(*scales)
+        _lib.check(ctx.lib.sfd2_extract_multiscale(ctx.h, _lib.ptr(arr), int(on_dev), H, W, sarr, len(scales),
+                                                   float(conf_th), int(topK), flags, kp.ctypes.data, sc.ctypes.data,
+                                                   de.ctypes.data, 0, cap, ctypes.byref(n)))
     n = n.value
     # the reference returns float64 containers (nets/extractor.py:322-337)
     return {"keypoints": kp[:n].astype(np.float64), "descriptors": de[:n].astype(np.float64),

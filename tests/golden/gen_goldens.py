@@ -185,6 +185,19 @@ def gen_extract(model, h, w, seed, topk, tag, keep_desc_all=False):
     print(f"extract_{tag}: N={len(sc)} N0={len(cand)} ties={n_ties} min score {sc.min():.5f}")
 
 
+def gen_extract_ms(model, h, w, seed, topk, scales, tag):
+    """G4b: extract_resnet_return with a scale pyramid (nets/extractor.py:113-124,211-236,322-330)."""
+    img = synth.make_image(h, w, seed)
+    pred = ref_ext.extract_resnet_return(model, img=torch.from_numpy(img)[None], topK=topk,
+                                         mask=None, conf_th=0.001, scales=list(scales))
+    kp, sc, de = pred["keypoints"], pred["scores"], pred["descriptors"]
+    out = {"h": h, "w": w, "seed": seed, "topk": topk, "scales": np.asarray(scales, dtype=np.float64),
+           "keypoints": kp.astype(np.float32), "scores": sc.astype(np.float32),
+           "descriptors": de.astype(np.float16)}
+    np.savez_compressed(os.path.join(HERE, f"extract_ms_{tag}.npz"), **out)
+    print(f"extract_ms_{tag}: N={len(sc)} scales={list(scales)}")
+
+
 def gen_extract_spp(model, h, w, seed, conf_th, tag):
     """G5: extract.py nms_fast (:17-84) and extract_spp_feats_singlescale (:205-277)."""
     img = synth.make_image(h, w, seed)
@@ -274,6 +287,10 @@ def gen_host():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     model = ref_model(0)
+    gen_extract_ms(model, 96, 128, 21, 150, [1.0, 0.5], "96x128_k150")
+    gen_extract_ms(model, 100, 130, 22, -1, [1.2, 1.0, 0.6], "100x130_all")
+    if len(sys.argv) > 1 and sys.argv[1] == "ms":
+        sys.exit(0)
     gen_det(model, 64, 96, 11, "64x96")
     gen_det(model, 100, 130, 12, "100x130")
     gen_nms()

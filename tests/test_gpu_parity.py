@@ -55,7 +55,11 @@ def _load(golden_dir, name):
 
 
 def _kp_index(kp):
-    return {(int(x), int(y)): i for i, (x, y) in enumerate(kp)}
+    # exact coordinates (pyramid levels map back to fractional positions); first occurrence wins
+    out = {}
+    for i, (x, y) in enumerate(kp):
+        out.setdefault((float(x), float(y)), i)
+    return out
 
 
 def _compare_extract(got, want, min_iou, desc_tol):
@@ -457,7 +461,7 @@ def test_strict_det_vs_oracle(model_f32, synth_sd, h, w, seed):
 
 def _compare_strict(got, want, desc_tol):
     mine = _kp_index(got["keypoints"])
-    rank = np.array([mine.get((int(x), int(y)), -1) for x, y in want["keypoints"]])
+    rank = np.array([mine.get((float(x), float(y)), -1) for x, y in want["keypoints"]])
     found = rank >= 0
     assert abs(len(got["scores"]) - len(want["scores"])) <= 2
     assert found.mean() >= 0.995, found.mean()
@@ -478,6 +482,91 @@ def test_strict_extract_vs_oracle_and_reference_golden(model_f32, synth_sd, gold
     g = _load(golden_dir, f"extract_{tag}.npz")
     ref = {"keypoints": g["keypoints"], "scores": g["scores"], "descriptors": g["descriptors"].astype(np.float64)}
     _compare_strict(got, ref, 2e-3)    # the fixture stores the reference's descriptors as fp16
+
+
+# ------------------------------------------------------------------ scale pyramid + uint8 ingest
+MS_CASES = [("96x128_k150", 96, 128, 21, 150, [1.0, 0.5]), ("100x130_all", 100, 130, 22, -1, [1.2, 1.0, 0.6])]
+
+
+@pytest.mark.parametrize("tag,h,w,seed,topk,scales", MS_CASES)
+def test_strict_multiscale_vs_oracle_and_reference_golden(model_f32, synth_sd, golden_dir, tag, h, w, seed, topk, scales):
+    from sfd2_amd.extractor import extract_resnet_return
+    img = synth.make_image(h, w, seed)
+    got = extract_resnet_return(model_f32, img[None], conf_th=0.001, topK=topk, scales=scales)
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk, scales=tuple(scales))
+    if topk > 0:
+        assert (np.diff(got["scores"]) <= 0).all() and len(got["scores"]) == topk
+        _compare_strict(got, want, 2e-5)
+    else:   # concatenation in scale order, each level sorted: compare level by level (same lengths up to near-threshold points)
+        assert abs(len(got["scores"]) - len(want["scores"])) <= 2
+        _compare_strict_unordered(got, want, 2e-5)
+    g = _load(golden_dir, f"extract_ms_{tag}.npz")
+    ref = {"keypoints": g["keypoints"], "scores": g["scores"], "descriptors": g["descriptors"].astype(np.float64)}
+    (_compare_strict if topk > 0 else _compare_strict_unordered)(got, ref, 2e-3)
+
+
+def _compare_strict_unordered(got, want, desc_tol):
+    # two pyramid levels can map key points onto the same coordinates: match with multiplicity, in order
+    mine = {}
+    for i, (x, y) in enumerate(got["keypoints"]):
+        mine.setdefault((float(x), float(y)), []).append(i)
+    rank = np.array([(mine.get((float(x), float(y))) or [-1]).pop(0) for x, y in want["keypoints"]])
+    found = rank >= 0
+    assert found.mean() >= 0.99, found.mean()
+    assert np.abs(rank[found] - np.flatnonzero(found)).max() <= 4
+    np.testing.assert_allclose(got["scores"][rank[found]], np.asarray(want["scores"], dtype=np.float64)[found], atol=1e-5, rtol=2e-4)
+    dd = np.abs(got["descriptors"][rank[found]] - np.asarray(want["descriptors"], dtype=np.float64)[found]).max()
+    assert dd <= desc_tol, dd
+
+
+@pytest.mark.parametrize("tag,h,w,seed,topk,scales", MS_CASES)
+def test_multiscale_f16_vs_oracle(model, synth_sd, tag, h, w, seed, topk, scales):
+    from sfd2_amd.extractor import extract_resnet_return
+    img = synth.make_image(h, w, seed)
+    got = extract_resnet_return(model, img[None], conf_th=0.001, topK=topk, scales=scales)
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk, scales=tuple(scales))
+    _compare_extract(got, want, 0.9, 3e-3)
+    np.testing.assert_allclose(np.linalg.norm(got["descriptors"], axis=1), 1.0, atol=1e-5)
+
+
+def test_multiscale_single_level_equals_single_scale(model):
+    """scales=[1.0] through the pyramid entry point == sfd2_extract, bit for bit."""
+    ctx = model.context
+    img = synth.make_image(240, 320, 3)
+    from sfd2_amd.extractor import extract_resnet_return
+    one = extract_resnet_return(model, img[None], conf_th=0.001, topK=512, scales=[1.0])
+    kp = np.empty((512, 2), np.float32); sc = np.empty((512,), np.float32); de = np.empty((512, 128), np.float32)
+    n = ctypes.c_int()
+    sarr = (ctypes.c_double * 1)(1.0)
+    _lib.check(ctx.lib.sfd2_extract_multiscale(ctx.h, img.ctypes.data, 0, 240, 320, sarr, 1, 0.001, 512, 0, kp.ctypes.data,
+                                               sc.ctypes.data, de.ctypes.data, 0, 512, ctypes.byref(n)))
+    k = n.value
+    assert k == len(one["scores"])
+    np.testing.assert_array_equal(kp[:k].astype(np.float64), one["keypoints"])
+    np.testing.assert_array_equal(sc[:k].astype(np.float64), one["scores"])
+    np.testing.assert_array_equal(de[:k].astype(np.float64), one["descriptors"])
+
+
+@pytest.mark.parametrize("precision", ["f16", "f32"])
+def test_uint8_hwc_ingest_equals_float_path(model, model_f32, precision):
+    """extract_localization.py:165-186: uint8 HWC (RGB or cv2 BGR) -> astype(float32) / 255. -> CHW on the device
+    must equal the same conversion done on the host, bit for bit, in both precisions and through the pyramid."""
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    m = model if precision == "f16" else model_f32
+    rs = np.random.RandomState(7)
+    base = (synth.make_image(120, 168, 9).transpose(1, 2, 0) * 255.0 + rs.uniform(-0.5, 0.5, (120, 168, 3)))
+    u8 = np.clip(np.rint(base), 0, 255).astype(np.uint8)
+    f = (u8.astype(np.float32).transpose(2, 0, 1) / 255.).astype(np.float32)
+    want = extract_resnet_return(m, f[None], conf_th=0.001, topK=300, scales=[1.0])
+    for arr, kw in [(u8, {}), (np.ascontiguousarray(u8[:, :, ::-1]), {"bgr": True}), (torch.from_numpy(u8).cuda(), {})]:
+        got = extract_resnet_return(m, arr, conf_th=0.001, topK=300, scales=[1.0], **kw)
+        for k in ("keypoints", "scores", "descriptors"):
+            np.testing.assert_array_equal(got[k], want[k])
+    want = extract_resnet_return(m, f[None], conf_th=0.001, topK=300, scales=[1.0, 0.75])
+    got = extract_resnet_return(m, u8, conf_th=0.001, topK=300, scales=[1.0, 0.75])
+    for k in ("keypoints", "scores", "descriptors"):
+        np.testing.assert_array_equal(got[k], want[k])
 
 
 def test_strict_full_size_vs_oracle(model_f32, synth_sd):

@@ -144,3 +144,27 @@ def test_nms_fast_and_extract_spp_match_reference(golden_dir, synth_sd):
     ok = rank >= 0
     np.testing.assert_allclose(pts[rank[ok], 2], gp[ok, 2], atol=1e-5, rtol=1e-4)
     np.testing.assert_allclose(desc[rank[ok]], g["desc"].astype(np.float32)[ok], atol=2e-3)
+
+
+@pytest.mark.parametrize("tag", ["96x128_k150", "100x130_all"])
+def test_extract_multiscale_matches_reference(golden_dir, synth_sd, tag):
+    """Scale pyramid (nets/extractor.py:113-124,211-236,322-330): level border quirk, fp32 back-mapping,
+    concatenation / global top-K."""
+    g = _load(golden_dir, f"extract_ms_{tag}.npz")
+    h, w, seed, topk = int(g["h"]), int(g["w"]), int(g["seed"]), int(g["topk"])
+    img = synth.make_image(h, w, seed)
+    pred = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk, scales=tuple(g["scales"]))
+    assert len(pred["scores"]) == len(g["scores"])
+    np.testing.assert_array_equal(pred["keypoints"], g["keypoints"].astype(np.float64))
+    np.testing.assert_allclose(pred["scores"], g["scores"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(pred["descriptors"], g["descriptors"].astype(np.float64), atol=2e-3)
+
+
+def test_oracle_uint8_ingest(synth_sd):
+    """extract_localization.py:168,185-186: uint8 HWC -> float32 -> CHW -> / 255."""
+    u8 = (synth.make_image(64, 96, 4).transpose(1, 2, 0) * 255).astype(np.uint8)
+    f = (u8.astype(np.float32).transpose(2, 0, 1) / 255.).astype(np.float32)
+    a = orc.extract_resnet_return(synth_sd, u8, topK=50)
+    b = orc.extract_resnet_return(synth_sd, f, topK=50)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
