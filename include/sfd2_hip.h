@@ -175,6 +175,12 @@ typedef struct {
     int32_t dtype;      /* SFD2_DT_*                                                  */
     int32_t layout;     /* SFD2_LAYOUT_*                                              */
     int32_t on_device;  /* 0 host, 1 device                                           */
+    const int32_t *rows; /* HOST array of n_rows row indices into data, or NULL: only these rows
+                          * take part and matches0 reports THEIR indices -- the db_3D_ids != -1
+                          * mask and the index remap of feature_matching
+                          * (it_loc/localize_cv2.py:531-534,557-559) done on the device     */
+    int32_t n_rows;
+    int32_t reserved;
 } sfd2_desc_set;
 
 /* One query against k database images in one launch (the localiser's inner loop,

@@ -40,7 +40,8 @@ class Timings(ctypes.Structure):
 
 class DescSet(ctypes.Structure):
     _fields_ = [("data", ctypes.c_void_p), ("n", ctypes.c_int32), ("dtype", ctypes.c_int32),
-                ("layout", ctypes.c_int32), ("on_device", ctypes.c_int32)]
+                ("layout", ctypes.c_int32), ("on_device", ctypes.c_int32),
+                ("rows", ctypes.c_void_p), ("n_rows", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class LayerTiming(ctypes.Structure):

@@ -24,15 +24,16 @@
 // ---------------------------------------------------------------- operand preparation
 // hi = fp16(v);  lo = fp16((v - hi) * 2^11)  so that  v ~= hi + lo * 2^-11  to ~2^-22 relative.
 __global__ __launch_bounds__(NT)
-void match_prep_kernel(const void *__restrict__ src, int n, int dim, int dtype, int layout,
-                       half_t *__restrict__ hi, half_t *__restrict__ lo)
+void match_prep_kernel(const void *__restrict__ src, int n, int n_src, const int *__restrict__ rows, int dim, int dtype,
+                       int layout, half_t *__restrict__ hi, half_t *__restrict__ lo)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)n * KD) return;
     const int i = (int)(t / KD), d = (int)(t % KD);
     double v = 0.0;
     if (d < dim) {
-        const size_t off = layout == 0 ? (size_t)i * dim + d : (size_t)d * n + i;
+        const int r = rows ? rows[i] : i;   // gathered subset (feature_matching's 3D-point mask, localize_cv2.py:531-534)
+        const size_t off = layout == 0 ? (size_t)r * dim + d : (size_t)d * n_src + r;
         if (dtype == 0) v = (double)reinterpret_cast<const float *>(src)[off];
         else if (dtype == 1) v = reinterpret_cast<const double *>(src)[off];
         else v = (double)(float)reinterpret_cast<const half_t *>(src)[off];
@@ -42,12 +43,13 @@ void match_prep_kernel(const void *__restrict__ src, int n, int dim, int dtype, 
     if (lo) lo[t] = (half_t)(float)((v - (double)(float)h) * 2048.0);
 }
 
-void launch_match_prep(hipStream_t st, const void *src, int n, int dim, int dtype, int layout, half_t *hi, half_t *lo)
+void launch_match_prep(hipStream_t st, const void *src, int n, int n_src, const int *rows, int dim, int dtype, int layout,
+                       half_t *hi, half_t *lo)
 {
     const size_t tot = (size_t)n * KD;
     if (tot == 0) return;
-    hipLaunchKernelGGL(match_prep_kernel, dim3((unsigned)((tot + NT - 1) / NT)), dim3(NT), 0, st, src, n, dim, dtype,
-                       layout, hi, lo);
+    hipLaunchKernelGGL(match_prep_kernel, dim3((unsigned)((tot + NT - 1) / NT)), dim3(NT), 0, st, src, n, n_src, rows, dim,
+                       dtype, layout, hi, lo);
 }
 
 // ---------------------------------------------------------------- fused GEMM + top-2
@@ -683,7 +685,7 @@ void match_decide_kernel(const MatchFinal *__restrict__ fins, int flavour, int m
             m = ok ? j : -1;
         }
     }
-    f.matches0[i] = m;
+    f.matches0[i] = (m >= 0 && f.remap) ? (long long)f.remap[m] : m;   // back to unmasked indexing (localize_cv2.py:557-559)
     f.scores0[i] = score;
 }
 

@@ -1160,23 +1160,34 @@ extern "C" int sfd2_debug_activation(sfd2_ctx *c, const char *name, float *out, 
 static size_t elt_size(int dtype) { return dtype == SFD2_DT_F64 ? 8 : (dtype == SFD2_DT_F16 ? 2 : 4); }
 
 // Makes a device fp16 [n][128] view (hi, optional lo) of one descriptor set.
-static int prep_set(sfd2_ctx *c, const void *src, int n, int dim, int dtype, int layout, int on_device, int need_lo,
-                    DevBuf &stage, size_t &stage_off, half_t *hi_dst, half_t *lo_dst, const half_t **hi, const half_t **lo)
+// n_src rows live in `src`; `rows` (host, n entries) selects and orders the ones that take part, or null = all n_src.
+static int prep_set(sfd2_ctx *c, const void *src, int n_src, const int32_t *rows, int n, int dim, int dtype, int layout,
+                    int on_device, int need_lo, DevBuf &stage, size_t &stage_off, half_t *hi_dst, half_t *lo_dst,
+                    const half_t **hi, const half_t **lo, const int **rows_dev = nullptr)
 {
-    if (dtype == SFD2_DT_F16 && layout == SFD2_LAYOUT_ND && on_device && dim == 128 && !need_lo) {
+    if (rows_dev) *rows_dev = nullptr;
+    if (!rows && dtype == SFD2_DT_F16 && layout == SFD2_LAYOUT_ND && on_device && dim == 128 && !need_lo) {
         *hi = reinterpret_cast<const half_t *>(src);
         *lo = nullptr;
         return 0;
     }
     const void *dev_src = src;
     if (!on_device) {
-        const size_t bytes = (size_t)n * dim * elt_size(dtype);
+        const size_t bytes = (size_t)n_src * dim * elt_size(dtype);
         void *dst = reinterpret_cast<char *>(stage.p) + stage_off;
         HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
         dev_src = dst;
         stage_off += (bytes + 255) & ~(size_t)255;
     }
-    launch_match_prep(c->stream, dev_src, n, dim, dtype, layout, hi_dst, need_lo ? lo_dst : nullptr);
+    const int *rd = nullptr;
+    if (rows) {
+        void *dst = reinterpret_cast<char *>(stage.p) + stage_off;
+        HIPCHECK(hipMemcpyAsync(dst, rows, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        rd = reinterpret_cast<const int *>(dst);
+        stage_off += ((size_t)n * sizeof(int32_t) + 255) & ~(size_t)255;
+        if (rows_dev) *rows_dev = rd;
+    }
+    launch_match_prep(c->stream, dev_src, n, n_src, rd, dim, dtype, layout, hi_dst, need_lo ? lo_dst : nullptr);
     *hi = hi_dst;
     *lo = need_lo ? lo_dst : nullptr;
     return 0;
@@ -1196,12 +1207,19 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     const int need_lo = conf->sim_mode == SFD2_SIM_F16X2;
     int max_n1 = 0;
     size_t tot_n1 = 0, stage_bytes = 0;
+    if (q->rows) return fail("sfd2_match_batch: row selection applies to database sets only");
+    std::vector<int> eff_n1(k);
     for (int i = 0; i < k; ++i) {
-        if (db[i].n < 0) return fail("negative n1");
+        if (db[i].n < 0 || db[i].n_rows < 0) return fail("negative n1");
         if (db[i].n > 0 && !db[i].data) return fail("sfd2_match_batch: null database descriptors");
-        max_n1 = std::max(max_n1, db[i].n);
-        tot_n1 += (size_t)db[i].n;
+        if (db[i].rows)
+            for (int r = 0; r < db[i].n_rows; ++r)
+                if (db[i].rows[r] < 0 || db[i].rows[r] >= db[i].n) return fail("sfd2_match_batch: row index out of range");
+        eff_n1[i] = db[i].rows ? db[i].n_rows : db[i].n;
+        max_n1 = std::max(max_n1, eff_n1[i]);
+        tot_n1 += (size_t)eff_n1[i];
         if (!db[i].on_device) stage_bytes += (((size_t)db[i].n * dim * elt_size(db[i].dtype)) + 255) & ~(size_t)255;
+        if (db[i].rows) stage_bytes += ((size_t)db[i].n_rows * sizeof(int32_t) + 255) & ~(size_t)255;
     }
     if (!q->on_device) stage_bytes += (((size_t)n0 * dim * elt_size(q->dtype)) + 255) & ~(size_t)255;
     const int max_n = std::max(n0, max_n1);
@@ -1244,7 +1262,7 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     prof_step_begin(c);
     size_t stage_off = 0;
     const half_t *q_hi = nullptr, *q_lo = nullptr;
-    if (prep_set(c, q->data, n0, dim, q->dtype, q->layout, q->on_device, need_lo, c->m_stage, stage_off,
+    if (prep_set(c, q->data, n0, nullptr, n0, dim, q->dtype, q->layout, q->on_device, need_lo, c->m_stage, stage_off,
                  c->m_hi0.as<half_t>(), c->m_lo0.as<half_t>(), &q_hi, &q_lo)) return -1;
     // job descriptors live in pinned host memory owned by the context; the event makes sure the
     // previous call's async copies have consumed them before they are rewritten
@@ -1266,14 +1284,17 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     float *red = c->m_red.as<float>();
     size_t off1 = 0, poff = 0, roff = 0;
     for (int i = 0; i < k; ++i) {
-        const int n1 = db[i].n;
+        const int n1 = eff_n1[i];
         const half_t *h = nullptr, *l = nullptr;
+        const int *remap = nullptr;
         if (n1 > 0) {
-            if (prep_set(c, db[i].data, n1, dim, db[i].dtype, db[i].layout, db[i].on_device, need_lo, c->m_stage, stage_off,
-                         c->m_hi1.as<half_t>() + off1 * 128, need_lo ? c->m_lo1.as<half_t>() + off1 * 128 : nullptr, &h, &l))
+            if (prep_set(c, db[i].data, db[i].n, db[i].rows, n1, dim, db[i].dtype, db[i].layout, db[i].on_device, need_lo,
+                         c->m_stage, stage_off, c->m_hi1.as<half_t>() + off1 * 128,
+                         need_lo ? c->m_lo1.as<half_t>() + off1 * 128 : nullptr, &h, &l, &remap))
                 return -1;
         }
         MatchFinal &fn = fins[i];
+        fn.remap = remap;
         if (single_gemm) {
             MatchJob2 &j2 = jobs2[i];
             j2.q_hi = q_hi; j2.d_hi = h; j2.n0 = n0; j2.n1 = n1;
@@ -1350,8 +1371,8 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
 extern "C" int sfd2_match(sfd2_ctx *c, const void *d0, int n0, const void *d1, int n1, int dim, int dtype, int layout,
                           int on_device, const sfd2_match_conf *conf, int64_t *matches0, float *scores0, int out_on_device)
 {
-    const sfd2_desc_set q = {d0, n0, dtype, layout, on_device};
-    const sfd2_desc_set db = {d1, n1, dtype, layout, on_device};
+    const sfd2_desc_set q = {d0, n0, dtype, layout, on_device, nullptr, 0, 0};
+    const sfd2_desc_set db = {d1, n1, dtype, layout, on_device, nullptr, 0, 0};
     return sfd2_match_batch(c, &q, &db, 1, dim, conf, matches0, scores0, out_on_device, 0);
 }
 

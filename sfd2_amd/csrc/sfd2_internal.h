@@ -91,8 +91,8 @@ void launch_nchw_f_to_nhwc_f(hipStream_t st, const float *in, int npix, int c, f
 
 // ------------------------------------------------------------------ matcher
 // convert descriptors to fp16 [n][128] (hi) and optional scaled residual (lo)
-void launch_match_prep(hipStream_t st, const void *src, int n, int dim, int dtype, int layout,
-                       half_t *hi, half_t *lo /*may be null*/);
+void launch_match_prep(hipStream_t st, const void *src, int n, int n_src, const int *rows, int dim, int dtype, int layout,
+                       half_t *hi, half_t *lo);
 struct MatchJob {          // one direction of one pair
     const half_t *a_hi;    // reduced side ("columns" j), [na][128]
     const half_t *a_lo;
@@ -125,6 +125,7 @@ struct MatchFinal {
     long long *matches0; float *scores0;
     float *red_f;  // scratch [3*n0]
     float *red_r;  // scratch [3*n1]
+    const int *remap;  // matched column -> caller's row index (gathered database sets), or null
 };
 void launch_match_finalize(hipStream_t st, const MatchFinal *fin_dev, int npairs, int max_n, int splits,
                            int flavour, int mutual, float ratio, float dist);

@@ -60,15 +60,21 @@ class Matcher:
 
     __call__ = forward
 
-    def match_batch(self, d0, d1_list):
+    def match_batch(self, d0, d1_list, rows_list=None):
         """One query against K database descriptor sets in a single launch (the localiser's
-        inner loop, it_loc/localize_cv2.py:705-715).  Returns ([K,N] matches0, [K,N] scores0)."""
+        inner loop, it_loc/localize_cv2.py:705-715).  Returns ([K,N] matches0, [K,N] scores0).
+        rows_list[i] (int array or None) restricts database set i to those rows; matches0 then
+        reports the caller's row indices (feature_matching's mask + remap, :531-534,557-559)."""
         d0 = np.ascontiguousarray(d0, dtype=np.float32)
         ds = [np.ascontiguousarray(d, dtype=np.float32) for d in d1_list]
         k, n0 = len(ds), d0.shape[0]
+        rows = [None] * k if rows_list is None else [None if r is None else np.ascontiguousarray(r, dtype=np.int32)
+                                                     for r in rows_list]
         ctx = _lib.default_context(self._device)
-        q = _lib.DescSet(d0.ctypes.data, n0, _lib.DT_F32, _lib.LAYOUT_ND, 0)
-        db = (_lib.DescSet * k)(*[_lib.DescSet(d.ctypes.data, d.shape[0], _lib.DT_F32, _lib.LAYOUT_ND, 0) for d in ds])
+        q = _lib.DescSet(d0.ctypes.data, n0, _lib.DT_F32, _lib.LAYOUT_ND, 0, None, 0, 0)
+        db = (_lib.DescSet * k)(*[_lib.DescSet(d.ctypes.data, d.shape[0], _lib.DT_F32, _lib.LAYOUT_ND, 0,
+                                               None if r is None else r.ctypes.data, 0 if r is None else len(r), 0)
+                                  for d, r in zip(ds, rows)])
         m = np.empty((k, n0), dtype=np.int64)
         s = np.empty((k, n0), dtype=np.float32)
         conf = self._conf()

@@ -641,3 +641,51 @@ def test_feature_matching_mask_and_remap():
     assert (feature_matching(q, db, mt, db_3D_ids=np.full(600, -1)) == -1).all()      # <= 3 valid: early out
     plain = feature_matching(q, db, mt)
     np.testing.assert_array_equal(plain, orc.itloc_matcher(q, db, "nnm")["matches0"])
+
+
+@pytest.mark.parametrize("mode", ["NNM", "NNR"])
+def test_feature_matching_batch_device_mask_and_remap(mode):
+    """One query against K database images, masks and remaps on the device:
+    equals the per-image feature_matching loop and the oracle on gathered descriptors."""
+    from sfd2_amd.localize import feature_matching, feature_matching_batch
+    from sfd2_amd.matcher import Matcher, confs as mconfs
+    mt = Matcher({"output": mode, "model": {**mconfs[mode]["model"], "sim_mode": "f16x2"}}).eval().cuda()
+    rs = np.random.RandomState(11)
+    q = synth.make_descriptors(500, seed=15).astype(np.float64)
+    dbs, ids = [], []
+    for i, n in enumerate([700, 64, 333, 10, 1200]):
+        d = synth.make_descriptors(n, seed=20 + i).astype(np.float64)
+        take = rs.permutation(n)[:n // 3]
+        d[take] = q[rs.permutation(500)[:len(take)]] + rs.normal(0, 0.01, (len(take), 128))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        dbs.append(d)
+        ids.append(np.where(rs.random_sample(n) < 0.5, rs.randint(0, 100000, n), -1))
+    ids[3][:] = -1
+    ids[3][:3] = 5                                       # exactly 3 valid -> early out, all -1
+    ids.append(None); dbs.append(dbs[0])                 # an unmasked image rides in the same batch
+    got = feature_matching_batch(q, dbs, mt, ids)
+    assert len(got) == len(dbs)
+    for i, (d, pid) in enumerate(zip(dbs, ids)):
+        np.testing.assert_array_equal(got[i], feature_matching(q, d, mt, db_3D_ids=pid), err_msg=str(i))
+        if pid is None:
+            want = orc.itloc_matcher(q, d, mode.lower())["matches0"]
+        else:
+            valid = np.flatnonzero(pid != -1)
+            if len(valid) <= 3:
+                want = np.full(500, -1)
+            else:
+                w = orc.itloc_matcher(q, d[valid], mode.lower())["matches0"]
+                want = np.where(w >= 0, valid[np.maximum(w, 0)], -1)
+        np.testing.assert_array_equal(got[i], want, err_msg=str(i))
+    assert (got[3] == -1).all()
+
+
+def test_match_batch_row_selection_rejects_bad_indices(ctx):
+    d = synth.make_descriptors(32, seed=1)
+    rows = np.array([0, 5, 32], dtype=np.int32)
+    q = _lib.DescSet(d.ctypes.data, 32, _lib.DT_F32, _lib.LAYOUT_ND, 0, None, 0, 0)
+    db = (_lib.DescSet * 1)(_lib.DescSet(d.ctypes.data, 32, _lib.DT_F32, _lib.LAYOUT_ND, 0, rows.ctypes.data, 3, 0))
+    conf = _lib.MatchConf(1, 1, 0.0, 0.0, 0)
+    m = np.empty((1, 32), np.int64); s = np.empty((1, 32), np.float32)
+    rc = ctx.lib.sfd2_match_batch(ctx.h, ctypes.byref(q), db, 1, 128, ctypes.byref(conf), m.ctypes.data, s.ctypes.data, 0, 0)
+    assert rc != 0 and b"out of range" in ctx.lib.sfd2_last_error()
