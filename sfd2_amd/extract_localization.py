@@ -60,3 +60,38 @@ def extract_one(model, extractor, image, original_size, conf):
     size = np.array(image.shape[-2:][::-1])
     pred['keypoints'] = rescale_keypoints(pred['keypoints'], original_size, size)
     return pred
+
+
+def main(conf, images, export_dir, state_dict=None, device=0, tag=None):
+    """extract_localization.py:221-275 without the image decoder: ``images`` yields
+    {'name': str, 'image': uint8 [H,W,3] RGB (or float [3,H,W] in [0,1]), 'original_size': (w, h)}
+    (what ImageDataset.__getitem__ returns before / after its astype-and-divide, :157-190); one
+    group per image goes to the feature store with the reference's dataset names and dtypes.
+    uint8 images are converted on the device.  Returns the store path."""
+    import os
+    from .feature_io import open_store, write_features
+    model, extractor = get_model(conf['model']['name'], weight_path=conf['model']['model_fn'],
+                                 use_stability=conf['model']['use_stability'], state_dict=state_dict, device=device)
+    os.makedirs(str(export_dir), exist_ok=True)
+    path = os.path.join(str(export_dir), conf['output'] + '.h5')
+    store = open_store(path, 'a')
+    try:
+        for data in images:
+            if tag is not None and data['name'].find(tag) < 0:
+                continue
+            img = data['image']
+            if img.dtype == np.uint8:
+                size = np.array(img.shape[:2][::-1])
+                feed = img
+            else:
+                size = np.array(img.shape[-2:][::-1])
+                feed = img[None] if img.ndim == 3 else img
+            pred = extractor(model, img=feed, topK=conf["model"]["max_keypoints"], mask=None,
+                             conf_th=conf["model"]["conf_th"], scales=conf["model"]["scales"])
+            pred['descriptors'] = pred['descriptors'].transpose()
+            pred['image_size'] = original_size = np.asarray(data['original_size'])
+            pred['keypoints'] = rescale_keypoints(pred['keypoints'], original_size, size)
+            write_features(store, data['name'], pred)
+    finally:
+        store.close()
+    return getattr(store, 'path', path)

@@ -48,3 +48,30 @@ def match_pair(model, feats0, feats1):
 def load_matcher(conf):
     Model = dynamic_load(matchers, conf['model']['name'])   # hloc/match_features.py:77-79
     return Model(conf['model']).eval().to('cuda')
+
+
+def main(conf, pair_list, features, export_dir, pairs_name='pairs'):
+    """hloc/match_features.py:48-123: ``pair_list`` holds the pairs file's lines ("name0 name1"),
+    ``features`` the feature store's name inside export_dir (:52-54).  Skips pairs already matched in
+    either order or already stored (:88-97), writes matches0 int16 / matching_scores0 fp16 per pair
+    (:108-116) into <features>-<conf output>-<pairs_name> (:81-82)."""
+    import os
+    from .feature_io import open_store, write_matches
+    model = load_matcher(conf)
+    feats = open_store(os.path.join(str(export_dir), features + '.h5'), 'r')
+    out_path = os.path.join(str(export_dir), f'{features}-{conf["output"]}-{pairs_name}.h5')
+    store = open_store(out_path, 'a')
+    try:
+        for name0, name1 in unique_pairs(pair_list):
+            pair = names_to_pair(name0, name1)
+            if pair in store:
+                continue
+            f0, f1 = feats[name0], feats[name1]
+            data = {'descriptors0': np.asarray(f0['descriptors'].__array__(), dtype=np.float32)[None],
+                    'descriptors1': np.asarray(f1['descriptors'].__array__(), dtype=np.float32)[None]}
+            pred = model(data)
+            write_matches(store, pair, pred['matches0'][0], pred['matching_scores0'][0])
+    finally:
+        store.close()
+        feats.close()
+    return getattr(store, 'path', out_path)

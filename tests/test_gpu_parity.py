@@ -689,3 +689,37 @@ def test_match_batch_row_selection_rejects_bad_indices(ctx):
     m = np.empty((1, 32), np.int64); s = np.empty((1, 32), np.float32)
     rc = ctx.lib.sfd2_match_batch(ctx.h, ctypes.byref(q), db, 1, 128, ctypes.byref(conf), m.ctypes.data, s.ctypes.data, 0, 0)
     assert rc != 0 and b"out of range" in ctx.lib.sfd2_last_error()
+
+
+def test_pipeline_mains_write_reference_layout(tmp_path, synth_sd):
+    """extract_localization.main -> feature store -> match_features.main, uint8 images in, the reference's
+    group / dataset names and dtypes out; stored matches equal a direct NearestNeighbor call."""
+    from sfd2_amd import extract_localization as el, match_features as mf, feature_io as fio
+    from sfd2_amd.matchers.nearest_neighbor import NearestNeighbor
+    name, conf = next(iter(el.confs.items()))
+    conf = {**conf, "model": {**conf["model"], "max_keypoints": 256}}
+    imgs = []
+    for i, nm in enumerate(["db/a.jpg", "db/b.jpg", "query/c.jpg"]):
+        u8 = (synth.make_image(96, 128, 40 + i).transpose(1, 2, 0) * 255).astype(np.uint8)
+        imgs.append({"name": nm, "image": u8, "original_size": (256, 192)})      # features live at 2x the network size
+    path = el.main(conf, imgs, tmp_path, state_dict=synth_sd)
+    st = fio.open_store(path, "r")
+    assert list(st.keys()) == ["db/a.jpg", "db/b.jpg", "query/c.jpg"]
+    g = st["db/a.jpg"]
+    n = g["scores"].shape[0]
+    assert g["keypoints"].shape == (n, 2) and g["descriptors"].shape == (128, n) and n > 50
+    assert g["keypoints"].dtype == np.float64 and g["descriptors"].dtype == np.float64 and g["scores"].dtype == np.float64
+    np.testing.assert_array_equal(g["image_size"].__array__(), [256, 192])
+    kp = g["keypoints"].__array__()
+    assert np.allclose((kp + .5) / 2 - .5, np.rint((kp + .5) / 2 - .5))          # (kp + .5) * scale - .5 with scale 2
+    pairs = ["query/c.jpg db/a.jpg", "db/a.jpg query/c.jpg", "query/c.jpg db/b.jpg"]
+    mpath = mf.main(mf.confs["NNM"], pairs, "feats-" + name, tmp_path)
+    ms = fio.open_store(mpath, "r")
+    assert list(ms.keys()) == ["query-c.jpg_db-a.jpg", "query-c.jpg_db-b.jpg"]           # the reversed duplicate is skipped
+    m = ms["query-c.jpg_db-a.jpg"]
+    assert m["matches0"].dtype == np.int16 and m["matching_scores0"].dtype == np.float16
+    nn = NearestNeighbor(mf.confs["NNM"]["model"]).eval().to("cuda")
+    pred = nn({"descriptors0": st["query/c.jpg"]["descriptors"].__array__().astype(np.float32)[None],
+               "descriptors1": st["db/a.jpg"]["descriptors"].__array__().astype(np.float32)[None]})
+    np.testing.assert_array_equal(m["matches0"][()], np.asarray(pred["matches0"][0]).astype(np.int16))
+    assert (m["matches0"][()] >= 0).sum() > 0
