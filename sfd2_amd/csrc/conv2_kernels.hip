@@ -35,8 +35,8 @@ __device__ __forceinline__ h4_t cvt4b(float a, float b, float c, float d)
     return r;
 }
 
-template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES>
-__global__ __launch_bounds__(NT2, 2)
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0>
+__global__ __launch_bounds__(NW * 64, (NW == 8 || ROWS != 0) ? 2 : 1)
 void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                         const half_t *__restrict__ wpk, const float *__restrict__ scale,
                         const float *__restrict__ shift, int CoutP, int relu,
@@ -45,7 +45,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 {
     constexpr int T = KS * KS;
     constexpr int PAD = KS / 2;
- constexpr int THT = (STRIDE == 1) ? TH2 : 4;      // output rows per tile: 8 (stride 1) or 4 (stride 2: the patch is 2x larger)
+    constexpr int THT = ROWS ? ROWS : ((STRIDE == 1) ? TH2 : 4);   // output rows per tile: 8 (stride 1) or 4 (stride 2: the patch is 2x larger)
     constexpr int PH = (THT - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
     constexpr int NPIX = PH * PW;
     constexpr int RB = CC * 2;                         // bytes per record (one pixel / one filter row of a K chunk)
@@ -53,11 +53,11 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     constexpr int SPR = RB / 16;                       // 16-byte slots per record (4 or 8)
     constexpr int SWS = (CC == 32) ? 2 : 1;            // swizzle: slot ^= (record >> SWS) & (SPR - 1)
     constexpr int XCH = (NPIX + RPC - 1) / RPC;        // 1 KB chunks of one patch
-    constexpr int XPW = (XCH + 7) / 8;                 // chunks per wave
+    constexpr int XPW = (XCH + NW - 1) / NW;           // chunks per wave
     constexpr int WCH = BN / RPC;                      // 1 KB chunks of one filter tile
-    constexpr int WPW = WCH / 8;                       // per wave
+    constexpr int WPW = WCH / NW;                      // per wave
     constexpr int XBYTES = XCH * 1024, WBYTES = BN * RB;
-    constexpr int WAVES_CH = 2, WAVES_PX = 4;   // (4 x 2 and s_setprio around the MFMA bursts measured no better)
+    constexpr int WAVES_CH = 2, WAVES_PX = NW / 2;   // (4 x 2 and s_setprio around the MFMA bursts measured no better)
     constexpr int CH_T = BN / WAVES_CH / 32;           // 2 or 4
     constexpr int PX_T = THT / WAVES_PX;               // image rows per wave (2 or 1)
 
@@ -82,7 +82,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     int xoff[XPW];
 #pragma unroll
     for (int i = 0; i < XPW; ++i) {
-        const int chunk = wave + 8 * i;
+        const int chunk = wave + NW * i;
         const int q = chunk * RPC + lane / SPR;
         const int slot = (lane % SPR) ^ ((q >> SWS) & (SPR - 1));  // logical 16-byte slot this lane's bytes hold
         int off = -1;
@@ -103,10 +103,10 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 
 #define ISSUE_X(chunk_, buf_)                                                                          \
     _Pragma("unroll") for (int i = 0; i < XPW; ++i) {                                                  \
-        if (wave + 8 * i < XCH) {                                                                      \
+        if (wave + NW * i < XCH) {                                                                     \
             const half_t *src = xoff[i] >= 0 ? in + (size_t)xoff[i] + (chunk_)*CC : zero_page + (lane % SPR) * 8; \
             __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                        \
-                                             (lds_void_t *)(Xs + (buf_)*XBYTES + (wave + 8 * i) * 1024), 16, 0, 0); \
+                                             (lds_void_t *)(Xs + (buf_)*XBYTES + (wave + NW * i) * 1024), 16, 0, 0); \
         }                                                                                              \
     }
 #define ISSUE_W(step_, buf_)                                                                           \
@@ -127,7 +127,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     const int NS = (Cin / CC) * T;
     ISSUE_X(0, 0)
     ISSUE_W(0, 0)
-    if (tid < BN) { SS[tid] = scale[n0 + tid]; SS[BN + tid] = shift[n0 + tid]; }
+    for (int t = tid; t < BN; t += NW * 64) { SS[t] = scale[n0 + t]; SS[BN + t] = shift[n0 + t]; }
     __syncthreads();   // hipcc drains vmcnt(0) before the barrier while LDS-DMA is in flight
 
     const int lrow = lane & 31, lhi = lane >> 5;
@@ -276,25 +276,25 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     }
 }
 
-template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES>
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0>
 static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                             const float *scale, const float *shift, int CoutP, int relu, const half_t *res,
                             void *out, int Ho, int Wo, const half_t *zero_page)
 {
-    constexpr int THT = (STRIDE == 1) ? TH2 : 4;
+    constexpr int THT = ROWS ? ROWS : ((STRIDE == 1) ? TH2 : 4);
     constexpr int PH = (THT - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
     constexpr int RPC = 1024 / (CC * 2);
     constexpr int XCH = (PH * PW + RPC - 1) / RPC;
     constexpr size_t lds = (size_t)2 * XCH * 1024 + (size_t)2 * BN * CC * 2 + (size_t)2 * BN * sizeof(float);
     static bool attr_done = false;
-    auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES>;
+    auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES, NW, ROWS>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + THT - 1) / THT;
     const int grid = tiles_x * tiles_y * (CoutP / BN);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT2), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, res, out,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, res, out,
                        Ho, Wo, tiles_x, zero_page);
 }
 
@@ -307,6 +307,8 @@ int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin)
     // 256-channel tiles: 64-wide K chunks (one block per CU either way, half the barriers);
     // 128-channel tiles: 32-wide chunks keep the LDS footprint at 60 KB -> two blocks per CU
     static const bool bn128 = getenv("SFD2_CONV_BN128") != nullptr;   // experiment: 128-channel tiles everywhere
+    static const bool small1 = getenv("SFD2_CONV_1X1_SMALL") != nullptr;   // experiment: 4-wave 4x32 tiles for 1x1
+    if (small1 && ks == 1 && CoutP % 256 == 0) return 32;
     if (CoutP % 256 == 0 && !bn128) return (Cin % 64 == 0) ? 64 : 32;
     return 32;
 }
@@ -336,6 +338,17 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
     if (cc == 0) return false;
     static const bool bn128 = getenv("SFD2_CONV_BN128") != nullptr;
     const int bn = (CoutP % 256 == 0 && !bn128) ? 256 : 128;
+    static const bool nw4 = getenv("SFD2_CONV_NW4") != nullptr;   // experiment: 4 waves, 128 ch x 128 px per wave
+    if (nw4 && ks == 3 && !out_f32 && bn == 256 && cc == 64 && !residual) {
+        launch_igemm2_t<3, 1, 256, 64, false, false, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
+        return true;
+    }
+    static const bool small1 = getenv("SFD2_CONV_1X1_SMALL") != nullptr;
+    if (small1 && ks == 1 && !out_f32 && bn == 256 && cc == 32) {
+        if (residual) launch_igemm2_t<1, 1, 256, 32, false, true, 4, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
+        else launch_igemm2_t<1, 1, 256, 32, false, false, 4, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
+        return true;
+    }
     if (ks == 3 && !out_f32) { if (bn == 256) SFD2_IG2(3, 256, false); else SFD2_IG2(3, 128, false); return true; }
     if (ks == 1 && !out_f32) { if (bn == 256) SFD2_IG2(1, 256, false); else SFD2_IG2(1, 128, false); return true; }
     if (ks == 1 && out_f32) { if (bn == 256) SFD2_IG2(1, 256, true); else SFD2_IG2(1, 128, true); return true; }

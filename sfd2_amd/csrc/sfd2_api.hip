@@ -84,6 +84,7 @@ struct sfd2_ctx {
     int last_sel_cap = 0;
     float *kpts_cur = nullptr, *kscores_cur = nullptr;   // where the last selection wrote its key points
     // scale pyramid staging (sfd2_extract_multiscale)
+    DevBuf arena;   // aliased activation slots of the throughput path (run_network)
     DevBuf img_scaled, ms_kp, ms_sc, ms_de, ms_keys, ms_sorted, ms_cnt;
     unsigned int ms_cand_seen[8] = {};
     int ms_cand_cap[8] = {};
@@ -174,7 +175,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
                       &c->g1a, &c->g1b, &c->g2a, &c->g2b, &c->g3a, &c->g3b, &c->grt1[0], &c->grt1[1], &c->grt1[2],
                       &c->grt2[0], &c->grt2[1], &c->grt2[2], &c->gro[0], &c->gro[1], &c->gro[2], &c->gpa0_o, &c->gpa_o,
                       &c->gda0_o, &c->gda_o, &c->m_rkeys, &c->g_keys, &c->g_state0, &c->g_state1, &c->g_kept,
-                      &c->img_scaled, &c->ms_kp, &c->ms_sc, &c->ms_de, &c->ms_keys, &c->ms_sorted, &c->ms_cnt};
+                      &c->arena, &c->img_scaled, &c->ms_kp, &c->ms_sc, &c->ms_de, &c->ms_keys, &c->ms_sorted, &c->ms_cnt};
     for (DevBuf *b : bufs) b->release();
     ConvW *ws[] = {&c->c1a, &c->c1b, &c->c2a, &c->c2b, &c->c3a, &c->c3b, &c->rb1[0], &c->rb1[1], &c->rb1[2],
                    &c->rb2[0], &c->rb2[1], &c->rb2[2], &c->rb3[0], &c->rb3[1], &c->rb3[2], &c->pa0, &c->pa3,
@@ -621,44 +622,69 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     hipStream_t st = c->stream;
     const int H = c->H, W = c->W, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
     const double P1 = (double)H * W, P4 = (double)H4 * W4, P8 = (double)H8 * W8;
+    // Activation placement.  det (the parity entry point) keeps every activation in its own buffer for
+    // sfd2_debug_activation.  The throughput path (sfd2_extract) packs the whole chain into four 61 MB slots of one
+    // arena (at 1600x1200), reusing a slot as soon as its tensor is dead, so the working set fits the 256 MB
+    // Infinity Cache and a layer mostly reads what the previous one just wrote (measured: ResBlocks 400 -> 366 us).
+    static const bool no_alias = getenv("SFD2_NO_ALIAS") != nullptr;
+    const bool alias = c->fuse_now && !no_alias;
+    DevBuf a1b = c->a1b, a2a = c->a2a, a2b = c->a2b, a3a = c->a3a, a3b = c->a3b, pa0_o = c->pa0_o, pa_o = c->pa_o,
+           da0_o = c->da0_o, da_o = c->da_o;   // non-owning views
+    DevBuf t1v[3] = {c->rt1[0], c->rt1[1], c->rt1[2]}, t2v[3] = {c->rt2[0], c->rt2[1], c->rt2[2]},
+           rov[3] = {c->ro[0], c->ro[1], c->ro[2]};
+    if (alias) {
+        const size_t P2 = (size_t)H2 * W2, P4s = (size_t)H4 * W4, P8s = (size_t)H8 * W8;
+        size_t S = std::max(P2 * 64 * 2, P4s * 256 * 2);
+        S = std::max(S, (P2 * 128 * 2 + 1) / 2);
+        S = std::max(S, 2 * (P8s * 256 * 2 + 256));
+        S = (S + 255) & ~(size_t)255;
+        HIPCHECK(c->arena.ensure(4 * S));
+        char *base = c->arena.as<char>();
+        auto slot = [&](int i, size_t off = 0) { DevBuf v; v.p = base + (size_t)i * S + off; v.cap = 0; return v; };
+        a1b = slot(0); a2a = slot(1) /* spans slots 1-2 */; a2b = slot(0); a3a = slot(3); a3b = slot(1);
+        for (int b = 0; b < 3; ++b) { t1v[b] = slot(0); t2v[b] = slot(2); rov[b] = slot((b & 1) ? 1 : 3); }
+        pa0_o = slot(0); pa_o = slot(0, (P8s * 256 * 2 + 255) & ~(size_t)255);
+        da0_o = slot(1); da_o = slot(2);
+    }
     if (c->fuse_now) {
         ProfScope ps(c, "conv1a+conv1b", "fused_stem_kernel", 2.0 * P1 * 64 * 27 + 2.0 * (double)H2 * W2 * 64 * 576,
                      P1 * 12 + (double)H2 * W2 * 128);
         launch_fused_stem(st, img_dev, H, W, normalise, c->c1a.w.as<half_t>(), c->c1a.scale.as<float>(),
                           c->c1a.shift.as<float>(), c->w1b_fused.as<half_t>(), c->c1b.scale.as<float>(),
-                          c->c1b.shift.as<float>(), c->a1b.as<half_t>(), H2, W2);
+                          c->c1b.shift.as<float>(), a1b.as<half_t>(), H2, W2);
     } else {
         {
             ProfScope ps(c, "conv1a", "conv1a_kernel", 2.0 * P1 * 64 * 27, P1 * (12 + 128));
             launch_conv1a(st, img_dev, H, W, normalise, c->c1a.w.as<half_t>(), c->c1a.scale.as<float>(),
                           c->c1a.shift.as<float>(), c->a1a.as<half_t>());
         }
-        conv(c, "conv1b", c->c1b, c->a1a, H, W, c->a1b, H2, W2, 1);
+        conv(c, "conv1b", c->c1b, c->a1a, H, W, a1b, H2, W2, 1);
     }
-    conv(c, "conv2a", c->c2a, c->a1b, H2, W2, c->a2a, H2, W2, 1);
-    conv(c, "conv2b", c->c2b, c->a2a, H2, W2, c->a2b, H4, W4, 1);
-    conv(c, "conv3a", c->c3a, c->a2b, H4, W4, c->a3a, H4, W4, 1);
-    conv(c, "conv3b", c->c3b, c->a3a, H4, W4, c->a3b, H4, W4, 1);
-    const DevBuf *x = &c->a3b;
+    conv(c, "conv2a", c->c2a, a1b, H2, W2, a2a, H2, W2, 1);
+    conv(c, "conv2b", c->c2b, a2a, H2, W2, a2b, H4, W4, 1);
+    conv(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1);
+    conv(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1);
+    const DevBuf *x = &a3b;
     static const char *nm1[3] = {"conv4.0.conv1", "conv4.1.conv1", "conv4.2.conv1"};
     static const char *nm2[3] = {"conv4.0.conv2", "conv4.1.conv2", "conv4.2.conv2"};
     static const char *nm3[3] = {"conv4.0.conv3", "conv4.1.conv3", "conv4.2.conv3"};
     for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
-        conv(c, nm1[b], c->rb1[b], *x, H4, W4, c->rt1[b], H4, W4, 1);
+        DevBuf &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];
+        conv(c, nm1[b], c->rb1[b], *x, H4, W4, t1, H4, W4, 1);
         {
             ProfScope ps(c, nm2[b], "gconv3x3_g8_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 4);
-            launch_gconv3x3_g8(st, c->rt1[b].as<half_t>(), H4, W4, c->rb2[b].w.as<half_t>(),
-                               c->rb2[b].scale.as<float>(), c->rb2[b].shift.as<float>(), c->rt2[b].as<half_t>());
+            launch_gconv3x3_g8(st, t1.as<half_t>(), H4, W4, c->rb2[b].w.as<half_t>(),
+                               c->rb2[b].scale.as<float>(), c->rb2[b].shift.as<float>(), t2.as<half_t>());
         }
-        conv(c, nm3[b], c->rb3[b], c->rt2[b], H4, W4, c->ro[b], H4, W4, 1, x->as<half_t>());
-        x = &c->ro[b];
+        conv(c, nm3[b], c->rb3[b], t2, H4, W4, ob, H4, W4, 1, x->as<half_t>());
+        x = &ob;
     }
-    conv(c, "convPa.0", c->pa0, *x, H4, W4, c->pa0_o, H8, W8, 1);
-    conv(c, "convPa.3", c->pa3, c->pa0_o, H8, W8, c->pa_o, H8, W8, 0);
-    conv(c, "convPb", c->pb, c->pa_o, H8, W8, c->logits, H8, W8, 0, nullptr, 1);
-    conv(c, "convDa.0", c->da0, *x, H4, W4, c->da0_o, H4, W4, 1);
-    conv(c, "convDa.3", c->da3, c->da0_o, H4, W4, c->da_o, H4, W4, 0);
-    conv(c, "convDb", c->db, c->da_o, H4, W4, c->draw, H4, W4, 0, nullptr, 1);
+    conv(c, "convPa.0", c->pa0, *x, H4, W4, pa0_o, H8, W8, 1);
+    conv(c, "convPa.3", c->pa3, pa0_o, H8, W8, pa_o, H8, W8, 0);
+    conv(c, "convPb", c->pb, pa_o, H8, W8, c->logits, H8, W8, 0, nullptr, 1);
+    conv(c, "convDa.0", c->da0, *x, H4, W4, da0_o, H4, W4, 1);
+    conv(c, "convDa.3", c->da3, da0_o, H4, W4, da_o, H4, W4, 0);
+    conv(c, "convDb", c->db, da_o, H4, W4, c->draw, H4, W4, 0, nullptr, 1);
     {
         ProfScope ps(c, "ConvSta", "convsta_kernel", 2.0 * P4 * 3 * 256, P4 * (512 + 12));
         launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
