@@ -35,7 +35,7 @@ __device__ __forceinline__ h4_t cvt4b(float a, float b, float c, float d)
     return r;
 }
 
-template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0>
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || ROWS != 0) ? 2 : 1)
 void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                         const half_t *__restrict__ wpk, const float *__restrict__ scale,
@@ -62,8 +62,10 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     constexpr int PX_T = THT / WAVES_PX;               // image rows per wave (2 or 1)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *Xs = smem;                          // [2][XBYTES]
-    unsigned char *Ws = smem + 2 * XBYTES;             // [2][WBYTES]
+    // XBUF == 1: the input patch is single-buffered (its reload is exposed once per K chunk), which brings the
+    // stride-2 tiles from 90 KB to 53 KB of LDS: three blocks per CU instead of one hide each other's step latencies
+    unsigned char *Xs = smem;                          // [XBUF][XBYTES]
+    unsigned char *Ws = smem + XBUF * XBYTES;          // [2][WBYTES]
     float *SS = reinterpret_cast<float *>(Ws + 2 * WBYTES);   // scale[BN], shift[BN] of this channel tile
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -143,13 +145,13 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 
     int chunk = 0, tap = 0;
     for (int s = 0; s < NS; ++s) {
-        const int wb = s & 1, xb = chunk & 1;
+        const int wb = s & 1, xb = (XBUF == 2) ? (chunk & 1) : 0;
         int ntap = tap + 1, nchunk = chunk;
         if (ntap == T) { ntap = 0; ++nchunk; }
         const bool has_next = (s + 1 < NS);
         const bool new_chunk = has_next && (ntap == 0);
         if (has_next) { ISSUE_W(s + 1, wb ^ 1) }
-        if (new_chunk) { ISSUE_X(nchunk, xb ^ 1) }
+        if (XBUF == 2 && new_chunk) { ISSUE_X(nchunk, xb ^ 1) }
 
         const int ky = tap / KS, kx = tap - ky * KS;
         const unsigned char *xs = Xs + xb * XBYTES;
@@ -195,6 +197,10 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             __builtin_amdgcn_sched_group_barrier(0x008, CH_T * PX_T, 0);
         }
         __syncthreads();
+        if (XBUF == 1 && new_chunk) {
+            ISSUE_X(nchunk, 0)
+            __syncthreads();
+        }
         tap = ntap;
         chunk = nchunk;
     }
@@ -276,7 +282,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     }
 }
 
-template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0>
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2>
 static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                             const float *scale, const float *shift, int CoutP, int relu, const half_t *res,
                             void *out, int Ho, int Wo, const half_t *zero_page)
@@ -285,9 +291,9 @@ static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int 
     constexpr int PH = (THT - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
     constexpr int RPC = 1024 / (CC * 2);
     constexpr int XCH = (PH * PW + RPC - 1) / RPC;
-    constexpr size_t lds = (size_t)2 * XCH * 1024 + (size_t)2 * BN * CC * 2 + (size_t)2 * BN * sizeof(float);
+    constexpr size_t lds = (size_t)XBUF * XCH * 1024 + (size_t)2 * BN * CC * 2 + (size_t)2 * BN * sizeof(float);
     static bool attr_done = false;
-    auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES, NW, ROWS>;
+    auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES, NW, ROWS, XBUF>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
@@ -320,8 +326,17 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
 {
     if (stride == 2) {
         if (conv_igemm2_chunk(ks, 2, CoutP, Cin) != 32 || residual || out_f32) return false;
-        if (CoutP % 256 == 0) launch_igemm2_t<3, 2, 256, 32, false, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
-        else launch_igemm2_t<3, 2, 128, 32, false, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
+        // single-buffered input patch (XBUF = 1): 53 / 69 KB of LDS instead of 90 / 106 KB, so 3 / 2 blocks share a CU
+        // and hide each other's per-step latencies (steps are only 8-16 MFMAs long here).  Measured at 1600x1200:
+        // conv2b 98 -> 70 us, convPa.0 120 -> 82 us.  SFD2_CONV_S2_XBUF2 restores the double-buffered variant.
+        static const bool xb2 = getenv("SFD2_CONV_S2_XBUF2") != nullptr;
+        if (xb2) {
+            if (CoutP % 256 == 0) launch_igemm2_t<3, 2, 256, 32, false, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
+            else launch_igemm2_t<3, 2, 128, 32, false, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
+        } else {
+            if (CoutP % 256 == 0) launch_igemm2_t<3, 2, 256, 32, false, false, 8, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
+            else launch_igemm2_t<3, 2, 128, 32, false, false, 8, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
+        }
         return true;
     }
 #define SFD2_IG2B(KS_, BN_, CC_, F32_)                                                                                   \
