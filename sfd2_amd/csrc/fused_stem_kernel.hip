@@ -2,18 +2,29 @@
 // in one kernel (nets/extractor.py:104, nets/sfd2.py:268-270,314-316).  The 64-channel full-resolution
 // tensor between the two convolutions (245 MB at 1600x1200, written and re-read once) never leaves
 // the CU: each block computes the 9 x 65 conv1a pixels its 4 x 32 conv1b outputs need into LDS
-// (MFMA, K = 48), then runs conv1b from there (MFMA, K = 9 x 64), streaming the 9 filter taps
-// through a double-buffered direct-to-LDS copy.  HBM traffic: image in, H/2 x W/2 x 64 out.
+// (MFMA, K = 48), then runs conv1b from there (MFMA, K = 9 x 64).  HBM traffic: image in,
+// H/2 x W/2 x 64 out.
+//
+// Persistent blocks (one per CU, 156 KB of LDS): the nine conv1b filter taps (72 KB) are staged into
+// LDS once per block and stay there, so phase 2 has no barriers and no per-tile filter traffic; the
+// image patch of the block's NEXT tile is fetched into registers before phase 2 of the current one
+// and lands in LDS afterwards, so its latency hides behind the MFMAs.  Barriers are raw
+// s_barrier + lgkmcnt(0) (LDS visibility only): a __syncthreads() would also drain vmcnt, i.e. wait
+// for the prefetch and for the previous tile's output stores.
+// Measured at 1600x1200: streamed taps, one tile per block 128 us -> resident taps 113 us -> persistent
+// + prefetch (this file) see profiles/.
 #include "sfd2_internal.h"
+#include <stdlib.h>
 
 #define NT 512           // 8 waves: wave -> (output row = wave >> 1, 32-channel half = wave & 1)
-#define F_TH 4           // conv1b output rows per block
+#define F_TH 4           // conv1b output rows per tile
 #define F_TW 32
 #define F_RH 9           // conv1a rows needed: 2*4 + 1
 #define F_RW 65
 #define F_RP (F_RH * F_RW)        // 585 conv1a pixels
 #define F_IH 11          // image rows needed
 #define F_IW 68          // image cols needed (67) + 1 so the zero-weight kx = 3 slot reads valid bytes
+#define F_IPT ((F_IH * F_IW + NT - 1) / NT)   // image pixels per thread (2)
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -25,59 +36,35 @@ __device__ __forceinline__ h4_t f_cvt4(float a, float b, float c, float d)
     return r;
 }
 
+// LDS-only barrier: every wave's LDS writes are visible to the block afterwards; global loads / stores stay in flight
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 __global__ __launch_bounds__(NT)
 void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalise,
                        const half_t *__restrict__ w1 /*[2][3][64][8] conv1a A fragments*/,
                        const float *__restrict__ sc1, const float *__restrict__ sh1,
                        const half_t *__restrict__ w2 /*[9][64 oc][64 ic] conv1b*/,
                        const float *__restrict__ sc2, const float *__restrict__ sh2,
-                       half_t *__restrict__ out /*[H2][W2][64]*/, int H2, int W2, int tiles_x)
+                       half_t *__restrict__ out /*[H2][W2][64]*/, int H2, int W2, int tiles_x, int n_tiles)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *X1 = smem;                                         // [F_RP][128 B], 16-B slots swizzled with (rec >> 1) & 7
-    unsigned char *Wt = X1 + ((F_RP * 128 + 1023) & ~1023);           // [2][64][128 B], same swizzle
-    half_t *IM = reinterpret_cast<half_t *>(Wt + 2 * 8192);           // [F_IH][F_IW][4]
+    unsigned char *Wt = X1 + ((F_RP * 128 + 1023) & ~1023);           // [9][64][128 B], same swizzle
+    half_t *IM = reinterpret_cast<half_t *>(Wt + 9 * 8192);           // [F_IH][F_IW][4]
     float *SS = reinterpret_cast<float *>(IM + F_IH * F_IW * 4);      // sc1, sh1, sc2, sh2 (64 each)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lhi = lane >> 5;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int oy0 = ty * F_TH, ox0 = tx * F_TW;
-    const int ry0 = 2 * oy0 - 1, rx0 = 2 * ox0 - 1;                   // image coords of conv1a region pixel (0, 0)
     const size_t plane = (size_t)H * W;
 
-    // filter tap t of conv1b -> Wt[buf]: 8 one-KB chunks (8 rows each), 1 per wave
-#define ISSUE_W2(tap_, buf_)                                                                              \
-    {                                                                                                     \
-        const int r = wave * 8 + (lane >> 3);                                                             \
-        const int slot = (lane & 7) ^ ((r >> 1) & 7);                                                     \
-        __builtin_amdgcn_global_load_lds((gbl_void_t *)(w2 + ((size_t)(tap_)*64 + r) * 64 + slot * 8),    \
-                                         (lds_void_t *)(Wt + (buf_)*8192 + wave * 1024), 16, 0, 0);       \
-    }
-    ISSUE_W2(0, 0)
-
-    // ---- image patch (normalised, fp16, 4 halves per pixel) and the four scale/shift vectors
-    for (int p = tid; p < F_IH * F_IW; p += NT) {
-        const int py = p / F_IW, px = p - py * F_IW;
-        const int iy = ry0 - 1 + py, ix = rx0 - 1 + px;
-        float r = 0.0f, g = 0.0f, b = 0.0f;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-            const size_t o = (size_t)iy * W + ix;
-            if (normalise & 2) {  // uint8 HWC ingest: x.astype(float32) / 255. (extract_localization.py:168,186)
-                const unsigned char *u = reinterpret_cast<const unsigned char *>(img) + o * 3;
-                const int sw = (normalise & 4) ? 2 : 0;  // BGR -> RGB (:165)
-                r = __fdiv_rn((float)u[sw], 255.0f); g = __fdiv_rn((float)u[1], 255.0f); b = __fdiv_rn((float)u[2 - sw], 255.0f);
-            } else {
-                r = img[o]; g = img[plane + o]; b = img[2 * plane + o];
-            }
-            if (normalise & 1) {
-                r = __fdiv_rn(__fsub_rn(r, 0.485f), 0.229f);
-                g = __fdiv_rn(__fsub_rn(g, 0.456f), 0.224f);
-                b = __fdiv_rn(__fsub_rn(b, 0.406f), 0.225f);
-            }
-        }
-        *reinterpret_cast<h4_t *>(IM + p * 4) = f_cvt4(r, g, b, 0.0f);
+    // all nine conv1b filter taps -> Wt, once per block: tap t = 8 one-KB chunks (8 rows each), 1 per wave
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int r = wave * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)(w2 + ((size_t)t * 64 + r) * 64 + slot * 8),
+                                         (lds_void_t *)(Wt + t * 8192 + wave * 1024), 16, 0, 0);
     }
     if (tid < 64) { SS[tid] = sc1[tid]; SS[64 + tid] = sh1[tid]; SS[128 + tid] = sc2[tid]; SS[192 + tid] = sh2[tid]; }
     h8_t a1[2][3];
@@ -86,112 +73,178 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
             a1[ct][ky] = *reinterpret_cast<const h8_t *>(w1 + ((size_t)(ct * 3 + ky) * 64 + lane) * 8);
-    __syncthreads();
 
-    // ---- phase 1: conv1a on the 585 region pixels, 32 per MFMA column block
-    for (int t = wave; t < (F_RP + 31) / 32; t += NT / 64) {
-        const int p = t * 32 + lrow;
-        const int pc = p < F_RP ? p : F_RP - 1;
-        const int ry = pc / F_RW, rx = pc - ry * F_RW;
-        f32x16_t acc[2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int q = (ry + ky) * F_IW + rx + 2 * lhi;
-            const h4_t lo = *reinterpret_cast<const h4_t *>(IM + q * 4);
-            const h4_t hi = *reinterpret_cast<const h4_t *>(IM + (q + 1) * 4);
-            h8_t b;
-            b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3];
-            b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
+    // raw image values of this thread's F_IPT patch pixels (fp32 planes or uint8 HWC), fetched one tile ahead
+    float pr[F_IPT][3];
+    unsigned pr_inside = 0;   // bit k: patch pixel k of this thread lies inside the image
+#define FETCH_IMG(tile_)                                                                                   \
+    {                                                                                                      \
+        const int ftx = (tile_) % tiles_x, fty = (tile_) / tiles_x;                                        \
+        const int fy0 = 2 * (fty * F_TH) - 2, fx0 = 2 * (ftx * F_TW) - 2;                                  \
+        pr_inside = 0;                                                                                     \
+        _Pragma("unroll") for (int k = 0; k < F_IPT; ++k) {                                                \
+            const int p = tid + k * NT;                                                                    \
+            const int py = p / F_IW, px = p - py * F_IW;                                                   \
+            const int iy = fy0 + py, ix = fx0 + px;                                                        \
+            float r = 0.0f, g = 0.0f, b = 0.0f;                                                            \
+            if (p < F_IH * F_IW && iy >= 0 && iy < H && ix >= 0 && ix < W) {                               \
+                const size_t o = (size_t)iy * W + ix;                                                      \
+                pr_inside |= 1u << k;                                                                      \
+                if (normalise & 2) { /* uint8 HWC ingest (extract_localization.py:165-186) */              \
+                    const unsigned char *u = reinterpret_cast<const unsigned char *>(img) + o * 3;         \
+                    const int sw = (normalise & 4) ? 2 : 0; /* BGR -> RGB (:165) */                        \
+                    r = (float)u[sw]; g = (float)u[1]; b = (float)u[2 - sw];                               \
+                } else {                                                                                   \
+                    r = img[o]; g = img[plane + o]; b = img[2 * plane + o];                                \
+                }                                                                                          \
+            }                                                                                              \
+            pr[k][0] = r; pr[k][1] = g; pr[k][2] = b;                                                      \
+        }                                                                                                  \
+    }
+    // normalise (astype(float32) / 255. for uint8, then norm_RGB: one IEEE sub + one IEEE div) and store as fp16
+#define STORE_IMG()                                                                                        \
+    _Pragma("unroll") for (int k = 0; k < F_IPT; ++k) {                                                    \
+        const int p = tid + k * NT;                                                                        \
+        float r = pr[k][0], g = pr[k][1], b = pr[k][2];                                                    \
+        if (pr_inside & (1u << k)) {   /* zero padding stays exactly zero */                               \
+            if (normalise & 2) { r = __fdiv_rn(r, 255.0f); g = __fdiv_rn(g, 255.0f); b = __fdiv_rn(b, 255.0f); } \
+            if (normalise & 1) {                                                                           \
+                r = __fdiv_rn(__fsub_rn(r, 0.485f), 0.229f);                                               \
+                g = __fdiv_rn(__fsub_rn(g, 0.456f), 0.224f);                                               \
+                b = __fdiv_rn(__fsub_rn(b, 0.406f), 0.225f);                                               \
+            }                                                                                              \
+        }                                                                                                  \
+        if (p < F_IH * F_IW) *reinterpret_cast<h4_t *>(IM + p * 4) = f_cvt4(r, g, b, 0.0f);                \
+    }
+
+    int tile = blockIdx.x;
+    FETCH_IMG(tile)
+    STORE_IMG()
+    __syncthreads();   // full barrier once: the filter copies (vmcnt) and IM / SS (LDS) are complete
+
+    for (;;) {
+        const int tx = tile % tiles_x, ty = tile / tiles_x;
+        const int oy0 = ty * F_TH, ox0 = tx * F_TW;
+        const int ry0 = 2 * oy0 - 1, rx0 = 2 * ox0 - 1;               // image coords of conv1a region pixel (0, 0)
+
+        // ---- phase 1: conv1a on the 585 region pixels, 32 per MFMA column block
+        for (int t = wave; t < (F_RP + 31) / 32; t += NT / 64) {
+            const int p = t * 32 + lrow;
+            const int pc = p < F_RP ? p : F_RP - 1;
+            const int ry = pc / F_RW, rx = pc - ry * F_RW;
+            f32x16_t acc[2];
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ct][ky], b, acc[ct], 0, 0, 0);
-        }
-        // conv1b zero-pads conv1a's OUTPUT: region pixels outside the image are zeros, not conv1a(0)
-        const int gy = ry0 + ry, gx = rx0 + rx;
-        const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        if (p < F_RP) {
-            const int sw = (p >> 1) & 7;
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+                for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c0 = ct * 32 + 8 * q + 4 * lhi;
-                    const float4 s = *reinterpret_cast<const float4 *>(SS + c0);
-                    const float4 h = *reinterpret_cast<const float4 *>(SS + 64 + c0);
-                    h4_t v = f_cvt4(0.f, 0.f, 0.f, 0.f);
-                    if (inside)
-                        v = f_cvt4(fmaxf(acc[ct][4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc[ct][4 * q + 1] * s.y + h.y, 0.0f),
-                                   fmaxf(acc[ct][4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc[ct][4 * q + 3] * s.w + h.w, 0.0f));
-                    *reinterpret_cast<h4_t *>(X1 + p * 128 + (((c0 >> 3) ^ sw) << 4) + (c0 & 4) * 2) = v;
-                }
+            for (int ky = 0; ky < 3; ++ky) {
+                const int q = (ry + ky) * F_IW + rx + 2 * lhi;
+                const h4_t lo = *reinterpret_cast<const h4_t *>(IM + q * 4);
+                const h4_t hi = *reinterpret_cast<const h4_t *>(IM + (q + 1) * 4);
+                h8_t b;
+                b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3];
+                b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ct][ky], b, acc[ct], 0, 0, 0);
+            }
+            // conv1b zero-pads conv1a's OUTPUT: region pixels outside the image are zeros, not conv1a(0)
+            const int gy = ry0 + ry, gx = rx0 + rx;
+            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            if (p < F_RP) {
+                const int sw = (p >> 1) & 7;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c0 = ct * 32 + 8 * q + 4 * lhi;
+                        const float4 s = *reinterpret_cast<const float4 *>(SS + c0);
+                        const float4 h = *reinterpret_cast<const float4 *>(SS + 64 + c0);
+                        h4_t v = f_cvt4(0.f, 0.f, 0.f, 0.f);
+                        if (inside)
+                            v = f_cvt4(fmaxf(acc[ct][4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc[ct][4 * q + 1] * s.y + h.y, 0.0f),
+                                       fmaxf(acc[ct][4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc[ct][4 * q + 3] * s.w + h.w, 0.0f));
+                        *reinterpret_cast<h4_t *>(X1 + p * 128 + (((c0 >> 3) ^ sw) << 4) + (c0 & 4) * 2) = v;
+                    }
+            }
         }
-    }
-    __syncthreads();   // X1 complete; also drains the tap-0 filter copy
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < n_tiles;
+        if (has_next) FETCH_IMG(next)      // global loads only; consumed after phase 2
+        LDS_BARRIER();                     // X1 complete; IM is free from here on
 
-    // ---- phase 2: conv1b (stride 2): wave -> (output row, 32-channel half)
-    const int orow = wave >> 1, cth = wave & 1;
-    f32x16_t acc2;
+        // ---- phase 2: conv1b (stride 2) from X1 and the resident taps: wave -> (output row, 32-channel half)
+        const int orow = wave >> 1, cth = wave & 1;
+        f32x16_t acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[r] = 0.0f;
-    const int ar = cth * 32 + lrow;
-    const int a_off = ar * 128, a_sw = (ar >> 1) & 7;
-    for (int tap = 0; tap < 9; ++tap) {
-        const int buf = tap & 1;
-        if (tap + 1 < 9) { ISSUE_W2(tap + 1, buf ^ 1) }
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int q = (2 * orow + ky) * F_RW + 2 * lrow + kx;
-        const unsigned char *xq = X1 + q * 128;
-        const int bsw = (q >> 1) & 7;
-        const unsigned char *wt = Wt + buf * 8192;
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.0f;
+        const int ar = cth * 32 + lrow;
+        const int a_off = ar * 128, a_sw = (ar >> 1) & 7;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int slot = kk * 2 + lhi;
-            const h8_t b = *reinterpret_cast<const h8_t *>(xq + ((slot ^ bsw) << 4));
-            const h8_t a = *reinterpret_cast<const h8_t *>(wt + a_off + ((slot ^ a_sw) << 4));
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2, 0, 0, 0);
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int q = (2 * orow + ky) * F_RW + 2 * lrow + kx;
+            const unsigned char *xq = X1 + q * 128;
+            const int bsw = (q >> 1) & 7;
+            const unsigned char *wt = Wt + tap * 8192;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int slot = kk * 2 + lhi;
+                const h8_t b = *reinterpret_cast<const h8_t *>(xq + ((slot ^ bsw) << 4));
+                const h8_t a = *reinterpret_cast<const h8_t *>(wt + a_off + ((slot ^ a_sw) << 4));
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2, 0, 0, 0);
+            }
         }
-        __syncthreads();
-    }
-#undef ISSUE_W2
 
-    const int oy = oy0 + orow, ox = ox0 + lrow;
-    const bool inb = oy < H2 && ox < W2;
-    half_t *o = out + ((size_t)(inb ? oy : 0) * W2 + (inb ? ox : 0)) * 64;
-    // lanes l and l+32 hold the two 8-byte halves of a 16-byte channel run: regroup two quads with
-    // v_permlane32_swap so every lane issues one 16-byte store per quad pair (as conv_igemm2)
+        const int oy = oy0 + orow, ox = ox0 + lrow;
+        const bool inb = oy < H2 && ox < W2;
+        half_t *o = out + ((size_t)(inb ? oy : 0) * W2 + (inb ? ox : 0)) * 64;
+        // lanes l and l+32 hold the two 8-byte halves of a 16-byte channel run: regroup two quads with
+        // v_permlane32_swap so every lane issues one 16-byte store per quad pair (as conv_igemm2)
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        uint2 pk[2];
+        for (int m = 0; m < 2; ++m) {
+            uint2 pk[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = 2 * m + j;
-            const int c0 = cth * 32 + 8 * q + 4 * lhi;
-            const float4 s = *reinterpret_cast<const float4 *>(SS + 128 + c0);
-            const float4 h = *reinterpret_cast<const float4 *>(SS + 192 + c0);
-            const h4_t hv = f_cvt4(fmaxf(acc2[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc2[4 * q + 1] * s.y + h.y, 0.0f),
-                                   fmaxf(acc2[4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc2[4 * q + 3] * s.w + h.w, 0.0f));
-            __builtin_memcpy(&pk[j], &hv, 8);
+            for (int j = 0; j < 2; ++j) {
+                const int q = 2 * m + j;
+                const int c0 = cth * 32 + 8 * q + 4 * lhi;
+                const float4 s = *reinterpret_cast<const float4 *>(SS + 128 + c0);
+                const float4 h = *reinterpret_cast<const float4 *>(SS + 192 + c0);
+                const h4_t hv = f_cvt4(fmaxf(acc2[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc2[4 * q + 1] * s.y + h.y, 0.0f),
+                                       fmaxf(acc2[4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc2[4 * q + 3] * s.w + h.w, 0.0f));
+                __builtin_memcpy(&pk[j], &hv, 8);
+            }
+            const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+            const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+            if (inb) *reinterpret_cast<uint4 *>(o + cth * 32 + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
         }
-        const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
-        const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
-        if (inb) *reinterpret_cast<uint4 *>(o + cth * 32 + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+        if (!has_next) break;
+        STORE_IMG()                        // the prefetched patch of the next tile -> IM
+        LDS_BARRIER();                     // IM complete, and every wave is done reading X1
+        tile = next;
     }
+#undef FETCH_IMG
+#undef STORE_IMG
 }
 
 void launch_fused_stem(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *w1, const float *sc1,
                        const float *sh1, const half_t *w2, const float *sc2, const float *sh2, half_t *out, int H2, int W2)
 {
     static bool attr_done = false;
-    const size_t lds = (size_t)((F_RP * 128 + 1023) & ~1023) + 2 * 8192 + (size_t)F_IH * F_IW * 4 * sizeof(half_t) + 256 * sizeof(float);
+    static int slots = 256;
+    const size_t lds = (size_t)((F_RP * 128 + 1023) & ~1023) + 9 * 8192 + (size_t)F_IH * F_IW * 4 * sizeof(half_t) + 256 * sizeof(float);
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            slots = cus;   // 156 KB of LDS: one resident block per CU
         attr_done = true;
     }
     const int tiles_x = (W2 + F_TW - 1) / F_TW, tiles_y = (H2 + F_TH - 1) / F_TH;
-    hipLaunchKernelGGL(fused_stem_kernel, dim3(tiles_x * tiles_y), dim3(NT), lds, st, img, H, W, normalise, w1, sc1, sh1, w2,
-                       sc2, sh2, out, H2, W2, tiles_x);
+    const int n_tiles = tiles_x * tiles_y;
+    const int grid = n_tiles < slots ? n_tiles : slots;
+    hipLaunchKernelGGL(fused_stem_kernel, dim3(grid), dim3(NT), lds, st, img, H, W, normalise, w1, sc1, sh1, w2, sc2, sh2, out,
+                       H2, W2, tiles_x, n_tiles);
 }
