@@ -416,23 +416,36 @@ void gconv3x3_g8_kernel(const half_t *__restrict__ in, int H, int W, const half_
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int g = lane >> 4, lcol = lane & 15;
 
+    // The 64-channel patch of chunk c + 1 is fetched into registers while chunk c computes and stores; barriers are
+    // LDS-only (s_barrier + lgkmcnt(0)) so neither that prefetch nor the output stores are drained at a barrier.
+    constexpr int NLD = (NPIX * 8 + NT - 1) / NT;   // 16-byte pieces per thread (7)
+    uint4 pre[NLD];
+#define G_FETCH(chunk_)                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < NLD; ++k) {                                                     \
+        const int p = tid + k * NT;                                                                       \
+        const int q = p >> 3, part = p & 7;                                                               \
+        const int py = q / G_PW, px = q - py * G_PW;                                                      \
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;                                                   \
+        uint4 v = make_uint4(0, 0, 0, 0);                                                                 \
+        if (p < NPIX * 8 && iy >= 0 && iy < H && ix >= 0 && ix < W)                                       \
+            v = *reinterpret_cast<const uint4 *>(in + ((size_t)(iy * W + ix) * 256 + (chunk_)*64 + part * 8)); \
+        pre[k] = v;                                                                                       \
+    }
+    G_FETCH(0)
     for (int chunk = 0; chunk < 4; ++chunk) {
-        if (chunk) __syncthreads();
-        for (int p = tid; p < NPIX * 8; p += NT) {
-            const int q = p >> 3, part = p & 7;
-            const int py = q / G_PW, px = q - py * G_PW;
-            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-                v = *reinterpret_cast<const uint4 *>(in + ((size_t)(iy * W + ix) * 256 + chunk * 64 + part * 8));
-            *reinterpret_cast<uint4 *>(Xs + q * GP + part * 8) = v;
+        if (chunk) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done reading Xs
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int p = tid + k * NT;
+            if (p < NPIX * 8) *reinterpret_cast<uint4 *>(Xs + (p >> 3) * GP + (p & 7) * 8) = pre[k];
         }
         const int pair = chunk * 4 + wave;
         h8_t wf[5];
 #pragma unroll
         for (int s = 0; s < 5; ++s)
             wf[s] = *reinterpret_cast<const h8_t *>(wpk + ((size_t)(pair * 5 + s) * 64 + lane) * 8);
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");               // Xs of this chunk complete
+        if (chunk + 1 < 4) { G_FETCH(chunk + 1) }
 
         f32x4_t acc[8];
 #pragma unroll
@@ -475,6 +488,7 @@ void gconv3x3_g8_kernel(const half_t *__restrict__ in, int H, int W, const half_
                 *reinterpret_cast<uint4 *>(out + ((size_t)oy * W + ox) * 256 + pair * 16 + (g & ~1) * 4) = v;
         }
     }
+#undef G_FETCH
 }
 
 void launch_gconv3x3_g8(hipStream_t st, const half_t *in, int H, int W, const half_t *wpk, const float *scale,
