@@ -186,7 +186,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 #define TA2 64        // candidate rows per LDS stage in the v2 kernel (16 KB; 128 measured slower: fewer blocks per CU)
-template <bool NEED2>
+template <bool NEED2, int ABL = 0>   // ABL: timing ablations only (wrong results): 1 = no arg-max epilogue
 __global__ __launch_bounds__(NT, 2)   // 140 VGPRs -> 3 blocks per CU; forcing 4 (128 VGPRs) spills and measured slower
 void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const half_t *__restrict__ zero_page)
 {
@@ -260,7 +260,10 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
                 }
                 const int jbase = ja0 + s * TA2 + sub * 32 + 4 * lhi;
                 const bool full = ja0 + s * TA2 + sub * 32 + 32 <= ja1;   // wave-uniform: no row of this sub-tile is padding
-                if (!NEED2 && full) {
+                if (ABL == 1) {
+                    bp[0] = fmaxf(bp[0], acc0[0] + acc0[5] + acc0[10] + acc0[15]);
+                    bp[1] = fmaxf(bp[1], acc1[0] + acc1[5] + acc1[10] + acc1[15]);
+                } else if (!NEED2 && full) {
                     // one v_and_or per element packs (15 - r) under the value, a max tree then yields the
                     // maximum AND its register; per-element index scans would make this kernel VALU-bound
                     // (measured 11.8 VALU instructions per MFMA with them)
@@ -601,9 +604,11 @@ void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int 
         if (!attr2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_v2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_v2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_v2_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr2 = true;
         }
         if (need_top2) hipLaunchKernelGGL(match_top2_v2_kernel<true>, grid, dim3(NT), lds, st, jobs_dev, splits, zero_page);
+        else if (getenv("SFD2_MATCH_ABLATE")) hipLaunchKernelGGL((match_top2_v2_kernel<false, 1>), grid, dim3(NT), lds, st, jobs_dev, splits, zero_page);
         else hipLaunchKernelGGL(match_top2_v2_kernel<false>, grid, dim3(NT), lds, st, jobs_dev, splits, zero_page);
         return;
     }
