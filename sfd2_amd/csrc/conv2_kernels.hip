@@ -66,7 +66,12 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     // stride-2 tiles from 90 KB to 53 KB of LDS: three blocks per CU instead of one hide each other's step latencies
     unsigned char *Xs = smem;                          // [XBUF][XBYTES]
     unsigned char *Ws = smem + XBUF * XBYTES;          // [2][WBYTES]
-    float *SS = reinterpret_cast<float *>(Ws + 2 * WBYTES);   // scale[BN], shift[BN] of this channel tile
+    // XBUF == 3 (1x1 layers only): three input buffers, the chunk two steps ahead is already in flight, barriers wait
+    // with a counted vmcnt.  With 256-channel tiles and 64-wide chunks that is exactly 160 KB, so scale/shift then
+    // come from global memory in the epilogue instead of LDS.
+    constexpr bool SS_LDS = !(XBUF == 3 && BN == 256 && CC == 64);
+    float *SS = reinterpret_cast<float *>(Ws + 2 * WBYTES);   // scale[BN], shift[BN] of this channel tile (SS_LDS)
+    static_assert(XBUF != 3 || (KS == 1 && STRIDE == 1), "XBUF = 3 is the 1x1 pipeline");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,10 +132,18 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     const int NS = (Cin / CC) * T;
+    // barrier that lets the XPW most recently issued copies (the chunk two steps ahead) stay in flight
+#define BARRIER_KEEP_X() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XPW) : "memory")
+#define BARRIER_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
     ISSUE_X(0, 0)
     ISSUE_W(0, 0)
-    for (int t = tid; t < BN; t += NW * 64) { SS[t] = scale[n0 + t]; SS[BN + t] = shift[n0 + t]; }
-    __syncthreads();   // hipcc drains vmcnt(0) before the barrier while LDS-DMA is in flight
+    if (SS_LDS)
+        for (int t = tid; t < BN; t += NW * 64) { SS[t] = scale[n0 + t]; SS[BN + t] = shift[n0 + t]; }
+    if (XBUF == 3) {
+        if (NS > 1) { ISSUE_X(1, 1) BARRIER_KEEP_X(); } else { BARRIER_DRAIN(); }
+    } else {
+        __syncthreads();   // hipcc drains vmcnt(0) before the barrier while LDS-DMA is in flight
+    }
 
     const int lrow = lane & 31, lhi = lane >> 5;
     // fragment read offsets that do not depend on the step
@@ -145,13 +158,14 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 
     int chunk = 0, tap = 0;
     for (int s = 0; s < NS; ++s) {
-        const int wb = s & 1, xb = (XBUF == 2) ? (chunk & 1) : 0;
+        const int wb = s & 1, xb = (XBUF == 3) ? (chunk % 3) : ((XBUF == 2) ? (chunk & 1) : 0);
         int ntap = tap + 1, nchunk = chunk;
         if (ntap == T) { ntap = 0; ++nchunk; }
         const bool has_next = (s + 1 < NS);
         const bool new_chunk = has_next && (ntap == 0);
         if (has_next) { ISSUE_W(s + 1, wb ^ 1) }
         if (XBUF == 2 && new_chunk) { ISSUE_X(nchunk, xb ^ 1) }
+        if (XBUF == 3 && s + 2 < NS) { ISSUE_X(s + 2, (s + 2) % 3) }   // after W(s + 1): the counted wait keeps exactly these
 
         const int ky = tap / KS, kx = tap - ky * KS;
         const unsigned char *xs = Xs + xb * XBYTES;
@@ -196,7 +210,11 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             if (kk + 1 < NK) __builtin_amdgcn_sched_group_barrier(0x100, CH_T + PX_T, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, CH_T * PX_T, 0);
         }
-        __syncthreads();
+        if (XBUF == 3) {
+            if (s + 2 < NS) BARRIER_KEEP_X(); else BARRIER_DRAIN();
+        } else {
+            __syncthreads();
+        }
         if (XBUF == 1 && new_chunk) {
             ISSUE_X(nchunk, 0)
             __syncthreads();
@@ -206,6 +224,8 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     }
 #undef ISSUE_X
 #undef ISSUE_W
+#undef BARRIER_KEEP_X
+#undef BARRIER_DRAIN
 
     // epilogue: y = acc * scale + shift (+ residual) (ReLU).  A lane owns, per register quad q, channels
     // 8q + 4*lhi .. +3 of one pixel, i.e. lanes l and l+32 hold the two 8-byte halves of one 16-byte
@@ -223,8 +243,8 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             if (OUT_F32) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 sc = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
-                    const float4 sh = *reinterpret_cast<const float4 *>(SS + BN + cl + 8 * q);
+                    const float4 sc = SS_LDS ? *reinterpret_cast<const float4 *>(SS + cl + 8 * q) : *reinterpret_cast<const float4 *>(scale + n0 + cl + 8 * q);
+                    const float4 sh = SS_LDS ? *reinterpret_cast<const float4 *>(SS + BN + cl + 8 * q) : *reinterpret_cast<const float4 *>(shift + n0 + cl + 8 * q);
                     float v0 = acc[ct][pr][4 * q + 0] * sc.x + sh.x;
                     float v1 = acc[ct][pr][4 * q + 1] * sc.y + sh.y;
                     float v2 = acc[ct][pr][4 * q + 2] * sc.z + sh.z;
@@ -255,8 +275,8 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int q = 2 * m + j;
-                        const float4 sc = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
-                        const float4 sh = *reinterpret_cast<const float4 *>(SS + BN + cl + 8 * q);
+                        const float4 sc = SS_LDS ? *reinterpret_cast<const float4 *>(SS + cl + 8 * q) : *reinterpret_cast<const float4 *>(scale + n0 + cl + 8 * q);
+                        const float4 sh = SS_LDS ? *reinterpret_cast<const float4 *>(SS + BN + cl + 8 * q) : *reinterpret_cast<const float4 *>(shift + n0 + cl + 8 * q);
                         float v0 = acc[ct][pr][4 * q + 0] * sc.x + sh.x;
                         float v1 = acc[ct][pr][4 * q + 1] * sc.y + sh.y;
                         float v2 = acc[ct][pr][4 * q + 2] * sc.z + sh.z;
@@ -291,7 +311,8 @@ static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int 
     constexpr int PH = (THT - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
     constexpr int RPC = 1024 / (CC * 2);
     constexpr int XCH = (PH * PW + RPC - 1) / RPC;
-    constexpr size_t lds = (size_t)XBUF * XCH * 1024 + (size_t)2 * BN * CC * 2 + (size_t)2 * BN * sizeof(float);
+    constexpr bool SS_LDS = !(XBUF == 3 && BN == 256 && CC == 64);
+    constexpr size_t lds = (size_t)XBUF * XCH * 1024 + (size_t)2 * BN * CC * 2 + (SS_LDS ? (size_t)2 * BN * sizeof(float) : 0);
     static bool attr_done = false;
     auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES, NW, ROWS, XBUF>;
     if (!attr_done) {
@@ -365,6 +386,18 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
         return true;
     }
     if (ks == 3 && !out_f32) { if (bn == 256) SFD2_IG2(3, 256, false); else SFD2_IG2(3, 128, false); return true; }
+    // Experiment (SFD2_CONV_1X1_XBUF3): three input buffers with the chunk two steps ahead in flight and counted-vmcnt
+    // barriers for the 1x1 layers.  Correct, but measured SLOWER than the two-buffer pipeline (conv1 34 -> 39 us,
+    // conv3 44.5 -> 49 us at 1600x1200): doubling the input bytes in flight is not what these layers lack.
+    static const bool x3 = getenv("SFD2_CONV_1X1_XBUF3") != nullptr;
+#define SFD2_IG1(BN_, CC_, F32_)                                                                                         \
+    do {                                                                                                                \
+        if (residual) launch_igemm2_t<1, 1, BN_, CC_, F32_, true, 8, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); \
+        else launch_igemm2_t<1, 1, BN_, CC_, F32_, false, 8, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);         \
+    } while (0)
+    if (ks == 1 && x3 && !out_f32 && bn == 256 && cc == 64) { SFD2_IG1(256, 64, false); return true; }
+    if (ks == 1 && x3 && out_f32 && bn == 128 && cc == 32) { SFD2_IG1(128, 32, true); return true; }
+#undef SFD2_IG1
     if (ks == 1 && !out_f32) { if (bn == 256) SFD2_IG2(1, 256, false); else SFD2_IG2(1, 128, false); return true; }
     if (ks == 1 && out_f32) { if (bn == 256) SFD2_IG2(1, 256, true); else SFD2_IG2(1, 128, true); return true; }
 #undef SFD2_IG2
