@@ -1,0 +1,191 @@
+// conv1x1_c256: the ResBlock 1x1 convolutions (256 -> 256, nets/sfd2.py:30-35,41-53: conv1 + bn1 + ReLU and
+// conv3 + bn3 + residual + ReLU) as a persistent streaming GEMM.
+//
+// These layers move 123-184 MB for 15.7 GFLOP: they are bound by how the bytes are moved, not by the MFMAs.  The
+// generic implicit-GEMM kernel re-stages the 128 KB filter matrix for every 256-pixel tile, visits every pixel
+// record four times (128 of its 512 bytes per K step) and pays a prologue / epilogue per tile (ablations: with
+// the input loads, the output stores or the MFMAs removed it still takes 27-30 of its 34 us).  Here instead:
+//   * the FILTERS LIVE IN REGISTERS for the whole kernel: wave w owns 64 output channels of one 32-pixel half,
+//     its 64 x 256 A fragments are 128 VGPRs loaded once;
+//   * pixels stream through a 4-stage LDS ring of 64-pixel groups (32 KB each, one contiguous piece of the NHWC
+//     tensor) filled by direct-to-LDS copies three groups ahead -- 96 KB per CU in flight, no filter traffic;
+//   * barriers wait with a counted vmcnt, so neither the prefetches nor the output stores are drained;
+//   * every B fragment read (ds_read_b128) feeds two MFMAs; records are 512 B, 16-byte slots XOR-swizzled with
+//     (pixel & 31) on the copy's source address and on the read.
+#include "sfd2_internal.h"
+#include <stdlib.h>
+
+#define NT1 512
+#define GPX 64                      // pixels per group (stage)
+#define NST 4                       // stages in the ring
+#define STAGE_BYTES (GPX * 512)
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __forceinline__ h4_t c1_cvt4(float a, float b, float c, float d)
+{
+    h4_t r;
+    r[0] = (half_t)a; r[1] = (half_t)b; r[2] = (half_t)c; r[3] = (half_t)d;
+    return r;
+}
+
+template <bool HAS_RES>
+__global__ __launch_bounds__(NT1, 2)
+void conv1x1_c256_kernel(const half_t *__restrict__ in, int npix, const half_t *__restrict__ w /*[256 out][256 in]*/,
+                         const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                         const half_t *__restrict__ res, half_t *__restrict__ out, int groups_per_block,
+                         const half_t *__restrict__ zero_page /* >= 512 B of zeros */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Xs = smem;                                              // [NST][GPX][512 B]
+    float *SS = reinterpret_cast<float *>(smem + NST * STAGE_BYTES);       // scale[256], shift[256]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhi = lane >> 5;
+    const int cg = wave & 3, ph = wave >> 2;       // 64-channel group, 32-pixel half of the stage
+    const int ngroups = (npix + GPX - 1) / GPX;
+    const int g0 = blockIdx.x * groups_per_block;
+    int g1 = g0 + groups_per_block;
+    if (g1 > ngroups) g1 = ngroups;
+    if (g0 >= g1) return;
+
+    // filters of this wave: A fragments of mfma_32x32x16 (row = channel, 8 consecutive k per lane)
+    h8_t a[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            a[t][kk] = *reinterpret_cast<const h8_t *>(w + (size_t)(cg * 64 + t * 32 + lrow) * 256 + kk * 16 + lhi * 8);
+    for (int t = tid; t < 256; t += NT1) { SS[t] = scale[t]; SS[256 + t] = shift[t]; }
+
+    // group g -> ring stage: 32 one-KB chunks (2 pixel records each), 4 per wave
+#define ISSUE_G(g_)                                                                                        \
+    {                                                                                                      \
+        unsigned char *st = Xs + ((g_) & (NST - 1)) * STAGE_BYTES;                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+            const int ch = wave * 4 + i;                                                                   \
+            const int p = ch * 2 + lhi;                            /* pixel within the stage */            \
+            const long long gp = (long long)(g_)*GPX + p;                                                  \
+            const half_t *src = gp < npix ? in + gp * 256 + ((lrow ^ (p & 31)) << 3) : zero_page + (lrow << 3); \
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)(st + ch * 1024), 16, 0, 0); \
+        }                                                                                                  \
+    }
+    // Counted wait: loads retire in order, so group g's copies have landed once no more than N vector-memory
+    // operations are outstanding, N = the fewest loads that can have been issued after them when iteration g
+    // starts: the copies of g+1 and g+2 (8), plus -- with a residual, whose loads are issued BEFORE the iteration's
+    // copies so that waiting for them never drains a prefetch -- one iteration's residual loads (4).  Stores are
+    // not relied upon (they may retire early); a smaller N only waits longer.
+#define WAIT_GROUP()                                                                                       \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(HAS_RES ? 12 : 8) : "memory")
+
+    ISSUE_G(g0)
+    if (g0 + 1 < g1) { ISSUE_G(g0 + 1) }
+    if (g0 + 2 < g1) { ISSUE_G(g0 + 2) }
+    __syncthreads();   // first group, SS (and everything else) complete
+
+    for (int g = g0; g < g1; ++g) {
+        if (g != g0) {
+            // tail: fewer copies are in flight than the constant assumes -> drain (at most twice per block)
+            if (g + 2 < g1) WAIT_GROUP(); else __syncthreads();
+        }
+        const unsigned char *st = Xs + (g & (NST - 1)) * STAGE_BYTES;
+        const int p = ph * 32 + lrow;            // this lane's pixel within the stage
+        const long long gp = (long long)g * GPX + p;
+        const bool inb = gp < npix;
+        const size_t obase = (size_t)(inb ? gp : 0) * 256 + cg * 64;
+
+        uint4 rq[2][2];
+        if (HAS_RES) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    rq[t][m] = make_uint4(0, 0, 0, 0);
+                    if (inb) rq[t][m] = *reinterpret_cast<const uint4 *>(res + obase + t * 32 + 8 * (2 * m + lhi));
+                }
+            asm volatile("" ::: "memory");       // keep the residual loads ahead of the copies below in program order
+        }
+        if (g + 3 < g1) { ISSUE_G(g + 3) }      // into the stage group g - 1 used: every wave is past it (barrier above)
+
+        f32x16_t acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        const unsigned char *xp = st + p * 512;
+        const int sw = p & 31;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const h8_t b = *reinterpret_cast<const h8_t *>(xp + (((kk * 2 + lhi) ^ sw) << 4));
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][kk], b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][kk], b, acc[1], 0, 0, 0);
+        }
+
+        // epilogue: y = acc * scale + shift (+ residual) (ReLU); v_permlane32_swap regroups two channel quads so each
+        // lane stores (and loaded its residual as) 16-byte runs -- same scheme as conv_igemm2
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int cl = cg * 64 + t * 32 + 4 * lhi;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                uint2 rp[2] = {make_uint2(0, 0), make_uint2(0, 0)};
+                if (HAS_RES) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(rq[t][m].x, rq[t][m].z, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(rq[t][m].y, rq[t][m].w, false, false);
+                    rp[0] = make_uint2(s0[0], s1[0]);
+                    rp[1] = make_uint2(s0[1], s1[1]);
+                }
+                uint2 pk[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int q = 2 * m + j;
+                    const float4 sc = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
+                    const float4 sh = *reinterpret_cast<const float4 *>(SS + 256 + cl + 8 * q);
+                    float v0 = acc[t][4 * q + 0] * sc.x + sh.x;
+                    float v1 = acc[t][4 * q + 1] * sc.y + sh.y;
+                    float v2 = acc[t][4 * q + 2] * sc.z + sh.z;
+                    float v3 = acc[t][4 * q + 3] * sc.w + sh.w;
+                    if (HAS_RES) {
+                        h4_t r;
+                        __builtin_memcpy(&r, &rp[j], 8);
+                        v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+                    }
+                    if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
+                    const h4_t hv = c1_cvt4(v0, v1, v2, v3);
+                    __builtin_memcpy(&pk[j], &hv, 8);
+                }
+                const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                if (inb)
+                    *reinterpret_cast<uint4 *>(out + obase + t * 32 + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+            }
+        }
+    }
+#undef ISSUE_G
+#undef WAIT_GROUP
+}
+
+void launch_conv1x1_c256(hipStream_t st, const half_t *in, int npix, const half_t *w_rowmajor, const float *scale,
+                         const float *shift, int relu, const half_t *res, half_t *out, const half_t *zero_page)
+{
+    static bool attr_done = false;
+    static int slots = 256;
+    const size_t lds = (size_t)NST * STAGE_BYTES + 512 * sizeof(float);
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_c256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_c256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            slots = cus;   // 130 KB of LDS, 8 waves of <= 256 VGPRs: one resident block per CU
+        attr_done = true;
+    }
+    const int ngroups = (npix + GPX - 1) / GPX;
+    if (ngroups == 0) return;
+    const int gpb = (ngroups + slots - 1) / slots;
+    const int grid = (ngroups + gpb - 1) / gpb;
+    if (res) hipLaunchKernelGGL(conv1x1_c256_kernel<true>, dim3(grid), dim3(NT1), lds, st, in, npix, w_rowmajor, scale, shift, relu, res, out, gpb, zero_page);
+    else hipLaunchKernelGGL(conv1x1_c256_kernel<false>, dim3(grid), dim3(NT1), lds, st, in, npix, w_rowmajor, scale, shift, relu, res, out, gpb, zero_page);
+}

@@ -35,7 +35,7 @@ __device__ __forceinline__ h4_t cvt4b(float a, float b, float c, float d)
     return r;
 }
 
-template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2>
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || ROWS != 0) ? 2 : 1)
 void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                         const half_t *__restrict__ wpk, const float *__restrict__ scale,
@@ -110,14 +110,14 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 
 #define ISSUE_X(chunk_, buf_)                                                                          \
     _Pragma("unroll") for (int i = 0; i < XPW; ++i) {                                                  \
-        if (wave + NW * i < XCH) {                                                                     \
+        if (ABL != 3 && wave + NW * i < XCH) {                                                                     \
             const half_t *src = xoff[i] >= 0 ? in + (size_t)xoff[i] + (chunk_)*CC : zero_page + (lane % SPR) * 8; \
             __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                        \
                                              (lds_void_t *)(Xs + (buf_)*XBYTES + (wave + NW * i) * 1024), 16, 0, 0); \
         }                                                                                              \
     }
 #define ISSUE_W(step_, buf_)                                                                           \
-    _Pragma("unroll") for (int i = 0; i < WPW; ++i) {                                                  \
+    _Pragma("unroll") for (int i = 0; i < (ABL == 4 ? 0 : WPW); ++i) {                                 \
         const half_t *src = wpk + (size_t)(step_)*CoutP * CC + woff[i];                                \
         __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                            \
                                          (lds_void_t *)(Ws + (buf_)*WBYTES + (wave * WPW + i) * 1024), 16, 0, 0); \
@@ -179,7 +179,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         }
         // software-pipelined fragment reads: the ds_reads of k-slice kk+1 are in flight while the
         // MFMAs of slice kk issue (two register sets, static indices)
-        constexpr int NK = CC / 16;
+        constexpr int NK = (ABL == 1) ? 0 : CC / 16;
         h8_t fa[2][CH_T], fb[2][PX_T];
 #pragma unroll
         for (int ct = 0; ct < CH_T; ++ct)
@@ -294,7 +294,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                     }
                     const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                     const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
-                    if (inb)
+                    if (inb && (ABL != 2 || t0[0] == 0x12345678u))
                         *reinterpret_cast<uint4 *>(reinterpret_cast<half_t *>(outv) + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
                 }
             }
@@ -302,7 +302,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     }
 }
 
-template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2>
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0>
 static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                             const float *scale, const float *shift, int CoutP, int relu, const half_t *res,
                             void *out, int Ho, int Wo, const half_t *zero_page)
@@ -314,7 +314,7 @@ static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int 
     constexpr bool SS_LDS = !(XBUF == 3 && BN == 256 && CC == 64);
     constexpr size_t lds = (size_t)XBUF * XCH * 1024 + (size_t)2 * BN * CC * 2 + (SS_LDS ? (size_t)2 * BN * sizeof(float) : 0);
     static bool attr_done = false;
-    auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES, NW, ROWS, XBUF>;
+    auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES, NW, ROWS, XBUF, ABL>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
@@ -389,6 +389,17 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
     // Experiment (SFD2_CONV_1X1_XBUF3): three input buffers with the chunk two steps ahead in flight and counted-vmcnt
     // barriers for the 1x1 layers.  Correct, but measured SLOWER than the two-buffer pipeline (conv1 34 -> 39 us,
     // conv3 44.5 -> 49 us at 1600x1200): doubling the input bytes in flight is not what these layers lack.
+    if (const char *ab = getenv("SFD2_CONV_1X1_ABLATE")) {   // timing ablations of the 1x1 256-channel layer (wrong results)
+        if (ks == 1 && !out_f32 && bn == 256 && cc == 64 && !residual) {
+            switch (ab[0]) {
+            case '1': launch_igemm2_t<1, 1, 256, 64, false, false, 8, 0, 2, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); return true;
+            case '2': launch_igemm2_t<1, 1, 256, 64, false, false, 8, 0, 2, 2>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); return true;
+            case '3': launch_igemm2_t<1, 1, 256, 64, false, false, 8, 0, 2, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); return true;
+            case '4': launch_igemm2_t<1, 1, 256, 64, false, false, 8, 0, 2, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); return true;
+            default: break;
+            }
+        }
+    }
     static const bool x3 = getenv("SFD2_CONV_1X1_XBUF3") != nullptr;
 #define SFD2_IG1(BN_, CC_, F32_)                                                                                         \
     do {                                                                                                                \

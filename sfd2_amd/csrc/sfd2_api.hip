@@ -50,6 +50,7 @@ struct DevBuf {
 struct ConvW {                 // one folded + packed layer
     int cin = 0, cout = 0, cout_pad = 0, ks = 0, stride = 1;
     DevBuf w, scale, shift;    // fp16 packed filters, fp32 [cout_pad]
+    DevBuf wrm;                // 1x1 256 -> 256 layers: the same filters as plain [cout][cin] fp16 (conv1x1_c256_kernel)
 };
 
 struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; };
@@ -155,8 +156,8 @@ extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
     for (int i = 0; i < 4; ++i) HIPCHECK(hipEventCreate(&c->ev[i]));
     HIPCHECK(hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming));
     c->fuse = getenv("SFD2_NO_FUSE") ? 0 : 1;
-    HIPCHECK(c->zero_page.ensure(256));
-    HIPCHECK(hipMemset(c->zero_page.p, 0, 256));
+    HIPCHECK(c->zero_page.ensure(1024));
+    HIPCHECK(hipMemset(c->zero_page.p, 0, 1024));
     *out = c;
     return 0;
 }
@@ -182,7 +183,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
                    &c->da0, &c->da3, &c->pb, &c->db, &c->f1a, &c->f1b, &c->f2a, &c->f2b, &c->f3a, &c->f3b, &c->frb1[0],
                    &c->frb1[1], &c->frb1[2], &c->frb2[0], &c->frb2[1], &c->frb2[2], &c->frb3[0], &c->frb3[1], &c->frb3[2],
                    &c->fpa0, &c->fpa3, &c->fda0, &c->fda3, &c->fpb, &c->fdb};
-    for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); }
+    for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); w->wrm.release(); }
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -263,6 +264,11 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
     if (upload(L.w, pk.data(), pk.size() * sizeof(half_t), c->stream)) return -1;
     if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
     if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+    if (ks == 1 && stride == 1 && cin == 256 && cout == 256) {
+        std::vector<half_t> rm((size_t)256 * 256);
+        for (size_t i = 0; i < rm.size(); ++i) rm[i] = (half_t)w->d[i];
+        if (upload(L.wrm, rm.data(), rm.size() * sizeof(half_t), c->stream)) return -1;
+    }
     return 0;
 }
 
@@ -549,6 +555,14 @@ static void conv(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &in
     const double flops = 2.0 * px * L.cout * L.cin * L.ks * L.ks;
     const double bytes = 2.0 * ((double)H * W * L.cin + (double)L.cout * L.cin * L.ks * L.ks) +
                          px * L.cout_pad * (out_f32 ? 4.0 : 2.0) + (res ? px * L.cout_pad * 2.0 : 0.0);
+    static const bool no_c1 = getenv("SFD2_NO_CONV1X1") != nullptr;
+    if (L.wrm.p && !out_f32 && !no_c1) {
+        snprintf(kn, sizeof(kn), "conv1x1_c256%s", res ? "+res" : "");
+        ProfScope ps(c, name, kn, flops, bytes);
+        launch_conv1x1_c256(c->stream, in.as<half_t>(), Ho * Wo, L.wrm.as<half_t>(), L.scale.as<float>(), L.shift.as<float>(),
+                            relu, res, reinterpret_cast<half_t *>(out.p), c->zero_page.as<half_t>());
+        return;
+    }
     ProfScope ps(c, name, kn, flops, bytes);
     launch_conv_igemm(c->stream, in.as<half_t>(), H, W, L.cin, L.w.as<half_t>(), L.scale.as<float>(),
                       L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu, res, out.p, out_f32, Ho, Wo,

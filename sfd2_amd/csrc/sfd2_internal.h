@@ -130,6 +130,10 @@ struct MatchFinal {
 void launch_match_finalize(hipStream_t st, const MatchFinal *fin_dev, int npairs, int max_n, int splits,
                            int flavour, int mutual, float ratio, float dist);
 
+// persistent streaming 1x1 conv, 256 -> 256 (ResBlock conv1 / conv3); w_rowmajor = [256 out][256 in] fp16; zero page >= 512 B
+void launch_conv1x1_c256(hipStream_t st, const half_t *in, int npix, const half_t *w_rowmajor, const float *scale,
+                         const float *shift, int relu, const half_t *res, half_t *out, const half_t *zero_page);
+
 // scale pyramid (nets/extractor.py:118-124,211-236,322-330)
 void launch_norm_resize(hipStream_t st, const float *img, int mode, int H, int W, int nh, int nw, float *out);
 void launch_ms_append(hipStream_t st, const float *kpts, const float *scores, const unsigned int *count, int cap, int W, int nw,
