@@ -564,44 +564,60 @@ void boundary_kernel(const unsigned long long *__restrict__ bnd, unsigned long l
 }
 
 // rank-by-counting sort of the selected keys (unique) into descending order.
-// block = 64 keys x 4 quarters of the comparison range.
+// block = 16 keys x 16 slices of the comparison range (256 blocks for 4096 keys instead of 64: the kernel is
+// latency-bound, 20 -> see profiles/ us); every slice streams its part of the keys through LDS in 256-key tiles.
+#define RS_KEYS 16
+#define RS_SL 16
 __global__ __launch_bounds__(NT)
 void rank_sort_kernel(const unsigned long long *__restrict__ sel, unsigned long long *__restrict__ sorted,
-                      int sel_cap, const unsigned int *__restrict__ counters)
+                      int sel_cap, const unsigned int *__restrict__ counters, int W, float *__restrict__ kpts,
+                      float *__restrict__ scores)
 {
-    __shared__ unsigned long long tile[4][256];
-    __shared__ unsigned int part[4][64];
+    __shared__ unsigned long long tile[RS_SL][64];
+    __shared__ unsigned int part[RS_SL][RS_KEYS];
     unsigned int n = counters[1];
     if (n > (unsigned int)sel_cap) n = sel_cap;
-    if (blockIdx.x * 64u >= n) return;
-    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const unsigned int i = blockIdx.x * 64 + li;
+    if (blockIdx.x * (unsigned int)RS_KEYS >= n) return;
+    const int li = threadIdx.x & (RS_KEYS - 1), q = threadIdx.x / RS_KEYS;      // key within the block, slice
+    const unsigned int i = blockIdx.x * RS_KEYS + li;
     const unsigned long long mine = i < n ? sel[i] : 0ull;
-    const unsigned int qlen = (n + 3) / 4, j0 = q * qlen;
+    const unsigned int qlen = (n + RS_SL - 1) / RS_SL, j0 = q * qlen;
     const unsigned int j1 = j0 + qlen < n ? j0 + qlen : n;
     unsigned int rank = 0;
-    for (unsigned int b = 0; b < qlen; b += 256) {           // same trip count for all four waves
-        for (int t = li; t < 256; t += 64) tile[q][t] = (j0 + b + t < j1) ? sel[j0 + b + t] : 0ull;
+    for (unsigned int b = 0; b < qlen; b += 64) {            // same trip count for every slice
+        for (int t = li; t < 64; t += RS_KEYS) tile[q][t] = (j0 + b + t < j1) ? sel[j0 + b + t] : 0ull;
         __syncthreads();
 #pragma unroll 8
-        for (int t = 0; t < 256; ++t) rank += tile[q][t] > mine ? 1u : 0u;
+        for (int t = 0; t < 64; ++t) rank += tile[q][t] > mine ? 1u : 0u;
         __syncthreads();
     }
     part[q][li] = rank;
     __syncthreads();
-    if (q == 0 && i < n) sorted[part[0][li] + part[1][li] + part[2][li] + part[3][li]] = mine;
+    if (q == 0 && i < n) {
+        unsigned int r = 0;
+#pragma unroll
+        for (int k = 0; k < RS_SL; ++k) r += part[k][li];
+        sorted[r] = mine;
+        if (kpts) {   // selection path: the key's pixel index and score go straight to the output row
+            const unsigned int idx = 0xFFFFFFFFu - (unsigned int)(mine & 0xFFFFFFFFull);
+            kpts[2 * r] = (float)(idx % (unsigned int)W);
+            kpts[2 * r + 1] = (float)(idx / (unsigned int)W);
+            scores[r] = __uint_as_float((unsigned int)(mine >> 32));
+        }
+    }
 }
 
 void launch_topk_sort(hipStream_t st, const unsigned long long *cand, int cand_cap, int top_k,
                       unsigned long long *sel, unsigned long long *sorted, int sel_cap, unsigned int *counters,
-                      unsigned long long *bnd)
+                      unsigned long long *bnd, int W, float *kpts, float *scores)
 {
     hipLaunchKernelGGL(select_threshold_kernel, dim3(1), dim3(1024), 0, st, cand_cap, top_k, counters);
     int grid = (cand_cap + NT - 1) / NT;
     if (grid > 256) grid = 256;
     hipLaunchKernelGGL(compact_selected_kernel, dim3(grid), dim3(NT), 0, st, cand, cand_cap, sel, sel_cap, bnd, counters);
     hipLaunchKernelGGL(boundary_kernel, dim3(1), dim3(1024), 0, st, bnd, sel, sel_cap, counters);
-    hipLaunchKernelGGL(rank_sort_kernel, dim3((sel_cap + 63) / 64), dim3(NT), 0, st, sel, sorted, sel_cap, counters);
+    hipLaunchKernelGGL(rank_sort_kernel, dim3((sel_cap + RS_KEYS - 1) / RS_KEYS), dim3(NT), 0, st, sel, sorted, sel_cap, counters, W,
+                       kpts, scores);
 }
 
 __global__ __launch_bounds__(NT)
@@ -946,7 +962,8 @@ void launch_ms_merge(hipStream_t st, int n_levels, const int *offsets, const uns
     if (top_k > 0) {
         hipLaunchKernelGGL(ms_keys_kernel, dim3((cap_total + NT - 1) / NT), dim3(NT), 0, st, lv, level_count, sc_stage, keys,
                            cap_total, ms_counters);
-        hipLaunchKernelGGL(rank_sort_kernel, dim3((cap_total + 63) / 64), dim3(NT), 0, st, keys, sorted, cap_total, ms_counters);
+        hipLaunchKernelGGL(rank_sort_kernel, dim3((cap_total + RS_KEYS - 1) / RS_KEYS), dim3(NT), 0, st, keys, sorted, cap_total, ms_counters, 1,
+                           nullptr, nullptr);
         order = sorted;
     }
     if (n_max <= 0) return;

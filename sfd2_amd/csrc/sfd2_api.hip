@@ -637,9 +637,10 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     const int H = c->H, W = c->W, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
     const double P1 = (double)H * W, P4 = (double)H4 * W4, P8 = (double)H8 * W8;
     // Activation placement.  det (the parity entry point) keeps every activation in its own buffer for
-    // sfd2_debug_activation.  The throughput path (sfd2_extract) packs the whole chain into four 61 MB slots of one
+    // sfd2_debug_activation.  The throughput path (sfd2_extract) packs the whole chain into three 61 MB slots of one
     // arena (at 1600x1200), reusing a slot as soon as its tensor is dead, so the working set fits the 256 MB
-    // Infinity Cache and a layer mostly reads what the previous one just wrote (measured: ResBlocks 400 -> 366 us).
+    // Infinity Cache and a layer mostly reads what the previous one just wrote (measured: ResBlocks 400 -> 344 us;
+    // four slots measure the same as three).
     static const bool no_alias = getenv("SFD2_NO_ALIAS") != nullptr;
     const bool alias = c->fuse_now && !no_alias;
     DevBuf a1b = c->a1b, a2a = c->a2a, a2b = c->a2b, a3a = c->a3a, a3b = c->a3b, pa0_o = c->pa0_o, pa_o = c->pa_o,
@@ -652,13 +653,19 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         S = std::max(S, (P2 * 128 * 2 + 1) / 2);
         S = std::max(S, 2 * (P8s * 256 * 2 + 256));
         S = (S + 255) & ~(size_t)255;
-        HIPCHECK(c->arena.ensure(4 * S));
+        HIPCHECK(c->arena.ensure(3 * S));
         char *base = c->arena.as<char>();
         auto slot = [&](int i, size_t off = 0) { DevBuf v; v.p = base + (size_t)i * S + off; v.cap = 0; return v; };
-        a1b = slot(0); a2a = slot(1) /* spans slots 1-2 */; a2b = slot(0); a3a = slot(3); a3b = slot(1);
-        for (int b = 0; b < 3; ++b) { t1v[b] = slot(0); t2v[b] = slot(2); rov[b] = slot((b & 1) ? 1 : 3); }
-        pa0_o = slot(0); pa_o = slot(0, (P8s * 256 * 2 + 255) & ~(size_t)255);
-        da0_o = slot(1); da_o = slot(2);
+        {
+            // three slots (184 MB): a ResBlock's output overwrites its own t1 (dead once conv3 starts), the next
+            // block's t1 takes the slot of the previous input
+            a1b = slot(0); a2a = slot(1) /* spans slots 1-2 */; a2b = slot(0); a3a = slot(1); a3b = slot(2);
+            t1v[0] = slot(0); t2v[0] = slot(1); rov[0] = slot(0);    // x = slot 2
+            t1v[1] = slot(2); t2v[1] = slot(1); rov[1] = slot(2);    // x = slot 0
+            t1v[2] = slot(0); t2v[2] = slot(1); rov[2] = slot(0);    // x = slot 2 -> final x = slot 0
+            pa0_o = slot(1); pa_o = slot(1, (P8s * 256 * 2 + 255) & ~(size_t)255);
+            da0_o = slot(2); da_o = slot(1);   // convDa.3 runs after convPb has consumed slot 1
+        }
     }
     if (c->fuse_now) {
         ProfScope ps(c, "conv1a+conv1b", "fused_stem_kernel", 2.0 * P1 * 64 * 27 + 2.0 * (double)H2 * W2 * 64 * 576,
@@ -786,13 +793,11 @@ static int run_selection(sfd2_ctx *c, const float *heat_dev, int H, int W, float
     }
     {
         ProfScope ps(c, "topk_sort", "hist_select+compact+rank_sort", 0.0, (double)sel_cap * 24);
-        launch_topk_sort(c->stream, c->cand.as<unsigned long long>(), c->cand_cap, top_k,
-                         c->sel.as<unsigned long long>(), c->sorted.as<unsigned long long>(), sel_cap,
-                         c->counters.as<unsigned int>(), c->bnd.as<unsigned long long>());
         c->kpts_cur = kpts_dev ? kpts_dev : c->kpts.as<float>();      // written in place when the caller's buffers are
         c->kscores_cur = scores_dev ? scores_dev : c->kscores.as<float>();   // device resident: no staging copies
-        launch_keys_to_kpts(c->stream, c->sorted.as<unsigned long long>(), c->counters.as<unsigned int>(), W,
-                            c->kpts_cur, c->kscores_cur, sel_cap);
+        launch_topk_sort(c->stream, c->cand.as<unsigned long long>(), c->cand_cap, top_k,
+                         c->sel.as<unsigned long long>(), c->sorted.as<unsigned long long>(), sel_cap,
+                         c->counters.as<unsigned int>(), c->bnd.as<unsigned long long>(), W, c->kpts_cur, c->kscores_cur);
     }
     HIPCHECK(hipGetLastError());
     return 0;

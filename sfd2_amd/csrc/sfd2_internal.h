@@ -66,9 +66,9 @@ void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radi
                        float *nms_dense /*may be null*/, unsigned long long *cand_keys, int cand_cap,
                        unsigned int *counters /*[0]=n_cand*/);
 // top-K of the candidate keys, sorted descending -> sorted_keys[0..n_sel), counters[1]=n_sel
-void launch_topk_sort(hipStream_t st, const unsigned long long *cand_keys, int cand_cap, int top_k,
-                      unsigned long long *sel_keys, unsigned long long *sorted_keys, int sel_cap,
-                      unsigned int *counters, unsigned long long *boundary_keys /*[cand_cap]*/);
+void launch_topk_sort(hipStream_t st, const unsigned long long *cand, int cand_cap, int top_k,
+                      unsigned long long *sel, unsigned long long *sorted, int sel_cap, unsigned int *counters,
+                      unsigned long long *bnd, int W, float *kpts, float *scores);   // kpts/scores: output rows (x, y), score
 #define SFD2_COUNTER_BYTES (64 + 65536 * 4)   // 16 counters + score histogram
 // greedy grid NMS of extract.py (nms_fast): init / one relaxation sweep / kept-score map
 void launch_greedy_init(hipStream_t st, const float *heat, int n, float conf_th, unsigned long long *keys, unsigned char *state);
