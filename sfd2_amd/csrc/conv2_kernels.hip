@@ -36,7 +36,7 @@ __device__ __forceinline__ h4_t cvt4b(float a, float b, float c, float d)
 }
 
 template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0>
-__global__ __launch_bounds__(NW * 64, (NW == 8 || ROWS != 0) ? 2 : 1)
+__global__ __launch_bounds__(NW * 64, (XBUF == 1 && BN == 128 && STRIDE == 1) ? 4 : ((NW == 8 || ROWS != 0) ? 2 : 1))
 void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                         const half_t *__restrict__ wpk, const float *__restrict__ scale,
                         const float *__restrict__ shift, int CoutP, int relu,
@@ -337,6 +337,10 @@ int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin)
     static const bool small1 = getenv("SFD2_CONV_1X1_SMALL") != nullptr;   // experiment: 4-wave 4x32 tiles for 1x1
     if (small1 && ks == 1 && CoutP % 256 == 0) return 32;
     if (CoutP % 256 == 0 && !bn128) return (Cin % 64 == 0) ? 64 : 32;
+    // conv2a (64 -> 128): the whole K of a tap row fits one 64-wide chunk, so the patch is staged once (XBUF = 1,
+    // 76 KB of LDS, two blocks per CU) and the 9 steps carry 16 MFMAs each instead of 18 steps of 8
+    static const bool c2a32 = getenv("SFD2_CONV2A_CC32") != nullptr;
+    if (ks == 3 && Cin == 64 && CoutP == 128 && !c2a32) return 64;
     return 32;
 }
 
@@ -383,6 +387,10 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
     if (small1 && ks == 1 && !out_f32 && bn == 256 && cc == 32) {
         if (residual) launch_igemm2_t<1, 1, 256, 32, false, true, 4, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         else launch_igemm2_t<1, 1, 256, 32, false, false, 4, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
+        return true;
+    }
+    if (ks == 3 && !out_f32 && bn == 128 && cc == 64 && Cin == 64 && !residual) {
+        launch_igemm2_t<3, 1, 128, 64, false, false, 8, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         return true;
     }
     if (ks == 3 && !out_f32) { if (bn == 256) SFD2_IG2(3, 256, false); else SFD2_IG2(3, 128, false); return true; }
