@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfd2hip.so")
-SOURCES = ["conv_kernels.hip", "conv2_kernels.hip", "conv1x1_kernels.hip", "conv_f32_kernels.hip", "fused_stem_kernel.hip", "post_kernels.hip", "match_kernels.hip", "sfd2_api.hip"]
+SOURCES = ["conv_kernels.hip", "conv2_kernels.hip", "conv1x1_kernels.hip", "resblock_kernel.hip", "conv_f32_kernels.hip", "fused_stem_kernel.hip", "post_kernels.hip", "match_kernels.hip", "sfd2_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("SFD2_EXTRA_FLAGS", "").split()
 

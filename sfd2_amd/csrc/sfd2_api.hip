@@ -51,6 +51,7 @@ struct ConvW {                 // one folded + packed layer
     int cin = 0, cout = 0, cout_pad = 0, ks = 0, stride = 1;
     DevBuf w, scale, shift;    // fp16 packed filters, fp32 [cout_pad]
     DevBuf wrm;                // 1x1 256 -> 256 layers: the same filters as plain [cout][cin] fp16 (conv1x1_c256_kernel)
+    DevBuf wgc;                // grouped 3x3: compact [256 oc][9 taps][8 in] fp16 (resblock_kernel)
 };
 
 struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; };
@@ -183,7 +184,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
                    &c->da0, &c->da3, &c->pb, &c->db, &c->f1a, &c->f1b, &c->f2a, &c->f2b, &c->f3a, &c->f3b, &c->frb1[0],
                    &c->frb1[1], &c->frb1[2], &c->frb2[0], &c->frb2[1], &c->frb2[2], &c->frb3[0], &c->frb3[1], &c->frb3[2],
                    &c->fpa0, &c->fpa3, &c->fda0, &c->fda3, &c->fpb, &c->fdb};
-    for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); w->wrm.release(); }
+    for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); w->wrm.release(); w->wgc.release(); }
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -326,6 +327,12 @@ static int pack_gconv(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
     if (upload(L.w, pk.data(), pk.size() * sizeof(half_t), c->stream)) return -1;
     if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
     if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+    std::vector<half_t> cp((size_t)256 * 9 * 8);
+    for (int oc = 0; oc < 256; ++oc)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int j = 0; j < 8; ++j)
+                cp[((size_t)oc * 9 + tap) * 8 + j] = (half_t)w->d[(((size_t)oc * 8 + j) * 3 + tap / 3) * 3 + tap % 3];
+    if (upload(L.wgc, cp.data(), cp.size() * sizeof(half_t), c->stream)) return -1;
     return 0;
 }
 
@@ -689,8 +696,22 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     static const char *nm1[3] = {"conv4.0.conv1", "conv4.1.conv1", "conv4.2.conv1"};
     static const char *nm2[3] = {"conv4.0.conv2", "conv4.1.conv2", "conv4.2.conv2"};
     static const char *nm3[3] = {"conv4.0.conv3", "conv4.1.conv3", "conv4.2.conv3"};
+    // SFD2_FUSED_RB: unset = the fused ResBlock kernel on the throughput path; "0" = three kernels per block;
+    // "det" = fused on the parity path too (conv4.b.bn1 / bn2 activations are then not materialised)
+    const char *frb = getenv("SFD2_FUSED_RB");
+    const bool fused_rb = frb ? (frb[0] == 'd' || (frb[0] != '0' && c->fuse_now)) : (c->fuse_now != 0);
+    static const char *nmf[3] = {"conv4.0", "conv4.1", "conv4.2"};
     for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
         DevBuf &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];
+        if (fused_rb && c->rb1[b].wrm.p && c->rb3[b].wrm.p) {
+            ProfScope ps(c, nmf[b], "resblock_kernel", 2.0 * P4 * 256 * (256 + 72 + 256), P4 * 256 * 4);
+            launch_resblock(st, x->as<half_t>(), H4, W4, c->rb1[b].wrm.as<half_t>(), c->rb1[b].scale.as<float>(),
+                            c->rb1[b].shift.as<float>(), c->rb2[b].wgc.as<half_t>(), c->rb2[b].scale.as<float>(),
+                            c->rb2[b].shift.as<float>(), c->rb3[b].wrm.as<half_t>(), c->rb3[b].scale.as<float>(),
+                            c->rb3[b].shift.as<float>(), alias ? t1.as<half_t>() : ob.as<half_t>(), c->zero_page.as<half_t>());
+            x = alias ? &t1 : &ob;   // the fused kernel must not write over its own input: with the arena the output takes t1's slot
+            continue;
+        }
         conv(c, nm1[b], c->rb1[b], *x, H4, W4, t1, H4, W4, 1);
         {
             ProfScope ps(c, nm2[b], "gconv3x3_g8_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 4);

@@ -134,6 +134,12 @@ void launch_match_finalize(hipStream_t st, const MatchFinal *fin_dev, int npairs
 void launch_conv1x1_c256(hipStream_t st, const half_t *in, int npix, const half_t *w_rowmajor, const float *scale,
                          const float *shift, int relu, const half_t *res, half_t *out, const half_t *zero_page);
 
+// fused ResBlock: conv1 1x1 + grouped 3x3 + conv3 1x1 + residual (resblock_kernel.hip); w1 / w3 row-major [256][256] fp16,
+// wg = the grouped conv's filters as compact [256 oc][9 taps][8 in] fp16; out must not alias x
+void launch_resblock(hipStream_t st, const half_t *x, int H, int W, const half_t *w1, const float *sc1, const float *sh1,
+                     const half_t *wg, const float *sc2, const float *sh2, const half_t *w3, const float *sc3, const float *sh3,
+                     half_t *out, const half_t *zero_page);
+
 // scale pyramid (nets/extractor.py:118-124,211-236,322-330)
 void launch_norm_resize(hipStream_t st, const float *img, int mode, int H, int W, int nh, int nw, float *out);
 void launch_ms_append(hipStream_t st, const float *kpts, const float *scores, const unsigned int *count, int cap, int W, int nw,

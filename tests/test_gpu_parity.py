@@ -723,3 +723,32 @@ def test_pipeline_mains_write_reference_layout(tmp_path, synth_sd):
                "descriptors1": st["db/a.jpg"]["descriptors"].__array__().astype(np.float32)[None]})
     np.testing.assert_array_equal(m["matches0"][()], np.asarray(pred["matches0"][0]).astype(np.int16))
     assert (m["matches0"][()] >= 0).sum() > 0
+
+
+@pytest.mark.parametrize("h,w,seed", [(64, 96, 11), (100, 130, 12), (37, 53, 13), (480, 640, 2)])
+def test_fused_resblock_vs_oracle_and_unfused(model, ctx, synth_sd, h, w, seed):
+    """resblock_kernel (conv1 + grouped conv + conv3 + residual in one kernel, the throughput path's ResBlock)
+    forced onto the parity entry point: its block outputs against the oracle's fp32 activations and against the
+    three-kernel path, and the heads computed from them."""
+    img = synth.make_image(h, w, seed)
+    x = orc.norm_rgb(img)
+    taps = {}
+    o_score, o_stab, o_desc = orc.det(synth_sd, x, taps)
+    score_u, stab_u, desc_u = model.det(x[None])
+    unfused = {k: ctx.debug_activation(k) for k in ("conv4.0", "conv4.1", "conv4.2")}
+    os.environ["SFD2_FUSED_RB"] = "det"
+    try:
+        score_f, stab_f, desc_f = model.det(x[None])
+        fused = {k: ctx.debug_activation(k) for k in ("conv4.0", "conv4.1", "conv4.2")}
+    finally:
+        del os.environ["SFD2_FUSED_RB"]
+    for k in fused:
+        want = taps[k]
+        assert fused[k].shape == want.shape
+        err = np.abs(fused[k] - want).max()
+        assert err <= 1.5e-2 * np.abs(want).max(), (k, err)
+        # same fp16 operands and K order as the three-kernel path: equal up to fp16 rounding of the intermediates
+        assert np.abs(fused[k] - unfused[k]).max() <= 4e-3 * np.abs(want).max(), k
+    assert (np.abs(score_f[0, 0] - o_score) <= 8e-2 * o_score + 1e-4).all()
+    assert np.abs(desc_f[0] - o_desc).max() <= 3e-3
+    assert (stab_f[0, 0] != o_stab).mean() < 0.01
