@@ -61,6 +61,12 @@ struct sfd2_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_jobs = nullptr;      // guards reuse of the pinned job descriptors below
+    // host images go through a copy stream into one of two staging slots, so the upload of image i + 1 overlaps the
+    // network of image i when the caller runs extracts back to back (SFD2_FLAG_ASYNC + pinned host memory)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_img_free[2] = {nullptr, nullptr};
+    DevBuf img2[2];
+    int img_slot = 0, img_slot_used = -1;
     void *pin_jobs = nullptr;
     size_t pin_cap = 0;
     bool weights_loaded = false;
@@ -156,6 +162,11 @@ extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
     HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; ++i) HIPCHECK(hipEventCreate(&c->ev[i]));
     HIPCHECK(hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming));
+    HIPCHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHECK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&c->ev_img_free[i], hipEventDisableTiming));
+    }
     c->fuse = getenv("SFD2_NO_FUSE") ? 0 : 1;
     HIPCHECK(c->zero_page.ensure(1024));
     HIPCHECK(hipMemset(c->zero_page.p, 0, 1024));
@@ -187,6 +198,12 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); w->wrm.release(); w->wgc.release(); }
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+        if (c->ev_img_free[i]) (void)hipEventDestroy(c->ev_img_free[i]);
+        c->img2[i].release();
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->pin_jobs) (void)hipHostFree(c->pin_jobs);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -743,9 +760,25 @@ static int stage_image(sfd2_ctx *c, const void *x, int on_device, int H, int W, 
 {
     if (on_device) { *dev = static_cast<const float *>(x); return 0; }
     const size_t bytes = (size_t)3 * H * W * (u8 ? 1 : sizeof(float));
-    HIPCHECK(c->img.ensure(bytes));
-    HIPCHECK(hipMemcpyAsync(c->img.p, x, bytes, hipMemcpyHostToDevice, c->stream));
-    *dev = c->img.as<float>();
+    const int slot = (c->img_slot ^= 1);
+    HIPCHECK(c->img2[slot].ensure(bytes));
+    // the slot's previous reader (the network two host images ago) must be done before the copy overwrites it
+    HIPCHECK(hipStreamWaitEvent(c->copy_stream, c->ev_img_free[slot], 0));
+    HIPCHECK(hipMemcpyAsync(c->img2[slot].p, x, bytes, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHECK(hipEventRecord(c->ev_copied[slot], c->copy_stream));
+    HIPCHECK(hipStreamWaitEvent(c->stream, c->ev_copied[slot], 0));
+    c->img_slot_used = slot;
+    *dev = c->img2[slot].as<float>();
+    return 0;
+}
+
+// after the network that read a staged host image has been enqueued: its slot may be refilled once that work is done
+static int release_image_slot(sfd2_ctx *c)
+{
+    if (c->img_slot_used >= 0) {
+        HIPCHECK(hipEventRecord(c->ev_img_free[c->img_slot_used], c->stream));
+        c->img_slot_used = -1;
+    }
     return 0;
 }
 
@@ -768,6 +801,7 @@ extern "C" int sfd2_det(sfd2_ctx *c, const float *x, int x_on_device, int H, int
     prof_step_begin(c);
     c->fuse_now = 0;   // det is the parity entry point: every activation stays readable (sfd2_debug_activation)
     if (run_network(c, img, (flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1)) return -1;
+    if (release_image_slot(c)) return -1;
     prof_step_end(c);
     const int HS = 8 * c->H8, WS = 8 * c->W8;
     if (hs) *hs = HS;
@@ -858,6 +892,7 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     c->fuse_now = c->fuse && c->precision == SFD2_PREC_F16;
     const int in_mode = ((flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1) | (u8 ? 2 : 0) | ((flags & SFD2_FLAG_IMG_BGR) ? 4 : 0);
     if (run_network(c, img_dev, in_mode)) return -1;
+    if (release_image_slot(c)) return -1;
     HIPCHECK(hipEventRecord(c->ev[1], c->stream));
     const int HS = 8 * c->H8, WS = 8 * c->W8;
     {
@@ -980,6 +1015,7 @@ extern "C" int sfd2_extract_multiscale(sfd2_ctx *c, const void *img, int img_on_
         HIPCHECK(hipMemcpyAsync(c->ms_cand_seen + l, c->counters.p, 4, hipMemcpyDeviceToHost, c->stream));
         c->ms_cand_cap[l] = c->cand_cap;
     }
+    if (release_image_slot(c)) return -1;     // every level has read the staged image
     const int64_t want = top_k > 0 ? std::min<int64_t>(top_k, cap_total) : cap_total;
     const int64_t n_max = cap_out >= 0 ? std::min<int64_t>(want, cap_out) : want;
     float *kp_dst = kpts_xy, *sc_dst = scores, *de_dst = desc;
@@ -1080,6 +1116,7 @@ extern "C" int sfd2_extract_spp(sfd2_ctx *c, const float *x, int x_on_device, in
     prof_step_begin(c);
     c->fuse_now = c->fuse && c->precision == SFD2_PREC_F16;
     if (run_network(c, img_dev, 0)) return -1;   // the caller normalised the image (extract.py:280-287)
+    if (release_image_slot(c)) return -1;
     const int HS = 8 * c->H8, WS = 8 * c->W8;
     launch_heatmap(c->stream, c->score.as<float>(), HS, WS, (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(),
                    c->H4, c->W4, H, W, c->heat.as<float>(), nullptr);
