@@ -725,7 +725,7 @@ def test_pipeline_mains_write_reference_layout(tmp_path, synth_sd):
     assert (m["matches0"][()] >= 0).sum() > 0
 
 
-@pytest.mark.parametrize("h,w,seed", [(64, 96, 11), (100, 130, 12), (37, 53, 13), (480, 640, 2)])
+@pytest.mark.parametrize("h,w,seed", [(64, 96, 11), (100, 130, 12), (37, 53, 13), (480, 640, 2), (8, 8, 3), (9, 17, 4), (16, 250, 5)])
 def test_fused_resblock_vs_oracle_and_unfused(model, ctx, synth_sd, h, w, seed):
     """resblock_kernel (conv1 + grouped conv + conv3 + residual in one kernel, the throughput path's ResBlock)
     forced onto the parity entry point: its block outputs against the oracle's fp32 activations and against the
