@@ -125,10 +125,15 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
             f32x16_t acc0;      // one accumulator chain: the SIMD's other wave fills the dependent-issue gaps
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc0[i] = 0.0f;
+            // the next k slice's fragment is requested before the current MFMA issues (LDS returns in order, so the
+            // compiler can wait with a counted lgkmcnt): LDS latency overlaps the matrix pipe inside one wave
+            h8_t bcur = *reinterpret_cast<const h8_t *>(xr);
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                const h8_t b0 = *reinterpret_cast<const h8_t *>(xr + kk * 32);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kk], b0, acc0, 0, 0, 0);
+                h8_t bnext = bcur;
+                if (kk + 1 < 16) bnext = *reinterpret_cast<const h8_t *>(xr + (kk + 1) * 32);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kk], bcur, acc0, 0, 0, 0);
+                bcur = bnext;
             }
             const bool inside = r >= 0 && r < H && ncol >= 0 && ncol < W;
             unsigned char *t1w = T1 + ((r + 3) % 3) * RB_ROW + n * 512;
@@ -195,10 +200,13 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
             f32x16_t acc0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc0[i] = 0.0f;
+            h8_t bcur = *reinterpret_cast<const h8_t *>(tp);
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                const h8_t b0 = *reinterpret_cast<const h8_t *>(tp + kk * 32);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3[kk], b0, acc0, 0, 0, 0);
+                h8_t bnext = bcur;
+                if (kk + 1 < 16) bnext = *reinterpret_cast<const h8_t *>(tp + (kk + 1) * 32);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3[kk], bcur, acc0, 0, 0, 0);
+                bcur = bnext;
             }
             const unsigned char *xres = XR + ((y + RB_NX) % RB_NX) * RB_PROW + pp_base;
             const bool st_ok = n >= 1 && n <= RB_SW && ncol < W;
