@@ -528,15 +528,29 @@ void compact_selected_kernel(const unsigned long long *__restrict__ cand, int ca
     unsigned int n = counters[0];
     if (n > (unsigned int)cand_cap) n = cand_cap;
     const unsigned int bstar = counters[4], all = counters[6];
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned long long key = cand[i];
+    // wave-aggregated cursors: one atomic per wave and list instead of one per key (same-address atomics serialise)
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned int stride = gridDim.x * blockDim.x;
+    for (unsigned int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += stride) {      // wave-uniform trip count
+        const unsigned int i = i0 + threadIdx.x;
+        const bool live = i < n;
+        const unsigned long long key = live ? cand[i] : 0ull;
         const unsigned int bin = (unsigned int)(key >> 47) & 0xFFFFu;
-        if (all || bin > bstar) {
-            const unsigned int pos = atomicAdd(&counters[2], 1u);
+        const bool to_sel = live && (all || bin > bstar), to_bnd = live && !to_sel && bin == bstar;
+        const unsigned long long ms = __ballot(to_sel), mb = __ballot(to_bnd);
+        unsigned int base_s = 0, base_b = 0;
+        if (lane == 0) {
+            if (ms) base_s = atomicAdd(&counters[2], (unsigned int)__popcll(ms));
+            if (mb) base_b = atomicAdd(&counters[3], (unsigned int)__popcll(mb));
+        }
+        base_s = __shfl(base_s, 0);
+        base_b = __shfl(base_b, 0);
+        if (to_sel) {
+            const unsigned int pos = base_s + (unsigned int)__popcll(ms & below);
             if (pos < (unsigned int)sel_cap) sel[pos] = key;
-        } else if (bin == bstar) {
-            const unsigned int pos = atomicAdd(&counters[3], 1u);
-            bnd[pos] = key;   // bnd has cand_cap entries
+        } else if (to_bnd) {
+            bnd[base_b + (unsigned int)__popcll(mb & below)] = key;   // bnd has cand_cap entries
         }
     }
 }
