@@ -1371,7 +1371,12 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     // previous call's async copies have consumed them before they are rewritten
     static_assert(sizeof(MatchJob2) <= 2 * sizeof(MatchJob), "descriptor buffer sizing");
     const size_t jobs_bytes = 2 * (size_t)k * sizeof(MatchJob), fins_bytes = (size_t)k * sizeof(MatchFinal);
-    HIPCHECK(hipEventSynchronize(c->ev_jobs));
+    // hipGraph capture of the caller's stream (tools/graph_replay.py): no host-side event waits while capturing; the
+    // captured copies read the pinned descriptors at replay time, so they must not be rewritten by eager calls meanwhile
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(c->stream, &cap_status);
+    const bool capturing = cap_status != hipStreamCaptureStatusNone;
+    if (!capturing) HIPCHECK(hipEventSynchronize(c->ev_jobs));
     if (jobs_bytes + fins_bytes > c->pin_cap) {
         if (c->pin_jobs) (void)hipHostFree(c->pin_jobs);
         c->pin_jobs = nullptr;
@@ -1428,7 +1433,7 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     }
     HIPCHECK(hipMemcpyAsync(c->m_jobs.p, jobs, jobs_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(c->m_fins.p, fins, fins_bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(hipEventRecord(c->ev_jobs, c->stream));
+    if (!capturing) HIPCHECK(hipEventRecord(c->ev_jobs, c->stream));
     if (single_gemm) {
         {
             ProfScope ps(c, "match_mutual", "match_mutual_kernel", 2.0 * (double)n0 * (double)tot_n1 * 128.0,

@@ -752,3 +752,56 @@ def test_fused_resblock_vs_oracle_and_unfused(model, ctx, synth_sd, h, w, seed):
     assert (np.abs(score_f[0, 0] - o_score) <= 8e-2 * o_score + 1e-4).all()
     assert np.abs(desc_f[0] - o_desc).max() <= 3e-3
     assert (stab_f[0, 0] != o_stab).mean() < 0.01
+
+
+def test_hipgraph_capture_replay_matches_eager(model):
+    """BASELINE configs[4]: one extract + match step captured on the context's stream and replayed as a hipGraph gives the
+    eager step's outputs bit for bit (device-resident inputs / outputs, SFD2_FLAG_ASYNC: the calls are pure stream work)."""
+    import torch
+    hip = ctypes.CDLL("libamdhip64.so")
+    ctx = model.context
+    lib = ctx.lib
+    H, W, K, KDB = 240, 320, 512, 3
+    img = torch.from_numpy(synth.make_image(H, W, 31)).cuda()
+    db = [torch.from_numpy(synth.make_descriptors(400 + 50 * i, seed=70 + i)).to(torch.float16).cuda().contiguous() for i in range(KDB)]
+    dbs = (_lib.DescSet * KDB)(*[_lib.DescSet(d.data_ptr(), d.shape[0], _lib.DT_F16, _lib.LAYOUT_ND, 1) for d in db])
+    mconf = _lib.MatchConf(_lib.MATCH_HLOC, 1, 0.0, 0.0, _lib.SIM_F16)
+    kp = torch.zeros((K, 2), device="cuda"); sc = torch.zeros((K,), device="cuda"); de = torch.zeros((K, 128), device="cuda")
+    mt = torch.full((KDB, K), -7, dtype=torch.int64, device="cuda"); ms = torch.zeros((KDB, K), device="cuda")
+    q = _lib.DescSet(de.data_ptr(), K, _lib.DT_F32, _lib.LAYOUT_ND, 1)
+    n = ctypes.c_int()
+
+    def step():
+        _lib.check(lib.sfd2_extract(ctx.h, img.data_ptr(), 1, H, W, 0.001, K, _lib.FLAG_ASYNC, kp.data_ptr(), sc.data_ptr(),
+                                    de.data_ptr(), 1, K, ctypes.byref(n)))
+        _lib.check(lib.sfd2_match_batch(ctx.h, ctypes.byref(q), dbs, KDB, 128, ctypes.byref(mconf), mt.data_ptr(), ms.data_ptr(),
+                                        1, _lib.FLAG_ASYNC))
+
+    torch.cuda.synchronize()
+    step(); step()
+    ctx.sync()
+    want = (kp.clone(), sc.clone(), de.clone(), mt.clone(), ms.clone())
+    assert (want[3] >= 0).sum() > 0
+    stream = ctypes.c_void_p(lib.sfd2_get_stream(ctx.h))
+    graph, gexec = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipStreamBeginCapture(stream, 2) == 0      # hipStreamCaptureModeRelaxed
+    try:
+        step()
+    finally:
+        rc = hip.hipStreamEndCapture(stream, ctypes.byref(graph))
+    assert rc == 0 and graph.value
+    assert hip.hipGraphInstantiate(ctypes.byref(gexec), graph, None, None, 0) == 0
+    for t in (kp, sc, de, ms):
+        t.zero_()
+    mt.fill_(-7)
+    torch.cuda.synchronize()
+    assert hip.hipGraphLaunch(gexec, stream) == 0
+    assert hip.hipGraphLaunch(gexec, stream) == 0
+    ctx.sync()
+    for got, exp in zip((kp, sc, de, mt, ms), want):
+        assert torch.equal(got, exp)
+    hip.hipGraphExecDestroy(gexec)
+    hip.hipGraphDestroy(graph)
+    step()        # eager calls keep working after the capture
+    ctx.sync()
+    assert torch.equal(mt, want[3])
