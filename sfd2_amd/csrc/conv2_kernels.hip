@@ -35,7 +35,7 @@ __device__ __forceinline__ h4_t cvt4b(float a, float b, float c, float d)
     return r;
 }
 
-template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0>
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0, int WBUF = 2>
 __global__ __launch_bounds__(NW * 64, (XBUF == 1 && BN == 128 && STRIDE == 1) ? 4 : ((NW == 8 || ROWS != 0) ? 2 : 1))
 void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                         const half_t *__restrict__ wpk, const float *__restrict__ scale,
@@ -70,7 +70,10 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     // with a counted vmcnt.  With 256-channel tiles and 64-wide chunks that is exactly 160 KB, so scale/shift then
     // come from global memory in the epilogue instead of LDS.
     constexpr bool SS_LDS = !(XBUF == 3 && BN == 256 && CC == 64);
-    float *SS = reinterpret_cast<float *>(Ws + 2 * WBYTES);   // scale[BN], shift[BN] of this channel tile (SS_LDS)
+    // WBUF == 3 (3x3 layers): a ring of three filter tiles, the tile two steps ahead in flight across the barrier
+    // (counted vmcnt), the next input chunk requested at the FIRST tap of the current one instead of the last.
+    static_assert(WBUF == 2 || (WBUF == 3 && KS == 3 && XBUF == 2), "WBUF = 3 is the 3x3 filter ring");
+    float *SS = reinterpret_cast<float *>(Ws + WBUF * WBYTES);   // scale[BN], shift[BN] of this channel tile (SS_LDS)
     static_assert(XBUF != 3 || (KS == 1 && STRIDE == 1), "XBUF = 3 is the 1x1 pipeline");
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -89,7 +92,8 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     int xoff[XPW];
 #pragma unroll
     for (int i = 0; i < XPW; ++i) {
-        const int chunk = wave + NW * i;
+        int chunk = wave + NW * i;
+        if (WBUF == 3 && chunk >= XCH) chunk = XCH - 1;   // every wave issues XPW copies (the waits count them): duplicates of the last chunk
         const int q = chunk * RPC + lane / SPR;
         const int slot = (lane % SPR) ^ ((q >> SWS) & (SPR - 1));  // logical 16-byte slot this lane's bytes hold
         int off = -1;
@@ -110,10 +114,11 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 
 #define ISSUE_X(chunk_, buf_)                                                                          \
     _Pragma("unroll") for (int i = 0; i < XPW; ++i) {                                                  \
-        if (ABL != 3 && wave + NW * i < XCH) {                                                                     \
+        if (ABL != 3 && (WBUF == 3 || wave + NW * i < XCH)) {                                          \
+            const int xc = (WBUF == 3 && wave + NW * i >= XCH) ? XCH - 1 : wave + NW * i;              \
             const half_t *src = xoff[i] >= 0 ? in + (size_t)xoff[i] + (chunk_)*CC : zero_page + (lane % SPR) * 8; \
             __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                        \
-                                             (lds_void_t *)(Xs + (buf_)*XBYTES + (wave + NW * i) * 1024), 16, 0, 0); \
+                                             (lds_void_t *)(Xs + (buf_)*XBYTES + xc * 1024), 16, 0, 0); \
         }                                                                                              \
     }
 #define ISSUE_W(step_, buf_)                                                                           \
@@ -139,8 +144,11 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     ISSUE_W(0, 0)
     if (SS_LDS)
         for (int t = tid; t < BN; t += NW * 64) { SS[t] = scale[n0 + t]; SS[BN + t] = shift[n0 + t]; }
+#define BARRIER_KEEP(n_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n_) : "memory")
     if (XBUF == 3) {
         if (NS > 1) { ISSUE_X(1, 1) BARRIER_KEEP_X(); } else { BARRIER_DRAIN(); }
+    } else if (WBUF == 3) {
+        if (NS > 1) { ISSUE_W(1, 1) BARRIER_KEEP(WPW); } else { BARRIER_DRAIN(); }
     } else {
         __syncthreads();   // hipcc drains vmcnt(0) before the barrier while LDS-DMA is in flight
     }
@@ -158,13 +166,21 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 
     int chunk = 0, tap = 0;
     for (int s = 0; s < NS; ++s) {
-        const int wb = s & 1, xb = (XBUF == 3) ? (chunk % 3) : ((XBUF == 2) ? (chunk & 1) : 0);
+        const int wb = (WBUF == 3) ? (s % 3) : (s & 1), xb = (XBUF == 3) ? (chunk % 3) : ((XBUF == 2) ? (chunk & 1) : 0);
         int ntap = tap + 1, nchunk = chunk;
         if (ntap == T) { ntap = 0; ++nchunk; }
         const bool has_next = (s + 1 < NS);
         const bool new_chunk = has_next && (ntap == 0);
-        if (has_next) { ISSUE_W(s + 1, wb ^ 1) }
-        if (XBUF == 2 && new_chunk) { ISSUE_X(nchunk, xb ^ 1) }
+        bool x_now = false, w_now = false;
+        if (WBUF == 3) {
+            x_now = (tap == 0) && (chunk + 1 < Cin / CC);
+            w_now = s + 2 < NS;
+            if (x_now) { ISSUE_X(chunk + 1, xb ^ 1) }        // nine steps ahead; older than every later filter copy
+            if (w_now) { ISSUE_W(s + 2, (s + 2) % 3) }      // into the ring slot step s - 1 read
+        } else {
+            if (has_next) { ISSUE_W(s + 1, wb ^ 1) }
+            if (XBUF == 2 && new_chunk) { ISSUE_X(nchunk, xb ^ 1) }
+        }
         if (XBUF == 3 && s + 2 < NS) { ISSUE_X(s + 2, (s + 2) % 3) }   // after W(s + 1): the counted wait keeps exactly these
 
         const int ky = tap / KS, kx = tap - ky * KS;
@@ -212,6 +228,12 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         }
         if (XBUF == 3) {
             if (s + 2 < NS) BARRIER_KEEP_X(); else BARRIER_DRAIN();
+        } else if (WBUF == 3) {
+            // the filter tile of step s + 1 was issued one step ago; only what this step issued may stay in flight
+            if (x_now && w_now) BARRIER_KEEP(XPW + WPW);
+            else if (w_now) BARRIER_KEEP(WPW);
+            else if (x_now) BARRIER_KEEP(XPW);
+            else BARRIER_DRAIN();
         } else {
             __syncthreads();
         }
@@ -225,6 +247,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #undef ISSUE_X
 #undef ISSUE_W
 #undef BARRIER_KEEP_X
+#undef BARRIER_KEEP
 #undef BARRIER_DRAIN
 
     // epilogue: y = acc * scale + shift (+ residual) (ReLU).  A lane owns, per register quad q, channels
@@ -302,7 +325,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     }
 }
 
-template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0>
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0, int WBUF = 2>
 static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                             const float *scale, const float *shift, int CoutP, int relu, const half_t *res,
                             void *out, int Ho, int Wo, const half_t *zero_page)
@@ -312,9 +335,9 @@ static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int 
     constexpr int RPC = 1024 / (CC * 2);
     constexpr int XCH = (PH * PW + RPC - 1) / RPC;
     constexpr bool SS_LDS = !(XBUF == 3 && BN == 256 && CC == 64);
-    constexpr size_t lds = (size_t)XBUF * XCH * 1024 + (size_t)2 * BN * CC * 2 + (SS_LDS ? (size_t)2 * BN * sizeof(float) : 0);
+    constexpr size_t lds = (size_t)XBUF * XCH * 1024 + (size_t)WBUF * BN * CC * 2 + (SS_LDS ? (size_t)2 * BN * sizeof(float) : 0);
     static bool attr_done = false;
-    auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES, NW, ROWS, XBUF, ABL>;
+    auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES, NW, ROWS, XBUF, ABL, WBUF>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
@@ -336,6 +359,8 @@ int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin)
     static const bool bn128 = getenv("SFD2_CONV_BN128") != nullptr;   // experiment: 128-channel tiles everywhere
     static const bool small1 = getenv("SFD2_CONV_1X1_SMALL") != nullptr;   // experiment: 4-wave 4x32 tiles for 1x1
     if (small1 && ks == 1 && CoutP % 256 == 0) return 32;
+    static const bool w3 = getenv("SFD2_CONV_WRING") != nullptr;   // experiment: 32-wide chunks + three-tile filter ring for 3x3 256-ch layers
+    if (w3 && ks == 3 && CoutP % 256 == 0) return 32;
     if (CoutP % 256 == 0 && !bn128) return (Cin % 64 == 0) ? 64 : 32;
     // conv2a (64 -> 128): the whole K of a tap row fits one 64-wide chunk, so the patch is staged once (XBUF = 1,
     // 76 KB of LDS, two blocks per CU) and the 9 steps carry 16 MFMAs each instead of 18 steps of 8
@@ -387,6 +412,11 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
     if (small1 && ks == 1 && !out_f32 && bn == 256 && cc == 32) {
         if (residual) launch_igemm2_t<1, 1, 256, 32, false, true, 4, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         else launch_igemm2_t<1, 1, 256, 32, false, false, 4, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
+        return true;
+    }
+    static const bool w3 = getenv("SFD2_CONV_WRING") != nullptr;
+    if (w3 && ks == 3 && !out_f32 && bn == 256 && cc == 32 && !residual) {
+        launch_igemm2_t<3, 1, 256, 32, false, false, 8, 0, 2, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         return true;
     }
     if (ks == 3 && !out_f32 && bn == 128 && cc == 64 && Cin == 64 && !residual) {
