@@ -69,6 +69,34 @@ def _to_u8_hwc(img):
     return a, False, a.shape[0], a.shape[1]
 
 
+def select_with_mask(keypoints, scores, descriptors, mask, topK):
+    """nets/extractor.py:240-319 on the score-sorted candidate list: label = B + 256 G + 65536 R of the mask pixel
+    under the key point (mask is the cv2 BGR image, :252); labelled key points (label != 0) are kept first, the
+    unlabelled ones only fill what is left of topK.  Host logic, exactly as in the reference (including its
+    behaviour for topK <= 0: the full lists with the labels of the labelled points only)."""
+    mask = np.asarray(mask)
+    id_img = np.int32(mask[:, :, 2]) * 256 * 256 + np.int32(mask[:, :, 1]) * 256 + np.int32(mask[:, :, 0])
+    gid = id_img[keypoints[:, 1].astype(np.int64), keypoints[:, 0].astype(np.int64)] if len(keypoints) else np.zeros((0,), np.int32)
+    w = np.flatnonzero(gid != 0)
+    wo = np.flatnonzero(gid == 0)
+    labels = gid[w].tolist()
+    if topK > 0:
+        if topK <= len(w):
+            idx = np.array(scores[w], dtype=float).argsort()[::-1][:topK]
+            sel = w[idx]
+            labels = np.array(labels, np.int32)[idx]
+        elif topK >= len(w) + len(wo):
+            sel = np.concatenate([w, wo])
+            labels = labels + [0] * len(wo)
+        else:
+            idx = np.array(scores[wo], dtype=float).argsort()[::-1][:topK - len(w)]
+            sel = np.concatenate([w, wo[idx]])
+            labels = labels + [0] * len(idx)
+        keypoints, scores, descriptors = keypoints[sel], scores[sel], descriptors[sel]
+    return {"keypoints": np.array(keypoints, dtype=float), "descriptors": np.array(descriptors, dtype=float),
+            "scores": np.array(scores, dtype=float), "labels": np.array(labels, np.int32)}
+
+
 def extract_resnet_return(model, img, conf_th=0.001, mask=None, topK=-1, **kwargs):
     """nets/extractor.py:97-338.  img: [1,3,H,W] in [0,1] (RGB), cpu or cuda -- or the decoder's
     uint8 [H,W,3] image as is (kwarg bgr=True for cv2.imread order): the astype(float32) / 255.
@@ -78,8 +106,9 @@ def extract_resnet_return(model, img, conf_th=0.001, mask=None, topK=-1, **kwarg
     sorted by score descending, N <= topK (topK <= 0: all candidates; with several scales the
     reference then returns the per-scale lists concatenated, and so does this)."""
     if mask is not None:
-        raise NotImplementedError("semantic-mask top-K branch (nets/extractor.py:240-319) is not on the shipped "
-                                  "pipelines' path (extract_localization.py:247 passes mask=None)")
+        # semantic-mask branch (nets/extractor.py:240-319): needs EVERY candidate, labelled ones are preferred
+        allp = extract_resnet_return(model, img, conf_th=conf_th, mask=None, topK=-1, **kwargs)
+        return select_with_mask(allp["keypoints"], allp["scores"], allp["descriptors"], mask, topK)
     scales = [float(s) for s in kwargs.get("scales", [1.0])]
     ctx = model.context
     flags = 0 if getattr(model, "require_stability", True) else _lib.FLAG_NO_STABILITY

@@ -1,8 +1,9 @@
 """Mirror of it_loc/matcher.py (reference): Matcher(conf) with conf['model']['name'] in
-{'nnm', 'nnr'}; forward takes numpy float64 [N,128] / [M,128] descriptor sets and
-returns numpy matches0 / matching_scores0 (it_loc/matcher.py:91-119).  The label path
-('nnml', matcher_with_label) is not on the shipped pipelines' path
-(it_loc/localize_cv2.py:714 with_label=False) and raises NotImplementedError."""
+{'nnm', 'nnr', 'nnml'}; forward takes numpy float64 [N,128] / [M,128] descriptor sets and
+returns numpy matches0 / matching_scores0 (it_loc/matcher.py:91-119).  'nnml' is the label-aware
+matcher (matcher_with_label, :239-297; disabled in the shipped pipelines, with_label=False at
+it_loc/localize_cv2.py:714): mutual NN inside every label the two images share, then mutual NN
+among the key points that are still unmatched; every similarity / arg-max runs on the device."""
 import ctypes
 
 import numpy as np
@@ -15,6 +16,7 @@ def names_to_pair(name0, name1):  # it_loc/matcher.py:20-21, hloc/utils/parsers.
 
 
 confs = {  # it_loc/matcher.py:24-82 (the entries that do not need external nets)
+    'NNML': {'output': 'NNML', 'model': {'name': 'nnml', 'do_mutual_check': True, 'distance_threshold': None}},
     'NNM': {'output': 'NNM', 'model': {'name': 'nnm', 'do_mutual_check': True, 'distance_threshold': None}},
     'NNR': {'output': 'NNR', 'model': {'name': 'nnr', 'do_mutual_check': True, 'distance_threshold': 0.9}},
 }
@@ -24,8 +26,8 @@ class Matcher:
     def __init__(self, conf):
         self.conf = conf
         self.mode = conf['model']['name']
-        if self.mode not in ('nnm', 'nnr'):
-            raise NotImplementedError(f"matcher mode {self.mode!r}: only 'nnm' and 'nnr' are on the hot path")
+        if self.mode not in ('nnm', 'nnr', 'nnml'):
+            raise NotImplementedError(f"matcher mode {self.mode!r}: 'nnm', 'nnr' and 'nnml' are implemented")
         self.sim_mode = conf['model'].get('sim_mode', 'f16')
         self._device = 0
 
@@ -38,13 +40,14 @@ class Matcher:
         return self
 
     def _conf(self):
-        flavour = _lib.MATCH_ITLOC_NNM if self.mode == 'nnm' else _lib.MATCH_ITLOC_NNR
+        flavour = _lib.MATCH_ITLOC_NNR if self.mode == 'nnr' else _lib.MATCH_ITLOC_NNM
         ratio = float(self.conf['model'].get('distance_threshold') or 0.0)
         return _lib.MatchConf(flavour, 1, ratio, 0.0, _lib.SIM_F16X2 if self.sim_mode == 'f16x2' else _lib.SIM_F16)
 
-    def forward(self, data):
-        d0 = np.ascontiguousarray(data['descriptors0'])
-        d1 = np.ascontiguousarray(data['descriptors1'])
+    def _match(self, d0, d1):
+        """One device call: (matches0 [n0] int64, top-1 similarity [n0] f32) in the mode's flavour."""
+        d0 = np.ascontiguousarray(d0)
+        d1 = np.ascontiguousarray(d1)
         dt = {np.dtype(np.float64): _lib.DT_F64, np.dtype(np.float32): _lib.DT_F32, np.dtype(np.float16): _lib.DT_F16}
         if d0.dtype not in dt or d1.dtype != d0.dtype:
             d0, d1 = d0.astype(np.float64), d1.astype(np.float64)
@@ -56,6 +59,40 @@ class Matcher:
         conf = self._conf()
         _lib.check(ctx.lib.sfd2_match(ctx.h, d0.ctypes.data, n0, d1.ctypes.data, n1, dim, dt[d0.dtype], _lib.LAYOUT_ND,
                                       0, ctypes.byref(conf), m.ctypes.data, s.ctypes.data, 0))
+        return m, s
+
+    def matcher_with_label(self, descriptors1, labels1, descriptors2, labels2):
+        """it_loc/matcher.py:239-297.  Returns [M, 2] (index in 1, index in 2)."""
+        labels1, labels2 = np.asarray(labels1), np.asarray(labels2)
+        uids2 = set(np.unique(labels2).tolist())
+        valid_uids = [v for v in np.unique(labels1).tolist() if v in uids2 and v > 0]
+        all_matches = []
+        for uid in valid_uids:                                   # same-label mutual NN (:248-264)
+            idx1 = np.where(labels1 == uid)[0]
+            idx2 = np.where(labels2 == uid)[0]
+            m, _ = self._match(descriptors1[idx1], descriptors2[idx2])
+            for i in np.flatnonzero(m >= 0):
+                all_matches.append((int(idx1[i]), int(idx2[m[i]])))
+        matched1 = {a for a, _ in all_matches}
+        matched2 = {b for _, b in all_matches}
+        idx1 = np.array([i for i in range(descriptors1.shape[0]) if i not in matched1], dtype=np.int64)
+        idx2 = np.array([i for i in range(descriptors2.shape[0]) if i not in matched2], dtype=np.int64)
+        if len(idx1) and len(idx2):                              # mutual NN among the rest (:266-293)
+            m, _ = self._match(descriptors1[idx1], descriptors2[idx2])
+            for i in np.flatnonzero(m >= 0):
+                all_matches.append((int(idx1[i]), int(idx2[m[i]])))
+        return np.array(all_matches, dtype=int).reshape(-1, 2)
+
+    def forward(self, data):
+        if self.mode == 'nnml':
+            d0, d1 = np.asarray(data['descriptors0']), np.asarray(data['descriptors1'])
+            pairs = self.matcher_with_label(d0, data['labels0'], d1, data['labels1'])
+            all_matches = np.ones((d0.shape[0],), dtype=int) * -1
+            for a, b in pairs:
+                all_matches[a] = b
+            _, s = self._match(d0, d1)                           # scores: top-1 similarity over ALL of image 2 (:111)
+            return {'matches0': all_matches, 'matching_scores0': s.astype(np.float64)}
+        m, s = self._match(data['descriptors0'], data['descriptors1'])
         return {'matches0': m, 'matching_scores0': s.astype(np.float64)}
 
     __call__ = forward

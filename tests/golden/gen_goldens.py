@@ -198,6 +198,30 @@ def gen_extract_ms(model, h, w, seed, topk, scales, tag):
     print(f"extract_ms_{tag}: N={len(sc)} scales={list(scales)}")
 
 
+def make_mask(h, w, seed):
+    """Synthetic instance mask (cv2 BGR uint8): 16-px blocks, ~40 % unlabelled (black), labels spread over the three bytes."""
+    rs = np.random.RandomState(seed)
+    gh, gw = (h + 15) // 16, (w + 15) // 16
+    ids = rs.randint(1, 9, (gh, gw)) * (rs.random_sample((gh, gw)) > 0.4)
+    pal = np.array([[0, 0, 0]] + [[(37 * i) % 256, (91 * i) % 7, i % 3] for i in range(1, 9)], dtype=np.uint8)
+    return np.repeat(np.repeat(pal[ids], 16, axis=0), 16, axis=1)[:h, :w].copy()
+
+
+def gen_extract_mask(model, h, w, seed, topk, tag):
+    """G4c: the semantic-mask selection branch of extract_resnet_return (nets/extractor.py:240-319)."""
+    for name in ("float", "int"):
+        if not hasattr(np, name):           # the reference still spells np.float / np.int there
+            setattr(np, name, {"float": float, "int": int}[name])
+    img = synth.make_image(h, w, seed)
+    mask = make_mask(h, w, seed + 1000)
+    pred = ref_ext.extract_resnet_return(model, img=torch.from_numpy(img)[None], topK=topk, mask=mask, conf_th=0.001, scales=[1.0])
+    out = {"h": h, "w": w, "seed": seed, "topk": topk, "mask": mask,
+           "keypoints": pred["keypoints"].astype(np.float32), "scores": pred["scores"].astype(np.float32),
+           "descriptors": pred["descriptors"].astype(np.float16), "labels": pred["labels"].astype(np.int32)}
+    np.savez_compressed(os.path.join(HERE, f"extract_mask_{tag}.npz"), **out)
+    print(f"extract_mask_{tag}: N={len(pred['scores'])} labelled={int((pred['labels'] != 0).sum())}")
+
+
 def gen_extract_spp(model, h, w, seed, conf_th, tag):
     """G5: extract.py nms_fast (:17-84) and extract_spp_feats_singlescale (:205-277)."""
     img = synth.make_image(h, w, seed)
@@ -256,6 +280,20 @@ def gen_matchers():
                                                       "descriptors1": d1.astype(np.float64)})
             out[f"{tag}/itloc/{name}/matches0"] = np.asarray(pred["matches0"]).astype(np.int64)
             out[f"{tag}/itloc/{name}/scores0"] = np.asarray(pred["matching_scores0"]).astype(np.float64)
+        # label-aware matcher (it_loc/matcher.py:239-297); the reference still spells np.int there
+        if not hasattr(np, "int"):
+            np.int = int
+        rl = np.random.RandomState(90 + s0)
+        l0 = rl.randint(0, 6, n0).astype(np.int32)
+        l1 = rl.randint(0, 6, n1).astype(np.int32)
+        l1[dst] = l0[src]                     # the planted pairs mostly share their label
+        flip = rl.random_sample(k) < 0.2
+        l1[dst[flip]] = rl.randint(0, 6, int(flip.sum()))
+        pred = Matcher({"output": "NNML", "model": {"name": "nnml"}}).eval()(
+            {"descriptors0": d0.astype(np.float64), "descriptors1": d1.astype(np.float64), "labels0": l0, "labels1": l1})
+        out[f"{tag}/labels0"], out[f"{tag}/labels1"] = l0, l1
+        out[f"{tag}/itloc/NNML/matches0"] = np.asarray(pred["matches0"]).astype(np.int64)
+        out[f"{tag}/itloc/NNML/scores0"] = np.asarray(pred["matching_scores0"]).astype(np.float64)
     np.savez_compressed(os.path.join(HERE, "matchers.npz"), **out)
     print("matchers:", {k: (int((v >= 0).sum()) if v.ndim else v) for k, v in out.items() if k.endswith("matches0")})
 
@@ -290,6 +328,14 @@ if __name__ == "__main__":
     gen_extract_ms(model, 96, 128, 21, 150, [1.0, 0.5], "96x128_k150")
     gen_extract_ms(model, 100, 130, 22, -1, [1.2, 1.0, 0.6], "100x130_all")
     if len(sys.argv) > 1 and sys.argv[1] == "ms":
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mask":
+        gen_extract_mask(model, 96, 128, 21, 120, "96x128_k120")      # topK <= labelled
+        gen_extract_mask(model, 96, 128, 21, 180, "96x128_k180")      # labelled < topK < all
+        gen_extract_mask(model, 100, 130, 22, 5000, "100x130_k5000")  # topK >= all
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "matchers":
+        gen_matchers()
         sys.exit(0)
     gen_det(model, 64, 96, 11, "64x96")
     gen_det(model, 100, 130, 12, "100x130")

@@ -805,3 +805,37 @@ def test_hipgraph_capture_replay_matches_eager(model):
     step()        # eager calls keep working after the capture
     ctx.sync()
     assert torch.equal(mt, want[3])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_itloc_label_matcher_vs_reference_golden(golden_dir, tag):
+    """Matcher mode 'nnml' (it_loc/matcher.py:239-297): every per-label and rest-set mutual NN on the
+    device, grouping on the host as in the reference."""
+    from sfd2_amd.matcher import Matcher
+    g = _load(golden_dir, "matchers.npz")
+    mt = Matcher({"output": "NNML", "model": {"name": "nnml", "sim_mode": "f16x2"}}).eval().cuda()
+    pred = mt({"descriptors0": g[f"{tag}/d0"].astype(np.float64), "descriptors1": g[f"{tag}/d1"].astype(np.float64),
+               "labels0": g[f"{tag}/labels0"], "labels1": g[f"{tag}/labels1"]})
+    np.testing.assert_array_equal(pred["matches0"], g[f"{tag}/itloc/NNML/matches0"])
+    np.testing.assert_allclose(pred["matching_scores0"], g[f"{tag}/itloc/NNML/scores0"], atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["96x128_k120", "96x128_k180", "100x130_k5000"])
+def test_strict_extract_mask_branch_vs_reference_golden(model_f32, synth_sd, golden_dir, tag):
+    """extract_resnet_return(mask=...) (nets/extractor.py:240-319): every candidate from the device,
+    the labelled-first selection on the host as in the reference."""
+    from sfd2_amd.extractor import extract_resnet_return
+    g = _load(golden_dir, f"extract_mask_{tag}.npz")
+    img = synth.make_image(int(g["h"]), int(g["w"]), int(g["seed"]))
+    got = extract_resnet_return(model_f32, img[None], conf_th=0.001, mask=g["mask"], topK=int(g["topk"]), scales=[1.0])
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=int(g["topk"]), mask=g["mask"])
+    assert got["labels"].dtype == np.int32 and len(got["labels"]) == len(got["scores"])
+    for ref in (want, {"keypoints": g["keypoints"], "scores": g["scores"], "descriptors": g["descriptors"].astype(np.float64),
+                       "labels": g["labels"]}):
+        assert abs(len(got["scores"]) - len(ref["scores"])) <= 2
+        mine = {(float(x), float(y)): i for i, (x, y) in enumerate(got["keypoints"])}
+        rank = np.array([mine.get((float(x), float(y)), -1) for x, y in ref["keypoints"]])
+        found = rank >= 0
+        assert found.mean() >= 0.99
+        np.testing.assert_array_equal(got["labels"][rank[found]], np.asarray(ref["labels"])[found])
+        assert np.abs(rank[found] - np.flatnonzero(found)).max() <= 3

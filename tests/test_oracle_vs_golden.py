@@ -168,3 +168,27 @@ def test_oracle_uint8_ingest(synth_sd):
     b = orc.extract_resnet_return(synth_sd, f, topK=50)
     for k in a:
         np.testing.assert_array_equal(a[k], b[k])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_itloc_label_matcher_matches_reference(golden_dir, tag):
+    """it_loc/matcher.py:239-297 (mode 'nnml'): per-label mutual NN, then mutual NN among the unmatched rest."""
+    g = _load(golden_dir, "matchers.npz")
+    pred = orc.itloc_matcher_with_label(g[f"{tag}/d0"], g[f"{tag}/labels0"], g[f"{tag}/d1"], g[f"{tag}/labels1"])
+    np.testing.assert_array_equal(pred["matches0"], g[f"{tag}/itloc/NNML/matches0"])
+    np.testing.assert_allclose(pred["matching_scores0"], g[f"{tag}/itloc/NNML/scores0"], atol=1e-6)
+    plain = orc.itloc_matcher(g[f"{tag}/d0"], g[f"{tag}/d1"], "nnm")["matches0"]
+    assert (pred["matches0"] != plain).any()          # the labels do change the result on this fixture
+
+
+@pytest.mark.parametrize("tag", ["96x128_k120", "96x128_k180", "100x130_k5000"])
+def test_extract_mask_branch_matches_reference(golden_dir, synth_sd, tag):
+    """Semantic-mask selection (nets/extractor.py:240-319): topK <= labelled, labelled < topK < all, topK >= all."""
+    g = _load(golden_dir, f"extract_mask_{tag}.npz")
+    img = synth.make_image(int(g["h"]), int(g["w"]), int(g["seed"]))
+    pred = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=int(g["topk"]), mask=g["mask"])
+    assert len(pred["scores"]) == len(g["scores"])
+    np.testing.assert_array_equal(pred["labels"], g["labels"])
+    np.testing.assert_array_equal(pred["keypoints"], g["keypoints"].astype(np.float64))
+    np.testing.assert_allclose(pred["scores"], g["scores"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(pred["descriptors"], g["descriptors"].astype(np.float64), atol=2e-3)
