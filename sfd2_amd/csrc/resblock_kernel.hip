@@ -146,7 +146,9 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
                 if (inside)
                     v = rb_cvt4(fmaxf(acc0[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc0[4 * q + 1] * s.y + h.y, 0.0f),
                                 fmaxf(acc0[4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc0[4 * q + 3] * s.w + h.w, 0.0f));
-                *reinterpret_cast<h4_t *>(t1w + (((c0 >> 3) ^ n) << 4) + (c0 & 4) * 2) = v;
+                // t1 slot of channel c: (c >> 4) + 16 * ((c >> 3) & 1) -- the two 8-channel groups of a pair sit 256 B apart, so
+                // the 16 lanes of a ds_read_b128 lane group of the grouped conv (two groups x 8 pixels) hit 16 distinct banks
+                *reinterpret_cast<h4_t *>(t1w + ((((c0 >> 4) + 16 * ((c0 >> 3) & 1)) ^ n) << 4) + (c0 & 4) * 2) = v;
             }
         }
         const int y = r - 1;                  // the output row this iteration finishes
@@ -176,7 +178,7 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
                     for (int tt = 0; tt < 2; ++tt) {
                         int p = tt * 16 + lcol + kx - 1;
                         p = p < 0 ? 0 : (p > 31 ? 31 : p);   // strip pixels 0 and 31 are halo: their outputs are not used
-                        const h8_t b = *reinterpret_cast<const h8_t *>(trow + p * 512 + (((2 * P + (g & 1)) ^ p) << 4));
+                        const h8_t b = *reinterpret_cast<const h8_t *>(trow + p * 512 + (((P + 16 * (g & 1)) ^ p) << 4));
                         acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, b, acc[tt], 0, 0, 0);
                     }
                 }
