@@ -96,9 +96,12 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         if (WBUF == 3 && chunk >= XCH) chunk = XCH - 1;   // every wave issues XPW copies (the waits count them): duplicates of the last chunk
         const int q = chunk * RPC + lane / SPR;
         const int slot = (lane % SPR) ^ ((q >> SWS) & (SPR - 1));  // logical 16-byte slot this lane's bytes hold
+        // stride 2: records are stored pair-swapped where bit 4 of the index is set, so that the B-fragment reads (lanes two
+        // records apart) alternate between the halves of the bank space instead of all landing in one (2-way conflicts)
+        const int ql = (STRIDE == 2) ? (q ^ ((q >> 4) & 1)) : q;   // logical record held at physical position q
         int off = -1;
-        if (chunk < XCH && q < NPIX) {
-            const int py = q / PW, px = q - py * PW;
+        if (chunk < XCH && ql < NPIX) {
+            const int py = ql / PW, px = ql - py * PW;
             const int iy = oy0 * STRIDE - PAD + py, ix = ox0 * STRIDE - PAD + px;
             if (iy >= 0 && iy < H && ix >= 0 && ix < W) off = (iy * W + ix) * Cin + slot * 8;
         }
@@ -189,7 +192,8 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         int b_off[PX_T], b_sw[PX_T];
 #pragma unroll
         for (int pr = 0; pr < PX_T; ++pr) {
-            const int q = ((wrow + pr) * STRIDE + ky) * PW + lrow * STRIDE + kx;
+            int q = ((wrow + pr) * STRIDE + ky) * PW + lrow * STRIDE + kx;
+            if (STRIDE == 2) q ^= (q >> 4) & 1;                    // physical position of the record
             b_off[pr] = q * RB;
             b_sw[pr] = (q >> SWS) & (SPR - 1);
         }

@@ -165,7 +165,9 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
                         if (inside)
                             v = f_cvt4(fmaxf(acc[ct][4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc[ct][4 * q + 1] * s.y + h.y, 0.0f),
                                        fmaxf(acc[ct][4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc[ct][4 * q + 3] * s.w + h.w, 0.0f));
-                        *reinterpret_cast<h4_t *>(X1 + p * 128 + (((c0 >> 3) ^ sw) << 4) + (c0 & 4) * 2) = v;
+                        // records are stored pair-swapped where bit 4 of the index is set: the stride-2 reads of phase 2
+                        // (lanes 256 B apart) then alternate between the two 128-byte halves of the bank space
+                        *reinterpret_cast<h4_t *>(X1 + (p ^ ((p >> 4) & 1)) * 128 + (((c0 >> 3) ^ sw) << 4) + (c0 & 4) * 2) = v;
                     }
             }
         }
@@ -185,7 +187,7 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
             const int q = (2 * orow + ky) * F_RW + 2 * lrow + kx;
-            const unsigned char *xq = X1 + q * 128;
+            const unsigned char *xq = X1 + (q ^ ((q >> 4) & 1)) * 128;
             const int bsw = (q >> 1) & 7;
             const unsigned char *wt = Wt + tap * 8192;
 #pragma unroll
