@@ -72,7 +72,12 @@ def main():
     ap.add_argument("--dump-layers", action="store_true", help="per-layer device times to stderr")
     ap.add_argument("--streams", type=int, default=1, help="contexts (HIP streams) per GPU processing different images concurrently")
     ap.add_argument("--no-profile", action="store_true", help="experiment: no per-launch events in the timed region")
+    ap.add_argument("--size", default=None, help="WxH of the synthetic query images (default 1600x1200, the size the metric "
+                                                 "is quoted on; e.g. 1024x1024 for BASELINE configs[3])")
     args = ap.parse_args()
+    global H, W
+    if args.size:
+        W, H = (int(v) for v in args.size.lower().split("x"))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -224,7 +229,7 @@ def main():
                       f"{r['bytes']/1e6:8.1f} MB {gb:8.0f} GB/s", file=sys.stderr)
         breakdown = {k: round(v["ms"] / 3, 4) for k, v in sorted(fam_all.items(), key=lambda kv: -kv[1]["ms"])}
         out = {
-            "metric": "images/sec extract" + ("" if args.extract_only else "+match") + " (1600x1200, n4096)",
+            "metric": "images/sec extract" + ("" if args.extract_only else "+match") + f" ({W}x{H}, n4096)",
             "value": round(args.steps * world / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
