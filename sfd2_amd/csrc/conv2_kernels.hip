@@ -35,7 +35,7 @@ __device__ __forceinline__ h4_t cvt4b(float a, float b, float c, float d)
     return r;
 }
 
-template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0, int WBUF = 2>
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0, int WBUF = 2, int TPS = 1>
 __global__ __launch_bounds__(NW * 64, (XBUF == 1 && BN == 128 && STRIDE == 1) ? 4 : ((NW == 8 || ROWS != 0) ? 2 : 1))
 void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                         const half_t *__restrict__ wpk, const float *__restrict__ scale,
@@ -54,9 +54,11 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     constexpr int SWS = (CC == 32) ? 2 : 1;            // swizzle: slot ^= (record >> SWS) & (SPR - 1)
     constexpr int XCH = (NPIX + RPC - 1) / RPC;        // 1 KB chunks of one patch
     constexpr int XPW = (XCH + NW - 1) / NW;           // chunks per wave
-    constexpr int WCH = BN / RPC;                      // 1 KB chunks of one filter tile
+    // TPS = filter taps per pipeline stage (1, or 3 = one filter row: a third fewer barriers, 48 MFMAs per wave between them)
+    static_assert(TPS == 1 || (TPS == 3 && KS == 3 && XBUF == 2 && WBUF == 2), "TPS = 3 is for the 3x3 two-buffer pipeline");
+    constexpr int WCH = TPS * BN / RPC;                // 1 KB chunks of one stage's filter tiles
     constexpr int WPW = WCH / NW;                      // per wave
-    constexpr int XBYTES = XCH * 1024, WBYTES = BN * RB;
+    constexpr int XBYTES = XCH * 1024, WBYTES = TPS * BN * RB;
     constexpr int WAVES_CH = 2, WAVES_PX = NW / 2;   // (4 x 2 and s_setprio around the MFMA bursts measured no better)
     constexpr int CH_T = BN / WAVES_CH / 32;           // 2 or 4
     constexpr int PX_T = THT / WAVES_PX;               // image rows per wave (2 or 1)
@@ -110,9 +112,9 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     int woff[WPW];
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-        const int r = (wave * WPW + i) * RPC + lane / SPR;
+        const int r = (wave * WPW + i) * RPC + lane / SPR;     // row of the stage tile: tap (r / BN), filter (r % BN)
         const int slot = (lane % SPR) ^ ((r >> SWS) & (SPR - 1));
-        woff[i] = (n0 + r) * CC + slot * 8;
+        woff[i] = ((r / BN) * CoutP + n0 + (r % BN)) * CC + slot * 8;
     }
 
 #define ISSUE_X(chunk_, buf_)                                                                          \
@@ -126,7 +128,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     }
 #define ISSUE_W(step_, buf_)                                                                           \
     _Pragma("unroll") for (int i = 0; i < (ABL == 4 ? 0 : WPW); ++i) {                                 \
-        const half_t *src = wpk + (size_t)(step_)*CoutP * CC + woff[i];                                \
+        const half_t *src = wpk + (size_t)(step_)*TPS * CoutP * CC + woff[i];                          \
         __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                            \
                                          (lds_void_t *)(Ws + (buf_)*WBYTES + (wave * WPW + i) * 1024), 16, 0, 0); \
     }
@@ -139,7 +141,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    const int NS = (Cin / CC) * T;
+    const int NS = (Cin / CC) * (T / TPS);             // pipeline stages
     // barrier that lets the XPW most recently issued copies (the chunk two steps ahead) stay in flight
 #define BARRIER_KEEP_X() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XPW) : "memory")
 #define BARRIER_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -170,7 +172,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     int chunk = 0, tap = 0;
     for (int s = 0; s < NS; ++s) {
         const int wb = (WBUF == 3) ? (s % 3) : (s & 1), xb = (XBUF == 3) ? (chunk % 3) : ((XBUF == 2) ? (chunk & 1) : 0);
-        int ntap = tap + 1, nchunk = chunk;
+        int ntap = tap + TPS, nchunk = chunk;
         if (ntap == T) { ntap = 0; ++nchunk; }
         const bool has_next = (s + 1 < NS);
         const bool new_chunk = has_next && (ntap == 0);
@@ -186,49 +188,52 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         }
         if (XBUF == 3 && s + 2 < NS) { ISSUE_X(s + 2, (s + 2) % 3) }   // after W(s + 1): the counted wait keeps exactly these
 
-        const int ky = tap / KS, kx = tap - ky * KS;
-        const unsigned char *xs = Xs + xb * XBYTES;
-        const unsigned char *ws = Ws + wb * WBYTES;
-        int b_off[PX_T], b_sw[PX_T];
 #pragma unroll
-        for (int pr = 0; pr < PX_T; ++pr) {
-            int q = ((wrow + pr) * STRIDE + ky) * PW + lrow * STRIDE + kx;
-            if (STRIDE == 2) q ^= (q >> 4) & 1;                    // physical position of the record
-            b_off[pr] = q * RB;
-            b_sw[pr] = (q >> SWS) & (SPR - 1);
-        }
-        // software-pipelined fragment reads: the ds_reads of k-slice kk+1 are in flight while the
-        // MFMAs of slice kk issue (two register sets, static indices)
-        constexpr int NK = (ABL == 1) ? 0 : CC / 16;
-        h8_t fa[2][CH_T], fb[2][PX_T];
+        for (int t3 = 0; t3 < TPS; ++t3) {
+            const int ky = (tap + t3) / KS, kx = (tap + t3) - ky * KS;
+            const unsigned char *xs = Xs + xb * XBYTES;
+            const unsigned char *ws = Ws + wb * WBYTES + t3 * (BN * RB);
+            int b_off[PX_T], b_sw[PX_T];
 #pragma unroll
-        for (int ct = 0; ct < CH_T; ++ct)
-            fa[0][ct] = *reinterpret_cast<const h8_t *>(ws + a_off[ct] + ((lhi ^ a_sw[ct]) << 4));
-#pragma unroll
-        for (int pr = 0; pr < PX_T; ++pr)
-            fb[0][pr] = *reinterpret_cast<const h8_t *>(xs + b_off[pr] + ((lhi ^ b_sw[pr]) << 4));
-        // pin the issue order (hipcc otherwise sinks every read next to its first use and waits
-        // lgkmcnt(0) in front of each MFMA group): reads of slice kk+1, then the MFMAs of slice kk
-        __builtin_amdgcn_sched_group_barrier(0x100, CH_T + PX_T, 0);
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-            const int cur = kk & 1, nxt = cur ^ 1;
-            if (kk + 1 < NK) {
-                const int slot = (kk + 1) * 2 + lhi;
-#pragma unroll
-                for (int ct = 0; ct < CH_T; ++ct)
-                    fa[nxt][ct] = *reinterpret_cast<const h8_t *>(ws + a_off[ct] + ((slot ^ a_sw[ct]) << 4));
-#pragma unroll
-                for (int pr = 0; pr < PX_T; ++pr)
-                    fb[nxt][pr] = *reinterpret_cast<const h8_t *>(xs + b_off[pr] + ((slot ^ b_sw[pr]) << 4));
+            for (int pr = 0; pr < PX_T; ++pr) {
+                int q = ((wrow + pr) * STRIDE + ky) * PW + lrow * STRIDE + kx;
+                if (STRIDE == 2) q ^= (q >> 4) & 1;                    // physical position of the record
+                b_off[pr] = q * RB;
+                b_sw[pr] = (q >> SWS) & (SPR - 1);
             }
+            // software-pipelined fragment reads: the ds_reads of k-slice kk+1 are in flight while the
+            // MFMAs of slice kk issue (two register sets, static indices)
+            constexpr int NK = (ABL == 1) ? 0 : CC / 16;
+            h8_t fa[2][CH_T], fb[2][PX_T];
 #pragma unroll
             for (int ct = 0; ct < CH_T; ++ct)
+                fa[0][ct] = *reinterpret_cast<const h8_t *>(ws + a_off[ct] + ((lhi ^ a_sw[ct]) << 4));
 #pragma unroll
-                for (int pr = 0; pr < PX_T; ++pr)
-                    acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][ct], fb[cur][pr], acc[ct][pr], 0, 0, 0);
-            if (kk + 1 < NK) __builtin_amdgcn_sched_group_barrier(0x100, CH_T + PX_T, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, CH_T * PX_T, 0);
+            for (int pr = 0; pr < PX_T; ++pr)
+                fb[0][pr] = *reinterpret_cast<const h8_t *>(xs + b_off[pr] + ((lhi ^ b_sw[pr]) << 4));
+            // pin the issue order (hipcc otherwise sinks every read next to its first use and waits
+            // lgkmcnt(0) in front of each MFMA group): reads of slice kk+1, then the MFMAs of slice kk
+            __builtin_amdgcn_sched_group_barrier(0x100, CH_T + PX_T, 0);
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk + 1 < NK) {
+                    const int slot = (kk + 1) * 2 + lhi;
+#pragma unroll
+                    for (int ct = 0; ct < CH_T; ++ct)
+                        fa[nxt][ct] = *reinterpret_cast<const h8_t *>(ws + a_off[ct] + ((slot ^ a_sw[ct]) << 4));
+#pragma unroll
+                    for (int pr = 0; pr < PX_T; ++pr)
+                        fb[nxt][pr] = *reinterpret_cast<const h8_t *>(xs + b_off[pr] + ((slot ^ b_sw[pr]) << 4));
+                }
+#pragma unroll
+                for (int ct = 0; ct < CH_T; ++ct)
+#pragma unroll
+                    for (int pr = 0; pr < PX_T; ++pr)
+                        acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][ct], fb[cur][pr], acc[ct][pr], 0, 0, 0);
+                if (kk + 1 < NK) __builtin_amdgcn_sched_group_barrier(0x100, CH_T + PX_T, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, CH_T * PX_T, 0);
+            }
         }
         if (XBUF == 3) {
             if (s + 2 < NS) BARRIER_KEEP_X(); else BARRIER_DRAIN();
@@ -329,7 +334,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     }
 }
 
-template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0, int WBUF = 2>
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0, int WBUF = 2, int TPS = 1>
 static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                             const float *scale, const float *shift, int CoutP, int relu, const half_t *res,
                             void *out, int Ho, int Wo, const half_t *zero_page)
@@ -339,9 +344,9 @@ static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int 
     constexpr int RPC = 1024 / (CC * 2);
     constexpr int XCH = (PH * PW + RPC - 1) / RPC;
     constexpr bool SS_LDS = !(XBUF == 3 && BN == 256 && CC == 64);
-    constexpr size_t lds = (size_t)XBUF * XCH * 1024 + (size_t)WBUF * BN * CC * 2 + (SS_LDS ? (size_t)2 * BN * sizeof(float) : 0);
+    constexpr size_t lds = (size_t)XBUF * XCH * 1024 + (size_t)WBUF * TPS * BN * CC * 2 + (SS_LDS ? (size_t)2 * BN * sizeof(float) : 0);
     static bool attr_done = false;
-    auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES, NW, ROWS, XBUF, ABL, WBUF>;
+    auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES, NW, ROWS, XBUF, ABL, WBUF, TPS>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
@@ -363,8 +368,8 @@ int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin)
     static const bool bn128 = getenv("SFD2_CONV_BN128") != nullptr;   // experiment: 128-channel tiles everywhere
     static const bool small1 = getenv("SFD2_CONV_1X1_SMALL") != nullptr;   // experiment: 4-wave 4x32 tiles for 1x1
     if (small1 && ks == 1 && CoutP % 256 == 0) return 32;
-    static const bool w3 = getenv("SFD2_CONV_WRING") != nullptr;   // experiment: 32-wide chunks + three-tile filter ring for 3x3 256-ch layers
-    if (w3 && ks == 3 && CoutP % 256 == 0) return 32;
+    static const bool w3 = getenv("SFD2_CONV_WRING") != nullptr || getenv("SFD2_CONV_TPS3") != nullptr;   // experiments on 32-wide chunks
+    if (w3 && ks == 3 && stride == 1 && CoutP % 256 == 0) return 32;
     if (CoutP % 256 == 0 && !bn128) return (Cin % 64 == 0) ? 64 : 32;
     // conv2a (64 -> 128): the whole K of a tap row fits one 64-wide chunk, so the patch is staged once (XBUF = 1,
     // 76 KB of LDS, two blocks per CU) and the 9 steps carry 16 MFMAs each instead of 18 steps of 8
@@ -416,6 +421,11 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
     if (small1 && ks == 1 && !out_f32 && bn == 256 && cc == 32) {
         if (residual) launch_igemm2_t<1, 1, 256, 32, false, true, 4, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         else launch_igemm2_t<1, 1, 256, 32, false, false, 4, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
+        return true;
+    }
+    static const bool tps3 = getenv("SFD2_CONV_TPS3") != nullptr;   // experiment: one filter ROW (3 taps) per pipeline stage
+    if (tps3 && ks == 3 && !out_f32 && bn == 256 && cc == 32 && !residual) {
+        launch_igemm2_t<3, 1, 256, 32, false, false, 8, 0, 2, 0, 2, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         return true;
     }
     static const bool w3 = getenv("SFD2_CONV_WRING") != nullptr;
