@@ -158,7 +158,7 @@ def main():
     sync_all()
     n_kp = ctypes.c_int(0)
     _lib.check(lib.sfd2_extract_count(ctx.h, ctypes.byref(n_kp)))
-    if n_kp.value != TOPK:
+    if n_kp.value != TOPK and not os.environ.get("SFD2_BENCH_ALLOW_FEW"):   # (timing ablations produce garbage images)
         raise SystemExit(f"synthetic image yielded {n_kp.value} < {TOPK} key points; the match leg assumes {TOPK}")
 
     def dominant_family(rows):

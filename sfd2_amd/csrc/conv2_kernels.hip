@@ -119,7 +119,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 
 #define ISSUE_X(chunk_, buf_)                                                                          \
     _Pragma("unroll") for (int i = 0; i < XPW; ++i) {                                                  \
-        if (ABL != 3 && (WBUF == 3 || wave + NW * i < XCH)) {                                          \
+        if (ABL != 3 && !(ABL == 7 && (chunk_) != 0) && (WBUF == 3 || wave + NW * i < XCH)) {           \
             const int xc = (WBUF == 3 && wave + NW * i >= XCH) ? XCH - 1 : wave + NW * i;              \
             const half_t *src = xoff[i] >= 0 ? in + (size_t)xoff[i] + (chunk_)*CC : zero_page + (lane % SPR) * 8; \
             __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                        \
@@ -127,7 +127,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         }                                                                                              \
     }
 #define ISSUE_W(step_, buf_)                                                                           \
-    _Pragma("unroll") for (int i = 0; i < (ABL == 4 ? 0 : WPW); ++i) {                                 \
+    _Pragma("unroll") for (int i = 0; i < ((ABL == 4 || (ABL == 7 && (step_) != 0)) ? 0 : WPW); ++i) { \
         const half_t *src = wpk + (size_t)(step_)*TPS * CoutP * CC + woff[i];                          \
         __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                            \
                                          (lds_void_t *)(Ws + (buf_)*WBYTES + (wave * WPW + i) * 1024), 16, 0, 0); \
@@ -217,7 +217,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
             for (int kk = 0; kk < NK; ++kk) {
                 const int cur = kk & 1, nxt = cur ^ 1;
-                if (kk + 1 < NK) {
+                if (kk + 1 < NK && ABL != 5) {   // ABL 5 (timing ablation): MFMAs on the first slice's fragments only
                     const int slot = (kk + 1) * 2 + lhi;
 #pragma unroll
                     for (int ct = 0; ct < CH_T; ++ct)
@@ -229,8 +229,13 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
                 for (int ct = 0; ct < CH_T; ++ct)
 #pragma unroll
-                    for (int pr = 0; pr < PX_T; ++pr)
-                        acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][ct], fb[cur][pr], acc[ct][pr], 0, 0, 0);
+                    for (int pr = 0; pr < PX_T; ++pr) {
+                        if (ABL == 6) {   // timing ablation: fragment reads without the MFMAs
+                            acc[ct][pr][0] += (float)fa[cur][ct][0] + (float)fb[cur][pr][0];
+                        } else {
+                            acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][ct], fb[cur][pr], acc[ct][pr], 0, 0, 0);
+                        }
+                    }
                 if (kk + 1 < NK) __builtin_amdgcn_sched_group_barrier(0x100, CH_T + PX_T, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, CH_T * PX_T, 0);
             }
@@ -422,6 +427,14 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
         if (residual) launch_igemm2_t<1, 1, 256, 32, false, true, 4, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         else launch_igemm2_t<1, 1, 256, 32, false, false, 4, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         return true;
+    }
+    if (const char *ab = getenv("SFD2_CONV_3X3_ABLATE")) {   // timing ablations of the dominant kernel (wrong results)
+        if (ks == 3 && !out_f32 && bn == 256 && cc == 64 && !residual) {
+            if (ab[0] == '5') { launch_igemm2_t<3, 1, 256, 64, false, false, 8, 0, 2, 5>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); return true; }
+            if (ab[0] == '6') { launch_igemm2_t<3, 1, 256, 64, false, false, 8, 0, 2, 6>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); return true; }
+            if (ab[0] == '7') { launch_igemm2_t<3, 1, 256, 64, false, false, 8, 0, 2, 7>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); return true; }
+            if (ab[0] == '1') { launch_igemm2_t<3, 1, 256, 64, false, false, 8, 0, 2, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); return true; }
+        }
     }
     static const bool tps3 = getenv("SFD2_CONV_TPS3") != nullptr;   // experiment: one filter ROW (3 taps) per pipeline stage
     if (tps3 && ks == 3 && !out_f32 && bn == 256 && cc == 32 && !residual) {
