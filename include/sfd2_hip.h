@@ -96,6 +96,18 @@ int sfd2_load_weights(sfd2_ctx *ctx, const sfd2_tensor *tensors, int n);
 #define SFD2_PREC_F32 1
 int sfd2_set_precision(sfd2_ctx *ctx, int mode);
 
+/* Execution options of a context (the reference has none: its layers are stock torch modules).
+ *   "fuse"      1 (default): sfd2_extract runs the fused kernels (stem, ResBlocks) over the aliased
+ *               activation arena; 0: one kernel per layer, private buffers.
+ *   "fuse_det"  0 (default): sfd2_det keeps every intermediate activation readable through
+ *               sfd2_debug_activation; 1: sfd2_det runs the throughput path's fused kernels on private
+ *               buffers (conv1a, conv4.b.bn1 / bn2 are then not materialised) -- how the parity tests
+ *               reach the kernels sfd2_extract uses.
+ *   "alias"     1 (default): the throughput path packs activations into the three-slot arena.
+ *   "graphs"    0 (default) / 1: sfd2_extract_match (below) replays a cached hipGraph per geometry.
+ * Unknown keys are an error. */
+int sfd2_set_option(sfd2_ctx *ctx, const char *key, int value);
+
 /* ResSegNetV2.det (nets/sfd2.py:313-354).  x: [3][H][W] fp32, normalised image
  * (pass SFD2_FLAG_IMG_NORMALISED) or raw [0,1] RGB (normalised on the fly).
  * score [8*H8][8*W8], stability [H][W], desc [128][Hc][Wc] (L2-normalised), fp32.
@@ -125,6 +137,15 @@ int sfd2_extract_multiscale(sfd2_ctx *ctx, const void *img, int img_on_device, i
                             const double *scales, int n_scales, float conf_th, int top_k, int flags,
                             float *kpts_xy, float *scores, float *desc, int out_on_device,
                             int64_t cap_out, int *n_out);
+
+/* The decoder's uint8 image to the network's input, ImageDataset.__getitem__ (extract_localization.py:168-186):
+ * astype(float32) -> cv2.resize(..., (new_w, new_h), INTER_CUBIC) when the size changes (the caller applies the
+ * resize_max / resize_force rule of :172-177) -> HWC to CHW -> / 255.  img_hwc uint8 [H][W][3] (SFD2_FLAG_IMG_BGR:
+ * cv2.imread order), host or device; out_chw_dev fp32 [3][new_h][new_w] on the device, ready for sfd2_extract.
+ * The cubic kernel restates OpenCV's published float32 algorithm (a = -0.75, replicated border, horizontal
+ * pass first); cv2 is not available to pin it against -- see oracle/oracle.py cv2_resize_cubic. */
+int sfd2_preprocess(sfd2_ctx *ctx, const unsigned char *img_hwc, int on_device, int H, int W, int flags,
+                    int new_h, int new_w, float *out_chw_dev);
 
 /* After an SFD2_FLAG_ASYNC extract: number of key points, once the stream is idle. */
 int sfd2_extract_count(sfd2_ctx *ctx, int *n_out);
@@ -190,6 +211,18 @@ typedef struct {
 int sfd2_match_batch(sfd2_ctx *ctx, const sfd2_desc_set *q, const sfd2_desc_set *db, int k, int dim,
                      const sfd2_match_conf *conf, int64_t *matches0, float *scores0, int out_on_device,
                      int flags);
+
+/* One query unit as pure stream work: sfd2_extract (SFD2_FLAG_ASYNC semantics, device-resident image
+ * and outputs, capacity top_k > 0) followed by sfd2_match_batch of the top_k descriptor rows against k
+ * device-resident database sets -- the per-query body of the localiser (it_loc/localizer.py:87 ->
+ * localize_cv2.py:705-715) with nothing returned to the host; the caller synchronises sfd2_get_stream().
+ * With sfd2_set_option("graphs", 1) the unit is captured into a hipGraph the second time a geometry
+ * (sizes, pointers, matcher conf) is seen and replayed afterwards; up to 16 geometries are cached per
+ * context (least recently used evicted), entries are dropped when the workspace is reallocated.
+ * k = 0 extracts only. */
+int sfd2_extract_match(sfd2_ctx *ctx, const void *img_dev, int H, int W, float conf_th, int top_k, int flags,
+                       float *kpts_xy, float *scores, float *desc, const sfd2_desc_set *db, int k, int dim,
+                       const sfd2_match_conf *conf, int64_t *matches0, float *scores0);
 
 int sfd2_get_timings(sfd2_ctx *ctx, sfd2_timings *out);
 

@@ -9,7 +9,16 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SFD2_LIB") or os.path.join(_HERE, "libsfd2hip.so")   # SFD2_LIB: kernel A/B experiments
+LIB_PATH = os.path.join(_HERE, "libsfd2hip.so")
+
+
+def use_library(path):
+    """Kernel A/B experiments (tools/): bind a differently built libsfd2hip before the first load().  An explicit call,
+    not an environment variable, so nothing outside the process can redirect the product to another binary."""
+    global LIB_PATH, _lib
+    if _lib is not None:
+        raise RuntimeError("use_library() must be called before the library is first loaded")
+    LIB_PATH = os.path.abspath(path)
 
 FLAG_ASYNC = 1
 FLAG_NO_STABILITY = 2
@@ -56,7 +65,7 @@ EXPORTS = [
     "sfd2_select_keypoints", "sfd2_sample_descriptors", "sfd2_heatmap", "sfd2_debug_activation",
     "sfd2_match", "sfd2_match_batch", "sfd2_get_timings", "sfd2_sync", "sfd2_set_profiling",
     "sfd2_get_layer_timings", "sfd2_set_precision", "sfd2_extract_spp", "sfd2_nms_fast",
-    "sfd2_set_profile_filter", "sfd2_extract_multiscale",
+    "sfd2_set_profile_filter", "sfd2_extract_multiscale", "sfd2_set_option", "sfd2_extract_match", "sfd2_preprocess",
 ]
 
 _lib = None
@@ -67,9 +76,16 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if LIB_PATH == os.path.join(_HERE, "libsfd2hip.so"):
+        # (re)build when the shared object is missing or older than its sources and a hipcc is at hand; on a box
+        # without hipcc the shipped .so is used as it is
+        from . import build as _build
+        if _build.needs_build() and _build.have_hipcc():
+            _build.build_lib()
     if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        raise RuntimeError(f"{LIB_PATH} is missing and no hipcc was found to build it "
+                           "(hipcc --offload-arch=gfx950; `python -c 'import __graft_entry__ as g; g.build()'`). "
+                           "There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci, cf, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
     pi = ctypes.POINTER(ctypes.c_int)
@@ -98,6 +114,10 @@ def load():
     lib.sfd2_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
     lib.sfd2_sync.argtypes = [vp]
     lib.sfd2_set_precision.argtypes = [vp, ci]
+    lib.sfd2_set_option.argtypes = [vp, ctypes.c_char_p, ci]
+    lib.sfd2_preprocess.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    lib.sfd2_extract_match.argtypes = [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, ctypes.POINTER(DescSet), ci, ci,
+                                       ctypes.POINTER(MatchConf), vp, vp]
     lib.sfd2_set_profiling.argtypes = [vp, ci]
     lib.sfd2_set_profile_filter.argtypes = [vp, ctypes.c_char_p]
     lib.sfd2_get_layer_timings.argtypes = [vp, ctypes.POINTER(LayerTiming), ci, pi]
@@ -177,6 +197,10 @@ class Context:
     def set_precision(self, mode):
         """'f16' (throughput mode, default) or 'f32' (strict parity mode)."""
         check(self.lib.sfd2_set_precision(self.h, {'f16': 0, 'f32': 1}[mode]))
+
+    def set_option(self, key, value):
+        """'fuse', 'fuse_det', 'alias', 'graphs' (include/sfd2_hip.h sfd2_set_option)."""
+        check(self.lib.sfd2_set_option(self.h, key.encode(), int(value)))
 
     def sync(self):
         check(self.lib.sfd2_sync(self.h))

@@ -14,29 +14,53 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build_lib(force=False, verbose=False):
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+def _hipcc():
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def have_hipcc():
+    return os.path.isfile(_hipcc()) and os.access(_hipcc(), os.X_OK)
+
+
+def needs_build():
+    """True when libsfd2hip.so is missing or older than any of its sources."""
+    if not os.path.exists(LIB):
+        return True
+    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "sfd2_internal.h"),
+                                                      os.path.join(HERE, "..", "include", "sfd2_hip.h")]
+    return any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs)
+
+
+def build_lib(force=False, verbose=False, out=None, extra_flags=()):
+    """out / extra_flags: experiment builds (e.g. -DSFD2_EXPERIMENTS into another .so); objects then go to a
+    side directory so the product objects are not disturbed."""
+    hipcc = _hipcc()
     objs = []
     deps = [os.path.join(CSRC, "sfd2_internal.h"), os.path.join(HERE, "..", "include", "sfd2_hip.h")]
     procs = []
+    lib = out or LIB
+    odir = CSRC
+    if out:
+        odir = os.path.join(os.path.dirname(os.path.abspath(out)), "obj_" + os.path.basename(out).replace(".", "_"))
+        os.makedirs(odir, exist_ok=True)
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(odir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(s, o) or any(_newer(d, o) for d in deps):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    if force or procs or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or procs or not os.path.exists(lib) or any(_newer(o, lib) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -370,15 +370,15 @@ int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin)
     if (stride != 1) return 0;
     // 256-channel tiles: 64-wide K chunks (one block per CU either way, half the barriers);
     // 128-channel tiles: 32-wide chunks keep the LDS footprint at 60 KB -> two blocks per CU
-    static const bool bn128 = getenv("SFD2_CONV_BN128") != nullptr;   // experiment: 128-channel tiles everywhere
-    static const bool small1 = getenv("SFD2_CONV_1X1_SMALL") != nullptr;   // experiment: 4-wave 4x32 tiles for 1x1
+    static const bool bn128 = sfd2_env("SFD2_CONV_BN128") != nullptr;   // experiment: 128-channel tiles everywhere
+    static const bool small1 = sfd2_env("SFD2_CONV_1X1_SMALL") != nullptr;   // experiment: 4-wave 4x32 tiles for 1x1
     if (small1 && ks == 1 && CoutP % 256 == 0) return 32;
-    static const bool w3 = getenv("SFD2_CONV_WRING") != nullptr || getenv("SFD2_CONV_TPS3") != nullptr;   // experiments on 32-wide chunks
+    static const bool w3 = sfd2_env("SFD2_CONV_WRING") != nullptr || sfd2_env("SFD2_CONV_TPS3") != nullptr;   // experiments on 32-wide chunks
     if (w3 && ks == 3 && stride == 1 && CoutP % 256 == 0) return 32;
     if (CoutP % 256 == 0 && !bn128) return (Cin % 64 == 0) ? 64 : 32;
     // conv2a (64 -> 128): the whole K of a tap row fits one 64-wide chunk, so the patch is staged once (XBUF = 1,
     // 76 KB of LDS, two blocks per CU) and the 9 steps carry 16 MFMAs each instead of 18 steps of 8
-    static const bool c2a32 = getenv("SFD2_CONV2A_CC32") != nullptr;
+    static const bool c2a32 = sfd2_env("SFD2_CONV2A_CC32") != nullptr;
     if (ks == 3 && Cin == 64 && CoutP == 128 && !c2a32) return 64;
     return 32;
 }
@@ -393,7 +393,7 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
         // single-buffered input patch (XBUF = 1): 53 / 69 KB of LDS instead of 90 / 106 KB, so 3 / 2 blocks share a CU
         // and hide each other's per-step latencies (steps are only 8-16 MFMAs long here).  Measured at 1600x1200:
         // conv2b 98 -> 70 us, convPa.0 120 -> 82 us.  SFD2_CONV_S2_XBUF2 restores the double-buffered variant.
-        static const bool xb2 = getenv("SFD2_CONV_S2_XBUF2") != nullptr;
+        static const bool xb2 = sfd2_env("SFD2_CONV_S2_XBUF2") != nullptr;
         if (xb2) {
             if (CoutP % 256 == 0) launch_igemm2_t<3, 2, 256, 32, false, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
             else launch_igemm2_t<3, 2, 128, 32, false, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
@@ -415,20 +415,21 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
     } while (0)
     const int cc = conv_igemm2_chunk(ks, 1, CoutP, Cin);
     if (cc == 0) return false;
-    static const bool bn128 = getenv("SFD2_CONV_BN128") != nullptr;
+    static const bool bn128 = sfd2_env("SFD2_CONV_BN128") != nullptr;
     const int bn = (CoutP % 256 == 0 && !bn128) ? 256 : 128;
-    static const bool nw4 = getenv("SFD2_CONV_NW4") != nullptr;   // experiment: 4 waves, 128 ch x 128 px per wave
+    static const bool nw4 = sfd2_env("SFD2_CONV_NW4") != nullptr;   // experiment: 4 waves, 128 ch x 128 px per wave
     if (nw4 && ks == 3 && !out_f32 && bn == 256 && cc == 64 && !residual) {
         launch_igemm2_t<3, 1, 256, 64, false, false, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         return true;
     }
-    static const bool small1 = getenv("SFD2_CONV_1X1_SMALL") != nullptr;
+    static const bool small1 = sfd2_env("SFD2_CONV_1X1_SMALL") != nullptr;
     if (small1 && ks == 1 && !out_f32 && bn == 256 && cc == 32) {
         if (residual) launch_igemm2_t<1, 1, 256, 32, false, true, 4, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         else launch_igemm2_t<1, 1, 256, 32, false, false, 4, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         return true;
     }
-    if (const char *ab = getenv("SFD2_CONV_3X3_ABLATE")) {   // timing ablations of the dominant kernel (wrong results)
+#ifdef SFD2_EXPERIMENTS
+    if (const char *ab = sfd2_env("SFD2_CONV_3X3_ABLATE")) {   // timing ablations of the dominant kernel (wrong results)
         if (ks == 3 && !out_f32 && bn == 256 && cc == 64 && !residual) {
             if (ab[0] == '5') { launch_igemm2_t<3, 1, 256, 64, false, false, 8, 0, 2, 5>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); return true; }
             if (ab[0] == '6') { launch_igemm2_t<3, 1, 256, 64, false, false, 8, 0, 2, 6>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); return true; }
@@ -436,12 +437,13 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
             if (ab[0] == '1') { launch_igemm2_t<3, 1, 256, 64, false, false, 8, 0, 2, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); return true; }
         }
     }
-    static const bool tps3 = getenv("SFD2_CONV_TPS3") != nullptr;   // experiment: one filter ROW (3 taps) per pipeline stage
+#endif
+    static const bool tps3 = sfd2_env("SFD2_CONV_TPS3") != nullptr;   // experiment: one filter ROW (3 taps) per pipeline stage
     if (tps3 && ks == 3 && !out_f32 && bn == 256 && cc == 32 && !residual) {
         launch_igemm2_t<3, 1, 256, 32, false, false, 8, 0, 2, 0, 2, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         return true;
     }
-    static const bool w3 = getenv("SFD2_CONV_WRING") != nullptr;
+    static const bool w3 = sfd2_env("SFD2_CONV_WRING") != nullptr;
     if (w3 && ks == 3 && !out_f32 && bn == 256 && cc == 32 && !residual) {
         launch_igemm2_t<3, 1, 256, 32, false, false, 8, 0, 2, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         return true;
@@ -454,7 +456,8 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
     // Experiment (SFD2_CONV_1X1_XBUF3): three input buffers with the chunk two steps ahead in flight and counted-vmcnt
     // barriers for the 1x1 layers.  Correct, but measured SLOWER than the two-buffer pipeline (conv1 34 -> 39 us,
     // conv3 44.5 -> 49 us at 1600x1200): doubling the input bytes in flight is not what these layers lack.
-    if (const char *ab = getenv("SFD2_CONV_1X1_ABLATE")) {   // timing ablations of the 1x1 256-channel layer (wrong results)
+#ifdef SFD2_EXPERIMENTS
+    if (const char *ab = sfd2_env("SFD2_CONV_1X1_ABLATE")) {   // timing ablations of the 1x1 256-channel layer (wrong results)
         if (ks == 1 && !out_f32 && bn == 256 && cc == 64 && !residual) {
             switch (ab[0]) {
             case '1': launch_igemm2_t<1, 1, 256, 64, false, false, 8, 0, 2, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); return true;
@@ -465,7 +468,8 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
             }
         }
     }
-    static const bool x3 = getenv("SFD2_CONV_1X1_XBUF3") != nullptr;
+#endif
+    static const bool x3 = sfd2_env("SFD2_CONV_1X1_XBUF3") != nullptr;
 #define SFD2_IG1(BN_, CC_, F32_)                                                                                         \
     do {                                                                                                                \
         if (residual) launch_igemm2_t<1, 1, BN_, CC_, F32_, true, 8, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page); \

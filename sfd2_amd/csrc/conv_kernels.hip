@@ -248,7 +248,7 @@ int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin);
 // SFD2_CONV_V1=1 forces the first-generation kernel (32-wide chunks) everywhere.
 int conv_igemm_chunk(int ks, int stride, int CoutP, int Cin)
 {
-    static const bool force_v1 = getenv("SFD2_CONV_V1") != nullptr;
+    static const bool force_v1 = sfd2_env("SFD2_CONV_V1") != nullptr;
     if (!force_v1) {
         const int c = conv_igemm2_chunk(ks, stride, CoutP, Cin);
         if (c) return c;
@@ -261,7 +261,7 @@ void launch_conv_igemm(hipStream_t st, const half_t *in, int H, int W, int Cin, 
                        const half_t *residual, void *out, int out_f32, int Ho, int Wo, const half_t *zero_page)
 {
     // second-generation kernel (conv2_kernels.hip) for the stride-1 layers; SFD2_CONV_V1=1 forces the first
-    if (getenv("SFD2_CONV_V1") == nullptr && zero_page &&
+    if (sfd2_env("SFD2_CONV_V1") == nullptr && zero_page &&
         launch_conv_igemm2(st, in, H, W, Cin, wpk, scale, shift, CoutP, ks, stride, relu, residual, out, out_f32, Ho, Wo, zero_page))
         return;
 #define SFD2_IGEMM(KS_, ST_, BN_, F32_)                                                                               \

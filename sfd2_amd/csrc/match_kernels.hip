@@ -597,18 +597,22 @@ void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_hi));
         attr_done = true;
     }
-    if (!use_lo && zero_page && getenv("SFD2_MATCH_V1") == nullptr) {
+    if (!use_lo && zero_page && sfd2_env("SFD2_MATCH_V1") == nullptr) {
         const dim3 grid((max_nb + 255) / 256, splits, njobs);
         const size_t lds = (size_t)2 * TA2 * 256;
         static bool attr2 = false;
         if (!attr2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_v2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_v2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#ifdef SFD2_EXPERIMENTS
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_v2_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
             attr2 = true;
         }
         if (need_top2) hipLaunchKernelGGL(match_top2_v2_kernel<true>, grid, dim3(NT), lds, st, jobs_dev, splits, zero_page);
-        else if (getenv("SFD2_MATCH_ABLATE")) hipLaunchKernelGGL((match_top2_v2_kernel<false, 1>), grid, dim3(NT), lds, st, jobs_dev, splits, zero_page);
+#ifdef SFD2_EXPERIMENTS
+        else if (sfd2_env("SFD2_MATCH_ABLATE")) hipLaunchKernelGGL((match_top2_v2_kernel<false, 1>), grid, dim3(NT), lds, st, jobs_dev, splits, zero_page);
+#endif
         else hipLaunchKernelGGL(match_top2_v2_kernel<false>, grid, dim3(NT), lds, st, jobs_dev, splits, zero_page);
         return;
     }

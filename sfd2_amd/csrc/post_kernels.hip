@@ -441,7 +441,7 @@ void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radi
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
             attr4 = true;
         }
-        static const int nms_threads = getenv("SFD2_NMS_THREADS") ? atoi(getenv("SFD2_NMS_THREADS")) : 1024;   // 512 threads: 56 us, 1024: 47 us at 1600x1200
+        static const int nms_threads = sfd2_env("SFD2_NMS_THREADS") ? atoi(sfd2_env("SFD2_NMS_THREADS")) : 1024;   // 512 threads: 56 us, 1024: 47 us at 1600x1200
         hipLaunchKernelGGL(nms4_select_kernel, dim3((W + N2_TW - 1) / N2_TW, (H + N2_TH - 1) / N2_TH), dim3(nms_threads), lds4,
                            st, heat, H, W, conf_th, border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist);
         return;
@@ -985,4 +985,80 @@ void launch_ms_merge(hipStream_t st, int n_levels, const int *offsets, const uns
     if (n_max <= 0) return;
     hipLaunchKernelGGL(ms_gather_kernel, dim3((n_max + 3) / 4), dim3(NT), 0, st, lv, level_count, order, kp_stage, sc_stage,
                        de_stage, n_max, kp_out, sc_out, de_out, ms_counters);
+}
+
+// ---------------------------------------------------------------- decoder-side ingest (extract_localization.py:158-186)
+// ImageDataset.__getitem__: image.astype(float32) -> cv2.resize(..., INTER_CUBIC) when max(w, h) > resize_max ->
+// HWC to CHW -> / 255.  OpenCV's float32 cubic resize, restated from its published algorithm (imgproc resize.cpp,
+// resizeGeneric_ with HResizeCubic / VResizeCubic): separable, horizontal pass first, Keys kernel with A = -0.75,
+// source coordinate (d + 0.5) * (src / dst) - 0.5 evaluated in double and rounded to float, taps sx-1 .. sx+2 with
+// replicated borders, no clamping of the overshoot.  Products and sums in the order the scalar code writes them, with
+// contraction forbidden (__fmul_rn / __fadd_rn) so the oracle's numpy restatement is reproduced bit for bit.
+__device__ __forceinline__ void cubic_coeffs(float x, float *c)
+{
+    const float A = -0.75f;
+    const float x1 = __fadd_rn(x, 1.0f);
+    c[0] = __fsub_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fsub_rn(__fmul_rn(A, x1), 5.0f * A), x1), 8.0f * A), x1), 4.0f * A);
+    c[1] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(A + 2.0f, x), A + 3.0f), x), x), 1.0f);
+    const float y = __fsub_rn(1.0f, x);
+    c[2] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(A + 2.0f, y), A + 3.0f), y), y), 1.0f);
+    c[3] = __fsub_rn(__fsub_rn(__fsub_rn(1.0f, c[0]), c[1]), c[2]);
+}
+
+__global__ __launch_bounds__(NT)
+void ingest_u8_kernel(const unsigned char *__restrict__ src, int H, int W, int bgr, int nh, int nw, double scale_x,
+                      double scale_y, float *__restrict__ out /*[3][nh][nw]*/)
+{
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    const int oy = blockIdx.y;
+    if (ox >= nw) return;
+    const size_t plane = (size_t)nh * nw;
+    if (nh == H && nw == W) {   // no resize: astype(float32) / 255.
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = (float)src[((size_t)oy * W + ox) * 3 + (bgr ? 2 - c : c)];
+            out[c * plane + (size_t)oy * nw + ox] = __fdiv_rn(v, 255.0f);
+        }
+        return;
+    }
+    float fx = (float)((ox + 0.5) * scale_x - 0.5);
+    float fy = (float)((oy + 0.5) * scale_y - 0.5);
+    const int sx = (int)floorf(fx), sy = (int)floorf(fy);
+    fx = __fsub_rn(fx, (float)sx);
+    fy = __fsub_rn(fy, (float)sy);
+    float a[4], b[4];
+    cubic_coeffs(fx, a);
+    cubic_coeffs(fy, b);
+    int xs[4], ys[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        xs[k] = min(max(sx - 1 + k, 0), W - 1);
+        ys[k] = min(max(sy - 1 + k, 0), H - 1);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int cs = bgr ? 2 - c : c;
+        float rows[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned char *row = src + (size_t)ys[r] * W * 3 + cs;
+            float acc = __fmul_rn((float)row[xs[0] * 3], a[0]);
+            acc = __fadd_rn(acc, __fmul_rn((float)row[xs[1] * 3], a[1]));
+            acc = __fadd_rn(acc, __fmul_rn((float)row[xs[2] * 3], a[2]));
+            acc = __fadd_rn(acc, __fmul_rn((float)row[xs[3] * 3], a[3]));
+            rows[r] = acc;
+        }
+        float v = __fmul_rn(rows[0], b[0]);
+        v = __fadd_rn(v, __fmul_rn(rows[1], b[1]));
+        v = __fadd_rn(v, __fmul_rn(rows[2], b[2]));
+        v = __fadd_rn(v, __fmul_rn(rows[3], b[3]));
+        out[c * plane + (size_t)oy * nw + ox] = __fdiv_rn(v, 255.0f);
+    }
+}
+
+void launch_ingest_u8(hipStream_t st, const unsigned char *src, int H, int W, int bgr, int nh, int nw, float *out)
+{
+    // cv2.resize: inv_scale = dsize / ssize (double), scale = 1. / inv_scale
+    const double scale_x = 1.0 / ((double)nw / (double)W), scale_y = 1.0 / ((double)nh / (double)H);
+    hipLaunchKernelGGL(ingest_u8_kernel, dim3((nw + NT - 1) / NT, nh), dim3(NT), 0, st, src, H, W, bgr, nh, nw, scale_x, scale_y, out);
 }

@@ -25,12 +25,15 @@ static int fail(const std::string &m)
             return fail(std::string(#expr) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
     } while (0)
 
+static unsigned long long g_alloc_gen = 0;   // bumped whenever a workspace buffer is (re)allocated: captured graphs hold raw pointers
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
+        ++g_alloc_gen;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
@@ -70,6 +73,14 @@ struct sfd2_ctx {
     void *pin_jobs = nullptr;
     size_t pin_cap = 0;
     bool weights_loaded = false;
+    bool has_sta = false;              // ConvSta present in the loaded state_dict (absent for require_stability=False models)
+    int opt_alias = 1;                 // sfd2_set_option "alias"
+    int fuse_det = 0;                  // sfd2_set_option "fuse_det"
+    int use_graphs = 0;                // sfd2_set_option "graphs"
+    int alias_now = 0;                 // set per call
+    struct GraphEntry *graphs = nullptr;   // hipGraph cache of sfd2_extract_match (see below)
+    int n_graphs = 0;
+    unsigned long long graph_clock = 0;
     // weights
     ConvW c1a, c1b, c2a, c2b, c3a, c3b, rb1[3], rb2[3], rb3[3], pa0, pa3, da0, da3, pb, db;
     DevBuf sta_w, sta_b, zero_page, w1b_fused;   // w1b_fused: conv1b filters as [9][64][64] for the fused stem
@@ -109,6 +120,7 @@ struct sfd2_ctx {
     std::string prof_filter;                  // only kernel labels containing this are timed
 };
 
+static void graphs_release(sfd2_ctx *c);
 #define PROF_SLOTS 48
 struct ProfScope {   // records an event pair around one launch when profiling is on
     sfd2_ctx *c; int slot;
@@ -167,7 +179,7 @@ extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
         HIPCHECK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&c->ev_img_free[i], hipEventDisableTiming));
     }
-    c->fuse = getenv("SFD2_NO_FUSE") ? 0 : 1;
+    c->fuse = sfd2_env("SFD2_NO_FUSE") ? 0 : 1;
     HIPCHECK(c->zero_page.ensure(1024));
     HIPCHECK(hipMemset(c->zero_page.p, 0, 1024));
     *out = c;
@@ -179,6 +191,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    graphs_release(c);
     DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
                       &c->rt1[0], &c->rt1[1], &c->rt1[2], &c->rt2[0], &c->rt2[1], &c->rt2[2], &c->ro[0], &c->ro[1],
                       &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
@@ -359,6 +372,8 @@ static int pack_igemm_f32(sfd2_ctx *c, const TMap &m, ConvW &L, const std::strin
 {
     const TView *w = find_t(m, conv + ".weight");
     if (!w) return fail("missing tensor: " + conv + ".weight");
+    if (w->shape.size() != 4 || w->shape[0] != cout || w->shape[1] != cin || w->shape[2] != ks || w->shape[3] != ks)
+        return fail("bad shape for " + conv + ".weight");
     const int cout_pad = (cout + 63) / 64 * 64;
     L.cin = cin; L.cout = cout; L.cout_pad = cout_pad; L.ks = ks; L.stride = stride;
     const int T = ks * ks, nch = cin / 32;
@@ -418,6 +433,8 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
 {
     if (!c || !tensors) return fail("sfd2_load_weights: null argument");
     HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    c->weights_loaded = false;   // a failure part-way must not leave a half-replaced set usable
     TMap m;
     for (int i = 0; i < n; ++i) {
         if (!tensors[i].name || !tensors[i].data) continue;
@@ -452,11 +469,18 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
     if (pack_igemm(c, m, c->da3, "convDa.3", "", 256, 256, 3, 1)) return -1;
     if (pack_igemm(c, m, c->pb, "convPb", "", 256, 65, 1, 1)) return -1;
     if (pack_igemm(c, m, c->db, "convDb", "", 256, 128, 1, 1)) return -1;
+    // ConvSta exists only in models built with require_stability=True (nets/sfd2.py:302-303); the reference loads
+    // checkpoints without it (strict=False, extract_localization.py:214), so it is optional here and stability
+    // requests are refused only when it is absent
     const TView *sw = find_t(m, "ConvSta.weight"), *sb = find_t(m, "ConvSta.bias");
-    if (!sw || !sb) return fail("missing tensor: ConvSta.{weight,bias}");
-    if (sw->numel() != 3 * 256 || sb->numel() != 3) return fail("bad shape for ConvSta");
-    if (upload(c->sta_w, sw->d, 3 * 256 * sizeof(float), c->stream)) return -1;
-    if (upload(c->sta_b, sb->d, 3 * sizeof(float), c->stream)) return -1;
+    c->has_sta = false;
+    if (sw || sb) {
+        if (!sw || !sb) return fail("missing tensor: ConvSta.{weight,bias} (only one of the two is present)");
+        if (sw->numel() != 3 * 256 || sb->numel() != 3) return fail("bad shape for ConvSta");
+        if (upload(c->sta_w, sw->d, 3 * 256 * sizeof(float), c->stream)) return -1;
+        if (upload(c->sta_b, sb->d, 3 * sizeof(float), c->stream)) return -1;
+        c->has_sta = true;
+    }
     if (pack_all_f32(c, m)) return -1;
     c->weights_loaded = true;
     return 0;
@@ -465,6 +489,16 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
 // ------------------------------------------------------------------------------------------ workspace
 static int down2(int n) { return (n - 1) / 2 + 1; }  // 3x3 stride 2 pad 1
 
+// which kernels / buffers the next network pass uses; call before ensure_workspace
+static void set_path(sfd2_ctx *c, bool parity_entry)
+{
+    const bool f16 = c->precision == SFD2_PREC_F16;
+    c->fuse_now = f16 && (parity_entry ? c->fuse_det : c->fuse);
+    c->alias_now = c->fuse_now && !parity_entry && c->opt_alias;
+}
+
+// Buffers are allocated for the path that is about to run only: the throughput path needs the 3-slot
+// arena + head outputs, the layer-wise paths one buffer per activation, strict mode the fp32 set.
 static int ensure_workspace(sfd2_ctx *c, int H, int W)
 {
     if (H < 8 || W < 8) return fail("image too small (need H, W >= 8)");
@@ -475,21 +509,27 @@ static int ensure_workspace(sfd2_ctx *c, int H, int W)
     c->H8 = down2(c->H4); c->W8 = down2(c->W4);
     const size_t P1 = (size_t)H * W, P2 = (size_t)c->H2 * c->W2, P4 = (size_t)c->H4 * c->W4, P8 = (size_t)c->H8 * c->W8;
     const size_t hb = sizeof(half_t);
-    HIPCHECK(c->a1a.ensure(P1 * 64 * hb));
-    HIPCHECK(c->a1b.ensure(P2 * 64 * hb));
-    HIPCHECK(c->a2a.ensure(P2 * 128 * hb));
-    HIPCHECK(c->a2b.ensure(P4 * 128 * hb));
-    HIPCHECK(c->a3a.ensure(P4 * 256 * hb));
-    HIPCHECK(c->a3b.ensure(P4 * 256 * hb));
-    for (int b = 0; b < 3; ++b) {
-        HIPCHECK(c->rt1[b].ensure(P4 * 256 * hb));
-        HIPCHECK(c->rt2[b].ensure(P4 * 256 * hb));
-        HIPCHECK(c->ro[b].ensure(P4 * 256 * hb));
+    const bool f32 = c->precision == SFD2_PREC_F32;
+    const bool layers = !f32 && !c->alias_now;      // private fp16 buffer per activation
+    if (layers) {
+        if (!c->fuse_now) HIPCHECK(c->a1a.ensure(P1 * 64 * hb));
+        HIPCHECK(c->a1b.ensure(P2 * 64 * hb));
+        HIPCHECK(c->a2a.ensure(P2 * 128 * hb));
+        HIPCHECK(c->a2b.ensure(P4 * 128 * hb));
+        HIPCHECK(c->a3a.ensure(P4 * 256 * hb));
+        HIPCHECK(c->a3b.ensure(P4 * 256 * hb));
+        for (int b = 0; b < 3; ++b) {
+            if (!c->fuse_now) {
+                HIPCHECK(c->rt1[b].ensure(P4 * 256 * hb));
+                HIPCHECK(c->rt2[b].ensure(P4 * 256 * hb));
+            }
+            HIPCHECK(c->ro[b].ensure(P4 * 256 * hb));
+        }
+        HIPCHECK(c->pa0_o.ensure(P8 * 256 * hb));
+        HIPCHECK(c->pa_o.ensure(P8 * 256 * hb));
+        HIPCHECK(c->da0_o.ensure(P4 * 256 * hb));
+        HIPCHECK(c->da_o.ensure(P4 * 256 * hb));
     }
-    HIPCHECK(c->pa0_o.ensure(P8 * 256 * hb));
-    HIPCHECK(c->pa_o.ensure(P8 * 256 * hb));
-    HIPCHECK(c->da0_o.ensure(P4 * 256 * hb));
-    HIPCHECK(c->da_o.ensure(P4 * 256 * hb));
     HIPCHECK(c->logits.ensure(P8 * 128 * sizeof(float)));
     HIPCHECK(c->draw.ensure(P4 * 128 * sizeof(float)));
     HIPCHECK(c->sta.ensure(P4 * 3 * sizeof(float)));
@@ -502,10 +542,16 @@ static int ensure_workspace(sfd2_ctx *c, int H, int W)
     HIPCHECK(c->bnd.ensure(cap * 8));
     HIPCHECK(c->counters.ensure(SFD2_COUNTER_BYTES));
     c->acts.clear();
-    auto reg = [&](const char *nm, const DevBuf &b, int f32, int planar, int ch, int pitch, int h, int w) {
-        c->acts[nm] = ActInfo{b.p, f32, planar, ch, pitch, h, w};
+    auto reg = [&](const char *nm, const void *ptr, int is_f32, int planar, int ch, int pitch, int h, int w) {
+        c->acts[nm] = ActInfo{ptr, is_f32, planar, ch, pitch, h, w};
     };
-    if (c->precision == SFD2_PREC_F32) {
+    static const char *n1[3] = {"conv4.0.bn1", "conv4.1.bn1", "conv4.2.bn1"};
+    static const char *n2[3] = {"conv4.0.bn2", "conv4.1.bn2", "conv4.2.bn2"};
+    static const char *n3[3] = {"conv4.0", "conv4.1", "conv4.2"};
+    reg("convPb", c->logits.p, 1, 0, 65, 128, c->H8, c->W8);
+    reg("convDb", c->draw.p, 1, 0, 128, 128, c->H4, c->W4);
+    reg("ConvSta", c->sta.p, 1, 1, 3, 0, c->H4, c->W4);
+    if (f32) {
         const size_t fb = sizeof(float);
         HIPCHECK(c->g1a.ensure(P1 * 64 * fb));
         HIPCHECK(c->g1b.ensure(P2 * 64 * fb));
@@ -522,50 +568,41 @@ static int ensure_workspace(sfd2_ctx *c, int H, int W)
         HIPCHECK(c->gpa_o.ensure(P8 * 256 * fb));
         HIPCHECK(c->gda0_o.ensure(P4 * 256 * fb));
         HIPCHECK(c->gda_o.ensure(P4 * 256 * fb));
-        static const char *fn1[3] = {"conv4.0.bn1", "conv4.1.bn1", "conv4.2.bn1"};
-        static const char *fn2[3] = {"conv4.0.bn2", "conv4.1.bn2", "conv4.2.bn2"};
-        static const char *fn3[3] = {"conv4.0", "conv4.1", "conv4.2"};
-        reg("conv1a", c->g1a, 1, 0, 64, 64, H, W);
-        reg("bn1b", c->g1b, 1, 0, 64, 64, c->H2, c->W2);
-        reg("conv2a", c->g2a, 1, 0, 128, 128, c->H2, c->W2);
-        reg("bn2b", c->g2b, 1, 0, 128, 128, c->H4, c->W4);
-        reg("conv3a", c->g3a, 1, 0, 256, 256, c->H4, c->W4);
-        reg("bn3b", c->g3b, 1, 0, 256, 256, c->H4, c->W4);
+        reg("conv1a", c->g1a.p, 1, 0, 64, 64, H, W);
+        reg("bn1b", c->g1b.p, 1, 0, 64, 64, c->H2, c->W2);
+        reg("conv2a", c->g2a.p, 1, 0, 128, 128, c->H2, c->W2);
+        reg("bn2b", c->g2b.p, 1, 0, 128, 128, c->H4, c->W4);
+        reg("conv3a", c->g3a.p, 1, 0, 256, 256, c->H4, c->W4);
+        reg("bn3b", c->g3b.p, 1, 0, 256, 256, c->H4, c->W4);
         for (int b = 0; b < 3; ++b) {
-            reg(fn1[b], c->grt1[b], 1, 0, 256, 256, c->H4, c->W4);
-            reg(fn2[b], c->grt2[b], 1, 0, 256, 256, c->H4, c->W4);
-            reg(fn3[b], c->gro[b], 1, 0, 256, 256, c->H4, c->W4);
+            reg(n1[b], c->grt1[b].p, 1, 0, 256, 256, c->H4, c->W4);
+            reg(n2[b], c->grt2[b].p, 1, 0, 256, 256, c->H4, c->W4);
+            reg(n3[b], c->gro[b].p, 1, 0, 256, 256, c->H4, c->W4);
         }
-        reg("convPa.0", c->gpa0_o, 1, 0, 256, 256, c->H8, c->W8);
-        reg("convPa", c->gpa_o, 1, 0, 256, 256, c->H8, c->W8);
-        reg("convDa.0", c->gda0_o, 1, 0, 256, 256, c->H4, c->W4);
-        reg("convDa", c->gda_o, 1, 0, 256, 256, c->H4, c->W4);
-        reg("convPb", c->logits, 1, 0, 65, 128, c->H8, c->W8);
-        reg("convDb", c->draw, 1, 0, 128, 128, c->H4, c->W4);
-        reg("ConvSta", c->sta, 1, 1, 3, 0, c->H4, c->W4);
+        reg("convPa.0", c->gpa0_o.p, 1, 0, 256, 256, c->H8, c->W8);
+        reg("convPa", c->gpa_o.p, 1, 0, 256, 256, c->H8, c->W8);
+        reg("convDa.0", c->gda0_o.p, 1, 0, 256, 256, c->H4, c->W4);
+        reg("convDa", c->gda_o.p, 1, 0, 256, 256, c->H4, c->W4);
         return 0;
     }
-    reg("conv1a", c->a1a, 0, 0, 64, 64, H, W);
-    reg("bn1b", c->a1b, 0, 0, 64, 64, c->H2, c->W2);
-    reg("conv2a", c->a2a, 0, 0, 128, 128, c->H2, c->W2);
-    reg("bn2b", c->a2b, 0, 0, 128, 128, c->H4, c->W4);
-    reg("conv3a", c->a3a, 0, 0, 256, 256, c->H4, c->W4);
-    reg("bn3b", c->a3b, 0, 0, 256, 256, c->H4, c->W4);
-    static const char *n1[3] = {"conv4.0.bn1", "conv4.1.bn1", "conv4.2.bn1"};
-    static const char *n2[3] = {"conv4.0.bn2", "conv4.1.bn2", "conv4.2.bn2"};
-    static const char *n3[3] = {"conv4.0", "conv4.1", "conv4.2"};
+    if (!layers) return 0;   // throughput path: intermediates live in aliased arena slots and are not readable
+    if (!c->fuse_now) reg("conv1a", c->a1a.p, 0, 0, 64, 64, H, W);
+    reg("bn1b", c->a1b.p, 0, 0, 64, 64, c->H2, c->W2);
+    reg("conv2a", c->a2a.p, 0, 0, 128, 128, c->H2, c->W2);
+    reg("bn2b", c->a2b.p, 0, 0, 128, 128, c->H4, c->W4);
+    reg("conv3a", c->a3a.p, 0, 0, 256, 256, c->H4, c->W4);
+    reg("bn3b", c->a3b.p, 0, 0, 256, 256, c->H4, c->W4);
     for (int b = 0; b < 3; ++b) {
-        reg(n1[b], c->rt1[b], 0, 0, 256, 256, c->H4, c->W4);
-        reg(n2[b], c->rt2[b], 0, 0, 256, 256, c->H4, c->W4);
-        reg(n3[b], c->ro[b], 0, 0, 256, 256, c->H4, c->W4);
+        if (!c->fuse_now) {
+            reg(n1[b], c->rt1[b].p, 0, 0, 256, 256, c->H4, c->W4);
+            reg(n2[b], c->rt2[b].p, 0, 0, 256, 256, c->H4, c->W4);
+        }
+        reg(n3[b], c->ro[b].p, 0, 0, 256, 256, c->H4, c->W4);
     }
-    reg("convPa.0", c->pa0_o, 0, 0, 256, 256, c->H8, c->W8);
-    reg("convPa", c->pa_o, 0, 0, 256, 256, c->H8, c->W8);
-    reg("convDa.0", c->da0_o, 0, 0, 256, 256, c->H4, c->W4);
-    reg("convDa", c->da_o, 0, 0, 256, 256, c->H4, c->W4);
-    reg("convPb", c->logits, 1, 0, 65, 128, c->H8, c->W8);
-    reg("convDb", c->draw, 1, 0, 128, 128, c->H4, c->W4);
-    reg("ConvSta", c->sta, 1, 1, 3, 0, c->H4, c->W4);
+    reg("convPa.0", c->pa0_o.p, 0, 0, 256, 256, c->H8, c->W8);
+    reg("convPa", c->pa_o.p, 0, 0, 256, 256, c->H8, c->W8);
+    reg("convDa.0", c->da0_o.p, 0, 0, 256, 256, c->H4, c->W4);
+    reg("convDa", c->da_o.p, 0, 0, 256, 256, c->H4, c->W4);
     return 0;
 }
 
@@ -579,7 +616,7 @@ static void conv(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &in
     const double flops = 2.0 * px * L.cout * L.cin * L.ks * L.ks;
     const double bytes = 2.0 * ((double)H * W * L.cin + (double)L.cout * L.cin * L.ks * L.ks) +
                          px * L.cout_pad * (out_f32 ? 4.0 : 2.0) + (res ? px * L.cout_pad * 2.0 : 0.0);
-    static const bool no_c1 = getenv("SFD2_NO_CONV1X1") != nullptr;
+    static const bool no_c1 = sfd2_env("SFD2_NO_CONV1X1") != nullptr;
     if (L.wrm.p && !out_f32 && !no_c1) {
         snprintf(kn, sizeof(kn), "conv1x1_c256%s", res ? "+res" : "");
         ProfScope ps(c, name, kn, flops, bytes);
@@ -641,7 +678,7 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
     convf(c, "convDa.0", c->fda0, *x, H4, W4, c->gda0_o, H4, W4, 1);
     convf(c, "convDa.3", c->fda3, c->gda0_o, H4, W4, c->gda_o, H4, W4, 0);
     convf(c, "convDb", c->fdb, c->gda_o, H4, W4, c->draw, H4, W4, 0);
-    {
+    if (c->has_sta) {
         ProfScope ps(c, "ConvSta", "convsta_f32_kernel", 2.0 * P4 * 3 * 256, P4 * (1024 + 12));
         launch_convsta_f32(st, x->as<float>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
     }
@@ -665,8 +702,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     // arena (at 1600x1200), reusing a slot as soon as its tensor is dead, so the working set fits the 256 MB
     // Infinity Cache and a layer mostly reads what the previous one just wrote (measured: ResBlocks 400 -> 344 us;
     // four slots measure the same as three).
-    static const bool no_alias = getenv("SFD2_NO_ALIAS") != nullptr;
-    const bool alias = c->fuse_now && !no_alias;
+    const bool alias = c->alias_now != 0;
     DevBuf a1b = c->a1b, a2a = c->a2a, a2b = c->a2b, a3a = c->a3a, a3b = c->a3b, pa0_o = c->pa0_o, pa_o = c->pa_o,
            da0_o = c->da0_o, da_o = c->da_o;   // non-owning views
     DevBuf t1v[3] = {c->rt1[0], c->rt1[1], c->rt1[2]}, t2v[3] = {c->rt2[0], c->rt2[1], c->rt2[2]},
@@ -713,10 +749,9 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     static const char *nm1[3] = {"conv4.0.conv1", "conv4.1.conv1", "conv4.2.conv1"};
     static const char *nm2[3] = {"conv4.0.conv2", "conv4.1.conv2", "conv4.2.conv2"};
     static const char *nm3[3] = {"conv4.0.conv3", "conv4.1.conv3", "conv4.2.conv3"};
-    // SFD2_FUSED_RB: unset = the fused ResBlock kernel on the throughput path; "0" = three kernels per block;
-    // "det" = fused on the parity path too (conv4.b.bn1 / bn2 activations are then not materialised)
-    const char *frb = getenv("SFD2_FUSED_RB");
-    const bool fused_rb = frb ? (frb[0] == 'd' || (frb[0] != '0' && c->fuse_now)) : (c->fuse_now != 0);
+    // fused ResBlock kernel wherever the fused path runs (SFD2_FUSED_RB=0 in experiment builds: three kernels per block)
+    const char *frb = sfd2_env("SFD2_FUSED_RB");
+    const bool fused_rb = c->fuse_now != 0 && !(frb && frb[0] == '0');
     static const char *nmf[3] = {"conv4.0", "conv4.1", "conv4.2"};
     for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
         DevBuf &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];
@@ -744,7 +779,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     conv(c, "convDa.0", c->da0, *x, H4, W4, da0_o, H4, W4, 1);
     conv(c, "convDa.3", c->da3, da0_o, H4, W4, da_o, H4, W4, 0);
     conv(c, "convDb", c->db, da_o, H4, W4, c->draw, H4, W4, 0, nullptr, 1);
-    {
+    if (c->has_sta) {
         ProfScope ps(c, "ConvSta", "convsta_kernel", 2.0 * P4 * 3 * 256, P4 * (512 + 12));
         launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
     }
@@ -794,12 +829,13 @@ extern "C" int sfd2_det(sfd2_ctx *c, const float *x, int x_on_device, int H, int
 {
     if (!c || !x) return fail("sfd2_det: null argument");
     if (!c->weights_loaded) return fail("sfd2_det: weights not loaded");
+    if (stability && !c->has_sta) return fail("sfd2_det: stability requested but the loaded state_dict has no ConvSta");
     HIPCHECK(hipSetDevice(c->device));
+    set_path(c, true);   // det is the parity entry point: every activation stays readable unless "fuse_det" is set
     if (ensure_workspace(c, H, W)) return -1;
     const float *img = nullptr;
     if (stage_image(c, x, x_on_device, H, W, &img)) return -1;
     prof_step_begin(c);
-    c->fuse_now = 0;   // det is the parity entry point: every activation stays readable (sfd2_debug_activation)
     if (run_network(c, img, (flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1)) return -1;
     if (release_image_slot(c)) return -1;
     prof_step_end(c);
@@ -880,7 +916,10 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
 {
     if (!c || !img) return fail("sfd2_extract: null argument");
     if (!c->weights_loaded) return fail("sfd2_extract: weights not loaded");
+    if (!(flags & SFD2_FLAG_NO_STABILITY) && !c->has_sta)
+        return fail("sfd2_extract: the loaded state_dict has no ConvSta; pass SFD2_FLAG_NO_STABILITY (use_stability=False)");
     HIPCHECK(hipSetDevice(c->device));
+    set_path(c, false);
     if (ensure_workspace(c, H, W)) return -1;
     const float *img_dev = nullptr;
     const int u8 = (flags & SFD2_FLAG_IMG_U8_HWC) ? 1 : 0;
@@ -889,7 +928,6 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     if (stage_image(c, img, img_on_device, H, W, &img_dev, u8)) return -1;
     HIPCHECK(hipEventRecord(c->ev[0], c->stream));
     prof_step_begin(c);
-    c->fuse_now = c->fuse && c->precision == SFD2_PREC_F16;
     const int in_mode = ((flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1) | (u8 ? 2 : 0) | ((flags & SFD2_FLAG_IMG_BGR) ? 4 : 0);
     if (run_network(c, img_dev, in_mode)) return -1;
     if (release_image_slot(c)) return -1;
@@ -946,6 +984,24 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     return 0;
 }
 
+// ImageDataset.__getitem__ after the decoder (extract_localization.py:168-186): astype(float32), cubic resize to
+// new_h x new_w when they differ from H x W, HWC -> CHW, / 255.  out_chw_dev: device, [3][new_h][new_w] fp32.
+extern "C" int sfd2_preprocess(sfd2_ctx *c, const unsigned char *img_hwc, int on_device, int H, int W, int flags, int new_h,
+                               int new_w, float *out_chw_dev)
+{
+    if (!c || !img_hwc || !out_chw_dev) return fail("sfd2_preprocess: null argument");
+    if (H < 1 || W < 1 || new_h < 1 || new_w < 1) return fail("sfd2_preprocess: bad size");
+    HIPCHECK(hipSetDevice(c->device));
+    const float *staged = nullptr;
+    if (stage_image(c, img_hwc, on_device, H, W, &staged, 1)) return -1;
+    launch_ingest_u8(c->stream, reinterpret_cast<const unsigned char *>(staged), H, W, (flags & SFD2_FLAG_IMG_BGR) ? 1 : 0, new_h,
+                     new_w, out_chw_dev);
+    if (release_image_slot(c)) return -1;
+    HIPCHECK(hipGetLastError());
+    if (!(flags & SFD2_FLAG_ASYNC)) HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 // Scale pyramid (nets/extractor.py:118-236,322-330): every level runs the single-scale pipeline on the bilinearly
 // resized normalised image, keeps its own top_k (the union's top_k is a subset of the levels' top_k), and the levels
 // are merged by score on the device.  Reference quirks kept: the border test uses the ORIGINAL W, H in level
@@ -958,6 +1014,8 @@ extern "C" int sfd2_extract_multiscale(sfd2_ctx *c, const void *img, int img_on_
     if (!c || !img || !scales) return fail("sfd2_extract_multiscale: null argument");
     if (n_scales < 1 || n_scales > 8) return fail("sfd2_extract_multiscale: 1..8 scales");
     if (!c->weights_loaded) return fail("sfd2_extract_multiscale: weights not loaded");
+    if (!(flags & SFD2_FLAG_NO_STABILITY) && !c->has_sta)
+        return fail("sfd2_extract_multiscale: the loaded state_dict has no ConvSta; pass SFD2_FLAG_NO_STABILITY");
     if (flags & SFD2_FLAG_ASYNC) return fail("sfd2_extract_multiscale: SFD2_FLAG_ASYNC is not supported");
     if (!kpts_xy || !scores) return fail("sfd2_extract_multiscale: kpts_xy and scores are required");
     HIPCHECK(hipSetDevice(c->device));
@@ -998,8 +1056,8 @@ extern "C" int sfd2_extract_multiscale(sfd2_ctx *c, const void *img, int img_on_
             lvl_img = c->img_scaled.as<float>();
             mode = 0;
         }
+        set_path(c, false);
         if (ensure_workspace(c, nh[l], nw[l])) return -1;
-        c->fuse_now = c->fuse && c->precision == SFD2_PREC_F16;
         if (run_network(c, lvl_img, mode)) return -1;
         launch_heatmap(c->stream, c->score.as<float>(), 8 * c->H8, 8 * c->W8,
                        (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(), c->H4, c->W4, nh[l], nw[l],
@@ -1109,12 +1167,14 @@ extern "C" int sfd2_extract_spp(sfd2_ctx *c, const float *x, int x_on_device, in
 {
     if (!c || !x) return fail("sfd2_extract_spp: null argument");
     if (!c->weights_loaded) return fail("sfd2_extract_spp: weights not loaded");
+    if (!(flags & SFD2_FLAG_NO_STABILITY) && !c->has_sta)
+        return fail("sfd2_extract_spp: the loaded state_dict has no ConvSta; pass SFD2_FLAG_NO_STABILITY");
     HIPCHECK(hipSetDevice(c->device));
+    set_path(c, false);
     if (ensure_workspace(c, H, W)) return -1;
     const float *img_dev = nullptr;
     if (stage_image(c, x, x_on_device, H, W, &img_dev)) return -1;
     prof_step_begin(c);
-    c->fuse_now = c->fuse && c->precision == SFD2_PREC_F16;
     if (run_network(c, img_dev, 0)) return -1;   // the caller normalised the image (extract.py:280-287)
     if (release_image_slot(c)) return -1;
     const int HS = 8 * c->H8, WS = 8 * c->W8;
@@ -1240,6 +1300,7 @@ extern "C" int sfd2_debug_activation(sfd2_ctx *c, const char *name, float *out, 
     auto it = c->acts.find(name);
     if (it == c->acts.end()) return fail(std::string("unknown activation: ") + name);
     const ActInfo &a = it->second;
+    if (!a.p) return fail(std::string("activation not materialised on this path: ") + name);
     if (ch) *ch = a.c;
     if (h) *h = a.h;
     if (w) *w = a.w;
@@ -1334,14 +1395,14 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     splits = std::max(1, std::min(splits, 8));
     const int min_n = std::max(1, std::min(n0, max_n1 > 0 ? max_n1 : 1));
     splits = std::min(splits, std::max(1, (min_n + 31) / 32));
-    if (const char *e = getenv("SFD2_MATCH_SPLITS")) splits = std::max(1, std::min(16, atoi(e)));
+    if (const char *e = sfd2_env("SFD2_MATCH_SPLITS")) splits = std::max(1, std::min(16, atoi(e)));
 
     const int need_top2 = (conf->flavour == SFD2_MATCH_ITLOC_NNR) ||
                           (conf->flavour == SFD2_MATCH_HLOC && conf->ratio_threshold > 0.0f);
     // Experiment (off by default, SFD2_MATCH_ONE_GEMM=1): both directions of the top-1 modes from ONE
     // GEMM with a DPP column reduction (match_mutual_kernel).  Correct, but VALU-bound: measured
     // 1103 us vs 470 us for the two-GEMM path on 50 x (4096 x 4096), so the second GEMM stays.
-    const bool single_gemm = !need_lo && !need_top2 && getenv("SFD2_MATCH_ONE_GEMM") != nullptr;
+    const bool single_gemm = !need_lo && !need_top2 && sfd2_env("SFD2_MATCH_ONE_GEMM") != nullptr;
     if (single_gemm) splits = std::max(splits, (max_n1 + 1023) / 1024);   // the kernel keeps <= 1024 candidates of column state
     const int nib = (n0 + 255) / 256;
 
@@ -1484,6 +1545,153 @@ extern "C" int sfd2_match(sfd2_ctx *c, const void *d0, int n0, const void *d1, i
     return sfd2_match_batch(c, &q, &db, 1, dim, conf, matches0, scores0, out_on_device, 0);
 }
 
+// ------------------------------------------------------------------------------------------ extract + match, hipGraph cache
+// One query unit of the localisation pipeline: extract one image, match its descriptors against k resident
+// database sets.  With option "graphs" the stream work of one unit is captured once per geometry and replayed
+// (BASELINE configs[4]: "per-GPU hipGraph capture").  A graph holds raw pointers, so the cache key is every argument
+// that ends up in a kernel parameter; entries die when any workspace buffer is reallocated (g_alloc_gen).
+struct GraphKey {
+    int H, W, top_k, flags, k, dim, n0;
+    float conf_th;
+    sfd2_match_conf conf;
+    const void *img, *kp, *sc, *de, *m, *ms;
+    unsigned long long db_hash;
+    bool operator==(const GraphKey &o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
+};
+struct GraphEntry {
+    GraphKey key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    unsigned long long gen = 0, last_use = 0;
+    int seen = 0;                       // eager passes made with this key (the first one sizes the workspace)
+    void *pin = nullptr;                // this entry's own job descriptors: replay re-reads them from pinned memory
+    size_t pin_cap = 0;
+    DevBuf jobs, fins;
+};
+#define SFD2_MAX_GRAPHS 16
+
+static void graph_entry_release(GraphEntry &e)
+{
+    if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    if (e.graph) (void)hipGraphDestroy(e.graph);
+    if (e.pin) (void)hipHostFree(e.pin);
+    e.jobs.release();
+    e.fins.release();
+    e = GraphEntry();
+}
+
+static void graphs_release(sfd2_ctx *c)
+{
+    if (!c->graphs) return;
+    for (int i = 0; i < c->n_graphs; ++i) graph_entry_release(c->graphs[i]);
+    delete[] c->graphs;
+    c->graphs = nullptr;
+    c->n_graphs = 0;
+}
+
+static int extract_match_eager(sfd2_ctx *c, const void *img, int H, int W, float conf_th, int top_k, int flags, float *kp,
+                               float *sc, float *de, const sfd2_desc_set *db, int k, int dim, const sfd2_match_conf *conf,
+                               int64_t *m, float *ms)
+{
+    int n_dummy = 0;
+    if (sfd2_extract(c, img, 1, H, W, conf_th, top_k, flags | SFD2_FLAG_ASYNC, kp, sc, de, 1, top_k, &n_dummy)) return -1;
+    if (k > 0) {
+        const sfd2_desc_set q = {de, top_k, SFD2_DT_F32, SFD2_LAYOUT_ND, 1, nullptr, 0, 0};
+        if (sfd2_match_batch(c, &q, db, k, dim, conf, m, ms, 1, SFD2_FLAG_ASYNC)) return -1;
+    }
+    return 0;
+}
+
+extern "C" int sfd2_extract_match(sfd2_ctx *c, const void *img_dev, int H, int W, float conf_th, int top_k, int flags,
+                                  float *kpts_xy, float *scores, float *desc, const sfd2_desc_set *db, int k, int dim,
+                                  const sfd2_match_conf *conf, int64_t *matches0, float *scores0)
+{
+    if (!c || !img_dev || !kpts_xy || !scores || !desc) return fail("sfd2_extract_match: null argument");
+    if (top_k <= 0) return fail("sfd2_extract_match: top_k must be positive (fixed-capacity device outputs)");
+    if (k < 0 || (k > 0 && (!db || !conf || !matches0 || !scores0))) return fail("sfd2_extract_match: null matcher argument");
+    for (int i = 0; i < k; ++i)
+        if (!db[i].on_device || db[i].rows) return fail("sfd2_extract_match: database sets must be device resident, without row selection");
+    HIPCHECK(hipSetDevice(c->device));
+    if (!c->use_graphs || c->prof_max_steps > 0)   // per-launch events cannot be read back from inside a graph
+        return extract_match_eager(c, img_dev, H, W, conf_th, top_k, flags, kpts_xy, scores, desc, db, k, dim, conf, matches0, scores0);
+
+    GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.H = H; key.W = W; key.top_k = top_k; key.flags = flags; key.k = k; key.dim = dim; key.n0 = top_k; key.conf_th = conf_th;
+    if (conf) key.conf = *conf;
+    key.img = img_dev; key.kp = kpts_xy; key.sc = scores; key.de = desc; key.m = matches0; key.ms = scores0;
+    unsigned long long h = 1469598103934665603ull;
+    for (int i = 0; i < k; ++i) {
+        const unsigned long long v[3] = {(unsigned long long)(uintptr_t)db[i].data, (unsigned long long)db[i].n,
+                                         ((unsigned long long)db[i].dtype << 8) | (unsigned long long)db[i].layout};
+        for (unsigned long long x : v) { h ^= x; h *= 1099511628211ull; }
+    }
+    key.db_hash = h;
+    if (!c->graphs) { c->graphs = new GraphEntry[SFD2_MAX_GRAPHS]; c->n_graphs = SFD2_MAX_GRAPHS; }
+    GraphEntry *e = nullptr, *lru = &c->graphs[0];
+    for (int i = 0; i < c->n_graphs; ++i) {
+        GraphEntry &g = c->graphs[i];
+        if (g.seen && g.key == key) { e = &g; break; }
+        if (g.last_use < lru->last_use) lru = &g;
+    }
+    if (!e) {   // new geometry: recycle the least recently used slot, run eagerly once (allocations happen here)
+        graph_entry_release(*lru);
+        e = lru;
+        e->key = key;
+    }
+    e->last_use = ++c->graph_clock;
+    if (e->exec && e->gen == g_alloc_gen) {
+        HIPCHECK(hipGraphLaunch(e->exec, c->stream));
+        return 0;
+    }
+    if (e->exec) {   // a workspace buffer moved since the capture: the graph's pointers are stale
+        (void)hipGraphExecDestroy(e->exec); e->exec = nullptr;
+        (void)hipGraphDestroy(e->graph); e->graph = nullptr;
+        e->seen = 0;
+    }
+    if (e->seen == 0) {
+        e->seen = 1;
+        return extract_match_eager(c, img_dev, H, W, conf_th, top_k, flags, kpts_xy, scores, desc, db, k, dim, conf, matches0, scores0);
+    }
+    // second sight of the key: capture.  The matcher's job descriptors are copied from pinned host memory by a graph
+    // node at every replay, so the entry gets its own pinned block and device copies that no other call rewrites.
+    const size_t jb = 2 * (size_t)std::max(k, 1) * sizeof(MatchJob), fb = (size_t)std::max(k, 1) * sizeof(MatchFinal);
+    if (!e->pin) {
+        HIPCHECK(hipHostMalloc(&e->pin, jb + fb, hipHostMallocDefault));
+        e->pin_cap = jb + fb;
+        HIPCHECK(e->jobs.ensure(jb));
+        HIPCHECK(e->fins.ensure(fb));
+    }
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipEventSynchronize(c->ev_jobs));
+    const unsigned long long gen0 = g_alloc_gen;
+    std::swap(c->pin_jobs, e->pin); std::swap(c->pin_cap, e->pin_cap);
+    std::swap(c->m_jobs, e->jobs); std::swap(c->m_fins, e->fins);
+    hipError_t be = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+    int rc = -1;
+    hipGraph_t g = nullptr;
+    if (be == hipSuccess) {
+        rc = extract_match_eager(c, img_dev, H, W, conf_th, top_k, flags, kpts_xy, scores, desc, db, k, dim, conf, matches0, scores0);
+        const hipError_t ee = hipStreamEndCapture(c->stream, &g);
+        if (ee != hipSuccess) rc = fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
+    } else {
+        fail(std::string("hipStreamBeginCapture: ") + hipGetErrorString(be));
+    }
+    std::swap(c->pin_jobs, e->pin); std::swap(c->pin_cap, e->pin_cap);
+    std::swap(c->m_jobs, e->jobs); std::swap(c->m_fins, e->fins);
+    if (rc != 0 || g_alloc_gen != gen0) {   // an allocation inside the capture means the warm-up pass did not cover it
+        if (g) (void)hipGraphDestroy(g);
+        e->seen = 0;
+        if (rc == 0) return fail("sfd2_extract_match: workspace changed during capture");
+        return -1;
+    }
+    e->graph = g;
+    HIPCHECK(hipGraphInstantiate(&e->exec, g, nullptr, nullptr, 0));
+    e->gen = g_alloc_gen;
+    HIPCHECK(hipGraphLaunch(e->exec, c->stream));
+    return 0;
+}
+
 extern "C" int sfd2_set_precision(sfd2_ctx *c, int mode)
 {
     if (!c) return fail("sfd2_set_precision: null ctx");
@@ -1491,6 +1699,20 @@ extern "C" int sfd2_set_precision(sfd2_ctx *c, int mode)
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
     c->precision = mode;
+    return 0;
+}
+
+extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
+{
+    if (!c || !key) return fail("sfd2_set_option: null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    const std::string k(key);
+    if (k == "fuse") c->fuse = value ? 1 : 0;
+    else if (k == "fuse_det") c->fuse_det = value ? 1 : 0;
+    else if (k == "alias") c->opt_alias = value ? 1 : 0;
+    else if (k == "graphs") c->use_graphs = value ? 1 : 0;
+    else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;
 }
 

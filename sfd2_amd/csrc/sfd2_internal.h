@@ -4,6 +4,15 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+// Experiment / ablation switches are read from the environment only in builds made with -DSFD2_EXPERIMENTS
+// (tools/ A/B runs); the product .so ignores them, so an exported variable can never change its results.
+#ifdef SFD2_EXPERIMENTS
+#include <stdlib.h>
+static inline const char *sfd2_env(const char *name) { return getenv(name); }
+#else
+static inline const char *sfd2_env(const char *) { return nullptr; }
+#endif
+
 typedef _Float16 half_t;
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
@@ -88,6 +97,9 @@ void launch_desc_normalise_nchw(hipStream_t st, const float *desc_nhwc, int npix
 void launch_nhwc_h_to_nchw_f(hipStream_t st, const half_t *in, int npix, int c_pitch, int c, float *out);
 void launch_nhwc_f_to_nchw_f(hipStream_t st, const float *in, int npix, int c_pitch, int c, float *out);
 void launch_nchw_f_to_nhwc_f(hipStream_t st, const float *in, int npix, int c, float *out);
+
+// decoder-side ingest: uint8 HWC (RGB or BGR) -> float32 CHW in [0,1] at nh x nw (cv2 INTER_CUBIC when the size changes)
+void launch_ingest_u8(hipStream_t st, const unsigned char *src, int H, int W, int bgr, int nh, int nw, float *out);
 
 // ------------------------------------------------------------------ matcher
 // convert descriptors to fp16 [n][128] (hi) and optional scaled residual (lo)

@@ -1,7 +1,9 @@
-"""Host driver pieces mirroring extract_localization.py (reference): the named confs
-(:25-120), get_model (:208-218) and the per-image post-processing of main (:245-272).
-Image decoding / cubic resize (cv2) and HDF5 writing (h5py) are outside the hot path
-(SURVEY.md section 8f rank 1); features are returned as the dict the reference writes."""
+"""Host driver mirroring extract_localization.py (reference): the named confs (:25-120), ImageDataset (:122-202),
+get_model (:208-218) and main (:221-279).  The decoder is whatever the host has (PIL here; the reference uses
+cv2.imread); everything after the decoder -- astype(float32), the cubic resize_max downsize, / 255, the network,
+selection and descriptors -- runs on the MI355X.  Work lists shard round-robin over `world` processes (one per GPU,
+no data-path collective); rank 0 merges the per-rank parts in index order."""
+import os
 import os.path as osp
 
 import numpy as np
@@ -27,12 +29,14 @@ def _conf(n, r):
 confs = dict(_conf(n, r) for n, r in ((4096, 1600), (3000, 1600), (2000, 1600), (4096, 1024), (3000, 1024), (2000, 1024)))
 
 
-def get_model(model_name, weight_path=None, use_stability=False, state_dict=None, device=0):
+def get_model(model_name, weight_path=None, use_stability=False, state_dict=None, device=0, precision="f32"):
     """extract_localization.py:208-218.  state_dict may be given directly (numpy / torch dict)
-    when the checkpoint is not a file; otherwise weight_path is read with torch.load."""
+    when the checkpoint is not a file; otherwise weight_path is read with torch.load (the reference's
+    {'model': state_dict, ...} checkpoint layout, :213-215).  precision: see ResSegNetV2 -- the drop-in default
+    is the strict parity mode, 'f16' is the explicit throughput switch."""
     if model_name != 'ressegnetv2':
         raise NotImplementedError("only 'ressegnetv2' is on the hot path (SURVEY.md section 2 #1)")
-    model = ResSegNetV2(outdim=128, require_stability=use_stability).eval()
+    model = ResSegNetV2(outdim=128, require_stability=use_stability, precision=precision).eval()
     if state_dict is None:
         import torch
         if not osp.exists(weight_path):
@@ -49,6 +53,83 @@ def rescale_keypoints(keypoints, original_size, size):
     return (keypoints + .5) * scales[None] - .5
 
 
+def resized_shape(w, h, resize_max=None, resize_force=False):
+    """extract_localization.py:172-175 -> (w_new, h_new), or (w, h) when the image is left alone."""
+    if resize_max and (resize_force or max(w, h) > resize_max):
+        scale = resize_max / max(h, w)
+        return int(round(w * scale)), int(round(h * scale))
+    return w, h
+
+
+def _read_rgb_u8(path):
+    """The decoder: uint8 [H,W,3] RGB (the reference: cv2.imread(..., IMREAD_COLOR)[:, :, ::-1], :162-165)."""
+    try:
+        from PIL import Image
+    except Exception as e:  # pragma: no cover
+        raise RuntimeError("no image decoder importable (PIL); pass decoded uint8 arrays instead of paths") from e
+    try:
+        with Image.open(path) as im:
+            return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
+    except (OSError, ValueError) as e:
+        raise ValueError(f'Cannot read image {str(path)}.') from e   # extract_localization.py:166-167
+
+
+class ImageDataset:
+    """extract_localization.py:122-202 without torch's Dataset base: same default_conf, the same file discovery
+    (globs under root, or an image list), __getitem__ -> {'name', 'image', 'original_size'}.  'image' is the DECODED
+    uint8 [H,W,3] RGB array; the float conversion and the cubic resize happen on the device (preprocess below), so
+    'resize' carries the target (w, h) instead of the resized pixels.  grayscale is not on the SFD2 path."""
+    default_conf = {
+        'globs': ['*.jpg', '*.png', '*.jpeg', '*.JPG', '*.PNG'],
+        'grayscale': False,
+        'resize_max': None,
+        'resize_force': False,
+    }
+
+    def __init__(self, root, conf, image_list=None, mask_root=None):
+        from pathlib import Path
+        self.conf = {**self.default_conf, **conf}
+        if self.conf['grayscale']:
+            raise NotImplementedError("grayscale input is not used by the ressegnetv2 confs")
+        self.root = Path(root)
+        self.paths = []
+        if image_list is None:
+            for g in self.conf['globs']:
+                self.paths += list(self.root.glob('**/' + g))
+            if len(self.paths) == 0:
+                raise ValueError(f'Could not find any image in root: {root}.')
+            self.paths = sorted(i.relative_to(self.root) for i in self.paths)
+        else:
+            with open(image_list, "r") as f:
+                self.paths = [Path(l.strip()) for l in f.readlines() if l.strip()]
+        self.mask_root = mask_root
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, idx):
+        path = self.paths[idx]
+        image = _read_rgb_u8(self.root / path)
+        h, w = image.shape[:2]
+        return {'name': str(path), 'image': image, 'original_size': np.array((w, h)),
+                'resize': resized_shape(w, h, self.conf['resize_max'], self.conf['resize_force'])}
+
+
+def preprocess(model, image_u8, resize=None, bgr=False):
+    """uint8 [H,W,3] -> torch cuda float32 [1,3,h,w] in [0,1]: ImageDataset.__getitem__'s astype / cv2.resize(INTER_CUBIC) /
+    transpose / 255 (:168-186) on the device (sfd2_preprocess)."""
+    import torch
+    from . import _lib
+    ctx = model.context
+    H, W = image_u8.shape[:2]
+    w_new, h_new = resize if resize is not None else (W, H)
+    out = torch.empty((1, 3, h_new, w_new), dtype=torch.float32, device=torch.device("cuda", ctx.device))
+    a = np.ascontiguousarray(image_u8, dtype=np.uint8)
+    _lib.check(ctx.lib.sfd2_preprocess(ctx.h, a.ctypes.data, 0, H, W, _lib.FLAG_IMG_BGR if bgr else 0, h_new, w_new,
+                                       out.data_ptr()))
+    return out
+
+
 def extract_one(model, extractor, image, original_size, conf):
     """One iteration of main's loop (extract_localization.py:245-272): image [1,3,H,W] in [0,1].
     Returns the group the reference writes: keypoints (N,2) f64, descriptors (128,N) f64,
@@ -62,27 +143,52 @@ def extract_one(model, extractor, image, original_size, conf):
     return pred
 
 
-def main(conf, images, export_dir, state_dict=None, device=0, tag=None):
-    """extract_localization.py:221-275 without the image decoder: ``images`` yields
-    {'name': str, 'image': uint8 [H,W,3] RGB (or float [3,H,W] in [0,1]), 'original_size': (w, h)}
-    (what ImageDataset.__getitem__ returns before / after its astype-and-divide, :157-190); one
-    group per image goes to the feature store with the reference's dataset names and dtypes.
-    uint8 images are converted on the device.  Returns the store path."""
-    import os
+def _part_path(export_dir, conf, rank, world):
+    base = os.path.join(str(export_dir), conf['output'])
+    return base + '.h5' if world == 1 else f'{base}.part{rank}of{world}.h5'
+
+
+def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precision="f32", world=1, rank=0,
+         barrier=None, model_and_extractor=None):
+    """extract_localization.py:221-279.  ``images``: an ImageDataset (decoded from files, resized per
+    conf['preprocessing']) or any indexable / iterable of {'name', 'image': uint8 [H,W,3] RGB or float [3,H,W] in
+    [0,1], 'original_size': (w, h)[, 'resize': (w, h)]}.  uint8 input is exact only together with the device resize
+    or for images that need none: the reference resizes the FLOAT image (:168-177), which a caller-side uint8 resize
+    cannot reproduce.  One group per image goes to the feature store with the reference's dataset names and dtypes.
+
+    Multi-GPU: with world > 1 this process takes items rank, rank + world, ... (extract_localization.py:240
+    is the loop that shards), writes them to its own part store and, after ``barrier()`` (torch.distributed.barrier
+    or equivalent; one process per GPU), rank 0 merges the parts into the final store in item order.
+    Returns the final store path (rank 0) or the part path (other ranks)."""
     from .feature_io import open_store, write_features
-    model, extractor = get_model(conf['model']['name'], weight_path=conf['model']['model_fn'],
-                                 use_stability=conf['model']['use_stability'], state_dict=state_dict, device=device)
+    from .sharding import shard_indices
+    if model_and_extractor is None:
+        model, extractor = get_model(conf['model']['name'], weight_path=conf['model']['model_fn'],
+                                     use_stability=conf['model']['use_stability'], state_dict=state_dict, device=device,
+                                     precision=precision)
+    else:
+        model, extractor = model_and_extractor
     os.makedirs(str(export_dir), exist_ok=True)
-    path = os.path.join(str(export_dir), conf['output'] + '.h5')
-    store = open_store(path, 'a')
+    if not hasattr(images, '__getitem__'):
+        images = list(images)
+    n_items = len(images)
+    path = _part_path(export_dir, conf, rank, world)
+    store = open_store(path, 'a' if world == 1 else 'w')
+    names = []
     try:
-        for data in images:
+        for idx in shard_indices(n_items, rank, world):
+            data = images[idx]
             if tag is not None and data['name'].find(tag) < 0:
                 continue
             img = data['image']
             if img.dtype == np.uint8:
-                size = np.array(img.shape[:2][::-1])
-                feed = img
+                H, W = img.shape[:2]
+                resize = tuple(data.get('resize', (W, H)))
+                if resize != (W, H):
+                    feed = preprocess(model, img, resize)       # device: float, cubic resize, / 255
+                    size = np.array(resize)
+                else:
+                    feed, size = img, np.array((W, H))          # converted while conv1a stages its patch
             else:
                 size = np.array(img.shape[-2:][::-1])
                 feed = img[None] if img.ndim == 3 else img
@@ -92,6 +198,43 @@ def main(conf, images, export_dir, state_dict=None, device=0, tag=None):
             pred['image_size'] = original_size = np.asarray(data['original_size'])
             pred['keypoints'] = rescale_keypoints(pred['keypoints'], original_size, size)
             write_features(store, data['name'], pred)
+            names.append((idx, data['name']))
+        actual = getattr(store, 'path', getattr(store, 'filename', path))
     finally:
         store.close()
-    return getattr(store, 'path', path)
+    if world == 1:
+        return actual
+    import json
+    with open(path + '.index.json', 'w') as f:      # (item index, group name) in this rank's write order
+        json.dump(names, f)
+    if barrier is not None:
+        barrier()
+    if rank != 0:
+        return actual
+    return merge_parts(export_dir, conf, world)
+
+
+def merge_parts(export_dir, conf, world):
+    """Rank 0, after every rank has closed its part: copy the groups of the `world` part stores into the final
+    store in item order (each part carries an index of (item index, group name))."""
+    import json
+    from .feature_io import open_store, write_features
+    items = []
+    for r in range(world):
+        with open(_part_path(export_dir, conf, r, world) + '.index.json') as f:
+            items += [(int(i), name, r) for i, name in json.load(f)]
+    items.sort()
+    final = open_store(_part_path(export_dir, conf, 0, 1), 'a')
+    parts = [open_store(_part_path(export_dir, conf, r, world), 'r') for r in range(world)]
+    try:
+        for _, name, r in items:
+            if name in final:
+                continue
+            g = parts[r][name]
+            write_features(final, name, {k: np.asarray(g[k].__array__()) for k in g.keys()})
+        actual = getattr(final, 'path', getattr(final, 'filename', None))
+    finally:
+        final.close()
+        for p in parts:
+            p.close()
+    return actual

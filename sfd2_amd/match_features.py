@@ -1,6 +1,8 @@
 """Host driver pieces mirroring hloc/match_features.py (reference): confs (:20-45), pair
 naming and de-duplication (:87-97), the per-pair call (:99-119) with the int16 / fp16 casts
 of the stored results.  HDF5 I/O (h5py) is outside the hot path."""
+import os
+
 import numpy as np
 
 from . import matchers
@@ -50,19 +52,33 @@ def load_matcher(conf):
     return Model(conf['model']).eval().to('cuda')
 
 
-def main(conf, pair_list, features, export_dir, pairs_name='pairs'):
+def _out_path(export_dir, features, conf, pairs_name, rank, world):
+    base = os.path.join(str(export_dir), f'{features}-{conf["output"]}-{pairs_name}')
+    return base + '.h5' if world == 1 else f'{base}.part{rank}of{world}.h5'
+
+
+def main(conf, pair_list, features, export_dir, pairs_name='pairs', world=1, rank=0, barrier=None, model=None):
     """hloc/match_features.py:48-123: ``pair_list`` holds the pairs file's lines ("name0 name1"),
     ``features`` the feature store's name inside export_dir (:52-54).  Skips pairs already matched in
     either order or already stored (:88-97), writes matches0 int16 / matching_scores0 fp16 per pair
-    (:108-116) into <features>-<conf output>-<pairs_name> (:81-82)."""
-    import os
+    (:108-116) into <features>-<conf output>-<pairs_name> (:81-82).
+
+    Multi-GPU (:90 is the loop that shards): the de-duplicated pair list is dealt round-robin over
+    `world` processes (one per GPU); each writes a part store, and after ``barrier()`` rank 0 merges the parts in
+    pair order.  ``model``: a ready matcher (tests inject a stub on CPU); default = the conf's HIP matcher."""
+    import json
     from .feature_io import open_store, write_matches
-    model = load_matcher(conf)
+    from .sharding import shard_indices
+    if model is None:
+        model = load_matcher(conf)
     feats = open_store(os.path.join(str(export_dir), features + '.h5'), 'r')
-    out_path = os.path.join(str(export_dir), f'{features}-{conf["output"]}-{pairs_name}.h5')
-    store = open_store(out_path, 'a')
+    out_path = _out_path(export_dir, features, conf, pairs_name, rank, world)
+    store = open_store(out_path, 'a' if world == 1 else 'w')
+    pairs = unique_pairs(pair_list)
+    done = []
     try:
-        for name0, name1 in unique_pairs(pair_list):
+        for idx in shard_indices(len(pairs), rank, world):
+            name0, name1 = pairs[idx]
             pair = names_to_pair(name0, name1)
             if pair in store:
                 continue
@@ -71,7 +87,36 @@ def main(conf, pair_list, features, export_dir, pairs_name='pairs'):
                     'descriptors1': np.asarray(f1['descriptors'].__array__(), dtype=np.float32)[None]}
             pred = model(data)
             write_matches(store, pair, pred['matches0'][0], pred['matching_scores0'][0])
+            done.append((idx, pair))
+        actual = getattr(store, 'path', getattr(store, 'filename', out_path))
     finally:
         store.close()
         feats.close()
-    return getattr(store, 'path', out_path)
+    if world == 1:
+        return actual
+    with open(out_path + '.index.json', 'w') as f:
+        json.dump(done, f)
+    if barrier is not None:
+        barrier()
+    if rank != 0:
+        return actual
+    items = []
+    for r in range(world):
+        with open(_out_path(export_dir, features, conf, pairs_name, r, world) + '.index.json') as f:
+            items += [(int(i), pair, r) for i, pair in json.load(f)]
+    items.sort()
+    final = open_store(_out_path(export_dir, features, conf, pairs_name, 0, 1), 'a')
+    parts = [open_store(_out_path(export_dir, features, conf, pairs_name, r, world), 'r') for r in range(world)]
+    try:
+        for _, pair, r in items:
+            if pair in final:
+                continue
+            g = final.create_group(pair)
+            for k in parts[r][pair].keys():
+                g.create_dataset(k, data=np.asarray(parts[r][pair][k].__array__()))   # already int16 / fp16
+        actual = getattr(final, 'path', getattr(final, 'filename', None))
+    finally:
+        final.close()
+        for p in parts:
+            p.close()
+    return actual

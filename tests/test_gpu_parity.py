@@ -39,7 +39,7 @@ def model(synth_sd):
     if not _gpu_ok():
         pytest.fail("no MI355X visible: GPU tests cannot run (there is no CPU fallback)")
     from sfd2_amd.model import ResSegNetV2
-    m = ResSegNetV2(outdim=128, require_stability=True).eval()
+    m = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval()
     m.load_state_dict(synth_sd)
     m.cuda(0)
     return m
@@ -307,7 +307,7 @@ def test_extract_async_device_outputs_equal_sync(model):
 def test_no_stability_and_empty_result(synth_sd):
     from sfd2_amd.extractor import extract_resnet_return
     from sfd2_amd.model import ResSegNetV2
-    m = ResSegNetV2(outdim=128, require_stability=False).eval()
+    m = ResSegNetV2(outdim=128, require_stability=False, precision="f16").eval()
     m.load_state_dict(synth_sd)
     m.cuda(0)
     img = synth.make_image(96, 128, 21)
@@ -736,12 +736,12 @@ def test_fused_resblock_vs_oracle_and_unfused(model, ctx, synth_sd, h, w, seed):
     o_score, o_stab, o_desc = orc.det(synth_sd, x, taps)
     score_u, stab_u, desc_u = model.det(x[None])
     unfused = {k: ctx.debug_activation(k) for k in ("conv4.0", "conv4.1", "conv4.2")}
-    os.environ["SFD2_FUSED_RB"] = "det"
+    ctx.set_option("fuse_det", 1)      # the throughput path's fused kernels at the parity entry point
     try:
         score_f, stab_f, desc_f = model.det(x[None])
         fused = {k: ctx.debug_activation(k) for k in ("conv4.0", "conv4.1", "conv4.2")}
     finally:
-        del os.environ["SFD2_FUSED_RB"]
+        ctx.set_option("fuse_det", 0)
     for k in fused:
         want = taps[k]
         assert fused[k].shape == want.shape
@@ -843,22 +843,19 @@ def test_strict_extract_mask_branch_vs_reference_golden(model_f32, synth_sd, gol
 
 def test_throughput_path_equals_layerwise_path_random_sizes(synth_sd):
     """The throughput path of sfd2_extract (fused stem, fused ResBlocks, aliased activation arena, persistent kernels)
-    against a context created with SFD2_NO_FUSE=1 (one kernel per layer, private buffers) on seeded random image
+    against a context with option "fuse" = 0 (one kernel per layer, private buffers) on seeded random image
     sizes, odd ones included: same key-point set up to near-threshold points, scores and descriptors within fp16
     rounding of the intermediates."""
     from sfd2_amd.model import ResSegNetV2
     from sfd2_amd.extractor import extract_resnet_return
 
     def make(no_fuse):
+        m = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval()
+        m.load_state_dict(synth_sd)
+        m.cuda(0)
         if no_fuse:
-            os.environ["SFD2_NO_FUSE"] = "1"      # read when the context is created
-        try:
-            m = ResSegNetV2(outdim=128, require_stability=True).eval()
-            m.load_state_dict(synth_sd)
-            m.cuda(0)
-            return m
-        finally:
-            os.environ.pop("SFD2_NO_FUSE", None)
+            m.context.set_option("fuse", 0)
+        return m
 
     fused, plain = make(False), make(True)
     rs = np.random.RandomState(123)

@@ -192,3 +192,76 @@ def test_extract_mask_branch_matches_reference(golden_dir, synth_sd, tag):
     np.testing.assert_array_equal(pred["keypoints"], g["keypoints"].astype(np.float64))
     np.testing.assert_allclose(pred["scores"], g["scores"], atol=1e-5, rtol=1e-4)
     np.testing.assert_allclose(pred["descriptors"], g["descriptors"].astype(np.float64), atol=2e-3)
+
+
+# ------------------------------------------------------------------ torch-CPU twin (bench.py's CPU baseline, tools/error_budget.py)
+@pytest.mark.parametrize("tag,h,w,seed,topk", [("96x128_k200", 96, 128, 21, 200), ("480x640_k1024", 480, 640, 0, 1024)])
+def test_torch_twin_vs_reference_golden_and_oracle(golden_dir, synth_sd, tag, h, w, seed, topk):
+    """oracle/torch_twin.py is what bench.py times as the CPU baseline: it must BE the reference's computation --
+    ordered key-point list equal to the reference golden's, descriptors to fp32 round-off, and equal to the C oracle."""
+    from oracle import torch_twin as tt
+    from sfd2_amd import synth
+    g = np.load(os.path.join(golden_dir, f"extract_{tag}.npz"))
+    img = synth.make_image(h, w, seed)
+    got = tt.extract(tt.Twin(synth_sd), img, conf_th=0.001, topK=topk)
+
+    def same_list(ref_kp, ref_sc, ref_de, de_tol):
+        # the twin folds bias + BatchNorm into one scale / shift after the convolution (as the HIP epilogue does), so
+        # scores differ from the reference's conv-bias-then-BN by fp32 round-off: the ordered list is equal up to swaps
+        # of near-equal scores
+        mine = {(float(x), float(y)): i for i, (x, y) in enumerate(got["keypoints"])}
+        rank = np.array([mine.get((float(x), float(y)), -1) for x, y in ref_kp])
+        found = rank >= 0
+        assert found.mean() >= 0.995, found.mean()
+        assert np.abs(rank[found] - np.flatnonzero(found)).max() <= 3
+        np.testing.assert_allclose(got["scores"][rank[found]], ref_sc[found], rtol=2e-4)
+        assert np.abs(got["descriptors"][rank[found]] - ref_de[found]).max() <= de_tol
+
+    same_list(g["keypoints"], g["scores"].astype(np.float64), g["descriptors"].astype(np.float64), 1e-3)   # fixture stores fp16
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk)
+    same_list(want["keypoints"], want["scores"], want["descriptors"], 1e-5)
+
+
+def test_torch_twin_matcher_vs_oracle():
+    from oracle import torch_twin as tt
+    from sfd2_amd import synth
+    d0, d1 = synth.make_descriptors(700, seed=1), synth.make_descriptors(900, seed=2)
+    d1[:300] = d0[100:400] + 0.05 * synth.make_descriptors(300, seed=3)
+    d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+    a = tt.nnm(d0, d1)
+    b = orc.hloc_nearest_neighbor(d0, d1, do_mutual_check=True)
+    np.testing.assert_array_equal(a["matches0"], b["matches0"])
+    np.testing.assert_allclose(a["matching_scores0"], b["matching_scores0"], atol=1e-6)
+
+
+def test_error_budget_policy_rounding():
+    """The rounding modes tools/error_budget.py uses: f16x2 keeps ~22 bits, f16 11, bf16 8."""
+    import torch
+    from oracle import torch_twin as tt
+    x = torch.linspace(0.1, 3.0, 1001)
+    for mode, tol in (("f16", 2 ** -11), ("bf16", 2 ** -8), ("f16x2", 2 ** -21), ("f32", 0.0)):
+        err = ((tt.rnd(x, mode) - x).abs() / x).max().item()
+        assert err <= tol, (mode, err)
+
+
+# ------------------------------------------------------------------ cv2 INTER_CUBIC restatement (parity unpinned: cv2 absent)
+def test_cv2_cubic_restatement_invariants():
+    """cv2 is not installed here, so orc.cv2_resize_cubic is checked against the algorithm's own invariants: constants are
+    reproduced, a linear ramp is reproduced away from the replicated border (cubic convolution has linear precision),
+    the four weights are the Keys a = -0.75 kernel and sum to one, the 2:1 downscale of OpenCV's documented example
+    (pixel centres at 2d + 0.5) uses weights (-0.09375, 0.59375, 0.59375, -0.09375)."""
+    c = orc._cubic_coeffs(np.array([0.0, 0.5, 0.25], np.float32))
+    np.testing.assert_allclose([k[0] for k in c], [0, 1, 0, 0], atol=1e-7)
+    np.testing.assert_allclose([k[1] for k in c], [-0.09375, 0.59375, 0.59375, -0.09375], atol=1e-7)
+    np.testing.assert_allclose(sum(k[2] for k in c), 1.0, atol=1e-6)
+    const = np.full((20, 30, 3), 77, np.float32)
+    np.testing.assert_allclose(orc.cv2_resize_cubic(const, (17, 11)), 77.0, atol=2e-5)
+    ramp = np.tile(np.arange(64, dtype=np.float32)[None, :, None], (40, 1, 3))
+    r = orc.cv2_resize_cubic(ramp, (32, 20))
+    np.testing.assert_allclose(r[5, 2:-2, 0], ((np.arange(32) + 0.5) * 2 - 0.5)[2:-2], atol=1e-4)
+    row = np.arange(16, dtype=np.float32) ** 2
+    img = np.tile(row[None, :, None], (8, 1, 1))
+    out = orc.cv2_resize_cubic(img, (8, 8))[3, 3, 0]        # taps 5, 6, 7, 8 at fx = 0.5
+    assert abs(out - (-0.09375 * 25 + 0.59375 * 36 + 0.59375 * 49 - 0.09375 * 64)) < 1e-4
+    item, size = orc.image_dataset_item((np.arange(50 * 70 * 3) % 251).astype(np.uint8).reshape(50, 70, 3), resize_max=35)
+    assert item.shape == (3, 25, 35) and tuple(size) == (70, 50) and item.dtype == np.float32

@@ -16,7 +16,7 @@ sd = synth.make_state_dict(0)
 
 
 def lane(seed, H, W, K, KDB):
-    m = ResSegNetV2(outdim=128, require_stability=True).eval()
+    m = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval()
     m.load_state_dict(sd)
     m.cuda(0)
     img = torch.from_numpy(synth.make_image(H, W, seed)).to(dev)

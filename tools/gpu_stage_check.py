@@ -67,7 +67,7 @@ def check_det(model, sd, h, w, seed):
 def main():
     big = "--big" in sys.argv
     sd = synth.make_state_dict(0)
-    model = ResSegNetV2(outdim=128, require_stability=True).eval()
+    model = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval()
     model.load_state_dict(sd)
     model.cuda()
     ctx = model.context

@@ -15,7 +15,7 @@ from sfd2_amd.model import ResSegNetV2
 hip = ctypes.CDLL("libamdhip64.so")
 H, W, K, KDB, N = 1200, 1600, 4096, 50, 60
 dev = torch.device("cuda", 0)
-m = ResSegNetV2(outdim=128, require_stability=True).eval()
+m = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval()
 m.load_state_dict(synth.make_state_dict(0))
 m.cuda(0)
 ctx = m.context
