@@ -994,21 +994,25 @@ void launch_ms_merge(hipStream_t st, int n_levels, const int *offsets, const uns
 // source coordinate (d + 0.5) * (src / dst) - 0.5 evaluated in double and rounded to float, taps sx-1 .. sx+2 with
 // replicated borders, no clamping of the overshoot.  Products and sums in the order the scalar code writes them, with
 // contraction forbidden (__fmul_rn / __fadd_rn) so the oracle's numpy restatement is reproduced bit for bit.
+// HIP's __fmul_rn / __fadd_rn are header inlines compiled under the default contract mode, so they still fuse; the
+// arithmetic below is therefore written with plain operators lexically under `fp contract(off)`.
 __device__ __forceinline__ void cubic_coeffs(float x, float *c)
 {
+#pragma clang fp contract(off)
     const float A = -0.75f;
-    const float x1 = __fadd_rn(x, 1.0f);
-    c[0] = __fsub_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fsub_rn(__fmul_rn(A, x1), 5.0f * A), x1), 8.0f * A), x1), 4.0f * A);
-    c[1] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(A + 2.0f, x), A + 3.0f), x), x), 1.0f);
-    const float y = __fsub_rn(1.0f, x);
-    c[2] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(A + 2.0f, y), A + 3.0f), y), y), 1.0f);
-    c[3] = __fsub_rn(__fsub_rn(__fsub_rn(1.0f, c[0]), c[1]), c[2]);
+    const float x1 = x + 1.0f;
+    c[0] = ((A * x1 - 5.0f * A) * x1 + 8.0f * A) * x1 - 4.0f * A;
+    c[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    const float y = 1.0f - x;
+    c[2] = ((A + 2.0f) * y - (A + 3.0f)) * y * y + 1.0f;
+    c[3] = 1.0f - c[0] - c[1] - c[2];
 }
 
 __global__ __launch_bounds__(NT)
 void ingest_u8_kernel(const unsigned char *__restrict__ src, int H, int W, int bgr, int nh, int nw, double scale_x,
                       double scale_y, float *__restrict__ out /*[3][nh][nw]*/)
 {
+#pragma clang fp contract(off)
     const int ox = blockIdx.x * blockDim.x + threadIdx.x;
     const int oy = blockIdx.y;
     if (ox >= nw) return;
@@ -1021,11 +1025,12 @@ void ingest_u8_kernel(const unsigned char *__restrict__ src, int H, int W, int b
         }
         return;
     }
-    float fx = (float)((ox + 0.5) * scale_x - 0.5);
-    float fy = (float)((oy + 0.5) * scale_y - 0.5);
+    const double dx = (ox + 0.5) * scale_x, dy = (oy + 0.5) * scale_y;
+    float fx = (float)(dx - 0.5);
+    float fy = (float)(dy - 0.5);
     const int sx = (int)floorf(fx), sy = (int)floorf(fy);
-    fx = __fsub_rn(fx, (float)sx);
-    fy = __fsub_rn(fy, (float)sy);
+    fx = fx - (float)sx;
+    fy = fy - (float)sy;
     float a[4], b[4];
     cubic_coeffs(fx, a);
     cubic_coeffs(fy, b);
@@ -1042,16 +1047,16 @@ void ingest_u8_kernel(const unsigned char *__restrict__ src, int H, int W, int b
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const unsigned char *row = src + (size_t)ys[r] * W * 3 + cs;
-            float acc = __fmul_rn((float)row[xs[0] * 3], a[0]);
-            acc = __fadd_rn(acc, __fmul_rn((float)row[xs[1] * 3], a[1]));
-            acc = __fadd_rn(acc, __fmul_rn((float)row[xs[2] * 3], a[2]));
-            acc = __fadd_rn(acc, __fmul_rn((float)row[xs[3] * 3], a[3]));
+            float acc = (float)row[xs[0] * 3] * a[0];
+            acc = acc + (float)row[xs[1] * 3] * a[1];
+            acc = acc + (float)row[xs[2] * 3] * a[2];
+            acc = acc + (float)row[xs[3] * 3] * a[3];
             rows[r] = acc;
         }
-        float v = __fmul_rn(rows[0], b[0]);
-        v = __fadd_rn(v, __fmul_rn(rows[1], b[1]));
-        v = __fadd_rn(v, __fmul_rn(rows[2], b[2]));
-        v = __fadd_rn(v, __fmul_rn(rows[3], b[3]));
+        float v = rows[0] * b[0];
+        v = v + rows[1] * b[1];
+        v = v + rows[2] * b[2];
+        v = v + rows[3] * b[3];
         out[c * plane + (size_t)oy * nw + ox] = __fdiv_rn(v, 255.0f);
     }
 }
