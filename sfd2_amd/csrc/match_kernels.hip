@@ -328,86 +328,78 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
 }
 
 // ---------------------------------------------------------------- single-GEMM mutual NN (top-1 both ways)
-// The two directions of the mutual check are the row and the column maxima of ONE similarity matrix.
-// With candidates on the MFMA rows and queries on the columns, the row direction is lane-local (as
-// above).  The column direction (best query per candidate) is reduced here without a second GEMM:
-//   1. element-wise max of the wave's two query tiles               (16 v_max per 32 candidates)
-//   2. max over the 32 lanes of each half-wave with DPP row shifts + one row broadcast
-//      (5 v_max_dpp per register; the result sits in lanes 31 / 63)
-//   3. only if a candidate's running best (kept in LDS) is beaten: recover the winning query from
-//      ballots and publish (value, query) with one 64-bit LDS atomic max.
-// Per block the column results are partial (its 256 queries); the finalize step merges blocks.
-__device__ __forceinline__ unsigned int f32_ord(float v)
-{
-    const unsigned int b = __float_as_uint(v);
-    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);   // order-preserving map float -> uint
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_max(float v)
-{
-    const int t = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-    return fmaxf(v, __int_as_float(t));
-}
-__device__ __forceinline__ float half_wave_max_to_last_lane(float v)
-{
-    v = dpp_max<0x111, 0xf>(v);   // row_shr:1
-    v = dpp_max<0x112, 0xf>(v);   // row_shr:2
-    v = dpp_max<0x114, 0xf>(v);   // row_shr:4
-    v = dpp_max<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every 16-lane row holds the row maximum
-    v = dpp_max<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold the half-wave maximum
-    return v;
-}
-
-#define MF_CHUNK 1024   // candidates per block (LDS column state): 8 KB keys + 4 KB filter values
+// The two directions of the mutual check are the row and the column maxima of ONE similarity matrix, so the top-1
+// modes (NNM / ONN, it_loc nnm: hloc/matchers/nearest_neighbor.py:38-57, it_loc/matcher.py:122-130) need one GEMM, not
+// two.  Orientation here: QUERIES are the MFMA rows (A operand, a wave keeps its 64 queries in registers), CANDIDATES
+// the columns (B operand, streamed through LDS).  In the 32x32 C layout a lane owns 16 query rows of ONE candidate
+// column, so per 32 x 32 sub-tile:
+//   forward (best candidate per query): 16 element-wise running maxima per lane, kept across the whole sweep, with the
+//       candidate TILE id packed into the 7 low mantissa bits (127 - tile: the lower tile wins among equal values).  The
+//       32-lane reduction happens once per sweep, through an LDS transposition, not per tile.
+//   reverse (best query per candidate): a 16 -> 1 in-lane maximum with the register id packed into 4 bits, the two query
+//       tiles and the two half-waves merged with two more id bits, one 128-byte store per tile: a per-strip partial
+//       [n0 / 64][n1] that match_mutual_reduce folds.
+// ~8 VALU instructions per MFMA instead of a second GEMM.  Packing perturbs a similarity by <= 2^-16 relative, far below
+// the fp16-operand error (1.5e-4); ties between values equal after truncation go to the lower index.
+#define MQ_NEG (-1.0e30f)     // "no value": finite, so that or-ing id bits into it cannot make a NaN
+#define MQ_TILE_BITS 7
+#define MQ_MAX_CHUNK (32 << MQ_TILE_BITS)   // candidates per split: the tile id must fit MQ_TILE_BITS
 
 __global__ __launch_bounds__(NT, 2)
 void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const half_t *__restrict__ zero_page)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long *colkey = reinterpret_cast<unsigned long long *>(smem + 2 * TA2 * 256);   // [MF_CHUNK]
-    float *colbest = reinterpret_cast<float *>(colkey + MF_CHUNK);                               // [MF_CHUNK]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][TA2][256 B]; at the end [4][64][32] floats
     const MatchJob2 job = jobs[blockIdx.z];
-    const int na = job.n1, nb = job.n0;          // a = database (candidates), b = queries
+    const int n1 = job.n1, n0 = job.n0;          // candidates, queries
     const int i_base = blockIdx.x * 256;
-    if (i_base >= nb) return;
+    if (i_base >= n0) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lcol = lane & 31, lhi = lane >> 5;
 
-    int chunk = (na + splits - 1) / splits;
+    int chunk = (n1 + splits - 1) / splits;
     chunk = (chunk + 31) & ~31;
     const int ja0 = blockIdx.y * chunk;
     int ja1 = ja0 + chunk;
-    if (ja1 > na) ja1 = na;
+    if (ja1 > n1) ja1 = n1;
 
-    for (int j = tid; j < MF_CHUNK; j += NT) { colkey[j] = 0ull; colbest[j] = -INFINITY; }
-
-    h8_t bq[2][8];
-    float qmask[2];
+    const int q0 = i_base + wave * 64;
+    const bool wave_active = q0 < n0;                 // wave-uniform
+    const bool partial_q = q0 + 64 > n0;              // some query row of this wave is padding
+    h8_t aq[2][8];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int qi = i_base + wave * 64 + t * 32 + lcol;
-        qmask[t] = qi < nb ? 0.0f : -INFINITY;
+        const int qi = q0 + t * 32 + lcol;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             h8_t z;
 #pragma unroll
             for (int e = 0; e < 8; ++e) z[e] = (half_t)0.0f;
-            bq[t][ks] = z;
-            if (qi < nb) bq[t][ks] = *reinterpret_cast<const h8_t *>(job.q_hi + (size_t)qi * KD + ks * 16 + lhi * 8);
+            aq[t][ks] = z;
+            if (qi < n0) aq[t][ks] = *reinterpret_cast<const h8_t *>(job.q_hi + (size_t)qi * KD + ks * 16 + lhi * 8);
         }
     }
-    const bool partial_q = i_base + wave * 64 + 64 > nb;     // wave-uniform: some query column is padding
-    float b1[2] = {-INFINITY, -INFINITY};
-    int i1[2] = {0, 0};
+    float rm[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rm[t][r] = MQ_NEG;
     f32x16_t zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+    // reverse id bits 5:4 = (1 - t, 1 - lhi): with the 4 register bits below them, a larger code is a lower-priority
+    // ... a larger code wins the max, so the lower (t, lhi, r) wins among values equal after truncation
+    const unsigned int cb[2] = {0x20u | ((1u - (unsigned)lhi) << 4), (1u - (unsigned)lhi) << 4};
+    float *rk = job.rkeys + (size_t)(blockIdx.x * 4 + wave) * n1;
+    // the mask lives in a VGPR so that (x & keep) | code is ONE v_and_or_b32 (VOP3 on gfx950 takes no literal, and the
+    // tile code is already the one scalar operand)
+    unsigned int keep = ~((1u << MQ_TILE_BITS) - 1u);
+    asm volatile("" : "+v"(keep));
 
     if (ja0 < ja1) {
         const int nst = (ja1 - ja0 + TA2 - 1) / TA2;
         const int srow = lane >> 4;
-#define ISSUE_A(stage_, buf_)                                                                            \
+#define ISSUE_B(stage_, buf_)                                                                            \
     _Pragma("unroll") for (int c = 0; c < TA2 / 16; ++c) {                                               \
         const int row = (wave * (TA2 / 16) + c) * 4 + srow;                                              \
         const int slot = (lane & 15) ^ (row & 15);                                                       \
@@ -416,127 +408,93 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const h
         __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                              \
                                          (lds_void_t *)(smem + (buf_)*TA2 * 256 + (wave * (TA2 / 16) + c) * 1024), 16, 0, 0); \
     }
-        ISSUE_A(0, 0)
+        ISSUE_B(0, 0)
         __syncthreads();
         for (int s = 0; s < nst; ++s) {
             const int buf = s & 1;
-            if (s + 1 < nst) { ISSUE_A(s + 1, buf ^ 1) }
+            if (s + 1 < nst) { ISSUE_B(s + 1, buf ^ 1) }
+            if (wave_active) {
 #pragma unroll
-            for (int sub = 0; sub < TA2 / 32; ++sub) {
-                f32x16_t acc0 = zero16, acc1 = zero16;
-                const int row = sub * 32 + lcol;
-                const unsigned char *arow = smem + (buf * TA2 + row) * 256;
-                const int sw = row & 15;
+                for (int sub = 0; sub < TA2 / 32; ++sub) {
+                    f32x16_t acc0 = zero16, acc1 = zero16;
+                    const int row = sub * 32 + lcol;
+                    const unsigned char *brow = smem + (buf * TA2 + row) * 256;
+                    const int sw = row & 15;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const h8_t a = *reinterpret_cast<const h8_t *>(arow + (((ks * 2 + lhi) ^ sw) << 4));
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[0][ks], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[1][ks], acc1, 0, 0, 0);
-                }
-                const int jloc0 = s * TA2 + sub * 32 + 4 * lhi;          // candidate (within the chunk) of register 0
-                const int jbase = ja0 + jloc0;
-                const bool full = ja0 + s * TA2 + sub * 32 + 32 <= ja1;   // wave-uniform
-                // ---- row direction (best candidate per query): lane-local, lazy index scan
-                if (full) {
-                    float m0 = acc0[0], m1 = acc1[0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) { m0 = fmaxf(m0, acc0[r]); m1 = fmaxf(m1, acc1[r]); }
-                    if (__any(m0 > b1[0])) {
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const h8_t b = *reinterpret_cast<const h8_t *>(brow + (((ks * 2 + lhi) ^ sw) << 4));
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[0][ks], b, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[1][ks], b, acc1, 0, 0, 0);
+                    }
+                    const int tile = s * (TA2 / 32) + sub;
+                    const int jt = ja0 + tile * 32;
+                    const int jcol = jt + lcol;                       // this lane's candidate
+                    if (jt + 32 > ja1 || partial_q) {                 // edge tiles only (wave-uniform, rare)
+                        asm volatile("" ::: "memory");                // keeps this block a branch: if-converted it costs 64 selects per tile
+                        const bool pad_col = jcol >= ja1;             // zero-page rows must never be a maximum
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int j = jbase + (r & 3) + 8 * (r >> 2);
-                            i1[0] = acc0[r] > b1[0] ? j : i1[0]; b1[0] = fmaxf(b1[0], acc0[r]);
+                            const int qr = q0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                            if (pad_col || qr >= n0) acc0[r] = MQ_NEG;
+                            if (pad_col || qr + 32 >= n0) acc1[r] = MQ_NEG;
                         }
                     }
-                    if (__any(m1 > b1[1])) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int j = jbase + (r & 3) + 8 * (r >> 2);
-                            i1[1] = acc1[r] > b1[1] ? j : i1[1]; b1[1] = fmaxf(b1[1], acc1[r]);
-                        }
-                    }
-                } else {
+                    // ---- forward: element-wise running maxima, tile id in the low bits
+                    const unsigned int code = (unsigned)((1 << MQ_TILE_BITS) - 1 - tile);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int j = jbase + (r & 3) + 8 * (r >> 2);
-                        const float v0 = j < ja1 ? acc0[r] : -INFINITY, v1 = j < ja1 ? acc1[r] : -INFINITY;
-                        i1[0] = v0 > b1[0] ? j : i1[0]; b1[0] = fmaxf(b1[0], v0);
-                        i1[1] = v1 > b1[1] ? j : i1[1]; b1[1] = fmaxf(b1[1], v1);
+                        rm[0][r] = fmaxf(rm[0][r], __uint_as_float((__float_as_uint(acc0[r]) & keep) | code));
+                        rm[1][r] = fmaxf(rm[1][r], __uint_as_float((__float_as_uint(acc1[r]) & keep) | code));
                     }
-                }
-                // ---- column direction (best query per candidate)
-                if (partial_q) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { acc0[r] += qmask[0]; acc1[r] += qmask[1]; }
-                }
-                float red[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[r] = half_wave_max_to_last_lane(fmaxf(acc0[r], acc1[r]));
-                // lanes 31 / 63 compare with the running best of their 16 candidates
-                unsigned int imp = 0;
-                if (lcol == 31) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 cb = *reinterpret_cast<const float4 *>(colbest + jloc0 + 8 * g);
-                        const int jg = jbase + 8 * g;
-                        if (red[4 * g + 0] > cb.x && jg + 0 < ja1) imp |= 1u << (4 * g + 0);
-                        if (red[4 * g + 1] > cb.y && jg + 1 < ja1) imp |= 1u << (4 * g + 1);
-                        if (red[4 * g + 2] > cb.z && jg + 2 < ja1) imp |= 1u << (4 * g + 2);
-                        if (red[4 * g + 3] > cb.w && jg + 3 < ja1) imp |= 1u << (4 * g + 3);
-                    }
-                }
-                const unsigned int imp_lo = __builtin_amdgcn_readlane(imp, 31), imp_hi = __builtin_amdgcn_readlane(imp, 63);
-                if (imp_lo | imp_hi) {                       // rare once the running bests have warmed up
+                    // ---- reverse: best of this lane's 2 x 16 query rows, then of the two half-waves
+                    float m0 = MQ_NEG, m1 = MQ_NEG;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        if (((imp_lo | imp_hi) >> r) & 1u) {
-                            const float m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(red[r]), 31));
-                            const float m_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(red[r]), 63));
-                            const float m = lhi ? m_hi : m_lo;
-                            const unsigned long long h0 = __ballot(acc0[r] == m), h1 = __ballot(acc1[r] == m);
-                            const unsigned int my = lhi ? 0xFFFFFFFFu : 0u;   // select this half's 32 ballot bits
-                            const unsigned int b0 = lhi ? (unsigned int)(h0 >> 32) : (unsigned int)h0;
-                            const unsigned int b1m = lhi ? (unsigned int)(h1 >> 32) : (unsigned int)h1;
-                            (void)my;
-                            const bool mine = (((lhi ? imp_hi : imp_lo) >> r) & 1u) != 0;
-                            if (mine && lcol == 31) {
-                                // lowest query index among the maxima: tile 0 first, then the lowest lane
-                                const int qi = b0 ? (__ffs(b0) - 1) : (32 + __ffs(b1m) - 1);
-                                const int i = i_base + wave * 64 + qi;
-                                const int jl = jloc0 + (r & 3) + 8 * (r >> 2);
-                                const unsigned long long key = ((unsigned long long)f32_ord(m) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)i);
-                                atomicMax(&colkey[jl], key);
-                                colbest[jl] = fmaxf(colbest[jl], m);   // a filter only: a stale value just costs one more attempt
-                            }
-                        }
+                        m0 = fmaxf(m0, __uint_as_float((__float_as_uint(acc0[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r)));
+                        m1 = fmaxf(m1, __uint_as_float((__float_as_uint(acc1[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r)));
                     }
+                    const float k0 = __uint_as_float((__float_as_uint(m0) & 0xFFFFFFCFu) | cb[0]);
+                    const float k1 = __uint_as_float((__float_as_uint(m1) & 0xFFFFFFCFu) | cb[1]);
+                    const unsigned int kb = __float_as_uint(fmaxf(k0, k1));
+                    const auto sw2 = __builtin_amdgcn_permlane32_swap(kb, kb, false, false);   // [0] = lanes 0-31's value, [1] = lanes 32-63's, in every lane
+                    const float kk = fmaxf(__uint_as_float(sw2[0]), __uint_as_float(sw2[1]));
+                    if (lhi == 0 && jcol < ja1) rk[jcol] = kk;
                 }
             }
             __syncthreads();
         }
-#undef ISSUE_A
+#undef ISSUE_B
     }
+    // ---- forward: reduce the 32 column classes of every query row through LDS (staging buffers are free now)
+    float *T = reinterpret_cast<float *>(smem) + wave * (64 * 32);
+    if (wave_active) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const float c1 = __shfl_xor(b1[t], 32);
-        const int j1 = __shfl_xor(i1[t], 32);
-        float n1v;
-        int n1i;
-        if (c1 > b1[t] || (c1 == b1[t] && j1 < i1[t])) { n1v = c1; n1i = j1; }
-        else { n1v = b1[t]; n1i = i1[t]; }
-        const int qi = i_base + wave * 64 + t * 32 + lcol;
-        if (lane < 32 && qi < nb) {
-            const size_t o = (size_t)blockIdx.y * nb + qi;
-            job.part_v1[o] = n1v;
-            job.part_i1[o] = n1i;
-        }
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * 32 + lcol] = rm[t][r];
     }
     __syncthreads();
-    // partial column results of this block's queries
-    for (int j = tid; j < ja1 - ja0; j += NT) job.rkeys[(size_t)blockIdx.x * na + ja0 + j] = colkey[j];
+    if (wave_active && q0 + lane < n0) {
+        float best = MQ_NEG;
+        int col = 0;
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) {
+            const float4 v = *reinterpret_cast<const float4 *>(T + lane * 32 + c4 * 4);
+            if (v.x > best) { best = v.x; col = c4 * 4 + 0; }      // strict '>' in column order: lowest candidate among equals
+            if (v.y > best) { best = v.y; col = c4 * 4 + 1; }
+            if (v.z > best) { best = v.z; col = c4 * 4 + 2; }
+            if (v.w > best) { best = v.w; col = c4 * 4 + 3; }
+        }
+        const unsigned int bits = __float_as_uint(best);
+        const int tile = (1 << MQ_TILE_BITS) - 1 - (int)(bits & ((1u << MQ_TILE_BITS) - 1u));
+        const size_t o = (size_t)blockIdx.y * n0 + q0 + lane;
+        const bool any = best > MQ_NEG;
+        job.part_v1[o] = any ? __uint_as_float(bits & ~((1u << MQ_TILE_BITS) - 1u)) : -INFINITY;
+        job.part_i1[o] = any ? ja0 + tile * 32 + col : 0;
+    }
 }
 
-// merges the partials: forward [splits][n0] (value, index), reverse [n_iblocks][n1] packed keys
+// merges the partials: forward [splits][n0] (value, index), reverse [ceil(n0 / 64)][n1] packed (value | 6-bit query id)
 __global__ __launch_bounds__(NT)
 void match_mutual_reduce_kernel(const MatchJob2 *__restrict__ jobs, const MatchFinal *__restrict__ fins, int splits)
 {
@@ -557,17 +515,19 @@ void match_mutual_reduce_kernel(const MatchJob2 *__restrict__ jobs, const MatchF
         f.red_f[(size_t)n + i] = -INFINITY;
         reinterpret_cast<int *>(f.red_f)[2 * (size_t)n + i] = bi;
     } else {
-        const int nib = (job.n0 + 255) / 256;
-        unsigned long long best = 0ull;
-        for (int b = 0; b < nib; ++b) {
-            const unsigned long long k = job.rkeys[(size_t)b * n + i];
-            best = k > best ? k : best;
+        const int nstrip = (job.n0 + 63) / 64;
+        float best = MQ_NEG;
+        int bs = 0;
+        for (int sidx = 0; sidx < nstrip; ++sidx) {       // ascending strips, strict '>': the lower query wins among equals
+            const float k = job.rkeys[(size_t)sidx * n + i];
+            if (k > best) { best = k; bs = sidx; }
         }
-        const unsigned int o = (unsigned int)(best >> 32);
-        const unsigned int bits = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;   // inverse of f32_ord
-        f.red_r[i] = best ? __uint_as_float(bits) : -INFINITY;
+        const unsigned int bits = __float_as_uint(best);
+        const int t = 1 - (int)((bits >> 5) & 1u), lh = 1 - (int)((bits >> 4) & 1u), r = 15 - (int)(bits & 15u);
+        const bool any = best > MQ_NEG;
+        f.red_r[i] = any ? __uint_as_float(bits & 0xFFFFFFC0u) : -INFINITY;
         f.red_r[(size_t)n + i] = -INFINITY;
-        reinterpret_cast<int *>(f.red_r)[2 * (size_t)n + i] = best ? (int)(0xFFFFFFFFu - (unsigned int)(best & 0xFFFFFFFFull)) : 0;
+        reinterpret_cast<int *>(f.red_r)[2 * (size_t)n + i] = any ? bs * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh : 0;
     }
 }
 
@@ -576,7 +536,7 @@ void launch_match_mutual(hipStream_t st, const MatchJob2 *jobs_dev, const MatchF
 {
     if (npairs <= 0 || max_n0 <= 0) return;
     static bool attr = false;
-    const size_t lds = (size_t)2 * TA2 * 256 + (size_t)MF_CHUNK * 12;
+    const size_t lds = (size_t)2 * TA2 * 256;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_mutual_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
@@ -585,6 +545,8 @@ void launch_match_mutual(hipStream_t st, const MatchJob2 *jobs_dev, const MatchF
     const int max_n = max_n0 > max_n1 ? max_n0 : max_n1;
     hipLaunchKernelGGL(match_mutual_reduce_kernel, dim3((max_n + NT - 1) / NT, npairs, 2), dim3(NT), 0, st, jobs_dev, fins_dev, splits);
 }
+
+int match_mutual_max_chunk(void) { return MQ_MAX_CHUNK; }
 
 void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int max_nb, int splits, int use_lo,
                        int need_top2, const half_t *zero_page)

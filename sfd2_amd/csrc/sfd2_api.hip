@@ -1399,12 +1399,20 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
 
     const int need_top2 = (conf->flavour == SFD2_MATCH_ITLOC_NNR) ||
                           (conf->flavour == SFD2_MATCH_HLOC && conf->ratio_threshold > 0.0f);
-    // Experiment (off by default, SFD2_MATCH_ONE_GEMM=1): both directions of the top-1 modes from ONE
-    // GEMM with a DPP column reduction (match_mutual_kernel).  Correct, but VALU-bound: measured
-    // 1103 us vs 470 us for the two-GEMM path on 50 x (4096 x 4096), so the second GEMM stays.
-    const bool single_gemm = !need_lo && !need_top2 && sfd2_env("SFD2_MATCH_ONE_GEMM") != nullptr;
-    if (single_gemm) splits = std::max(splits, (max_n1 + 1023) / 1024);   // the kernel keeps <= 1024 candidates of column state
-    const int nib = (n0 + 255) / 256;
+    // Top-1 modes (NNM / ONN / it_loc nnm) take both directions from ONE GEMM (match_mutual_kernel: element-wise running
+    // maxima for the row direction, in-lane 16 -> 1 maxima for the column direction).  SFD2_MATCH_TWO_GEMM (experiment
+    // builds) restores the two-GEMM kernel for A/B runs; modes that need the second-best value keep it.
+    const bool single_gemm = !need_lo && !need_top2 && sfd2_env("SFD2_MATCH_TWO_GEMM") == nullptr;
+    if (single_gemm) {
+        // one GEMM per pair instead of two: twice the blocks per job for the same tail behaviour
+        const int qblocks = (n0 + 255) / 256;
+        splits = (768 * 6 + k * qblocks - 1) / (k * qblocks);
+        splits = std::max(1, std::min(splits, 8));
+        splits = std::min(splits, std::max(1, (std::max(1, max_n1) + 31) / 32));
+        if (const char *e = sfd2_env("SFD2_MATCH_SPLITS")) splits = std::max(1, std::min(16, atoi(e)));
+        splits = std::max(splits, (max_n1 + match_mutual_max_chunk() - 1) / match_mutual_max_chunk());   // tile id bits
+    }
+    const int nstrip = (n0 + 63) / 64;
 
     HIPCHECK(c->m_stage.ensure(std::max<size_t>(stage_bytes, 256)));
     HIPCHECK(c->m_hi0.ensure((size_t)n0 * 128 * 2));
@@ -1415,7 +1423,7 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     const size_t per_pair_f = (size_t)splits * n0, tot_part = (size_t)k * per_pair_f + (size_t)splits * tot_n1;
     HIPCHECK(c->m_part_f.ensure(std::max<size_t>(tot_part, 1) * 2 * sizeof(float)));
     HIPCHECK(c->m_part_i.ensure(std::max<size_t>(tot_part, 1) * sizeof(int)));
-    if (single_gemm) HIPCHECK(c->m_rkeys.ensure(std::max<size_t>((size_t)nib * tot_n1, 1) * 8));
+    if (single_gemm) HIPCHECK(c->m_rkeys.ensure(std::max<size_t>((size_t)nstrip * tot_n1, 1) * sizeof(float)));
     HIPCHECK(c->m_red.ensure(((size_t)k * n0 + tot_n1 + 1) * 3 * sizeof(float)));
     HIPCHECK(c->m_jobs.ensure((size_t)2 * k * sizeof(MatchJob)));
     HIPCHECK(c->m_fins.ensure((size_t)k * sizeof(MatchFinal)));
@@ -1468,7 +1476,7 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
             MatchJob2 &j2 = jobs2[i];
             j2.q_hi = q_hi; j2.d_hi = h; j2.n0 = n0; j2.n1 = n1;
             j2.part_v1 = pf + 2 * poff; j2.part_i1 = pi + poff;
-            j2.rkeys = c->m_rkeys.as<unsigned long long>() + (size_t)nib * off1;
+            j2.rkeys = c->m_rkeys.as<float>() + (size_t)nstrip * off1;
             poff += (size_t)splits * n0 + (size_t)splits * n1;
             fn.f_v1 = fn.f_v2 = fn.r_v1 = fn.r_v2 = nullptr; fn.f_i1 = fn.r_i1 = nullptr;
         } else {
