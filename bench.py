@@ -180,6 +180,7 @@ def main():
                                                           "per-kernel events are not available then")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-f32 leg")
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the extra untimed-by-contract sustained leg (0 = off)")
+    ap.add_argument("--lib", default=None, help="kernel A/B runs: another build of libsfd2hip.so (sfd2_amd/build.py build_lib(out=...))")
     ap.add_argument("--size", default=None, help="WxH of the synthetic query images (default 1600x1200, the size the metric "
                                                  "is quoted on; e.g. 1024x1024 for BASELINE configs[3])")
     args = ap.parse_args()
@@ -206,6 +207,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from sfd2_amd import _lib, synth
+    if args.lib:
+        _lib.use_library(args.lib)
     from sfd2_amd.model import ResSegNetV2
 
     sd = synth.make_state_dict(0)

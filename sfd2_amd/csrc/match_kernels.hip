@@ -327,176 +327,14 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
     }
 }
 
-// ---------------------------------------------------------------- single-GEMM mutual NN (top-1 both ways)
-// The two directions of the mutual check are the row and the column maxima of ONE similarity matrix, so the top-1
-// modes (NNM / ONN, it_loc nnm: hloc/matchers/nearest_neighbor.py:38-57, it_loc/matcher.py:122-130) need one GEMM, not
-// two.  Orientation here: QUERIES are the MFMA rows (A operand, a wave keeps its 64 queries in registers), CANDIDATES
-// the columns (B operand, streamed through LDS).  In the 32x32 C layout a lane owns 16 query rows of ONE candidate
-// column, so per 32 x 32 sub-tile:
-//   forward (best candidate per query): 16 element-wise running maxima per lane, kept across the whole sweep, with the
-//       candidate TILE id packed into the 7 low mantissa bits (127 - tile: the lower tile wins among equal values).  The
-//       32-lane reduction happens once per sweep, through an LDS transposition, not per tile.
-//   reverse (best query per candidate): a 16 -> 1 in-lane maximum with the register id packed into 4 bits, the two query
-//       tiles and the two half-waves merged with two more id bits, one 128-byte store per tile: a per-strip partial
-//       [n0 / 64][n1] that match_mutual_reduce folds.
-// ~8 VALU instructions per MFMA instead of a second GEMM.  Packing perturbs a similarity by <= 2^-16 relative, far below
-// the fp16-operand error (1.5e-4); ties between values equal after truncation go to the lower index.
-#define MQ_NEG (-1.0e30f)     // "no value": finite, so that or-ing id bits into it cannot make a NaN
-#define MQ_TILE_BITS 7
-#define MQ_MAX_CHUNK (32 << MQ_TILE_BITS)   // candidates per split: the tile id must fit MQ_TILE_BITS
+// ---------------------------------------------------------------- single-GEMM mutual NN: match_mutual_kernel.hip
+#define MQ_NEG (-0x1p100f)
+void launch_match_mutual_gemm(hipStream_t st, const MatchJob2 *jobs_dev, int npairs, int max_n0, int splits, const half_t *zero_page);
+int match_mutual_strip(void);
 
-__global__ __launch_bounds__(NT, 2)
-void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const half_t *__restrict__ zero_page)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][TA2][256 B]; at the end [4][64][32] floats
-    const MatchJob2 job = jobs[blockIdx.z];
-    const int n1 = job.n1, n0 = job.n0;          // candidates, queries
-    const int i_base = blockIdx.x * 256;
-    if (i_base >= n0) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lcol = lane & 31, lhi = lane >> 5;
-
-    int chunk = (n1 + splits - 1) / splits;
-    chunk = (chunk + 31) & ~31;
-    const int ja0 = blockIdx.y * chunk;
-    int ja1 = ja0 + chunk;
-    if (ja1 > n1) ja1 = n1;
-
-    const int q0 = i_base + wave * 64;
-    const bool wave_active = q0 < n0;                 // wave-uniform
-    const bool partial_q = q0 + 64 > n0;              // some query row of this wave is padding
-    h8_t aq[2][8];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int qi = q0 + t * 32 + lcol;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            h8_t z;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (half_t)0.0f;
-            aq[t][ks] = z;
-            if (qi < n0) aq[t][ks] = *reinterpret_cast<const h8_t *>(job.q_hi + (size_t)qi * KD + ks * 16 + lhi * 8);
-        }
-    }
-    float rm[2][16];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rm[t][r] = MQ_NEG;
-    f32x16_t zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
-    // reverse id bits 5:4 = (1 - t, 1 - lhi): with the 4 register bits below them, a larger code is a lower-priority
-    // ... a larger code wins the max, so the lower (t, lhi, r) wins among values equal after truncation
-    const unsigned int cb[2] = {0x20u | ((1u - (unsigned)lhi) << 4), (1u - (unsigned)lhi) << 4};
-    float *rk = job.rkeys + (size_t)(blockIdx.x * 4 + wave) * n1;
-    // the mask lives in a VGPR so that (x & keep) | code is ONE v_and_or_b32 (VOP3 on gfx950 takes no literal, and the
-    // tile code is already the one scalar operand)
-    unsigned int keep = ~((1u << MQ_TILE_BITS) - 1u);
-    asm volatile("" : "+v"(keep));
-
-    if (ja0 < ja1) {
-        const int nst = (ja1 - ja0 + TA2 - 1) / TA2;
-        const int srow = lane >> 4;
-#define ISSUE_B(stage_, buf_)                                                                            \
-    _Pragma("unroll") for (int c = 0; c < TA2 / 16; ++c) {                                               \
-        const int row = (wave * (TA2 / 16) + c) * 4 + srow;                                              \
-        const int slot = (lane & 15) ^ (row & 15);                                                       \
-        const int ja = ja0 + (stage_)*TA2 + row;                                                         \
-        const half_t *src = ja < ja1 ? job.d_hi + (size_t)ja * KD + slot * 8 : zero_page + (lane & 3) * 8; \
-        __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                              \
-                                         (lds_void_t *)(smem + (buf_)*TA2 * 256 + (wave * (TA2 / 16) + c) * 1024), 16, 0, 0); \
-    }
-        ISSUE_B(0, 0)
-        __syncthreads();
-        for (int s = 0; s < nst; ++s) {
-            const int buf = s & 1;
-            if (s + 1 < nst) { ISSUE_B(s + 1, buf ^ 1) }
-            if (wave_active) {
-#pragma unroll
-                for (int sub = 0; sub < TA2 / 32; ++sub) {
-                    f32x16_t acc0 = zero16, acc1 = zero16;
-                    const int row = sub * 32 + lcol;
-                    const unsigned char *brow = smem + (buf * TA2 + row) * 256;
-                    const int sw = row & 15;
-#pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) {
-                        const h8_t b = *reinterpret_cast<const h8_t *>(brow + (((ks * 2 + lhi) ^ sw) << 4));
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[0][ks], b, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[1][ks], b, acc1, 0, 0, 0);
-                    }
-                    const int tile = s * (TA2 / 32) + sub;
-                    const int jt = ja0 + tile * 32;
-                    const int jcol = jt + lcol;                       // this lane's candidate
-                    if (jt + 32 > ja1 || partial_q) {                 // edge tiles only (wave-uniform, rare)
-                        asm volatile("" ::: "memory");                // keeps this block a branch: if-converted it costs 64 selects per tile
-                        const bool pad_col = jcol >= ja1;             // zero-page rows must never be a maximum
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int qr = q0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                            if (pad_col || qr >= n0) acc0[r] = MQ_NEG;
-                            if (pad_col || qr + 32 >= n0) acc1[r] = MQ_NEG;
-                        }
-                    }
-                    // ---- forward: element-wise running maxima, tile id in the low bits
-                    const unsigned int code = (unsigned)((1 << MQ_TILE_BITS) - 1 - tile);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        rm[0][r] = fmaxf(rm[0][r], __uint_as_float((__float_as_uint(acc0[r]) & keep) | code));
-                        rm[1][r] = fmaxf(rm[1][r], __uint_as_float((__float_as_uint(acc1[r]) & keep) | code));
-                    }
-                    // ---- reverse: best of this lane's 2 x 16 query rows, then of the two half-waves
-                    float m0 = MQ_NEG, m1 = MQ_NEG;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        m0 = fmaxf(m0, __uint_as_float((__float_as_uint(acc0[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r)));
-                        m1 = fmaxf(m1, __uint_as_float((__float_as_uint(acc1[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r)));
-                    }
-                    const float k0 = __uint_as_float((__float_as_uint(m0) & 0xFFFFFFCFu) | cb[0]);
-                    const float k1 = __uint_as_float((__float_as_uint(m1) & 0xFFFFFFCFu) | cb[1]);
-                    const unsigned int kb = __float_as_uint(fmaxf(k0, k1));
-                    const auto sw2 = __builtin_amdgcn_permlane32_swap(kb, kb, false, false);   // [0] = lanes 0-31's value, [1] = lanes 32-63's, in every lane
-                    const float kk = fmaxf(__uint_as_float(sw2[0]), __uint_as_float(sw2[1]));
-                    if (lhi == 0 && jcol < ja1) rk[jcol] = kk;
-                }
-            }
-            __syncthreads();
-        }
-#undef ISSUE_B
-    }
-    // ---- forward: reduce the 32 column classes of every query row through LDS (staging buffers are free now)
-    float *T = reinterpret_cast<float *>(smem) + wave * (64 * 32);
-    if (wave_active) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) T[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * 32 + lcol] = rm[t][r];
-    }
-    __syncthreads();
-    if (wave_active && q0 + lane < n0) {
-        float best = MQ_NEG;
-        int col = 0;
-#pragma unroll
-        for (int c4 = 0; c4 < 8; ++c4) {
-            const float4 v = *reinterpret_cast<const float4 *>(T + lane * 32 + c4 * 4);
-            if (v.x > best) { best = v.x; col = c4 * 4 + 0; }      // strict '>' in column order: lowest candidate among equals
-            if (v.y > best) { best = v.y; col = c4 * 4 + 1; }
-            if (v.z > best) { best = v.z; col = c4 * 4 + 2; }
-            if (v.w > best) { best = v.w; col = c4 * 4 + 3; }
-        }
-        const unsigned int bits = __float_as_uint(best);
-        const int tile = (1 << MQ_TILE_BITS) - 1 - (int)(bits & ((1u << MQ_TILE_BITS) - 1u));
-        const size_t o = (size_t)blockIdx.y * n0 + q0 + lane;
-        const bool any = best > MQ_NEG;
-        job.part_v1[o] = any ? __uint_as_float(bits & ~((1u << MQ_TILE_BITS) - 1u)) : -INFINITY;
-        job.part_i1[o] = any ? ja0 + tile * 32 + col : 0;
-    }
-}
-
-// merges the partials: forward [splits][n0] (value, index), reverse [ceil(n0 / 64)][n1] packed (value | 6-bit query id)
+// merges the partials: forward [splits][n0] (value, index), reverse [ceil(n0 / strip)][n1] packed (value | query id bits)
 __global__ __launch_bounds__(NT)
-void match_mutual_reduce_kernel(const MatchJob2 *__restrict__ jobs, const MatchFinal *__restrict__ fins, int splits)
+void match_mutual_reduce_kernel(const MatchJob2 *__restrict__ jobs, const MatchFinal *__restrict__ fins, int splits, int strip)
 {
     const MatchJob2 job = jobs[blockIdx.y];
     const MatchFinal f = fins[blockIdx.y];
@@ -515,19 +353,29 @@ void match_mutual_reduce_kernel(const MatchJob2 *__restrict__ jobs, const MatchF
         f.red_f[(size_t)n + i] = -INFINITY;
         reinterpret_cast<int *>(f.red_f)[2 * (size_t)n + i] = bi;
     } else {
-        const int nstrip = (job.n0 + 63) / 64;
+        const int nstrip = (job.n0 + strip - 1) / strip;
         float best = MQ_NEG;
         int bs = 0;
-        for (int sidx = 0; sidx < nstrip; ++sidx) {       // ascending strips, strict '>': the lower query wins among equals
+        int sidx = 0;
+        for (; sidx + 8 <= nstrip; sidx += 8) {            // 8 independent loads in flight per thread (52 MB per 50 pairs)
+            float k[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) k[u] = job.rkeys[(size_t)(sidx + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k[u] > best) { best = k[u]; bs = sidx + u; }   // ascending strips, strict '>': the lower query wins among equals
+        }
+        for (; sidx < nstrip; ++sidx) {
             const float k = job.rkeys[(size_t)sidx * n + i];
             if (k > best) { best = k; bs = sidx; }
         }
         const unsigned int bits = __float_as_uint(best);
-        const int t = 1 - (int)((bits >> 5) & 1u), lh = 1 - (int)((bits >> 4) & 1u), r = 15 - (int)(bits & 15u);
+        // id bits: 3:0 = 15 - register, 4 = 1 - half-wave, (64-query strips only) 5 = 1 - query tile
+        const int t = strip == 64 ? 1 - (int)((bits >> 5) & 1u) : 0, lh = 1 - (int)((bits >> 4) & 1u), r = 15 - (int)(bits & 15u);
         const bool any = best > MQ_NEG;
         f.red_r[i] = any ? __uint_as_float(bits & 0xFFFFFFC0u) : -INFINITY;
         f.red_r[(size_t)n + i] = -INFINITY;
-        reinterpret_cast<int *>(f.red_r)[2 * (size_t)n + i] = any ? bs * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh : 0;
+        reinterpret_cast<int *>(f.red_r)[2 * (size_t)n + i] = any ? bs * strip + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh : 0;
     }
 }
 
@@ -535,18 +383,11 @@ void launch_match_mutual(hipStream_t st, const MatchJob2 *jobs_dev, const MatchF
                          int max_n1, int splits, const half_t *zero_page)
 {
     if (npairs <= 0 || max_n0 <= 0) return;
-    static bool attr = false;
-    const size_t lds = (size_t)2 * TA2 * 256;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_mutual_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
-    hipLaunchKernelGGL(match_mutual_kernel, dim3((max_n0 + 255) / 256, splits, npairs), dim3(NT), lds, st, jobs_dev, splits, zero_page);
+    launch_match_mutual_gemm(st, jobs_dev, npairs, max_n0, splits, zero_page);
     const int max_n = max_n0 > max_n1 ? max_n0 : max_n1;
-    hipLaunchKernelGGL(match_mutual_reduce_kernel, dim3((max_n + NT - 1) / NT, npairs, 2), dim3(NT), 0, st, jobs_dev, fins_dev, splits);
+    hipLaunchKernelGGL(match_mutual_reduce_kernel, dim3((max_n + NT - 1) / NT, npairs, 2), dim3(NT), 0, st, jobs_dev, fins_dev, splits,
+                       match_mutual_strip());
 }
-
-int match_mutual_max_chunk(void) { return MQ_MAX_CHUNK; }
 
 void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int max_nb, int splits, int use_lo,
                        int need_top2, const half_t *zero_page)

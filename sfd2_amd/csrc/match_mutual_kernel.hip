@@ -1,0 +1,213 @@
+// Single-GEMM mutual nearest neighbour for the top-1 matcher modes.  Own translation unit because it is compiled with
+// -fno-honor-nans (sfd2_amd/build.py): the maxima below run on bit-packed floats, and without that flag hipcc puts a
+// NaN-canonicalising v_max_f32 x, x in front of every fmaxf operand it cannot prove quiet (4 VALU per element instead
+// of 2).  Nothing in this file can produce a NaN: similarities of finite fp16 operands, MQ_NEG, and id bits or-ed into
+// the low mantissa.
+#include "sfd2_internal.h"
+#include <math.h>
+
+#define NT 256
+#define KD 128
+#define TA2 64        // candidate rows per LDS stage
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+// The two directions of the mutual check are the row and the column maxima of ONE similarity matrix, so the top-1
+// modes (NNM / ONN, it_loc nnm: hloc/matchers/nearest_neighbor.py:38-57, it_loc/matcher.py:122-130) need one GEMM, not
+// two.  Orientation here: QUERIES are the MFMA rows (A operand, a wave keeps its 64 queries in registers), CANDIDATES
+// the columns (B operand, streamed through LDS).  In the 32x32 C layout a lane owns 16 query rows of ONE candidate
+// column, so per 32 x 32 sub-tile:
+//   forward (best candidate per query): 16 element-wise running maxima per lane, kept across the whole sweep, with the
+//       candidate TILE id packed into the 7 low mantissa bits (127 - tile: the lower tile wins among equal values).  The
+//       32-lane reduction happens once per sweep, through an LDS transposition, not per tile.
+//   reverse (best query per candidate): a 16 -> 1 in-lane maximum with the register id packed into 4 bits, the two query
+//       tiles and the two half-waves merged with two more id bits, one 128-byte store per tile: a per-strip partial
+//       [n0 / 64][n1] that match_mutual_reduce folds.
+// ~8 VALU instructions per MFMA instead of a second GEMM.  Packing perturbs a similarity by <= 2^-16 relative, far below
+// the fp16-operand error (1.5e-4); ties between values equal after truncation go to the lower index.
+#define MQ_NEG (-0x1p100f)    // "no value": finite with an all-zero mantissa, so or-ing id bits can only make it MORE negative
+#define MQ_TILE_BITS 7
+#define MQ_MAX_CHUNK (32 << MQ_TILE_BITS)   // candidates per split: the tile id must fit MQ_TILE_BITS
+
+__global__ __launch_bounds__(NT, 2)
+void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const half_t *__restrict__ zero_page)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][TA2][256 B]; at the end [4][64][32] floats
+    const MatchJob2 job = jobs[blockIdx.z];
+    const int n1 = job.n1, n0 = job.n0;          // candidates, queries
+    const int i_base = blockIdx.x * 256;
+    if (i_base >= n0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lcol = lane & 31, lhi = lane >> 5;
+
+    int chunk = (n1 + splits - 1) / splits;
+    chunk = (chunk + 31) & ~31;
+    const int ja0 = blockIdx.y * chunk;
+    int ja1 = ja0 + chunk;
+    if (ja1 > n1) ja1 = n1;
+
+    const int q0 = i_base + wave * 64;
+    const bool wave_active = q0 < n0;                 // wave-uniform
+    const bool partial_q = q0 + 64 > n0;              // some query row of this wave is padding
+    h8_t aq[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int qi = q0 + t * 32 + lcol;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            h8_t z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (half_t)0.0f;
+            aq[t][ks] = z;
+            if (qi < n0) aq[t][ks] = *reinterpret_cast<const h8_t *>(job.q_hi + (size_t)qi * KD + ks * 16 + lhi * 8);
+        }
+    }
+    float rm[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rm[t][r] = MQ_NEG;
+    f32x16_t zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+    // reverse id bits 5:4 = (1 - t, 1 - lhi) above the 4 register bits: the larger code wins the max, so the lower
+    // (t, lhi, r) wins among values equal after truncation
+    const unsigned int cb[2] = {0x20u | ((1u - (unsigned)lhi) << 4), (1u - (unsigned)lhi) << 4};
+    // this wave's row of the reverse partials as a buffer resource covering candidates [0, ja1)
+    const __amdgpu_buffer_rsrc_t rk_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        job.rkeys + (size_t)(blockIdx.x * 4 + wave) * n1, 0, ja1 * 4, 0x00020000);
+    // the mask lives in a VGPR so that (x & keep) | code is ONE v_and_or_b32 (VOP3 on gfx950 takes no literal, and the
+    // tile code is already the one scalar operand)
+    unsigned int keep = ~((1u << MQ_TILE_BITS) - 1u);
+    asm volatile("" : "+v"(keep));
+
+    // MFMAs of one 32-candidate tile (LDS rows SUB_ * 32 .. + 31 of buffer BUF_) against the wave's 64 queries
+#define MQ_TILE_MFMA(N0_, N1_, BUF_, SUB_)                                                               \
+    {                                                                                                    \
+        const int row_ = (SUB_)*32 + lcol;                                                               \
+        const unsigned char *brow_ = smem + ((BUF_)*TA2 + row_) * 256;                                   \
+        const int sw_ = row_ & 15;                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                               \
+            const h8_t b_ = *reinterpret_cast<const h8_t *>(brow_ + (((ks * 2 + lhi) ^ sw_) << 4));     \
+            N0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[0][ks], b_, ks == 0 ? zero16 : N0_, 0, 0, 0); \
+            N1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[1][ks], b_, ks == 0 ? zero16 : N1_, 0, 0, 0); \
+        }                                                                                                \
+    }
+    // edge tiles only (wave-uniform, rare): padding candidate columns (zero-page rows) and padding query rows must never
+    // be a maximum.  The empty asm keeps the block a branch: if-converted it costs 64 selects on every tile.
+#define MQ_TILE_MASK(C0_, C1_, TILE_)                                                                    \
+    if (ja0 + (TILE_)*32 + 32 > ja1 || partial_q) {                                                      \
+        asm volatile("" ::: "memory");                                                                   \
+        const bool pad_col_ = ja0 + (TILE_)*32 + lcol >= ja1;                                            \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
+            const int qr_ = q0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;                                       \
+            if (pad_col_ || qr_ >= n0) C0_[r] = MQ_NEG;                                                  \
+            if (pad_col_ || qr_ + 32 >= n0) C1_[r] = MQ_NEG;                                             \
+        }                                                                                                \
+    }
+    // epilogue of a finished tile: forward running maxima (tile id packed), reverse per-candidate maximum (row id
+    // packed), the two query tiles and the two half-waves merged, one 128-byte store.  Bounds-checked buffer store:
+    // padding columns fall outside the descriptor and are dropped by the hardware, the upper half-wave repeats the
+    // lower one's store -- no exec-mask branch.
+#define MQ_TILE_EPI(C0_, C1_, TILE_)                                                                     \
+    {                                                                                                    \
+        const unsigned int code_ = (unsigned)((1 << MQ_TILE_BITS) - 1 - (TILE_));                        \
+        float m0_ = MQ_NEG, m1_ = MQ_NEG;                                                                \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
+            rm[0][r] = fmaxf(rm[0][r], __uint_as_float((__float_as_uint(C0_[r]) & keep) | code_));      \
+            rm[1][r] = fmaxf(rm[1][r], __uint_as_float((__float_as_uint(C1_[r]) & keep) | code_));      \
+            m0_ = fmaxf(m0_, __uint_as_float((__float_as_uint(C0_[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r))); \
+            m1_ = fmaxf(m1_, __uint_as_float((__float_as_uint(C1_[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r))); \
+        }                                                                                                \
+        const float k0_ = __uint_as_float((__float_as_uint(m0_) & 0xFFFFFFCFu) | cb[0]);                 \
+        const float k1_ = __uint_as_float((__float_as_uint(m1_) & 0xFFFFFFCFu) | cb[1]);                 \
+        const unsigned int kb_ = __float_as_uint(fmaxf(k0_, k1_));                                       \
+        const auto sw2_ = __builtin_amdgcn_permlane32_swap(kb_, kb_, false, false);                      \
+        const float kk_ = fmaxf(__uint_as_float(sw2_[0]), __uint_as_float(sw2_[1]));                     \
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(kk_), rk_rsrc, (ja0 + (TILE_)*32 + lcol) * 4, 0, 0); \
+    }
+
+    if (ja0 < ja1) {
+        const int nst = (ja1 - ja0 + TA2 - 1) / TA2;
+        const int srow = lane >> 4;
+#define ISSUE_B(stage_, buf_)                                                                            \
+    _Pragma("unroll") for (int c = 0; c < TA2 / 16; ++c) {                                               \
+        const int row = (wave * (TA2 / 16) + c) * 4 + srow;                                              \
+        const int slot = (lane & 15) ^ (row & 15);                                                       \
+        const int ja = ja0 + (stage_)*TA2 + row;                                                         \
+        const half_t *src = ja < ja1 ? job.d_hi + (size_t)ja * KD + slot * 8 : zero_page + (lane & 3) * 8; \
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                              \
+                                         (lds_void_t *)(smem + (buf_)*TA2 * 256 + (wave * (TA2 / 16) + c) * 1024), 16, 0, 0); \
+    }
+        ISSUE_B(0, 0)
+        __syncthreads();
+        // tile by tile.  Measured alternatives (profiles/r02_match_pmc.txt): the MFMAs of tile k + 1 software-pipelined
+        // with the epilogue of tile k (+2 %, register pressure), the same pinned with sched_barrier (+3 %), 32 queries per
+        // wave at 4 waves per SIMD (+12 %), 128-candidate stages (+23 %, spills), one wave per SIMD (+48 %)
+        for (int s = 0; s < nst; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nst) { ISSUE_B(s + 1, buf ^ 1) }
+            if (wave_active) {
+#pragma unroll
+                for (int sub = 0; sub < TA2 / 32; ++sub) {
+                    f32x16_t c0 = zero16, c1 = zero16;
+                    const int tile = s * (TA2 / 32) + sub;
+                    MQ_TILE_MFMA(c0, c1, buf, sub)
+                    MQ_TILE_MASK(c0, c1, tile)
+                    MQ_TILE_EPI(c0, c1, tile)
+                }
+            }
+            __syncthreads();
+        }
+#undef ISSUE_B
+        __syncthreads();
+    }
+#undef MQ_TILE_MFMA
+#undef MQ_TILE_MASK
+#undef MQ_TILE_EPI
+    // ---- forward: reduce the 32 column classes of every query row through LDS (staging buffers are free now)
+    float *T = reinterpret_cast<float *>(smem) + wave * (64 * 32);
+    if (wave_active) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * 32 + lcol] = rm[t][r];
+    }
+    __syncthreads();
+    if (wave_active && q0 + lane < n0) {
+        float best = MQ_NEG;
+        int col = 0;
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) {
+            const float4 v = *reinterpret_cast<const float4 *>(T + lane * 32 + c4 * 4);
+            if (v.x > best) { best = v.x; col = c4 * 4 + 0; }      // strict '>' in column order: lowest candidate among equals
+            if (v.y > best) { best = v.y; col = c4 * 4 + 1; }
+            if (v.z > best) { best = v.z; col = c4 * 4 + 2; }
+            if (v.w > best) { best = v.w; col = c4 * 4 + 3; }
+        }
+        const unsigned int bits = __float_as_uint(best);
+        const int tile = (1 << MQ_TILE_BITS) - 1 - (int)(bits & ((1u << MQ_TILE_BITS) - 1u));
+        const size_t o = (size_t)blockIdx.y * n0 + q0 + lane;
+        const bool any = best > MQ_NEG;
+        job.part_v1[o] = any ? __uint_as_float(bits & ~((1u << MQ_TILE_BITS) - 1u)) : -INFINITY;
+        job.part_i1[o] = any ? ja0 + tile * 32 + col : 0;
+    }
+}
+
+
+
+int match_mutual_strip(void) { return 64; }   // queries per reverse-partial strip (match_mutual_reduce decodes accordingly)
+
+void launch_match_mutual_gemm(hipStream_t st, const MatchJob2 *jobs_dev, int npairs, int max_n0, int splits, const half_t *zero_page)
+{
+    static bool attr = false;
+    const size_t lds = (size_t)2 * TA2 * 256;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_mutual_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(match_mutual_kernel, dim3((max_n0 + 255) / 256, splits, npairs), dim3(NT), lds, st, jobs_dev, splits, zero_page);
+}
+
+int match_mutual_max_chunk(void) { return MQ_MAX_CHUNK; }

@@ -1412,7 +1412,7 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
         if (const char *e = sfd2_env("SFD2_MATCH_SPLITS")) splits = std::max(1, std::min(16, atoi(e)));
         splits = std::max(splits, (max_n1 + match_mutual_max_chunk() - 1) / match_mutual_max_chunk());   // tile id bits
     }
-    const int nstrip = (n0 + 63) / 64;
+    const int nstrip = (n0 + match_mutual_strip() - 1) / match_mutual_strip();
 
     HIPCHECK(c->m_stage.ensure(std::max<size_t>(stage_bytes, 256)));
     HIPCHECK(c->m_hi0.ensure((size_t)n0 * 128 * 2));

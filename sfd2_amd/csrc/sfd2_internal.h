@@ -123,12 +123,13 @@ struct MatchJob2 {         // one pair, both directions from one GEMM (top-1 mod
     int n0, n1;
     float *part_v1;        // forward partials [splits][n0]
     int *part_i1;
-    float *rkeys;          // reverse partials [ceil(n0/64)][n1]: value with the strip-local query id in the 6 low mantissa bits
+    float *rkeys;          // reverse partials [ceil(n0/strip)][n1]: value with the strip-local query id in the low mantissa bits
 };
 struct MatchFinal;
 void launch_match_mutual(hipStream_t st, const MatchJob2 *jobs_dev, const MatchFinal *fins_dev, int npairs, int max_n0,
                          int max_n1, int splits, const half_t *zero_page);
-int match_mutual_max_chunk(void);   // most candidates one split of the single-GEMM kernel may sweep
+int match_mutual_max_chunk(void);
+int match_mutual_strip(void);        // queries per reverse-partial strip of the single-GEMM kernel   // most candidates one split of the single-GEMM kernel may sweep
 void launch_match_decide(hipStream_t st, const MatchFinal *fin_dev, int npairs, int max_n, int flavour, int mutual,
                          float ratio, float dist);
 struct MatchFinal {
