@@ -78,6 +78,10 @@ struct sfd2_ctx {
     int fuse_det = 0;                  // sfd2_set_option "fuse_det"
     int use_graphs = 0;                // sfd2_set_option "graphs"
     int alias_now = 0;                 // set per call
+    int opt_branches = 0;              // sfd2_set_option "branches": detector branch on a second stream beside the descriptor branch
+    hipStream_t side_stream = nullptr; // the detector branch (convPa.0 -> convPa.3 -> convPb -> detector_head)
+    hipStream_t cur_stream = nullptr;  // stream the conv()/ProfScope helpers launch on (main or side)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     struct GraphEntry *graphs = nullptr;   // hipGraph cache of sfd2_extract_match (see below)
     int n_graphs = 0;
     unsigned long long graph_clock = 0;
@@ -141,11 +145,11 @@ struct ProfScope {   // records an event pair around one launch when profiling i
         c->prof_tab[row].flops = flops;
         c->prof_tab[row].bytes = bytes;
         c->prof_row[(size_t)c->prof_step * PROF_SLOTS + slot] = row;
-        (void)hipEventRecord(c->prof_ev[((size_t)c->prof_step * PROF_SLOTS + slot) * 2], c->stream);
+        (void)hipEventRecord(c->prof_ev[((size_t)c->prof_step * PROF_SLOTS + slot) * 2], c->cur_stream);
     }
     ~ProfScope()
     {
-        if (slot >= 0) (void)hipEventRecord(c->prof_ev[((size_t)c->prof_step * PROF_SLOTS + slot) * 2 + 1], c->stream);
+        if (slot >= 0) (void)hipEventRecord(c->prof_ev[((size_t)c->prof_step * PROF_SLOTS + slot) * 2 + 1], c->cur_stream);
     }
 };
 static void prof_step_begin(sfd2_ctx *c) { c->prof_slot = 0; }
@@ -175,6 +179,10 @@ extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
     for (int i = 0; i < 4; ++i) HIPCHECK(hipEventCreate(&c->ev[i]));
     HIPCHECK(hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming));
     HIPCHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHECK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    c->cur_stream = c->stream;
     for (int i = 0; i < 2; ++i) {
         HIPCHECK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&c->ev_img_free[i], hipEventDisableTiming));
@@ -217,6 +225,9 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
         c->img2[i].release();
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->pin_jobs) (void)hipHostFree(c->pin_jobs);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -620,12 +631,12 @@ static void conv(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &in
     if (L.wrm.p && !out_f32 && !no_c1) {
         snprintf(kn, sizeof(kn), "conv1x1_c256%s", res ? "+res" : "");
         ProfScope ps(c, name, kn, flops, bytes);
-        launch_conv1x1_c256(c->stream, in.as<half_t>(), Ho * Wo, L.wrm.as<half_t>(), L.scale.as<float>(), L.shift.as<float>(),
+        launch_conv1x1_c256(c->cur_stream, in.as<half_t>(), Ho * Wo, L.wrm.as<half_t>(), L.scale.as<float>(), L.shift.as<float>(),
                             relu, res, reinterpret_cast<half_t *>(out.p), c->zero_page.as<half_t>());
         return;
     }
     ProfScope ps(c, name, kn, flops, bytes);
-    launch_conv_igemm(c->stream, in.as<half_t>(), H, W, L.cin, L.w.as<half_t>(), L.scale.as<float>(),
+    launch_conv_igemm(c->cur_stream, in.as<half_t>(), H, W, L.cin, L.w.as<half_t>(), L.scale.as<float>(),
                       L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu, res, out.p, out_f32, Ho, Wo,
                       c->zero_page.as<half_t>());
 }
@@ -693,6 +704,7 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
 // ResSegNetV2.det up to the three head outputs (nets/sfd2.py:314-328, :340-345)
 static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
 {
+    c->cur_stream = c->stream;
     if (c->precision == SFD2_PREC_F32) return run_network_f32(c, img_dev, normalise);
     hipStream_t st = c->stream;
     const int H = c->H, W = c->W, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
@@ -713,7 +725,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         S = std::max(S, (P2 * 128 * 2 + 1) / 2);
         S = std::max(S, 2 * (P8s * 256 * 2 + 256));
         S = (S + 255) & ~(size_t)255;
-        HIPCHECK(c->arena.ensure(3 * S));
+        HIPCHECK(c->arena.ensure((c->opt_branches ? 4 : 3) * S));
         char *base = c->arena.as<char>();
         auto slot = [&](int i, size_t off = 0) { DevBuf v; v.p = base + (size_t)i * S + off; v.cap = 0; return v; };
         {
@@ -725,6 +737,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
             t1v[2] = slot(0); t2v[2] = slot(1); rov[2] = slot(0);    // x = slot 2 -> final x = slot 0
             pa0_o = slot(1); pa_o = slot(1, (P8s * 256 * 2 + 255) & ~(size_t)255);
             da0_o = slot(2); da_o = slot(1);   // convDa.3 runs after convPb has consumed slot 1
+            if (c->opt_branches) da_o = slot(3);   // the two head branches run concurrently: no slot is shared between them
         }
     }
     if (c->fuse_now) {
@@ -773,9 +786,29 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         conv(c, nm3[b], c->rb3[b], t2, H4, W4, ob, H4, W4, 1, x->as<half_t>());
         x = &ob;
     }
+    // The two head branches read the backbone output and nothing of each other (nets/sfd2.py:328-342).  The detector
+    // branch works on the 1/8 map (convPa.3: 133 tiles for 256 CUs at 1600x1200), so on its own it leaves part of the
+    // chip idle; with option "branches" it runs on a side stream beside the descriptor branch (fork / join by events;
+    // inside a captured hipGraph this becomes a fork in the graph).  Measured (tools/ab_branches.py, interleaved A/B at
+    // 1600x1200): 1.260 -> 1.238 ms per extract (-1.7 %), outputs bit-identical.  Off by default: overlapped launches
+    // stretch each other's event-timed durations, and bench.py's per-kernel roofline wants uncontended ones.
+    const bool fork = c->opt_branches != 0;
+    if (fork) {
+        HIPCHECK(hipEventRecord(c->ev_fork, st));
+        HIPCHECK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        c->cur_stream = c->side_stream;
+    }
     conv(c, "convPa.0", c->pa0, *x, H4, W4, pa0_o, H8, W8, 1);
     conv(c, "convPa.3", c->pa3, pa0_o, H8, W8, pa_o, H8, W8, 0);
     conv(c, "convPb", c->pb, pa_o, H8, W8, c->logits, H8, W8, 0, nullptr, 1);
+    {
+        ProfScope ps(c, "detector_head", "detector_head_kernel", 0.0, P8 * (65 * 4 + 256));
+        launch_detector_head(c->cur_stream, c->logits.as<float>(), 128, H8, W8, c->score.as<float>());
+    }
+    if (fork) {
+        HIPCHECK(hipEventRecord(c->ev_join, c->side_stream));
+        c->cur_stream = st;
+    }
     conv(c, "convDa.0", c->da0, *x, H4, W4, da0_o, H4, W4, 1);
     conv(c, "convDa.3", c->da3, da0_o, H4, W4, da_o, H4, W4, 0);
     conv(c, "convDb", c->db, da_o, H4, W4, c->draw, H4, W4, 0, nullptr, 1);
@@ -783,10 +816,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         ProfScope ps(c, "ConvSta", "convsta_kernel", 2.0 * P4 * 3 * 256, P4 * (512 + 12));
         launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
     }
-    {
-        ProfScope ps(c, "detector_head", "detector_head_kernel", 0.0, P8 * (65 * 4 + 256));
-        launch_detector_head(st, c->logits.as<float>(), 128, H8, W8, c->score.as<float>());
-    }
+    if (fork) HIPCHECK(hipStreamWaitEvent(st, c->ev_join, 0));
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -1720,6 +1750,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "fuse_det") c->fuse_det = value ? 1 : 0;
     else if (k == "alias") c->opt_alias = value ? 1 : 0;
     else if (k == "graphs") c->use_graphs = value ? 1 : 0;
+    else if (k == "branches") c->opt_branches = value ? 1 : 0;
     else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;
 }
