@@ -105,6 +105,9 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *               reach the kernels sfd2_extract uses.
  *   "alias"     1 (default): the throughput path packs activations into the three-slot arena.
  *   "graphs"    0 (default) / 1: sfd2_extract_match (below) replays a cached hipGraph per geometry.
+ *   "fuse_post" 1 (default): on the extract path, for H and W multiples of 8, detector soft-max + depth-to-space and
+ *               stability weighting run as one kernel that writes the heat map (no score map in memory); 0: two
+ *               kernels.  Bit-identical key points either way.
  *   "branches"  0 (default) / 1: the detector branch (convPa, convPb, soft-max) runs on a second HIP stream beside
  *               the descriptor branch (convDa, convDb) -- they share only the backbone output (-1.7 % per extract).
  * Unknown keys are an error. */

@@ -13,6 +13,16 @@
 
 #define NT 256
 
+// histogram bin of a candidate key (score bits << 32 | ~index): the 16 exponent + mantissa bits below the sign, rebased
+// so that bin 0 starts at 2^-12 and the last bin ends at 2^4, clamped.  Monotone in the score, which is all the
+// threshold search needs: keys above the boundary bin are selected outright, the boundary bin is ranked exactly.
+// (Heat-map scores are products of a soft-max probability and a stability weight: (0, 1].)
+__device__ __forceinline__ unsigned int key_bin(unsigned long long key)
+{
+    const int b = (int)((unsigned int)(key >> 47) & 0xFFFFu) - ((127 - 12) << 8);
+    return (unsigned int)(b < 0 ? 0 : (b > SFD2_HIST_BINS - 1 ? SFD2_HIST_BINS - 1 : b));
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -111,6 +121,49 @@ void launch_heatmap(hipStream_t st, const float *score, int hs, int ws, const fl
     const float st_y = hc > 0 ? (float)hc / (float)H : 1.0f, st_x = wc > 0 ? (float)wc / (float)W : 1.0f;
     hipLaunchKernelGGL(heatmap_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(NT), 0, st, score, hs, ws, sc_y, sc_x,
                        sta, hc, wc, st_y, st_x, H, W, heat, stab_out);
+}
+
+// detector head + heat map in one pass (extract path, H == 8 * hc8, W == 8 * wc8 so the score map needs no resize):
+// one wave per 8 x 8 cell as detector_head_kernel, the lane then weights its pixel with the stability value exactly as
+// heatmap_kernel does -- same operations, same results, and the 7.7 MB score map is neither written nor read back.
+// (Folding this into the NMS tile load as well was measured and lost: the NMS regions overlap 3.9-fold, so the per-cell
+// soft-max would be evaluated 4.8 times over: 69 -> 76 us for the three stages.)
+__global__ __launch_bounds__(NT)
+void heads_heat_kernel(const float *__restrict__ logits, int pitch, int hc8, int wc8, const float *__restrict__ sta, int hc, int wc,
+                       float st_y, float st_x, int H, int W, float *__restrict__ heat)
+{
+    const int lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (cell >= hc8 * wc8) return;
+    const int cy = cell / wc8, cx = cell - cy * wc8;
+    const float *p = logits + (size_t)cell * pitch;
+    const float e = expf(p[lane]);
+    const float ed = expf(p[64]);
+    const float den = (wave_sum(e) + ed) + 0.00001f;
+    const float s = e / den;
+    const int y = 8 * cy + (lane >> 3), x = 8 * cx + (lane & 7);
+    float stab = 1.0f;
+    if (sta) {
+        const LinCoef ly = lin_coef(y, hc, H, st_y), lx = lin_coef(x, wc, W, st_x);
+        const size_t plane = (size_t)hc * wc;
+        const float v0 = bilerp(sta, wc, ly, lx);
+        const float v1 = bilerp(sta + plane, wc, ly, lx);
+        const float v2 = bilerp(sta + 2 * plane, wc, ly, lx);
+        int best = 0;
+        float bv = v0;
+        if (v1 > bv) { bv = v1; best = 1; }
+        if (v2 > bv) { bv = v2; best = 2; }
+        stab = best == 0 ? 0.1f : (best == 1 ? 0.5f : 1.0f);
+    }
+    heat[(size_t)y * W + x] = __fmul_rn(s, stab);
+}
+
+void launch_heads_heat(hipStream_t st, const float *logits, int pitch, int hc8, int wc8, const float *sta, int hc, int wc,
+                       int H, int W, float *heat)
+{
+    const float st_y = hc > 0 ? (float)hc / (float)H : 1.0f, st_x = wc > 0 ? (float)wc / (float)W : 1.0f;   // as launch_heatmap
+    const int cells = hc8 * wc8;
+    hipLaunchKernelGGL(heads_heat_kernel, dim3((cells + 3) / 4), dim3(NT), 0, st, logits, pitch, hc8, wc8, sta, hc, wc, st_y, st_x, H, W, heat);
 }
 
 // ---------------------------------------------------------------- simple_nms (+ threshold/border/compaction)
@@ -230,13 +283,11 @@ void nms_select_kernel(const float *__restrict__ heat, int H, int W, int radius,
 // compared in registers and turned into bit masks with wave ballots; the two mask dilations
 // (supp_mask = max_pool(max_mask) > 0) are bit operations on 128-bit rows.  The suppressed score
 // map (where(supp, 0, scores)) is formed on the fly from S and the supp bits.
-#define N2_TH 24
 #define N2_TW 88
 #define N2_HALO 20
-#define N2_RH 64
 #define N2_RW 128
 #define N2_SP 136   // S row pitch: 4 pad floats (-inf) on either side
-#define N2_AR (N2_RH + 8)
+// region rows RH (64 or 136) is a template parameter: tile rows = RH - 2 * halo, A plane rows = RH + 8
 
 __device__ __forceinline__ void pool8(const float (&v)[16], float (&o)[8])
 {
@@ -252,7 +303,7 @@ __device__ __forceinline__ void pool8(const float (&v)[16], float (&o)[8])
     for (int j = 0; j < 8; ++j) o[j] = fmaxf(suf[j], pre[j]);
 }
 
-template <bool MASKED>
+template <bool MASKED, int N2_RH>
 __device__ __forceinline__ void n2_row_pass(const float *__restrict__ S, float *__restrict__ A,
                                             const unsigned long long *__restrict__ supp)
 {
@@ -286,7 +337,7 @@ __device__ __forceinline__ void n2_row_pass(const float *__restrict__ S, float *
 }
 
 // column pass + compare; MASKED: new = old | (ss == pool(ss) & ~supp), else new = (s == pool(s))
-template <bool MASKED>
+template <bool MASKED, int N2_RH>
 __device__ __forceinline__ void n2_col_pass(const float *__restrict__ S, const float *__restrict__ A,
                                             const unsigned long long *__restrict__ supp,
                                             unsigned long long *__restrict__ mask)
@@ -318,6 +369,7 @@ __device__ __forceinline__ void n2_col_pass(const float *__restrict__ S, const f
     }
 }
 
+template <int N2_RH>
 __device__ __forceinline__ void n2_dilate(const unsigned long long *__restrict__ m, unsigned long long *__restrict__ tmp,
                                           unsigned long long *__restrict__ supp)
 {
@@ -344,11 +396,13 @@ __device__ __forceinline__ void n2_dilate(const unsigned long long *__restrict__
     __syncthreads();
 }
 
+template <int N2_RH>
 __global__ __launch_bounds__(1024)
 void nms4_select_kernel(const float *__restrict__ heat, int H, int W, float conf_th, int border, int Hb, int Wb,
                         float *__restrict__ nms_dense, unsigned long long *__restrict__ cand, int cand_cap,
                         unsigned int *__restrict__ counters, unsigned int *__restrict__ hist)
 {
+    constexpr int N2_TH = N2_RH - 2 * N2_HALO, N2_AR = N2_RH + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *S = reinterpret_cast<float *>(smem);                         // [RH][SP]
     float *A = S + N2_RH * N2_SP;                                       // [RH + 8][RW]
@@ -369,39 +423,51 @@ void nms4_select_kernel(const float *__restrict__ heat, int H, int W, float conf
         A[(N2_RH + 4) * N2_RW + i] = NEG;
     }
     __syncthreads();
-    n2_row_pass<false>(S, A, nullptr);
+    n2_row_pass<false, N2_RH>(S, A, nullptr);
     __syncthreads();
-    n2_col_pass<false>(S, A, nullptr, M);                                // max_mask = scores == max_pool(scores)
+    n2_col_pass<false, N2_RH>(S, A, nullptr, M);                                // max_mask = scores == max_pool(scores)
     __syncthreads();
     for (int it = 0; it < 2; ++it) {
-        n2_dilate(M, TM, SU);                                            // supp_mask = max_pool(max_mask) > 0
-        n2_row_pass<true>(S, A, SU);
+        n2_dilate<N2_RH>(M, TM, SU);                                            // supp_mask = max_pool(max_mask) > 0
+        n2_row_pass<true, N2_RH>(S, A, SU);
         __syncthreads();
-        n2_col_pass<true>(S, A, SU, M);                                  // max_mask |= new_max_mask & ~supp_mask
+        n2_col_pass<true, N2_RH>(S, A, SU, M);                                  // max_mask |= new_max_mask & ~supp_mask
         __syncthreads();
     }
     // Candidates are first gathered per block in LDS (the A plane is free now) so that the global
     // cursor sees ONE atomic per block: tens of thousands of same-address atomics (~12 ns each at
     // the L2) were the whole cost of this kernel.
-    unsigned long long *lkeys = reinterpret_cast<unsigned long long *>(A);   // <= 24*88 keys = 16.5 KB
+    unsigned long long *lkeys = reinterpret_cast<unsigned long long *>(A);   // <= TH * 88 keys (16.5 / 66 KB), A holds AR * 128 floats
     // (all LDS stays in the one dynamic array: a static __shared__ would shift its 16-byte base)
     unsigned int &l_cnt = reinterpret_cast<unsigned int *>(TM + 2 * N2_RH)[0];
     unsigned int &l_base = reinterpret_cast<unsigned int *>(TM + 2 * N2_RH)[1];
     if (threadIdx.x == 0) l_cnt = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < N2_TH * N2_TW; i += blockDim.x) {
+    for (int i0 = 0; i0 < N2_TH * N2_TW; i0 += blockDim.x) {             // wave-uniform trip count (ballots below)
+        const int i = i0 + threadIdx.x;
         const int ty = i / N2_TW, tx = i - ty * N2_TW;
         const int gy = blockIdx.y * N2_TH + ty, gx = blockIdx.x * N2_TW + tx;
-        if (gy >= H || gx >= W) continue;
-        const int ry = ty + N2_HALO, rx = tx + N2_HALO;
-        const bool mk = (M[2 * ry + (rx >> 6)] >> (rx & 63)) & 1ull;
-        const float v = mk ? S[ry * N2_SP + 4 + rx] : 0.0f;              // where(max_mask, scores, zeros)
-        if (nms_dense) nms_dense[(size_t)gy * W + gx] = v;
-        if (cand && v > conf_th && gx >= border && gx < Wb - border && gy >= border && gy < Hb - border) {
-            const unsigned int idx = (unsigned int)(gy * W + gx);
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
-            lkeys[atomicAdd(&l_cnt, 1u)] = key;
+        bool is_cand = false;
+        unsigned long long key = 0ull;
+        if (i < N2_TH * N2_TW && gy < H && gx < W) {
+            const int ry = ty + N2_HALO, rx = tx + N2_HALO;
+            const bool mk = (M[2 * ry + (rx >> 6)] >> (rx & 63)) & 1ull;
+            const float v = mk ? S[ry * N2_SP + 4 + rx] : 0.0f;          // where(max_mask, scores, zeros)
+            if (nms_dense) nms_dense[(size_t)gy * W + gx] = v;
+            if (cand && v > conf_th && gx >= border && gx < Wb - border && gy >= border && gy < Hb - border) {
+                const unsigned int idx = (unsigned int)(gy * W + gx);
+                key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+                is_cand = true;
+            }
+        }
+        // one LDS atomic per wave (a few hundred same-address atomics per block serialise otherwise)
+        const unsigned long long mc = __ballot(is_cand);
+        if (mc) {
+            const int lane = threadIdx.x & 63;
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(&l_cnt, (unsigned int)__popcll(mc));
+            base = __shfl(base, 0);
+            if (is_cand) lkeys[base + (unsigned int)__popcll(mc & ((1ull << lane) - 1ull))] = key;
         }
     }
     __syncthreads();
@@ -413,7 +479,7 @@ void nms4_select_kernel(const float *__restrict__ heat, int H, int W, float conf
         if (pos < (unsigned int)cand_cap) {
             const unsigned long long key = lkeys[i];
             cand[pos] = key;
-            atomicAdd(&hist[(unsigned int)(key >> 47) & 0xFFFFu], 1u);
+            atomicAdd(&hist[key_bin(key)], 1u);
         }
     }
 }
@@ -426,24 +492,37 @@ void hist_from_cand_kernel(const unsigned long long *__restrict__ cand, int cand
     unsigned int n = counters[0];
     if (n > (unsigned int)cand_cap) n = cand_cap;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        atomicAdd(&hist[(unsigned int)(cand[i] >> 47) & 0xFFFFu], 1u);
+        atomicAdd(&hist[key_bin(cand[i])], 1u);
 }
 
 void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radius, float conf_th, int border, int Hb, int Wb,
                        float *nms_dense, unsigned long long *cand, int cand_cap, unsigned int *counters)
 {
-    unsigned int *hist = counters + 16;   // counters[0..15], then 65536 histogram bins
+    unsigned int *hist = counters + 16;   // counters[0..15], then SFD2_HIST_BINS histogram bins
     if (radius == 4) {
+        // The kernel is VALU-issue bound (profiles/r02_nms_pmc.txt: 1 215 VALU instructions per thread, 8 waves per SIMD),
+        // so what counts is the number of REGION pixels the busiest CU has to process.  Two tile heights: 24 rows (region
+        // 64 x 128, 73 KB of LDS, two blocks per CU, 3.9x halo overhead) or 96 rows (region 136 x 128, 155 KB, one block
+        // per CU, 2.1x) -- whichever gives the busiest CU less to do for this image (1600x1200: 247 big tiles = one
+        // round on 256 CUs instead of 950 small ones).
         static bool attr4 = false;
-        const size_t lds4 = (size_t)(N2_RH * N2_SP + N2_AR * N2_RW) * sizeof(float) + 3 * 2 * N2_RH * sizeof(unsigned long long) + 16;
+        auto lds_of = [](int rh) { return (size_t)(rh * N2_SP + (rh + 8) * N2_RW) * sizeof(float) + 3 * 2 * rh * sizeof(unsigned long long) + 16; };
         if (!attr4) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms4_select_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms4_select_kernel<64>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(64));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms4_select_kernel<136>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(136));
             attr4 = true;
         }
-        static const int nms_threads = sfd2_env("SFD2_NMS_THREADS") ? atoi(sfd2_env("SFD2_NMS_THREADS")) : 1024;   // 512 threads: 56 us, 1024: 47 us at 1600x1200
-        hipLaunchKernelGGL(nms4_select_kernel, dim3((W + N2_TW - 1) / N2_TW, (H + N2_TH - 1) / N2_TH), dim3(nms_threads), lds4,
-                           st, heat, H, W, conf_th, border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist);
+        const int gx = (W + N2_TW - 1) / N2_TW;
+        const long long nb_s = (long long)gx * ((H + 23) / 24), nb_b = (long long)gx * ((H + 95) / 96);
+        const long long work_s = ((nb_s + 511) / 512) * 2 * 64, work_b = ((nb_b + 255) / 256) * 136;   // region rows on the busiest CU
+        static const char *force = sfd2_env("SFD2_NMS_TILE");
+        const bool big = force ? force[0] == 'b' : work_b < work_s;
+        if (big) hipLaunchKernelGGL(nms4_select_kernel<136>, dim3(gx, (H + 95) / 96), dim3(1024), lds_of(136), st, heat, H, W, conf_th,
+                                    border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist);
+        else hipLaunchKernelGGL(nms4_select_kernel<64>, dim3(gx, (H + 23) / 24), dim3(1024), lds_of(64), st, heat, H, W, conf_th,
+                                border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist);
         return;
     }
     static bool attr_done = false;
@@ -463,15 +542,15 @@ void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radi
 // key order == score descending, then pixel index ascending (the tie rule of DESIGN.md).
 // counters: [0] n_cand (may exceed cap: overflow flag), [1] n_selected (K), [2] cursor of keys above
 //           the boundary bin, [3] boundary-list cursor, [4] boundary bin b*, [5] keys still needed
-//           from bin b*, [6] select-all flag; counters[16 ..] = 65536-bin histogram of score bits >> 15
+//           from bin b*, [6] select-all flag; counters[16 ..] = SFD2_HIST_BINS-bin histogram (key_bin)
 //           (filled by the NMS kernel while it appends candidates).
 __global__ __launch_bounds__(1024)
 void select_threshold_kernel(int cand_cap, int top_k, unsigned int *__restrict__ counters)
 {
-    // 65536 bins = 1024 threads x 64 bins.  Parallel: per-thread group sums, suffix scan over the
-    // 1024 groups (wave shuffles + 16 wave totals), then one wave resolves the bin inside the group.
+    // 4096 bins = 1024 threads x 4 bins.  Per-thread group sums, suffix scan over the 1024 groups (wave shuffles +
+    // 16 wave totals), then the thread owning the boundary group resolves the bin among its four.
+    static_assert(SFD2_HIST_BINS == 4096, "one uint4 of bins per thread");
     __shared__ unsigned int wsum[16];
-    __shared__ unsigned int s_group, s_above;
     const unsigned int *hist = counters + 16;
     unsigned int n = counters[0];
     if (n > (unsigned int)cand_cap) n = cand_cap;
@@ -481,41 +560,31 @@ void select_threshold_kernel(int cand_cap, int top_k, unsigned int *__restrict__
         return;
     }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    unsigned int sum = 0;
-    const uint4 *h4 = reinterpret_cast<const uint4 *>(hist + 64 * t);
-#pragma unroll
-    for (int b = 0; b < 16; ++b) { const uint4 v = h4[b]; sum += v.x + v.y + v.z + v.w; }
-    // inclusive suffix sum within the wave: suf = sum of groups t .. (wave end)
-    unsigned int suf = sum;
+    const uint4 hv = reinterpret_cast<const uint4 *>(hist)[t];
+    const unsigned int sum = hv.x + hv.y + hv.z + hv.w;
+    unsigned int suf = sum;                    // inclusive suffix sum within the wave: groups t .. (wave end)
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const unsigned int o = __shfl_down(suf, d);
         if (lane + d < 64) suf += o;
     }
-    if (lane == 0) wsum[wave] = suf;          // total of this wave's 64 groups
-    if (t == 0) s_group = 0xFFFFFFFFu;
+    if (lane == 0) wsum[wave] = suf;
     __syncthreads();
     unsigned int higher = 0;                   // keys in all groups of higher waves
     for (int w = wave + 1; w < 16; ++w) higher += wsum[w];
     const unsigned int above_incl = higher + suf;          // keys in groups >= t
-    const unsigned int above_excl = above_incl - sum;      // keys in groups  > t
-    if (above_excl < k && above_incl >= k) { s_group = t; s_above = above_excl; }   // exactly one thread
-    __syncthreads();
-    if (wave == 0) {
-        const unsigned int g = s_group;
-        const unsigned int hv = hist[64 * g + lane];
-        unsigned int sb = hv;                  // inclusive suffix over the 64 bins of the group
+    unsigned int above = above_incl - sum;                 // keys in groups  > t
+    if (above < k && above_incl >= k) {                    // exactly one thread: walk its bins from the top
+        const unsigned int b[4] = {hv.x, hv.y, hv.z, hv.w};
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned int o = __shfl_down(sb, d);
-            if (lane + d < 64) sb += o;
-        }
-        const unsigned int incl = s_above + sb, excl = incl - hv;
-        if (excl < k && incl >= k) {
-            counters[1] = k; counters[2] = 0; counters[3] = 0;
-            counters[4] = 64 * g + lane;       // boundary bin
-            counters[5] = k - excl;            // how many of its keys are selected
-            counters[6] = 0;
+        for (int j = 3; j >= 0; --j) {
+            if (above < k && above + b[j] >= k) {
+                counters[1] = k; counters[2] = 0; counters[3] = 0;
+                counters[4] = 4 * t + j;       // boundary bin
+                counters[5] = k - above;       // how many of its keys are selected
+                counters[6] = 0;
+            }
+            above += b[j];
         }
     }
 }
@@ -536,7 +605,7 @@ void compact_selected_kernel(const unsigned long long *__restrict__ cand, int ca
         const unsigned int i = i0 + threadIdx.x;
         const bool live = i < n;
         const unsigned long long key = live ? cand[i] : 0ull;
-        const unsigned int bin = (unsigned int)(key >> 47) & 0xFFFFu;
+        const unsigned int bin = key_bin(key);
         const bool to_sel = live && (all || bin > bstar), to_bnd = live && !to_sel && bin == bstar;
         const unsigned long long ms = __ballot(to_sel), mb = __ballot(to_bnd);
         unsigned int base_s = 0, base_b = 0;

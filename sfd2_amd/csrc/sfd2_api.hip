@@ -78,6 +78,8 @@ struct sfd2_ctx {
     int fuse_det = 0;                  // sfd2_set_option "fuse_det"
     int use_graphs = 0;                // sfd2_set_option "graphs"
     int alias_now = 0;                 // set per call
+    int opt_fuse_post = 1;             // sfd2_set_option "fuse_post": heads -> heat map -> NMS in one kernel on the extract path
+    int skip_head_now = 0;             // set per call: run_network leaves the detector soft-max to the fused NMS kernel
     int opt_branches = 0;              // sfd2_set_option "branches": detector branch on a second stream beside the descriptor branch
     hipStream_t side_stream = nullptr; // the detector branch (convPa.0 -> convPa.3 -> convPb -> detector_head)
     hipStream_t cur_stream = nullptr;  // stream the conv()/ProfScope helpers launch on (main or side)
@@ -693,7 +695,7 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
         ProfScope ps(c, "ConvSta", "convsta_f32_kernel", 2.0 * P4 * 3 * 256, P4 * (1024 + 12));
         launch_convsta_f32(st, x->as<float>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
     }
-    {
+    if (!c->skip_head_now) {
         ProfScope ps(c, "detector_head", "detector_head_kernel", 0.0, P8 * (65 * 4 + 256));
         launch_detector_head(st, c->logits.as<float>(), 128, H8, W8, c->score.as<float>());
     }
@@ -801,7 +803,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     conv(c, "convPa.0", c->pa0, *x, H4, W4, pa0_o, H8, W8, 1);
     conv(c, "convPa.3", c->pa3, pa0_o, H8, W8, pa_o, H8, W8, 0);
     conv(c, "convPb", c->pb, pa_o, H8, W8, c->logits, H8, W8, 0, nullptr, 1);
-    {
+    if (!c->skip_head_now) {
         ProfScope ps(c, "detector_head", "detector_head_kernel", 0.0, P8 * (65 * 4 + 256));
         launch_detector_head(c->cur_stream, c->logits.as<float>(), 128, H8, W8, c->score.as<float>());
     }
@@ -959,11 +961,21 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     HIPCHECK(hipEventRecord(c->ev[0], c->stream));
     prof_step_begin(c);
     const int in_mode = ((flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1) | (u8 ? 2 : 0) | ((flags & SFD2_FLAG_IMG_BGR) ? 4 : 0);
-    if (run_network(c, img_dev, in_mode)) return -1;
+    // H, W multiples of 8 (every BASELINE geometry): the score map needs no resize, so the detector soft-max and the
+    // stability weighting run as ONE kernel that writes the heat map directly; the score map is never materialised
+    const bool fuse_post = c->opt_fuse_post && H % 8 == 0 && W % 8 == 0;
+    c->skip_head_now = fuse_post ? 1 : 0;
+    const int net_rc = run_network(c, img_dev, in_mode);
+    c->skip_head_now = 0;
+    if (net_rc) return -1;
     if (release_image_slot(c)) return -1;
     HIPCHECK(hipEventRecord(c->ev[1], c->stream));
     const int HS = 8 * c->H8, WS = 8 * c->W8;
-    {
+    if (fuse_post) {
+        ProfScope ps(c, "heads+heatmap", "heads_heat_kernel", 0.0, (double)c->H8 * c->W8 * 65 * 4 + (double)H * W * 4);
+        launch_heads_heat(c->stream, c->logits.as<float>(), 128, c->H8, c->W8,
+                          (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(), c->H4, c->W4, H, W, c->heat.as<float>());
+    } else {
         ProfScope ps(c, "heatmap", "heatmap_kernel", 0.0, (double)H * W * 8);
         launch_heatmap(c->stream, c->score.as<float>(), HS, WS,
                        (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(), c->H4, c->W4, H, W,
@@ -1751,6 +1763,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "alias") c->opt_alias = value ? 1 : 0;
     else if (k == "graphs") c->use_graphs = value ? 1 : 0;
     else if (k == "branches") c->opt_branches = value ? 1 : 0;
+    else if (k == "fuse_post") c->opt_fuse_post = value ? 1 : 0;
     else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;
 }

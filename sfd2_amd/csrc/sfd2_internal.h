@@ -74,11 +74,16 @@ void launch_heatmap(hipStream_t st, const float *score, int hs, int ws, const fl
 void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radius, float conf_th, int border, int Hb, int Wb,
                        float *nms_dense /*may be null*/, unsigned long long *cand_keys, int cand_cap,
                        unsigned int *counters /*[0]=n_cand*/);
+// detector head + heat map in one kernel: logits [hc8 * wc8][pitch] (65 used), sta [3][hc][wc] or null -> heat [H][W];
+// needs H == 8 * hc8 and W == 8 * wc8 (no score-map resize)
+void launch_heads_heat(hipStream_t st, const float *logits, int pitch, int hc8, int wc8, const float *sta, int hc, int wc,
+                       int H, int W, float *heat);
 // top-K of the candidate keys, sorted descending -> sorted_keys[0..n_sel), counters[1]=n_sel
 void launch_topk_sort(hipStream_t st, const unsigned long long *cand, int cand_cap, int top_k,
                       unsigned long long *sel, unsigned long long *sorted, int sel_cap, unsigned int *counters,
                       unsigned long long *bnd, int W, float *kpts, float *scores);   // kpts/scores: output rows (x, y), score
-#define SFD2_COUNTER_BYTES (64 + 65536 * 4)   // 16 counters + score histogram
+#define SFD2_HIST_BINS 4096                   // score bits >> 15, rebased to [2^-12, 2^4) and clamped (post_kernels.hip key_bin)
+#define SFD2_COUNTER_BYTES (64 + SFD2_HIST_BINS * 4)   // 16 counters + score histogram
 // greedy grid NMS of extract.py (nms_fast): init / one relaxation sweep / kept-score map
 void launch_greedy_init(hipStream_t st, const float *heat, int n, float conf_th, unsigned long long *keys, unsigned char *state);
 void launch_greedy_iter(hipStream_t st, const unsigned long long *keys, const unsigned char *sin, unsigned char *sout,

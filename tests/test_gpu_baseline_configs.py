@@ -364,3 +364,28 @@ def test_state_dict_without_convsta(synth_sd, precision):
 def test_set_option_rejects_unknown_key(model):
     with pytest.raises(RuntimeError, match="unknown key"):
         model.context.set_option("turbo", 1)
+
+
+# ------------------------------------------------------------------ detector head + heat map in one kernel
+@pytest.mark.parametrize("h,w,stab", [(96, 128, True), (240, 320, True), (480, 640, True), (104, 136, False), (8, 8, True),
+                                      (1200, 1600, True), (768, 1024, False)])
+def test_fused_post_equals_three_kernel_path(synth_sd, h, w, stab):
+    """Option "fuse_post" (default on the extract path when H, W are multiples of 8): detector soft-max + depth-to-space
+    and stability up-sampling / arg-max / LUT in ONE kernel against the detector_head -> heatmap chain: identical key
+    points, scores and descriptors, bit for bit (the heat map is formed by the same operations)."""
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    m = _make(synth_sd, "f16", stability=stab)
+    img = torch.from_numpy(synth.make_image(h, w, 7 * h + w)).cuda()
+    topk = 4096 if h >= 768 else 300
+    a = extract_resnet_return(m, img[None], conf_th=0.001, topK=topk, scales=[1.0])
+    m.context.set_option("fuse_post", 0)
+    b = extract_resnet_return(m, img[None], conf_th=0.001, topK=topk, scales=[1.0])
+    assert len(a["scores"]) == len(b["scores"]) and (len(a["scores"]) > 0 or h == 8)
+    for k in ("keypoints", "scores", "descriptors"):
+        np.testing.assert_array_equal(a[k], b[k])
+    allk = extract_resnet_return(m, img[None], conf_th=0.001, topK=-1, scales=[1.0])      # every candidate, unfused
+    m.context.set_option("fuse_post", 1)
+    allf = extract_resnet_return(m, img[None], conf_th=0.001, topK=-1, scales=[1.0])
+    for k in ("keypoints", "scores", "descriptors"):
+        np.testing.assert_array_equal(allf[k], allk[k])
