@@ -163,6 +163,15 @@ int sfd2_extract_count(sfd2_ctx *ctx, int *n_out);
 int sfd2_extract_spp(sfd2_ctx *ctx, const float *x, int x_on_device, int H, int W, float conf_th, int flags,
                      float *kpts_xy, float *scores, float *desc, int64_t cap_out, int *n_out,
                      float *heat_out, float *desc_full_out);
+/* extrat_spp_feats_multiscale (extract.py:87-201): the caller supplies the level schedule (nh, nw per level, emit = the
+ * level passes the max_scale / max_size test; Python's float arithmetic and round() decide it); level 0 is the
+ * NORMALISED image itself, every further level the bilinear resize of the PREVIOUS one.  Per emitted level: detector
+ * score resized to the level (no stability weighting, as the reference), heat >= conf_th, greedy NMS radius 4,
+ * confidence order, border 4 against the ORIGINAL W, H, descriptors sampled at level coordinates.  kpts_xy are in
+ * LEVEL coordinates, concatenated level by level; level_count[l] = key points of level l.  Host buffers. */
+int sfd2_extract_spp_levels(sfd2_ctx *ctx, const float *x, int x_on_device, int H, int W, int n_levels,
+                            const int32_t *nh, const int32_t *nw, const int32_t *emit, float conf_th, int flags,
+                            float *kpts_xy, float *scores, float *desc, int64_t cap_out, int32_t *level_count);
 /* nms_fast on a dense map: kept[y][x] = heat if the pixel survives greedy NMS else 0 (host buffers) */
 int sfd2_nms_fast(sfd2_ctx *ctx, const float *heat, int H, int W, float conf_th, int dist, float *kept_out);
 
@@ -193,6 +202,15 @@ int sfd2_debug_activation(sfd2_ctx *ctx, const char *name, float *out, int64_t c
 int sfd2_match(sfd2_ctx *ctx, const void *d0, int n0, const void *d1, int n1, int dim,
                int dtype, int layout, int on_device, const sfd2_match_conf *conf,
                int64_t *matches0, float *scores0, int out_on_device);
+
+/* Segmented (block-masked) matcher: rows [seg0[s], seg0[s+1]) of d0 against rows [seg1[s], seg1[s+1]) of d1 only, all
+ * n_seg segments in one launch -- the same-label phase of the label-aware matcher once both sets are ordered by label
+ * (Matcher.matcher_with_label, it_loc/matcher.py:239-264).  seg0 / seg1: n_seg + 1 ascending HOST offsets starting at
+ * 0 and ending at n0 / n1 (an empty range on either side = no matches for that segment's rows).
+ * matches0 [n0]: global row of d1 or -1; scores0 [n0] as sfd2_match, within the segment. */
+int sfd2_match_segments(sfd2_ctx *ctx, const void *d0, int n0, const void *d1, int n1, int dim,
+                        int dtype, int layout, int on_device, int n_seg, const int32_t *seg0, const int32_t *seg1,
+                        const sfd2_match_conf *conf, int64_t *matches0, float *scores0, int out_on_device);
 
 /* One descriptor set handed to the batched matcher. */
 typedef struct {

@@ -65,7 +65,7 @@ EXPORTS = [
     "sfd2_select_keypoints", "sfd2_sample_descriptors", "sfd2_heatmap", "sfd2_debug_activation",
     "sfd2_match", "sfd2_match_batch", "sfd2_get_timings", "sfd2_sync", "sfd2_set_profiling",
     "sfd2_get_layer_timings", "sfd2_set_precision", "sfd2_extract_spp", "sfd2_nms_fast",
-    "sfd2_set_profile_filter", "sfd2_extract_multiscale", "sfd2_set_option", "sfd2_extract_match", "sfd2_preprocess",
+    "sfd2_set_profile_filter", "sfd2_extract_multiscale", "sfd2_set_option", "sfd2_extract_match", "sfd2_preprocess", "sfd2_extract_spp_levels", "sfd2_match_segments",
 ]
 
 _lib = None
@@ -103,12 +103,14 @@ def load():
     lib.sfd2_extract_multiscale.argtypes = [vp, vp, ci, ci, ci, vp, ci, cf, ci, ci, vp, vp, vp, ci, i64, pi]
     lib.sfd2_extract_spp.argtypes = [vp, vp, ci, ci, ci, cf, ci, vp, vp, vp, i64, pi, vp, vp]
     lib.sfd2_nms_fast.argtypes = [vp, vp, ci, ci, cf, ci, vp]
+    lib.sfd2_extract_spp_levels.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, cf, ci, vp, vp, vp, i64, vp]
     lib.sfd2_simple_nms.argtypes = [vp, vp, ci, ci, ci, vp]
     lib.sfd2_select_keypoints.argtypes = [vp, vp, ci, ci, cf, ci, ci, ci, vp, vp, i64, pi]
     lib.sfd2_sample_descriptors.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, vp]
     lib.sfd2_heatmap.argtypes = [vp, vp, ci, ci, vp, ci, ci, ci, ci, vp]
     lib.sfd2_debug_activation.argtypes = [vp, ctypes.c_char_p, vp, i64, pi, pi, pi]
     lib.sfd2_match.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, ctypes.POINTER(MatchConf), vp, vp, ci]
+    lib.sfd2_match_segments.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, ctypes.POINTER(MatchConf), vp, vp, ci]
     lib.sfd2_match_batch.argtypes = [vp, ctypes.POINTER(DescSet), ctypes.POINTER(DescSet), ci, ci,
                                      ctypes.POINTER(MatchConf), vp, vp, ci, ci]
     lib.sfd2_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]

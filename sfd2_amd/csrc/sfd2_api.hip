@@ -1248,6 +1248,70 @@ extern "C" int sfd2_extract_spp(sfd2_ctx *c, const float *x, int x_on_device, in
     return 0;
 }
 
+// extrat_spp_feats_multiscale (extract.py:87-201).  The level schedule (Python floats, round()) is the caller's; this
+// runs it: level 0 is the given NORMALISED image, every further level is the bilinear resize (align_corners=False) of
+// the PREVIOUS level (:186-188, whether or not that level was emitted), and for every emitted level: det -> score map
+// resized to the level size, NO stability weighting (:115 ignores it), heat >= conf_th, greedy grid NMS radius 4,
+// sort by confidence, 4-pixel border tested against the ORIGINAL W, H in level coordinates (:143-147), descriptors
+// sampled at level coordinates and renormalised (:163-174).  Key points are returned in LEVEL coordinates with the
+// per-level counts; the caller maps them back in float64 (x * W / nw, :176-177).  No top-K.
+extern "C" int sfd2_extract_spp_levels(sfd2_ctx *c, const float *x, int x_on_device, int H, int W, int n_levels,
+                                       const int32_t *nh, const int32_t *nw, const int32_t *emit, float conf_th, int flags,
+                                       float *kpts_xy, float *scores, float *desc, int64_t cap_out, int32_t *level_count)
+{
+    if (!c || !x || !nh || !nw || !emit || !level_count) return fail("sfd2_extract_spp_levels: null argument");
+    if (n_levels < 1 || n_levels > 64) return fail("sfd2_extract_spp_levels: 1..64 levels");
+    if (!c->weights_loaded) return fail("sfd2_extract_spp_levels: weights not loaded");
+    if (nh[0] != H || nw[0] != W) return fail("sfd2_extract_spp_levels: level 0 must be the image itself");
+    (void)flags;
+    HIPCHECK(hipSetDevice(c->device));
+    const float *cur = nullptr;
+    if (stage_image(c, x, x_on_device, H, W, &cur)) return -1;
+    DevBuf lvl[2];          // ping-pong level images (released at the end: this entry point is not on the throughput path)
+    int64_t total = 0;
+    int rc = 0;
+    for (int l = 0; l < n_levels && rc == 0; ++l) {
+        level_count[l] = 0;
+        if (nh[l] < 8 || nw[l] < 8) { rc = fail("sfd2_extract_spp_levels: a level is smaller than 8x8"); break; }
+        if (l > 0) {
+            DevBuf &dst = lvl[l & 1];
+            if (dst.ensure((size_t)3 * nh[l] * nw[l] * sizeof(float)) != hipSuccess) { rc = fail("sfd2_extract_spp_levels: out of memory"); break; }
+            launch_norm_resize(c->stream, cur, 0, nh[l - 1], nw[l - 1], nh[l], nw[l], dst.as<float>());
+            cur = dst.as<float>();
+        }
+        if (!emit[l]) continue;
+        set_path(c, false);
+        if ((rc = ensure_workspace(c, nh[l], nw[l])) != 0) break;
+        if ((rc = run_network(c, cur, 0)) != 0) break;
+        launch_heatmap(c->stream, c->score.as<float>(), 8 * c->H8, 8 * c->W8, nullptr, c->H4, c->W4, nh[l], nw[l],
+                       c->heat.as<float>(), nullptr);
+        if ((rc = run_greedy_nms(c, c->heat.as<float>(), nh[l], nw[l], conf_th, 4)) != 0) break;
+        if ((rc = run_selection(c, c->g_kept.as<float>(), nh[l], nw[l], 0.0f, 0, 4, 0, nullptr, nullptr, nullptr, H, W)) != 0) break;
+        int n = 0;
+        if ((rc = read_counts(c, -1, &n)) != 0) break;
+        if (total + n > cap_out) { rc = fail("sfd2_extract_spp_levels: output capacity exceeded"); break; }
+        if (n > 0) {
+            if (copy_out(c, kpts_xy + 2 * total, c->kpts.p, (size_t)n * 2 * sizeof(float), 0) ||
+                copy_out(c, scores + total, c->kscores.p, (size_t)n * sizeof(float), 0)) { rc = -1; break; }
+            if (desc) {
+                if (c->kdesc.ensure((size_t)n * 128 * sizeof(float)) != hipSuccess) { rc = fail("sfd2_extract_spp_levels: out of memory"); break; }
+                launch_sample_desc(c->stream, c->draw.as<float>(), c->H4, c->W4, nh[l], nw[l], c->kpts.as<float>(), nullptr, n,
+                                   c->kdesc.as<float>());
+                if (copy_out(c, desc + 128 * total, c->kdesc.p, (size_t)n * 128 * sizeof(float), 0)) { rc = -1; break; }
+            }
+            if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail("sfd2_extract_spp_levels: stream error"); break; }
+        }
+        level_count[l] = n;
+        total += n;
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)release_image_slot(c);
+    lvl[0].release();
+    lvl[1].release();
+    if (rc == 0 && hipGetLastError() != hipSuccess) rc = fail("sfd2_extract_spp_levels: kernel launch failed");
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------ stage entry points
 static int heat_to_device(sfd2_ctx *c, const float *heat, int H, int W)
 {
@@ -1584,6 +1648,148 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) c->tim.ms_match = ms;
     }
+    return 0;
+}
+
+// Segmented matcher: rows [seg0[s], seg0[s+1]) of d0 are matched against rows [seg1[s], seg1[s+1]) of d1 only -- the
+// diagonal blocks of a block-masked similarity matrix, all segments in ONE launch of the matcher kernels (grid z =
+// segment).  This is the same-label phase of the label-aware matcher (it_loc/matcher.py:248-264) once both descriptor
+// sets are ordered by label.  matches0[i] = row of d1 (global index) or -1; scores0 as sfd2_match, within the segment.
+extern "C" int sfd2_match_segments(sfd2_ctx *c, const void *d0, int n0, const void *d1, int n1, int dim, int dtype, int layout,
+                                   int on_device, int n_seg, const int32_t *seg0, const int32_t *seg1,
+                                   const sfd2_match_conf *conf, int64_t *matches0, float *scores0, int out_on_device)
+{
+    if (!c || !conf || !seg0 || !seg1 || !matches0 || !scores0) return fail("sfd2_match_segments: null argument");
+    if (dim <= 0 || dim > 128) return fail("descriptor dimension must be in [1,128]");
+    if (n0 < 0 || n1 < 0 || n_seg < 0) return fail("negative size");
+    if (n0 == 0) return 0;
+    if (!d0 || (n1 > 0 && !d1)) return fail("sfd2_match_segments: null descriptors");
+    if (seg0[0] != 0 || seg1[0] != 0 || seg0[n_seg] != n0 || seg1[n_seg] != n1) return fail("sfd2_match_segments: segment offsets must span [0, n]");
+    for (int i = 0; i < n_seg; ++i)
+        if (seg0[i + 1] < seg0[i] || seg1[i + 1] < seg1[i]) return fail("sfd2_match_segments: segment offsets must ascend");
+    HIPCHECK(hipSetDevice(c->device));
+    const int need_lo = conf->sim_mode == SFD2_SIM_F16X2;
+    const int need_top2 = (conf->flavour == SFD2_MATCH_ITLOC_NNR) || (conf->flavour == SFD2_MATCH_HLOC && conf->ratio_threshold > 0.0f);
+    const bool single_gemm = !need_lo && !need_top2;
+    std::vector<int> live;                     // segments with rows on both sides
+    int max_a = 0, max_b = 0;
+    for (int i = 0; i < n_seg; ++i)
+        if (seg0[i + 1] > seg0[i] && seg1[i + 1] > seg1[i]) {
+            live.push_back(i);
+            max_a = std::max(max_a, seg0[i + 1] - seg0[i]);
+            max_b = std::max(max_b, seg1[i + 1] - seg1[i]);
+        }
+    const int k = (int)live.size();
+    // rows without a partner segment: no match
+    HIPCHECK(c->m_out_m.ensure((size_t)n0 * sizeof(long long)));
+    HIPCHECK(c->m_out_s.ensure((size_t)n0 * sizeof(float)));
+    long long *out_m = out_on_device ? reinterpret_cast<long long *>(matches0) : c->m_out_m.as<long long>();
+    float *out_s = out_on_device ? scores0 : c->m_out_s.as<float>();
+    HIPCHECK(hipMemsetAsync(out_m, 0xFF, (size_t)n0 * sizeof(long long), c->stream));     // -1
+    HIPCHECK(hipMemsetAsync(out_s, 0, (size_t)n0 * sizeof(float), c->stream));
+    if (k > 0) {
+        int splits = std::max(1, (max_b + match_mutual_max_chunk() - 1) / match_mutual_max_chunk());
+        const int strip = match_mutual_strip();
+        size_t stage_bytes = 256 + (((size_t)n1 * sizeof(int32_t)) + 255);
+        if (!on_device) stage_bytes += ((((size_t)n0 + n1) * dim * elt_size(dtype)) + 511);
+        HIPCHECK(c->m_stage.ensure(stage_bytes));
+        HIPCHECK(c->m_hi0.ensure((size_t)n0 * 128 * 2));
+        HIPCHECK(c->m_hi1.ensure((size_t)std::max(n1, 1) * 128 * 2));
+        if (need_lo) { HIPCHECK(c->m_lo0.ensure((size_t)n0 * 128 * 2)); HIPCHECK(c->m_lo1.ensure((size_t)std::max(n1, 1) * 128 * 2)); }
+        const size_t tot_part = (size_t)splits * ((size_t)n0 + n1);
+        HIPCHECK(c->m_part_f.ensure(tot_part * 2 * sizeof(float)));
+        HIPCHECK(c->m_part_i.ensure(tot_part * sizeof(int)));
+        size_t rk = 0;
+        for (int i : live) rk += (size_t)((seg0[i + 1] - seg0[i] + strip - 1) / strip) * (size_t)(seg1[i + 1] - seg1[i]);
+        if (single_gemm) HIPCHECK(c->m_rkeys.ensure(std::max<size_t>(rk, 1) * sizeof(float)));
+        HIPCHECK(c->m_red.ensure(((size_t)n0 + n1 + 1) * 3 * sizeof(float)));
+        HIPCHECK(c->m_jobs.ensure((size_t)2 * k * sizeof(MatchJob)));
+        HIPCHECK(c->m_fins.ensure((size_t)k * sizeof(MatchFinal)));
+        prof_step_begin(c);
+        size_t stage_off = 0;
+        const half_t *h0 = nullptr, *l0 = nullptr, *h1 = nullptr, *l1 = nullptr;
+        // forced conversion into the context's fp16 buffers (a device-resident fp16 set would otherwise be used in place,
+        // which is fine too: the jobs only need row-offset pointers)
+        if (prep_set(c, d0, n0, nullptr, n0, dim, dtype, layout, on_device, need_lo, c->m_stage, stage_off, c->m_hi0.as<half_t>(),
+                     c->m_lo0.as<half_t>(), &h0, &l0)) return -1;
+        if (prep_set(c, d1, n1, nullptr, n1, dim, dtype, layout, on_device, need_lo, c->m_stage, stage_off, c->m_hi1.as<half_t>(),
+                     c->m_lo1.as<half_t>(), &h1, &l1)) return -1;
+        // identity column map: remap + seg1[s] turns a segment-local match into the global row of d1
+        std::vector<int32_t> iota((size_t)n1);
+        for (int i = 0; i < n1; ++i) iota[i] = i;
+        int32_t *iota_dev = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(c->m_stage.p) + ((stage_off + 255) & ~(size_t)255));
+        HIPCHECK(hipMemcpyAsync(iota_dev, iota.data(), (size_t)n1 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));      // iota is a host temporary
+        const size_t jobs_bytes = 2 * (size_t)k * sizeof(MatchJob), fins_bytes = (size_t)k * sizeof(MatchFinal);
+        HIPCHECK(hipEventSynchronize(c->ev_jobs));
+        if (jobs_bytes + fins_bytes > c->pin_cap) {
+            if (c->pin_jobs) (void)hipHostFree(c->pin_jobs);
+            c->pin_jobs = nullptr;
+            c->pin_cap = 0;
+            HIPCHECK(hipHostMalloc(&c->pin_jobs, jobs_bytes + fins_bytes, hipHostMallocDefault));
+            c->pin_cap = jobs_bytes + fins_bytes;
+        }
+        MatchJob *jobs = reinterpret_cast<MatchJob *>(c->pin_jobs);
+        MatchJob2 *jobs2 = reinterpret_cast<MatchJob2 *>(c->pin_jobs);
+        MatchFinal *fins = reinterpret_cast<MatchFinal *>(reinterpret_cast<char *>(c->pin_jobs) + jobs_bytes);
+        float *pf = c->m_part_f.as<float>();
+        int *pi = c->m_part_i.as<int>();
+        float *red = c->m_red.as<float>();
+        size_t poff = 0, roff = 0, rkoff = 0;
+        for (int j = 0; j < k; ++j) {
+            const int sg = live[j], a0 = seg0[sg], na = seg0[sg + 1] - a0, b0 = seg1[sg], nb = seg1[sg + 1] - b0;
+            MatchFinal &fn = fins[j];
+            fn.remap = iota_dev + b0;
+            if (single_gemm) {
+                MatchJob2 &j2 = jobs2[j];
+                j2.q_hi = h0 + (size_t)a0 * 128; j2.d_hi = h1 + (size_t)b0 * 128; j2.n0 = na; j2.n1 = nb;
+                j2.part_v1 = pf + 2 * poff; j2.part_i1 = pi + poff;
+                j2.rkeys = c->m_rkeys.as<float>() + rkoff;
+                rkoff += (size_t)((na + strip - 1) / strip) * nb;
+                poff += (size_t)splits * na + (size_t)splits * nb;
+                fn.f_v1 = fn.f_v2 = fn.r_v1 = fn.r_v2 = nullptr; fn.f_i1 = fn.r_i1 = nullptr;
+            } else {
+                MatchJob &f = jobs[2 * j], &r = jobs[2 * j + 1];
+                f.a_hi = h1 + (size_t)b0 * 128; f.a_lo = l1 ? l1 + (size_t)b0 * 128 : nullptr;
+                f.b_hi = h0 + (size_t)a0 * 128; f.b_lo = l0 ? l0 + (size_t)a0 * 128 : nullptr; f.na = nb; f.nb = na;
+                f.part_v1 = pf + 2 * poff; f.part_v2 = pf + 2 * poff + (size_t)splits * na; f.part_i1 = pi + poff;
+                poff += (size_t)splits * na;
+                r.a_hi = f.b_hi; r.a_lo = f.b_lo; r.b_hi = f.a_hi; r.b_lo = f.a_lo; r.na = na; r.nb = nb;
+                r.part_v1 = pf + 2 * poff; r.part_v2 = pf + 2 * poff + (size_t)splits * nb; r.part_i1 = pi + poff;
+                poff += (size_t)splits * nb;
+                fn.f_v1 = f.part_v1; fn.f_v2 = f.part_v2; fn.f_i1 = f.part_i1;
+                fn.r_v1 = r.part_v1; fn.r_v2 = r.part_v2; fn.r_i1 = r.part_i1;
+            }
+            fn.n0 = na; fn.n1 = nb;
+            fn.matches0 = out_m + a0;
+            fn.scores0 = out_s + a0;
+            fn.red_f = red + 3 * roff; roff += (size_t)na;
+            fn.red_r = red + 3 * roff; roff += (size_t)nb;
+        }
+        HIPCHECK(hipMemcpyAsync(c->m_jobs.p, jobs, jobs_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipMemcpyAsync(c->m_fins.p, fins, fins_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipEventRecord(c->ev_jobs, c->stream));
+        const int max_n = std::max(max_a, max_b);
+        if (single_gemm) {
+            ProfScope ps(c, "match_segments", "match_mutual_kernel", 0.0, 0.0);
+            launch_match_mutual(c->stream, c->m_jobs.as<MatchJob2>(), c->m_fins.as<MatchFinal>(), k, max_a, max_b, splits,
+                                c->zero_page.as<half_t>());
+            launch_match_decide(c->stream, c->m_fins.as<MatchFinal>(), k, max_n, conf->flavour, conf->do_mutual_check,
+                                conf->ratio_threshold, conf->distance_threshold);
+        } else {
+            ProfScope ps(c, "match_segments", "match_top2_kernel", 0.0, 0.0);
+            launch_match_top2(c->stream, c->m_jobs.as<MatchJob>(), 2 * k, max_n, splits, need_lo, need_top2, c->zero_page.as<half_t>());
+            launch_match_finalize(c->stream, c->m_fins.as<MatchFinal>(), k, max_n, splits, conf->flavour, conf->do_mutual_check,
+                                  conf->ratio_threshold, conf->distance_threshold);
+        }
+        prof_step_end(c);
+        HIPCHECK(hipGetLastError());
+    }
+    if (!out_on_device) {
+        if (copy_out(c, matches0, c->m_out_m.p, (size_t)n0 * sizeof(long long), 0)) return -1;
+        if (copy_out(c, scores0, c->m_out_s.p, (size_t)n0 * sizeof(float), 0)) return -1;
+    }
+    HIPCHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -1,8 +1,8 @@
 """Host-side mirror of extract.py (reference), the older SuperPoint-style extractor:
-nms_fast (:17-84), extract_spp_feats_singlescale (:205-277), extract_spp_return (:280-302).
-Not used by the shipped pipelines but on the hot-path table (8a18).
-The greedy grid NMS runs on the GPU as an exact parallel relaxation (libsfd2hip sfd2_nms_fast /
-sfd2_extract_spp); multi-scale (extrat_spp_feats_multiscale :87-201) is a "next" row."""
+nms_fast (:17-84), extrat_spp_feats_multiscale (:87-201), extract_spp_feats_singlescale (:205-277),
+extract_spp_return (:280-302).  Not used by the shipped pipelines but on the hot-path table
+(8a18, 8f rank 3).  The greedy grid NMS runs on the GPU as an exact parallel relaxation (libsfd2hip sfd2_nms_fast /
+sfd2_extract_spp / sfd2_extract_spp_levels)."""
 import ctypes
 
 import numpy as np
@@ -73,10 +73,67 @@ def extract_spp_feats_singlescale(model, img, conf_th=0.10):
     return pts, de[:n].copy(), pts[:, 2].copy(), dfull, heat
 
 
+def spp_level_schedule(H, W, scale_f=2 ** 0.25, min_scale=0.05, max_scale=1.0, min_size=256, max_size=2048):
+    """The while-loop of extract.py:102-188 as a list of (nh, nw, emit): Python float arithmetic and round() exactly as
+    the reference (s /= scale_f; nh, nw = round(H * s), round(W * s))."""
+    assert max_scale <= 1
+    s = 1.0
+    nh, nw = H, W
+    levels = []
+    while s + 0.001 >= max(min_scale, min_size / max(H, W)):
+        levels.append((nh, nw, s - 0.001 <= min(max_scale, max_size / max(H, W))))
+        s /= scale_f
+        nh, nw = round(H * s), round(W * s)
+    return levels
+
+
+def extrat_spp_feats_multiscale(model, img, conf_th=0.0050, scale_f=2 ** 0.25,
+                                min_scale=0.05, max_scale=1.0, min_size=256, max_size=2048):
+    """extract.py:87-201 (the reference's spelling).  img: [1,3,H,W] NORMALISED image.  Returns
+    (all_pts [N,3] f64 (x, y, score) in original-image coordinates, all_descs [N,128], all_scores [N]) with the levels
+    concatenated in scale order, or (None, None, None) when no level is emitted."""
+    ctx = model.context
+    if torch is not None and isinstance(img, torch.Tensor):
+        a = img.detach().to(torch.float32).cpu().numpy()
+    else:
+        a = np.asarray(img, dtype=np.float32)
+    a = np.ascontiguousarray(a.reshape(a.shape[-3:]))
+    _, H, W = a.shape
+    levels = spp_level_schedule(H, W, scale_f, min_scale, max_scale, min_size, max_size)
+    if not any(e for _, _, e in levels):
+        return None, None, None
+    nl = len(levels)
+    nh = (ctypes.c_int32 * nl)(*[l[0] for l in levels])
+    nw = (ctypes.c_int32 * nl)(*[l[1] for l in levels])
+    em = (ctypes.c_int32 * nl)(*[int(l[2]) for l in levels])
+    cap = sum(l[0] * l[1] for l in levels if l[2])
+    kp = np.empty((cap, 2), dtype=np.float32)
+    sc = np.empty((cap,), dtype=np.float32)
+    de = np.empty((cap, 128), dtype=np.float32)
+    cnt = (ctypes.c_int32 * nl)()
+    _lib.check(ctx.lib.sfd2_extract_spp_levels(ctx.h, a.ctypes.data, 0, H, W, nl, nh, nw, em, float(conf_th), 0,
+                                               kp.ctypes.data, sc.ctypes.data, de.ctypes.data, cap, cnt))
+    all_pts, all_descs = [], []
+    off = 0
+    for (lh, lw, emit), n in zip(levels, cnt):
+        if not emit:
+            continue
+        pts = np.zeros((n, 3))                                   # float64, as the reference's np.zeros((3, N))
+        pts[:, 0] = kp[off:off + n, 0].astype(np.float64) * W / lw     # extract.py:176-177
+        pts[:, 1] = kp[off:off + n, 1].astype(np.float64) * H / lh
+        pts[:, 2] = sc[off:off + n]
+        all_pts.append(pts)
+        all_descs.append(de[off:off + n].copy())
+        off += n
+    all_pts = np.vstack(all_pts)
+    return all_pts, np.vstack(all_descs), all_pts[:, 2]
+
+
 def extract_spp_return(sgd2, img_path, conf_th=0.1, need_nms=False, multi_scale=False, min_size=256, max_size=9999):
     """extract.py:280-302 (tensor input; a str path needs the caller's own image decoding)."""
     if isinstance(img_path, str):
         raise NotImplementedError("pass the normalised image tensor [1,3,H,W]; image decoding is outside the hot path")
-    if multi_scale:
-        raise NotImplementedError("multi-scale extraction (extract.py:87-201) is a 'next' row (SURVEY.md section 8f)")
+    if multi_scale:      # extract.py:295-299: scale_f = 1.2
+        return extrat_spp_feats_multiscale(model=sgd2, img=img_path, conf_th=conf_th, scale_f=1.2, min_size=min_size,
+                                           max_size=max_size)
     return extract_spp_feats_singlescale(model=sgd2, img=img_path, conf_th=conf_th)

@@ -61,35 +61,57 @@ class Matcher:
                                       0, ctypes.byref(conf), m.ctypes.data, s.ctypes.data, 0))
         return m, s
 
+    def _match_segments(self, d0, d1, seg0, seg1):
+        """One device call over all segments: rows [seg0[s], seg0[s+1]) of d0 against rows [seg1[s], seg1[s+1]) of d1."""
+        d0 = np.ascontiguousarray(d0, dtype=np.float64)
+        d1 = np.ascontiguousarray(d1, dtype=np.float64)
+        seg0 = np.ascontiguousarray(seg0, dtype=np.int32)
+        seg1 = np.ascontiguousarray(seg1, dtype=np.int32)
+        ctx = _lib.default_context(self._device)
+        m = np.empty((d0.shape[0],), dtype=np.int64)
+        s = np.empty((d0.shape[0],), dtype=np.float32)
+        conf = self._conf()
+        _lib.check(ctx.lib.sfd2_match_segments(ctx.h, d0.ctypes.data, d0.shape[0], d1.ctypes.data, d1.shape[0], d0.shape[1],
+                                               _lib.DT_F64, _lib.LAYOUT_ND, 0, len(seg0) - 1, seg0.ctypes.data, seg1.ctypes.data,
+                                               ctypes.byref(conf), m.ctypes.data, s.ctypes.data, 0))
+        return m, s
+
     def matcher_with_label(self, descriptors1, labels1, descriptors2, labels2):
-        """it_loc/matcher.py:239-297.  Returns [M, 2] (index in 1, index in 2)."""
-        labels1, labels2 = np.asarray(labels1), np.asarray(labels2)
-        uids2 = set(np.unique(labels2).tolist())
-        valid_uids = [v for v in np.unique(labels1).tolist() if v in uids2 and v > 0]
-        all_matches = []
-        for uid in valid_uids:                                   # same-label mutual NN (:248-264)
-            idx1 = np.where(labels1 == uid)[0]
-            idx2 = np.where(labels2 == uid)[0]
-            m, _ = self._match(descriptors1[idx1], descriptors2[idx2])
-            for i in np.flatnonzero(m >= 0):
-                all_matches.append((int(idx1[i]), int(idx2[m[i]])))
-        matched1 = {a for a, _ in all_matches}
-        matched2 = {b for _, b in all_matches}
-        idx1 = np.array([i for i in range(descriptors1.shape[0]) if i not in matched1], dtype=np.int64)
-        idx2 = np.array([i for i in range(descriptors2.shape[0]) if i not in matched2], dtype=np.int64)
-        if len(idx1) and len(idx2):                              # mutual NN among the rest (:266-293)
-            m, _ = self._match(descriptors1[idx1], descriptors2[idx2])
-            for i in np.flatnonzero(m >= 0):
-                all_matches.append((int(idx1[i]), int(idx2[m[i]])))
-        return np.array(all_matches, dtype=int).reshape(-1, 2)
+        """it_loc/matcher.py:239-297.  Returns [M, 2] (index in 1, index in 2), in the reference's order: same-label
+        matches label by label (ascending label, ascending index in 1), then the matches among the rest.
+        Device work: ONE segmented launch for every shared label (both sets ordered by label, the diagonal blocks of the
+        block-masked similarity matrix), one launch for the rest; host work is vectorised numpy."""
+        d1 = np.asarray(descriptors1)
+        d2 = np.asarray(descriptors2)
+        labels1, labels2 = np.asarray(labels1).reshape(-1), np.asarray(labels2).reshape(-1)
+        shared = np.intersect1d(np.unique(labels1), np.unique(labels2))
+        shared = shared[shared > 0]
+        all_matches = np.zeros((0, 2), dtype=int)
+        if len(shared) and len(d1) and len(d2):
+            # rows that carry a shared label, grouped by label (stable: ascending original index inside a label)
+            k1 = np.flatnonzero(np.isin(labels1, shared))
+            k2 = np.flatnonzero(np.isin(labels2, shared))
+            o1 = k1[np.argsort(labels1[k1], kind="stable")]
+            o2 = k2[np.argsort(labels2[k2], kind="stable")]
+            seg0 = np.concatenate([[0], np.cumsum([np.count_nonzero(labels1[o1] == u) for u in shared])])
+            seg1 = np.concatenate([[0], np.cumsum([np.count_nonzero(labels2[o2] == u) for u in shared])])
+            m, _ = self._match_segments(d1[o1], d2[o2], seg0, seg1)
+            hit = np.flatnonzero(m >= 0)                              # label-major, then ascending row: the reference's order
+            all_matches = np.stack([o1[hit], o2[m[hit]]], axis=1).astype(int)
+        rest1 = np.setdiff1d(np.arange(len(d1)), all_matches[:, 0])   # (:266-281) everything still unmatched, any label
+        rest2 = np.setdiff1d(np.arange(len(d2)), all_matches[:, 1])
+        if len(rest1) and len(rest2):                                 # mutual NN among the rest (:283-293)
+            m, _ = self._match(d1[rest1], d2[rest2])
+            hit = np.flatnonzero(m >= 0)
+            all_matches = np.concatenate([all_matches, np.stack([rest1[hit], rest2[m[hit]]], axis=1).astype(int)], axis=0)
+        return all_matches.reshape(-1, 2)
 
     def forward(self, data):
         if self.mode == 'nnml':
             d0, d1 = np.asarray(data['descriptors0']), np.asarray(data['descriptors1'])
             pairs = self.matcher_with_label(d0, data['labels0'], d1, data['labels1'])
             all_matches = np.ones((d0.shape[0],), dtype=int) * -1
-            for a, b in pairs:
-                all_matches[a] = b
+            all_matches[pairs[:, 0]] = pairs[:, 1]
             _, s = self._match(d0, d1)                           # scores: top-1 similarity over ALL of image 2 (:111)
             return {'matches0': all_matches, 'matching_scores0': s.astype(np.float64)}
         m, s = self._match(data['descriptors0'], data['descriptors1'])

@@ -240,6 +240,16 @@ def gen_extract_spp(model, h, w, seed, conf_th, tag):
     print(f"extract_spp_{tag}: N={len(pts)} ties={out['n_ties']} nms_fast kept {o.shape[1]} of {n}")
 
 
+def gen_extract_spp_ms(model, h, w, seed, conf_th, min_size, tag):
+    """extract.py extrat_spp_feats_multiscale (:87-201), scale_f = 1.2 as extract_spp_return calls it (:295-297)."""
+    img = synth.make_image(h, w, seed)
+    x = norm_rgb(img)
+    pts, desc, scores = ref_extract.extrat_spp_feats_multiscale(model, x, conf_th=conf_th, scale_f=1.2, min_size=min_size, max_size=9999)
+    out = {"h": h, "w": w, "seed": seed, "conf_th": conf_th, "min_size": min_size, "pts": pts, "desc": desc.astype(np.float32)}
+    np.savez_compressed(os.path.join(HERE, f"extract_spp_ms_{tag}.npz"), **out)
+    print(f"extract_spp_ms_{tag}: N={len(pts)}")
+
+
 def gen_matchers():
     """G6: hloc NearestNeighbor (hloc/matchers/nearest_neighbor.py:27-57) with the
     NNM / ONN / NNR confs (hloc/match_features.py:20-45) + a ratio-test conf, and
@@ -334,6 +344,10 @@ if __name__ == "__main__":
         gen_extract_mask(model, 96, 128, 21, 180, "96x128_k180")      # labelled < topK < all
         gen_extract_mask(model, 100, 130, 22, 5000, "100x130_k5000")  # topK >= all
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sppms":
+        gen_extract_spp_ms(model, 96, 128, 21, 0.02, 40, "96x128")
+        gen_extract_spp_ms(model, 100, 130, 22, 0.05, 64, "100x130")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "matchers":
         gen_matchers()
         sys.exit(0)
@@ -344,5 +358,7 @@ if __name__ == "__main__":
     gen_extract(model, 100, 130, 22, -1, "100x130_all")
     gen_extract(model, 480, 640, 0, 1024, "480x640_k1024")
     gen_extract_spp(model, 96, 128, 21, 0.02, "96x128")
+    gen_extract_spp_ms(model, 96, 128, 21, 0.02, 40, "96x128")
+    gen_extract_spp_ms(model, 100, 130, 22, 0.05, 64, "100x130")
     gen_matchers()
     gen_host()

@@ -389,3 +389,93 @@ def test_fused_post_equals_three_kernel_path(synth_sd, h, w, stab):
     allf = extract_resnet_return(m, img[None], conf_th=0.001, topK=-1, scales=[1.0])
     for k in ("keypoints", "scores", "descriptors"):
         np.testing.assert_array_equal(allf[k], allk[k])
+
+
+# ------------------------------------------------------------------ extract.py multi-scale variant (VERDICT r1 missing #3)
+@pytest.mark.parametrize("tag,min_size", [("96x128", 40), ("100x130", 64)])
+def test_extrat_spp_feats_multiscale_vs_reference_golden_and_oracle(model_f32, synth_sd, golden_dir, tag, min_size):
+    """extrat_spp_feats_multiscale (extract.py:87-201) through sfd2_extract_spp_levels, strict mode: the reference
+    golden's key points (original-image coordinates, float64), in its order up to near-ties, descriptors to 2e-5; and
+    the schedule helper reproduces the reference's level sizes."""
+    from sfd2_amd import extract as ex
+    g = np.load(os.path.join(golden_dir, f"extract_spp_ms_{tag}.npz"))
+    h, w = int(g["h"]), int(g["w"])
+    x = orc.norm_rgb(synth.make_image(h, w, int(g["seed"])))
+    pts, desc, scores = ex.extrat_spp_feats_multiscale(model_f32, x[None], conf_th=float(g["conf_th"]), scale_f=1.2,
+                                                       min_size=min_size, max_size=9999)
+    assert pts.dtype == np.float64 and pts.shape[1] == 3 and desc.shape == (len(pts), 128)
+    assert abs(len(pts) - len(g["pts"])) <= 3
+    mine = {(round(float(p[0]), 5), round(float(p[1]), 5)): i for i, p in enumerate(pts)}
+    idx = np.array([mine.get((round(float(p[0]), 5), round(float(p[1]), 5)), -1) for p in g["pts"]])
+    ok = idx >= 0
+    assert ok.mean() >= 0.99, ok.mean()
+    assert np.abs(idx[ok] - np.flatnonzero(ok)).max() <= 4
+    np.testing.assert_allclose(pts[idx[ok], 2], g["pts"][ok, 2], rtol=3e-4)
+    assert np.abs(desc[idx[ok]] - g["desc"][ok]).max() <= 2e-5
+    np.testing.assert_array_equal(scores, pts[:, 2])
+    want = orc.extrat_spp_feats_multiscale(synth_sd, x, conf_th=float(g["conf_th"]), scale_f=1.2, min_size=min_size, max_size=9999)
+    assert abs(len(want[0]) - len(pts)) <= 3
+    assert ex.extrat_spp_feats_multiscale(model_f32, x[None], min_size=4096) == (None, None, None)
+    lv = ex.spp_level_schedule(480, 640, 1.2, min_size=256, max_size=9999)
+    assert lv[0] == (480, 640, True) and lv[1][:2] == (400, 533) and all(e for _, _, e in lv) and min(max(a, b) for a, b, _ in lv) >= 255
+    r = ex.extract_spp_return(model_f32, x[None], conf_th=float(g["conf_th"]), multi_scale=True, min_size=min_size)
+    assert len(r) == 3 and len(r[0]) == len(pts)
+
+
+# ------------------------------------------------------------------ segmented (block-masked) matcher (VERDICT r1 missing #4)
+@pytest.mark.parametrize("sim_mode", ["f16", "f16x2"])
+@pytest.mark.parametrize("mode", ["nnm", "nnr"])
+def test_match_segments_equals_per_segment_calls(sim_mode, mode):
+    """sfd2_match_segments: every segment pair in ONE launch equals a loop of sfd2_match calls on the sub-ranges, for the
+    single-GEMM kernel (nnm / f16) and the two-GEMM kernels (nnr, f16x2); empty segments on either side give -1."""
+    from sfd2_amd.matcher import Matcher
+    mt = Matcher({"output": "X", "model": {"name": mode, "distance_threshold": 0.9 if mode == "nnr" else None, "sim_mode": sim_mode}}).eval().cuda()
+    rs = np.random.RandomState(5)
+    len0 = [300, 0, 17, 1, 700, 64, 5]
+    len1 = [280, 40, 0, 3, 650, 64, 900]
+    d0 = synth.make_descriptors(sum(len0), seed=41).astype(np.float64)
+    d1 = synth.make_descriptors(sum(len1), seed=42).astype(np.float64)
+    seg0 = np.concatenate([[0], np.cumsum(len0)]); seg1 = np.concatenate([[0], np.cumsum(len1)])
+    for a, b, la, lb in zip(seg0, seg1, len0, len1):      # plant matches inside the segments
+        k = min(la, lb) // 2
+        if k:
+            src, dst = rs.permutation(la)[:k], rs.permutation(lb)[:k]
+            noisy = d0[a + src] + 0.05 * rs.standard_normal((k, 128))
+            d1[b + dst] = noisy / np.linalg.norm(noisy, axis=1, keepdims=True)
+    m, s = mt._match_segments(d0, d1, seg0, seg1)
+    assert m.shape == (len(d0),) and (m >= -1).all()
+    for a, b, la, lb in zip(seg0, seg1, len0, len1):
+        if la == 0:
+            continue
+        if lb == 0:
+            assert (m[a:a + la] == -1).all() and (s[a:a + la] == 0).all()
+            continue
+        mm, ss = mt._match(d0[a:a + la], d1[b:b + lb])
+        want = np.where(mm >= 0, mm + b, -1)
+        np.testing.assert_array_equal(m[a:a + la], want)
+        np.testing.assert_array_equal(s[a:a + la], ss)
+    assert (m >= 0).sum() > 300
+
+
+def test_label_matcher_single_launch_vs_oracle_f16():
+    """Matcher 'nnml' with the default fp16 GEMM: one segmented launch for all shared labels + one for the rest, against
+    the oracle's label matcher on the rows that are decided by a clear similarity gap."""
+    from sfd2_amd.matcher import Matcher
+    rs = np.random.RandomState(9)
+    n0, n1 = 900, 1100
+    d0 = synth.make_descriptors(n0, seed=51).astype(np.float64)
+    d1 = synth.make_descriptors(n1, seed=52).astype(np.float64)
+    l0 = rs.randint(0, 6, n0); l1 = rs.randint(0, 7, n1)      # label 0 = unlabelled, 6 only in image 1
+    k = 400
+    src, dst = rs.permutation(n0)[:k], rs.permutation(n1)[:k]
+    noisy = d0[src] + 0.05 * rs.standard_normal((k, 128))
+    d1[dst] = noisy / np.linalg.norm(noisy, axis=1, keepdims=True)
+    l1[dst[:300]] = l0[src[:300]]                               # most planted pairs share a label
+    mt = Matcher({"output": "NNML", "model": {"name": "nnml"}}).eval().cuda()
+    got = mt({"descriptors0": d0, "descriptors1": d1, "labels0": l0, "labels1": l1})
+    want = orc.itloc_matcher_with_label(d0, l0, d1, l1)
+    agree = (got["matches0"] == want["matches0"]).mean()
+    assert agree >= 0.97, agree                                  # fp16 similarities flip only near-ties
+    planted = np.full(n0, -1); planted[src] = dst
+    strong = src[:300]
+    assert (got["matches0"][strong] == planted[strong]).mean() >= 0.99

@@ -619,7 +619,7 @@ def test_extract_py_api_vs_reference_golden_and_oracle(model, model_f32, synth_s
             assert np.abs(desc[rank[ok]] - ref_desc[ok]).max() <= dt
         np.testing.assert_allclose(desc_full, want[3], atol=max(tol_desc, 2e-5))
     with pytest.raises(NotImplementedError):
-        extract_spp_return(model, x[None], multi_scale=True)
+        extract_spp_return(model, "an/image/path.jpg")       # decoding stays with the caller
 
 
 def test_feature_matching_mask_and_remap():

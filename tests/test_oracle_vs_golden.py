@@ -265,3 +265,25 @@ def test_cv2_cubic_restatement_invariants():
     assert abs(out - (-0.09375 * 25 + 0.59375 * 36 + 0.59375 * 49 - 0.09375 * 64)) < 1e-4
     item, size = orc.image_dataset_item((np.arange(50 * 70 * 3) % 251).astype(np.uint8).reshape(50, 70, 3), resize_max=35)
     assert item.shape == (3, 25, 35) and tuple(size) == (70, 50) and item.dtype == np.float32
+
+
+@pytest.mark.parametrize("tag,min_size", [("96x128", 40), ("100x130", 64)])
+def test_extract_spp_multiscale_vs_reference_golden(golden_dir, synth_sd, tag, min_size):
+    """extract.py:87-201 (progressive down-scaling, no stability, original-size border test, float64 back-mapping):
+    the oracle's restatement against the reference's own output -- same key points in the same order, scores and
+    descriptors to fp32 round-off."""
+    from sfd2_amd import synth
+    g = np.load(os.path.join(golden_dir, f"extract_spp_ms_{tag}.npz"))
+    x = orc.norm_rgb(synth.make_image(int(g["h"]), int(g["w"]), int(g["seed"])))
+    pts, desc, scores = orc.extrat_spp_feats_multiscale(synth_sd, x, conf_th=float(g["conf_th"]), scale_f=1.2, min_size=min_size,
+                                                        max_size=9999)
+    assert pts.shape == g["pts"].shape and pts.dtype == np.float64
+    # the order inside a level is by confidence; equal up to swaps of near-equal scores
+    np.testing.assert_allclose(np.sort(pts[:, 2])[::-1], np.sort(g["pts"][:, 2])[::-1], rtol=2e-4)
+    mine = {(round(float(p[0]), 6), round(float(p[1]), 6)): i for i, p in enumerate(pts)}
+    idx = np.array([mine.get((round(float(p[0]), 6), round(float(p[1]), 6)), -1) for p in g["pts"]])
+    assert (idx >= 0).mean() >= 0.995
+    ok = idx >= 0
+    assert np.abs(idx[ok] - np.flatnonzero(ok)).max() <= 3
+    assert np.abs(desc[idx[ok]] - g["desc"][ok]).max() <= 2e-5
+    assert orc.extrat_spp_feats_multiscale(synth_sd, x, min_size=4096)[0] is None      # no level emitted -> (None, None, None)
