@@ -83,12 +83,12 @@ void conv1x1_c256_kernel(const half_t *__restrict__ in, int npix, const half_t *
     ISSUE_G(g0)
     if (g0 + 1 < g1) { ISSUE_G(g0 + 1) }
     if (g0 + 2 < g1) { ISSUE_G(g0 + 2) }
-    __syncthreads();   // first group, SS (and everything else) complete
+    SFD2_BARRIER_DRAIN();   // first group, SS (and everything else) complete
 
     for (int g = g0; g < g1; ++g) {
         if (g != g0) {
             // tail: fewer copies are in flight than the constant assumes -> drain (at most twice per block)
-            if (g + 2 < g1) WAIT_GROUP(); else __syncthreads();
+            if (g + 2 < g1) WAIT_GROUP(); else SFD2_BARRIER_DRAIN();
         }
         const unsigned char *st = Xs + (g & (NST - 1)) * STAGE_BYTES;
         const int p = ph * 32 + lrow;            // this lane's pixel within the stage

@@ -155,7 +155,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     } else if (WBUF == 3) {
         if (NS > 1) { ISSUE_W(1, 1) BARRIER_KEEP(WPW); } else { BARRIER_DRAIN(); }
     } else {
-        __syncthreads();   // hipcc drains vmcnt(0) before the barrier while LDS-DMA is in flight
+        SFD2_BARRIER_DRAIN();   // hipcc drains vmcnt(0) before the barrier while LDS-DMA is in flight
     }
 
     const int lrow = lane & 31, lhi = lane >> 5;
@@ -249,11 +249,11 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             else if (x_now) BARRIER_KEEP(XPW);
             else BARRIER_DRAIN();
         } else {
-            __syncthreads();
+            SFD2_BARRIER_DRAIN();
         }
         if (XBUF == 1 && new_chunk) {
             ISSUE_X(nchunk, 0)
-            __syncthreads();
+            SFD2_BARRIER_DRAIN();
         }
         tap = ntap;
         chunk = nchunk;

@@ -120,7 +120,7 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
     int tile = blockIdx.x;
     FETCH_IMG(tile)
     STORE_IMG()
-    __syncthreads();   // full barrier once: the filter copies (vmcnt) and IM / SS (LDS) are complete
+    SFD2_BARRIER_DRAIN();   // full barrier once: the filter copies (vmcnt) and IM / SS (LDS) are complete
 
     for (;;) {
         const int tx = tile % tiles_x, ty = tile / tiles_x;

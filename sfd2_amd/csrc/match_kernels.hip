@@ -242,7 +242,7 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
                                          (lds_void_t *)(smem + (buf_)*TA2 * 256 + (wave * (TA2 / 16) + c) * 1024), 16, 0, 0); \
     }
         ISSUE_A(0, 0)
-        __syncthreads();
+        SFD2_BARRIER_DRAIN();
         for (int s = 0; s < nst; ++s) {
             const int buf = s & 1;
             if (s + 1 < nst) { ISSUE_A(s + 1, buf ^ 1) }
@@ -294,7 +294,7 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
                     }
                 }
             }
-            __syncthreads();
+            SFD2_BARRIER_DRAIN();
         }
 #undef ISSUE_A
     }

@@ -141,7 +141,7 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const h
                                          (lds_void_t *)(smem + (buf_)*TA2 * 256 + (wave * (TA2 / 16) + c) * 1024), 16, 0, 0); \
     }
         ISSUE_B(0, 0)
-        __syncthreads();
+        SFD2_BARRIER_DRAIN();
         // tile by tile.  Measured alternatives (profiles/r02_match_pmc.txt): the MFMAs of tile k + 1 software-pipelined
         // with the epilogue of tile k (+2 %, register pressure), the same pinned with sched_barrier (+3 %), 32 queries per
         // wave at 4 waves per SIMD (+12 %), 128-candidate stages (+23 %, spills), one wave per SIMD (+48 %)
@@ -158,7 +158,7 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const h
                     MQ_TILE_EPI(c0, c1, tile)
                 }
             }
-            __syncthreads();
+            SFD2_BARRIER_DRAIN();
         }
 #undef ISSUE_B
         __syncthreads();

@@ -106,7 +106,7 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
 #define RB_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
     RB_ISSUE_X(ya - 1)
-    __syncthreads();    // GW and the first row complete
+    SFD2_BARRIER_DRAIN();    // GW and the first row complete
 
     const int n = lrow;                       // this lane's strip pixel in the 32x32 MFMAs
     const int pp_base = (n >> 1) * 1056 + (n & 1) * 512;               // its record in a pair-padded row

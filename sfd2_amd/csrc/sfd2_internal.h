@@ -13,6 +13,11 @@ static inline const char *sfd2_env(const char *name) { return getenv(name); }
 static inline const char *sfd2_env(const char *) { return nullptr; }
 #endif
 
+// Block barrier that must make other waves' LDS-DMA copies (global_load_lds) visible: the drain of the vector-memory
+// counter is written out.  A plain __syncthreads() happens to emit the same s_waitcnt vmcnt(0) today while a copy is in
+// flight, but that is hipcc's choice, not a language guarantee.
+#define SFD2_BARRIER_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 typedef _Float16 half_t;
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
