@@ -362,10 +362,16 @@ static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int 
                        Ho, Wo, tiles_x, zero_page);
 }
 
+bool conv3x3_pp_serves(int ks, int stride, int CoutP, int Cin);
+void launch_conv3x3_pp(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
+                       const float *scale, const float *shift, int CoutP, int relu, half_t *out,
+                       int Ho, int Wo, const half_t *zero_page);
+
 // K-chunk width the v2 kernel wants the filters packed with (0 = layer is not served by v2)
 int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin)
 {
     if (CoutP % 128 != 0) return 0;
+    if (conv3x3_pp_serves(ks, stride, CoutP, Cin)) return 32;   // conv3_kernels.hip
     if (stride == 2) return (ks == 3) ? 32 : 0;        // stride-2 3x3: 4-row tiles, 32-wide chunks (patch 9 x 65 records)
     if (stride != 1) return 0;
     // 256-channel tiles: 64-wide K chunks (one block per CU either way, half the barriers);
@@ -415,6 +421,10 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
     } while (0)
     const int cc = conv_igemm2_chunk(ks, 1, CoutP, Cin);
     if (cc == 0) return false;
+    if (conv3x3_pp_serves(ks, 1, CoutP, Cin) && !residual && !out_f32) {
+        launch_conv3x3_pp(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, reinterpret_cast<half_t *>(out), Ho, Wo, zero_page);
+        return true;
+    }
     static const bool bn128 = sfd2_env("SFD2_CONV_BN128") != nullptr;
     const int bn = (CoutP % 256 == 0 && !bn128) ? 256 : 128;
     static const bool nw4 = sfd2_env("SFD2_CONV_NW4") != nullptr;   // experiment: 4 waves, 128 ch x 128 px per wave

@@ -1,0 +1,303 @@
+// conv3x3_pp: third-generation implicit-GEMM kernel for the 3x3 stride-1 layers with >= 256 output
+// channels (conv3a / conv3b, convPa.3, convDa.0 / convDa.3: nets/sfd2.py:274-297), which carry ~60 % of
+// the network's FLOPs.  Same GEMM orientation, LDS record layout / swizzle and epilogue as
+// conv2_kernels.hip; what changes is the tile and the schedule.
+//
+//   * tile = 128 channels x (16 x 32) pixels, K chunk of 32 input channels.  The copies into LDS go
+//     through the LDS-DMA path, which moves ~18 B/clk/CU -- with 256-channel x 256-pixel tiles the
+//     37 KB a K step needs take as long as the step's MFMAs (75 us of copies alone on the 141-GFLOP
+//     layers).  This shape needs two thirds of those bytes per FLOP (8 KB of filters per tap instead
+//     of 2 x 8, the larger patch amortised over nine taps).
+//   * the eight waves form two groups of four (one wave of each group on every SIMD) that run the
+//     SAME code one barrier apart.  A unit of work = one filter tap x 32 channels = 12 fragment reads
+//     + 16 MFMAs per wave, written as a LOAD section (fragment ds_reads, plus this wave's share of the
+//     next staging copies) and an MFMA section, each closed by a workgroup barrier.  Because group 1
+//     executed one extra barrier at the start, its LOAD section runs while group 0's MFMA section owns
+//     the matrix pipe and vice versa: copies, LDS reads and address arithmetic of one wave are hidden
+//     behind the other wave's MFMAs instead of both waves of a SIMD stalling together.
+//
+// Time in "slots" (the interval between two consecutive barriers); unit u = 9 * chunk + tap:
+//     group 0:  LOAD(u) in slot 2u,      MFMA(u) in slot 2u + 1
+//     group 1:  LOAD(u) in slot 2u + 1,  MFMA(u) in slot 2u + 2
+// Staging (stage = one filter row ky of a chunk = 3 units, two buffers; patch = one chunk = 9 units,
+// two buffers):
+//     * filters of stage t + 1 are requested in LOAD(3t) (by each wave, for its own 3 pieces) into the
+//       buffer stage t - 1 used: its last reader was group 1's LOAD(3t - 1), one slot before group 0's
+//       LOAD(3t), so every LOAD of a stage's last tap retires its reads (lgkmcnt(0)) before its barrier.
+//     * the patch of chunk c + 1 is requested one piece at a time in LOAD of taps 0, 1, 3, 4, 6 of
+//       chunk c (same argument for the buffer's previous readers: tap 8 is a stage's last tap).
+//     * both sections of a stage's last tap end with vmcnt(0): everything requested so far has landed
+//       before the barrier that precedes the first read of the next stage (the youngest request is one
+//       unit = two slots old at that point, so the wait is normally free).
+#include "sfd2_internal.h"
+
+#define PP_TW 32
+#define PP_TH 16
+#define PP_BN 128
+#define PP_CC 32
+#define PP_PW (PP_TW + 2)
+#define PP_PH (PP_TH + 2)
+#define PP_NPIX (PP_PH * PP_PW)                 // 612 patch records of 64 B
+#define PP_XCH ((PP_NPIX + 15) / 16)            // 39 pieces of 1 KB
+#define PP_XPW 5                                // pieces per wave (waves issue 5 each; the tail repeats the last piece)
+#define PP_XBYTES (PP_XCH * 1024)
+#define PP_FBYTES (3 * PP_BN * PP_CC * 2)       // one filter row: 3 taps x 128 filters x 64 B = 24 KB
+#define PP_FPW 3                                // filter pieces per wave per stage (24 / 8)
+
+typedef __attribute__((address_space(3))) void lds_void3_t;
+typedef const __attribute__((address_space(1))) void gbl_void3_t;
+
+__device__ __forceinline__ int xcd_swizzle3(int bid, int nblk)
+{
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+__device__ __forceinline__ h4_t cvt4c(float a, float b, float c, float d)
+{
+    h4_t r;
+    r[0] = (half_t)a; r[1] = (half_t)b; r[2] = (half_t)c; r[3] = (half_t)d;
+    return r;
+}
+
+// STAGGER = 0 builds the same loop without the one-barrier offset (A/B switch for the schedule itself)
+template <int STAGGER, int PRIO, int ABL = 0>
+__global__ __launch_bounds__(512, 2)
+void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
+                       const half_t *__restrict__ wpk, const float *__restrict__ scale,
+                       const float *__restrict__ shift, int CoutP, int relu,
+                       half_t *__restrict__ out, int Ho, int Wo, int tiles_x,
+                       const half_t *__restrict__ zero_page)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Xs = smem;                              // [2][PP_XBYTES]
+    unsigned char *Fs = smem + 2 * PP_XBYTES;              // [2][PP_FBYTES]
+    float *SS = reinterpret_cast<float *>(Fs + 2 * PP_FBYTES);   // scale[128], shift[128]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                             // waves w and w + 4 share a SIMD
+    const int wch = (wave & 1) * 64;                       // 2 channel tiles
+    const int wrow = (wave >> 1) * 4;                      // 4 image rows = 4 pixel tiles
+
+    const int n_tiles_n = CoutP / PP_BN;
+    const int swz = xcd_swizzle3(blockIdx.x, gridDim.x);
+    const int tn = swz % n_tiles_n;
+    const int tsp = swz / n_tiles_n;
+    const int tx = tsp % tiles_x, ty = tsp / tiles_x;
+    const int oy0 = ty * PP_TH, ox0 = tx * PP_TW, n0 = tn * PP_BN;
+
+    // ---- per-lane staging sources (element offsets; -1 = zero page)
+    int xoff[PP_XPW];
+#pragma unroll
+    for (int i = 0; i < PP_XPW; ++i) {
+        int piece = wave + 8 * i;
+        if (piece >= PP_XCH) piece = PP_XCH - 1;
+        const int q = piece * 16 + (lane >> 2);
+        const int slot = (lane & 3) ^ ((q >> 2) & 3);
+        int off = -1;
+        if (q < PP_NPIX) {
+            const int py = q / PP_PW, px = q - py * PP_PW;
+            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) off = (iy * W + ix) * Cin + slot * 8;
+        }
+        xoff[i] = off;
+    }
+    int woff[PP_FPW];
+#pragma unroll
+    for (int i = 0; i < PP_FPW; ++i) {
+        const int r = (wave * PP_FPW + i) * 16 + (lane >> 2);   // row of the stage tile: tap r / 128, filter r % 128
+        const int slot = (lane & 3) ^ ((r >> 2) & 3);
+        woff[i] = ((r / PP_BN) * CoutP + n0 + (r % PP_BN)) * PP_CC + slot * 8;
+    }
+
+#define PP_ISSUE_X1(chunk_, buf_, i_)                                                                  \
+    do {                                                                                               \
+        const int pc_ = (wave + 8 * (i_) < PP_XCH) ? wave + 8 * (i_) : PP_XCH - 1;                     \
+        const half_t *src_ = xoff[i_] >= 0 ? in + (size_t)xoff[i_] + (chunk_)*PP_CC : zero_page + (lane & 3) * 8; \
+        __builtin_amdgcn_global_load_lds((gbl_void3_t *)src_,                                          \
+                                         (lds_void3_t *)(Xs + (buf_)*PP_XBYTES + pc_ * 1024), 16, 0, 0); \
+    } while (0)
+#define PP_ISSUE_F(stage_, buf_)                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < PP_FPW; ++i_) {                                            \
+        const half_t *src_ = wpk + (size_t)(stage_)*3 * CoutP * PP_CC + woff[i_];                      \
+        __builtin_amdgcn_global_load_lds((gbl_void3_t *)src_,                                          \
+                                         (lds_void3_t *)(Fs + (buf_)*PP_FBYTES + (wave * PP_FPW + i_) * 1024), 16, 0, 0); \
+    }
+
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int NCH = Cin / PP_CC;
+    const int NST = NCH * 3;
+
+#pragma unroll
+    for (int i = 0; i < PP_XPW; ++i) PP_ISSUE_X1(0, 0, i);
+    PP_ISSUE_F(0, 0)
+    for (int t = tid; t < PP_BN; t += 512) { SS[t] = scale[n0 + t]; SS[PP_BN + t] = shift[n0 + t]; }
+    SFD2_BARRIER_DRAIN();
+    if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
+
+    const int lrow = lane & 31, lhi = lane >> 5;
+    int a_off[2], a_sw[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int r = wch + ct * 32 + lrow;
+        a_off[ct] = r * 64;
+        a_sw[ct] = (r >> 2) & 3;
+    }
+    const int qb = wrow * PP_PW + lrow;
+
+    for (int c = 0; c < NCH; ++c) {
+        const unsigned char *xs = Xs + (c & 1) * PP_XBYTES;
+        const bool more_x = c + 1 < NCH;
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+            const int ky = t9 / 3, kx = t9 % 3;
+            const int st = c * 3 + ky;
+            const unsigned char *fs = Fs + (st & 1) * PP_FBYTES + kx * (PP_BN * 64);
+            // ---------------- LOAD section
+            h8_t fa[2][2], fb[2][4];
+            if (ABL & 2) {   // timing ablation: no fragment reads
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) fb[kk][pr] = h8_t{(half_t)(float)lane, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) fa[kk][ct] = h8_t{(half_t)(float)c, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
+            int qv = qb;
+            asm volatile("" : "+v"(qv));   // recompute the 8 patch addresses per unit (hoisted out of the loop they are 72 registers)
+#pragma unroll
+            for (int pr = 0; pr < ((ABL & 2) ? 0 : 4); ++pr) {
+                const int q = qv + (pr + ky) * PP_PW + kx;
+                const int sw = (q >> 2) & 3;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    fb[kk][pr] = *reinterpret_cast<const h8_t *>(xs + q * 64 + (((kk * 2 + lhi) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int ct = 0; ct < ((ABL & 2) ? 0 : 2); ++ct)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    fa[kk][ct] = *reinterpret_cast<const h8_t *>(fs + a_off[ct] + (((kk * 2 + lhi) ^ a_sw[ct]) << 4));
+            if (!(ABL & 1) && kx == 0 && st + 1 < NST) { PP_ISSUE_F(st + 1, (st + 1) & 1) }
+            if (!(ABL & 1) && more_x) {
+                if (t9 == 0) PP_ISSUE_X1(c + 1, (c + 1) & 1, 0);
+                if (t9 == 1) PP_ISSUE_X1(c + 1, (c + 1) & 1, 1);
+                if (t9 == 3) PP_ISSUE_X1(c + 1, (c + 1) & 1, 2);
+                if (t9 == 4) PP_ISSUE_X1(c + 1, (c + 1) & 1, 3);
+                if (t9 == 6) PP_ISSUE_X1(c + 1, (c + 1) & 1, 4);
+            }
+            if (kx == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- MFMA section
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr)
+                        acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][ct], fb[kk][pr], acc[ct][pr], 0, 0, 0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kx == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // group 1's last MFMA section has nobody left to hand the pipe to
+            if (!(STAGGER && grp == 1 && t9 == 8 && c + 1 == NCH)) asm volatile("s_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef PP_ISSUE_X1
+#undef PP_ISSUE_F
+
+    // epilogue: y = acc * scale + shift (ReLU), regrouped with v_permlane32_swap into 16-byte stores
+    // (see conv2_kernels.hip)
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+        const int oy = oy0 + wrow + pr, ox = ox0 + lrow;
+        const bool inb = oy < Ho && ox < Wo;
+        const size_t pix = (size_t)(inb ? oy : 0) * Wo + (inb ? ox : 0);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int cl = wch + ct * 32 + 4 * lhi;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const size_t o16 = pix * CoutP + n0 + wch + ct * 32 + 8 * (2 * m + lhi);
+                uint2 pk[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int q = 2 * m + j;
+                    const float4 sc = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
+                    const float4 sh = *reinterpret_cast<const float4 *>(SS + PP_BN + cl + 8 * q);
+                    float v0 = acc[ct][pr][4 * q + 0] * sc.x + sh.x;
+                    float v1 = acc[ct][pr][4 * q + 1] * sc.y + sh.y;
+                    float v2 = acc[ct][pr][4 * q + 2] * sc.z + sh.z;
+                    float v3 = acc[ct][pr][4 * q + 3] * sc.w + sh.w;
+                    if (relu) {
+                        v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
+                    }
+                    const h4_t hv = cvt4c(v0, v1, v2, v3);
+                    __builtin_memcpy(&pk[j], &hv, 8);
+                }
+                const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                if (inb) *reinterpret_cast<uint4 *>(out + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+            }
+        }
+    }
+}
+
+template <int STAGGER, int PRIO, int ABL = 0>
+static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
+                        const float *scale, const float *shift, int CoutP, int relu, half_t *out,
+                        int Ho, int Wo, const half_t *zero_page)
+{
+    constexpr size_t lds = (size_t)2 * PP_XBYTES + (size_t)2 * PP_FBYTES + 2 * PP_BN * sizeof(float);
+    static bool attr_done = false;
+    auto kern = conv3x3_pp_kernel<STAGGER, PRIO, ABL>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int tiles_x = (Wo + PP_TW - 1) / PP_TW, tiles_y = (Ho + PP_TH - 1) / PP_TH;
+    const int grid = tiles_x * tiles_y * (CoutP / PP_BN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out,
+                       Ho, Wo, tiles_x, zero_page);
+}
+
+// does conv3x3_pp serve this layer?  (decided from the layer's shape alone: the filters are packed for it)
+bool conv3x3_pp_serves(int ks, int stride, int CoutP, int Cin)
+{
+#ifdef SFD2_CONV_PP
+    return ks == 3 && stride == 1 && CoutP % 256 == 0 && Cin % 64 == 0;
+#else
+    (void)ks; (void)stride; (void)CoutP; (void)Cin;
+    return false;
+#endif
+}
+
+void launch_conv3x3_pp(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
+                       const float *scale, const float *shift, int CoutP, int relu, half_t *out,
+                       int Ho, int Wo, const half_t *zero_page)
+{
+#if defined(SFD2_CONV_PP_ABL)
+    launch_pp_t<1, 1, SFD2_CONV_PP_ABL>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
+#elif defined(SFD2_CONV_PP_NOSTAGGER)
+    launch_pp_t<0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
+#elif defined(SFD2_CONV_PP_NOPRIO)
+    launch_pp_t<1, 0>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
+#else
+    launch_pp_t<1, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
+#endif
+}
