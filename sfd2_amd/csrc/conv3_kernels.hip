@@ -221,6 +221,8 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #undef PP_ISSUE_X1
 #undef PP_ISSUE_F
 
+    const float lo = relu ? 0.0f : -__builtin_huge_valf();   // ReLU without a branch (this file is compiled with -fno-honor-nans:
+                                                              // no canonicalising v_max in front of each fmaxf)
     // epilogue: y = acc * scale + shift (ReLU), regrouped with v_permlane32_swap into 16-byte stores
     // (see conv2_kernels.hip)
 #pragma unroll
@@ -244,9 +246,7 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                     float v1 = acc[ct][pr][4 * q + 1] * sc.y + sh.y;
                     float v2 = acc[ct][pr][4 * q + 2] * sc.z + sh.z;
                     float v3 = acc[ct][pr][4 * q + 3] * sc.w + sh.w;
-                    if (relu) {
-                        v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
-                    }
+                    v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
                     const h4_t hv = cvt4c(v0, v1, v2, v3);
                     __builtin_memcpy(&pk[j], &hv, 8);
                 }
@@ -277,27 +277,26 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
 }
 
 // does conv3x3_pp serve this layer?  (decided from the layer's shape alone: the filters are packed for it)
+// Measured at 1600x1200 (tools/ab_libs.py, interleaved A/B on one box): conv3b 132.7 -> 122.3 us, convDa.0 134.5 -> 126.1,
+// convDa.3 132.7 -> 122.2, conv3a 77.3 -> 72.8, convPa.3 60.4 -> 54.5; the same tile WITHOUT the one-barrier offset: 144 us
+// (experiment builds: SFD2_CONV_PP_NOSTAGGER=1).  conv2a (64 -> 128 channels, two K chunks) is slower here (91 vs 81 us: the
+// 63 KB prologue is a fifth of its K loop) and stays on conv_igemm2.
 bool conv3x3_pp_serves(int ks, int stride, int CoutP, int Cin)
 {
-#ifdef SFD2_CONV_PP
-    return ks == 3 && stride == 1 && CoutP % 256 == 0 && Cin % 64 == 0;
-#else
-    (void)ks; (void)stride; (void)CoutP; (void)Cin;
-    return false;
-#endif
+    static const bool off = sfd2_env("SFD2_CONV_NO_PP") != nullptr;   // experiment builds: conv_igemm2 for these layers
+    return !off && ks == 3 && stride == 1 && CoutP % 256 == 0 && Cin % 64 == 0;
 }
 
 void launch_conv3x3_pp(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                        const float *scale, const float *shift, int CoutP, int relu, half_t *out,
                        int Ho, int Wo, const half_t *zero_page)
 {
-#if defined(SFD2_CONV_PP_ABL)
-    launch_pp_t<1, 1, SFD2_CONV_PP_ABL>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
-#elif defined(SFD2_CONV_PP_NOSTAGGER)
-    launch_pp_t<0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
-#elif defined(SFD2_CONV_PP_NOPRIO)
-    launch_pp_t<1, 0>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
-#else
-    launch_pp_t<1, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
+#ifdef SFD2_EXPERIMENTS
+    static const bool nostagger = sfd2_env("SFD2_CONV_PP_NOSTAGGER") != nullptr;
+    if (nostagger) {
+        launch_pp_t<0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
+        return;
+    }
 #endif
+    launch_pp_t<1, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
 }

@@ -39,6 +39,8 @@ void launch_fused_stem(hipStream_t st, const float *img, int H, int W, int norma
 // Implicit-GEMM conv on MFMA (3x3 or 1x1, stride 1 or 2, Cin % 32 == 0, Cout_pad % 64 == 0).
 //   in  [H][W][Cin] fp16,  wpk [Cin/cc][ks*ks][Cout_pad][cc] fp16 (cc = conv_igemm_chunk),  scale/shift [Cout_pad]
 //   out [Ho][Wo][Cout_pad] fp16 (relu / residual optional) or fp32 (out_f32)
+// conv3_kernels.hip: the 3x3 stride-1 layers with >= 256 output channels
+bool conv3x3_pp_serves(int ks, int stride, int CoutP, int Cin);
 void launch_conv_igemm(hipStream_t st, const half_t *in, int H, int W, int Cin,
                        const half_t *wpk, const float *scale, const float *shift, int Cout_pad,
                        int ks, int stride, int relu, const half_t *residual,
