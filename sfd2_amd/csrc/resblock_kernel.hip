@@ -23,6 +23,9 @@
 
 #define RB_NT 512
 #define RB_SW 30                    // output columns per strip (32 with the halo = one MFMA pixel tile)
+#ifndef RB_PF
+#define RB_PF 4                     // k-slice fragments in flight ahead of the 1x1 convolutions' MFMAs
+#endif
 #define RB_NX 3                     // x rows in the ring (rows r - 1, r and the one in flight)
 #define RB_GW_BYTES (256 * 9 * 8 * 2) // grouped-conv filters, compact [oc][tap][8 in] fp16 (36 KB)
 #define RB_ROW (32 * 512)           // bytes of one 32-pixel row of 256 fp16 channels (t1 ring: XOR-swizzled records)
@@ -40,6 +43,19 @@ __device__ __forceinline__ h4_t rb_cvt4(float a, float b, float c, float d)
 
 // scale / shift of 4 consecutive channels starting at base + 4 * lhi, base wave-uniform: scalar loads (scalar cache,
 // no LDS bandwidth -- the kernel is LDS-read bound) of both halves, selected per lane half
+// 16-byte LDS read of four floats, TYPED LIKE THE MFMA FRAGMENT READS.  hipcc orders LDS reads against in-flight
+// direct-to-LDS copies by type-based alias analysis: a float-typed ds_read "may alias" the copies' destination, so the
+// compiler drains s_waitcnt vmcnt(0) in front of it -- i.e. in front of every epilogue's scale / shift reads, once the next
+// row's copies (and the previous row's output stores) are in flight: three full memory-latency stalls per row.  Read as
+// _Float16 x 8 like the fragments, the same bytes carry no such wait (conv4.x 77 -> 70 us at 1600x1200).
+__device__ __forceinline__ float4 rb_lds4(const float *p)
+{
+    const h8_t raw = *reinterpret_cast<const h8_t *>(reinterpret_cast<const unsigned char *>(p));
+    float4 r;
+    __builtin_memcpy(&r, &raw, 16);
+    return r;
+}
+
 __device__ __forceinline__ float4 rb_ss(const float *__restrict__ p, int base, int lhi)
 {
     const float4 lo = *reinterpret_cast<const float4 *>(p + base), hi = *reinterpret_cast<const float4 *>(p + base + 4);
@@ -127,21 +143,28 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
             for (int i = 0; i < 16; ++i) acc0[i] = 0.0f;
             // the next k slice's fragment is requested before the current MFMA issues (LDS returns in order, so the
             // compiler can wait with a counted lgkmcnt): LDS latency overlaps the matrix pipe inside one wave
-            h8_t bcur = *reinterpret_cast<const h8_t *>(xr);
+            // four k-slice fragments in flight ahead of the MFMA that needs them (LDS returns in order: the waits are
+            // counted lgkmcnt); the issue order is pinned -- left alone hipcc reads two, waits for both, issues two MFMAs
+            h8_t bq[RB_PF];
+#pragma unroll
+            for (int j = 0; j < RB_PF; ++j) bq[j] = *reinterpret_cast<const h8_t *>(xr + j * 32);
+            __builtin_amdgcn_sched_group_barrier(0x100, RB_PF, 0);
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                h8_t bnext = bcur;
-                if (kk + 1 < 16) bnext = *reinterpret_cast<const h8_t *>(xr + (kk + 1) * 32);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kk], bcur, acc0, 0, 0, 0);
-                bcur = bnext;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kk], bq[kk % RB_PF], acc0, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (kk + RB_PF < 16) {
+                    bq[kk % RB_PF] = *reinterpret_cast<const h8_t *>(xr + (kk + RB_PF) * 32);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
             const bool inside = r >= 0 && r < H && ncol >= 0 && ncol < W;
             unsigned char *t1w = T1 + ((r + 3) % 3) * RB_ROW + n * 512;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c0 = wave * 32 + 8 * q + 4 * lhi;
-                const float4 s = *reinterpret_cast<const float4 *>(SS + c0);
-                const float4 h = *reinterpret_cast<const float4 *>(SS + 256 + c0);
+                const float4 s = rb_lds4(SS + c0);
+                const float4 h = rb_lds4(SS + 256 + c0);
                 h4_t v = rb_cvt4(0.f, 0.f, 0.f, 0.f);
                 if (inside)
                     v = rb_cvt4(fmaxf(acc0[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc0[4 * q + 1] * s.y + h.y, 0.0f),
@@ -183,8 +206,8 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
                     }
                 }
                 const int c0 = P * 16 + g * 4;
-                const float4 s2 = *reinterpret_cast<const float4 *>(SS + 512 + c0);
-                const float4 h2 = *reinterpret_cast<const float4 *>(SS + 768 + c0);
+                const float4 s2 = rb_lds4(SS + 512 + c0);
+                const float4 h2 = rb_lds4(SS + 768 + c0);
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     const int j = tt * 16 + lcol;
@@ -202,13 +225,18 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
             f32x16_t acc0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc0[i] = 0.0f;
-            h8_t bcur = *reinterpret_cast<const h8_t *>(tp);
+            h8_t bq[RB_PF];
+#pragma unroll
+            for (int j = 0; j < RB_PF; ++j) bq[j] = *reinterpret_cast<const h8_t *>(tp + j * 32);
+            __builtin_amdgcn_sched_group_barrier(0x100, RB_PF, 0);
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                h8_t bnext = bcur;
-                if (kk + 1 < 16) bnext = *reinterpret_cast<const h8_t *>(tp + (kk + 1) * 32);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3[kk], bcur, acc0, 0, 0, 0);
-                bcur = bnext;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3[kk], bq[kk % RB_PF], acc0, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (kk + RB_PF < 16) {
+                    bq[kk % RB_PF] = *reinterpret_cast<const h8_t *>(tp + (kk + RB_PF) * 32);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
             const unsigned char *xres = XR + ((y + RB_NX) % RB_NX) * RB_PROW + pp_base;
             const bool st_ok = n >= 1 && n <= RB_SW && ncol < W;
@@ -221,8 +249,8 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
                 for (int j = 0; j < 2; ++j) {
                     const int q = 2 * m + j;
                     const int c0 = cl + 8 * q;
-                    const float4 s3 = *reinterpret_cast<const float4 *>(SS + 1024 + c0);
-                    const float4 h3 = *reinterpret_cast<const float4 *>(SS + 1280 + c0);
+                    const float4 s3 = rb_lds4(SS + 1024 + c0);
+                    const float4 h3 = rb_lds4(SS + 1280 + c0);
                     const h4_t rs = *reinterpret_cast<const h4_t *>(xres + (((c0 >> 3) ^ (n & 1)) << 4) + (c0 & 4) * 2);
                     const h4_t hv = rb_cvt4(fmaxf(acc0[4 * q + 0] * s3.x + h3.x + (float)rs[0], 0.0f),
                                             fmaxf(acc0[4 * q + 1] * s3.y + h3.y + (float)rs[1], 0.0f),
