@@ -178,7 +178,8 @@ def main():
                     "(default 2: the kernels of one image leave CUs idle -- tile tails, the small selection kernels, the row-marching "
                     "ResBlocks -- that a second image's kernels fill: +17 %% images/sec on one MI355X; 3 measures no better)")
     ap.add_argument("--no-profile", action="store_true", help="experiment: no per-launch events in the timed region")
-    ap.add_argument("--graphs", action="store_true", help="sfd2_extract_match with the per-context hipGraph cache (configs[4]); "
+    ap.add_argument("--no-graphs", action="store_true", help="headline leg with eager launches instead of the per-context hipGraph cache")
+    ap.add_argument("--graphs", action="store_true", help="(default since round 2; kept for old command lines) sfd2_extract_match with the per-context hipGraph cache (configs[4]); "
                                                           "per-kernel events are not available then")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-f32 leg")
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the extra untimed-by-contract sustained leg (0 = off)")
@@ -225,6 +226,7 @@ def main():
     dbs = (_lib.DescSet * K_DB)(*[_lib.DescSet(d.data_ptr(), N_DB, _lib.DT_F16, _lib.LAYOUT_ND, 1) for d in db])
     mconf = _lib.MatchConf(_lib.MATCH_HLOC, 1, 0.0, 0.0, _lib.SIM_F16)   # NNM (hloc/match_features.py:21-28)
 
+    use_graphs = not args.no_graphs
     class Lane:   # one context = one HIP stream, its packed weights, workspace and output buffers
         def __init__(self):
             self.model = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval()
@@ -238,7 +240,7 @@ def main():
             self.mscores = torch.empty((K_DB, TOPK), dtype=torch.float32, device=dev)
             self.q = _lib.DescSet(self.desc.data_ptr(), TOPK, _lib.DT_F32, _lib.LAYOUT_ND, 1)
             self.n_out = ctypes.c_int(0)
-            if args.graphs:
+            if use_graphs:
                 self.ctx.set_option("graphs", 1)
 
     lanes = [Lane() for _ in range(max(1, args.streams))]
@@ -247,9 +249,9 @@ def main():
     matches = lanes[0].matches
     torch.cuda.synchronize()
 
-    def step(i, only=None):
+    def step(i, only=None, eager=False):
         ln = lanes[i % len(lanes)] if only is None else only
-        if args.graphs:
+        if use_graphs and not eager:
             _lib.check(lib.sfd2_extract_match(ln.ctx.h, imgs[i % n_img].data_ptr(), H, W, 0.001, TOPK, 0, ln.kpts.data_ptr(),
                                               ln.scores.data_ptr(), ln.desc.data_ptr(), dbs, 0 if args.extract_only else K_DB, 128,
                                               ctypes.byref(mconf), ln.matches.data_ptr(), ln.mscores.data_ptr()))
@@ -297,14 +299,14 @@ def main():
     # untimed pre-pass with every launch bracketed: per-kernel breakdown + which family dominates
     ctx.set_profiling(8)
     for i in range(3):
-        step(0)
+        step(0, lanes[0], eager=True)
     breakdown_rows = ctx.layer_timings()
     fam_all = dominant_family(breakdown_rows)
     dom_name = max(fam_all.items(), key=lambda kv: kv[1]["ms"])[0]
 
     # timed region: HIP events only around the dominant kernel's launches (an event pair costs
     # ~2-4 us of stream time; bracketing all ~35 launches would slow the step by ~10 %)
-    ctx.set_profiling(0 if (args.no_profile or args.graphs) else 2 * args.steps + 2, dom_name)
+    ctx.set_profiling(0 if (args.no_profile or use_graphs) else 2 * args.steps + 2, dom_name)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -330,20 +332,20 @@ def main():
     # stream; the concurrent region's figures are reported next to it.
     single = None
     layers_concurrent = None
-    if len(lanes) > 1 and not (args.no_profile or args.graphs):
+    if (len(lanes) > 1 or use_graphs) and not args.no_profile:
         layers_concurrent = layers
         ctx.set_profiling(2 * args.steps + 2, dom_name)
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(i, lanes[0])
+            step(i, lanes[0], eager=True)
         lanes[0].ctx.sync()
         barrier()
         d1 = max_over_ranks(time.perf_counter() - t0)
         layers = ctx.layer_timings()
         ctx.set_profiling(0)
         single = {"value": round(args.steps * world / d1, 3), "unit": "images/sec", "ms_per_step": round(d1 / args.steps * 1e3, 4),
-                  "steps": args.steps, "streams_per_gpu": 1}
+                  "steps": args.steps, "streams_per_gpu": 1, "launches": "eager, HIP events around the dominant kernel"}
 
     # extra leg (not `value`): the same steps for ~args.sustain seconds without any per-launch events, to show the
     # K-step number is not a boost-clock artefact
@@ -395,7 +397,7 @@ def main():
         if not fam:
             print(json.dumps({"value": round(args.steps * world / dt, 3), "n_gpus": world, "ms_per_step": round(dt / args.steps * 1e3, 4),
                               "sustained": sustained, "strict_f32": strict,
-                              "note": "no per-launch events (--no-profile / --graphs)", "graphs": bool(args.graphs)}), flush=True)
+                              "note": "no per-launch events (--no-profile)", "graphs": bool(use_graphs)}), flush=True)
             if dist is not None:
                 dist.barrier()
                 dist.destroy_process_group()
@@ -410,10 +412,11 @@ def main():
                     "traffic": pmc_traffic(dom_name),
                     "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this command; not re-measured in this run)"}
             if single is not None:
-                roof["measured_in"] = ("single-stream timed leg of this run (same K steps and bracketing, one stream per GPU: see "
-                                       "'single_stream'); in the headline region two streams share the CUs and a launch's event-timed "
-                                       "duration includes its neighbour's work (see 'concurrent')")
-                famc = dominant_family(layers_concurrent)
+                roof["measured_in"] = ("single-stream timed leg of this run (same K steps and bracketing, one stream per GPU, eager "
+                                       "launches: see 'single_stream').  The headline region replays one hipGraph per image on "
+                                       f"{len(lanes)} stream(s) per GPU: no per-launch events inside a graph, and with two streams a launch's "
+                                       "duration includes its neighbour's work ('concurrent' = the eager two-stream figure when --no-graphs)")
+                famc = dominant_family(layers_concurrent or [])
                 if dom_name in famc and famc[dom_name]["ms"] > 0:
                     ac = famc[dom_name]["flops"] / (famc[dom_name]["ms"] * 1e-3) / 1e12
                     roof["concurrent"] = {"achieved": round(ac, 2), "frac": round(ac / PEAK_TFLOPS_F16, 4),
@@ -443,7 +446,8 @@ def main():
                                     "aachen_v1.1 query extract + NNM match vs netvlad-50 resident db sets (BASELINE configs[2])"),
                        "image": f"{W}x{H}", "max_keypoints": TOPK, "db_sets_per_query": 0 if args.extract_only else K_DB,
                        "db_keypoints": N_DB, "weights": "synthetic seeded ResSegNetV2 (checkpoint not shipped)",
-                       "parallelism": f"images sharded over {world} GPU(s), no collective", "streams_per_gpu": len(lanes)},
+                       "parallelism": f"images sharded over {world} GPU(s), no collective", "streams_per_gpu": len(lanes),
+                       "launch": "hipGraph replay per image (sfd2_extract_match)" if use_graphs else "eager"},
             "roofline": roof, "kernel_ms_per_step": breakdown, "device_ms_per_step": round(total_ms, 4),
             "mutual_matches_last_step": n_matched,
             "parity": {"mode": "f16 throughput", "descriptors_max_abs": "<= 3e-3 (measured 1.8e-3)", "keypoint_set_iou": ">= 0.95",

@@ -24,7 +24,7 @@
 #define RB_NT 512
 #define RB_SW 30                    // output columns per strip (32 with the halo = one MFMA pixel tile)
 #ifndef RB_PF
-#define RB_PF 4                     // k-slice fragments in flight ahead of the 1x1 convolutions' MFMAs
+#define RB_PF 2                     // k-slice fragments in flight ahead of the 1x1 convolutions' MFMAs
 #endif
 #define RB_NX 3                     // x rows in the ring (rows r - 1, r and the one in flight)
 #define RB_GW_BYTES (256 * 9 * 8 * 2) // grouped-conv filters, compact [oc][tap][8 in] fp16 (36 KB)

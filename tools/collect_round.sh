@@ -10,14 +10,15 @@ cd $R
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/pytest_gpu.txt
 python bench.py --steps 20 --warmup 5 --dump-layers > $out/bench.json 2> $out/layer_table.txt
 python bench.py --steps 20 --warmup 5 --extract-only --no-cpu-baseline > $out/bench_extract_only.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 --graphs --no-cpu-baseline > $out/bench_graphs.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-graphs --no-cpu-baseline --no-strict > $out/bench_eager.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --streams 1 --no-cpu-baseline --no-strict > $out/bench_streams1.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --size 1024x1024 --no-cpu-baseline > $out/bench_1024x1024.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --size 1024x768 --no-cpu-baseline > $out/bench_1024x768.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strict --sustain 0"
 rocprofv3 --kernel-trace --stats -d $out/prof -o $tag -- $B > $out/prof_bench.json 2> $out/prof.err
 python $R/tools/rocprof_summary.py $out/prof/*/${tag}_results.db > $out/rocprof_kernel_stats.txt 2>> $out/prof.err || python $R/tools/rocprof_summary.py $out/prof/${tag}_results.db > $out/rocprof_kernel_stats.txt 2>> $out/prof.err
-S="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strict --sustain 0"
+S="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strict --sustain 0 --no-graphs --streams 1"
 rocprofv3 --pmc FETCH_SIZE -d $out/pmc1 -o x --output-format csv -- $S > /dev/null 2> $out/pmc1.err
 rocprofv3 --pmc WRITE_SIZE -d $out/pmc2 -o x --output-format csv -- $S > /dev/null 2> $out/pmc2.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $out/pmc3 -o x --output-format csv -- $S > /dev/null 2> $out/pmc3.err
