@@ -169,8 +169,8 @@ def spawn_workers(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extract-only", action="store_true", help="configs[1]: extract without matching")
     ap.add_argument("--dump-layers", action="store_true", help="per-layer device times to stderr")
@@ -178,6 +178,7 @@ def main():
                     "(default 2: the kernels of one image leave CUs idle -- tile tails, the small selection kernels, the row-marching "
                     "ResBlocks -- that a second image's kernels fill: +17 %% images/sec on one MI355X; 3 measures no better)")
     ap.add_argument("--no-profile", action="store_true", help="experiment: no per-launch events in the timed region")
+    ap.add_argument("--branches", action="store_true", help="experiment: detector-head branch on a side stream (option 'branches')")
     ap.add_argument("--no-graphs", action="store_true", help="headline leg with eager launches instead of the per-context hipGraph cache")
     ap.add_argument("--graphs", action="store_true", help="(default since round 2; kept for old command lines) sfd2_extract_match with the per-context hipGraph cache (configs[4]); "
                                                           "per-kernel events are not available then")
@@ -242,6 +243,8 @@ def main():
             self.n_out = ctypes.c_int(0)
             if use_graphs:
                 self.ctx.set_option("graphs", 1)
+            if args.branches:
+                self.ctx.set_option("branches", 1)
 
     lanes = [Lane() for _ in range(max(1, args.streams))]
     ctx = lanes[0].ctx
