@@ -20,17 +20,28 @@
 // base + 32 * kk -- immediates, no address arithmetic (the kernel was VALU-bound: 610 VALU instructions per row).
 #include "sfd2_internal.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 #define RB_NT 512
 #define RB_SW 30                    // output columns per strip (32 with the halo = one MFMA pixel tile)
 #ifndef RB_PF
 #define RB_PF 2                     // k-slice fragments in flight ahead of the 1x1 convolutions' MFMAs
 #endif
-#define RB_NX 3                     // x rows in the ring (rows r - 1, r and the one in flight)
+#define RB_NX 4                     // x rows in the ring: r - 1 (residual), r, the one in flight, and one of slack that replaces a barrier
 #define RB_GW_BYTES (256 * 9 * 8 * 2) // grouped-conv filters, compact [oc][tap][8 in] fp16 (36 KB)
 #define RB_ROW (32 * 512)           // bytes of one 32-pixel row of 256 fp16 channels (t1 ring: XOR-swizzled records)
 #define RB_PROW (16 * 1056)         // x ring / t2 row: pixel PAIRS of 1024 B + 32 B pad, slot bit 0 XORed with the pixel's parity
 
+// -DSFD2_RB_TRACE: cycle stamps of one block's waves 0 and 4 at the section boundaries of every row, printed by the
+// launcher after the 40th launch (how the per-row budget in DESIGN.md was measured)
+#ifdef SFD2_RB_TRACE
+__device__ unsigned long long g_rb_trace[2][64][8];   // [wave 0 | 4][row][stamp]
+#define RB_STAMP(k_)                                                                          \
+    if (blockIdx.x == gridDim.x / 2 && (wave == 0 || wave == 4) && lane == 0 && r - (ya - 1) < 64) \
+        g_rb_trace[wave >> 2][r - (ya - 1)][k_] = __builtin_readcyclecounter();
+#else
+#define RB_STAMP(k_)
+#endif
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
@@ -41,8 +52,9 @@ __device__ __forceinline__ h4_t rb_cvt4(float a, float b, float c, float d)
     return r;
 }
 
-// scale / shift of 4 consecutive channels starting at base + 4 * lhi, base wave-uniform: scalar loads (scalar cache,
-// no LDS bandwidth -- the kernel is LDS-read bound) of both halves, selected per lane half
+// scale / shift of 4 consecutive channels starting at base + 4 * lhi, base wave-uniform: scalar loads of both halves,
+// selected per lane half.  NOT used: measured slower than the LDS reads in both 1x1 epilogues (conv4.x 73 -> 82 us: the
+// scalar-load latency plus eight v_cndmask per float4 pair cost more than the LDS round trips they replace).
 // 16-byte LDS read of four floats, TYPED LIKE THE MFMA FRAGMENT READS.  hipcc orders LDS reads against in-flight
 // direct-to-LDS copies by type-based alias analysis: a float-typed ds_read "may alias" the copies' destination, so the
 // compiler drains s_waitcnt vmcnt(0) in front of it -- i.e. in front of every epilogue's scale / shift reads, once the next
@@ -51,6 +63,15 @@ __device__ __forceinline__ h4_t rb_cvt4(float a, float b, float c, float d)
 __device__ __forceinline__ float4 rb_lds4(const float *p)
 {
     const h8_t raw = *reinterpret_cast<const h8_t *>(reinterpret_cast<const unsigned char *>(p));
+    float4 r;
+    __builtin_memcpy(&r, &raw, 16);
+    return r;
+}
+
+// the same through an LDS byte offset: base register + immediate (one address VGPR for all of a wave's scale / shift reads)
+__device__ __forceinline__ float4 rb_lds4o(const unsigned char *lds, unsigned off)
+{
+    const h8_t raw = *reinterpret_cast<const h8_t *>(lds + off);
     float4 r;
     __builtin_memcpy(&r, &raw, 16);
     return r;
@@ -72,10 +93,9 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *XR = smem;                               // [RB_NX] pair-padded rows
-    unsigned char *T2 = XR + RB_NX * RB_PROW;               // one pair-padded row
-    unsigned char *T1 = T2 + RB_PROW;                       // [3][32][512]
-    unsigned char *GW = T1 + 3 * RB_ROW;                    // grouped-conv filters [256][9][8] fp16
-    float *SS = reinterpret_cast<float *>(GW + RB_GW_BYTES);   // sc1 sh1 sc2 sh2 sc3 sh3, 256 each
+    unsigned char *T2 = XR + RB_NX * RB_PROW;               // [2] pair-padded rows
+    unsigned char *T1 = T2 + 2 * RB_PROW;                   // [3][32][512]
+    float *SS = reinterpret_cast<float *>(T1 + 3 * RB_ROW);   // sc1 sh1 sc2 sh2 sc3 sh3, 256 each
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,10 +115,6 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
         a1[kk] = *reinterpret_cast<const h8_t *>(w1 + o);
         a3[kk] = *reinterpret_cast<const h8_t *>(w3 + o);
     }
-    // grouped-conv filters stay in LDS in compact form (the block-diagonal MFMA fragments would be 80 VGPRs per wave
-    // on top of the 128 of W1 / W3: that spilled, and every spill reload drains the in-flight row copies)
-    for (int t = tid; t < RB_GW_BYTES / 16; t += RB_NT)
-        reinterpret_cast<uint4 *>(GW)[t] = reinterpret_cast<const uint4 *>(wg)[t];
     for (int t = tid; t < 256; t += RB_NT) {
         SS[t] = sc1[t]; SS[256 + t] = sh1[t]; SS[512 + t] = sc2[t]; SS[768 + t] = sh2[t]; SS[1024 + t] = sc3[t]; SS[1280 + t] = sh3[t];
     }
@@ -117,9 +133,7 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
             __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)(dst + ch * 1056), 16, 0, 0); \
         }                                                                                                  \
     }
-#define RB_WAIT_KEEP2() asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define RB_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#define RB_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
     RB_ISSUE_X(ya - 1)
     SFD2_BARRIER_DRAIN();    // GW and the first row complete
@@ -128,11 +142,54 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
     const int pp_base = (n >> 1) * 1056 + (n & 1) * 512;               // its record in a pair-padded row
     const int bfrag = pp_base + ((lhi ^ (n & 1)) << 4);                // + 32 * kk = its B fragment of k slice kk
     const int ncol = col0 + n;
+    // Loop-invariant per-lane offsets, kept to a few registers by hand.  Left to itself hipcc hoists every (tap, pixel
+    // tile, channel pair) address of the grouped conv and every scale / shift / t1-write address out of the row loop --
+    // ~45 registers on top of the 128 of W1 / W3 -- and then has none left to keep more than one LDS read in flight: the
+    // grouped conv ran as 30 dependent LDS round trips per row (2200 of the row's 7700 cycles), the epilogues as 4 each.
+    const int lcol = lane & 15, g = lane >> 4;
+    unsigned goff[5][2];                      // t1 fragment offsets inside a ring row, pair 2 * wave (the odd pair: ^ 16)
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+        int tap = 2 * s5 + (g >> 1);
+        if (tap > 8) tap = 8;                 // zero-weight slot: any valid location
+        const int kx = tap % 3;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            int p = tt * 16 + lcol + kx - 1;
+            p = p < 0 ? 0 : (p > 31 ? 31 : p);   // strip pixels 0 and 31 are halo: their outputs are not used
+            goff[s5][tt] = p * 512 + (((wave * 2 + 16 * (g & 1)) ^ p) << 4);
+        }
+    }
+    const bool k1_row1 = (g >> 1) != 0;       // k step 1: tap 3 (ky = 1) for the upper half of the lanes, tap 2 (ky = 0) below
+    // grouped-conv filter fragments (mfma_16x16x32: row = out channel lane & 15 of a 16-channel pair, k = (lane >> 4) * 8 + j;
+    // block diagonal over the pair's two groups, two taps per k step, zero in the 10th tap slot): 2 pairs x 5 steps, masked
+    // once and RESIDENT (40 VGPRs -- affordable since the offsets above stopped being hoisted).  Re-read from LDS per row they
+    // were a third of the grouped conv's LDS traffic, the stage's limit with all eight waves in it at once.
+    h8_t ga[2][5];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            const int tap = 2 * s5 + (g >> 1);
+            const bool live = tap <= 8 && (lcol >> 3) == (g & 1);
+            h8_t v = *reinterpret_cast<const h8_t *>(wg + ((((size_t)wave * 2 + pi) * 16 + lcol) * 9 + (tap > 8 ? 8 : tap)) * 8);
+            if (!live) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)0.0f;
+            }
+            ga[pi][s5] = v;
+        }
+    const unsigned ssb = (unsigned)(reinterpret_cast<unsigned char *>(SS) - smem) + (wave * 32 + 4 * lhi) * 4;   // scale / shift: + immediates
+    const unsigned ssg = (unsigned)(reinterpret_cast<unsigned char *>(SS) - smem) + (wave * 32 + g * 4) * 4;     // (grouped conv's lane layout)
     for (int r = ya - 1; r <= yb; ++r) {
-        // ---- x row r has landed and every wave is past conv3(r - 2); its slot takes row r + 1.  Vector-memory
-        // operations retire in order: once at most the two newest (the output stores of row r - 2) are outstanding,
-        // the copies of row r, issued before them, are complete.
-        if (r != ya - 1) { if (r - 2 >= ya) RB_WAIT_KEEP2(); else RB_WAIT_ALL(); }   // no stores behind the first rows' copies
+        // ONE block barrier per row (after the grouped conv).  It publishes (1) the t2 row, (2) the x row r + 1 this wave
+        // requested at the top of the iteration (its vmcnt(0) sits in front of the barrier, ~4000 cycles after the request).
+        // What a second barrier at the top of the row used to protect is covered by one more buffer each: t2 rows alternate
+        // between two buffers (a wave can only reach the next write of a buffer through a barrier every wave arrives at after
+        // its last read of it), and the x ring has a fourth slot (the copy of row r + 1 overwrites row r - 3, whose last
+        // reader finished before the previous barrier).  Without the second barrier the waves of a SIMD drift apart by up to
+        // a row, and one wave's MFMA stages overlap the other's epilogues.
+        RB_STAMP(0)
         if (r + 1 <= yb) { RB_ISSUE_X(r + 1) }
 
         // ---- conv1(r): t1 row r, this wave's 32 channels
@@ -158,70 +215,87 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             }
+#ifdef SFD2_RB_TRACE
+            asm volatile("s_nop 0" ::"v"(acc0[0]));
+#endif
+            RB_STAMP(1)
             const bool inside = r >= 0 && r < H && ncol >= 0 && ncol < W;
-            unsigned char *t1w = T1 + ((r + 3) % 3) * RB_ROW + n * 512;
+            int nv = n;
+            unsigned ssv = ssb;
+            asm volatile("" : "+v"(nv), "+v"(ssv));   // (recomputed per row instead of hoisted)
+            unsigned char *t1w = T1 + ((r + 3) % 3) * RB_ROW + nv * 512;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c0 = wave * 32 + 8 * q + 4 * lhi;
-                const float4 s = rb_lds4(SS + c0);
-                const float4 h = rb_lds4(SS + 256 + c0);
+                const float4 s = rb_lds4o(smem, ssv + 32 * q);
+                const float4 h = rb_lds4o(smem, ssv + 1024 + 32 * q);
                 h4_t v = rb_cvt4(0.f, 0.f, 0.f, 0.f);
                 if (inside)
                     v = rb_cvt4(fmaxf(acc0[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc0[4 * q + 1] * s.y + h.y, 0.0f),
                                 fmaxf(acc0[4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc0[4 * q + 3] * s.w + h.w, 0.0f));
                 // t1 slot of channel c: (c >> 4) + 16 * ((c >> 3) & 1) -- the two 8-channel groups of a pair sit 256 B apart, so
                 // the 16 lanes of a ds_read_b128 lane group of the grouped conv (two groups x 8 pixels) hit 16 distinct banks
-                *reinterpret_cast<h4_t *>(t1w + ((((c0 >> 4) + 16 * ((c0 >> 3) & 1)) ^ n) << 4) + (c0 & 4) * 2) = v;
+                *reinterpret_cast<h4_t *>(t1w + ((((c0 >> 4) + 16 * ((c0 >> 3) & 1)) ^ nv) << 4) + (c0 & 4) * 2) = v;
             }
         }
         const int y = r - 1;                  // the output row this iteration finishes
-        if (y < ya) continue;
-
-        // ---- gconv(y): t2 row from t1 rows y-1, y, y+1 (this wave's own channels: no barrier needed)
-        {
-            const int lcol = lane & 15, g = lane >> 4;
+        RB_STAMP(2)
+        // ---- gconv(y): t2 row from t1 rows y-1, y, y+1 (this wave's own channels: no barrier needed).  Ten k steps
+        // (2 channel pairs x 5 tap pairs), each two t1 fragments + two MFMAs against a resident filter fragment; the
+        // fragments of step st + 1 are requested before the MFMAs of step st issue.
+        if (y >= ya) {
+            const unsigned t1b = (unsigned)(T1 - smem);
+            const unsigned rw0 = t1b + ((y + 2) % 3) * RB_ROW, rw1 = t1b + (y % 3) * RB_ROW, rw2 = t1b + ((y + 1) % 3) * RB_ROW;
+            unsigned x16 = 16;
+            asm volatile("" : "+v"(x16));                 // (the odd pair's offsets: not hoisted)
+            h8_t fb[2][2];
+            f32x4_t acc[2][2];
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) acc[pi][tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#define RB_GLOAD(st_)                                                                                           \
+            {                                                                                                   \
+                const int pi_ = (st_) / 5, s_ = (st_) % 5;                                                      \
+                const unsigned rw_ = (s_ == 0) ? rw0 : (s_ == 1) ? (k1_row1 ? rw1 : rw0) : (s_ == 2) ? rw1 : rw2; \
+                _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                \
+                    fb[(st_) & 1][tt] = *reinterpret_cast<const h8_t *>(smem + rw_ + (pi_ ? (goff[s_][tt] ^ x16) : goff[s_][tt])); \
+            }
+            RB_GLOAD(0)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int st = 0; st < 10; ++st) {
+                if (st + 1 < 10) RB_GLOAD(st + 1)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    acc[st / 5][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga[st / 5][st % 5], fb[st & 1][tt], acc[st / 5][tt], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+#undef RB_GLOAD
+            unsigned sgv = ssg;
+            asm volatile("" : "+v"(sgv));
 #pragma unroll
             for (int pi = 0; pi < 2; ++pi) {
-                const int P = wave * 2 + pi;              // 16-channel pair
-                f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int s = 0; s < 5; ++s) {
-                    int tap = 2 * s + (g >> 1);
-                    if (tap > 8) tap = 8;                 // zero-weight slot: any valid location
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    const unsigned char *trow = T1 + ((y + ky - 1 + 3) % 3) * RB_ROW;
-                    // A fragment of mfma_16x16x32 (row = out channel lane & 15 of the pair, k = (lane >> 4) * 8 + j): block
-                    // diagonal over the pair's two groups, zero in the 10th tap slot
-                    h8_t af = *reinterpret_cast<const h8_t *>(GW + ((P * 16 + lcol) * 9 + tap) * 16);
-                    if (((lcol >> 3) != (g & 1)) || (2 * s + (g >> 1) > 8)) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) af[e] = (half_t)0.0f;
-                    }
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        int p = tt * 16 + lcol + kx - 1;
-                        p = p < 0 ? 0 : (p > 31 ? 31 : p);   // strip pixels 0 and 31 are halo: their outputs are not used
-                        const h8_t b = *reinterpret_cast<const h8_t *>(trow + p * 512 + (((P + 16 * (g & 1)) ^ p) << 4));
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, b, acc[tt], 0, 0, 0);
-                    }
-                }
-                const int c0 = P * 16 + g * 4;
-                const float4 s2 = rb_lds4(SS + 512 + c0);
-                const float4 h2 = rb_lds4(SS + 768 + c0);
+                const int c0 = (wave * 2 + pi) * 16 + g * 4;
+                const float4 s2 = rb_lds4o(smem, sgv + 2048 + pi * 64);
+                const float4 h2 = rb_lds4o(smem, sgv + 3072 + pi * 64);
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     const int j = tt * 16 + lcol;
-                    const h4_t v = rb_cvt4(fmaxf(acc[tt][0] * s2.x + h2.x, 0.0f), fmaxf(acc[tt][1] * s2.y + h2.y, 0.0f),
-                                           fmaxf(acc[tt][2] * s2.z + h2.z, 0.0f), fmaxf(acc[tt][3] * s2.w + h2.w, 0.0f));
-                    *reinterpret_cast<h4_t *>(T2 + (j >> 1) * 1056 + (j & 1) * 512 + ((((c0 >> 3) ^ (j & 1))) << 4) + (c0 & 4) * 2) = v;
+                    const h4_t v = rb_cvt4(fmaxf(acc[pi][tt][0] * s2.x + h2.x, 0.0f), fmaxf(acc[pi][tt][1] * s2.y + h2.y, 0.0f),
+                                           fmaxf(acc[pi][tt][2] * s2.z + h2.z, 0.0f), fmaxf(acc[pi][tt][3] * s2.w + h2.w, 0.0f));
+                    *reinterpret_cast<h4_t *>(T2 + (y & 1) * RB_PROW + (j >> 1) * 1056 + (j & 1) * 512 + ((((c0 >> 3) ^ (j & 1))) << 4) + (c0 & 4) * 2) = v;
                 }
             }
         }
-        RB_LDS_BARRIER();                     // t2 row complete (all 256 channels)
+        RB_STAMP(3)
+        RB_WAIT_ALL();                        // t2 row complete (all 256 channels), x row r + 1 landed
+        RB_STAMP(4)
 
         // ---- conv3(y) + bn3 + residual (x row y, from the LDS ring) + ReLU -> HBM
-        {
-            const unsigned char *tp = T2 + bfrag;
+        if (y >= ya) {
+            const unsigned char *tp = T2 + (y & 1) * RB_PROW + bfrag;
             f32x16_t acc0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc0[i] = 0.0f;
@@ -238,10 +312,16 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             }
+#ifdef SFD2_RB_TRACE
+            asm volatile("s_nop 0" ::"v"(acc0[0]));
+#endif
+            RB_STAMP(5)
             const unsigned char *xres = XR + ((y + RB_NX) % RB_NX) * RB_PROW + pp_base;
             const bool st_ok = n >= 1 && n <= RB_SW && ncol < W;
             half_t *orow = out + ((size_t)y * W + (st_ok ? ncol : 0)) * 256;
             const int cl = wave * 32 + 4 * lhi;
+            unsigned ssv3 = ssb;
+            asm volatile("" : "+v"(ssv3));
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 uint2 pk[2];
@@ -249,8 +329,8 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
                 for (int j = 0; j < 2; ++j) {
                     const int q = 2 * m + j;
                     const int c0 = cl + 8 * q;
-                    const float4 s3 = rb_lds4(SS + 1024 + c0);
-                    const float4 h3 = rb_lds4(SS + 1280 + c0);
+                    const float4 s3 = rb_lds4o(smem, ssv3 + 4096 + 32 * q);
+                    const float4 h3 = rb_lds4o(smem, ssv3 + 5120 + 32 * q);
                     const h4_t rs = *reinterpret_cast<const h4_t *>(xres + (((c0 >> 3) ^ (n & 1)) << 4) + (c0 & 4) * 2);
                     const h4_t hv = rb_cvt4(fmaxf(acc0[4 * q + 0] * s3.x + h3.x + (float)rs[0], 0.0f),
                                             fmaxf(acc0[4 * q + 1] * s3.y + h3.y + (float)rs[1], 0.0f),
@@ -264,11 +344,10 @@ void resblock_kernel(const half_t *__restrict__ x, int H, int W,
                     *reinterpret_cast<uint4 *>(orow + wave * 32 + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1s[0], t0[1], t1s[1]);
             }
         }
+        RB_STAMP(6)
     }
 #undef RB_ISSUE_X
-#undef RB_WAIT_KEEP2
 #undef RB_WAIT_ALL
-#undef RB_LDS_BARRIER
 }
 
 void launch_resblock(hipStream_t st, const half_t *x, int H, int W, const half_t *w1, const float *sc1, const float *sh1,
@@ -277,7 +356,7 @@ void launch_resblock(hipStream_t st, const half_t *x, int H, int W, const half_t
 {
     static bool attr_done = false;
     static int slots = 256;
-    const size_t lds = (size_t)(RB_NX + 1) * RB_PROW + 3 * RB_ROW + RB_GW_BYTES + 6 * 256 * sizeof(float);
+    const size_t lds = (size_t)(RB_NX + 2) * RB_PROW + 3 * RB_ROW + 6 * 256 * sizeof(float);
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resblock_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int dev = 0, cus = 0;
@@ -294,4 +373,21 @@ void launch_resblock(hipStream_t st, const half_t *x, int H, int W, const half_t
     segs = (H + rpi - 1) / rpi;
     hipLaunchKernelGGL(resblock_kernel, dim3(strips * segs), dim3(RB_NT), lds, st, x, H, W, w1, sc1, sh1, wg, sc2, sh2, w3,
                        sc3, sh3, out, strips, rpi, zero_page);
+#ifdef SFD2_RB_TRACE
+    {
+        static int dumps = 0;
+        if (H >= 200 && ++dumps == 40) {
+            (void)hipStreamSynchronize(st);
+            static unsigned long long h[2][64][8];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rb_trace), sizeof(h));
+            fprintf(stderr, "rbtrace columns: copies+conv1 MFMAs | conv1 epilogue | grouped conv | barrier | conv3 MFMAs | conv3 epilogue+store | to next row\n");
+            for (int w = 0; w < 2; ++w)
+                for (int r = 2; r < 10; ++r) {
+                    fprintf(stderr, "rbtrace wave %d row %2d:", w * 4, r);
+                    for (int k = 1; k < 7; ++k) fprintf(stderr, " %6lld", (long long)(h[w][r][k] - h[w][r][k - 1]));
+                    fprintf(stderr, "  | %lld\n", (long long)(h[w][r + 1][0] - h[w][r][6]));
+                }
+        }
+    }
+#endif
 }
