@@ -17,7 +17,8 @@ Multi-GPU: one process per GPU, images sharded, no collective on the data path
 `value` is the throughput mode (precision 'f16': descriptors within 3e-3 of the reference, key-point IoU >= 0.95;
 profiles/r02_error_budget.txt shows why no cheaper-than-1.3x mixed mode reaches 1e-3).  The same workload in the
 strict parity mode (precision 'f32': descriptors within 2e-5, key-point list equal up to near-ties) is timed right
-after it and reported as `strict_f32` in the same line; tolerances are asserted by tests/, not here.
+after it and reported as `strict_f32` in the same line, and again with the convolutions on the fp16 matrix path in three
+hi / lo passes (precision 'f16x3', same tolerances) as `strict_f16x3`; tolerances are asserted by tests/, not here.
 """
 import argparse
 import ctypes
@@ -366,10 +367,12 @@ def main():
 
     # strict parity mode, same workload, same bracket (precision 'f32'; the matcher is unchanged: its fp16 GEMM already
     # meets the 1e-3 similarity tolerance)
-    strict = None
-    if not args.no_strict:
+    # parity modes, same workload, same bracket: precision 'f32' (exact fp32 on the f32-input MFMA) and 'f16x3' (the same
+    # buffers and layer sequence with the convolutions on the fp16 matrix path in three passes); the matcher is unchanged:
+    # its fp16 GEMM already meets the 1e-3 similarity tolerance
+    def parity_leg(mode):
         for ln in lanes:
-            ln.ctx.set_precision("f32")
+            ln.ctx.set_precision(mode)
         n_st = max(4, min(args.steps, 10))
 
         def sstep(i):
@@ -391,8 +394,15 @@ def main():
         dst = max_over_ranks(time.perf_counter() - t0)
         for ln in lanes:
             ln.ctx.set_precision("f16")
-        strict = {"value": round(n_st * world / dst, 3), "unit": "images/sec", "ms_per_step": round(dst / n_st * 1e3, 3),
-                  "steps": n_st, "dtype": "f32", "streams_per_gpu": len(lanes), "parity": "descriptors <= 2e-5, ordered key-point list equal up to near-ties (tests/test_gpu_parity.py::test_strict_*)"}
+        return {"value": round(n_st * world / dst, 3), "unit": "images/sec", "ms_per_step": round(dst / n_st * 1e3, 3),
+                "steps": n_st, "dtype": mode, "streams_per_gpu": len(lanes),
+                "parity": "descriptors <= 2e-5, ordered key-point list equal up to near-ties "
+                          + ("(tests/test_gpu_parity.py::test_strict_*)" if mode == "f32" else "(tests/test_gpu_baseline_configs.py::test_f16x3_*)")}
+
+    strict = strict_x3 = None
+    if not args.no_strict:
+        strict = parity_leg("f32")
+        strict_x3 = parity_leg("f16x3")
 
     if rank == 0:
         # dominant kernel family = largest summed device time
@@ -455,7 +465,7 @@ def main():
             "mutual_matches_last_step": n_matched,
             "parity": {"mode": "f16 throughput", "descriptors_max_abs": "<= 3e-3 (measured 1.8e-3)", "keypoint_set_iou": ">= 0.95",
                        "selection_given_heat_map": "bit-exact", "asserted_in": "tests/test_gpu_parity.py"},
-            "single_stream": single, "sustained": sustained, "strict_f32": strict,
+            "single_stream": single, "sustained": sustained, "strict_f32": strict, "strict_f16x3": strict_x3,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)

@@ -91,9 +91,13 @@ int sfd2_load_weights(sfd2_ctx *ctx, const sfd2_tensor *tensors, int n);
 
 /* Arithmetic of the conv stack.  SFD2_PREC_F16 (default): fp16 MFMA operands, fp32 accumulate,
  * fp16 activations -- the throughput mode.  SFD2_PREC_F32: exact fp32 on the f32-input MFMA with
- * fp32 activations -- the parity mode (differs from the fp32 reference by summation order only). */
+ * fp32 activations -- the parity mode (differs from the fp32 reference by summation order only).
+ * SFD2_PREC_F16X3: the parity mode's buffers, filters and layer sequence with the 3x3 / 1x1 convolutions on the fp16
+ * matrix path in three passes (operands split into hi + lo fp16 while they are staged; ~2^-22 per product against
+ * fp32's 2^-24, fp32 accumulation) -- descriptors within 2e-5 of the reference like SFD2_PREC_F32, ~2x its speed. */
 #define SFD2_PREC_F16 0
 #define SFD2_PREC_F32 1
+#define SFD2_PREC_F16X3 2
 int sfd2_set_precision(sfd2_ctx *ctx, int mode);
 
 /* Execution options of a context (the reference has none: its layers are stock torch modules).

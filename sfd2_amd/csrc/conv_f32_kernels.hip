@@ -215,6 +215,245 @@ void launch_conv_igemm_f32(hipStream_t st, const float *in, int H, int W, int Ci
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same implicit GEMM on the fp16 matrix path, three passes ("f16x3", precision mode SFD2_PREC_F16X3): every fp32
+// operand x is split while it is staged into LDS into hi = fp16(x) and lo = fp16((x - hi) * 2048), and
+//     x * w  ~=  hi_x * hi_w  +  (hi_x * lo_w + lo_x * hi_w) / 2048          (the lo * lo term, <= 2^-22 relative, is dropped)
+// with both sums accumulated in fp32 by v_mfma_f32_32x32x16_f16.  Activations and filters stay fp32 in HBM: nothing but
+// this kernel changes against the strict mode.  The factor 2048 keeps lo in fp16's normal range whenever x is (so it does
+// not matter whether the matrix pipe flushes fp16 subnormals).  Per product the error is ~2^-22 relative against fp32's
+// 2^-24; accumulation is fp32 as before.  Cost: 3 MFMAs of 32 cycles per 16-wide k slice instead of 8 of 64.
+#define PIXH 40   // halves per pixel record in LDS: 32 + 8 pad (80 B: conflict-free ds_read_b128)
+#define X3_SCALE 2048.0f
+
+__device__ __forceinline__ void x3_split(const float4 v, h4_t &hi, h4_t &lo)
+{
+    hi[0] = (half_t)v.x; hi[1] = (half_t)v.y; hi[2] = (half_t)v.z; hi[3] = (half_t)v.w;
+    lo[0] = (half_t)((v.x - (float)hi[0]) * X3_SCALE);
+    lo[1] = (half_t)((v.y - (float)hi[1]) * X3_SCALE);
+    lo[2] = (half_t)((v.z - (float)hi[2]) * X3_SCALE);
+    lo[3] = (half_t)((v.w - (float)hi[3]) * X3_SCALE);
+}
+
+template <int KS, int STRIDE, int BN, bool HAS_RES>
+__global__ __launch_bounds__(NT)
+void conv_igemm_x3_kernel(const float *__restrict__ in, int H, int W, int Cin,
+                          const float *__restrict__ wpk, const float *__restrict__ scale,
+                          const float *__restrict__ shift, int CoutP, int relu,
+                          const float *__restrict__ res, float *__restrict__ out,
+                          int Ho, int Wo, int tiles_x)
+{
+    constexpr int T = KS * KS;
+    constexpr int PAD = KS / 2;
+    constexpr int PH = (TH - 1) * STRIDE + KS;
+    constexpr int PW = (TW - 1) * STRIDE + KS;
+    constexpr int NPIX = PH * PW;
+    constexpr int XPIECES = NPIX * 8;                  // 4-channel pieces of one patch chunk (32 channels / pixel)
+    constexpr int WPIECES = BN * 8;
+    constexpr int WP = WPIECES / NT;                   // BN 64 -> 2, 128 -> 4
+    constexpr int WAVES_CH = (BN >= 128) ? 2 : 1;
+    constexpr int WAVES_PX = 4 / WAVES_CH;
+    constexpr int CH_T = BN / WAVES_CH / 32;
+    constexpr int PX_T = TH / WAVES_PX;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half_t *Xh = reinterpret_cast<half_t *>(smem);     // [NPIX][PIXH]
+    half_t *Xl = Xh + NPIX * PIXH;
+    half_t *Wh = Xl + NPIX * PIXH;                     // [2][BN][PIXH]
+    half_t *Wl = Wh + 2 * BN * PIXH;
+    float *SS = reinterpret_cast<float *>(Wl + 2 * BN * PIXH);   // scale[BN], shift[BN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wch = (wave % WAVES_CH) * (CH_T * 32);
+    const int wrow = (wave / WAVES_CH) * PX_T;
+    const int n_tiles_n = CoutP / BN;
+    const int swz = xcd_swizzle_f(blockIdx.x, gridDim.x);
+    const int tn = swz % n_tiles_n;
+    const int tsp = swz / n_tiles_n;
+    const int tx = tsp % tiles_x, ty = tsp / tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = tn * BN;
+
+    float4 wr[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#define X3_STAGE_X(chunk_)                                                                             \
+    for (int p = tid; p < XPIECES; p += NT) {                                                          \
+        const int q = p >> 3, part = p & 7;                                                            \
+        const int py = q / PW, px = q - py * PW;                                                       \
+        const int iy = oy0 * STRIDE - PAD + py, ix = ox0 * STRIDE - PAD + px;                          \
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W)                                                    \
+            v = *reinterpret_cast<const float4 *>(in + ((size_t)(iy * W + ix) * Cin + (chunk_)*CC + part * 4)); \
+        h4_t hi, lo;                                                                                   \
+        x3_split(v, hi, lo);                                                                           \
+        *reinterpret_cast<h4_t *>(Xh + q * PIXH + part * 4) = hi;                                      \
+        *reinterpret_cast<h4_t *>(Xl + q * PIXH + part * 4) = lo;                                      \
+    }
+#define X3_LOAD_W(step_)                                                                               \
+    {                                                                                                  \
+        const float *wbase_ = wpk + ((size_t)(step_)*CoutP + n0) * CC;                                 \
+        _Pragma("unroll") for (int i = 0; i < WP; ++i)                                                 \
+            wr[i] = *reinterpret_cast<const float4 *>(wbase_ + (size_t)(tid + i * NT) * 4);            \
+    }
+#define X3_STORE_W(buf_)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < WP; ++i) {                                                   \
+        const int p = tid + i * NT, row = p >> 3, part = p & 7;                                        \
+        /* the filters arrive pre-split (x3_split_kernel): 16 bytes = 4 hi + 4 lo halves of one float4 */ \
+        *reinterpret_cast<float2 *>(Wh + ((buf_)*BN + row) * PIXH + part * 4) = make_float2(wr[i].x, wr[i].y); \
+        *reinterpret_cast<float2 *>(Wl + ((buf_)*BN + row) * PIXH + part * 4) = make_float2(wr[i].z, wr[i].w); \
+    }
+
+    f32x16_t accm[CH_T][PX_T], accl[CH_T][PX_T];       // hi * hi  |  (hi * lo + lo * hi) * 2048
+#pragma unroll
+    for (int a = 0; a < CH_T; ++a)
+#pragma unroll
+        for (int b = 0; b < PX_T; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[a][b][r] = 0.0f; accl[a][b][r] = 0.0f; }
+
+    const int NS = (Cin / CC) * T;
+    X3_STAGE_X(0)
+    X3_LOAD_W(0)
+    X3_STORE_W(0)
+    if (tid < BN) { SS[tid] = scale[n0 + tid]; SS[BN + tid] = shift[n0 + tid]; }
+    __syncthreads();
+
+    const int lrow = lane & 31, lk = (lane >> 5) * 8;
+    int chunk = 0, tap = 0;
+    for (int s = 0; s < NS; ++s) {
+        const int wb = s & 1;
+        int ntap = tap + 1, nchunk = chunk;
+        if (ntap == T) { ntap = 0; ++nchunk; }
+        const bool has_next = (s + 1 < NS);
+        const bool new_chunk = has_next && (ntap == 0);
+        if (has_next) X3_LOAD_W(s + 1)
+
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const half_t *wh = Wh + wb * BN * PIXH, *wl = Wl + wb * BN * PIXH;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            h8_t ah[CH_T], al[CH_T], bh[PX_T], bl[PX_T];
+#pragma unroll
+            for (int ct = 0; ct < CH_T; ++ct) {
+                const int o = (wch + ct * 32 + lrow) * PIXH + kb * 16 + lk;
+                ah[ct] = *reinterpret_cast<const h8_t *>(wh + o);
+                al[ct] = *reinterpret_cast<const h8_t *>(wl + o);
+            }
+#pragma unroll
+            for (int pr = 0; pr < PX_T; ++pr) {
+                const int q = ((wrow + pr) * STRIDE + ky) * PW + lrow * STRIDE + kx;
+                bh[pr] = *reinterpret_cast<const h8_t *>(Xh + q * PIXH + kb * 16 + lk);
+                bl[pr] = *reinterpret_cast<const h8_t *>(Xl + q * PIXH + kb * 16 + lk);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CH_T; ++ct)
+#pragma unroll
+                for (int pr = 0; pr < PX_T; ++pr) {
+                    accm[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ct], bh[pr], accm[ct][pr], 0, 0, 0);
+                    accl[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ct], bl[pr], accl[ct][pr], 0, 0, 0);
+                    accl[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ct], bh[pr], accl[ct][pr], 0, 0, 0);
+                }
+        }
+        if (has_next) { X3_STORE_W(wb ^ 1) }
+        __syncthreads();
+        if (new_chunk) {          // every wave is past its reads of the patch: re-stage it
+            X3_STAGE_X(nchunk)
+            __syncthreads();
+        }
+        tap = ntap;
+        chunk = nchunk;
+    }
+#undef X3_STAGE_X
+#undef X3_LOAD_W
+#undef X3_STORE_W
+
+#pragma unroll
+    for (int pr = 0; pr < PX_T; ++pr) {
+        const int oy = oy0 + wrow + pr, ox = ox0 + lrow;
+        if (oy < Ho && ox < Wo) {
+            const size_t pix = (size_t)oy * Wo + ox;
+#pragma unroll
+            for (int ct = 0; ct < CH_T; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = wch + ct * 32 + 8 * q + 4 * (lane >> 5);
+                    const float4 sc = *reinterpret_cast<const float4 *>(SS + cl);
+                    const float4 sh = *reinterpret_cast<const float4 *>(SS + BN + cl);
+                    constexpr float inv = 1.0f / X3_SCALE;
+                    float v0 = (accm[ct][pr][4 * q + 0] + accl[ct][pr][4 * q + 0] * inv) * sc.x + sh.x;
+                    float v1 = (accm[ct][pr][4 * q + 1] + accl[ct][pr][4 * q + 1] * inv) * sc.y + sh.y;
+                    float v2 = (accm[ct][pr][4 * q + 2] + accl[ct][pr][4 * q + 2] * inv) * sc.z + sh.z;
+                    float v3 = (accm[ct][pr][4 * q + 3] + accl[ct][pr][4 * q + 3] * inv) * sc.w + sh.w;
+                    const size_t o = pix * CoutP + n0 + cl;
+                    if (HAS_RES) {
+                        const float4 r = *reinterpret_cast<const float4 *>(res + o);
+                        v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+                    }
+                    if (relu) {
+                        v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
+                    }
+                    *reinterpret_cast<float4 *>(out + o) = make_float4(v0, v1, v2, v3);
+                }
+        }
+    }
+}
+
+// packed fp32 filters -> the same array with every float4 replaced by (4 hi halves, 4 lo halves)
+__global__ __launch_bounds__(NT)
+void x3_split_kernel(const float4 *__restrict__ w, size_t n4, uint4 *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n4) return;
+    h4_t hi, lo;
+    x3_split(w[i], hi, lo);
+    uint4 o;
+    __builtin_memcpy(&o.x, &hi, 8);
+    __builtin_memcpy(&o.z, &lo, 8);
+    out[i] = o;
+}
+
+void launch_x3_split(hipStream_t st, const float *w, size_t n_floats, void *out)
+{
+    const size_t n4 = n_floats / 4;
+    hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)((n4 + NT - 1) / NT)), dim3(NT), 0, st,
+                       reinterpret_cast<const float4 *>(w), n4, reinterpret_cast<uint4 *>(out));
+}
+
+template <int KS, int STRIDE, int BN, bool HAS_RES>
+static void launch_x3_t(hipStream_t st, const float *in, int H, int W, int Cin, const float *wpk, const float *scale,
+                        const float *shift, int CoutP, int relu, const float *res, float *out, int Ho, int Wo)
+{
+    constexpr int PH = (TH - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
+    constexpr size_t lds = (size_t)(PH * PW + 2 * BN) * PIXH * sizeof(half_t) * 2 + (size_t)2 * BN * sizeof(float);
+    static bool attr_done = false;
+    auto kern = conv_igemm_x3_kernel<KS, STRIDE, BN, HAS_RES>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+    hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y * (CoutP / BN)), dim3(NT), lds, st, in, H, W, Cin, wpk, scale, shift,
+                       CoutP, relu, res, out, Ho, Wo, tiles_x);
+}
+
+void launch_conv_igemm_x3(hipStream_t st, const float *in, int H, int W, int Cin, const float *wpk,
+                          const float *scale, const float *shift, int CoutP, int ks, int stride, int relu,
+                          const float *residual, float *out, int Ho, int Wo)
+{
+#define SFD2_X3(KS_, ST_, BN_)                                                                                         \
+    do {                                                                                                              \
+        if (residual) launch_x3_t<KS_, ST_, BN_, true>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo); \
+        else launch_x3_t<KS_, ST_, BN_, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo);         \
+    } while (0)
+    const bool b128 = (CoutP % 128 == 0);
+    if (ks == 3 && stride == 1) { if (b128) SFD2_X3(3, 1, 128); else SFD2_X3(3, 1, 64); }
+    else if (ks == 3 && stride == 2) { if (b128) SFD2_X3(3, 2, 128); else SFD2_X3(3, 2, 64); }
+    else if (ks == 1 && stride == 1) { if (b128) SFD2_X3(1, 1, 128); else SFD2_X3(1, 1, 64); }
+    else abort();
+#undef SFD2_X3
+}
+
+// ---------------------------------------------------------------------------------------------
 // conv1a (3 -> 64, 3x3) + norm_RGB + BN + ReLU, fp32 VALU, accumulation order (c, ky, kx) as the
 // reference's direct convolution.  One thread = one pixel, 64 output channels in 4 passes of 16.
 __global__ __launch_bounds__(NT)

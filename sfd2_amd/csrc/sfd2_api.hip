@@ -55,6 +55,8 @@ struct ConvW {                 // one folded + packed layer
     DevBuf w, scale, shift;    // fp16 packed filters, fp32 [cout_pad]
     DevBuf wrm;                // 1x1 256 -> 256 layers: the same filters as plain [cout][cin] fp16 (conv1x1_c256_kernel)
     DevBuf wgc;                // grouped 3x3: compact [256 oc][9 taps][8 in] fp16 (resblock_kernel)
+    DevBuf wx3;                // fp32 layers, SFD2_PREC_F16X3: every float4 of w as (4 hi, 4 lo) fp16, made on first use
+    size_t w_floats = 0;       // floats in w (fp32 layers)
 };
 
 struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; };
@@ -218,7 +220,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
                    &c->da0, &c->da3, &c->pb, &c->db, &c->f1a, &c->f1b, &c->f2a, &c->f2b, &c->f3a, &c->f3b, &c->frb1[0],
                    &c->frb1[1], &c->frb1[2], &c->frb2[0], &c->frb2[1], &c->frb2[2], &c->frb3[0], &c->frb3[1], &c->frb3[2],
                    &c->fpa0, &c->fpa3, &c->fda0, &c->fda3, &c->fpb, &c->fdb};
-    for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); w->wrm.release(); w->wgc.release(); }
+    for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); w->wrm.release(); w->wgc.release(); w->wx3.release(); }
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
     for (int i = 0; i < 2; ++i) {
@@ -522,7 +524,7 @@ static int ensure_workspace(sfd2_ctx *c, int H, int W)
     c->H8 = down2(c->H4); c->W8 = down2(c->W4);
     const size_t P1 = (size_t)H * W, P2 = (size_t)c->H2 * c->W2, P4 = (size_t)c->H4 * c->W4, P8 = (size_t)c->H8 * c->W8;
     const size_t hb = sizeof(half_t);
-    const bool f32 = c->precision == SFD2_PREC_F32;
+    const bool f32 = c->precision != SFD2_PREC_F16;   // SFD2_PREC_F32 and SFD2_PREC_F16X3 share the fp32 buffers
     const bool layers = !f32 && !c->alias_now;      // private fp16 buffer per activation
     if (layers) {
         if (!c->fuse_now) HIPCHECK(c->a1a.ensure(P1 * 64 * hb));
@@ -648,11 +650,18 @@ static void convf(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &i
                   int Ho, int Wo, int relu, const float *res = nullptr)
 {
     char kn[48];
-    snprintf(kn, sizeof(kn), "conv_igemm_f32<%d,%d,%d>", L.ks, L.stride, (L.cout_pad % 128 == 0) ? 128 : 64);
+    const bool x3 = c->precision == SFD2_PREC_F16X3;
+    if (x3 && !L.wx3.p) {      // split the packed filters once: the kernel then stages them without arithmetic
+        ConvW &Lm = const_cast<ConvW &>(L);
+        const size_t nfl = (size_t)L.ks * L.ks * L.cout_pad * L.cin;
+        if (Lm.wx3.ensure(nfl * sizeof(float)) != hipSuccess) { fail("out of device memory (f16x3 filters)"); return; }
+        launch_x3_split(c->stream, L.w.as<float>(), nfl, Lm.wx3.p);
+    }
+    snprintf(kn, sizeof(kn), "conv_igemm_%s<%d,%d,%d>", x3 ? "x3" : "f32", L.ks, L.stride, (L.cout_pad % 128 == 0) ? 128 : 64);
     const double px = (double)Ho * Wo;
     ProfScope ps(c, name, kn, 2.0 * px * L.cout * L.cin * L.ks * L.ks,
                  4.0 * ((double)H * W * L.cin + (double)L.cout * L.cin * L.ks * L.ks + px * L.cout_pad * (res ? 2 : 1)));
-    launch_conv_igemm_f32(c->stream, in.as<float>(), H, W, L.cin, L.w.as<float>(), L.scale.as<float>(),
+    (x3 ? launch_conv_igemm_x3 : launch_conv_igemm_f32)(c->stream, in.as<float>(), H, W, L.cin, x3 ? L.wx3.as<float>() : L.w.as<float>(), L.scale.as<float>(),
                           L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu, res, out.as<float>(), Ho, Wo);
 }
 
@@ -708,7 +717,7 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
 static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
 {
     c->cur_stream = c->stream;
-    if (c->precision == SFD2_PREC_F32) return run_network_f32(c, img_dev, normalise);
+    if (c->precision != SFD2_PREC_F16) return run_network_f32(c, img_dev, normalise);
     hipStream_t st = c->stream;
     const int H = c->H, W = c->W, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
     const double P1 = (double)H * W, P4 = (double)H4 * W4, P8 = (double)H8 * W8;
@@ -1952,7 +1961,7 @@ extern "C" int sfd2_extract_match(sfd2_ctx *c, const void *img_dev, int H, int W
 extern "C" int sfd2_set_precision(sfd2_ctx *c, int mode)
 {
     if (!c) return fail("sfd2_set_precision: null ctx");
-    if (mode != SFD2_PREC_F16 && mode != SFD2_PREC_F32) return fail("sfd2_set_precision: unknown mode");
+    if (mode != SFD2_PREC_F16 && mode != SFD2_PREC_F32 && mode != SFD2_PREC_F16X3) return fail("sfd2_set_precision: unknown mode");
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
     c->precision = mode;

@@ -63,6 +63,11 @@ void launch_convsta(hipStream_t st, const half_t *in, int npix, const float *w /
 void launch_conv_igemm_f32(hipStream_t st, const float *in, int H, int W, int Cin, const float *wpk,
                            const float *scale, const float *shift, int Cout_pad, int ks, int stride, int relu,
                            const float *residual, float *out, int Ho, int Wo);
+// the same signature on the fp16 matrix path in three passes (SFD2_PREC_F16X3); wpk = the filters after launch_x3_split
+void launch_x3_split(hipStream_t st, const float *w, size_t n_floats, void *out);
+void launch_conv_igemm_x3(hipStream_t st, const float *in, int H, int W, int Cin, const float *wpk,
+                           const float *scale, const float *shift, int Cout_pad, int ks, int stride, int relu,
+                           const float *residual, float *out, int Ho, int Wo);
 void launch_conv1a_f32(hipStream_t st, const float *img_chw, int H, int W, int normalise, const float *w /*[64][27]*/,
                        const float *scale, const float *shift, float *out /*[H][W][64]*/);
 void launch_gconv_f32(hipStream_t st, const float *in, int H, int W, const float *w /*[256][72]*/, const float *scale,

@@ -479,3 +479,47 @@ def test_label_matcher_single_launch_vs_oracle_f16():
     planted = np.full(n0, -1); planted[src] = dst
     strong = src[:300]
     assert (got["matches0"][strong] == planted[strong]).mean() >= 0.99
+
+
+# ------------------------------------------------------------------ SFD2_PREC_F16X3: the parity mode on the fp16 matrix path, three passes
+@pytest.fixture(scope="module")
+def model_x3(synth_sd):
+    from sfd2_amd.model import ResSegNetV2
+    m = ResSegNetV2(outdim=128, require_stability=True, precision="f16x3").eval()
+    m.load_state_dict(synth_sd)
+    m.cuda(0)
+    return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,seed", [(64, 96, 11), (100, 130, 12), (37, 53, 13)])
+def test_f16x3_det_vs_oracle(model_x3, synth_sd, h, w, seed):
+    """Every tapped activation, the score map and the descriptor map of the three-pass fp16 mode against the fp32 oracle,
+    with the strict mode's tolerances (tests/test_gpu_parity.py::test_strict_det_vs_oracle)."""
+    import oracle.oracle as orc
+    img = synth.make_image(h, w, seed)
+    x = orc.norm_rgb(img)
+    taps = {}
+    o_score, o_stab, o_desc = orc.det(synth_sd, x, taps)
+    score, stab, desc = model_x3.det(x[None])
+    ctx = model_x3.context
+    for name, want in taps.items():
+        got = ctx.debug_activation(name)
+        np.testing.assert_allclose(got, want, atol=1e-4, rtol=1e-4, err_msg=name)
+    np.testing.assert_allclose(score[0, 0], o_score, atol=1e-6, rtol=2e-4)
+    np.testing.assert_allclose(desc[0], o_desc, atol=2e-5)
+    assert (stab[0, 0] != o_stab).mean() <= 5e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,seed,topk", [(96, 128, 21, 200), (480, 640, 0, 1024), (1200, 1600, 5, 4096)])
+def test_f16x3_extract_vs_oracle(model_x3, synth_sd, h, w, seed, topk):
+    """Key-point list (order up to near-ties), scores and descriptors (<= 2e-5) of the f16x3 mode against the oracle, up to the
+    full BASELINE size."""
+    import oracle.oracle as orc
+    from sfd2_amd.extractor import extract_resnet_return
+    from tests.test_gpu_parity import _compare_strict
+    img = synth.make_image(h, w, seed)
+    got = extract_resnet_return(model_x3, img[None], conf_th=0.001, topK=topk, scales=[1.0])
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk)
+    _compare_strict(got, want, 2e-5)
