@@ -141,8 +141,8 @@ void conv1x1_c256_kernel(const half_t *__restrict__ in, int npix, const half_t *
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int q = 2 * m + j;
-                    const float4 sc = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
-                    const float4 sh = *reinterpret_cast<const float4 *>(SS + 256 + cl + 8 * q);
+                    const float4 sc = sfd2_lds_f4(SS + cl + 8 * q);          // (typed like the fragments: no vmcnt(0) drain of the ring)
+                    const float4 sh = sfd2_lds_f4(SS + 256 + cl + 8 * q);
                     float v0 = acc[t][4 * q + 0] * sc.x + sh.x;
                     float v1 = acc[t][4 * q + 1] * sc.y + sh.y;
                     float v2 = acc[t][4 * q + 2] * sc.z + sh.z;

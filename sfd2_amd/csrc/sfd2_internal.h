@@ -22,6 +22,21 @@ typedef _Float16 half_t;
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+#ifdef __HIPCC__
+// 16-byte LDS read of four floats, TYPED LIKE THE MFMA FRAGMENT READS (_Float16 x 8).  hipcc orders LDS reads against
+// in-flight direct-to-LDS copies (global_load_lds) by type-based alias analysis: a float-typed ds_read "may alias" the
+// copies' destination and gets an s_waitcnt vmcnt(0) in front of it, which drains every copy (and store) in flight;
+// read as the fragments' type, the same bytes carry no such wait.  Use for scale / shift tables that share LDS with
+// staged tiles in kernels that keep copies in flight across the read (conv1x1_c256_kernel, resblock_kernel).
+__device__ __forceinline__ float4 sfd2_lds_f4(const float *p)
+{
+    const h8_t raw = *reinterpret_cast<const h8_t *>(reinterpret_cast<const unsigned char *>(p));
+    float4 r;
+    __builtin_memcpy(&r, &raw, 16);
+    return r;
+}
+#endif
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ conv stack
