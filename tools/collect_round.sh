@@ -8,6 +8,7 @@ out=$R/gpurun_out/$tag
 mkdir -p $out
 cd $R
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/pytest_gpu.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.txt 2>&1
 python bench.py --steps 20 --warmup 5 --dump-layers > $out/bench.json 2> $out/layer_table.txt
 python bench.py --steps 20 --warmup 5 --extract-only --no-cpu-baseline > $out/bench_extract_only.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-graphs --no-cpu-baseline --no-strict > $out/bench_eager.json 2>/dev/null
@@ -18,6 +19,10 @@ cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strict --sustain 0"
 rocprofv3 --kernel-trace --stats -d $out/prof -o $tag -- $B > $out/prof_bench.json 2> $out/prof.err
 python $R/tools/rocprof_summary.py $out/prof/*/${tag}_results.db > $out/rocprof_kernel_stats.txt 2>> $out/prof.err || python $R/tools/rocprof_summary.py $out/prof/${tag}_results.db > $out/rocprof_kernel_stats.txt 2>> $out/prof.err
+S1="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strict --sustain 0 --no-graphs --streams 1"
+rocprofv3 --kernel-trace --stats -d $out/prof1 -o ${tag}s1 -- $S1 > $out/prof_bench_streams1.json 2> $out/prof1.err
+python $R/tools/rocprof_summary.py $out/prof1/*/${tag}s1_results.db > $out/rocprof_kernel_stats_streams1.txt 2>> $out/prof1.err || python $R/tools/rocprof_summary.py $out/prof1/${tag}s1_results.db > $out/rocprof_kernel_stats_streams1.txt 2>> $out/prof1.err
+rm -rf $out/prof1/*/*.db $out/prof1/*.db
 S="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strict --sustain 0 --no-graphs --streams 1"
 rocprofv3 --pmc FETCH_SIZE -d $out/pmc1 -o x --output-format csv -- $S > /dev/null 2> $out/pmc1.err
 rocprofv3 --pmc WRITE_SIZE -d $out/pmc2 -o x --output-format csv -- $S > /dev/null 2> $out/pmc2.err
