@@ -112,6 +112,9 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *   "fuse_post" 1 (default): on the extract path, for H and W multiples of 8, detector soft-max + depth-to-space and
  *               stability weighting run as one kernel that writes the heat map (no score map in memory); 0: two
  *               kernels.  Bit-identical key points either way.
+ *   "sparse_desc" 1 (default): on the extract path (top_k > 0, 16 * top_k <= descriptor-map pixels) convDb runs after
+ *               the selection on the 4 * top_k bilinear corner pixels only, the dense descriptor map is not written;
+ *               0: dense map, then sampling.  Bit-identical descriptors either way.
  *   "branches"  0 (default) / 1: the detector branch (convPa, convPb, soft-max) runs on a second HIP stream beside
  *               the descriptor branch (convDa, convDb) -- they share only the backbone output (-1.7 % per extract).
  * Unknown keys are an error. */

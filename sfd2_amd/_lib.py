@@ -201,7 +201,7 @@ class Context:
         check(self.lib.sfd2_set_precision(self.h, {'f16': 0, 'f32': 1, 'f16x3': 2}[mode]))
 
     def set_option(self, key, value):
-        """'fuse', 'fuse_det', 'alias', 'graphs' (include/sfd2_hip.h sfd2_set_option)."""
+        """'fuse', 'fuse_det', 'alias', 'graphs', 'fuse_post', 'sparse_desc', 'branches' (include/sfd2_hip.h sfd2_set_option)."""
         check(self.lib.sfd2_set_option(self.h, key.encode(), int(value)))
 
     def sync(self):

@@ -800,6 +800,29 @@ void launch_greedy_final(hipStream_t st, const float *heat, const unsigned char 
 // One wave per key point, lane l owns channels 2l, 2l+1.  The four taps are L2-normalised on
 // the fly (F.normalize of the dense map, nets/sfd2.py:342, commutes with the gather), blended
 // with torch's grid_sample weights (zeros padding, align_corners=False) and re-normalised.
+// torch grid_sample geometry of one key point (zeros padding, align_corners=False): corner pixels, validity, weights
+struct SampleGeom {
+    int x0, y0, x1, y1;
+    bool vx0, vx1, vy0, vy1;
+    float w_nw, w_ne, w_sw, w_se;
+};
+__device__ __forceinline__ SampleGeom sample_geom(float kx, float ky, float half_w, float half_h, int hc, int wc)
+{
+    SampleGeom g;
+    const float gx = __fsub_rn(__fdiv_rn(kx, half_w), 1.0f);
+    const float gy = __fsub_rn(__fdiv_rn(ky, half_h), 1.0f);
+    const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.0f), (float)wc), 1.0f), 2.0f);
+    const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.0f), (float)hc), 1.0f), 2.0f);
+    const float fx = floorf(ix), fy = floorf(iy);
+    g.x0 = (int)fx; g.y0 = (int)fy; g.x1 = g.x0 + 1; g.y1 = g.y0 + 1;
+    const float ex = __fsub_rn(__fadd_rn(fx, 1.0f), ix), ey = __fsub_rn(__fadd_rn(fy, 1.0f), iy);
+    const float dx = __fsub_rn(ix, fx), dy = __fsub_rn(iy, fy);
+    g.w_nw = __fmul_rn(ex, ey); g.w_ne = __fmul_rn(dx, ey); g.w_sw = __fmul_rn(ex, dy); g.w_se = __fmul_rn(dx, dy);
+    g.vx0 = g.x0 >= 0 && g.x0 < wc; g.vx1 = g.x1 >= 0 && g.x1 < wc;
+    g.vy0 = g.y0 >= 0 && g.y0 < hc; g.vy1 = g.y1 >= 0 && g.y1 < hc;
+    return g;
+}
+
 __global__ __launch_bounds__(NT)
 void sample_desc_kernel(const float *__restrict__ dmap, int hc, int wc, float half_w, float half_h,
                         const float *__restrict__ kpts, const unsigned int *__restrict__ count, int n_max,
@@ -810,29 +833,20 @@ void sample_desc_kernel(const float *__restrict__ dmap, int hc, int wc, float ha
     int n = n_max;
     if (count) { const unsigned int c = *count; if ((unsigned int)n > c) n = (int)c; }
     if (i >= n) return;
-    const float gx = __fsub_rn(__fdiv_rn(kpts[2 * i], half_w), 1.0f);
-    const float gy = __fsub_rn(__fdiv_rn(kpts[2 * i + 1], half_h), 1.0f);
-    const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.0f), (float)wc), 1.0f), 2.0f);
-    const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.0f), (float)hc), 1.0f), 2.0f);
-    const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
-    const float ex = __fsub_rn(__fadd_rn(fx, 1.0f), ix), ey = __fsub_rn(__fadd_rn(fy, 1.0f), iy);
-    const float dx = __fsub_rn(ix, fx), dy = __fsub_rn(iy, fy);
-    const float w_nw = __fmul_rn(ex, ey), w_ne = __fmul_rn(dx, ey), w_sw = __fmul_rn(ex, dy), w_se = __fmul_rn(dx, dy);
-    const bool vx0 = x0 >= 0 && x0 < wc, vx1 = x1 >= 0 && x1 < wc;
-    const bool vy0 = y0 >= 0 && y0 < hc, vy1 = y1 >= 0 && y1 < hc;
+    const SampleGeom g = sample_geom(kpts[2 * i], kpts[2 * i + 1], half_w, half_h, hc, wc);
     float a0 = 0.0f, a1 = 0.0f;
-#define SFD2_TAP(valid_, yy_, xx_, wgt_)                                                             \
+#define SFD2_TAP(valid_, yy_, xx_, wgt_, corner_)                                                    \
     if (valid_) {                                                                                    \
-        const float2 v = *reinterpret_cast<const float2 *>(dmap + ((size_t)(yy_) * wc + (xx_)) * 128 + 2 * lane); \
+        const size_t row = (size_t)(yy_) * wc + (xx_);                                               \
+        const float2 v = *reinterpret_cast<const float2 *>(dmap + row * 128 + 2 * lane);             \
         const float nrm = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y)), 1e-12f);                     \
         a0 += __fdiv_rn(v.x, nrm) * (wgt_);                                                          \
         a1 += __fdiv_rn(v.y, nrm) * (wgt_);                                                          \
     }
-    SFD2_TAP(vy0 && vx0, y0, x0, w_nw)
-    SFD2_TAP(vy0 && vx1, y0, x1, w_ne)
-    SFD2_TAP(vy1 && vx0, y1, x0, w_sw)
-    SFD2_TAP(vy1 && vx1, y1, x1, w_se)
+    SFD2_TAP(g.vy0 && g.vx0, g.y0, g.x0, g.w_nw, 0)
+    SFD2_TAP(g.vy0 && g.vx1, g.y0, g.x1, g.w_ne, 1)
+    SFD2_TAP(g.vy1 && g.vx0, g.y1, g.x0, g.w_sw, 2)
+    SFD2_TAP(g.vy1 && g.vx1, g.y1, g.x1, g.w_se, 3)
 #undef SFD2_TAP
     const float nrm = sqrtf(wave_sum(a0 * a0 + a1 * a1));
     *reinterpret_cast<float2 *>(out + (size_t)i * 128 + 2 * lane) = make_float2(__fdiv_rn(a0, nrm), __fdiv_rn(a1, nrm));
@@ -844,6 +858,111 @@ void launch_sample_desc(hipStream_t st, const float *dmap, int hc, int wc, int n
     if (n_max <= 0) return;
     hipLaunchKernelGGL(sample_desc_kernel, dim3((n_max + 3) / 4), dim3(NT), 0, st, dmap, hc, wc, (float)nw / 2.0f,
                        (float)nh / 2.0f, kpts, count, n_max, out);
+}
+
+// Sparse descriptor head (extract path): convDb is a 1x1 convolution and only the four bilinear corners of the selected
+// key points are ever sampled (16 384 of 120 000 pixels at 1600x1200, top-4096), so on the throughput path convDb runs
+// AFTER the selection, on those pixels only, and the 61 MB fp32 descriptor map is never written.  Same-box A/B
+// (tools/ab_option.py sparse_desc 0 1): 1.135 -> 1.083 ms per extract -- 52 us, of which only 18 are the kernels' own
+// (dense convDb 28 + sampling 9.5 vs 19): the rest is what the map's write cost the kernels after it.
+// The three steps in ONE kernel: a block takes 16 key points, gathers their 64 corner pixels (256 fp16 channels each) into
+// LDS, runs convDb on them with MFMAs (128 out channels x 64 pixels x K = 256; wave w owns channels 32w .. 32w + 31, its
+// filter fragments come straight from the packed filters in L2), parks the fp32 result in LDS and samples it.  K ascends
+// in 16-wide slices into one accumulator and the epilogue is acc * scale + shift, exactly as conv_igemm2 computes the
+// dense map, so the descriptors are bit-identical to the dense path's.
+#define DH_KP 16
+#define DH_XREC 528      // bytes per gathered pixel record: 512 + 16 pad (conflict-free ds_read_b128)
+#define DH_OREC 132      // floats per conv output record: 128 + 4 pad
+__global__ __launch_bounds__(NT)
+void desc_head_kernel(const half_t *__restrict__ fmap /*[hc][wc][256]*/, int hc, int wc, float half_w, float half_h,
+                      const half_t *__restrict__ wpk /*[8 chunks][CoutP][32]*/, int CoutP, const float *__restrict__ scale,
+                      const float *__restrict__ shift, const float *__restrict__ kpts, const unsigned int *__restrict__ count,
+                      int n_max, float *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char X[4 * DH_KP * DH_XREC];
+    __shared__ __attribute__((aligned(16))) float O[4 * DH_KP * DH_OREC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int n = n_max;
+    if (count) { const unsigned int c = *count; if ((unsigned int)n > c) n = (int)c; }
+    const int k0 = blockIdx.x * DH_KP;
+    if (k0 >= n) return;
+
+    // filter fragments of this wave's 32 output channels (requested first: they land while the corners are gathered)
+    h8_t a[16];
+    const int lrow = lane & 31, lhi = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+        a[kk] = *reinterpret_cast<const h8_t *>(wpk + ((size_t)(kk >> 1) * CoutP + wave * 32 + lrow) * 32 + (kk & 1) * 16 + lhi * 8);
+
+    // gather: half a wave per pixel record (32 lanes x 16 B), zeros for corners outside the map / key points past the count
+    for (int rec = wave * 2 + lhi; rec < 4 * DH_KP; rec += 8) {
+        const int kp = k0 + (rec >> 2), corner = rec & 3;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (kp < n) {
+            const SampleGeom g = sample_geom(kpts[2 * kp], kpts[2 * kp + 1], half_w, half_h, hc, wc);
+            const int yy = (corner & 2) ? g.y1 : g.y0, xx = (corner & 1) ? g.x1 : g.x0;
+            const bool ok = ((corner & 2) ? g.vy1 : g.vy0) && ((corner & 1) ? g.vx1 : g.vx0);
+            if (ok) v = *reinterpret_cast<const uint4 *>(fmap + ((size_t)yy * wc + xx) * 256 + lrow * 8);
+        }
+        *reinterpret_cast<uint4 *>(X + rec * DH_XREC + lrow * 16) = v;
+    }
+    __syncthreads();
+
+    f32x16_t acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const h8_t b = *reinterpret_cast<const h8_t *>(X + (t * 32 + lrow) * DH_XREC + kk * 32 + lhi * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], b, acc[t], 0, 0, 0);
+        }
+    // C layout: lane owns pixel (t * 32 + lrow), channels wave * 32 + 8 q + 4 lhi + j
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = wave * 32 + 8 * q + 4 * lhi;
+            const float4 sc = *reinterpret_cast<const float4 *>(scale + c0);
+            const float4 sh = *reinterpret_cast<const float4 *>(shift + c0);
+            const float4 v = make_float4(acc[t][4 * q + 0] * sc.x + sh.x, acc[t][4 * q + 1] * sc.y + sh.y,
+                                         acc[t][4 * q + 2] * sc.z + sh.z, acc[t][4 * q + 3] * sc.w + sh.w);
+            *reinterpret_cast<float4 *>(O + (t * 32 + lrow) * DH_OREC + c0) = v;
+        }
+    __syncthreads();
+
+    // sampling: one wave per key point, lane l owns channels 2l, 2l + 1 (as sample_desc_kernel)
+    for (int j = wave; j < DH_KP; j += NT / 64) {
+        const int kp = k0 + j;
+        if (kp >= n) break;
+        const SampleGeom g = sample_geom(kpts[2 * kp], kpts[2 * kp + 1], half_w, half_h, hc, wc);
+        float a0 = 0.0f, a1 = 0.0f;
+#define SFD2_TAP(valid_, wgt_, corner_)                                                              \
+        if (valid_) {                                                                                \
+            const float2 v = *reinterpret_cast<const float2 *>(O + (4 * j + (corner_)) * DH_OREC + 2 * lane); \
+            const float nrm = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y)), 1e-12f);                 \
+            a0 += __fdiv_rn(v.x, nrm) * (wgt_);                                                      \
+            a1 += __fdiv_rn(v.y, nrm) * (wgt_);                                                      \
+        }
+        SFD2_TAP(g.vy0 && g.vx0, g.w_nw, 0)
+        SFD2_TAP(g.vy0 && g.vx1, g.w_ne, 1)
+        SFD2_TAP(g.vy1 && g.vx0, g.w_sw, 2)
+        SFD2_TAP(g.vy1 && g.vx1, g.w_se, 3)
+#undef SFD2_TAP
+        const float nrm = sqrtf(wave_sum(a0 * a0 + a1 * a1));
+        *reinterpret_cast<float2 *>(out + (size_t)kp * 128 + 2 * lane) = make_float2(__fdiv_rn(a0, nrm), __fdiv_rn(a1, nrm));
+    }
+}
+
+void launch_desc_head(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, int CoutP,
+                      const float *scale, const float *shift, const float *kpts, const unsigned int *count, int n_max, float *out)
+{
+    if (n_max <= 0) return;
+    hipLaunchKernelGGL(desc_head_kernel, dim3((n_max + DH_KP - 1) / DH_KP), dim3(NT), 0, st, fmap, hc, wc, (float)nw / 2.0f,
+                       (float)nh / 2.0f, wpk, CoutP, scale, shift, kpts, count, n_max, out);
 }
 
 // ---------------------------------------------------------------- dense descriptor normalise + NHWC -> NCHW

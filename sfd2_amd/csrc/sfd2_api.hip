@@ -82,6 +82,9 @@ struct sfd2_ctx {
     int alias_now = 0;                 // set per call
     int opt_fuse_post = 1;             // sfd2_set_option "fuse_post": heads -> heat map -> NMS in one kernel on the extract path
     int skip_head_now = 0;             // set per call: run_network leaves the detector soft-max to the fused NMS kernel
+    int opt_sparse_desc = 1;           // sfd2_set_option "sparse_desc": extract path runs convDb on the sampled corner pixels only
+    int skip_db_now = 0;               // set per call: run_network leaves convDb to the sparse descriptor head
+    const half_t *da_cur = nullptr;    // convDa.3 output of the last fp16 network pass
     int opt_branches = 0;              // sfd2_set_option "branches": detector branch on a second stream beside the descriptor branch
     hipStream_t side_stream = nullptr; // the detector branch (convPa.0 -> convPa.3 -> convPb -> detector_head)
     hipStream_t cur_stream = nullptr;  // stream the conv()/ProfScope helpers launch on (main or side)
@@ -823,7 +826,8 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     }
     conv(c, "convDa.0", c->da0, *x, H4, W4, da0_o, H4, W4, 1);
     conv(c, "convDa.3", c->da3, da0_o, H4, W4, da_o, H4, W4, 0);
-    conv(c, "convDb", c->db, da_o, H4, W4, c->draw, H4, W4, 0, nullptr, 1);
+    c->da_cur = da_o.as<half_t>();
+    if (!c->skip_db_now) conv(c, "convDb", c->db, da_o, H4, W4, c->draw, H4, W4, 0, nullptr, 1);
     if (c->has_sta) {
         ProfScope ps(c, "ConvSta", "convsta_kernel", 2.0 * P4 * 3 * 256, P4 * (512 + 12));
         launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
@@ -975,8 +979,16 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     // stability weighting run as ONE kernel that writes the heat map directly; the score map is never materialised
     const bool fuse_post = c->opt_fuse_post && H % 8 == 0 && W % 8 == 0;
     c->skip_head_now = fuse_post ? 1 : 0;
+    // Sparse descriptor head: convDb is 1x1 and only the bilinear corners of the selected key points are sampled, so on the
+    // throughput path it runs after the selection, on 4 x K gathered pixels instead of the whole 1/4-resolution map (the
+    // 61 MB fp32 descriptor map is never written; bit-identical descriptors).  Dense when more than a quarter of the map
+    // would be gathered (top_k <= 0: every candidate).
+    const int sel_bound = top_k > 0 ? top_k : c->cand_cap;
+    const bool sparse_desc = c->opt_sparse_desc && c->fuse_now && desc && top_k > 0 && (size_t)16 * sel_bound <= (size_t)c->H4 * c->W4;
+    c->skip_db_now = sparse_desc ? 1 : 0;
     const int net_rc = run_network(c, img_dev, in_mode);
     c->skip_head_now = 0;
+    c->skip_db_now = 0;
     if (net_rc) return -1;
     if (release_image_slot(c)) return -1;
     HIPCHECK(hipEventRecord(c->ev[1], c->stream));
@@ -1006,9 +1018,15 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
             HIPCHECK(c->kdesc.ensure((size_t)sel_cap * 128 * sizeof(float)));
             desc_dst = c->kdesc.as<float>();
         }
-        ProfScope ps(c, "sample_desc", "sample_desc_kernel", 0.0, (double)sel_cap * 128 * 4 * 5);
-        launch_sample_desc(c->stream, c->draw.as<float>(), c->H4, c->W4, H, W, c->kpts_cur,
-                           c->counters.as<unsigned int>() + 1, sel_cap, desc_dst);
+        if (sparse_desc) {
+            ProfScope ps(c, "desc_head", "desc_head_kernel", 2.0 * 4 * sel_cap * 128 * 256, (double)sel_cap * (4 * 512 + 512));
+            launch_desc_head(c->stream, c->da_cur, c->H4, c->W4, H, W, c->db.w.as<half_t>(), c->db.cout_pad, c->db.scale.as<float>(),
+                             c->db.shift.as<float>(), c->kpts_cur, c->counters.as<unsigned int>() + 1, sel_cap, desc_dst);
+        } else {
+            ProfScope ps(c, "sample_desc", "sample_desc_kernel", 0.0, (double)sel_cap * 128 * 4 * 5);
+            launch_sample_desc(c->stream, c->draw.as<float>(), c->H4, c->W4, H, W, c->kpts_cur,
+                               c->counters.as<unsigned int>() + 1, sel_cap, desc_dst);
+        }
     }
     prof_step_end(c);
     HIPCHECK(hipEventRecord(c->ev[2], c->stream));
@@ -1980,6 +1998,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "graphs") c->use_graphs = value ? 1 : 0;
     else if (k == "branches") c->opt_branches = value ? 1 : 0;
     else if (k == "fuse_post") c->opt_fuse_post = value ? 1 : 0;
+    else if (k == "sparse_desc") c->opt_sparse_desc = value ? 1 : 0;
     else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;
 }

@@ -523,3 +523,25 @@ def test_f16x3_extract_vs_oracle(model_x3, synth_sd, h, w, seed, topk):
     got = extract_resnet_return(model_x3, img[None], conf_th=0.001, topK=topk, scales=[1.0])
     want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk)
     _compare_strict(got, want, 2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,topk", [(480, 640, 1024), (1200, 1600, 4096), (333, 517, 300)])
+def test_sparse_descriptor_head_bit_identical(synth_sd, h, w, topk):
+    """Option "sparse_desc" (convDb on the gathered bilinear corners of the selected key points only) against the dense
+    descriptor map + sampling: same key points, same scores, bit-identical descriptors."""
+    from sfd2_amd.model import ResSegNetV2
+    from sfd2_amd.extractor import extract_resnet_return
+    outs = []
+    for sparse in (1, 0):
+        m = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval()
+        m.load_state_dict(synth_sd)
+        m.cuda(0)
+        m.context.set_option("sparse_desc", sparse)
+        img = synth.make_image(h, w, 77)
+        outs.append(extract_resnet_return(m, img[None], conf_th=0.001, topK=topk, scales=[1.0]))
+    a, b = outs
+    np.testing.assert_array_equal(a["keypoints"], b["keypoints"])
+    np.testing.assert_array_equal(a["scores"], b["scores"])
+    np.testing.assert_array_equal(a["descriptors"], b["descriptors"])
+    assert np.isfinite(a["descriptors"]).all() and len(a["keypoints"]) > 0
