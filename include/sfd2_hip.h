@@ -112,6 +112,7 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *   "fuse_post" 1 (default): on the extract path, for H and W multiples of 8, detector soft-max + depth-to-space and
  *               stability weighting run as one kernel that writes the heat map (no score map in memory); 0: two
  *               kernels.  Bit-identical key points either way.
+ *   "fuse_pb"   1 (default): with "fuse_post", convPb runs inside that kernel as well (the logits never reach memory).
  *   "sparse_desc" 1 (default): on the extract path (top_k > 0, 16 * top_k <= descriptor-map pixels) convDb runs after
  *               the selection on the 4 * top_k bilinear corner pixels only, the dense descriptor map is not written;
  *               0: dense map, then sampling.  Bit-identical descriptors either way.

@@ -166,6 +166,95 @@ void launch_heads_heat(hipStream_t st, const float *logits, int pitch, int hc8, 
     hipLaunchKernelGGL(heads_heat_kernel, dim3((cells + 3) / 4), dim3(NT), 0, st, logits, pitch, hc8, wc8, sta, hc, wc, st_y, st_x, H, W, heat);
 }
 
+// convPb + detector head + heat map in one kernel (extract path, H and W multiples of 8).  A block takes 32 consecutive
+// 8 x 8 cells: their 256-channel convPa.3 vectors go to LDS, waves 0-2 run convPb on them with MFMAs (65 real of 96
+// computed output channels x 32 cells x K = 256; filter fragments straight from the packed filters in L2), the fp32
+// logits are parked in LDS, and every wave then finishes eight cells exactly as heads_heat_kernel does.  K ascends in
+// 16-wide slices into one accumulator and the epilogue is acc * scale + shift, as conv_igemm2 computes the logits, so the
+// heat map is bit-identical; the 15 MB logit tensor (128-channel pitch for 65 logits) is neither written nor read.
+#define PH_CELLS 32
+#define PH_XREC 528      // bytes per gathered cell record: 512 + 16 pad
+#define PH_OREC 100      // floats per logit record: 96 + 4 pad
+__global__ __launch_bounds__(NT)
+void pb_heads_heat_kernel(const half_t *__restrict__ fmap /*[cells][256]*/, int hc8, int wc8,
+                          const half_t *__restrict__ wpk /*[8 chunks][CoutP][32]*/, int CoutP, const float *__restrict__ scale,
+                          const float *__restrict__ shift, const float *__restrict__ sta, int hc, int wc, float st_y, float st_x,
+                          int H, int W, float *__restrict__ heat)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char X[PH_CELLS * PH_XREC];
+    __shared__ __attribute__((aligned(16))) float O[PH_CELLS * PH_OREC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lhi = lane >> 5;
+    const int ncell = hc8 * wc8, c0cell = blockIdx.x * PH_CELLS;
+
+    h8_t a[16];
+    if (wave < 3) {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            a[kk] = *reinterpret_cast<const h8_t *>(wpk + ((size_t)(kk >> 1) * CoutP + wave * 32 + lrow) * 32 + (kk & 1) * 16 + lhi * 8);
+    }
+    for (int rec = wave * 2 + lhi; rec < PH_CELLS; rec += 8) {
+        const int cell = c0cell + rec;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (cell < ncell) v = *reinterpret_cast<const uint4 *>(fmap + (size_t)cell * 256 + lrow * 8);
+        *reinterpret_cast<uint4 *>(X + rec * PH_XREC + lrow * 16) = v;
+    }
+    __syncthreads();
+    if (wave < 3) {
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const h8_t b = *reinterpret_cast<const h8_t *>(X + lrow * PH_XREC + kk * 32 + lhi * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = wave * 32 + 8 * q + 4 * lhi;
+            const float4 sc = *reinterpret_cast<const float4 *>(scale + c0);
+            const float4 sh = *reinterpret_cast<const float4 *>(shift + c0);
+            *reinterpret_cast<float4 *>(O + lrow * PH_OREC + c0) =
+                make_float4(acc[4 * q + 0] * sc.x + sh.x, acc[4 * q + 1] * sc.y + sh.y, acc[4 * q + 2] * sc.z + sh.z, acc[4 * q + 3] * sc.w + sh.w);
+        }
+    }
+    __syncthreads();
+    for (int j = wave; j < PH_CELLS; j += NT / 64) {
+        const int cell = c0cell + j;
+        if (cell >= ncell) break;
+        const int cy = cell / wc8, cx = cell - cy * wc8;
+        const float *p = O + j * PH_OREC;
+        const float e = expf(p[lane]);
+        const float ed = expf(p[64]);
+        const float den = (wave_sum(e) + ed) + 0.00001f;
+        const float s = e / den;
+        const int y = 8 * cy + (lane >> 3), x = 8 * cx + (lane & 7);
+        float stab = 1.0f;
+        if (sta) {
+            const LinCoef ly = lin_coef(y, hc, H, st_y), lx = lin_coef(x, wc, W, st_x);
+            const size_t plane = (size_t)hc * wc;
+            const float v0 = bilerp(sta, wc, ly, lx);
+            const float v1 = bilerp(sta + plane, wc, ly, lx);
+            const float v2 = bilerp(sta + 2 * plane, wc, ly, lx);
+            int best = 0;
+            float bv = v0;
+            if (v1 > bv) { bv = v1; best = 1; }
+            if (v2 > bv) { bv = v2; best = 2; }
+            stab = best == 0 ? 0.1f : (best == 1 ? 0.5f : 1.0f);
+        }
+        heat[(size_t)y * W + x] = __fmul_rn(s, stab);
+    }
+}
+
+void launch_pb_heads_heat(hipStream_t st, const half_t *fmap, int hc8, int wc8, const half_t *wpk, int CoutP, const float *scale,
+                          const float *shift, const float *sta, int hc, int wc, int H, int W, float *heat)
+{
+    const float st_y = hc > 0 ? (float)hc / (float)H : 1.0f, st_x = wc > 0 ? (float)wc / (float)W : 1.0f;   // as launch_heatmap
+    const int cells = hc8 * wc8;
+    hipLaunchKernelGGL(pb_heads_heat_kernel, dim3((cells + PH_CELLS - 1) / PH_CELLS), dim3(NT), 0, st, fmap, hc8, wc8, wpk, CoutP,
+                       scale, shift, sta, hc, wc, st_y, st_x, H, W, heat);
+}
+
 // ---------------------------------------------------------------- simple_nms (+ threshold/border/compaction)
 // One block = 32 x 64 output pixels, LDS region = tile + 5*radius halo (radius 4 -> 72 x 104):
 // five chained 9x9 max-pools, each run as a row pass and a column pass over the whole region; a

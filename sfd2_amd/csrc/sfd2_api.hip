@@ -84,6 +84,9 @@ struct sfd2_ctx {
     int skip_head_now = 0;             // set per call: run_network leaves the detector soft-max to the fused NMS kernel
     int opt_sparse_desc = 1;           // sfd2_set_option "sparse_desc": extract path runs convDb on the sampled corner pixels only
     int skip_db_now = 0;               // set per call: run_network leaves convDb to the sparse descriptor head
+    int skip_pb_now = 0;               // set per call: run_network leaves convPb to the fused detector head
+    int opt_fuse_pb = 1;               // sfd2_set_option "fuse_pb": convPb inside the fused detector-head / heat-map kernel
+    const half_t *pa_cur = nullptr;    // convPa.3 output of the last fp16 network pass
     const half_t *da_cur = nullptr;    // convDa.3 output of the last fp16 network pass
     int opt_branches = 0;              // sfd2_set_option "branches": detector branch on a second stream beside the descriptor branch
     hipStream_t side_stream = nullptr; // the detector branch (convPa.0 -> convPa.3 -> convPb -> detector_head)
@@ -753,6 +756,9 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
             pa0_o = slot(1); pa_o = slot(1, (P8s * 256 * 2 + 255) & ~(size_t)255);
             da0_o = slot(2); da_o = slot(1);   // convDa.3 runs after convPb has consumed slot 1
             if (c->opt_branches) da_o = slot(3);   // the two head branches run concurrently: no slot is shared between them
+            // convPb fused into the detector-head kernel: convPa.3's output must outlive the network pass, so convDa.3
+            // writes over the backbone output instead (slot 0) -- ConvSta, its last reader, then runs before the heads
+            if (c->skip_pb_now) da_o = slot(0);
         }
     }
     if (c->fuse_now) {
@@ -807,6 +813,11 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     // inside a captured hipGraph this becomes a fork in the graph).  Measured (tools/ab_branches.py, interleaved A/B at
     // 1600x1200): 1.260 -> 1.238 ms per extract (-1.7 %), outputs bit-identical.  Off by default: overlapped launches
     // stretch each other's event-timed durations, and bench.py's per-kernel roofline wants uncontended ones.
+    const bool sta_early = alias && c->skip_pb_now;
+    if (c->has_sta && sta_early) {
+        ProfScope ps(c, "ConvSta", "convsta_kernel", 2.0 * P4 * 3 * 256, P4 * (512 + 12));
+        launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
+    }
     const bool fork = c->opt_branches != 0;
     if (fork) {
         HIPCHECK(hipEventRecord(c->ev_fork, st));
@@ -815,7 +826,8 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     }
     conv(c, "convPa.0", c->pa0, *x, H4, W4, pa0_o, H8, W8, 1);
     conv(c, "convPa.3", c->pa3, pa0_o, H8, W8, pa_o, H8, W8, 0);
-    conv(c, "convPb", c->pb, pa_o, H8, W8, c->logits, H8, W8, 0, nullptr, 1);
+    c->pa_cur = pa_o.as<half_t>();
+    if (!c->skip_pb_now) conv(c, "convPb", c->pb, pa_o, H8, W8, c->logits, H8, W8, 0, nullptr, 1);
     if (!c->skip_head_now) {
         ProfScope ps(c, "detector_head", "detector_head_kernel", 0.0, P8 * (65 * 4 + 256));
         launch_detector_head(c->cur_stream, c->logits.as<float>(), 128, H8, W8, c->score.as<float>());
@@ -828,7 +840,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     conv(c, "convDa.3", c->da3, da0_o, H4, W4, da_o, H4, W4, 0);
     c->da_cur = da_o.as<half_t>();
     if (!c->skip_db_now) conv(c, "convDb", c->db, da_o, H4, W4, c->draw, H4, W4, 0, nullptr, 1);
-    if (c->has_sta) {
+    if (c->has_sta && !sta_early) {
         ProfScope ps(c, "ConvSta", "convsta_kernel", 2.0 * P4 * 3 * 256, P4 * (512 + 12));
         launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
     }
@@ -979,6 +991,8 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     // stability weighting run as ONE kernel that writes the heat map directly; the score map is never materialised
     const bool fuse_post = c->opt_fuse_post && H % 8 == 0 && W % 8 == 0;
     c->skip_head_now = fuse_post ? 1 : 0;
+    const bool fuse_pb = fuse_post && c->opt_fuse_pb && c->fuse_now && !c->opt_branches && c->pb.cout_pad >= 96;
+    c->skip_pb_now = fuse_pb ? 1 : 0;
     // Sparse descriptor head: convDb is 1x1 and only the bilinear corners of the selected key points are sampled, so on the
     // throughput path it runs after the selection, on 4 x K gathered pixels instead of the whole 1/4-resolution map (the
     // 61 MB fp32 descriptor map is never written; bit-identical descriptors).  Dense when more than a quarter of the map
@@ -989,11 +1003,18 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     const int net_rc = run_network(c, img_dev, in_mode);
     c->skip_head_now = 0;
     c->skip_db_now = 0;
+    c->skip_pb_now = 0;
     if (net_rc) return -1;
     if (release_image_slot(c)) return -1;
     HIPCHECK(hipEventRecord(c->ev[1], c->stream));
     const int HS = 8 * c->H8, WS = 8 * c->W8;
-    if (fuse_post) {
+    if (fuse_pb) {
+        ProfScope ps(c, "convPb+heads+heatmap", "pb_heads_heat_kernel", 2.0 * c->H8 * c->W8 * 65 * 256,
+                     (double)c->H8 * c->W8 * 512 + (double)H * W * 4);
+        launch_pb_heads_heat(c->stream, c->pa_cur, c->H8, c->W8, c->pb.w.as<half_t>(), c->pb.cout_pad, c->pb.scale.as<float>(),
+                             c->pb.shift.as<float>(), (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(), c->H4, c->W4,
+                             H, W, c->heat.as<float>());
+    } else if (fuse_post) {
         ProfScope ps(c, "heads+heatmap", "heads_heat_kernel", 0.0, (double)c->H8 * c->W8 * 65 * 4 + (double)H * W * 4);
         launch_heads_heat(c->stream, c->logits.as<float>(), 128, c->H8, c->W8,
                           (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(), c->H4, c->W4, H, W, c->heat.as<float>());
@@ -1999,6 +2020,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "branches") c->opt_branches = value ? 1 : 0;
     else if (k == "fuse_post") c->opt_fuse_post = value ? 1 : 0;
     else if (k == "sparse_desc") c->opt_sparse_desc = value ? 1 : 0;
+    else if (k == "fuse_pb") c->opt_fuse_pb = value ? 1 : 0;
     else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;
 }

@@ -124,6 +124,8 @@ void launch_sample_desc(hipStream_t st, const float *desc_nhwc, int hc, int wc, 
                         const float *kpts_xy, const unsigned int *count /*device, may be null*/, int n_max,
                         float *out);
 // sparse descriptor head (extract path): gather the key points' bilinear corner pixels, convDb on them, sample -- one kernel
+void launch_pb_heads_heat(hipStream_t st, const half_t *fmap, int hc8, int wc8, const half_t *wpk, int CoutP, const float *scale,
+                          const float *shift, const float *sta, int hc, int wc, int H, int W, float *heat);
 void launch_desc_head(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, int CoutP,
                       const float *scale, const float *shift, const float *kpts, const unsigned int *count, int n_max, float *out);
 // desc_raw NHWC [P][128] -> normalised NCHW [128][P]

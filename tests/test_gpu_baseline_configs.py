@@ -545,3 +545,25 @@ def test_sparse_descriptor_head_bit_identical(synth_sd, h, w, topk):
     np.testing.assert_array_equal(a["scores"], b["scores"])
     np.testing.assert_array_equal(a["descriptors"], b["descriptors"])
     assert np.isfinite(a["descriptors"]).all() and len(a["keypoints"]) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,topk", [(480, 640, 1024), (1200, 1600, 4096), (256, 264, 300)])
+def test_fused_convpb_head_bit_identical(synth_sd, h, w, topk):
+    """Option "fuse_pb" (convPb inside the detector-head / heat-map kernel, ConvSta moved ahead of the heads, convDa.3 into
+    the backbone output's arena slot) against the separate convPb launch: identical key points, scores, descriptors."""
+    from sfd2_amd.model import ResSegNetV2
+    from sfd2_amd.extractor import extract_resnet_return
+    outs = []
+    for fuse in (1, 0):
+        m = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval()
+        m.load_state_dict(synth_sd)
+        m.cuda(0)
+        m.context.set_option("fuse_pb", fuse)
+        img = synth.make_image(h, w, 78)
+        outs.append(extract_resnet_return(m, img[None], conf_th=0.001, topK=topk, scales=[1.0]))
+    a, b = outs
+    np.testing.assert_array_equal(a["keypoints"], b["keypoints"])
+    np.testing.assert_array_equal(a["scores"], b["scores"])
+    np.testing.assert_array_equal(a["descriptors"], b["descriptors"])
+    assert len(a["keypoints"]) > 0
