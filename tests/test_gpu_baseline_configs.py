@@ -567,3 +567,29 @@ def test_fused_convpb_head_bit_identical(synth_sd, h, w, topk):
     np.testing.assert_array_equal(a["scores"], b["scores"])
     np.testing.assert_array_equal(a["descriptors"], b["descriptors"])
     assert len(a["keypoints"]) > 0
+
+
+@pytest.mark.gpu
+def test_fused_heads_edge_cases(synth_sd):
+    """The fused heads on inputs that leave them (almost) nothing to do: a constant image (no or few key points, count <
+    top_k), the smallest image (8 x 8), top_k far above the candidate count, and top_k <= 0 (dense descriptor map path):
+    same results as with both fusions switched off, no NaNs."""
+    from sfd2_amd.model import ResSegNetV2
+    from sfd2_amd.extractor import extract_resnet_return
+    models = []
+    for on in (1, 0):
+        m = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval()
+        m.load_state_dict(synth_sd)
+        m.cuda(0)
+        m.context.set_option("sparse_desc", on)
+        m.context.set_option("fuse_pb", on)
+        models.append(m)
+    cases = [(np.full((3, 64, 96), 0.5, np.float32), 500), (synth.make_image(8, 8, 3), 100), (synth.make_image(40, 48, 4), 100000),
+             (synth.make_image(64, 64, 5), -1), (np.zeros((3, 32, 40), np.float32), 50)]
+    for img, topk in cases:
+        a, b = [extract_resnet_return(m, img[None], conf_th=0.001, topK=topk, scales=[1.0]) for m in models]
+        assert len(a["keypoints"]) == len(b["keypoints"]), (img.shape, topk)
+        np.testing.assert_array_equal(a["keypoints"], b["keypoints"])
+        np.testing.assert_array_equal(a["scores"], b["scores"])
+        np.testing.assert_array_equal(a["descriptors"], b["descriptors"])
+        assert np.isfinite(a["descriptors"]).all()
