@@ -454,6 +454,129 @@ void launch_conv_igemm_x3(hipStream_t st, const float *in, int H, int W, int Cin
 }
 
 // ---------------------------------------------------------------------------------------------
+// ResBlock.conv2 (3x3, groups = 32) in the f16x3 mode: gconv3x3_g8_kernel's layout (two groups per 16x16x32 MFMA with
+// block-diagonal filter fragments, 5 k steps for the 9 taps) on fp32 activations, three passes as conv_igemm_x3_kernel.
+// The 64-channel patch chunk is split into hi / lo planes while it is staged; the filter fragments are pre-split
+// (gconv_x3_pack_kernel, once per context): [16 pairs][5 steps][64 lanes][8 hi | 8 lo].
+#define GX_P 72   // halves per pixel record of one plane: 64 + 8 pad
+#define GX_PH 6
+#define GX_PW 34
+__global__ __launch_bounds__(NT)
+void gconv_x3_pack_kernel(const float *__restrict__ w /*[256][8][3][3]*/, half_t *__restrict__ out)
+{
+    const int idx = blockIdx.x * NT + threadIdx.x;          // (pair * 5 + s) * 64 + lane
+    if (idx >= 16 * 5 * 64) return;
+    const int lane = idx & 63, s5 = (idx >> 6) % 5, pair = idx / (5 * 64);
+    const int i = lane & 15, g = lane >> 4;
+    const int tap = 2 * s5 + (g >> 1), oc = pair * 16 + i;
+    const bool live = tap <= 8 && (i >> 3) == (g & 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = live ? w[((size_t)oc * 8 + j) * 9 + tap] : 0.0f;
+        const half_t hi = (half_t)v;
+        out[(size_t)idx * 16 + j] = hi;
+        out[(size_t)idx * 16 + 8 + j] = (half_t)((v - (float)hi) * X3_SCALE);
+    }
+}
+
+void launch_gconv_x3_pack(hipStream_t st, const float *w, void *out)
+{
+    hipLaunchKernelGGL(gconv_x3_pack_kernel, dim3((16 * 5 * 64 + NT - 1) / NT), dim3(NT), 0, st, w, reinterpret_cast<half_t *>(out));
+}
+
+__global__ __launch_bounds__(NT)
+void gconv_x3_kernel(const float *__restrict__ in, int H, int W, const half_t *__restrict__ wpk,
+                     const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out, int tiles_x)
+{
+    constexpr int NPIX = GX_PH * GX_PW;
+    __shared__ __attribute__((aligned(16))) half_t Xh[NPIX * GX_P];
+    __shared__ __attribute__((aligned(16))) half_t Xl[NPIX * GX_P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int swz = xcd_swizzle_f(blockIdx.x, gridDim.x);
+    const int tx = swz % tiles_x, ty = swz / tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int g = lane >> 4, lcol = lane & 15;
+
+    constexpr int NLD = (NPIX * 16 + NT - 1) / NT;   // float4 pieces per thread per 64-channel chunk (13)
+    float4 pre[NLD];
+#define GX_FETCH(chunk_)                                                                                  \
+    _Pragma("unroll") for (int k = 0; k < NLD; ++k) {                                                     \
+        const int p = tid + k * NT;                                                                       \
+        const int q = p >> 4, part = p & 15;                                                              \
+        const int py = q / GX_PW, px = q - py * GX_PW;                                                    \
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;                                                   \
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+        if (p < NPIX * 16 && iy >= 0 && iy < H && ix >= 0 && ix < W)                                      \
+            v = *reinterpret_cast<const float4 *>(in + ((size_t)(iy * W + ix) * 256 + (chunk_)*64 + part * 4)); \
+        pre[k] = v;                                                                                       \
+    }
+    GX_FETCH(0)
+    for (int chunk = 0; chunk < 4; ++chunk) {
+        if (chunk) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done reading the planes
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int p = tid + k * NT;
+            if (p < NPIX * 16) {
+                h4_t hi, lo;
+                x3_split(pre[k], hi, lo);
+                *reinterpret_cast<h4_t *>(Xh + (p >> 4) * GX_P + (p & 15) * 4) = hi;
+                *reinterpret_cast<h4_t *>(Xl + (p >> 4) * GX_P + (p & 15) * 4) = lo;
+            }
+        }
+        const int pair = chunk * 4 + wave;
+        h8_t wh[5], wl[5];
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            const half_t *wp = wpk + ((size_t)(pair * 5 + s5) * 64 + lane) * 16;
+            wh[s5] = *reinterpret_cast<const h8_t *>(wp);
+            wl[s5] = *reinterpret_cast<const h8_t *>(wp + 8);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");               // planes of this chunk complete
+        if (chunk + 1 < 4) { GX_FETCH(chunk + 1) }
+
+        f32x4_t accm[8], accl[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { accm[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; accl[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            int tap = 2 * s5 + (g >> 1);
+            if (tap > 8) tap = 8;  // zero-weight slot: read any valid location
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int q = ((t >> 1) + ky) * GX_PW + (t & 1) * 16 + lcol + kx;
+                const h8_t bh = *reinterpret_cast<const h8_t *>(Xh + q * GX_P + wave * 16 + (g & 1) * 8);
+                const h8_t bl = *reinterpret_cast<const h8_t *>(Xl + q * GX_P + wave * 16 + (g & 1) * 8);
+                accm[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s5], bh, accm[t], 0, 0, 0);
+                accl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s5], bl, accl[t], 0, 0, 0);
+                accl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s5], bh, accl[t], 0, 0, 0);
+            }
+        }
+        const int c0 = pair * 16 + g * 4;
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c0);
+        const float4 sh = *reinterpret_cast<const float4 *>(shift + c0);
+        constexpr float inv = 1.0f / X3_SCALE;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int oy = oy0 + (t >> 1), ox = ox0 + (t & 1) * 16 + lcol;
+            if (oy < H && ox < W)
+                *reinterpret_cast<float4 *>(out + ((size_t)oy * W + ox) * 256 + c0) =
+                    make_float4(fmaxf((accm[t][0] + accl[t][0] * inv) * sc.x + sh.x, 0.0f), fmaxf((accm[t][1] + accl[t][1] * inv) * sc.y + sh.y, 0.0f),
+                                fmaxf((accm[t][2] + accl[t][2] * inv) * sc.z + sh.z, 0.0f), fmaxf((accm[t][3] + accl[t][3] * inv) * sc.w + sh.w, 0.0f));
+        }
+    }
+#undef GX_FETCH
+}
+
+void launch_gconv_x3(hipStream_t st, const float *in, int H, int W, const void *wpk, const float *scale, const float *shift,
+                     float *out)
+{
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    hipLaunchKernelGGL(gconv_x3_kernel, dim3(tiles_x * tiles_y), dim3(NT), 0, st, in, H, W, reinterpret_cast<const half_t *>(wpk),
+                       scale, shift, out, tiles_x);
+}
+
+// ---------------------------------------------------------------------------------------------
 // conv1a (3 -> 64, 3x3) + norm_RGB + BN + ReLU, fp32 VALU, accumulation order (c, ky, kx) as the
 // reference's direct convolution.  One thread = one pixel, 64 output channels in 4 passes of 16.
 __global__ __launch_bounds__(NT)

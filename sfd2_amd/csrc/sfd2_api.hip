@@ -694,9 +694,19 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
     for (int b = 0; b < 3; ++b) {
         convf(c, nm1[b], c->frb1[b], *x, H4, W4, c->grt1[b], H4, W4, 1);
         {
-            ProfScope ps(c, nm2[b], "gconv_f32_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 8);
-            launch_gconv_f32(st, c->grt1[b].as<float>(), H4, W4, c->frb2[b].w.as<float>(), c->frb2[b].scale.as<float>(),
-                             c->frb2[b].shift.as<float>(), c->grt2[b].as<float>());
+            if (c->precision == SFD2_PREC_F16X3) {
+                if (!c->frb2[b].wx3.p) {
+                    HIPCHECK(c->frb2[b].wx3.ensure((size_t)16 * 5 * 64 * 16 * sizeof(half_t)));
+                    launch_gconv_x3_pack(st, c->frb2[b].w.as<float>(), c->frb2[b].wx3.p);
+                }
+                ProfScope ps(c, nm2[b], "gconv_x3_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 8);
+                launch_gconv_x3(st, c->grt1[b].as<float>(), H4, W4, c->frb2[b].wx3.p, c->frb2[b].scale.as<float>(),
+                                c->frb2[b].shift.as<float>(), c->grt2[b].as<float>());
+            } else {
+                ProfScope ps(c, nm2[b], "gconv_f32_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 8);
+                launch_gconv_f32(st, c->grt1[b].as<float>(), H4, W4, c->frb2[b].w.as<float>(), c->frb2[b].scale.as<float>(),
+                                 c->frb2[b].shift.as<float>(), c->grt2[b].as<float>());
+            }
         }
         convf(c, nm3[b], c->frb3[b], c->grt2[b], H4, W4, c->gro[b], H4, W4, 1, x->as<float>());
         x = &c->gro[b];

@@ -80,6 +80,8 @@ void launch_conv_igemm_f32(hipStream_t st, const float *in, int H, int W, int Ci
                            const float *residual, float *out, int Ho, int Wo);
 // the same signature on the fp16 matrix path in three passes (SFD2_PREC_F16X3); wpk = the filters after launch_x3_split
 void launch_x3_split(hipStream_t st, const float *w, size_t n_floats, void *out);
+void launch_gconv_x3_pack(hipStream_t st, const float *w /*[256][8][3][3]*/, void *out /*16 * 5 * 64 * 16 halves*/);
+void launch_gconv_x3(hipStream_t st, const float *in, int H, int W, const void *wpk, const float *scale, const float *shift, float *out);
 void launch_conv_igemm_x3(hipStream_t st, const float *in, int H, int W, int Cin, const float *wpk,
                            const float *scale, const float *shift, int Cout_pad, int ks, int stride, int relu,
                            const float *residual, float *out, int Ho, int Wo);
