@@ -49,8 +49,9 @@ void conv_igemm_f32_kernel(const float *__restrict__ in, int H, int W, int Cin,
     constexpr int PX_T = TH / WAVES_PX;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *Xs = reinterpret_cast<float *>(smem);       // [NPIX][PIXF]
-    float *Ws = Xs + NPIX * PIXF;                      // [2][BN][PIXF]
+    constexpr int XB = (KS == 1) ? 2 : 1;              // 1x1: the patch is double-buffered and prefetched like the filters
+    float *Xs = reinterpret_cast<float *>(smem);       // [XB][NPIX][PIXF]
+    float *Ws = Xs + XB * NPIX * PIXF;                 // [2][BN][PIXF]
     float *SS = Ws + 2 * BN * PIXF;                    // scale[BN], shift[BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,6 +77,25 @@ void conv_igemm_f32_kernel(const float *__restrict__ in, int H, int W, int Cin,
         if (iy >= 0 && iy < H && ix >= 0 && ix < W)                                                    \
             v = *reinterpret_cast<const float4 *>(in + ((size_t)(iy * W + ix) * Cin + (chunk_)*CC + part * 4)); \
         *reinterpret_cast<float4 *>(Xs + q * PIXF + part * 4) = v;                                     \
+    }
+    // 1x1 layers: every step is a new chunk; the next chunk's pieces are fetched into registers before the MFMAs and stored
+    // after them into the other buffer (one barrier per step, no exposed global-load latency; see conv_igemm_x3_kernel)
+    constexpr int XP = (KS == 1) ? (XPIECES + NT - 1) / NT : 1;
+    float4 xr[XP];
+#define LOAD_X(chunk_)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                   \
+        const int p = tid + i * NT, q = p >> 3, part = p & 7;                                          \
+        const int py = q / PW, px = q - py * PW;                                                       \
+        const int iy = oy0 + py, ix = ox0 + px;                                                        \
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+        if (p < XPIECES && iy < H && ix < W)                                                           \
+            v = *reinterpret_cast<const float4 *>(in + ((size_t)(iy * W + ix) * Cin + (chunk_)*CC + part * 4)); \
+        xr[i] = v;                                                                                     \
+    }
+#define STORE_X(buf_)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                   \
+        const int p = tid + i * NT, q = p >> 3, part = p & 7;                                          \
+        if (p < XPIECES) *reinterpret_cast<float4 *>(Xs + ((buf_)*NPIX + q) * PIXF + part * 4) = xr[i]; \
     }
 #define LOAD_W(step_)                                                                                  \
     {                                                                                                  \
@@ -113,6 +133,7 @@ void conv_igemm_f32_kernel(const float *__restrict__ in, int H, int W, int Cin,
         const bool has_next = (s + 1 < NS);
         const bool new_chunk = has_next && (ntap == 0);
         if (has_next) LOAD_W(s + 1)
+        if (KS == 1 && has_next) { LOAD_X(s + 1) }
 
         const int ky = tap / KS, kx = tap - ky * KS;
         const float *ws = Ws + wb * BN * PIXF;
@@ -125,7 +146,7 @@ void conv_igemm_f32_kernel(const float *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
             for (int pr = 0; pr < PX_T; ++pr) {
                 const int q = ((wrow + pr) * STRIDE + ky) * PW + lrow * STRIDE + kx;
-                b[pr] = *reinterpret_cast<const float4 *>(Xs + q * PIXF + kb * 8 + lk);
+                b[pr] = *reinterpret_cast<const float4 *>(Xs + ((KS == 1 ? (s & 1) * NPIX : 0) + q) * PIXF + kb * 8 + lk);
             }
 #pragma unroll
             for (int ct = 0; ct < CH_T; ++ct)
@@ -138,8 +159,9 @@ void conv_igemm_f32_kernel(const float *__restrict__ in, int H, int W, int Cin,
                 }
         }
         if (has_next) { STORE_W(wb ^ 1) }
+        if (KS == 1 && has_next) { STORE_X((s + 1) & 1) }
         __syncthreads();
-        if (new_chunk) {          // every wave is past its reads of the patch: re-stage it
+        if (KS != 1 && new_chunk) {          // every wave is past its reads of the patch: re-stage it
             STAGE_X(nchunk)
             __syncthreads();
         }
@@ -147,6 +169,8 @@ void conv_igemm_f32_kernel(const float *__restrict__ in, int H, int W, int Cin,
         chunk = nchunk;
     }
 #undef STAGE_X
+#undef LOAD_X
+#undef STORE_X
 #undef LOAD_W
 #undef STORE_W
 
@@ -185,7 +209,7 @@ static void launch_f32_t(hipStream_t st, const float *in, int H, int W, int Cin,
                          const float *shift, int CoutP, int relu, const float *res, float *out, int Ho, int Wo)
 {
     constexpr int PH = (TH - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
-    constexpr size_t lds = (size_t)(PH * PW + 2 * BN) * PIXF * sizeof(float) + (size_t)2 * BN * sizeof(float);
+    constexpr size_t lds = (size_t)((KS == 1 ? 2 : 1) * PH * PW + 2 * BN) * PIXF * sizeof(float) + (size_t)2 * BN * sizeof(float);
     static bool attr_done = false;
     auto kern = conv_igemm_f32_kernel<KS, STRIDE, BN, HAS_RES>;
     if (!attr_done) {
@@ -256,9 +280,10 @@ void conv_igemm_x3_kernel(const float *__restrict__ in, int H, int W, int Cin,
     constexpr int PX_T = TH / WAVES_PX;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    half_t *Xh = reinterpret_cast<half_t *>(smem);     // [NPIX][PIXH]
-    half_t *Xl = Xh + NPIX * PIXH;
-    half_t *Wh = Xl + NPIX * PIXH;                     // [2][BN][PIXH]
+    constexpr int XB = (KS == 1) ? 2 : 1;              // 1x1: the patch is double-buffered and prefetched like the filters
+    half_t *Xh = reinterpret_cast<half_t *>(smem);     // [XB][NPIX][PIXH]
+    half_t *Xl = Xh + XB * NPIX * PIXH;
+    half_t *Wh = Xl + XB * NPIX * PIXH;                // [2][BN][PIXH]
     half_t *Wl = Wh + 2 * BN * PIXH;
     float *SS = reinterpret_cast<float *>(Wl + 2 * BN * PIXH);   // scale[BN], shift[BN]
 
@@ -288,6 +313,31 @@ void conv_igemm_x3_kernel(const float *__restrict__ in, int H, int W, int Cin,
         x3_split(v, hi, lo);                                                                           \
         *reinterpret_cast<h4_t *>(Xh + q * PIXH + part * 4) = hi;                                      \
         *reinterpret_cast<h4_t *>(Xl + q * PIXH + part * 4) = lo;                                      \
+    }
+    // 1x1 layers: every step is a new 32-channel chunk.  Re-staging the patch between two barriers after the MFMAs (as the
+    // 3x3 layers do once per nine taps) exposes a global-load latency per step; here the next chunk's pieces are fetched
+    // into registers before the MFMAs and split / stored after them, into the other buffer: one barrier per step.
+    constexpr int XP = (KS == 1) ? (XPIECES + NT - 1) / NT : 1;
+    float4 xr[XP];
+#define X3_LOAD_X(chunk_)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                   \
+        const int p = tid + i * NT, q = p >> 3, part = p & 7;                                          \
+        const int py = q / PW, px = q - py * PW;                                                       \
+        const int iy = oy0 + py, ix = ox0 + px;                                                        \
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+        if (p < XPIECES && iy < H && ix < W)                                                           \
+            v = *reinterpret_cast<const float4 *>(in + ((size_t)(iy * W + ix) * Cin + (chunk_)*CC + part * 4)); \
+        xr[i] = v;                                                                                     \
+    }
+#define X3_STORE_X(buf_)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                   \
+        const int p = tid + i * NT, q = p >> 3, part = p & 7;                                          \
+        if (p < XPIECES) {                                                                             \
+            h4_t hi, lo;                                                                               \
+            x3_split(xr[i], hi, lo);                                                                   \
+            *reinterpret_cast<h4_t *>(Xh + ((buf_)*NPIX + q) * PIXH + part * 4) = hi;                  \
+            *reinterpret_cast<h4_t *>(Xl + ((buf_)*NPIX + q) * PIXH + part * 4) = lo;                  \
+        }                                                                                              \
     }
 #define X3_LOAD_W(step_)                                                                               \
     {                                                                                                  \
@@ -327,6 +377,7 @@ void conv_igemm_x3_kernel(const float *__restrict__ in, int H, int W, int Cin,
         const bool has_next = (s + 1 < NS);
         const bool new_chunk = has_next && (ntap == 0);
         if (has_next) X3_LOAD_W(s + 1)
+        if (KS == 1 && has_next) { X3_LOAD_X(s + 1) }
 
         const int ky = tap / KS, kx = tap - ky * KS;
         const half_t *wh = Wh + wb * BN * PIXH, *wl = Wl + wb * BN * PIXH;
@@ -342,8 +393,9 @@ void conv_igemm_x3_kernel(const float *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
             for (int pr = 0; pr < PX_T; ++pr) {
                 const int q = ((wrow + pr) * STRIDE + ky) * PW + lrow * STRIDE + kx;
-                bh[pr] = *reinterpret_cast<const h8_t *>(Xh + q * PIXH + kb * 16 + lk);
-                bl[pr] = *reinterpret_cast<const h8_t *>(Xl + q * PIXH + kb * 16 + lk);
+                const int xq = (KS == 1 ? (s & 1) * NPIX : 0) + q;
+                bh[pr] = *reinterpret_cast<const h8_t *>(Xh + xq * PIXH + kb * 16 + lk);
+                bl[pr] = *reinterpret_cast<const h8_t *>(Xl + xq * PIXH + kb * 16 + lk);
             }
 #pragma unroll
             for (int ct = 0; ct < CH_T; ++ct)
@@ -355,8 +407,9 @@ void conv_igemm_x3_kernel(const float *__restrict__ in, int H, int W, int Cin,
                 }
         }
         if (has_next) { X3_STORE_W(wb ^ 1) }
+        if (KS == 1 && has_next) { X3_STORE_X((s + 1) & 1) }
         __syncthreads();
-        if (new_chunk) {          // every wave is past its reads of the patch: re-stage it
+        if (KS != 1 && new_chunk) {          // every wave is past its reads of the patch: re-stage it
             X3_STAGE_X(nchunk)
             __syncthreads();
         }
@@ -364,6 +417,8 @@ void conv_igemm_x3_kernel(const float *__restrict__ in, int H, int W, int Cin,
         chunk = nchunk;
     }
 #undef X3_STAGE_X
+#undef X3_LOAD_X
+#undef X3_STORE_X
 #undef X3_LOAD_W
 #undef X3_STORE_W
 
@@ -424,7 +479,7 @@ static void launch_x3_t(hipStream_t st, const float *in, int H, int W, int Cin, 
                         const float *shift, int CoutP, int relu, const float *res, float *out, int Ho, int Wo)
 {
     constexpr int PH = (TH - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
-    constexpr size_t lds = (size_t)(PH * PW + 2 * BN) * PIXH * sizeof(half_t) * 2 + (size_t)2 * BN * sizeof(float);
+    constexpr size_t lds = (size_t)((KS == 1 ? 2 : 1) * PH * PW + 2 * BN) * PIXH * sizeof(half_t) * 2 + (size_t)2 * BN * sizeof(float);
     static bool attr_done = false;
     auto kern = conv_igemm_x3_kernel<KS, STRIDE, BN, HAS_RES>;
     if (!attr_done) {
