@@ -80,15 +80,15 @@ void conv_igemm_f32_kernel(const float *__restrict__ in, int H, int W, int Cin,
     }
     // 1x1 layers: every step is a new chunk; the next chunk's pieces are fetched into registers before the MFMAs and stored
     // after them into the other buffer (one barrier per step, no exposed global-load latency; see conv_igemm_x3_kernel)
-    constexpr int XP = (KS == 1) ? (XPIECES + NT - 1) / NT : 1;
+    constexpr int XP = (XPIECES + NT - 1) / NT;
     float4 xr[XP];
 #define LOAD_X(chunk_)                                                                                 \
     _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                   \
         const int p = tid + i * NT, q = p >> 3, part = p & 7;                                          \
         const int py = q / PW, px = q - py * PW;                                                       \
-        const int iy = oy0 + py, ix = ox0 + px;                                                        \
+        const int iy = oy0 * STRIDE - PAD + py, ix = ox0 * STRIDE - PAD + px;                          \
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
-        if (p < XPIECES && iy < H && ix < W)                                                           \
+        if (p < XPIECES && iy >= 0 && iy < H && ix >= 0 && ix < W)                                     \
             v = *reinterpret_cast<const float4 *>(in + ((size_t)(iy * W + ix) * Cin + (chunk_)*CC + part * 4)); \
         xr[i] = v;                                                                                     \
     }
@@ -133,7 +133,7 @@ void conv_igemm_f32_kernel(const float *__restrict__ in, int H, int W, int Cin,
         const bool has_next = (s + 1 < NS);
         const bool new_chunk = has_next && (ntap == 0);
         if (has_next) LOAD_W(s + 1)
-        if (KS == 1 && has_next) { LOAD_X(s + 1) }
+        if ((KS == 1 && has_next) || new_chunk) { LOAD_X(nchunk) }   // 1x1: every step; 3x3: at a chunk's last tap
 
         const int ky = tap / KS, kx = tap - ky * KS;
         const float *ws = Ws + wb * BN * PIXF;
@@ -161,8 +161,8 @@ void conv_igemm_f32_kernel(const float *__restrict__ in, int H, int W, int Cin,
         if (has_next) { STORE_W(wb ^ 1) }
         if (KS == 1 && has_next) { STORE_X((s + 1) & 1) }
         __syncthreads();
-        if (KS != 1 && new_chunk) {          // every wave is past its reads of the patch: re-stage it
-            STAGE_X(nchunk)
+        if (KS != 1 && new_chunk) {          // every wave is past its reads of the (single) patch buffer: store the prefetched chunk
+            STORE_X(0)
             __syncthreads();
         }
         tap = ntap;
@@ -317,15 +317,15 @@ void conv_igemm_x3_kernel(const float *__restrict__ in, int H, int W, int Cin,
     // 1x1 layers: every step is a new 32-channel chunk.  Re-staging the patch between two barriers after the MFMAs (as the
     // 3x3 layers do once per nine taps) exposes a global-load latency per step; here the next chunk's pieces are fetched
     // into registers before the MFMAs and split / stored after them, into the other buffer: one barrier per step.
-    constexpr int XP = (KS == 1) ? (XPIECES + NT - 1) / NT : 1;
+    constexpr int XP = (XPIECES + NT - 1) / NT;
     float4 xr[XP];
 #define X3_LOAD_X(chunk_)                                                                              \
     _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                   \
         const int p = tid + i * NT, q = p >> 3, part = p & 7;                                          \
         const int py = q / PW, px = q - py * PW;                                                       \
-        const int iy = oy0 + py, ix = ox0 + px;                                                        \
+        const int iy = oy0 * STRIDE - PAD + py, ix = ox0 * STRIDE - PAD + px;                          \
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
-        if (p < XPIECES && iy < H && ix < W)                                                           \
+        if (p < XPIECES && iy >= 0 && iy < H && ix >= 0 && ix < W)                                     \
             v = *reinterpret_cast<const float4 *>(in + ((size_t)(iy * W + ix) * Cin + (chunk_)*CC + part * 4)); \
         xr[i] = v;                                                                                     \
     }
@@ -377,7 +377,8 @@ void conv_igemm_x3_kernel(const float *__restrict__ in, int H, int W, int Cin,
         const bool has_next = (s + 1 < NS);
         const bool new_chunk = has_next && (ntap == 0);
         if (has_next) X3_LOAD_W(s + 1)
-        if (KS == 1 && has_next) { X3_LOAD_X(s + 1) }
+        // next patch chunk -> registers, ahead of this step's MFMAs (1x1: every step; 3x3: at a chunk's last tap)
+        if ((KS == 1 && has_next) || new_chunk) { X3_LOAD_X(nchunk) }
 
         const int ky = tap / KS, kx = tap - ky * KS;
         const half_t *wh = Wh + wb * BN * PIXH, *wl = Wl + wb * BN * PIXH;
@@ -409,8 +410,8 @@ void conv_igemm_x3_kernel(const float *__restrict__ in, int H, int W, int Cin,
         if (has_next) { X3_STORE_W(wb ^ 1) }
         if (KS == 1 && has_next) { X3_STORE_X((s + 1) & 1) }
         __syncthreads();
-        if (KS != 1 && new_chunk) {          // every wave is past its reads of the patch: re-stage it
-            X3_STAGE_X(nchunk)
+        if (KS != 1 && new_chunk) {          // every wave is past its reads of the (single) patch buffer: split + store the prefetched chunk
+            X3_STORE_X(0)
             __syncthreads();
         }
         tap = ntap;
