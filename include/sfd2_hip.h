@@ -94,7 +94,7 @@ int sfd2_load_weights(sfd2_ctx *ctx, const sfd2_tensor *tensors, int n);
  * fp32 activations -- the parity mode (differs from the fp32 reference by summation order only).
  * SFD2_PREC_F16X3: the parity mode's buffers, filters and layer sequence with the 3x3 / 1x1 convolutions on the fp16
  * matrix path in three passes (operands split into hi + lo fp16 while they are staged; ~2^-22 per product against
- * fp32's 2^-24, fp32 accumulation) -- descriptors within 2e-5 of the reference like SFD2_PREC_F32, ~2x its speed. */
+ * fp32's 2^-24, fp32 accumulation) -- descriptors within 2e-5 of the reference like SFD2_PREC_F32, ~1.9x its speed. */
 #define SFD2_PREC_F16 0
 #define SFD2_PREC_F32 1
 #define SFD2_PREC_F16X3 2

@@ -32,7 +32,7 @@ class ResSegNetV2:
         descriptors within 3e-3 (measured 1.8e-3), key-point set IoU >= 0.95 on the synthetic weights
         (profiles/r02_error_budget.txt); ask for it explicitly.  'f16x3' = the strict mode's buffers and layer sequence with
         the 3x3 / 1x1 convolutions on the fp16 matrix path in three hi / lo passes (~2^-22 per product, fp32 accumulation):
-        the strict mode's tolerances hold (tests/test_gpu_baseline_configs.py::test_f16x3_*), 1.4x its speed."""
+        the strict mode's tolerances hold (tests/test_gpu_baseline_configs.py::test_f16x3_*), 1.9x its speed."""
         if precision not in ("f16", "f32", "f16x3"):
             raise ValueError("precision must be 'f16', 'f32' or 'f16x3'")
         self.precision = precision
