@@ -593,3 +593,41 @@ def test_fused_heads_edge_cases(synth_sd):
         np.testing.assert_array_equal(a["scores"], b["scores"])
         np.testing.assert_array_equal(a["descriptors"], b["descriptors"])
         assert np.isfinite(a["descriptors"]).all()
+
+
+@pytest.mark.gpu
+def test_hipgraph_cache_landscape_portrait_mix(synth_sd):
+    """a stream that mixes landscape and portrait images keeps one cached hipGraph per geometry.  Alternating
+    480x640 / 640x480 (and changing K between rounds) through sfd2_extract_match with option "graphs": every call equals
+    the eager result of a context without the option, bit for bit."""
+    import torch
+    from sfd2_amd.model import ResSegNetV2
+    ms_ = []
+    for graphs in (0, 1):
+        m = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval()
+        m.load_state_dict(synth_sd)
+        m.cuda(0)
+        m.context.set_option("graphs", graphs)
+        ms_.append(m)
+    K, N = 1024, 1024
+    imgs = {(480, 640): torch.from_numpy(synth.make_image(480, 640, 91)).cuda(), (640, 480): torch.from_numpy(synth.make_image(640, 480, 92)).cuda()}
+    db = [torch.from_numpy(synth.make_descriptors(N, seed=95 + i)).to(torch.float16).cuda().contiguous() for i in range(5)]
+    mconf = _lib.MatchConf(_lib.MATCH_HLOC, 1, 0.0, 0.0, _lib.SIM_F16)
+
+    def unit(m, hw, kdb):
+        ctx = m.context
+        dbs = (_lib.DescSet * kdb)(*[_lib.DescSet(d.data_ptr(), N, _lib.DT_F16, _lib.LAYOUT_ND, 1) for d in db[:kdb]])
+        kp = torch.zeros((K, 2), device="cuda"); sc = torch.zeros((K,), device="cuda"); de = torch.zeros((K, 128), device="cuda")
+        mt = torch.full((kdb, K), -7, dtype=torch.int64, device="cuda"); msc = torch.zeros((kdb, K), device="cuda")
+        _lib.check(ctx.lib.sfd2_extract_match(ctx.h, imgs[hw].data_ptr(), hw[0], hw[1], 0.001, K, 0, kp.data_ptr(), sc.data_ptr(),
+                                              de.data_ptr(), dbs, kdb, 128, ctypes.byref(mconf), mt.data_ptr(), msc.data_ptr()))
+        ctx.sync()
+        return kp, sc, de, mt, msc
+
+    seq = [((480, 640), 5), ((640, 480), 5), ((480, 640), 5), ((640, 480), 5), ((480, 640), 3), ((640, 480), 5), ((480, 640), 5), ((480, 640), 3)]
+    for hw, kdb in seq:
+        want = unit(ms_[0], hw, kdb)
+        got = unit(ms_[1], hw, kdb)
+        assert (want[3] >= 0).sum() > 0
+        for g, w in zip(got, want):
+            assert torch.equal(g, w), (hw, kdb)
