@@ -367,6 +367,11 @@ void launch_conv3x3_pp(hipStream_t st, const half_t *in, int H, int W, int Cin, 
                        const float *scale, const float *shift, int CoutP, int relu, half_t *out,
                        int Ho, int Wo, const half_t *zero_page);
 
+bool conv3x3_rf_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo);
+void launch_conv3x3_rf(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
+                       const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out,
+                       int Ho, int Wo, const half_t *zero_page);
+
 // K-chunk width the v2 kernel wants the filters packed with (0 = layer is not served by v2)
 int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin)
 {
@@ -394,6 +399,10 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
                         const float *scale, const float *shift, int CoutP, int ks, int stride, int relu,
                         const half_t *residual, void *out, int out_f32, int Ho, int Wo, const half_t *zero_page)
 {
+    if (!residual && !out_f32 && conv3x3_rf_serves(ks, stride, CoutP, Cin, Ho, Wo)) {   // conv3rf_kernels.hip: small outputs
+        launch_conv3x3_rf(st, in, H, W, Cin, wpk, scale, shift, CoutP, stride, relu, reinterpret_cast<half_t *>(out), Ho, Wo, zero_page);
+        return true;
+    }
     if (stride == 2) {
         if (conv_igemm2_chunk(ks, 2, CoutP, Cin) != 32 || residual || out_f32) return false;
         // single-buffered input patch (XBUF = 1): 53 / 69 KB of LDS instead of 90 / 106 KB, so 3 / 2 blocks share a CU

@@ -62,7 +62,13 @@ __device__ __forceinline__ h4_t cvt4c(float a, float b, float c, float d)
 }
 
 // STAGGER = 0 builds the same loop without the one-barrier offset (A/B switch for the schedule itself)
-template <int STAGGER, int PRIO, int ABL = 0>
+#ifndef SFD2_PP_KXM
+#define SFD2_PP_KXM 1
+#endif
+// KXM = 1: the nine taps of a chunk run column by column (stage = one filter COLUMN kx, units ky = 0, 1, 2), so that the
+// pixel fragments of patch row r serve output rows r, r - 1, r - 2 of the same stage from registers: a stage reads six
+// patch rows once (4 + 1 + 1 over its three units) instead of four rows per unit -- 8 fragment reads per unit instead of 12.
+template <int STAGGER, int PRIO, int ABL = 0, int KXM = SFD2_PP_KXM>
 __global__ __launch_bounds__(512, 2)
 void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                        const half_t *__restrict__ wpk, const float *__restrict__ scale,
@@ -109,7 +115,8 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     for (int i = 0; i < PP_FPW; ++i) {
         const int r = (wave * PP_FPW + i) * 16 + (lane >> 2);   // row of the stage tile: tap r / 128, filter r % 128
         const int slot = (lane & 3) ^ ((r >> 2) & 3);
-        woff[i] = ((r / PP_BN) * CoutP + n0 + (r % PP_BN)) * PP_CC + slot * 8;
+        // KXM: the stage's three taps are (ky = r / 128, kx = stage % 3), three filter rows apart in the packed array
+        woff[i] = ((r / PP_BN) * (KXM ? 3 : 1) * CoutP + n0 + (r % PP_BN)) * PP_CC + slot * 8;
     }
 
 #define PP_ISSUE_X1(chunk_, buf_, i_)                                                                  \
@@ -121,7 +128,7 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     } while (0)
 #define PP_ISSUE_F(stage_, buf_)                                                                       \
     _Pragma("unroll") for (int i_ = 0; i_ < PP_FPW; ++i_) {                                            \
-        const half_t *src_ = wpk + (size_t)(stage_)*3 * CoutP * PP_CC + woff[i_];                      \
+        const half_t *src_ = wpk + (size_t)(KXM ? ((stage_) / 3) * 9 + (stage_) % 3 : (stage_)*3) * CoutP * PP_CC + woff[i_]; \
         __builtin_amdgcn_global_load_lds((gbl_void3_t *)src_,                                          \
                                          (lds_void3_t *)(Fs + (buf_)*PP_FBYTES + (wave * PP_FPW + i_) * 1024), 16, 0, 0); \
     }
@@ -157,11 +164,14 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     for (int c = 0; c < NCH; ++c) {
         const unsigned char *xs = Xs + (c & 1) * PP_XBYTES;
         const bool more_x = c + 1 < NCH;
+        h8_t fr[2][6];                                     // KXM: the stage's six patch rows
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9) {
-            const int ky = t9 / 3, kx = t9 % 3;
-            const int st = c * 3 + ky;
-            const unsigned char *fs = Fs + (st & 1) * PP_FBYTES + kx * (PP_BN * 64);
+            // u3 = unit within the stage (the stage's last unit carries the waits), sg = stage within the chunk
+            const int sg = t9 / 3, u3 = t9 % 3;
+            const int ky = KXM ? u3 : sg, kx = KXM ? sg : u3;
+            const int st = c * 3 + sg;
+            const unsigned char *fs = Fs + (st & 1) * PP_FBYTES + u3 * (PP_BN * 64);
             // ---------------- LOAD section
             h8_t fa[2][2], fb[2][4];
             if (ABL & 2) {   // timing ablation: no fragment reads
@@ -175,8 +185,18 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             }
             int qv = qb;
             asm volatile("" : "+v"(qv));   // recompute the 8 patch addresses per unit (hoisted out of the loop they are 72 registers)
+            if (KXM && !(ABL & 2)) {
 #pragma unroll
-            for (int pr = 0; pr < ((ABL & 2) ? 0 : 4); ++pr) {
+                for (int j = (u3 == 0 ? 0 : 3 + u3); j < 4 + u3; ++j) {   // rows 0..3, then 4, then 5
+                    const int q = qv + j * PP_PW + kx;
+                    const int sw = (q >> 2) & 3;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        fr[kk][j] = *reinterpret_cast<const h8_t *>(xs + q * 64 + (((kk * 2 + lhi) ^ sw) << 4));
+                }
+            }
+#pragma unroll
+            for (int pr = 0; pr < ((ABL & 2) || KXM ? 0 : 4); ++pr) {
                 const int q = qv + (pr + ky) * PP_PW + kx;
                 const int sw = (q >> 2) & 3;
 #pragma unroll
@@ -188,7 +208,7 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
                     fa[kk][ct] = *reinterpret_cast<const h8_t *>(fs + a_off[ct] + (((kk * 2 + lhi) ^ a_sw[ct]) << 4));
-            if (!(ABL & 1) && kx == 0 && st + 1 < NST) { PP_ISSUE_F(st + 1, (st + 1) & 1) }
+            if (!(ABL & 1) && u3 == 0 && st + 1 < NST) { PP_ISSUE_F(st + 1, (st + 1) & 1) }
             if (!(ABL & 1) && more_x) {
                 if (t9 == 0) PP_ISSUE_X1(c + 1, (c + 1) & 1, 0);
                 if (t9 == 1) PP_ISSUE_X1(c + 1, (c + 1) & 1, 1);
@@ -196,7 +216,7 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                 if (t9 == 4) PP_ISSUE_X1(c + 1, (c + 1) & 1, 3);
                 if (t9 == 6) PP_ISSUE_X1(c + 1, (c + 1) & 1, 4);
             }
-            if (kx == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (u3 == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -209,10 +229,11 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int pr = 0; pr < 4; ++pr)
-                        acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][ct], fb[kk][pr], acc[ct][pr], 0, 0, 0);
+                        acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][ct], KXM && !(ABL & 2) ? fr[kk][pr + u3] : fb[kk][pr],
+                                                                             acc[ct][pr], 0, 0, 0);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (kx == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (u3 == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // group 1's last MFMA section has nobody left to hand the pipe to
             if (!(STAGGER && grp == 1 && t9 == 8 && c + 1 == NCH)) asm volatile("s_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);

@@ -1,0 +1,305 @@
+// conv3x3_rf: implicit-GEMM kernel for the 3x3 layers with >= 256 output channels whose output is SMALL (stride-2
+// convPa.0, and convPa.3 behind it: 150 x 200 pixels at 1600x1200; every 256-channel 3x3 layer of a 640x480 image).
+// nets/sfd2.py:285-297.  Same GEMM orientation, record swizzle, filter packing and epilogue as conv3_kernels.hip.
+//
+// With 30 000 output pixels the 512-pixel x 128-channel tiles of conv3x3_pp give 140 blocks for 256 CUs (and the
+// stride-2 kernel's 4-row tiles 266: two rounds, the second one almost empty).  This kernel's tile is 128 pixels
+// (8 rows x 16) x ALL 256 channels: 247 blocks for 150 x 200.  A tile that small cannot afford to stage the filters in
+// LDS (147 KB per K chunk for 128 pixels: the ~18 B/clk LDS-DMA path would take twice as long as the chunk's MFMAs),
+// so the FILTERS NEVER TOUCH THE LDS: each of the eight waves owns 32 output channels and loads its A fragments straight
+// from the packed filter array (L2-resident, 1.2 MB per layer) into registers, one whole chunk (nine units of tap x 32
+// channels) ahead in a ring of nine: vector-memory operations complete in issue order, so a counted wait for a filter
+// load also waits for every patch copy issued before it -- the ring gives those copies nine units to land.  Only the
+// input patch goes through the LDS (buffer_load ... lds, three buffers of one 32-channel chunk each, the patch two
+// chunks ahead requested one piece per unit); every wave reads all four pixel fragments of it.
+//
+//   per unit and wave: 2 global_load_dwordx4 (A), 8 ds_read_b128 (B), 8 MFMAs 32x32x16; B lives in a ring of three K
+//   halves (the reads of half h + 2 are issued in front of the MFMAs of half h); one workgroup barrier per chunk, in
+//   front of the chunk's last unit.
+//
+// Patch records (64 B = 32 channels of one pixel, 16-byte slots XOR-swizzled by (record >> 2) & 3 as everywhere):
+//   stride 1: record = row * 32 + col                     (10 rows x 18 columns used)
+//   stride 2: record = row * 40 + (col even ? col / 2 : 17 + col / 2)   (17 rows x 33 columns, de-interleaved by column
+//             parity so that the 16 pixels of a fragment row are 16 CONSECUTIVE records for every tap)
+// A pixel fragment is 2 output rows x 16 pixels; the row pitches (32, 40) make the two half-fragments 0 mod 16 records
+// apart, which is what keeps the ds_read_b128 lane groups (MI355X_MICROARCH.md, LDS) conflict-free.
+#include "sfd2_internal.h"
+
+#define RF_TH 8
+#define RF_TW 16
+#define RF_BN 256
+#define RF_CC 32
+
+typedef __attribute__((address_space(3))) void lds_void4_t;
+typedef const __attribute__((address_space(1))) void gbl_void4_t;
+
+template <int S>
+struct RfGeom {
+    static constexpr int PH = (RF_TH - 1) * S + 3;        // 10 / 17 patch rows
+    static constexpr int PWU = (RF_TW - 1) * S + 3;       // 18 / 33 used records per row
+    static constexpr int P = S == 2 ? 40 : 32;            // row pitch in records
+    static constexpr int NREC = PH * P;
+    static constexpr int NPIECE = (NREC + 15) / 16;       // 20 / 43 pieces of 1 KB
+    static constexpr int PPW = (NPIECE + 7) / 8;          // pieces per wave (the tail repeats the last piece)
+    static constexpr int XBYTES = NPIECE * 1024;
+    static constexpr int DF = 2 * S * P;                  // records between two fragments (two output rows)
+    // vector-memory operations a wave issues after the last piece of a patch and before the chunk-boundary wait for it
+    // one chunk later: the filter loads of units PPW-1..8 and 0..7 (2 each) and the PPW pieces of the patch after it
+    static constexpr int VMW = 2 * (10 - PPW) + 16 + PPW;
+};
+
+__device__ __forceinline__ int xcd_swizzle4(int bid, int nblk)
+{
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+__device__ __forceinline__ h4_t cvt4r(float a, float b, float c, float d)
+{
+    h4_t r;
+    r[0] = (half_t)a; r[1] = (half_t)b; r[2] = (half_t)c; r[3] = (half_t)d;
+    return r;
+}
+
+// one LDS-DMA piece: 64 lanes x 16 bytes from base + voff (+ soff) to 1 KB of LDS at dst; offsets beyond nbytes read zeros.
+// (buffer_load ... lds, not global_load ... lds: hipcc books the latter as a FLAT access that may complete out of order
+// and from then on turns every counted wait for a filter load into vmcnt(0) -- one full drain per chunk.)
+__device__ __forceinline__ void rf_copy_piece(const half_t *base, int nbytes, unsigned char *dst, int voff, int soff)
+{
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(base), 0, nbytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void4_t *)dst, 16, voff, soff, 0, 0);
+}
+
+// ABL: timing ablations for experiment builds (wrong results): 1 = no filter loads in the loop, 2 = no fragment reads,
+// 4 = no patch copies in the loop, 8 = no output stores
+template <int S, int ABL = 0>
+__global__ __launch_bounds__(512, 2)
+void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
+                       const half_t *__restrict__ wpk, const float *__restrict__ scale,
+                       const float *__restrict__ shift, int CoutP, int relu,
+                       half_t *__restrict__ out, int Ho, int Wo, int tiles_x,
+                       const half_t *__restrict__ zero_page)
+{
+    using G = RfGeom<S>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Xs = smem;                              // [3][XBYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lhi = lane >> 5, l32 = lane & 31, ly = l32 >> 4, lx = l32 & 15;
+
+    const int n_tiles_n = CoutP / RF_BN;
+    const int swz = xcd_swizzle4(blockIdx.x, gridDim.x);
+    const int tn = swz % n_tiles_n;
+    const int tsp = swz / n_tiles_n;
+    const int tx = tsp % tiles_x, ty = tsp / tiles_x;
+    const int oy0 = ty * RF_TH, ox0 = tx * RF_TW, n0 = tn * RF_BN + wave * 32;
+
+    // ---- per-lane staging sources: byte offsets into the input for buffer_load ... lds; padding and out-of-image
+    // records get an offset beyond the buffer's range, for which the hardware returns zeros
+    const int in_bytes = (int)((size_t)H * W * Cin * sizeof(half_t));
+    int xoff[G::PPW];
+#pragma unroll
+    for (int i = 0; i < G::PPW; ++i) {
+        int piece = wave + 8 * i;
+        if (piece >= G::NPIECE) piece = G::NPIECE - 1;
+        const int q = piece * 16 + (lane >> 2);
+        const int slot = (lane & 3) ^ ((q >> 2) & 3);
+        const int row = q / G::P, ir = q - row * G::P;
+        int off = (int)0x80000000;
+        if (row < G::PH && ir < G::PWU) {
+            const int col = S == 2 ? (ir < RF_TW + 1 ? 2 * ir : 2 * (ir - (RF_TW + 1)) + 1) : ir;
+            const int iy = oy0 * S - 1 + row, ix = ox0 * S - 1 + col;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) off = ((iy * W + ix) * Cin + slot * 8) * (int)sizeof(half_t);
+        }
+        xoff[i] = off;
+    }
+
+#define RF_ISSUE_X1(chunk_, buf_, i_)                                                                  \
+    do {                                                                                               \
+        const int pc_ = (wave + 8 * (i_) < G::NPIECE) ? wave + 8 * (i_) : G::NPIECE - 1;               \
+        rf_copy_piece(in, in_bytes, Xs + (buf_)*G::XBYTES + pc_ * 1024, xoff[i_], (chunk_)*RF_CC * (int)sizeof(half_t)); \
+    } while (0)
+#define RF_ISSUE_X(chunk_, buf_)                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < G::PPW; ++i_) RF_ISSUE_X1(chunk_, buf_, i_);
+
+    // A fragments: lane -> filter row n0 + (lane & 31), K slice (lane >> 5) + 2 * kk of the unit's [CoutP][32] tile
+    int aoff = (n0 + l32) * RF_CC + lhi * 8;
+#define RF_LOAD_A(u_, dst_)                                                                            \
+    do {                                                                                               \
+        int ao_ = aoff;                                                                                \
+        asm volatile("" : "+v"(ao_));                                                                  \
+        const half_t *ap_ = wpk + (size_t)(u_)*CoutP * RF_CC + ao_;                                    \
+        dst_[0] = *reinterpret_cast<const h8_t *>(ap_);                                                \
+        dst_[1] = *reinterpret_cast<const h8_t *>(ap_ + 16);                                           \
+    } while (0)
+
+    // B fragments: record of (fragment 0, tap) for this lane; fragment f is f * DF records further
+    const int qb = ly * S * G::P + lx;
+#define RF_READ_B(xs_, t_, kk_, dst_)                                                                  \
+    do {                                                                                               \
+        const int ky_ = (t_) / 3, kx_ = (t_) % 3;                                                      \
+        const int to_ = ky_ * G::P + (S == 2 ? (kx_ == 0 ? 0 : (kx_ == 1 ? RF_TW + 1 : 1)) : kx_);     \
+        int q_ = qb;                                                                                   \
+        asm volatile("" : "+v"(q_));                                                                   \
+        q_ += to_;                                                                                     \
+        const unsigned char *bp_ = (xs_) + q_ * 64 + (((((kk_)*2 + lhi)) ^ ((q_ >> 2) & 3)) << 4);    \
+        _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_)                                               \
+            dst_[f_] = *reinterpret_cast<const h8_t *>(bp_ + f_ * (G::DF * 64));                       \
+    } while (0)
+
+    f32x16_t acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+
+    const int NCH = Cin / RF_CC;
+    const int NU = NCH * 9;
+    h8_t fa[9][2], fb[3][4];
+
+    RF_ISSUE_X(0, 0)
+    RF_ISSUE_X(1, 1)                                       // Cin >= 64: at least two chunks
+#pragma unroll
+    for (int u = 0; u < 9; ++u) RF_LOAD_A(u, fa[u]);
+    // (waiting for the first patch only and letting the rest land behind counted waits was measured: no gain)
+    SFD2_BARRIER_DRAIN();
+    RF_READ_B(Xs, 0, 0, fb[0]);
+    RF_READ_B(Xs, 0, 1, fb[1]);
+
+    int bc = 0;                                            // c % 3: three patch buffers
+    for (int c = 0; c < NCH; ++c) {
+        const int bn = bc == 2 ? 0 : bc + 1, bnn = bn == 2 ? 0 : bn + 1;
+        const unsigned char *xs = Xs + bc * G::XBYTES;
+        const unsigned char *xn = Xs + bn * G::XBYTES;
+        // the patch two chunks ahead goes into the buffer chunk c - 1 used (every wave passed that chunk's boundary
+        // barrier with its reads retired), one piece per unit so that the copies of the 247 blocks do not arrive at the
+        // memory system as one burst.  The last two chunks re-request the last patch (branch-free: the in-flight counts
+        // stay what the waits assume).
+        const int cx = c + 2 < NCH ? c + 2 : NCH - 1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int u = c * 9 + t;
+            if (t < G::PPW && !(ABL & 4)) RF_ISSUE_X1(cx, bnn, t);
+            if (t == 8) {
+                // chunk boundary: my pieces of the next patch have landed (VMW younger operations may still be in flight),
+                // my reads of this one are done; then the whole block's.  The last chunk's look-ahead reads return
+                // stale records that no MFMA consumes.
+                static_assert(RfGeom<1>::VMW == 33 && RfGeom<2>::VMW == 30, "chunk-boundary wait counts");
+                if (S == 2) asm volatile("s_waitcnt vmcnt(30) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(33) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int h = 2 * t + kk;                  // K half of the chunk; its fragments sit in fb[h % 3]
+                if (ABL & 2) {
+                } else if (h + 2 < 18) RF_READ_B(xs, (h + 2) / 2, (h + 2) % 2, fb[(h + 2) % 3]);
+                else RF_READ_B(xn, (h + 2 - 18) / 2, (h + 2) % 2, fb[(h + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][kk], fb[h % 3][f], acc[f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the last chunk re-loads the last unit's filters (unconditional, like the copies)
+            if (!(ABL & 1)) RF_LOAD_A((u + 9 < NU ? u + 9 : NU - 1), fa[t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bc = bn;
+    }
+#undef RF_ISSUE_X
+#undef RF_ISSUE_X1
+#undef RF_LOAD_A
+#undef RF_READ_B
+
+    const float lo = relu ? 0.0f : -__builtin_huge_valf();   // branch-free ReLU (this file is compiled with -fno-honor-nans)
+    // epilogue: y = acc * scale + shift (ReLU), regrouped with v_permlane32_swap into 16-byte stores (conv2_kernels.hip)
+    float4 sc[4], sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sc[q] = *reinterpret_cast<const float4 *>(scale + n0 + 4 * lhi + 8 * q);
+        sh[q] = *reinterpret_cast<const float4 *>(shift + n0 + 4 * lhi + 8 * q);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int oy = oy0 + 2 * f + ly, ox = ox0 + lx;
+        const bool inb = oy < Ho && ox < Wo;
+        const size_t pix = (size_t)(inb ? oy : 0) * Wo + (inb ? ox : 0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const size_t o16 = pix * CoutP + n0 + 8 * (2 * m + lhi);
+            uint2 pk[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = 2 * m + j;
+                float v0 = acc[f][4 * q + 0] * sc[q].x + sh[q].x;
+                float v1 = acc[f][4 * q + 1] * sc[q].y + sh[q].y;
+                float v2 = acc[f][4 * q + 2] * sc[q].z + sh[q].z;
+                float v3 = acc[f][4 * q + 3] * sc[q].w + sh[q].w;
+                v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
+                const h4_t hv = cvt4r(v0, v1, v2, v3);
+                __builtin_memcpy(&pk[j], &hv, 8);
+            }
+            const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+            const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+            if (inb && (!(ABL & 8) || t0[0] == 0x12345678u)) *reinterpret_cast<uint4 *>(out + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+        }
+    }
+}
+
+template <int S, int ABL = 0>
+static void launch_rf_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
+                        const float *scale, const float *shift, int CoutP, int relu, half_t *out,
+                        int Ho, int Wo, const half_t *zero_page)
+{
+    constexpr size_t lds = (size_t)3 * RfGeom<S>::XBYTES;
+    static bool attr_done = false;
+    auto kern = conv3x3_rf_kernel<S, ABL>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int tiles_x = (Wo + RF_TW - 1) / RF_TW, tiles_y = (Ho + RF_TH - 1) / RF_TH;
+    const int grid = tiles_x * tiles_y * (CoutP / RF_BN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out,
+                       Ho, Wo, tiles_x, zero_page);
+}
+
+// does conv3x3_rf serve this layer?  Shape AND output size decide (the filter packing is the 32-channel-chunk one that
+// conv3x3_pp and the stride-2 conv_igemm2 use, so the choice can be made per launch).
+bool conv3x3_rf_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo)
+{
+    static const char *mode = sfd2_env("SFD2_CONV_RF");   // experiments: "off", "all"
+    if (mode && mode[0] == 'o') return false;
+    if (ks != 3 || (stride != 1 && stride != 2) || CoutP % RF_BN != 0 || Cin % 64 != 0) return false;
+    if (mode && mode[0] == 'a') return true;
+    if (stride == 2) return true;
+    // stride 1: conv3x3_pp (512 pixels x 128 channels per block) is the faster kernel per FLOP but needs ~2 blocks per CU
+    // worth of output; compare rounds on the 256 CUs weighted by the measured time of one round of each (Cin = 256:
+    // ~60 us against ~37 us; 1600x1200: convPa.3 52 -> 40 us here, conv3b 119 -> 143 us)
+    const long long pp_blocks = (long long)((Wo + 31) / 32) * ((Ho + 15) / 16) * (CoutP / 128);
+    const long long rf_blocks = (long long)((Wo + RF_TW - 1) / RF_TW) * ((Ho + RF_TH - 1) / RF_TH) * (CoutP / RF_BN);
+    return ((rf_blocks + 255) / 256) * 10 < ((pp_blocks + 255) / 256) * 16;
+}
+
+void launch_conv3x3_rf(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
+                       const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out,
+                       int Ho, int Wo, const half_t *zero_page)
+{
+#ifdef SFD2_EXPERIMENTS
+    if (const char *ab = sfd2_env("SFD2_RF_ABL")) {
+        switch (atoi(ab) * 4 + stride) {
+#define RF_ABL_CASE(a_) \
+        case (a_) * 4 + 1: launch_rf_t<1, a_>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page); return; \
+        case (a_) * 4 + 2: launch_rf_t<2, a_>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page); return;
+            RF_ABL_CASE(1) RF_ABL_CASE(2) RF_ABL_CASE(3) RF_ABL_CASE(4) RF_ABL_CASE(5) RF_ABL_CASE(6) RF_ABL_CASE(7) RF_ABL_CASE(8) RF_ABL_CASE(15)
+#undef RF_ABL_CASE
+        default: break;
+        }
+    }
+#endif
+    if (stride == 2) launch_rf_t<2>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
+    else launch_rf_t<1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
+}

@@ -634,6 +634,7 @@ static void conv(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &in
     const int bn = (L.cout_pad % 256 == 0) ? 256 : (L.cout_pad % 128 == 0 ? 128 : 64);
     snprintf(kn, sizeof(kn), "conv_igemm<%d,%d,%d%s>", L.ks, L.stride, bn, out_f32 ? ",f32" : "");
     if (!res && !out_f32 && conv3x3_pp_serves(L.ks, L.stride, L.cout_pad, L.cin)) snprintf(kn, sizeof(kn), "conv3x3_pp");
+    if (!res && !out_f32 && conv3x3_rf_serves(L.ks, L.stride, L.cout_pad, L.cin, Ho, Wo)) snprintf(kn, sizeof(kn), "conv3x3_rf<%d>", L.stride);
     const double px = (double)Ho * Wo;
     const double flops = 2.0 * px * L.cout * L.cin * L.ks * L.ks;
     const double bytes = 2.0 * ((double)H * W * L.cin + (double)L.cout * L.cin * L.ks * L.ks) +

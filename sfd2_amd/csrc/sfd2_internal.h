@@ -56,6 +56,8 @@ void launch_fused_stem(hipStream_t st, const float *img, int H, int W, int norma
 //   out [Ho][Wo][Cout_pad] fp16 (relu / residual optional) or fp32 (out_f32)
 // conv3_kernels.hip: the 3x3 stride-1 layers with >= 256 output channels
 bool conv3x3_pp_serves(int ks, int stride, int CoutP, int Cin);
+// conv3rf_kernels.hip: the same layers (and their stride-2 siblings) when the output is small
+bool conv3x3_rf_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo);
 void launch_conv_igemm(hipStream_t st, const half_t *in, int H, int W, int Cin,
                        const half_t *wpk, const float *scale, const float *shift, int Cout_pad,
                        int ks, int stride, int relu, const half_t *residual,

@@ -40,11 +40,22 @@ for line in sys.stdin:
         break
 ''' % os.path.abspath(ROOT)
 
+
+def split_spec(spec):
+    """'lib.so@KEY=VAL,KEY2=VAL2' -> (lib path, environment of its worker)"""
+    lib, _, envs = spec.partition("@")
+    env = dict(os.environ)
+    for kv in filter(None, envs.split(",")):
+        k, _, v = kv.partition("=")
+        env[k] = v
+    return lib, env
+
 ap = argparse.ArgumentParser()
 ap.add_argument("libs", nargs="+")
 ap.add_argument("--rounds", type=int, default=3)
 args = ap.parse_args()
-procs = [subprocess.Popen([sys.executable, "-c", WORKER, l], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for l in args.libs]
+procs = [subprocess.Popen([sys.executable, "-c", WORKER, split_spec(l)[0]], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
+                          env=split_spec(l)[1]) for l in args.libs]
 def ask(p, cmd):
     p.stdin.write(cmd + "\n"); p.stdin.flush()
     return json.loads(p.stdout.readline())

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Compare the 3x3-layer activations of two libsfd2hip builds (layer-wise path, same inputs) and screen the second
 one for run-to-run differences (hand-synchronised kernels: a race shows up as a tile that changes between runs).
-    python tools/check_conv_variant.py default build/variants/libsfd2hip_pp.so"""
+    python tools/check_conv_variant.py default build/variants/libsfd2hip_pp.so
+(a library may carry environment switches for its worker: default@SFD2_CONV_RF=off)"""
 import os
 import subprocess
 import sys
@@ -10,7 +11,7 @@ import tempfile
 import numpy as np
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-LAYERS = ["conv3a", "bn3b", "convPa", "convDa.0", "convDa"]
+LAYERS = ["bn2b", "conv3a", "bn3b", "convPa.0", "convPa", "convDa.0", "convDa"]
 SIZES = [(1200, 1600), (240, 320), (133, 211), (512, 384), (64, 1056)]
 WORKER = r'''
 import sys, numpy as np
@@ -42,12 +43,23 @@ for (h, w) in %r:
 np.savez(sys.argv[2], **out)
 ''' % (os.path.abspath(ROOT), SIZES, LAYERS)
 
+
+def split_spec(spec):
+    """'lib.so@KEY=VAL,KEY2=VAL2' -> (lib path, environment of its worker)"""
+    lib, _, envs = spec.partition("@")
+    env = dict(os.environ)
+    for kv in filter(None, envs.split(",")):
+        k, _, v = kv.partition("=")
+        env[k] = v
+    return lib, env
+
 a, b = sys.argv[1], sys.argv[2]
 tmp = tempfile.mkdtemp()
 files = []
 for i, lib in enumerate((a, b)):
     f = os.path.join(tmp, f"acts_{i}.npz")
-    subprocess.run([sys.executable, "-c", WORKER, lib, f], check=True)
+    lib_path, env = split_spec(lib)
+    subprocess.run([sys.executable, "-c", WORKER, lib_path, f], check=True, env=env)
     files.append(np.load(f))
 for key in files[0].files:
     x, y = files[0][key].astype(np.float32), files[1][key].astype(np.float32)
