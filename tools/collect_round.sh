@@ -15,6 +15,7 @@ python bench.py --steps 20 --warmup 5 --no-graphs --no-cpu-baseline --no-strict 
 python bench.py --steps 20 --warmup 5 --streams 1 --no-cpu-baseline --no-strict > $out/bench_streams1.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --size 1024x1024 --no-cpu-baseline > $out/bench_1024x1024.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --size 1024x768 --no-cpu-baseline > $out/bench_1024x768.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --size 640x480 --no-cpu-baseline --dump-layers > $out/bench_640x480.json 2> $out/layer_table_640x480.txt
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strict --sustain 0"
 rocprofv3 --kernel-trace --stats -d $out/prof -o $tag -- $B > $out/prof_bench.json 2> $out/prof.err
