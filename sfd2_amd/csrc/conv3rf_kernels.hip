@@ -275,7 +275,7 @@ bool conv3x3_rf_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo)
     if (mode && mode[0] == 'o') return false;
     if (ks != 3 || (stride != 1 && stride != 2) || CoutP % RF_BN != 0 || Cin % 64 != 0) return false;
     if (mode && mode[0] == 'a') return true;
-    if (stride == 2) return true;
+    if (stride == 2) return true;   // (conv2b, 128 -> 128 channels, through a 128-channel-block variant: 74 vs 70 us, not kept)
     // stride 1: conv3x3_pp (512 pixels x 128 channels per block) is the faster kernel per FLOP but needs ~2 blocks per CU
     // worth of output; compare rounds on the 256 CUs weighted by the measured time of one round of each (Cin = 256:
     // ~60 us against ~37 us; 1600x1200: convPa.3 52 -> 40 us here, conv3b 119 -> 143 us)
