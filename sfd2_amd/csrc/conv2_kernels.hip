@@ -408,14 +408,16 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
         // single-buffered input patch (XBUF = 1): 53 / 69 KB of LDS instead of 90 / 106 KB, so 3 / 2 blocks share a CU
         // and hide each other's per-step latencies (steps are only 8-16 MFMAs long here).  Measured at 1600x1200:
         // conv2b 98 -> 70 us, convPa.0 120 -> 82 us.  SFD2_CONV_S2_XBUF2 restores the double-buffered variant.
+#ifdef SFD2_EXPERIMENTS
         static const bool xb2 = sfd2_env("SFD2_CONV_S2_XBUF2") != nullptr;
         if (xb2) {
             if (CoutP % 256 == 0) launch_igemm2_t<3, 2, 256, 32, false, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
             else launch_igemm2_t<3, 2, 128, 32, false, false>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
-        } else {
-            if (CoutP % 256 == 0) launch_igemm2_t<3, 2, 256, 32, false, false, 8, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
-            else launch_igemm2_t<3, 2, 128, 32, false, false, 8, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
+            return true;
         }
+#endif
+        if (CoutP % 256 == 0) launch_igemm2_t<3, 2, 256, 32, false, false, 8, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
+        else launch_igemm2_t<3, 2, 128, 32, false, false, 8, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page);
         return true;
     }
 #define SFD2_IG2B(KS_, BN_, CC_, F32_)                                                                                   \
@@ -436,6 +438,7 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
     }
     static const bool bn128 = sfd2_env("SFD2_CONV_BN128") != nullptr;
     const int bn = (CoutP % 256 == 0 && !bn128) ? 256 : 128;
+#ifdef SFD2_EXPERIMENTS
     static const bool nw4 = sfd2_env("SFD2_CONV_NW4") != nullptr;   // experiment: 4 waves, 128 ch x 128 px per wave
     if (nw4 && ks == 3 && !out_f32 && bn == 256 && cc == 64 && !residual) {
         launch_igemm2_t<3, 1, 256, 64, false, false, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
@@ -447,6 +450,7 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
         else launch_igemm2_t<1, 1, 256, 32, false, false, 4, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         return true;
     }
+#endif
 #ifdef SFD2_EXPERIMENTS
     if (const char *ab = sfd2_env("SFD2_CONV_3X3_ABLATE")) {   // timing ablations of the dominant kernel (wrong results)
         if (ks == 3 && !out_f32 && bn == 256 && cc == 64 && !residual) {
@@ -457,6 +461,7 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
         }
     }
 #endif
+#ifdef SFD2_EXPERIMENTS
     static const bool tps3 = sfd2_env("SFD2_CONV_TPS3") != nullptr;   // experiment: one filter ROW (3 taps) per pipeline stage
     if (tps3 && ks == 3 && !out_f32 && bn == 256 && cc == 32 && !residual) {
         launch_igemm2_t<3, 1, 256, 32, false, false, 8, 0, 2, 0, 2, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
@@ -467,6 +472,7 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
         launch_igemm2_t<3, 1, 256, 32, false, false, 8, 0, 2, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         return true;
     }
+#endif
     if (ks == 3 && !out_f32 && bn == 128 && cc == 64 && Cin == 64 && !residual) {
         launch_igemm2_t<3, 1, 128, 64, false, false, 8, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, residual, out, Ho, Wo, zero_page);
         return true;
@@ -488,6 +494,7 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
         }
     }
 #endif
+#ifdef SFD2_EXPERIMENTS
     static const bool x3 = sfd2_env("SFD2_CONV_1X1_XBUF3") != nullptr;
 #define SFD2_IG1(BN_, CC_, F32_)                                                                                         \
     do {                                                                                                                \
@@ -497,6 +504,7 @@ bool launch_conv_igemm2(hipStream_t st, const half_t *in, int H, int W, int Cin,
     if (ks == 1 && x3 && !out_f32 && bn == 256 && cc == 64) { SFD2_IG1(256, 64, false); return true; }
     if (ks == 1 && x3 && out_f32 && bn == 128 && cc == 32) { SFD2_IG1(128, 32, true); return true; }
 #undef SFD2_IG1
+#endif
     if (ks == 1 && !out_f32) { if (bn == 256) SFD2_IG2(1, 256, false); else SFD2_IG2(1, 128, false); return true; }
     if (ks == 1 && out_f32) { if (bn == 256) SFD2_IG2(1, 256, true); else SFD2_IG2(1, 128, true); return true; }
 #undef SFD2_IG2

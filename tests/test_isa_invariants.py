@@ -1,0 +1,129 @@
+"""What the hand-scheduled kernels rely on from hipcc, checked on the gfx950 assembly (no GPU needed; ADVICE r1: "check the ISA in
+CI").  Each of these was a measured regression at some point: a spilled register, a compiler-inserted
+`s_waitcnt vmcnt(0)` that drains a copy ring inside a K loop, a counted wait that silently became a full drain."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from sfd2_amd import build
+
+CSRC = build.CSRC
+
+
+def _device_asm(tmp_path_factory, src):
+    if not build.have_hipcc():
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / (src + ".s")
+    flags = [f for f in build.FLAGS if f not in ("-fPIC",)] + build.SRC_FLAGS.get(src, [])
+    subprocess.check_call([build._hipcc()] + flags + ["-S", "--cuda-device-only", "-o", str(out), os.path.join(CSRC, src)])
+    return open(out).read()
+
+
+def _kernels(asm):
+    """{mangled name: {'body': [lines], 'meta': {...}}} for every kernel of one translation unit"""
+    out = {}
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M):
+        out[m.group(1)] = {"body": m.group(2).split("\n")}
+    for m in re.finditer(r"\.name:\s+(_Z\w+)\n(.*?)\.wavefront_size", asm, re.S):
+        if m.group(1) in out:
+            meta = dict(re.findall(r"\.(\w+):\s+(\d+)", m.group(2)))
+            out[m.group(1)]["meta"] = {k: int(v) for k, v in meta.items()}
+    return out
+
+
+def _mfma_span(body):
+    idx = [i for i, l in enumerate(body) if "v_mfma" in l]
+    return body[idx[0]:idx[-1] + 1] if idx else []
+
+
+def _count(lines, pattern):
+    return sum(1 for l in lines if re.search(pattern, l))
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    cache = {}
+
+    def get(src):
+        if src not in cache:
+            cache[src] = _kernels(_device_asm(tmp_path_factory, src))
+        return cache[src]
+    return get
+
+
+@pytest.mark.parametrize("src", ["conv3_kernels.hip", "conv3rf_kernels.hip", "resblock_kernel.hip", "conv1x1_kernels.hip",
+                                 "match_mutual_kernel.hip", "fused_stem_kernel.hip", "conv2_kernels.hip"])
+def test_no_spills_and_two_waves_per_simd(asm, src):
+    ks = asm(src)
+    assert ks, src
+    for name, k in ks.items():
+        meta = k.get("meta")
+        assert meta is not None, name
+        assert meta["vgpr_count"] <= 256, (name, meta["vgpr_count"])      # two waves per SIMD
+        assert _count(_mfma_span(k["body"]), r"\bscratch_") == 0, name    # never a spill inside a K loop
+        # conv2a's kernel (64 -> 128 channels, 128 registers for four waves per SIMD) parks one address pair across its
+        # loop: one store in the prologue, one reload in the epilogue
+        allowed = 2 if "conv_igemm2_kernelILi3ELi1ELi128ELi64E" in name else 0
+        assert meta["vgpr_spill_count"] <= allowed and meta["sgpr_spill_count"] == 0, (name, meta)
+
+
+def test_conv3x3_pp_loop_has_only_its_own_drains(asm):
+    ks = {n: k for n, k in asm("conv3_kernels.hip").items() if "conv3x3_pp_kernel" in n}
+    assert ks
+    for name, k in ks.items():
+        span = _mfma_span(k["body"])
+        assert _count(span, r"v_mfma_f32_32x32x16_f16") == 144          # 9 units x 16
+        # (the span runs from the first to the last MFMA of the unrolled chunk body: the first unit's LOAD section and the
+        # last unit's closing wait lie outside it)
+        # the two written-out vmcnt(0) of each stage's last unit (3 stages), nothing from hipcc
+        assert _count(span, r"s_waitcnt.*vmcnt\(0\)") == 5, name
+        assert _count(span, r"ds_read_b128") == 72 - 12                  # 8 fragment reads per unit (filter-column order)
+        assert _count(span, r"s_barrier") == 16
+
+
+def test_conv3x3_rf_loop_keeps_counted_waits(asm):
+    ks = {n: k for n, k in asm("conv3rf_kernels.hip").items() if "conv3x3_rf_kernel" in n}
+    assert len(ks) == 2
+    for name, k in ks.items():
+        span = _mfma_span(k["body"])
+        assert _count(span, r"v_mfma_f32_32x32x16_f16") == 72            # 9 units x 8
+        # no full drain inside the chunk loop: filter loads and patch copies are waited for by count
+        assert _count(span, r"s_waitcnt.*vmcnt\(0\)") == 0, name
+        assert _count(span, r"global_load_dwordx4") == 16                # the filter ring: 2 loads per unit (the last unit's follow its MFMAs)
+        assert _count(span, r"buffer_load_dwordx4 .* lds") in (2, 5)     # one patch piece per unit (stride 1 / 2; the first precedes the span)
+        assert _count(k["body"], r"global_load_lds") == 0                # (hipcc drains behind the FLAT form)
+        assert _count(span, r"s_barrier") == 1
+
+
+def test_resblock_row_loop_drains(asm):
+    ks = {n: k for n, k in asm("resblock_kernel.hip").items() if "resblock_kernel" in n}
+    assert ks
+    for name, k in ks.items():
+        span = _mfma_span(k["body"])
+        # typed LDS reads (sfd2_lds_f4 / rb_lds4): no compiler vmcnt(0) in front of the scale / shift reads; what is left are
+        # the written-out waits of the row pipeline
+        assert _count(span, r"s_waitcnt.*vmcnt\(0\)") <= 3, (name, _count(span, r"s_waitcnt.*vmcnt\(0\)"))
+
+
+def test_conv1x1_ring_not_drained_in_epilogue(asm):
+    ks = {n: k for n, k in asm("conv1x1_kernels.hip").items() if "conv1x1_c256_kernel" in n}
+    assert ks
+    for name, k in ks.items():
+        span = _mfma_span(k["body"])
+        # the residual variant (parity path only) waits for its residual loads, the youngest operations in flight
+        limit = 5 if "ILb1E" in name else 0
+        assert _count(span, r"s_waitcnt.*vmcnt\(0\)") <= limit, (name, _count(span, r"s_waitcnt.*vmcnt\(0\)"))
+
+
+def test_matcher_valu_budget(asm):
+    ks = {n: k for n, k in asm("match_mutual_kernel.hip").items() if "match_mutual_kernel" in n}
+    assert len(ks) == 1
+    k = next(iter(ks.values()))
+    mfma = _count(k["body"], r"v_mfma")
+    maxes = _count(k["body"], r"v_max3?_f32")
+    # -fno-honor-nans: no canonicalising v_max x, x in front of the packed maxima (it doubled the VALU count);
+    # two tiles' epilogues: 64 v_max3 + ~35 v_max
+    assert mfma == 32 and maxes <= 110, (mfma, maxes)
+    assert _count(k["body"], r"v_max_f32_e32 (v\d+), \1, \1") == 0
