@@ -274,6 +274,8 @@ bool conv3x3_rf_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo)
     static const char *mode = sfd2_env("SFD2_CONV_RF");   // experiments: "off", "all"
     if (mode && mode[0] == 'o') return false;
     if (ks != 3 || (stride != 1 && stride != 2) || CoutP % RF_BN != 0 || Cin % 64 != 0) return false;
+    // the patch copies address the input through a buffer descriptor with 32-bit byte offsets
+    if ((long long)(Ho * stride + 2) * (Wo * stride + 2) * Cin * (long long)sizeof(half_t) >= (1ll << 31)) return false;
     if (mode && mode[0] == 'a') return true;
     if (stride == 2) return true;   // (conv2b, 128 -> 128 channels, through a 128-channel-block variant: 74 vs 70 us, not kept)
     // stride 1: conv3x3_pp (512 pixels x 128 channels per block) is the faster kernel per FLOP but needs ~2 blocks per CU
