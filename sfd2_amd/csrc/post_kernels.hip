@@ -13,16 +13,6 @@
 
 #define NT 256
 
-// histogram bin of a candidate key (score bits << 32 | ~index): the 16 exponent + mantissa bits below the sign, rebased
-// so that bin 0 starts at 2^-12 and the last bin ends at 2^4, clamped.  Monotone in the score, which is all the
-// threshold search needs: keys above the boundary bin are selected outright, the boundary bin is ranked exactly.
-// (Heat-map scores are products of a soft-max probability and a stability weight: (0, 1].)
-__device__ __forceinline__ unsigned int key_bin(unsigned long long key)
-{
-    const int b = (int)((unsigned int)(key >> 47) & 0xFFFFu) - ((127 - 12) << 8);
-    return (unsigned int)(b < 0 ? 0 : (b > SFD2_HIST_BINS - 1 ? SFD2_HIST_BINS - 1 : b));
-}
-
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -365,214 +355,6 @@ void nms_select_kernel(const float *__restrict__ heat, int H, int W, int radius,
     }
 }
 
-// ---------------------------------------------------------------- fast path, radius 4
-// Same algorithm, restructured for the LDS: region 64 x 128 (tile 24 x 88 + 20-px halo), only two
-// float planes (scores S, row-pass result A).  Each max-pool is a register-blocked row pass
-// (8 outputs from 16 loaded values: suffix/prefix maxima) and a column pass whose result is
-// compared in registers and turned into bit masks with wave ballots; the two mask dilations
-// (supp_mask = max_pool(max_mask) > 0) are bit operations on 128-bit rows.  The suppressed score
-// map (where(supp, 0, scores)) is formed on the fly from S and the supp bits.
-#define N2_TW 88
-#define N2_HALO 20
-#define N2_RW 128
-#define N2_SP 136   // S row pitch: 4 pad floats (-inf) on either side
-// region rows RH (64 or 136) is a template parameter: tile rows = RH - 2 * halo, A plane rows = RH + 8
-
-__device__ __forceinline__ void pool8(const float (&v)[16], float (&o)[8])
-{
-    // o[j] = max(v[j .. j+8]) = max(suffix max of v[0..7] at j, prefix max of v[8..15] at j)
-    float suf[8], pre[8];
-    suf[7] = v[7];
-#pragma unroll
-    for (int j = 6; j >= 0; --j) suf[j] = fmaxf(v[j], suf[j + 1]);
-    pre[0] = v[8];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) pre[j] = fmaxf(pre[j - 1], v[8 + j]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = fmaxf(suf[j], pre[j]);
-}
-
-template <bool MASKED, int N2_RH>
-__device__ __forceinline__ void n2_row_pass(const float *__restrict__ S, float *__restrict__ A,
-                                            const unsigned long long *__restrict__ supp)
-{
-    const float NEG = -INFINITY;
-    for (int u = threadIdx.x; u < N2_RH * 16; u += blockDim.x) {
-        const int y = u >> 4, x0 = (u & 15) * 8;
-        float v[16];
-        const float4 *src = reinterpret_cast<const float4 *>(S + y * N2_SP + x0);   // region cols x0-4 .. x0+11
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 t = src[q];
-            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-        }
-        if (MASKED) {
-            // bits of region cols x0-4 .. x0+11, taken from the row mask shifted left by 4
-            const unsigned long long w0 = supp[2 * y], w1 = supp[2 * y + 1];
-            const unsigned long long lo = w0 << 4, hi = (w1 << 4) | (w0 >> 60), top = w1 >> 60;
-            unsigned long long bits;
-            if (x0 < 64) bits = (lo >> x0) | (x0 ? (hi << (64 - x0)) : 0ull);
-            else { const int sft = x0 - 64; bits = (hi >> sft) | (sft ? (top << (64 - sft)) : 0ull); }
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (((bits >> i) & 1ull) && v[i] != NEG) v[i] = 0.0f;   // padding stays -inf
-        }
-        float o[8];
-        pool8(v, o);
-        float4 *dst = reinterpret_cast<float4 *>(A + (y + 4) * N2_RW + x0);
-        dst[0] = make_float4(o[0], o[1], o[2], o[3]);
-        dst[1] = make_float4(o[4], o[5], o[6], o[7]);
-    }
-}
-
-// column pass + compare; MASKED: new = old | (ss == pool(ss) & ~supp), else new = (s == pool(s))
-template <bool MASKED, int N2_RH>
-__device__ __forceinline__ void n2_col_pass(const float *__restrict__ S, const float *__restrict__ A,
-                                            const unsigned long long *__restrict__ supp,
-                                            unsigned long long *__restrict__ mask)
-{
-    const float NEG = -INFINITY;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int u = wave; u < (N2_RH / 8) * 2; u += nw) {
-        const int k = u >> 1, h = u & 1, x = h * 64 + lane;
-        float a[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a[i] = A[(8 * k + i) * N2_RW + x];
-        float o[8];
-        pool8(a, o);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int y = 8 * k + j;
-            const float sv = S[y * N2_SP + 4 + x];
-            bool cond;
-            if (MASKED) {
-                const bool sb = (supp[2 * y + h] >> lane) & 1ull;
-                const float ss = (sb && sv != NEG) ? 0.0f : sv;
-                cond = (ss == o[j]) && sv != NEG && !sb;
-            } else {
-                cond = (sv == o[j]) && sv != NEG;
-            }
-            const unsigned long long word = __ballot(cond);
-            if (lane == 0) mask[2 * y + h] = MASKED ? (mask[2 * y + h] | word) : word;
-        }
-    }
-}
-
-template <int N2_RH>
-__device__ __forceinline__ void n2_dilate(const unsigned long long *__restrict__ m, unsigned long long *__restrict__ tmp,
-                                          unsigned long long *__restrict__ supp)
-{
-    for (int u = threadIdx.x; u < N2_RH; u += blockDim.x) {
-        const unsigned long long w0 = m[2 * u], w1 = m[2 * u + 1];
-        unsigned long long d0 = w0, d1 = w1;
-#pragma unroll
-        for (int sft = 1; sft <= 4; ++sft) {
-            d0 |= (w0 << sft) | (w0 >> sft) | (w1 << (64 - sft));
-            d1 |= (w1 << sft) | (w1 >> sft) | (w0 >> (64 - sft));
-        }
-        tmp[2 * u] = d0;
-        tmp[2 * u + 1] = d1;
-    }
-    __syncthreads();
-    for (int u = threadIdx.x; u < N2_RH * 2; u += blockDim.x) {
-        const int y = u >> 1, h = u & 1;
-        unsigned long long d = 0ull;
-#pragma unroll
-        for (int dy = -4; dy <= 4; ++dy)
-            if (y + dy >= 0 && y + dy < N2_RH) d |= tmp[2 * (y + dy) + h];
-        supp[u] = d;
-    }
-    __syncthreads();
-}
-
-template <int N2_RH>
-__global__ __launch_bounds__(1024)
-void nms4_select_kernel(const float *__restrict__ heat, int H, int W, float conf_th, int border, int Hb, int Wb,
-                        float *__restrict__ nms_dense, unsigned long long *__restrict__ cand, int cand_cap,
-                        unsigned int *__restrict__ counters, unsigned int *__restrict__ hist)
-{
-    constexpr int N2_TH = N2_RH - 2 * N2_HALO, N2_AR = N2_RH + 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *S = reinterpret_cast<float *>(smem);                         // [RH][SP]
-    float *A = S + N2_RH * N2_SP;                                       // [RH + 8][RW]
-    unsigned long long *M = reinterpret_cast<unsigned long long *>(A + N2_AR * N2_RW);   // [RH][2]
-    unsigned long long *SU = M + 2 * N2_RH;
-    unsigned long long *TM = SU + 2 * N2_RH;
-    const float NEG = -INFINITY;
-    const int gy0 = blockIdx.y * N2_TH - N2_HALO, gx0 = blockIdx.x * N2_TW - N2_HALO;
-
-    for (int i = threadIdx.x; i < N2_RH * N2_SP; i += blockDim.x) {
-        const int y = i / N2_SP, xs = i - y * N2_SP;
-        const int gy = gy0 + y, gx = gx0 + xs - 4;
-        const bool in = xs >= 4 && xs < 4 + N2_RW && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        S[i] = in ? heat[(size_t)gy * W + gx] : NEG;
-    }
-    for (int i = threadIdx.x; i < 4 * N2_RW; i += blockDim.x) {          // -inf rows above / below A
-        A[i] = NEG;
-        A[(N2_RH + 4) * N2_RW + i] = NEG;
-    }
-    __syncthreads();
-    n2_row_pass<false, N2_RH>(S, A, nullptr);
-    __syncthreads();
-    n2_col_pass<false, N2_RH>(S, A, nullptr, M);                                // max_mask = scores == max_pool(scores)
-    __syncthreads();
-    for (int it = 0; it < 2; ++it) {
-        n2_dilate<N2_RH>(M, TM, SU);                                            // supp_mask = max_pool(max_mask) > 0
-        n2_row_pass<true, N2_RH>(S, A, SU);
-        __syncthreads();
-        n2_col_pass<true, N2_RH>(S, A, SU, M);                                  // max_mask |= new_max_mask & ~supp_mask
-        __syncthreads();
-    }
-    // Candidates are first gathered per block in LDS (the A plane is free now) so that the global
-    // cursor sees ONE atomic per block: tens of thousands of same-address atomics (~12 ns each at
-    // the L2) were the whole cost of this kernel.
-    unsigned long long *lkeys = reinterpret_cast<unsigned long long *>(A);   // <= TH * 88 keys (16.5 / 66 KB), A holds AR * 128 floats
-    // (all LDS stays in the one dynamic array: a static __shared__ would shift its 16-byte base)
-    unsigned int &l_cnt = reinterpret_cast<unsigned int *>(TM + 2 * N2_RH)[0];
-    unsigned int &l_base = reinterpret_cast<unsigned int *>(TM + 2 * N2_RH)[1];
-    if (threadIdx.x == 0) l_cnt = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < N2_TH * N2_TW; i0 += blockDim.x) {             // wave-uniform trip count (ballots below)
-        const int i = i0 + threadIdx.x;
-        const int ty = i / N2_TW, tx = i - ty * N2_TW;
-        const int gy = blockIdx.y * N2_TH + ty, gx = blockIdx.x * N2_TW + tx;
-        bool is_cand = false;
-        unsigned long long key = 0ull;
-        if (i < N2_TH * N2_TW && gy < H && gx < W) {
-            const int ry = ty + N2_HALO, rx = tx + N2_HALO;
-            const bool mk = (M[2 * ry + (rx >> 6)] >> (rx & 63)) & 1ull;
-            const float v = mk ? S[ry * N2_SP + 4 + rx] : 0.0f;          // where(max_mask, scores, zeros)
-            if (nms_dense) nms_dense[(size_t)gy * W + gx] = v;
-            if (cand && v > conf_th && gx >= border && gx < Wb - border && gy >= border && gy < Hb - border) {
-                const unsigned int idx = (unsigned int)(gy * W + gx);
-                key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
-                is_cand = true;
-            }
-        }
-        // one LDS atomic per wave (a few hundred same-address atomics per block serialise otherwise)
-        const unsigned long long mc = __ballot(is_cand);
-        if (mc) {
-            const int lane = threadIdx.x & 63;
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(&l_cnt, (unsigned int)__popcll(mc));
-            base = __shfl(base, 0);
-            if (is_cand) lkeys[base + (unsigned int)__popcll(mc & ((1ull << lane) - 1ull))] = key;
-        }
-    }
-    __syncthreads();
-    if (!cand || l_cnt == 0) return;
-    if (threadIdx.x == 0) l_base = atomicAdd(&counters[0], l_cnt);
-    __syncthreads();
-    for (unsigned int i = threadIdx.x; i < l_cnt; i += blockDim.x) {
-        const unsigned int pos = l_base + i;
-        if (pos < (unsigned int)cand_cap) {
-            const unsigned long long key = lkeys[i];
-            cand[pos] = key;
-            atomicAdd(&hist[key_bin(key)], 1u);
-        }
-    }
-}
-
 // generic-radius kernel also feeds the histogram (same key -> bin map)
 __global__ __launch_bounds__(NT)
 void hist_from_cand_kernel(const unsigned long long *__restrict__ cand, int cand_cap,
@@ -588,30 +370,8 @@ void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radi
                        float *nms_dense, unsigned long long *cand, int cand_cap, unsigned int *counters)
 {
     unsigned int *hist = counters + 16;   // counters[0..15], then SFD2_HIST_BINS histogram bins
-    if (radius == 4) {
-        // The kernel is VALU-issue bound (profiles/r02_nms_pmc.txt: 1 215 VALU instructions per thread, 8 waves per SIMD),
-        // so what counts is the number of REGION pixels the busiest CU has to process.  Two tile heights: 24 rows (region
-        // 64 x 128, 73 KB of LDS, two blocks per CU, 3.9x halo overhead) or 96 rows (region 136 x 128, 155 KB, one block
-        // per CU, 2.1x) -- whichever gives the busiest CU less to do for this image (1600x1200: 247 big tiles = one
-        // round on 256 CUs instead of 950 small ones).
-        static bool attr4 = false;
-        auto lds_of = [](int rh) { return (size_t)(rh * N2_SP + (rh + 8) * N2_RW) * sizeof(float) + 3 * 2 * rh * sizeof(unsigned long long) + 16; };
-        if (!attr4) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms4_select_kernel<64>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(64));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms4_select_kernel<136>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(136));
-            attr4 = true;
-        }
-        const int gx = (W + N2_TW - 1) / N2_TW;
-        const long long nb_s = (long long)gx * ((H + 23) / 24), nb_b = (long long)gx * ((H + 95) / 96);
-        const long long work_s = ((nb_s + 511) / 512) * 2 * 64, work_b = ((nb_b + 255) / 256) * 136;   // region rows on the busiest CU
-        static const char *force = sfd2_env("SFD2_NMS_TILE");
-        const bool big = force ? force[0] == 'b' : work_b < work_s;
-        if (big) hipLaunchKernelGGL(nms4_select_kernel<136>, dim3(gx, (H + 95) / 96), dim3(1024), lds_of(136), st, heat, H, W, conf_th,
-                                    border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist);
-        else hipLaunchKernelGGL(nms4_select_kernel<64>, dim3(gx, (H + 23) / 24), dim3(1024), lds_of(64), st, heat, H, W, conf_th,
-                                border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist);
+    if (radius == 4) {   // nms4_kernels.hip
+        launch_nms4_select(st, heat, H, W, conf_th, border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist);
         return;
     }
     static bool attr_done = false;

@@ -115,6 +115,19 @@ void launch_topk_sort(hipStream_t st, const unsigned long long *cand, int cand_c
                       unsigned long long *bnd, int W, float *kpts, float *scores);   // kpts/scores: output rows (x, y), score
 #define SFD2_HIST_BINS 4096                   // score bits >> 15, rebased to [2^-12, 2^4) and clamped (post_kernels.hip key_bin)
 #define SFD2_COUNTER_BYTES (64 + SFD2_HIST_BINS * 4)   // 16 counters + score histogram
+// histogram bin of a candidate key (score bits << 32 | ~index): the 16 exponent + mantissa bits below the sign, rebased
+// so that bin 0 starts at 2^-12 and the last bin ends at 2^4, clamped.  Monotone in the score, which is all the
+// threshold search needs: keys above the boundary bin are selected outright, the boundary bin is ranked exactly.
+// (Heat-map scores are products of a soft-max probability and a stability weight: (0, 1].)
+__device__ __forceinline__ unsigned int key_bin(unsigned long long key)
+{
+    const int b = (int)((unsigned int)(key >> 47) & 0xFFFFu) - ((127 - 12) << 8);
+    return (unsigned int)(b < 0 ? 0 : (b > SFD2_HIST_BINS - 1 ? SFD2_HIST_BINS - 1 : b));
+}
+
+// nms4_kernels.hip: simple_nms with radius 4 + threshold + border + compaction (launch_nms_select serves other radii)
+void launch_nms4_select(hipStream_t st, const float *heat, int H, int W, float conf_th, int border, int Hb, int Wb, float *nms_dense,
+                        unsigned long long *cand, int cand_cap, unsigned int *counters, unsigned int *hist);
 // greedy grid NMS of extract.py (nms_fast): init / one relaxation sweep / kept-score map
 void launch_greedy_init(hipStream_t st, const float *heat, int n, float conf_th, unsigned long long *keys, unsigned char *state);
 void launch_greedy_iter(hipStream_t st, const unsigned long long *keys, const unsigned char *sin, unsigned char *sout,
