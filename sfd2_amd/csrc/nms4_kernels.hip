@@ -37,12 +37,18 @@ __device__ __forceinline__ void pool8(const float (&v)[16], float (&o)[8])
 // the next, so round 2 and the column passes read the suppressed map directly.  Neighbouring threads read those
 // columns as part of their 16-wide windows while they are being rewritten; every reader applies the same bits itself,
 // so it sees the same values either way.
-template <bool MASKED, int N2_RH>
+//
+// Only the tile has to be exact at the end, and every round consumes 8 rows / columns of halo (4 for the dilation, 4 for the
+// pool): round K's row pass covers rows [8K, RH - 8K) and the 8-column units [K, 16 - K), its column pass the 8-row
+// blocks [K, RH / 8 - K).  Words and values outside those ranges go stale; nothing inside the next round's range reads them.
+template <bool MASKED, int N2_RH, int K>
 __device__ __forceinline__ void n2_row_pass(float *__restrict__ S, float *__restrict__ A,
                                             const unsigned long long *__restrict__ supp)
 {
-    for (int u = threadIdx.x; u < N2_RH * 16; u += blockDim.x) {
-        const int y = u >> 4, x0 = (u & 15) * 8;
+    constexpr int Y0 = 8 * K, NY = N2_RH - 16 * K, U0 = K, NU = 16 - 2 * K;
+    for (int i = threadIdx.x; i < NY * NU; i += blockDim.x) {
+        const int yy = i / NU;
+        const int y = Y0 + yy, x0 = (U0 + i - yy * NU) * 8;
         float v[16];
         const float4 *src = reinterpret_cast<const float4 *>(S + y * N2_SP + x0);   // region cols x0-4 .. x0+11
 #pragma unroll
@@ -78,13 +84,13 @@ __device__ __forceinline__ void n2_row_pass(float *__restrict__ S, float *__rest
 
 // Column pass + compare: eq[y] = ballot(s == max_pool(s)) on the (suppressed) score map, 64 columns per word.  Which of
 // these bits count (inside the image, not suppressed) is settled on whole words by n2_merge / n2_dilate.
-template <int N2_RH>
+template <int N2_RH, int K>
 __device__ __forceinline__ void n2_col_pass(const float *__restrict__ S, const float *__restrict__ A,
                                             unsigned long long *__restrict__ eq)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int u = wave; u < (N2_RH / 8) * 2; u += nw) {
-        const int k = u >> 1, h = u & 1, x = h * 64 + lane;
+    for (int u = wave; u < (N2_RH / 8 - 2 * K) * 2; u += nw) {
+        const int k = K + (u >> 1), h = u & 1, x = h * 64 + lane;
         float a[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) a[i] = A[(8 * k + i) * N2_RW + x];
@@ -183,19 +189,19 @@ void nms4_select_kernel(const float *__restrict__ heat, int H, int W, float conf
         VL[u] = w;
     }
     __syncthreads();
-    n2_row_pass<false, N2_RH>(S, A, nullptr);
+    n2_row_pass<false, N2_RH, 0>(S, A, nullptr);
     __syncthreads();
-    n2_col_pass<N2_RH>(S, A, EQ);                                               // max_mask = scores == max_pool(scores)
+    n2_col_pass<N2_RH, 0>(S, A, EQ);                                            // max_mask = scores == max_pool(scores)
     __syncthreads();
     n2_dilate<N2_RH, true>(M, TM, SU, EQ, VL);                                  // supp_mask = max_pool(max_mask) > 0
-    n2_row_pass<true, N2_RH>(S, A, SU);
+    n2_row_pass<true, N2_RH, 1>(S, A, SU);
     __syncthreads();
-    n2_col_pass<N2_RH>(S, A, EQ);
+    n2_col_pass<N2_RH, 1>(S, A, EQ);
     __syncthreads();
     n2_dilate<N2_RH, false>(M, TM, SU, EQ, VL);                                 // max_mask |= new_max_mask & ~supp_mask; next supp
-    n2_row_pass<true, N2_RH>(S, A, SU);
+    n2_row_pass<true, N2_RH, 2>(S, A, SU);
     __syncthreads();
-    n2_col_pass<N2_RH>(S, A, EQ);
+    n2_col_pass<N2_RH, 2>(S, A, EQ);
     __syncthreads();
     for (int u = threadIdx.x; u < N2_RH * 2; u += blockDim.x) M[u] = n2_merged<false>(M, EQ, VL, SU, u);
     // Candidates are first gathered per block in LDS (the A plane is free now) so that the global
