@@ -169,11 +169,25 @@ void nms4_select_kernel(const float *__restrict__ heat, int H, int W, float conf
     const float NEG = -INFINITY;
     const int gy0 = blockIdx.y * N2_TH - N2_HALO, gx0 = blockIdx.x * N2_TW - N2_HALO;
 
-    for (int i = threadIdx.x; i < N2_RH * N2_SP; i += blockDim.x) {
-        const int y = i / N2_SP, xs = i - y * N2_SP;
-        const int gy = gy0 + y, gx = gx0 + xs - 4;
-        const bool in = xs >= 4 && xs < 4 + N2_RW && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        S[i] = in ? heat[(size_t)gy * W + gx] : NEG;
+    // region -> S in groups of four columns (34 per row: the region's 32 and the two -inf pads); gx0 is a multiple of 4, so
+    // with W % 4 == 0 a group is one aligned 16-byte load
+    const bool w4 = (W & 3) == 0;
+    for (int i = threadIdx.x; i < N2_RH * (N2_SP / 4); i += blockDim.x) {
+        const int y = i / (N2_SP / 4), g = i - y * (N2_SP / 4);
+        const int gy = gy0 + y, gx = gx0 + 4 * g - 4;
+        float4 v = make_float4(NEG, NEG, NEG, NEG);
+        if (g >= 1 && g <= N2_RW / 4 && gy >= 0 && gy < H && gx + 3 >= 0 && gx < W) {
+            const float *row = heat + (size_t)gy * W;
+            if (w4 && gx >= 0 && gx + 3 < W) {
+                v = *reinterpret_cast<const float4 *>(row + gx);
+            } else {
+                if (gx >= 0) v.x = row[gx];
+                if (gx + 1 >= 0 && gx + 1 < W) v.y = row[gx + 1];
+                if (gx + 2 >= 0 && gx + 2 < W) v.z = row[gx + 2];
+                if (gx + 3 < W) v.w = row[gx + 3];
+            }
+        }
+        *reinterpret_cast<float4 *>(S + y * N2_SP + 4 * g) = v;
     }
     for (int i = threadIdx.x; i < 4 * N2_RW; i += blockDim.x) {          // -inf rows above / below A
         A[i] = NEG;
