@@ -169,8 +169,10 @@ __global__ __launch_bounds__(NT)
 void pb_heads_heat_kernel(const half_t *__restrict__ fmap /*[cells][256]*/, int hc8, int wc8,
                           const half_t *__restrict__ wpk /*[8 chunks][CoutP][32]*/, int CoutP, const float *__restrict__ scale,
                           const float *__restrict__ shift, const float *__restrict__ sta, int hc, int wc, float st_y, float st_x,
-                          int H, int W, float *__restrict__ heat)
+                          int H, int W, float *__restrict__ heat, unsigned int *__restrict__ zero_words, int n_zero)
 {
+    // the selection counters + score histogram that the NMS kernel behind this one appends to (saves a memset node)
+    if (zero_words && (int)(blockIdx.x * blockDim.x + threadIdx.x) < n_zero) zero_words[blockIdx.x * blockDim.x + threadIdx.x] = 0u;
     __shared__ __attribute__((aligned(16))) unsigned char X[PH_CELLS * PH_XREC];
     __shared__ __attribute__((aligned(16))) float O[PH_CELLS * PH_OREC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -237,13 +239,18 @@ void pb_heads_heat_kernel(const half_t *__restrict__ fmap /*[cells][256]*/, int 
 }
 
 void launch_pb_heads_heat(hipStream_t st, const half_t *fmap, int hc8, int wc8, const half_t *wpk, int CoutP, const float *scale,
-                          const float *shift, const float *sta, int hc, int wc, int H, int W, float *heat)
+                          const float *shift, const float *sta, int hc, int wc, int H, int W, float *heat, unsigned int *zero_words,
+                          int n_zero)
 {
     const float st_y = hc > 0 ? (float)hc / (float)H : 1.0f, st_x = wc > 0 ? (float)wc / (float)W : 1.0f;   // as launch_heatmap
     const int cells = hc8 * wc8;
-    hipLaunchKernelGGL(pb_heads_heat_kernel, dim3((cells + PH_CELLS - 1) / PH_CELLS), dim3(NT), 0, st, fmap, hc8, wc8, wpk, CoutP,
-                       scale, shift, sta, hc, wc, st_y, st_x, H, W, heat);
+    const int grid = (cells + PH_CELLS - 1) / PH_CELLS;
+    if (grid * NT < n_zero) zero_words = nullptr;          // (tiny images: the caller keeps its memset)
+    hipLaunchKernelGGL(pb_heads_heat_kernel, dim3(grid), dim3(NT), 0, st, fmap, hc8, wc8, wpk, CoutP,
+                       scale, shift, sta, hc, wc, st_y, st_x, H, W, heat, zero_words, n_zero);
 }
+
+bool pb_heads_heat_clears(int hc8, int wc8, int n_zero) { return ((hc8 * wc8 + PH_CELLS - 1) / PH_CELLS) * NT >= n_zero; }
 
 // ---------------------------------------------------------------- simple_nms (+ threshold/border/compaction)
 // One block = 32 x 64 output pixels, LDS region = tile + 5*radius halo (radius 4 -> 72 x 104):

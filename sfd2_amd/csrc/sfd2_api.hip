@@ -75,6 +75,7 @@ struct sfd2_ctx {
     void *pin_jobs = nullptr;
     size_t pin_cap = 0;
     bool weights_loaded = false;
+    bool counters_clean = false;       // the kernel in front of the selection cleared the counters (pb_heads_heat_kernel)
     bool has_sta = false;              // ConvSta present in the loaded state_dict (absent for require_stability=False models)
     int opt_alias = 1;                 // sfd2_set_option "alias"
     int fuse_det = 0;                  // sfd2_set_option "fuse_det"
@@ -945,7 +946,8 @@ static int run_selection(sfd2_ctx *c, const float *heat_dev, int H, int W, float
     HIPCHECK(c->sorted.ensure((size_t)sel_cap * 8));
     HIPCHECK(c->kpts.ensure((size_t)sel_cap * 2 * sizeof(float)));
     HIPCHECK(c->kscores.ensure((size_t)sel_cap * sizeof(float)));
-    HIPCHECK(hipMemsetAsync(c->counters.p, 0, SFD2_COUNTER_BYTES, c->stream));
+    if (!c->counters_clean) HIPCHECK(hipMemsetAsync(c->counters.p, 0, SFD2_COUNTER_BYTES, c->stream));
+    c->counters_clean = false;
     {
         ProfScope ps(c, "nms_select", "nms_select_kernel", 0.0, (double)H * W * 4);
         launch_nms_select(c->stream, heat_dev, H, W, radius, conf_th, border, Hb, Wb, nms_dense,
@@ -1024,7 +1026,8 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
                      (double)c->H8 * c->W8 * 512 + (double)H * W * 4);
         launch_pb_heads_heat(c->stream, c->pa_cur, c->H8, c->W8, c->pb.w.as<half_t>(), c->pb.cout_pad, c->pb.scale.as<float>(),
                              c->pb.shift.as<float>(), (flags & SFD2_FLAG_NO_STABILITY) ? nullptr : c->sta.as<float>(), c->H4, c->W4,
-                             H, W, c->heat.as<float>());
+                             H, W, c->heat.as<float>(), c->counters.as<unsigned int>(), SFD2_COUNTER_BYTES / 4);
+        c->counters_clean = pb_heads_heat_clears(c->H8, c->W8, SFD2_COUNTER_BYTES / 4);
     } else if (fuse_post) {
         ProfScope ps(c, "heads+heatmap", "heads_heat_kernel", 0.0, (double)c->H8 * c->W8 * 65 * 4 + (double)H * W * 4);
         launch_heads_heat(c->stream, c->logits.as<float>(), 128, c->H8, c->W8,

@@ -142,7 +142,9 @@ void launch_sample_desc(hipStream_t st, const float *desc_nhwc, int hc, int wc, 
                         float *out);
 // sparse descriptor head (extract path): gather the key points' bilinear corner pixels, convDb on them, sample -- one kernel
 void launch_pb_heads_heat(hipStream_t st, const half_t *fmap, int hc8, int wc8, const half_t *wpk, int CoutP, const float *scale,
-                          const float *shift, const float *sta, int hc, int wc, int H, int W, float *heat);
+                          const float *shift, const float *sta, int hc, int wc, int H, int W, float *heat,
+                          unsigned int *zero_words /*nullable: n_zero words cleared if the grid covers them*/, int n_zero);
+bool pb_heads_heat_clears(int hc8, int wc8, int n_zero);
 void launch_desc_head(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, int CoutP,
                       const float *scale, const float *shift, const float *kpts, const unsigned int *count, int n_max, float *out);
 // desc_raw NHWC [P][128] -> normalised NCHW [128][P]
