@@ -1594,8 +1594,8 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     HIPCHECK(c->m_part_i.ensure(std::max<size_t>(tot_part, 1) * sizeof(int)));
     if (single_gemm) HIPCHECK(c->m_rkeys.ensure(std::max<size_t>((size_t)nstrip * tot_n1, 1) * sizeof(float)));
     HIPCHECK(c->m_red.ensure(((size_t)k * n0 + tot_n1 + 1) * 3 * sizeof(float)));
-    HIPCHECK(c->m_jobs.ensure((size_t)2 * k * sizeof(MatchJob)));
-    HIPCHECK(c->m_fins.ensure((size_t)k * sizeof(MatchFinal)));
+    // job and final descriptors share one device block (jobs first), filled by ONE copy from the pinned block
+    HIPCHECK(c->m_jobs.ensure((size_t)2 * k * sizeof(MatchJob) + (size_t)k * sizeof(MatchFinal)));
     HIPCHECK(c->m_out_m.ensure((size_t)k * n0 * sizeof(long long)));
     HIPCHECK(c->m_out_s.ensure((size_t)k * n0 * sizeof(float)));
 
@@ -1669,19 +1669,19 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
         fn.red_f = red + 3 * roff; roff += (size_t)n0;
         fn.red_r = red + 3 * roff; roff += (size_t)n1;
     }
-    HIPCHECK(hipMemcpyAsync(c->m_jobs.p, jobs, jobs_bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(hipMemcpyAsync(c->m_fins.p, fins, fins_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->m_jobs.p, jobs, jobs_bytes + fins_bytes, hipMemcpyHostToDevice, c->stream));
+    MatchFinal *fins_dev = reinterpret_cast<MatchFinal *>(static_cast<char *>(c->m_jobs.p) + jobs_bytes);
     if (!capturing) HIPCHECK(hipEventRecord(c->ev_jobs, c->stream));
     if (single_gemm) {
         {
             ProfScope ps(c, "match_mutual", "match_mutual_kernel", 2.0 * (double)n0 * (double)tot_n1 * 128.0,
                          2.0 * ((double)k * n0 + (double)tot_n1) * 128.0);
-            launch_match_mutual(c->stream, c->m_jobs.as<MatchJob2>(), c->m_fins.as<MatchFinal>(), k, n0, max_n1, splits,
+            launch_match_mutual(c->stream, c->m_jobs.as<MatchJob2>(), fins_dev, k, n0, max_n1, splits,
                                 c->zero_page.as<half_t>());
         }
         {
             ProfScope ps(c, "match_finalize", "match_decide", 0.0, (double)tot_part * 12);
-            launch_match_decide(c->stream, c->m_fins.as<MatchFinal>(), k, max_n, conf->flavour, conf->do_mutual_check,
+            launch_match_decide(c->stream, fins_dev, k, max_n, conf->flavour, conf->do_mutual_check,
                                 conf->ratio_threshold, conf->distance_threshold);
         }
     } else {
@@ -1695,7 +1695,7 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
         }
         {
             ProfScope ps(c, "match_finalize", "match_reduce+decide", 0.0, (double)tot_part * 12);
-            launch_match_finalize(c->stream, c->m_fins.as<MatchFinal>(), k, max_n, splits, conf->flavour,
+            launch_match_finalize(c->stream, fins_dev, k, max_n, splits, conf->flavour,
                                   conf->do_mutual_check, conf->ratio_threshold, conf->distance_threshold);
         }
     }
@@ -1766,8 +1766,7 @@ extern "C" int sfd2_match_segments(sfd2_ctx *c, const void *d0, int n0, const vo
         for (int i : live) rk += (size_t)((seg0[i + 1] - seg0[i] + strip - 1) / strip) * (size_t)(seg1[i + 1] - seg1[i]);
         if (single_gemm) HIPCHECK(c->m_rkeys.ensure(std::max<size_t>(rk, 1) * sizeof(float)));
         HIPCHECK(c->m_red.ensure(((size_t)n0 + n1 + 1) * 3 * sizeof(float)));
-        HIPCHECK(c->m_jobs.ensure((size_t)2 * k * sizeof(MatchJob)));
-        HIPCHECK(c->m_fins.ensure((size_t)k * sizeof(MatchFinal)));
+        HIPCHECK(c->m_jobs.ensure((size_t)2 * k * sizeof(MatchJob) + (size_t)k * sizeof(MatchFinal)));
         prof_step_begin(c);
         size_t stage_off = 0;
         const half_t *h0 = nullptr, *l0 = nullptr, *h1 = nullptr, *l1 = nullptr;
@@ -1829,20 +1828,20 @@ extern "C" int sfd2_match_segments(sfd2_ctx *c, const void *d0, int n0, const vo
             fn.red_f = red + 3 * roff; roff += (size_t)na;
             fn.red_r = red + 3 * roff; roff += (size_t)nb;
         }
-        HIPCHECK(hipMemcpyAsync(c->m_jobs.p, jobs, jobs_bytes, hipMemcpyHostToDevice, c->stream));
-        HIPCHECK(hipMemcpyAsync(c->m_fins.p, fins, fins_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipMemcpyAsync(c->m_jobs.p, jobs, jobs_bytes + fins_bytes, hipMemcpyHostToDevice, c->stream));
+        MatchFinal *fins_dev = reinterpret_cast<MatchFinal *>(static_cast<char *>(c->m_jobs.p) + jobs_bytes);
         HIPCHECK(hipEventRecord(c->ev_jobs, c->stream));
         const int max_n = std::max(max_a, max_b);
         if (single_gemm) {
             ProfScope ps(c, "match_segments", "match_mutual_kernel", 0.0, 0.0);
-            launch_match_mutual(c->stream, c->m_jobs.as<MatchJob2>(), c->m_fins.as<MatchFinal>(), k, max_a, max_b, splits,
+            launch_match_mutual(c->stream, c->m_jobs.as<MatchJob2>(), fins_dev, k, max_a, max_b, splits,
                                 c->zero_page.as<half_t>());
-            launch_match_decide(c->stream, c->m_fins.as<MatchFinal>(), k, max_n, conf->flavour, conf->do_mutual_check,
+            launch_match_decide(c->stream, fins_dev, k, max_n, conf->flavour, conf->do_mutual_check,
                                 conf->ratio_threshold, conf->distance_threshold);
         } else {
             ProfScope ps(c, "match_segments", "match_top2_kernel", 0.0, 0.0);
             launch_match_top2(c->stream, c->m_jobs.as<MatchJob>(), 2 * k, max_n, splits, need_lo, need_top2, c->zero_page.as<half_t>());
-            launch_match_finalize(c->stream, c->m_fins.as<MatchFinal>(), k, max_n, splits, conf->flavour, conf->do_mutual_check,
+            launch_match_finalize(c->stream, fins_dev, k, max_n, splits, conf->flavour, conf->do_mutual_check,
                                   conf->ratio_threshold, conf->distance_threshold);
         }
         prof_step_end(c);
@@ -1978,8 +1977,7 @@ extern "C" int sfd2_extract_match(sfd2_ctx *c, const void *img_dev, int H, int W
     if (!e->pin) {
         HIPCHECK(hipHostMalloc(&e->pin, jb + fb, hipHostMallocDefault));
         e->pin_cap = jb + fb;
-        HIPCHECK(e->jobs.ensure(jb));
-        HIPCHECK(e->fins.ensure(fb));
+        HIPCHECK(e->jobs.ensure(jb + fb));
     }
     HIPCHECK(hipStreamSynchronize(c->stream));
     HIPCHECK(hipEventSynchronize(c->ev_jobs));
