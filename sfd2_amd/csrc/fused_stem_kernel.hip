@@ -67,12 +67,10 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
                                          (lds_void_t *)(Wt + t * 8192 + wave * 1024), 16, 0, 0);
     }
     if (tid < 64) { SS[tid] = sc1[tid]; SS[64 + tid] = sh1[tid]; SS[128 + tid] = sc2[tid]; SS[192 + tid] = sh2[tid]; }
-    h8_t a1[2][3];
+    h8_t a1[3];                        // conv1a filter fragments of this wave's 32-channel half (wave & 1)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-            a1[ct][ky] = *reinterpret_cast<const h8_t *>(w1 + ((size_t)(ct * 3 + ky) * 64 + lane) * 8);
+    for (int ky = 0; ky < 3; ++ky)
+        a1[ky] = *reinterpret_cast<const h8_t *>(w1 + ((size_t)((wave & 1) * 3 + ky) * 64 + lane) * 8);
 
     // raw image values of this thread's F_IPT patch pixels (fp32 planes or uint8 HWC), fetched one tile ahead
     float pr[F_IPT][3];
@@ -127,16 +125,18 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
         const int oy0 = ty * F_TH, ox0 = tx * F_TW;
         const int ry0 = 2 * oy0 - 1, rx0 = 2 * ox0 - 1;               // image coords of conv1a region pixel (0, 0)
 
-        // ---- phase 1: conv1a on the 585 region pixels, 32 per MFMA column block
-        for (int t = wave; t < (F_RP + 31) / 32; t += NT / 64) {
+        // ---- phase 1: conv1a on the 585 region pixels, 32 per MFMA column block.  A unit of work is (column block, 32-channel
+        // half): 38 units over 8 waves = at most 5 per wave (whole blocks were 3 + 3 + 3 + 2 + ... = 6 half-units on the
+        // busiest waves); a wave's half is fixed (wave & 1), so it keeps three filter fragments instead of six.  (Measured: 85.0 ->
+        // 84.4 us -- the phases are serialised VALU / LDS / MFMA sections, not this imbalance.)
+        const int ct1 = wave & 1;
+        for (int t = wave >> 1; t < (F_RP + 31) / 32; t += NT / 128) {
             const int p = t * 32 + lrow;
             const int pc = p < F_RP ? p : F_RP - 1;
             const int ry = pc / F_RW, rx = pc - ry * F_RW;
-            f32x16_t acc[2];
+            f32x16_t acc;
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int q = (ry + ky) * F_IW + rx + 2 * lhi;
@@ -145,9 +145,7 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
                 h8_t b;
                 b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3];
                 b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ct][ky], b, acc[ct], 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ky], b, acc, 0, 0, 0);
             }
             // conv1b zero-pads conv1a's OUTPUT: region pixels outside the image are zeros, not conv1a(0)
             const int gy = ry0 + ry, gx = rx0 + rx;
@@ -155,20 +153,18 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
             if (p < F_RP) {
                 const int sw = (p >> 1) & 7;
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c0 = ct * 32 + 8 * q + 4 * lhi;
-                        const float4 s = *reinterpret_cast<const float4 *>(SS + c0);
-                        const float4 h = *reinterpret_cast<const float4 *>(SS + 64 + c0);
-                        h4_t v = f_cvt4(0.f, 0.f, 0.f, 0.f);
-                        if (inside)
-                            v = f_cvt4(fmaxf(acc[ct][4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc[ct][4 * q + 1] * s.y + h.y, 0.0f),
-                                       fmaxf(acc[ct][4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc[ct][4 * q + 3] * s.w + h.w, 0.0f));
-                        // records are stored pair-swapped where bit 4 of the index is set: the stride-2 reads of phase 2
-                        // (lanes 256 B apart) then alternate between the two 128-byte halves of the bank space
-                        *reinterpret_cast<h4_t *>(X1 + (p ^ ((p >> 4) & 1)) * 128 + (((c0 >> 3) ^ sw) << 4) + (c0 & 4) * 2) = v;
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = ct1 * 32 + 8 * q + 4 * lhi;
+                    const float4 s = *reinterpret_cast<const float4 *>(SS + c0);
+                    const float4 h = *reinterpret_cast<const float4 *>(SS + 64 + c0);
+                    h4_t v = f_cvt4(0.f, 0.f, 0.f, 0.f);
+                    if (inside)
+                        v = f_cvt4(fmaxf(acc[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc[4 * q + 1] * s.y + h.y, 0.0f),
+                                   fmaxf(acc[4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc[4 * q + 3] * s.w + h.w, 0.0f));
+                    // records are stored pair-swapped where bit 4 of the index is set: the stride-2 reads of phase 2
+                    // (lanes 256 B apart) then alternate between the two 128-byte halves of the bank space
+                    *reinterpret_cast<h4_t *>(X1 + (p ^ ((p >> 4) & 1)) * 128 + (((c0 >> 3) ^ sw) << 4) + (c0 & 4) * 2) = v;
+                }
             }
         }
         const int next = tile + (int)gridDim.x;
