@@ -721,12 +721,13 @@ void launch_sample_desc(hipStream_t st, const float *dmap, int hc, int wc, int n
 // AFTER the selection, on those pixels only, and the 61 MB fp32 descriptor map is never written.  Same-box A/B
 // (tools/ab_option.py sparse_desc 0 1): 1.135 -> 1.083 ms per extract -- 52 us, of which only 18 are the kernels' own
 // (dense convDb 28 + sampling 9.5 vs 19): the rest is what the map's write cost the kernels after it.
-// The three steps in ONE kernel: a block takes 16 key points, gathers their 64 corner pixels (256 fp16 channels each) into
+// The three steps in ONE kernel: a block takes 8 key points, gathers their 64 corner pixels (256 fp16 channels each) into
 // LDS, runs convDb on them with MFMAs (128 out channels x 64 pixels x K = 256; wave w owns channels 32w .. 32w + 31, its
 // filter fragments come straight from the packed filters in L2), parks the fp32 result in LDS and samples it.  K ascends
 // in 16-wide slices into one accumulator and the epilogue is acc * scale + shift, exactly as conv_igemm2 computes the
 // dense map, so the descriptors are bit-identical to the dense path's.
-#define DH_KP 16
+#define DH_KP 8         // key points per block: 32 corner records = one MFMA tile; 512 blocks for 4 096 key points, two per CU
+                        // (16 per block: 17.5 us, 8: 12.7 us -- the kernel is a chain of memory round trips, concurrency hides them)
 #define DH_XREC 528      // bytes per gathered pixel record: 512 + 16 pad (conflict-free ds_read_b128)
 #define DH_OREC 132      // floats per conv output record: 128 + 4 pad
 __global__ __launch_bounds__(NT)
@@ -750,35 +751,54 @@ void desc_head_kernel(const half_t *__restrict__ fmap /*[hc][wc][256]*/, int hc,
     for (int kk = 0; kk < 16; ++kk)
         a[kk] = *reinterpret_cast<const h8_t *>(wpk + ((size_t)(kk >> 1) * CoutP + wave * 32 + lrow) * 32 + (kk & 1) * 16 + lhi * 8);
 
-    // gather: half a wave per pixel record (32 lanes x 16 B), zeros for corners outside the map / key points past the count
-    for (int rec = wave * 2 + lhi; rec < 4 * DH_KP; rec += 8) {
+    // gather: half a wave per pixel record (32 lanes x 16 B), zeros for corners outside the map / key points past the count.
+    // Written as three unrolled stages (coordinates, map loads, LDS stores) with unconditional loads from a clamped
+    // address: as one loop with the loads under their conditions, the eight records of a half-wave were eight
+    // back-to-back memory round trips (coordinate, then pixel), most of this kernel's 19 us.
+    constexpr int DH_NR = 4 * DH_KP / 8;
+    float kx[DH_NR], ky[DH_NR];
+#pragma unroll
+    for (int i = 0; i < DH_NR; ++i) {
+        const int kp = k0 + ((wave * 2 + lhi + 8 * i) >> 2);
+        const int kc = kp < n ? kp : n - 1;
+        kx[i] = kpts[2 * kc];
+        ky[i] = kpts[2 * kc + 1];
+    }
+    uint4 gv[DH_NR];
+    bool gok[DH_NR];
+#pragma unroll
+    for (int i = 0; i < DH_NR; ++i) {
+        const int rec = wave * 2 + lhi + 8 * i;
         const int kp = k0 + (rec >> 2), corner = rec & 3;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (kp < n) {
-            const SampleGeom g = sample_geom(kpts[2 * kp], kpts[2 * kp + 1], half_w, half_h, hc, wc);
-            const int yy = (corner & 2) ? g.y1 : g.y0, xx = (corner & 1) ? g.x1 : g.x0;
-            const bool ok = ((corner & 2) ? g.vy1 : g.vy0) && ((corner & 1) ? g.vx1 : g.vx0);
-            if (ok) v = *reinterpret_cast<const uint4 *>(fmap + ((size_t)yy * wc + xx) * 256 + lrow * 8);
-        }
-        *reinterpret_cast<uint4 *>(X + rec * DH_XREC + lrow * 16) = v;
+        const SampleGeom g = sample_geom(kx[i], ky[i], half_w, half_h, hc, wc);
+        const int yy = (corner & 2) ? g.y1 : g.y0, xx = (corner & 1) ? g.x1 : g.x0;
+        gok[i] = kp < n && ((corner & 2) ? g.vy1 : g.vy0) && ((corner & 1) ? g.vx1 : g.vx0);
+        const size_t pix = gok[i] ? (size_t)yy * wc + xx : 0;
+        gv[i] = *reinterpret_cast<const uint4 *>(fmap + pix * 256 + lrow * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < DH_NR; ++i) {
+        const int rec = wave * 2 + lhi + 8 * i;
+        *reinterpret_cast<uint4 *>(X + rec * DH_XREC + lrow * 16) = gok[i] ? gv[i] : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
 
-    f32x16_t acc[2];
+    constexpr int DH_NT = 4 * DH_KP / 32;             // 32-record MFMA tiles
+    f32x16_t acc[DH_NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < DH_NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < DH_NT; ++t) {
             const h8_t b = *reinterpret_cast<const h8_t *>(X + (t * 32 + lrow) * DH_XREC + kk * 32 + lhi * 16);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], b, acc[t], 0, 0, 0);
         }
     // C layout: lane owns pixel (t * 32 + lrow), channels wave * 32 + 8 q + 4 lhi + j
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < DH_NT; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c0 = wave * 32 + 8 * q + 4 * lhi;
