@@ -211,9 +211,13 @@ void pb_heads_heat_kernel(const half_t *__restrict__ fmap /*[cells][256]*/, int 
         }
     }
     __syncthreads();
-    for (int j = wave; j < PH_CELLS; j += NT / 64) {
-        const int cell = c0cell + j;
-        if (cell >= ncell) break;
+    // (branch-free and unrolled by four: the twelve stability-map loads of a cell are then in flight for four cells at a
+    // time instead of one memory round trip per cell)
+#pragma unroll 4
+    for (int jj = 0; jj < PH_CELLS / (NT / 64); ++jj) {
+        const int j = wave + jj * (NT / 64);
+        const bool live = c0cell + j < ncell;
+        const int cell = live ? c0cell + j : ncell - 1;
         const int cy = cell / wc8, cx = cell - cy * wc8;
         const float *p = O + j * PH_OREC;
         const float e = expf(p[lane]);
@@ -234,7 +238,7 @@ void pb_heads_heat_kernel(const half_t *__restrict__ fmap /*[cells][256]*/, int 
             if (v2 > bv) { bv = v2; best = 2; }
             stab = best == 0 ? 0.1f : (best == 1 ? 0.5f : 1.0f);
         }
-        heat[(size_t)y * W + x] = __fmul_rn(s, stab);
+        if (live) heat[(size_t)y * W + x] = __fmul_rn(s, stab);
     }
 }
 
