@@ -155,7 +155,7 @@ template <int N2_RH>
 __global__ __launch_bounds__(1024)
 void nms4_select_kernel(const float *__restrict__ heat, int H, int W, float conf_th, int border, int Hb, int Wb,
                         float *__restrict__ nms_dense, unsigned long long *__restrict__ cand, int cand_cap,
-                        unsigned int *__restrict__ counters, unsigned int *__restrict__ hist)
+                        unsigned int *__restrict__ counters, unsigned int *__restrict__ hist, int fuse_threshold, int top_k)
 {
     constexpr int N2_TH = N2_RH - 2 * N2_HALO, N2_AR = N2_RH + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -255,21 +255,32 @@ void nms4_select_kernel(const float *__restrict__ heat, int H, int W, float conf
         }
     }
     __syncthreads();
-    if (!cand || l_cnt == 0) return;
-    if (threadIdx.x == 0) l_base = atomicAdd(&counters[0], l_cnt);
-    __syncthreads();
-    for (unsigned int i = threadIdx.x; i < l_cnt; i += blockDim.x) {
-        const unsigned int pos = l_base + i;
-        if (pos < (unsigned int)cand_cap) {
-            const unsigned long long key = lkeys[i];
-            cand[pos] = key;
-            atomicAdd(&hist[key_bin(key)], 1u);
+    if (!cand) return;
+    if (l_cnt != 0) {
+        if (threadIdx.x == 0) l_base = atomicAdd(&counters[0], l_cnt);
+        __syncthreads();
+        for (unsigned int i = threadIdx.x; i < l_cnt; i += blockDim.x) {
+            const unsigned int pos = l_base + i;
+            if (pos < (unsigned int)cand_cap) {
+                const unsigned long long key = lkeys[i];
+                cand[pos] = key;
+                atomicAdd(&hist[key_bin(key)], 1u);
+            }
         }
     }
+    if (!fuse_threshold) return;
+    // the last block to finish (ticket in counters[7]) searches the top-K threshold in the now complete histogram: the
+    // selection chain behind this kernel starts at the compaction (one launch less).  Histogram and count are atomics, read
+    // back with device-scope atomic loads: no fence (sfd2_select_threshold).
+    __syncthreads();                                     // this block's atomics are acknowledged (vmcnt(0))
+    if (threadIdx.x == 0) l_base = atomicAdd(&counters[7], 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!l_base) return;
+    sfd2_select_threshold<true>(cand_cap, top_k, counters, reinterpret_cast<unsigned int *>(lkeys));
 }
 
 void launch_nms4_select(hipStream_t st, const float *heat, int H, int W, float conf_th, int border, int Hb, int Wb, float *nms_dense,
-                        unsigned long long *cand, int cand_cap, unsigned int *counters, unsigned int *hist)
+                        unsigned long long *cand, int cand_cap, unsigned int *counters, unsigned int *hist, int fuse_threshold, int top_k)
 {
     // The kernel is VALU-issue bound (profiles/r02_nms_pmc.txt: 1 215 VALU instructions per thread, 8 waves per SIMD),
     // so what counts is the number of REGION pixels the busiest CU has to process.  Two tile heights: 24 rows (region
@@ -291,7 +302,7 @@ void launch_nms4_select(hipStream_t st, const float *heat, int H, int W, float c
     static const char *force = sfd2_env("SFD2_NMS_TILE");
     const bool big = force ? force[0] == 'b' : work_b < work_s;
     if (big) hipLaunchKernelGGL(nms4_select_kernel<136>, dim3(gx, (H + 95) / 96), dim3(1024), lds_of(136), st, heat, H, W, conf_th,
-                                border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist);
+                                border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist, fuse_threshold, top_k);
     else hipLaunchKernelGGL(nms4_select_kernel<64>, dim3(gx, (H + 23) / 24), dim3(1024), lds_of(64), st, heat, H, W, conf_th,
-                            border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist);
+                            border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist, fuse_threshold, top_k);
 }

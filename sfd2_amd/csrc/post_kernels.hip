@@ -377,13 +377,13 @@ void hist_from_cand_kernel(const unsigned long long *__restrict__ cand, int cand
         atomicAdd(&hist[key_bin(cand[i])], 1u);
 }
 
-void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radius, float conf_th, int border, int Hb, int Wb,
-                       float *nms_dense, unsigned long long *cand, int cand_cap, unsigned int *counters)
+bool launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radius, float conf_th, int border, int Hb, int Wb,
+                       float *nms_dense, unsigned long long *cand, int cand_cap, unsigned int *counters, int fuse_threshold, int top_k)
 {
     unsigned int *hist = counters + 16;   // counters[0..15], then SFD2_HIST_BINS histogram bins
     if (radius == 4) {   // nms4_kernels.hip
-        launch_nms4_select(st, heat, H, W, conf_th, border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist);
-        return;
+        launch_nms4_select(st, heat, H, W, conf_th, border, Hb, Wb, nms_dense, cand, cand_cap, counters, hist, fuse_threshold, top_k);
+        return fuse_threshold != 0 && cand != nullptr;
     }
     static bool attr_done = false;
     const size_t lds = (size_t)NMS_N * (3 * sizeof(float) + 1);
@@ -395,6 +395,7 @@ void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radi
     hipLaunchKernelGGL(nms_select_kernel, dim3((W + NMS_TW - 1) / NMS_TW, (H + NMS_TH - 1) / NMS_TH), dim3(512), lds,
                        st, heat, H, W, radius, conf_th, border, Hb, Wb, nms_dense, cand, cand_cap, counters);
     if (cand) hipLaunchKernelGGL(hist_from_cand_kernel, dim3(64), dim3(NT), 0, st, cand, cand_cap, counters, hist);
+    return false;
 }
 
 // ---------------------------------------------------------------- top-K + sort
@@ -407,46 +408,8 @@ void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radi
 __global__ __launch_bounds__(1024)
 void select_threshold_kernel(int cand_cap, int top_k, unsigned int *__restrict__ counters)
 {
-    // 4096 bins = 1024 threads x 4 bins.  Per-thread group sums, suffix scan over the 1024 groups (wave shuffles +
-    // 16 wave totals), then the thread owning the boundary group resolves the bin among its four.
-    static_assert(SFD2_HIST_BINS == 4096, "one uint4 of bins per thread");
     __shared__ unsigned int wsum[16];
-    const unsigned int *hist = counters + 16;
-    unsigned int n = counters[0];
-    if (n > (unsigned int)cand_cap) n = cand_cap;
-    const unsigned int k = (top_k <= 0 || (unsigned int)top_k > n) ? n : (unsigned int)top_k;
-    if (k == n) {
-        if (threadIdx.x == 0) { counters[1] = n; counters[2] = 0; counters[3] = 0; counters[4] = 0; counters[5] = 0; counters[6] = 1; }
-        return;
-    }
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint4 hv = reinterpret_cast<const uint4 *>(hist)[t];
-    const unsigned int sum = hv.x + hv.y + hv.z + hv.w;
-    unsigned int suf = sum;                    // inclusive suffix sum within the wave: groups t .. (wave end)
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned int o = __shfl_down(suf, d);
-        if (lane + d < 64) suf += o;
-    }
-    if (lane == 0) wsum[wave] = suf;
-    __syncthreads();
-    unsigned int higher = 0;                   // keys in all groups of higher waves
-    for (int w = wave + 1; w < 16; ++w) higher += wsum[w];
-    const unsigned int above_incl = higher + suf;          // keys in groups >= t
-    unsigned int above = above_incl - sum;                 // keys in groups  > t
-    if (above < k && above_incl >= k) {                    // exactly one thread: walk its bins from the top
-        const unsigned int b[4] = {hv.x, hv.y, hv.z, hv.w};
-#pragma unroll
-        for (int j = 3; j >= 0; --j) {
-            if (above < k && above + b[j] >= k) {
-                counters[1] = k; counters[2] = 0; counters[3] = 0;
-                counters[4] = 4 * t + j;       // boundary bin
-                counters[5] = k - above;       // how many of its keys are selected
-                counters[6] = 0;
-            }
-            above += b[j];
-        }
-    }
+    sfd2_select_threshold<false>(cand_cap, top_k, counters, wsum);
 }
 
 __global__ __launch_bounds__(NT)
@@ -479,28 +442,28 @@ void compact_selected_kernel(const unsigned long long *__restrict__ cand, int ca
             const unsigned int pos = base_s + (unsigned int)__popcll(ms & below);
             if (pos < (unsigned int)sel_cap) sel[pos] = key;
         } else if (to_bnd) {
-            bnd[base_b + (unsigned int)__popcll(mb & below)] = key;   // bnd has cand_cap entries
+            __hip_atomic_store(bnd + base_b + (unsigned int)__popcll(mb & below), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bnd has cand_cap entries
         }
     }
-}
-
-// the boundary bin: rank its keys by counting and keep the `need` largest
-__global__ __launch_bounds__(1024)
-void boundary_kernel(const unsigned long long *__restrict__ bnd, unsigned long long *__restrict__ sel, int sel_cap,
-                     const unsigned int *__restrict__ counters)
-{
-    __shared__ unsigned long long tile[1024];
-    const unsigned int nb = counters[3], need = counters[5], k = counters[1];
+    // the last block to finish ranks the boundary bin (counters[8] = ticket): one launch less.  The boundary keys are
+    // written and read with device-scope atomic stores / loads and the cursors are atomics: no fence (see sfd2_ld_agent).
+    __shared__ unsigned int s_last;
+    __syncthreads();                                     // every store of this block is acknowledged (vmcnt(0))
+    if (threadIdx.x == 0) s_last = atomicAdd(&counters[8], 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    const unsigned int nb = sfd2_ld_agent(counters + 3), need = counters[5], k = counters[1];
     if (counters[6] || need == 0) return;
+    __shared__ unsigned long long tile[NT];
     const unsigned int base_out = k - need;
     for (unsigned int i0 = 0; i0 < nb; i0 += blockDim.x) {
         const unsigned int i = i0 + threadIdx.x;
-        const unsigned long long mine = i < nb ? bnd[i] : 0ull;
+        const unsigned long long mine = i < nb ? __hip_atomic_load(bnd + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         unsigned int rank = 0;
-        for (unsigned int b = 0; b < nb; b += 1024) {
-            tile[threadIdx.x] = (b + threadIdx.x < nb) ? bnd[b + threadIdx.x] : 0ull;
+        for (unsigned int b = 0; b < nb; b += NT) {
+            tile[threadIdx.x] = (b + threadIdx.x < nb) ? __hip_atomic_load(bnd + b + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             __syncthreads();
-            const unsigned int lim = nb - b < 1024 ? nb - b : 1024;
+            const unsigned int lim = nb - b < NT ? nb - b : NT;
             for (unsigned int t = 0; t < lim; ++t) rank += tile[t] > mine ? 1u : 0u;
             __syncthreads();
         }
@@ -529,8 +492,26 @@ void rank_sort_kernel(const unsigned long long *__restrict__ sel, unsigned long 
     const unsigned int qlen = (n + RS_SL - 1) / RS_SL, j0 = q * qlen;
     const unsigned int j1 = j0 + qlen < n ? j0 + qlen : n;
     unsigned int rank = 0;
+    // this thread's four keys of the first four tiles (4 096 selected keys = four tiles per slice) are requested up front:
+    // one memory round trip instead of one per tile
+    unsigned long long pre[4][64 / RS_KEYS];
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+        for (int tt = 0; tt < 64 / RS_KEYS; ++tt) {
+            const unsigned int j = j0 + pb * 64 + li + tt * RS_KEYS;
+            pre[pb][tt] = (pb * 64u < qlen && j < j1) ? sel[j] : 0ull;
+        }
     for (unsigned int b = 0; b < qlen; b += 64) {            // same trip count for every slice
-        for (int t = li; t < 64; t += RS_KEYS) tile[q][t] = (j0 + b + t < j1) ? sel[j0 + b + t] : 0ull;
+        if (b < 256) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb)
+                if (b == pb * 64u)
+#pragma unroll
+                    for (int tt = 0; tt < 64 / RS_KEYS; ++tt) tile[q][li + tt * RS_KEYS] = pre[pb][tt];
+        } else {
+            for (int t = li; t < 64; t += RS_KEYS) tile[q][t] = (j0 + b + t < j1) ? sel[j0 + b + t] : 0ull;
+        }
         __syncthreads();
 #pragma unroll 8
         for (int t = 0; t < 64; ++t) rank += tile[q][t] > mine ? 1u : 0u;
@@ -552,15 +533,14 @@ void rank_sort_kernel(const unsigned long long *__restrict__ sel, unsigned long 
     }
 }
 
-void launch_topk_sort(hipStream_t st, const unsigned long long *cand, int cand_cap, int top_k,
+void launch_topk_sort(hipStream_t st, bool threshold_done, const unsigned long long *cand, int cand_cap, int top_k,
                       unsigned long long *sel, unsigned long long *sorted, int sel_cap, unsigned int *counters,
                       unsigned long long *bnd, int W, float *kpts, float *scores)
 {
-    hipLaunchKernelGGL(select_threshold_kernel, dim3(1), dim3(1024), 0, st, cand_cap, top_k, counters);
+    if (!threshold_done) hipLaunchKernelGGL(select_threshold_kernel, dim3(1), dim3(1024), 0, st, cand_cap, top_k, counters);
     int grid = (cand_cap + NT - 1) / NT;
     if (grid > 256) grid = 256;
     hipLaunchKernelGGL(compact_selected_kernel, dim3(grid), dim3(NT), 0, st, cand, cand_cap, sel, sel_cap, bnd, counters);
-    hipLaunchKernelGGL(boundary_kernel, dim3(1), dim3(1024), 0, st, bnd, sel, sel_cap, counters);
     hipLaunchKernelGGL(rank_sort_kernel, dim3((sel_cap + RS_KEYS - 1) / RS_KEYS), dim3(NT), 0, st, sel, sorted, sel_cap, counters, W,
                        kpts, scores);
 }

@@ -948,16 +948,17 @@ static int run_selection(sfd2_ctx *c, const float *heat_dev, int H, int W, float
     HIPCHECK(c->kscores.ensure((size_t)sel_cap * sizeof(float)));
     if (!c->counters_clean) HIPCHECK(hipMemsetAsync(c->counters.p, 0, SFD2_COUNTER_BYTES, c->stream));
     c->counters_clean = false;
+    bool threshold_done = false;
     {
         ProfScope ps(c, "nms_select", "nms_select_kernel", 0.0, (double)H * W * 4);
-        launch_nms_select(c->stream, heat_dev, H, W, radius, conf_th, border, Hb, Wb, nms_dense,
-                          c->cand.as<unsigned long long>(), c->cand_cap, c->counters.as<unsigned int>());
+        threshold_done = launch_nms_select(c->stream, heat_dev, H, W, radius, conf_th, border, Hb, Wb, nms_dense,
+                                           c->cand.as<unsigned long long>(), c->cand_cap, c->counters.as<unsigned int>(), 1, top_k);
     }
     {
         ProfScope ps(c, "topk_sort", "hist_select+compact+rank_sort", 0.0, (double)sel_cap * 24);
         c->kpts_cur = kpts_dev ? kpts_dev : c->kpts.as<float>();      // written in place when the caller's buffers are
         c->kscores_cur = scores_dev ? scores_dev : c->kscores.as<float>();   // device resident: no staging copies
-        launch_topk_sort(c->stream, c->cand.as<unsigned long long>(), c->cand_cap, top_k,
+        launch_topk_sort(c->stream, threshold_done, c->cand.as<unsigned long long>(), c->cand_cap, top_k,
                          c->sel.as<unsigned long long>(), c->sorted.as<unsigned long long>(), sel_cap,
                          c->counters.as<unsigned int>(), c->bnd.as<unsigned long long>(), W, c->kpts_cur, c->kscores_cur);
     }

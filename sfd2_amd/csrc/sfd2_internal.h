@@ -102,15 +102,16 @@ void launch_heatmap(hipStream_t st, const float *score, int hs, int ws, const fl
 // simple_nms + threshold + border; appends (score,idx) keys; optional dense output
 // border test: x in [border, Wb-border), y in [border, Hb-border) -- Hb/Wb are the ORIGINAL image dims when the map
 // is a rescaled pyramid level (nets/extractor.py:181-184 tests against W, H, not nw, nh)
-void launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radius, float conf_th, int border, int Hb, int Wb,
+// returns true when the top-K threshold search ran inside the NMS kernel (radius 4 with fuse_threshold)
+bool launch_nms_select(hipStream_t st, const float *heat, int H, int W, int radius, float conf_th, int border, int Hb, int Wb,
                        float *nms_dense /*may be null*/, unsigned long long *cand_keys, int cand_cap,
-                       unsigned int *counters /*[0]=n_cand*/);
+                       unsigned int *counters /*[0]=n_cand*/, int fuse_threshold = 0, int top_k = 0);
 // detector head + heat map in one kernel: logits [hc8 * wc8][pitch] (65 used), sta [3][hc][wc] or null -> heat [H][W];
 // needs H == 8 * hc8 and W == 8 * wc8 (no score-map resize)
 void launch_heads_heat(hipStream_t st, const float *logits, int pitch, int hc8, int wc8, const float *sta, int hc, int wc,
                        int H, int W, float *heat);
 // top-K of the candidate keys, sorted descending -> sorted_keys[0..n_sel), counters[1]=n_sel
-void launch_topk_sort(hipStream_t st, const unsigned long long *cand, int cand_cap, int top_k,
+void launch_topk_sort(hipStream_t st, bool threshold_done, const unsigned long long *cand, int cand_cap, int top_k,
                       unsigned long long *sel, unsigned long long *sorted, int sel_cap, unsigned int *counters,
                       unsigned long long *bnd, int W, float *kpts, float *scores);   // kpts/scores: output rows (x, y), score
 #define SFD2_HIST_BINS 4096                   // score bits >> 15, rebased to [2^-12, 2^4) and clamped (post_kernels.hip key_bin)
@@ -125,9 +126,67 @@ __device__ __forceinline__ unsigned int key_bin(unsigned long long key)
     return (unsigned int)(b < 0 ? 0 : (b > SFD2_HIST_BINS - 1 ? SFD2_HIST_BINS - 1 : b));
 }
 
+// threshold search over the 4096-bin score histogram by ONE block of 1024 threads (select_threshold_kernel, or the last
+// block of nms4_select_kernel to finish).  wsum: 16 words of LDS.  COHERENT: the histogram and the candidate count were
+// written by device-scope atomics of other blocks of THIS launch, so they are read with device-scope atomic loads (this
+// part has one L2 per XCD; a release / acquire fence pair instead would write back and invalidate that L2 -- measured:
+// 27 -> 83 us for the NMS kernel).
+__device__ __forceinline__ unsigned int sfd2_ld_agent(const unsigned int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool COHERENT>
+__device__ __forceinline__ void sfd2_select_threshold(int cand_cap, int top_k, unsigned int *__restrict__ counters, unsigned int *wsum)
+{
+    // 4096 bins = 1024 threads x 4 bins.  Per-thread group sums, suffix scan over the 1024 groups (wave shuffles +
+    // 16 wave totals), then the thread owning the boundary group resolves the bin among its four.
+    static_assert(SFD2_HIST_BINS == 4096, "one uint4 of bins per thread");
+    const unsigned int *hist = counters + 16;
+    unsigned int n = COHERENT ? sfd2_ld_agent(counters) : counters[0];
+    if (n > (unsigned int)cand_cap) n = cand_cap;
+    const unsigned int k = (top_k <= 0 || (unsigned int)top_k > n) ? n : (unsigned int)top_k;
+    if (k == n) {
+        if (threadIdx.x == 0) { counters[1] = n; counters[2] = 0; counters[3] = 0; counters[4] = 0; counters[5] = 0; counters[6] = 1; }
+        return;
+    }
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint4 hv;
+    if (COHERENT) hv = make_uint4(sfd2_ld_agent(hist + 4 * t), sfd2_ld_agent(hist + 4 * t + 1), sfd2_ld_agent(hist + 4 * t + 2), sfd2_ld_agent(hist + 4 * t + 3));
+    else hv = reinterpret_cast<const uint4 *>(hist)[t];
+    const unsigned int sum = hv.x + hv.y + hv.z + hv.w;
+    unsigned int suf = sum;                    // inclusive suffix sum within the wave: groups t .. (wave end)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int o = __shfl_down(suf, d);
+        if (lane + d < 64) suf += o;
+    }
+    if (lane == 0) wsum[wave] = suf;
+    __syncthreads();
+    unsigned int higher = 0;                   // keys in all groups of higher waves
+    for (int w = wave + 1; w < 16; ++w) higher += wsum[w];
+    const unsigned int above_incl = higher + suf;          // keys in groups >= t
+    unsigned int above = above_incl - sum;                 // keys in groups  > t
+    if (above < k && above_incl >= k) {                    // exactly one thread: walk its bins from the top
+        const unsigned int b[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            if (above < k && above + b[j] >= k) {
+                counters[1] = k; counters[2] = 0; counters[3] = 0;
+                counters[4] = 4 * t + j;       // boundary bin
+                counters[5] = k - above;       // how many of its keys are selected
+                counters[6] = 0;
+            }
+            above += b[j];
+        }
+    }
+}
+
 // nms4_kernels.hip: simple_nms with radius 4 + threshold + border + compaction (launch_nms_select serves other radii)
+// fuse_threshold: the last block to finish also runs the top-K threshold search (counters[7] = its ticket counter);
+// launch_topk_sort is then called with threshold_done
 void launch_nms4_select(hipStream_t st, const float *heat, int H, int W, float conf_th, int border, int Hb, int Wb, float *nms_dense,
-                        unsigned long long *cand, int cand_cap, unsigned int *counters, unsigned int *hist);
+                        unsigned long long *cand, int cand_cap, unsigned int *counters, unsigned int *hist, int fuse_threshold, int top_k);
 // greedy grid NMS of extract.py (nms_fast): init / one relaxation sweep / kept-score map
 void launch_greedy_init(hipStream_t st, const float *heat, int n, float conf_th, unsigned long long *keys, unsigned char *state);
 void launch_greedy_iter(hipStream_t st, const unsigned long long *keys, const unsigned char *sin, unsigned char *sout,
