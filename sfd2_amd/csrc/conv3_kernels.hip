@@ -73,13 +73,13 @@ __global__ __launch_bounds__(512, 2)
 void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                        const half_t *__restrict__ wpk, const float *__restrict__ scale,
                        const float *__restrict__ shift, int CoutP, int relu,
-                       half_t *__restrict__ out, int Ho, int Wo, int tiles_x,
+                       half_t *__restrict__ out, int Ho, int Wo, int tiles_x, int n_tiles,
                        const half_t *__restrict__ zero_page)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Xs = smem;                              // [2][PP_XBYTES]
     unsigned char *Fs = smem + 2 * PP_XBYTES;              // [2][PP_FBYTES]
-    float *SS = reinterpret_cast<float *>(Fs + 2 * PP_FBYTES);   // scale[128], shift[128]
+    float *SSb = reinterpret_cast<float *>(Fs + 2 * PP_FBYTES);  // [2] x (scale[128], shift[128]): one set per tile parity
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,37 +87,41 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     const int wch = (wave & 1) * 64;                       // 2 channel tiles
     const int wrow = (wave >> 1) * 4;                      // 4 image rows = 4 pixel tiles
 
+    // PERSISTENT blocks (one per CU: 127 KB of LDS): tiles blockIdx.x, + gridDim.x, ...  The next tile's first patch and
+    // filter row are requested BEFORE the current tile's epilogue, so they land behind its conversions and stores instead
+    // of in front of an idle matrix pipe (2-3 us per tile), and the second tile of a CU needs no block launch.
     const int n_tiles_n = CoutP / PP_BN;
-    const int swz = xcd_swizzle3(blockIdx.x, gridDim.x);
-    const int tn = swz % n_tiles_n;
-    const int tsp = swz / n_tiles_n;
-    const int tx = tsp % tiles_x, ty = tsp / tiles_x;
-    const int oy0 = ty * PP_TH, ox0 = tx * PP_TW, n0 = tn * PP_BN;
-
-    // ---- per-lane staging sources (element offsets; -1 = zero page)
-    int xoff[PP_XPW];
-#pragma unroll
-    for (int i = 0; i < PP_XPW; ++i) {
-        int piece = wave + 8 * i;
-        if (piece >= PP_XCH) piece = PP_XCH - 1;
-        const int q = piece * 16 + (lane >> 2);
-        const int slot = (lane & 3) ^ ((q >> 2) & 3);
-        int off = -1;
-        if (q < PP_NPIX) {
-            const int py = q / PP_PW, px = q - py * PP_PW;
-            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) off = (iy * W + ix) * Cin + slot * 8;
-        }
-        xoff[i] = off;
+    int oy0, ox0, n0;
+    int xoff[PP_XPW], woff[PP_FPW];
+#define PP_SETUP(tile_)                                                                                \
+    {                                                                                                  \
+        const int swz_ = xcd_swizzle3((tile_), n_tiles);                                               \
+        const int tn_ = swz_ % n_tiles_n, tsp_ = swz_ / n_tiles_n;                                     \
+        const int tx_ = tsp_ % tiles_x, ty_ = tsp_ / tiles_x;                                          \
+        oy0 = ty_ * PP_TH; ox0 = tx_ * PP_TW; n0 = tn_ * PP_BN;                                        \
+        /* per-lane staging sources (element offsets; -1 = zero page) */                               \
+        _Pragma("unroll") for (int i = 0; i < PP_XPW; ++i) {                                           \
+            int piece = wave + 8 * i;                                                                  \
+            if (piece >= PP_XCH) piece = PP_XCH - 1;                                                   \
+            const int q = piece * 16 + (lane >> 2);                                                    \
+            const int slot = (lane & 3) ^ ((q >> 2) & 3);                                              \
+            int off = -1;                                                                              \
+            if (q < PP_NPIX) {                                                                         \
+                const int py = q / PP_PW, px = q - py * PP_PW;                                         \
+                const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;                                        \
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) off = (iy * W + ix) * Cin + slot * 8;      \
+            }                                                                                          \
+            xoff[i] = off;                                                                             \
+        }                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < PP_FPW; ++i) {                                           \
+            const int r = (wave * PP_FPW + i) * 16 + (lane >> 2);   /* row of the stage tile: tap r / 128, filter r % 128 */ \
+            const int slot = (lane & 3) ^ ((r >> 2) & 3);                                              \
+            /* KXM: the stage's three taps are (ky = r / 128, kx = stage % 3), three filter rows apart in the packed array */ \
+            woff[i] = ((r / PP_BN) * (KXM ? 3 : 1) * CoutP + n0 + (r % PP_BN)) * PP_CC + slot * 8;     \
+        }                                                                                              \
     }
-    int woff[PP_FPW];
-#pragma unroll
-    for (int i = 0; i < PP_FPW; ++i) {
-        const int r = (wave * PP_FPW + i) * 16 + (lane >> 2);   // row of the stage tile: tap r / 128, filter r % 128
-        const int slot = (lane & 3) ^ ((r >> 2) & 3);
-        // KXM: the stage's three taps are (ky = r / 128, kx = stage % 3), three filter rows apart in the packed array
-        woff[i] = ((r / PP_BN) * (KXM ? 3 : 1) * CoutP + n0 + (r % PP_BN)) * PP_CC + slot * 8;
-    }
+    int tile = blockIdx.x;
+    PP_SETUP(tile)
 
 #define PP_ISSUE_X1(chunk_, buf_, i_)                                                                  \
     do {                                                                                               \
@@ -133,23 +137,13 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                                          (lds_void3_t *)(Fs + (buf_)*PP_FBYTES + (wave * PP_FPW + i_) * 1024), 16, 0, 0); \
     }
 
-    f32x16_t acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
     const int NCH = Cin / PP_CC;
     const int NST = NCH * 3;
 
 #pragma unroll
     for (int i = 0; i < PP_XPW; ++i) PP_ISSUE_X1(0, 0, i);
     PP_ISSUE_F(0, 0)
-    for (int t = tid; t < PP_BN; t += 512) { SS[t] = scale[n0 + t]; SS[PP_BN + t] = shift[n0 + t]; }
-    SFD2_BARRIER_DRAIN();
-    if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
+    for (int t = tid; t < PP_BN; t += 512) { SSb[t] = scale[n0 + t]; SSb[PP_BN + t] = shift[n0 + t]; }
 
     const int lrow = lane & 31, lhi = lane >> 5;
     int a_off[2], a_sw[2];
@@ -160,6 +154,18 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         a_sw[ct] = (r >> 2) & 3;
     }
     const int qb = wrow * PP_PW + lrow;
+
+    for (int it = 0;; ++it) {
+    float *SS = SSb + (it & 1) * 2 * PP_BN;
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    SFD2_BARRIER_DRAIN();
+    if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
 
     for (int c = 0; c < NCH; ++c) {
         const unsigned char *xs = Xs + (c & 1) * PP_XBYTES;
@@ -239,8 +245,18 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-#undef PP_ISSUE_X1
-#undef PP_ISSUE_F
+    // the next tile's first copies go out before this tile's epilogue (buffers 0: last read a chunk / a stage ago)
+    const int eoy0 = oy0, eox0 = ox0, en0 = n0;
+    const int next = tile + (int)gridDim.x;
+    const bool has_next = next < n_tiles;
+    if (has_next) {
+        PP_SETUP(next)
+#pragma unroll
+        for (int i = 0; i < PP_XPW; ++i) PP_ISSUE_X1(0, 0, i);
+        PP_ISSUE_F(0, 0)
+        float *SSn = SSb + ((it + 1) & 1) * 2 * PP_BN;
+        for (int t = tid; t < PP_BN; t += 512) { SSn[t] = scale[n0 + t]; SSn[PP_BN + t] = shift[n0 + t]; }
+    }
 
     const float lo = relu ? 0.0f : -__builtin_huge_valf();   // ReLU without a branch (this file is compiled with -fno-honor-nans:
                                                               // no canonicalising v_max in front of each fmaxf)
@@ -248,7 +264,7 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     // (see conv2_kernels.hip)
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {
-        const int oy = oy0 + wrow + pr, ox = ox0 + lrow;
+        const int oy = eoy0 + wrow + pr, ox = eox0 + lrow;
         const bool inb = oy < Ho && ox < Wo;
         const size_t pix = (size_t)(inb ? oy : 0) * Wo + (inb ? ox : 0);
 #pragma unroll
@@ -256,7 +272,7 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             const int cl = wch + ct * 32 + 4 * lhi;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const size_t o16 = pix * CoutP + n0 + wch + ct * 32 + 8 * (2 * m + lhi);
+                const size_t o16 = pix * CoutP + en0 + wch + ct * 32 + 8 * (2 * m + lhi);
                 uint2 pk[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -273,10 +289,16 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                 }
                 const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                 const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
-                if (inb) *reinterpret_cast<uint4 *>(out + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                if (inb && (!(ABL & 4) || t0[0] == 0x12345678u)) *reinterpret_cast<uint4 *>(out + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
             }
         }
     }
+    if (!has_next) break;
+    tile = next;
+    }
+#undef PP_ISSUE_X1
+#undef PP_ISSUE_F
+#undef PP_SETUP
 }
 
 template <int STAGGER, int PRIO, int ABL = 0>
@@ -284,17 +306,24 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
                         const float *scale, const float *shift, int CoutP, int relu, half_t *out,
                         int Ho, int Wo, const half_t *zero_page)
 {
-    constexpr size_t lds = (size_t)2 * PP_XBYTES + (size_t)2 * PP_FBYTES + 2 * PP_BN * sizeof(float);
+    constexpr size_t lds = (size_t)2 * PP_XBYTES + (size_t)2 * PP_FBYTES + 4 * PP_BN * sizeof(float);
     static bool attr_done = false;
     auto kern = conv3x3_pp_kernel<STAGGER, PRIO, ABL>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 0;
+        slots = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+                    ? cus : 256;                           // one resident block per CU
+    }
     const int tiles_x = (Wo + PP_TW - 1) / PP_TW, tiles_y = (Ho + PP_TH - 1) / PP_TH;
-    const int grid = tiles_x * tiles_y * (CoutP / PP_BN);
+    const int n_tiles = tiles_x * tiles_y * (CoutP / PP_BN);
+    const int grid = n_tiles < slots ? n_tiles : slots;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out,
-                       Ho, Wo, tiles_x, zero_page);
+                       Ho, Wo, tiles_x, n_tiles, zero_page);
 }
 
 // does conv3x3_pp serve this layer?  (decided from the layer's shape alone: the filters are packed for it)
@@ -313,6 +342,14 @@ void launch_conv3x3_pp(hipStream_t st, const half_t *in, int H, int W, int Cin, 
                        int Ho, int Wo, const half_t *zero_page)
 {
 #ifdef SFD2_EXPERIMENTS
+    if (const char *ab = sfd2_env("SFD2_PP_ABL")) {   // timing ablations (wrong results): 1 no copies, 2 no reads, 4 no stores
+        switch (atoi(ab)) {
+        case 4: launch_pp_t<1, 1, 4>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page); return;
+        case 7: launch_pp_t<1, 1, 7>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page); return;
+        case 3: launch_pp_t<1, 1, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page); return;
+        default: break;
+        }
+    }
     static const bool nostagger = sfd2_env("SFD2_CONV_PP_NOSTAGGER") != nullptr;
     if (nostagger) {
         launch_pp_t<0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);

@@ -272,7 +272,8 @@ void nms4_select_kernel(const float *__restrict__ heat, int H, int W, float conf
     // the last block to finish (ticket in counters[7]) searches the top-K threshold in the now complete histogram: the
     // selection chain behind this kernel starts at the compaction (one launch less).  Histogram and count are atomics, read
     // back with device-scope atomic loads: no fence (sfd2_select_threshold).
-    __syncthreads();                                     // this block's atomics are acknowledged (vmcnt(0))
+    SFD2_BARRIER_DRAIN();   // this block's atomics are acknowledged: the vmcnt(0) is written out -- a workgroup-scope
+                            // __syncthreads() does not wait for global operations on this target
     if (threadIdx.x == 0) l_base = atomicAdd(&counters[7], 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
     __syncthreads();
     if (!l_base) return;

@@ -448,7 +448,8 @@ void compact_selected_kernel(const unsigned long long *__restrict__ cand, int ca
     // the last block to finish ranks the boundary bin (counters[8] = ticket): one launch less.  The boundary keys are
     // written and read with device-scope atomic stores / loads and the cursors are atomics: no fence (see sfd2_ld_agent).
     __shared__ unsigned int s_last;
-    __syncthreads();                                     // every store of this block is acknowledged (vmcnt(0))
+    SFD2_BARRIER_DRAIN();   // every store / atomic of this block is acknowledged: the vmcnt(0) is written out -- a
+                            // workgroup-scope __syncthreads() does not wait for global operations on this target
     if (threadIdx.x == 0) s_last = atomicAdd(&counters[8], 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;

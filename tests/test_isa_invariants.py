@@ -66,7 +66,11 @@ def test_no_spills_and_two_waves_per_simd(asm, src):
         # conv2a's kernel (64 -> 128 channels, 128 registers for four waves per SIMD) parks one address pair across its
         # loop: one store in the prologue, one reload in the epilogue
         allowed = 2 if "conv_igemm2_kernelILi3ELi1ELi128ELi64E" in name else 0
-        assert meta["vgpr_spill_count"] <= allowed and meta["sgpr_spill_count"] == 0, (name, meta)
+        assert meta["vgpr_spill_count"] <= allowed, (name, meta)
+        # scalar spills go to VGPR lanes (v_writelane / v_readlane); the persistent conv3x3_pp parks a few tile-loop scalars
+        # that way, outside the K loop
+        assert meta["sgpr_spill_count"] <= (8 if "conv3x3_pp_kernel" in name else 0), (name, meta)
+        assert _count(_mfma_span(k["body"]), r"v_readlane|v_writelane") == 0, name
 
 
 def test_conv3x3_pp_loop_has_only_its_own_drains(asm):
