@@ -9,6 +9,7 @@ mkdir -p $out
 cd $R
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.txt 2>&1
+python tools/determinism_check.py 2000 > $out/determinism.txt 2>&1
 python bench.py --steps 20 --warmup 5 --dump-layers > $out/bench.json 2> $out/layer_table.txt
 python bench.py --steps 20 --warmup 5 --extract-only --no-cpu-baseline > $out/bench_extract_only.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-graphs --no-cpu-baseline --no-strict > $out/bench_eager.json 2>/dev/null
