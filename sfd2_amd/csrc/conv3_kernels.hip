@@ -330,11 +330,12 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
 // Measured at 1600x1200 (tools/ab_libs.py, interleaved A/B on one box): conv3b 132.7 -> 122.3 us, convDa.0 134.5 -> 126.1,
 // convDa.3 132.7 -> 122.2, conv3a 77.3 -> 72.8, convPa.3 60.4 -> 54.5; the same tile WITHOUT the one-barrier offset: 144 us
 // (experiment builds: SFD2_CONV_PP_NOSTAGGER=1).  conv2a (64 -> 128 channels, two K chunks) is slower here (91 vs 81 us: the
-// 63 KB prologue is a fifth of its K loop) and stays on conv_igemm2.
+// 63 KB prologue is a fifth of its K loop; with the persistent blocks 87.5 vs 82.7) and stays on conv_igemm2.
 bool conv3x3_pp_serves(int ks, int stride, int CoutP, int Cin)
 {
     static const bool off = sfd2_env("SFD2_CONV_NO_PP") != nullptr;   // experiment builds: conv_igemm2 for these layers
-    return !off && ks == 3 && stride == 1 && CoutP % 256 == 0 && Cin % 64 == 0;
+    static const bool c128 = sfd2_env("SFD2_PP_COUT128") != nullptr;   // experiment: conv2a (64 -> 128 channels) too
+    return !off && ks == 3 && stride == 1 && (CoutP % 256 == 0 || (c128 && CoutP % 128 == 0)) && Cin % 64 == 0;
 }
 
 void launch_conv3x3_pp(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,

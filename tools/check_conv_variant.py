@@ -11,7 +11,7 @@ import tempfile
 import numpy as np
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-LAYERS = ["bn1b", "bn2b", "conv3a", "bn3b", "convPa.0", "convPa", "convDa.0", "convDa"]
+LAYERS = ["bn1b", "conv2a", "bn2b", "conv3a", "bn3b", "convPa.0", "convPa", "convDa.0", "convDa"]
 SIZES = [(1200, 1600), (240, 320), (133, 211), (512, 384), (64, 1056)]
 WORKER = r'''
 import sys, numpy as np
