@@ -73,47 +73,65 @@ __device__ __forceinline__ void rf_copy_piece(const half_t *base, int nbytes, un
 
 // ABL: timing ablations for experiment builds (wrong results): 1 = no filter loads in the loop, 2 = no fragment reads,
 // 4 = no patch copies in the loop, 8 = no output stores
-template <int S, int ABL = 0>
+//
+// BN = output channels per block = the layer's padded channel count: 256 (eight waves x 32 channels, every wave all four
+// pixel fragments) or 128 (four channel groups x two pixel halves of two fragments: conv2b).
+//
+// PERSISTENT blocks (one per CU): tiles blockIdx.x, + gridDim.x, ...  The chunk pipeline does not stop at a tile boundary:
+// the patch ring (chunk C + 2 requested during chunk C), the filter ring (unit U + 9 loaded after unit U; the filters repeat
+// from tile to tile) and the fragment prefetch run across it, and a tile's epilogue sits between the last unit of its last
+// chunk and the first unit of the next tile's first chunk, whose operands are already in registers / in flight.  A
+// one-tile-per-CU launch (convPa.0 / convPa.3 at 1600x1200) behaves as before; conv2b (938 tiles of four chunks) no longer
+// pays a 230 KB prologue burst and an epilogue per 4.6k cycles of MFMA work with nothing running beside them.
+template <int S, int BN = RF_BN, int ABL = 0>
 __global__ __launch_bounds__(512, 2)
 void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                        const half_t *__restrict__ wpk, const float *__restrict__ scale,
                        const float *__restrict__ shift, int CoutP, int relu,
-                       half_t *__restrict__ out, int Ho, int Wo, int tiles_x,
+                       half_t *__restrict__ out, int Ho, int Wo, int tiles_x, int n_tiles,
                        const half_t *__restrict__ zero_page)
 {
     using G = RfGeom<S>;
+    constexpr int NWC = BN / 32, NF = 4 / (8 / NWC);       // channel groups; pixel fragments per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Xs = smem;                              // [3][XBYTES]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lhi = lane >> 5, l32 = lane & 31, ly = l32 >> 4, lx = l32 & 15;
+    const int f0 = (wave / NWC) * NF;
+    const int n0 = (wave % NWC) * 32;                      // CoutP == BN: one channel tile (launcher)
 
-    const int n_tiles_n = CoutP / RF_BN;
-    const int swz = xcd_swizzle4(blockIdx.x, gridDim.x);
-    const int tn = swz % n_tiles_n;
-    const int tsp = swz / n_tiles_n;
-    const int tx = tsp % tiles_x, ty = tsp / tiles_x;
-    const int oy0 = ty * RF_TH, ox0 = tx * RF_TW, n0 = tn * RF_BN + wave * 32;
+    const int NCH = Cin / RF_CC;
+    const int NU = NCH * 9;
+    const int n_my = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this block
+    const int TC = n_my * NCH;                             // chunks of this block
 
-    // ---- per-lane staging sources: byte offsets into the input for buffer_load ... lds; padding and out-of-image
-    // records get an offset beyond the buffer's range, for which the hardware returns zeros
+    // ---- per-lane staging sources of ONE tile: byte offsets into the input for buffer_load ... lds; padding and
+    // out-of-image records get an offset beyond the buffer's range, for which the hardware returns zeros
     const int in_bytes = (int)((size_t)H * W * Cin * sizeof(half_t));
     int xoff[G::PPW];
-#pragma unroll
-    for (int i = 0; i < G::PPW; ++i) {
-        int piece = wave + 8 * i;
-        if (piece >= G::NPIECE) piece = G::NPIECE - 1;
-        const int q = piece * 16 + (lane >> 2);
-        const int slot = (lane & 3) ^ ((q >> 2) & 3);
-        const int row = q / G::P, ir = q - row * G::P;
-        int off = (int)0x80000000;
-        if (row < G::PH && ir < G::PWU) {
-            const int col = S == 2 ? (ir < RF_TW + 1 ? 2 * ir : 2 * (ir - (RF_TW + 1)) + 1) : ir;
-            const int iy = oy0 * S - 1 + row, ix = ox0 * S - 1 + col;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) off = ((iy * W + ix) * Cin + slot * 8) * (int)sizeof(half_t);
-        }
-        xoff[i] = off;
+    int xoff_seq = -1;                                     // which of this block's tiles xoff describes
+#define RF_SETUP_X(seq_)                                                                               \
+    {                                                                                                  \
+        const int swz_ = xcd_swizzle4((int)blockIdx.x + (seq_) * (int)gridDim.x, n_tiles);             \
+        const int tx_ = swz_ % tiles_x, ty_ = swz_ / tiles_x;                                          \
+        const int poy0_ = ty_ * RF_TH, pox0_ = tx_ * RF_TW;                                            \
+        _Pragma("unroll") for (int i = 0; i < G::PPW; ++i) {                                           \
+            int piece = wave + 8 * i;                                                                  \
+            if (piece >= G::NPIECE) piece = G::NPIECE - 1;                                             \
+            const int q = piece * 16 + (lane >> 2);                                                    \
+            const int slot = (lane & 3) ^ ((q >> 2) & 3);                                              \
+            const int row = q / G::P, ir = q - row * G::P;                                             \
+            int off = (int)0x80000000;                                                                 \
+            if (row < G::PH && ir < G::PWU) {                                                          \
+                const int col = S == 2 ? (ir < RF_TW + 1 ? 2 * ir : 2 * (ir - (RF_TW + 1)) + 1) : ir;  \
+                const int iy = poy0_ * S - 1 + row, ix = pox0_ * S - 1 + col;                          \
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) off = ((iy * W + ix) * Cin + slot * 8) * (int)sizeof(half_t); \
+            }                                                                                          \
+            xoff[i] = off;                                                                             \
+        }                                                                                              \
+        xoff_seq = (seq_);                                                                             \
     }
 
 #define RF_ISSUE_X1(chunk_, buf_, i_)                                                                  \
@@ -145,22 +163,29 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         asm volatile("" : "+v"(q_));                                                                   \
         q_ += to_;                                                                                     \
         const unsigned char *bp_ = (xs_) + q_ * 64 + (((((kk_)*2 + lhi)) ^ ((q_ >> 2) & 3)) << 4);    \
-        _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_)                                               \
-            dst_[f_] = *reinterpret_cast<const h8_t *>(bp_ + f_ * (G::DF * 64));                       \
+        _Pragma("unroll") for (int f_ = 0; f_ < NF; ++f_)                                              \
+            dst_[f_] = *reinterpret_cast<const h8_t *>(bp_ + (f0 + f_) * (G::DF * 64));                \
     } while (0)
 
-    f32x16_t acc[4];
+    f32x16_t acc[NF];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+    h8_t fa[9][2], fb[3][NF];
 
-    const int NCH = Cin / RF_CC;
-    const int NU = NCH * 9;
-    h8_t fa[9][2], fb[3][4];
+    // scale / shift of this wave's 32 channels stay in registers (one channel tile: the same for every tile)
+    float4 sc[4], sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sc[q] = *reinterpret_cast<const float4 *>(scale + n0 + 4 * lhi + 8 * q);
+        sh[q] = *reinterpret_cast<const float4 *>(shift + n0 + 4 * lhi + 8 * q);
+    }
+    const float lo = relu ? 0.0f : -__builtin_huge_valf();   // branch-free ReLU (this file is compiled with -fno-honor-nans)
 
+    RF_SETUP_X(0)
     RF_ISSUE_X(0, 0)
-    RF_ISSUE_X(1, 1)                                       // Cin >= 64: at least two chunks
+    RF_ISSUE_X(1, 1)                                       // Cin >= 64: at least two chunks per tile
 #pragma unroll
     for (int u = 0; u < 9; ++u) RF_LOAD_A(u, fa[u]);
     // (waiting for the first patch only and letting the rest land behind counted waits was measured: no gain)
@@ -168,24 +193,26 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     RF_READ_B(Xs, 0, 0, fb[0]);
     RF_READ_B(Xs, 0, 1, fb[1]);
 
-    int bc = 0;                                            // c % 3: three patch buffers
-    for (int c = 0; c < NCH; ++c) {
+    int bc = 0;                                            // C % 3: three patch buffers
+    int c = 0, seq = 0;                                    // chunk within the tile, tile of this block
+    for (int C = 0; C < TC; ++C) {
         const int bn = bc == 2 ? 0 : bc + 1, bnn = bn == 2 ? 0 : bn + 1;
         const unsigned char *xs = Xs + bc * G::XBYTES;
         const unsigned char *xn = Xs + bn * G::XBYTES;
-        // the patch two chunks ahead goes into the buffer chunk c - 1 used (every wave passed that chunk's boundary
-        // barrier with its reads retired), one piece per unit so that the copies of the 247 blocks do not arrive at the
-        // memory system as one burst.  The last two chunks re-request the last patch (branch-free: the in-flight counts
-        // stay what the waits assume).
-        const int cx = c + 2 < NCH ? c + 2 : NCH - 1;
+        // the patch two chunks ahead (of this or of the next tile) goes into the buffer chunk C - 1 used (every wave passed
+        // that chunk's boundary barrier with its reads retired), one piece per unit so that the copies of all blocks do not
+        // arrive at the memory system as one burst.  The block's last two chunks re-request its last patch (branch-free:
+        // the in-flight counts stay what the waits assume).
+        const int Cx = C + 2 < TC ? C + 2 : TC - 1;
+        const int seq_x = Cx / NCH, cx = Cx - seq_x * NCH;
+        if (seq_x != xoff_seq) RF_SETUP_X(seq_x)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int u = c * 9 + t;
             if (t < G::PPW && !(ABL & 4)) RF_ISSUE_X1(cx, bnn, t);
             if (t == 8) {
-                // chunk boundary: my pieces of the next patch have landed (VMW younger operations may still be in flight),
-                // my reads of this one are done; then the whole block's.  The last chunk's look-ahead reads return
-                // stale records that no MFMA consumes.
+                // chunk boundary: my pieces of the next patch have landed (VMW younger operations may still be in flight;
+                // a tile's epilogue only adds younger ones), my reads of this one are done; then the whole block's.  The
+                // last chunk's look-ahead reads return stale records that no MFMA consumes.
                 static_assert(RfGeom<1>::VMW == 33 && RfGeom<2>::VMW == 30, "chunk-boundary wait counts");
                 if (S == 2) asm volatile("s_waitcnt vmcnt(30) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(33) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -199,72 +226,84 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                 else RF_READ_B(xn, (h + 2 - 18) / 2, (h + 2) % 2, fb[(h + 2) % 3]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int f = 0; f < 4; ++f)
+                for (int f = 0; f < NF; ++f)
                     acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][kk], fb[h % 3][f], acc[f], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // the last chunk re-loads the last unit's filters (unconditional, like the copies)
-            if (!(ABL & 1)) RF_LOAD_A((u + 9 < NU ? u + 9 : NU - 1), fa[t]);
+            // nine units ahead: the same filters serve every tile, so the ring wraps at a tile's last unit
+            int ua = c * 9 + t + 9;
+            if (ua >= NU) ua -= NU;
+            if (!(ABL & 1)) RF_LOAD_A(ua, fa[t]);
             __builtin_amdgcn_sched_barrier(0);
         }
         bc = bn;
+        if (++c < NCH) continue;
+
+        // ---- the tile's epilogue: y = acc * scale + shift (ReLU), regrouped with v_permlane32_swap into 16-byte stores
+        // (conv2_kernels.hip); the next tile's first operands are already in registers / in flight
+        {
+            const int swz_ = xcd_swizzle4((int)blockIdx.x + seq * (int)gridDim.x, n_tiles);
+            const int tx_ = swz_ % tiles_x, ty_ = swz_ / tiles_x;
+            const int oy0 = ty_ * RF_TH, ox0 = tx_ * RF_TW;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int oy = oy0 + 2 * (f0 + f) + ly, ox = ox0 + lx;
+                const bool inb = oy < Ho && ox < Wo;
+                const size_t pix = (size_t)(inb ? oy : 0) * Wo + (inb ? ox : 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const size_t o16 = pix * CoutP + n0 + 8 * (2 * m + lhi);
+                    uint2 pk[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int q = 2 * m + j;
+                        float v0 = acc[f][4 * q + 0] * sc[q].x + sh[q].x;
+                        float v1 = acc[f][4 * q + 1] * sc[q].y + sh[q].y;
+                        float v2 = acc[f][4 * q + 2] * sc[q].z + sh[q].z;
+                        float v3 = acc[f][4 * q + 3] * sc[q].w + sh[q].w;
+                        v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
+                        const h4_t hv = cvt4r(v0, v1, v2, v3);
+                        __builtin_memcpy(&pk[j], &hv, 8);
+                    }
+                    const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                    const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                    if (inb && (!(ABL & 8) || t0[0] == 0x12345678u)) *reinterpret_cast<uint4 *>(out + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+            }
+        }
+        c = 0;
+        ++seq;
     }
 #undef RF_ISSUE_X
 #undef RF_ISSUE_X1
 #undef RF_LOAD_A
 #undef RF_READ_B
-
-    const float lo = relu ? 0.0f : -__builtin_huge_valf();   // branch-free ReLU (this file is compiled with -fno-honor-nans)
-    // epilogue: y = acc * scale + shift (ReLU), regrouped with v_permlane32_swap into 16-byte stores (conv2_kernels.hip)
-    float4 sc[4], sh[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        sc[q] = *reinterpret_cast<const float4 *>(scale + n0 + 4 * lhi + 8 * q);
-        sh[q] = *reinterpret_cast<const float4 *>(shift + n0 + 4 * lhi + 8 * q);
-    }
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const int oy = oy0 + 2 * f + ly, ox = ox0 + lx;
-        const bool inb = oy < Ho && ox < Wo;
-        const size_t pix = (size_t)(inb ? oy : 0) * Wo + (inb ? ox : 0);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const size_t o16 = pix * CoutP + n0 + 8 * (2 * m + lhi);
-            uint2 pk[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int q = 2 * m + j;
-                float v0 = acc[f][4 * q + 0] * sc[q].x + sh[q].x;
-                float v1 = acc[f][4 * q + 1] * sc[q].y + sh[q].y;
-                float v2 = acc[f][4 * q + 2] * sc[q].z + sh[q].z;
-                float v3 = acc[f][4 * q + 3] * sc[q].w + sh[q].w;
-                v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
-                const h4_t hv = cvt4r(v0, v1, v2, v3);
-                __builtin_memcpy(&pk[j], &hv, 8);
-            }
-            const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
-            const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
-            if (inb && (!(ABL & 8) || t0[0] == 0x12345678u)) *reinterpret_cast<uint4 *>(out + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
-        }
-    }
+#undef RF_SETUP_X
 }
 
-template <int S, int ABL = 0>
+template <int S, int BN = RF_BN, int ABL = 0>
 static void launch_rf_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                         const float *scale, const float *shift, int CoutP, int relu, half_t *out,
                         int Ho, int Wo, const half_t *zero_page)
 {
     constexpr size_t lds = (size_t)3 * RfGeom<S>::XBYTES;
     static bool attr_done = false;
-    auto kern = conv3x3_rf_kernel<S, ABL>;
+    static int slots = 256;
+    auto kern = conv3x3_rf_kernel<S, BN, ABL>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            slots = cus;                                   // one resident block per CU (3 x 43 KB of LDS for stride 2)
         attr_done = true;
     }
     const int tiles_x = (Wo + RF_TW - 1) / RF_TW, tiles_y = (Ho + RF_TH - 1) / RF_TH;
-    const int grid = tiles_x * tiles_y * (CoutP / RF_BN);
+    const int n_tiles = tiles_x * tiles_y;                 // CoutP == BN: one channel tile
+    const int grid = n_tiles < slots ? n_tiles : slots;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out,
-                       Ho, Wo, tiles_x, zero_page);
+                       Ho, Wo, tiles_x, n_tiles, zero_page);
 }
 
 // does conv3x3_rf serve this layer?  Shape AND output size decide (the filter packing is the 32-channel-chunk one that
@@ -273,11 +312,12 @@ bool conv3x3_rf_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo)
 {
     static const char *mode = sfd2_env("SFD2_CONV_RF");   // experiments: "off", "all"
     if (mode && mode[0] == 'o') return false;
-    if (ks != 3 || (stride != 1 && stride != 2) || CoutP % RF_BN != 0 || Cin % 64 != 0) return false;
+    if (ks != 3 || (stride != 1 && stride != 2) || Cin % 64 != 0) return false;
+    if (CoutP != RF_BN && !(CoutP == 128 && stride == 2)) return false;   // one channel tile per block: 256, or conv2b's 128
     // the patch copies address the input through a buffer descriptor with 32-bit byte offsets
     if ((long long)(Ho * stride + 2) * (Wo * stride + 2) * Cin * (long long)sizeof(half_t) >= (1ll << 31)) return false;
     if (mode && mode[0] == 'a') return true;
-    if (stride == 2) return true;   // (conv2b, 128 -> 128 channels, through a 128-channel-block variant: 74 vs 70 us, not kept)
+    if (stride == 2) return true;
     // stride 1: conv3x3_pp (512 pixels x 128 channels per block) is the faster kernel per FLOP but needs ~2 blocks per CU
     // worth of output; compare rounds on the 256 CUs weighted by the measured time of one round of each (Cin = 256:
     // ~60 us against ~37 us; 1600x1200: convPa.3 52 -> 40 us here, conv3b 119 -> 143 us)
@@ -291,17 +331,18 @@ void launch_conv3x3_rf(hipStream_t st, const half_t *in, int H, int W, int Cin, 
                        int Ho, int Wo, const half_t *zero_page)
 {
 #ifdef SFD2_EXPERIMENTS
-    if (const char *ab = sfd2_env("SFD2_RF_ABL")) {
+    if (const char *ab = sfd2_env("SFD2_RF_ABL"); ab && CoutP == RF_BN) {
         switch (atoi(ab) * 4 + stride) {
 #define RF_ABL_CASE(a_) \
-        case (a_) * 4 + 1: launch_rf_t<1, a_>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page); return; \
-        case (a_) * 4 + 2: launch_rf_t<2, a_>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page); return;
+        case (a_) * 4 + 1: launch_rf_t<1, RF_BN, a_>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page); return; \
+        case (a_) * 4 + 2: launch_rf_t<2, RF_BN, a_>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page); return;
             RF_ABL_CASE(1) RF_ABL_CASE(2) RF_ABL_CASE(3) RF_ABL_CASE(4) RF_ABL_CASE(5) RF_ABL_CASE(6) RF_ABL_CASE(7) RF_ABL_CASE(8) RF_ABL_CASE(15)
 #undef RF_ABL_CASE
         default: break;
         }
     }
 #endif
-    if (stride == 2) launch_rf_t<2>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
+    if (CoutP == 128) launch_rf_t<2, 128>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
+    else if (stride == 2) launch_rf_t<2>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
     else launch_rf_t<1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
 }
