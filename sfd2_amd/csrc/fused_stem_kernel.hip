@@ -15,6 +15,7 @@
 // + prefetch (this file) see profiles/.
 #include "sfd2_internal.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 #define NT 512           // 8 waves: wave -> (output row = wave >> 1, 32-channel half = wave & 1)
 #define F_TH 4           // conv1b output rows per tile
@@ -36,10 +37,38 @@ __device__ __forceinline__ h4_t f_cvt4(float a, float b, float c, float d)
     return r;
 }
 
+// -DSFD2_STEM_TRACE: cycle stamps of block 0's waves 0 and 7 at the section boundaries of its first tiles, printed by the
+// launcher after a few launches (profiles/r02_stem_trace.txt).
+#ifdef SFD2_STEM_TRACE
+__device__ unsigned long long g_stem_trace[2][16][8];
+#define ST_STAMP(k_)                                                                          \
+    if (blockIdx.x == 0 && (wave == 0 || wave == 7) && lane == 0 && tcount < 16)              \
+        g_stem_trace[wave == 7][tcount][k_] = __builtin_readcyclecounter();
+#else
+#define ST_STAMP(k_)
+#endif
+
+// a / d for the four normalisation constants (0.229, 0.224, 0.225, 255), bit-identical to the IEEE division: Markstein's
+// q = RN(a * r), e = fma(-q, d, a), q' = fma(e, r, q) with r = RN(1 / d) is the correctly rounded quotient for every float
+// with 1e-30 <= |a| <= 1e30 -- checked exhaustively over all 2^32 inputs per constant (tools/verify_const_div.c,
+// profiles/r02_const_div_exhaustive.txt).  Three operations instead of the ~11 of the division routine (v_div_scale x 2,
+// quarter-rate v_rcp, fma chain, v_div_fmas, v_div_fixup).  Anything outside [1e-20, 1e20] (zero, non-finite, tiny, huge)
+// takes the routine, behind a real branch (the empty asm keeps hipcc from computing both and selecting).
+__device__ __forceinline__ float f_div_const(float a, float d, float r)
+{
+    const float m = fabsf(a);
+    if (__builtin_expect(!(m >= 1e-20f && m <= 1e20f), 0)) {
+        asm volatile("" ::: "memory");
+        return __fdiv_rn(a, d);
+    }
+    const float q = __fmul_rn(a, r);
+    return __fmaf_rn(__fmaf_rn(-q, d, a), r, q);
+}
+
 // LDS-only barrier: every wave's LDS writes are visible to the block afterwards; global loads / stores stay in flight
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-__global__ __launch_bounds__(NT)
+__global__ __launch_bounds__(NT, 2)   // one block per CU (156 KB of LDS): two waves per SIMD, 256 registers each
 void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalise,
                        const half_t *__restrict__ w1 /*[2][3][64][8] conv1a A fragments*/,
                        const float *__restrict__ sc1, const float *__restrict__ sh1,
@@ -73,8 +102,17 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
         a1[ky] = *reinterpret_cast<const h8_t *>(w1 + ((size_t)((wave & 1) * 3 + ky) * 64 + lane) * 8);
 
     // raw image values of this thread's F_IPT patch pixels (fp32 planes or uint8 HWC), fetched one tile ahead
-    float pr[F_IPT][3];
+    // raw values as loaded (float bits, or the uint8 byte): converted and normalised when they are written to LDS, so that
+    // requesting them never waits
+    unsigned int pr[F_IPT][3];
     unsigned pr_inside = 0;   // bit k: patch pixel k of this thread lies inside the image
+    int fpy[F_IPT], fpx[F_IPT];   // this thread's patch pixels (the same for every tile)
+#pragma unroll
+    for (int k = 0; k < F_IPT; ++k) {
+        const int p = tid + k * NT;
+        fpy[k] = p / F_IW;
+        fpx[k] = p - fpy[k] * F_IW;
+    }
 #define FETCH_IMG(tile_)                                                                                   \
     {                                                                                                      \
         const int ftx = (tile_) % tiles_x, fty = (tile_) / tiles_x;                                        \
@@ -82,18 +120,18 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
         pr_inside = 0;                                                                                     \
         _Pragma("unroll") for (int k = 0; k < F_IPT; ++k) {                                                \
             const int p = tid + k * NT;                                                                    \
-            const int py = p / F_IW, px = p - py * F_IW;                                                   \
-            const int iy = fy0 + py, ix = fx0 + px;                                                        \
-            float r = 0.0f, g = 0.0f, b = 0.0f;                                                            \
+            const int iy = fy0 + fpy[k], ix = fx0 + fpx[k];                                                \
+            unsigned int r = 0u, g = 0u, b = 0u;                                                           \
             if (p < F_IH * F_IW && iy >= 0 && iy < H && ix >= 0 && ix < W) {                               \
                 const size_t o = (size_t)iy * W + ix;                                                      \
                 pr_inside |= 1u << k;                                                                      \
                 if (normalise & 2) { /* uint8 HWC ingest (extract_localization.py:165-186) */              \
                     const unsigned char *u = reinterpret_cast<const unsigned char *>(img) + o * 3;         \
                     const int sw = (normalise & 4) ? 2 : 0; /* BGR -> RGB (:165) */                        \
-                    r = (float)u[sw]; g = (float)u[1]; b = (float)u[2 - sw];                               \
+                    r = u[sw]; g = u[1]; b = u[2 - sw];                                                    \
                 } else {                                                                                   \
-                    r = img[o]; g = img[plane + o]; b = img[2 * plane + o];                                \
+                    const unsigned int *iu = reinterpret_cast<const unsigned int *>(img);                  \
+                    r = iu[o]; g = iu[plane + o]; b = iu[2 * plane + o];                                   \
                 }                                                                                          \
             }                                                                                              \
             pr[k][0] = r; pr[k][1] = g; pr[k][2] = b;                                                      \
@@ -103,24 +141,61 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
 #define STORE_IMG()                                                                                        \
     _Pragma("unroll") for (int k = 0; k < F_IPT; ++k) {                                                    \
         const int p = tid + k * NT;                                                                        \
-        float r = pr[k][0], g = pr[k][1], b = pr[k][2];                                                    \
+        float r, g, b;                                                                                     \
+        if (normalise & 2) { r = (float)pr[k][0]; g = (float)pr[k][1]; b = (float)pr[k][2]; }              \
+        else { r = __uint_as_float(pr[k][0]); g = __uint_as_float(pr[k][1]); b = __uint_as_float(pr[k][2]); } \
         if (pr_inside & (1u << k)) {   /* zero padding stays exactly zero */                               \
-            if (normalise & 2) { r = __fdiv_rn(r, 255.0f); g = __fdiv_rn(g, 255.0f); b = __fdiv_rn(b, 255.0f); } \
+            if (normalise & 2) {                                                                           \
+                r = f_div_const(r, 255.0f, 1.0f / 255.0f); g = f_div_const(g, 255.0f, 1.0f / 255.0f);      \
+                b = f_div_const(b, 255.0f, 1.0f / 255.0f);                                                 \
+            }                                                                                              \
             if (normalise & 1) {                                                                           \
-                r = __fdiv_rn(__fsub_rn(r, 0.485f), 0.229f);                                               \
-                g = __fdiv_rn(__fsub_rn(g, 0.456f), 0.224f);                                               \
-                b = __fdiv_rn(__fsub_rn(b, 0.406f), 0.225f);                                               \
+                r = f_div_const(__fsub_rn(r, 0.485f), 0.229f, 1.0f / 0.229f);                              \
+                g = f_div_const(__fsub_rn(g, 0.456f), 0.224f, 1.0f / 0.224f);                              \
+                b = f_div_const(__fsub_rn(b, 0.406f), 0.225f, 1.0f / 0.225f);                              \
             }                                                                                              \
         }                                                                                                  \
         if (p < F_IH * F_IW) *reinterpret_cast<h4_t *>(IM + p * 4) = f_cvt4(r, g, b, 0.0f);                \
     }
 
+    // ---- phase 1 geometry, the same for every tile: a unit = (32-pixel column block, this wave's 32-channel half); 19
+    // blocks over four wave pairs = 5, 5, 5, 4 units.  Per unit: image-patch read offset, X1 record offset and swizzle,
+    // region coordinates for the image-bounds test (a measured tile spent ~1 150 cycles per unit around 96 cycles of MFMA,
+    // most of it this arithmetic recomputed per tile: profiles/r02_stem_trace.txt).
+    constexpr int P1_UNITS = ((F_RP + 31) / 32 + 3) / 4;
+    const int ct1 = wave & 1;
+    const int p1_n = ((F_RP + 31) / 32 - (wave >> 1) + 3) / 4;
+    int p1_im[P1_UNITS], p1_x[P1_UNITS], p1_sw[P1_UNITS], p1_ry[P1_UNITS], p1_rx[P1_UNITS];
+    bool p1_ok[P1_UNITS];
+#pragma unroll
+    for (int i = 0; i < P1_UNITS; ++i) {
+        const int p = ((wave >> 1) + 4 * i) * 32 + lrow;
+        const int pc = p < F_RP ? p : F_RP - 1;
+        const int ry = pc / F_RW, rx = pc - ry * F_RW;
+        p1_ok[i] = p < F_RP;
+        p1_ry[i] = ry;
+        p1_rx[i] = rx;
+        p1_im[i] = (ry * F_IW + rx + 2 * lhi) * 4;                       // halfs
+        p1_x[i] = (p ^ ((p >> 4) & 1)) * 128 + 8 * lhi;                  // bytes; + ((channel slot ^ swizzle) << 4)
+        p1_sw[i] = ((p >> 1) & 7) << 4;
+    }
+    float4 s1[4], h1[4];                                   // conv1a scale / shift of this wave's channels
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        s1[q] = *reinterpret_cast<const float4 *>(sc1 + ct1 * 32 + 8 * q + 4 * lhi);
+        h1[q] = *reinterpret_cast<const float4 *>(sh1 + ct1 * 32 + 8 * q + 4 * lhi);
+    }
+
     int tile = blockIdx.x;
     FETCH_IMG(tile)
     STORE_IMG()
+    if (tile + (int)gridDim.x < n_tiles) FETCH_IMG(tile + (int)gridDim.x)   // the second tile's patch: written to LDS a tile later
     SFD2_BARRIER_DRAIN();   // full barrier once: the filter copies (vmcnt) and IM / SS (LDS) are complete
 
-    for (;;) {
+    int tcount = 0;
+    (void)tcount;
+    for (;; ++tcount) {
+        ST_STAMP(0)
         const int tx = tile % tiles_x, ty = tile / tiles_x;
         const int oy0 = ty * F_TH, ox0 = tx * F_TW;
         const int ry0 = 2 * oy0 - 1, rx0 = 2 * ox0 - 1;               // image coords of conv1a region pixel (0, 0)
@@ -129,48 +204,45 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
         // half): 38 units over 8 waves = at most 5 per wave (whole blocks were 3 + 3 + 3 + 2 + ... = 6 half-units on the
         // busiest waves); a wave's half is fixed (wave & 1), so it keeps three filter fragments instead of six.  (Measured: 85.0 ->
         // 84.4 us -- the phases are serialised VALU / LDS / MFMA sections, not this imbalance.)
-        const int ct1 = wave & 1;
-        for (int t = wave >> 1; t < (F_RP + 31) / 32; t += NT / 128) {
-            const int p = t * 32 + lrow;
-            const int pc = p < F_RP ? p : F_RP - 1;
-            const int ry = pc / F_RW, rx = pc - ry * F_RW;
-            f32x16_t acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int i = 0; i < P1_UNITS; ++i) {
+            if (i < p1_n) {                                // wave-uniform: the last wave pair has one unit less
+                f32x16_t acc;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int q = (ry + ky) * F_IW + rx + 2 * lhi;
-                const h4_t lo = *reinterpret_cast<const h4_t *>(IM + q * 4);
-                const h4_t hi = *reinterpret_cast<const h4_t *>(IM + (q + 1) * 4);
-                h8_t b;
-                b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3];
-                b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ky], b, acc, 0, 0, 0);
-            }
-            // conv1b zero-pads conv1a's OUTPUT: region pixels outside the image are zeros, not conv1a(0)
-            const int gy = ry0 + ry, gx = rx0 + rx;
-            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            if (p < F_RP) {
-                const int sw = (p >> 1) & 7;
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const half_t *src = IM + p1_im[i] + ky * (F_IW * 4);
+                    const h4_t lo = *reinterpret_cast<const h4_t *>(src);
+                    const h4_t hi = *reinterpret_cast<const h4_t *>(src + 4);
+                    h8_t b;
+                    b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3];
+                    b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ky], b, acc, 0, 0, 0);
+                }
+                // conv1b zero-pads conv1a's OUTPUT: region pixels outside the image are zeros, not conv1a(0); the select is
+                // on the packed result (no branch around the epilogue)
+                const int gy = ry0 + p1_ry[i], gx = rx0 + p1_rx[i];
+                const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int c0 = ct1 * 32 + 8 * q + 4 * lhi;
-                    const float4 s = *reinterpret_cast<const float4 *>(SS + c0);
-                    const float4 h = *reinterpret_cast<const float4 *>(SS + 64 + c0);
-                    h4_t v = f_cvt4(0.f, 0.f, 0.f, 0.f);
-                    if (inside)
-                        v = f_cvt4(fmaxf(acc[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc[4 * q + 1] * s.y + h.y, 0.0f),
-                                   fmaxf(acc[4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc[4 * q + 3] * s.w + h.w, 0.0f));
+                    h4_t v = f_cvt4(fmaxf(acc[4 * q + 0] * s1[q].x + h1[q].x, 0.0f), fmaxf(acc[4 * q + 1] * s1[q].y + h1[q].y, 0.0f),
+                                    fmaxf(acc[4 * q + 2] * s1[q].z + h1[q].z, 0.0f), fmaxf(acc[4 * q + 3] * s1[q].w + h1[q].w, 0.0f));
+                    uint2 pk;
+                    __builtin_memcpy(&pk, &v, 8);
+                    if (!inside) pk = make_uint2(0u, 0u);
                     // records are stored pair-swapped where bit 4 of the index is set: the stride-2 reads of phase 2
                     // (lanes 256 B apart) then alternate between the two 128-byte halves of the bank space
-                    *reinterpret_cast<h4_t *>(X1 + (p ^ ((p >> 4) & 1)) * 128 + (((c0 >> 3) ^ sw) << 4) + (c0 & 4) * 2) = v;
+                    if (p1_ok[i]) *reinterpret_cast<uint2 *>(X1 + p1_x[i] + ((((ct1 * 4 + q) << 4)) ^ p1_sw[i])) = pk;
                 }
             }
         }
-        const int next = tile + (int)gridDim.x;
+        ST_STAMP(1)
+        const int next = tile + (int)gridDim.x, next2 = next + (int)gridDim.x;
         const bool has_next = next < n_tiles;
-        if (has_next) FETCH_IMG(next)      // global loads only; consumed after phase 2
+        ST_STAMP(2)
         LDS_BARRIER();                     // X1 complete; IM is free from here on
+        ST_STAMP(3)
 
         // ---- phase 2: conv1b (stride 2) from X1 and the resident taps: wave -> (output row, 32-channel half)
         const int orow = wave >> 1, cth = wave & 1;
@@ -195,6 +267,11 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
             }
         }
 
+        ST_STAMP(4)
+        // the NEXT tile's patch (requested a whole tile ago) -> IM, in front of this tile's output stores: the wait hipcc
+        // places in front of it then finds nothing younger than that request in flight (behind the stores it waited for
+        // them: ~1 000 cycles of every tile), and the registers are free for the request of the tile after next
+        if (has_next) STORE_IMG()
         const int oy = oy0 + orow, ox = ox0 + lrow;
         const bool inb = oy < H2 && ox < W2;
         half_t *o = out + ((size_t)(inb ? oy : 0) * W2 + (inb ? ox : 0)) * 64;
@@ -217,9 +294,12 @@ void fused_stem_kernel(const float *__restrict__ img, int H, int W, int normalis
             const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
             if (inb) *reinterpret_cast<uint4 *>(o + cth * 32 + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
         }
+        ST_STAMP(5)
         if (!has_next) break;
-        STORE_IMG()                        // the prefetched patch of the next tile -> IM
+        if (next2 < n_tiles) FETCH_IMG(next2)   // global loads only; consumed after phase 2 of the next tile
+        ST_STAMP(6)
         LDS_BARRIER();                     // IM complete, and every wave is done reading X1
+        ST_STAMP(7)
         tile = next;
     }
 #undef FETCH_IMG
@@ -245,4 +325,21 @@ void launch_fused_stem(hipStream_t st, const float *img, int H, int W, int norma
     const int grid = n_tiles < slots ? n_tiles : slots;
     hipLaunchKernelGGL(fused_stem_kernel, dim3(grid), dim3(NT), lds, st, img, H, W, normalise, w1, sc1, sh1, w2, sc2, sh2, out,
                        H2, W2, tiles_x, n_tiles);
+#ifdef SFD2_STEM_TRACE
+    {
+        static int dumps = 0;
+        if (H >= 1000 && ++dumps == 40) {
+            (void)hipStreamSynchronize(st);
+            static unsigned long long h[2][16][8];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stem_trace), sizeof(h));
+            fprintf(stderr, "stemtrace columns: phase 1 | - | barrier wait | phase 2 MFMAs | image -> LDS + epilogue + stores | fetch issue (tile + 2) | barrier wait\n");
+            for (int w = 0; w < 2; ++w)
+                for (int t = 2; t < 10; ++t) {
+                    fprintf(stderr, "stemtrace wave %d tile %2d:", w * 7, t);
+                    for (int k = 1; k < 8; ++k) fprintf(stderr, " %6lld", (long long)(h[w][t][k] - h[w][t][k - 1]));
+                    fprintf(stderr, "  (tile %lld)\n", (long long)(h[w][t + 1][0] - h[w][t][0]));
+                }
+        }
+    }
+#endif
 }
