@@ -283,6 +283,19 @@ def test_extract_full_size_1600x1200(model, synth_sd):
     _compare_extract(got, want, 0.93, 3e-3)
 
 
+def test_extract_beyond_one_round_of_tiles_2048x1536(model, synth_sd):
+    """A 3-megapixel image: the stride-2 convPa.0 has 384 tiles (and conv2b 1 536) for the 256 persistent blocks of
+    conv3x3_rf, i.e. its tile loop with the pipeline running across tile boundaries, and conv3x3_pp runs three tiles per
+    block.  Same comparison with the oracle as at 1600x1200."""
+    from sfd2_amd.extractor import extract_resnet_return
+    import torch
+    img = synth.make_image(1536, 2048, 15)
+    got = extract_resnet_return(model, torch.from_numpy(img)[None].cuda(), conf_th=0.001, topK=4096, scales=[1.0])
+    assert len(got["scores"]) == 4096
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=4096)
+    _compare_extract(got, want, 0.93, 3e-3)
+
+
 def test_extract_async_device_outputs_equal_sync(model):
     import torch
     from sfd2_amd.extractor import extract_resnet_return
