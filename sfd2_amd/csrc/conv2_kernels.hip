@@ -368,6 +368,7 @@ void launch_conv3x3_pp(hipStream_t st, const half_t *in, int H, int W, int Cin, 
                        int Ho, int Wo, const half_t *zero_page);
 
 bool conv3x3_rf_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo);
+bool conv3x3_rf_resident(int ks, int stride, int CoutP, int Cin);
 void launch_conv3x3_rf(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                        const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out,
                        int Ho, int Wo, const half_t *zero_page);
@@ -377,6 +378,7 @@ int conv_igemm2_chunk(int ks, int stride, int CoutP, int Cin)
 {
     if (CoutP % 128 != 0) return 0;
     if (conv3x3_pp_serves(ks, stride, CoutP, Cin)) return 32;   // conv3_kernels.hip
+    if (conv3x3_rf_resident(ks, stride, CoutP, Cin)) return 32; // conv3rf_kernels.hip (conv2a)
     if (stride == 2) return (ks == 3) ? 32 : 0;        // stride-2 3x3: 4-row tiles, 32-wide chunks (patch 9 x 65 records)
     if (stride != 1) return 0;
     // 256-channel tiles: 64-wide K chunks (one block per CU either way, half the barriers);

@@ -24,6 +24,7 @@
 // A pixel fragment is 2 output rows x 16 pixels; the row pitches (32, 40) make the two half-fragments 0 mod 16 records
 // apart, which is what keeps the ds_read_b128 lane groups (MI355X_MICROARCH.md, LDS) conflict-free.
 #include "sfd2_internal.h"
+#include <type_traits>
 
 #define RF_TH 8
 #define RF_TW 16
@@ -83,7 +84,12 @@ __device__ __forceinline__ void rf_copy_piece(const half_t *base, int nbytes, un
 // chunk and the first unit of the next tile's first chunk, whose operands are already in registers / in flight.  A
 // one-tile-per-CU launch (convPa.0 / convPa.3 at 1600x1200) behaves as before; conv2b (938 tiles of four chunks) no longer
 // pays a 230 KB prologue burst and an epilogue per 4.6k cycles of MFMA work with nothing running beside them.
-template <int S, int BN = RF_BN, int ABL = 0>
+//
+// RES (conv2a: 64 -> 128 channels, two chunks = 18 units): the filter ring covers the WHOLE filter set (18 x 2 fragments =
+// 144 registers per wave), so the filters are loaded once per block and never again -- the 128-pixel tile that cannot
+// afford to stream 295 KB of filters per tile does not have to.  The chunk loop is unrolled over the two chunks so that the
+// fragment index is a compile-time constant.
+template <int S, int BN = RF_BN, int ABL = 0, bool RES = false>
 __global__ __launch_bounds__(512, 2)
 void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                        const half_t *__restrict__ wpk, const float *__restrict__ scale,
@@ -95,6 +101,12 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     constexpr int NWC = BN / 32, NF = 4 / (8 / NWC);       // channel groups; pixel fragments per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Xs = smem;                              // [3][XBYTES]
+    // (an epilogue staged through LDS -- whole 256-byte pixel rows, 1 KB contiguous per store instruction instead of 32 B of
+    // 32 pixels -- was built for conv2a's 123 MB of output and measured: 77.7 vs 77.3 us, i.e. the stores are not what this
+    // layer waits for; kept as an option)
+    constexpr bool STG = false;
+    unsigned char *Stage = smem + 3 * G::XBYTES;           // [128][BN] fp16 when STG
+    (void)Stage;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -172,14 +184,18 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
-    h8_t fa[9][2], fb[3][NF];
+    constexpr int NFA = RES ? 18 : 9;
+    h8_t fa[NFA][2], fb[3][NF];
 
-    // scale / shift of this wave's 32 channels stay in registers (one channel tile: the same for every tile)
+    // scale / shift of this wave's 32 channels stay in registers (one channel tile: the same for every tile); RES has no
+    // registers to spare and re-reads them per tile
     float4 sc[4], sh[4];
+    if (!RES) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        sc[q] = *reinterpret_cast<const float4 *>(scale + n0 + 4 * lhi + 8 * q);
-        sh[q] = *reinterpret_cast<const float4 *>(shift + n0 + 4 * lhi + 8 * q);
+        for (int q = 0; q < 4; ++q) {
+            sc[q] = *reinterpret_cast<const float4 *>(scale + n0 + 4 * lhi + 8 * q);
+            sh[q] = *reinterpret_cast<const float4 *>(shift + n0 + 4 * lhi + 8 * q);
+        }
     }
     const float lo = relu ? 0.0f : -__builtin_huge_valf();   // branch-free ReLU (this file is compiled with -fno-honor-nans)
 
@@ -187,15 +203,17 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     RF_ISSUE_X(0, 0)
     RF_ISSUE_X(1, 1)                                       // Cin >= 64: at least two chunks per tile
 #pragma unroll
-    for (int u = 0; u < 9; ++u) RF_LOAD_A(u, fa[u]);
+    for (int u = 0; u < NFA; ++u) RF_LOAD_A(u, fa[u]);
     // (waiting for the first patch only and letting the rest land behind counted waits was measured: no gain)
     SFD2_BARRIER_DRAIN();
     RF_READ_B(Xs, 0, 0, fb[0]);
     RF_READ_B(Xs, 0, 1, fb[1]);
 
     int bc = 0;                                            // C % 3: three patch buffers
-    int c = 0, seq = 0;                                    // chunk within the tile, tile of this block
-    for (int C = 0; C < TC; ++C) {
+    int c = 0, seq = 0, C = 0;                             // chunk within the tile, tile of this block, chunk of this block
+    // one chunk; CC = the chunk's index within the tile as a constant (RES), or -1 (runtime c)
+    auto chunk = [&](auto cc_tag) {
+        constexpr int CC = decltype(cc_tag)::value;
         const int bn = bc == 2 ? 0 : bc + 1, bnn = bn == 2 ? 0 : bn + 1;
         const unsigned char *xs = Xs + bc * G::XBYTES;
         const unsigned char *xn = Xs + bn * G::XBYTES;
@@ -212,9 +230,11 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             if (t == 8) {
                 // chunk boundary: my pieces of the next patch have landed (VMW younger operations may still be in flight;
                 // a tile's epilogue only adds younger ones), my reads of this one are done; then the whole block's.  The
-                // last chunk's look-ahead reads return stale records that no MFMA consumes.
+                // last chunk's look-ahead reads return stale records that no MFMA consumes.  (RES issues no filter
+                // loads: only the PPW pieces of the patch after next are younger.)
                 static_assert(RfGeom<1>::VMW == 33 && RfGeom<2>::VMW == 30, "chunk-boundary wait counts");
-                if (S == 2) asm volatile("s_waitcnt vmcnt(30) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (RES) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else if (S == 2) asm volatile("s_waitcnt vmcnt(30) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(33) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -227,54 +247,99 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
-                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][kk], fb[h % 3][f], acc[f], 0, 0, 0);
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[RES ? CC * 9 + t : t][kk], fb[h % 3][f], acc[f], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // nine units ahead: the same filters serve every tile, so the ring wraps at a tile's last unit
-            int ua = c * 9 + t + 9;
-            if (ua >= NU) ua -= NU;
-            if (!(ABL & 1)) RF_LOAD_A(ua, fa[t]);
+            if (!RES) {
+                // nine units ahead: the same filters serve every tile, so the ring wraps at a tile's last unit
+                int ua = c * 9 + t + 9;
+                if (ua >= NU) ua -= NU;
+                if (!(ABL & 1)) RF_LOAD_A(ua, fa[t]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         bc = bn;
-        if (++c < NCH) continue;
-
-        // ---- the tile's epilogue: y = acc * scale + shift (ReLU), regrouped with v_permlane32_swap into 16-byte stores
-        // (conv2_kernels.hip); the next tile's first operands are already in registers / in flight
-        {
-            const int swz_ = xcd_swizzle4((int)blockIdx.x + seq * (int)gridDim.x, n_tiles);
-            const int tx_ = swz_ % tiles_x, ty_ = swz_ / tiles_x;
-            const int oy0 = ty_ * RF_TH, ox0 = tx_ * RF_TW;
+        ++C;
+    };
+    // a tile's epilogue: y = acc * scale + shift (ReLU), regrouped with v_permlane32_swap into 16-byte stores
+    // (conv2_kernels.hip); the next tile's first operands are already in registers / in flight
+    auto epilogue = [&]() {
+        if (RES) {
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const int oy = oy0 + 2 * (f0 + f) + ly, ox = ox0 + lx;
-                const bool inb = oy < Ho && ox < Wo;
-                const size_t pix = (size_t)(inb ? oy : 0) * Wo + (inb ? ox : 0);
+            for (int q = 0; q < 4; ++q) {
+                sc[q] = *reinterpret_cast<const float4 *>(scale + n0 + 4 * lhi + 8 * q);
+                sh[q] = *reinterpret_cast<const float4 *>(shift + n0 + 4 * lhi + 8 * q);
+            }
+        }
+        const int swz_ = xcd_swizzle4((int)blockIdx.x + seq * (int)gridDim.x, n_tiles);
+        const int tx_ = swz_ % tiles_x, ty_ = swz_ / tiles_x;
+        const int oy0 = ty_ * RF_TH, ox0 = tx_ * RF_TW;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const size_t o16 = pix * CoutP + n0 + 8 * (2 * m + lhi);
-                    uint2 pk[2];
+        for (int f = 0; f < NF; ++f) {
+            const int oy = oy0 + 2 * (f0 + f) + ly, ox = ox0 + lx;
+            const bool inb = oy < Ho && ox < Wo;
+            const size_t pix = (size_t)(inb ? oy : 0) * Wo + (inb ? ox : 0);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int q = 2 * m + j;
-                        float v0 = acc[f][4 * q + 0] * sc[q].x + sh[q].x;
-                        float v1 = acc[f][4 * q + 1] * sc[q].y + sh[q].y;
-                        float v2 = acc[f][4 * q + 2] * sc[q].z + sh[q].z;
-                        float v3 = acc[f][4 * q + 3] * sc[q].w + sh[q].w;
-                        v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
-                        const h4_t hv = cvt4r(v0, v1, v2, v3);
-                        __builtin_memcpy(&pk[j], &hv, 8);
-                    }
-                    const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
-                    const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
-                    if (inb && (!(ABL & 8) || t0[0] == 0x12345678u)) *reinterpret_cast<uint4 *>(out + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+            for (int m = 0; m < 2; ++m) {
+                const size_t o16 = pix * CoutP + n0 + 8 * (2 * m + lhi);
+                uint2 pk[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int q = 2 * m + j;
+                    float v0 = acc[f][4 * q + 0] * sc[q].x + sh[q].x;
+                    float v1 = acc[f][4 * q + 1] * sc[q].y + sh[q].y;
+                    float v2 = acc[f][4 * q + 2] * sc[q].z + sh[q].z;
+                    float v3 = acc[f][4 * q + 3] * sc[q].w + sh[q].w;
+                    v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
+                    const h4_t hv = cvt4r(v0, v1, v2, v3);
+                    __builtin_memcpy(&pk[j], &hv, 8);
                 }
+                const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                const uint4 v16 = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                if (STG) {
+                    // through LDS: [128 pixels][BN channels] fp16 with the 16-byte slots XOR-swizzled by the pixel index
+                    const int px = 32 * (f0 + f) + l32;
+                    const int slot = (n0 >> 3) + 2 * m + lhi;
+                    *reinterpret_cast<uint4 *>(Stage + px * (BN * 2) + ((slot ^ (px & 15)) << 4)) = v16;
+                } else if (inb && (!(ABL & 8) || t0[0] == 0x12345678u)) {
+                    *reinterpret_cast<uint4 *>(out + o16) = v16;
+                }
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+        }
+        if (STG) {
+            // ... and out again as whole pixel rows: a store instruction covers 64 consecutive 16-byte slots = four
+            // neighbouring pixels x 256 B = 1 KB of contiguous output (the direct form writes 32 B of 32 pixels per
+            // instruction; the output of conv2a is 123 MB and its stores were as long as its MFMAs)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            constexpr int SLOTS = BN / 8;                  // 16-byte slots per pixel
+#pragma unroll
+            for (int k = 0; k < 128 * SLOTS / 512; ++k) {
+                const int i = tid + k * 512;
+                const int px = i / SLOTS, slot = i - px * SLOTS;
+                const int fr = px >> 5, l = px & 31;
+                const int oy = oy0 + 2 * fr + (l >> 4), ox = ox0 + (l & 15);
+                const uint4 v16 = *reinterpret_cast<const uint4 *>(Stage + px * (BN * 2) + ((slot ^ (px & 15)) << 4));
+                if (oy < Ho && ox < Wo && !(ABL & 8))
+                    *reinterpret_cast<uint4 *>(out + ((size_t)oy * Wo + ox) * CoutP + slot * 8) = v16;
             }
         }
         c = 0;
         ++seq;
+    };
+    if constexpr (RES) {
+        for (int s2 = 0; s2 < n_my; ++s2) {
+            chunk(std::integral_constant<int, 0>{});
+            chunk(std::integral_constant<int, 1>{});
+            epilogue();
+        }
+    } else {
+        while (C < TC) {
+            chunk(std::integral_constant<int, -1>{});
+            if (++c == NCH) epilogue();
+        }
     }
 #undef RF_ISSUE_X
 #undef RF_ISSUE_X1
@@ -283,7 +348,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #undef RF_SETUP_X
 }
 
-template <int S, int BN = RF_BN, int ABL = 0>
+template <int S, int BN = RF_BN, int ABL = 0, bool RES = false>
 static void launch_rf_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                         const float *scale, const float *shift, int CoutP, int relu, half_t *out,
                         int Ho, int Wo, const half_t *zero_page)
@@ -291,7 +356,7 @@ static void launch_rf_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
     constexpr size_t lds = (size_t)3 * RfGeom<S>::XBYTES;
     static bool attr_done = false;
     static int slots = 256;
-    auto kern = conv3x3_rf_kernel<S, BN, ABL>;
+    auto kern = conv3x3_rf_kernel<S, BN, ABL, RES>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int dev = 0, cus = 0;
@@ -308,19 +373,28 @@ static void launch_rf_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
 
 // does conv3x3_rf serve this layer?  Shape AND output size decide (the filter packing is the 32-channel-chunk one that
 // conv3x3_pp and the stride-2 conv_igemm2 use, so the choice can be made per launch).
+// conv2a (64 -> 128 channels, stride 1) goes through the resident-filter variant at every size: its filters are packed in
+// 32-channel chunks for that (conv_igemm2_chunk asks)
+bool conv3x3_rf_resident(int ks, int stride, int CoutP, int Cin)
+{
+    static const bool no_res = sfd2_env("SFD2_RF_NO_RES") != nullptr;   // experiment: conv_igemm2 for conv2a
+    return !no_res && ks == 3 && stride == 1 && CoutP == 128 && Cin == 64;
+}
+
 bool conv3x3_rf_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo)
 {
     static const char *mode = sfd2_env("SFD2_CONV_RF");   // experiments: "off", "all"
     if (mode && mode[0] == 'o') return false;
     if (ks != 3 || (stride != 1 && stride != 2) || Cin % 64 != 0) return false;
-    if (CoutP != RF_BN && !(CoutP == 128 && stride == 2)) return false;   // one channel tile per block: 256, or conv2b's 128
     // the patch copies address the input through a buffer descriptor with 32-bit byte offsets
     if ((long long)(Ho * stride + 2) * (Wo * stride + 2) * Cin * (long long)sizeof(half_t) >= (1ll << 31)) return false;
+    if (conv3x3_rf_resident(ks, stride, CoutP, Cin)) return true;
+    if (CoutP != RF_BN && !(CoutP == 128 && stride == 2)) return false;   // one channel tile per block: 256, or conv2b's 128
     if (mode && mode[0] == 'a') return true;
     if (stride == 2) return true;
     // stride 1: conv3x3_pp (512 pixels x 128 channels per block) is the faster kernel per FLOP but needs ~2 blocks per CU
     // worth of output; compare rounds on the 256 CUs weighted by the measured time of one round of each (Cin = 256:
-    // ~60 us against ~37 us; 1600x1200: convPa.3 52 -> 40 us here, conv3b 119 -> 143 us)
+    // ~60 us against ~37 us; 1600x1200: convPa.3 52 -> 40 us here, conv3b 113 -> 130 us)
     const long long pp_blocks = (long long)((Wo + 31) / 32) * ((Ho + 15) / 16) * (CoutP / 128);
     const long long rf_blocks = (long long)((Wo + RF_TW - 1) / RF_TW) * ((Ho + RF_TH - 1) / RF_TH) * (CoutP / RF_BN);
     return ((rf_blocks + 255) / 256) * 10 < ((pp_blocks + 255) / 256) * 16;
@@ -342,7 +416,8 @@ void launch_conv3x3_rf(hipStream_t st, const half_t *in, int H, int W, int Cin, 
         }
     }
 #endif
-    if (CoutP == 128) launch_rf_t<2, 128>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
+    if (CoutP == 128 && stride == 1) launch_rf_t<1, 128, 0, true>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
+    else if (CoutP == 128) launch_rf_t<2, 128>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
     else if (stride == 2) launch_rf_t<2>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
     else launch_rf_t<1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page);
 }
