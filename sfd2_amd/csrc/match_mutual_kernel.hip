@@ -144,7 +144,9 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const h
         SFD2_BARRIER_DRAIN();
         // tile by tile.  Measured alternatives (profiles/r02_match_pmc.txt): the MFMAs of tile k + 1 software-pipelined
         // with the epilogue of tile k (+2 %, register pressure), the same pinned with sched_barrier (+3 %), 32 queries per
-        // wave at 4 waves per SIMD (+12 %), 128-candidate stages (+23 %, spills), one wave per SIMD (+48 %)
+        // wave at 4 waves per SIMD (+12 %), 128-candidate stages (+23 %, spills), one wave per SIMD (+48 %); late round 2:
+        // two wave groups one barrier apart as in conv3x3_pp (512 queries per block, MFMA section / epilogue section per tile,
+        // three candidate stages in flight): bit-identical, 269 -> 322-341 us
         for (int s = 0; s < nst; ++s) {
             const int buf = s & 1;
             if (s + 1 < nst) { ISSUE_B(s + 1, buf ^ 1) }
