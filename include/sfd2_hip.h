@@ -94,10 +94,17 @@ int sfd2_load_weights(sfd2_ctx *ctx, const sfd2_tensor *tensors, int n);
  * fp32 activations -- the parity mode (differs from the fp32 reference by summation order only).
  * SFD2_PREC_F16X3: the parity mode's buffers, filters and layer sequence with the 3x3 / 1x1 convolutions on the fp16
  * matrix path in three passes (operands split into hi + lo fp16 while they are staged; ~2^-22 per product against
- * fp32's 2^-24, fp32 accumulation) -- descriptors within 2e-5 of the reference like SFD2_PREC_F32, ~1.9x its speed. */
+ * fp32's 2^-24, fp32 accumulation) -- descriptors within 2e-5 of the reference like SFD2_PREC_F32, ~1.9x its speed.
+ * SFD2_PREC_F16C: compensated fp16 -- the throughput mode's layout and kernels, with the backbone (conv1a .. conv4.2)
+ * carrying a second 2-byte plane per activation and per filter that holds the fp16 rounding residual and the value at
+ * fp8 precision; every backbone layer adds the two first-order error terms with ONE block-scaled fp8 MFMA per 32
+ * channels (1.65x the matrix time of the fp16 layer).  Operands then carry ~15 significant bits: descriptors within
+ * 1e-3 of the fp32 reference (measured <= 3e-4), which is the tolerance BASELINE.json's north_star states.  The head
+ * branches stay plain fp16 (they contribute 2.4e-4 on their own).  Option "comp_heads" extends it to convPa / convDa. */
 #define SFD2_PREC_F16 0
 #define SFD2_PREC_F32 1
 #define SFD2_PREC_F16X3 2
+#define SFD2_PREC_F16C 3
 int sfd2_set_precision(sfd2_ctx *ctx, int mode);
 
 /* Execution options of a context (the reference has none: its layers are stock torch modules).

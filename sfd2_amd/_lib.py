@@ -198,7 +198,7 @@ class Context:
 
     def set_precision(self, mode):
         """'f16' (throughput mode, default) or 'f32' (strict parity mode)."""
-        check(self.lib.sfd2_set_precision(self.h, {'f16': 0, 'f32': 1, 'f16x3': 2}[mode]))
+        check(self.lib.sfd2_set_precision(self.h, {'f16': 0, 'f32': 1, 'f16x3': 2, 'f16c': 3}[mode]))
 
     def set_option(self, key, value):
         """'fuse', 'fuse_det', 'alias', 'graphs', 'fuse_post', 'sparse_desc', 'branches' (include/sfd2_hip.h sfd2_set_option)."""

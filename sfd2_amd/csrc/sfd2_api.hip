@@ -4,6 +4,7 @@
 #include "sfd2_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cmath>
 #include <cstdio>
@@ -25,7 +26,7 @@ static int fail(const std::string &m)
             return fail(std::string(#expr) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
     } while (0)
 
-static unsigned long long g_alloc_gen = 0;   // bumped whenever a workspace buffer is (re)allocated: captured graphs hold raw pointers
+static std::atomic<unsigned long long> g_alloc_gen{0};   // (process-wide, contexts may live on different threads) bumped whenever a workspace buffer is (re)allocated: captured graphs hold raw pointers
 
 struct DevBuf {
     void *p = nullptr;
@@ -56,10 +57,13 @@ struct ConvW {                 // one folded + packed layer
     DevBuf wrm;                // 1x1 256 -> 256 layers: the same filters as plain [cout][cin] fp16 (conv1x1_c256_kernel)
     DevBuf wgc;                // grouped 3x3: compact [256 oc][9 taps][8 in] fp16 (resblock_kernel)
     DevBuf wx3;                // fp32 layers, SFD2_PREC_F16X3: every float4 of w as (4 hi, 4 lo) fp16, made on first use
+    DevBuf wc;                 // SFD2_PREC_F16C: [2 * cin / 32][taps][cout_pad][32] units -- the fp16 filters in 32-wide chunks, then the
+                               // corr units (fp8 of w * 2^b0, fp8 of (w - fp16(w)) * 2^(b0 + 11)); conv1a / grouped conv: hi then lo fragments
+    int sbyte = 127;           // E8M0 scale byte of the layer's corr MFMAs: 127 - 9 - b0
     size_t w_floats = 0;       // floats in w (fp32 layers)
 };
 
-struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; };
+struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; const void *pc = nullptr; /* corr plane (f16c) */ };
 
 struct sfd2_ctx {
     int device = 0;
@@ -293,6 +297,38 @@ static int fold_scale_shift(const TMap &m, const std::string &conv, const std::s
     return 0;
 }
 
+// OCP fp8 e4m3fn, round to nearest even, saturating at +-448 (the filters' corr units of SFD2_PREC_F16C)
+static unsigned char f32_to_e4m3(float f)
+{
+    const unsigned char sign = std::signbit(f) ? 0x80 : 0x00;
+    float a = std::fabs(f);
+    if (!(a == a)) return sign | 0x7f;
+    if (a >= 448.0f) return sign | 0x7e;
+    if (a < 0x1p-10f) return sign;                     // below half of the smallest subnormal (2^-9); the tie rounds to even = 0
+    int e;
+    (void)std::frexp(a, &e);                           // a = m * 2^e, m in [0.5, 1)
+    int ex = e - 1;                                    // a in [2^ex, 2^(ex+1))
+    if (ex < -6) ex = -6;                              // subnormal range shares the exponent of the smallest normal
+    const float q = std::ldexp(a, 3 - ex);             // units of 2^(ex-3): 8..16 for normals, 0..8 for subnormals
+    float r = std::nearbyint(q);                       // default rounding mode: to nearest even
+    int mant = (int)r, be = ex + 7;
+    if (ex == -6 && mant < 8) return sign | (unsigned char)mant;      // subnormal (biased exponent 0)
+    if (mant == 16) { mant = 8; ++be; }
+    if (be > 15 || (be == 15 && mant - 8 > 6)) return sign | 0x7e;
+    return sign | (unsigned char)((be << 3) | (mant - 8));
+}
+
+// scale exponent b0 of a layer's corr filters: the largest power of two with max|w| * 2^b0 <= 448
+static int corr_b0(const float *w, size_t n)
+{
+    float mx = 0.0f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w[i]));
+    if (!(mx > 0.0f) || !std::isfinite(mx)) return 0;
+    int b0 = (int)std::floor(std::log2(448.0f / mx));
+    while (std::ldexp(mx, b0) > 448.0f) --b0;
+    return std::max(-40, std::min(40, b0));
+}
+
 static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &conv, const std::string &bn, int cin,
                       int cout, int ks, int stride)
 {
@@ -322,6 +358,28 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
         for (size_t i = 0; i < rm.size(); ++i) rm[i] = (half_t)w->d[i];
         if (upload(L.wrm, rm.data(), rm.size() * sizeof(half_t), c->stream)) return -1;
     }
+    {   // SFD2_PREC_F16C: 32-wide chunks of the fp16 filters, then the corr units in the same geometry
+        const int nch32 = cin / 32;
+        const size_t plane = (size_t)nch32 * T * cout_pad * 32;
+        std::vector<unsigned short> pc(2 * plane, 0);
+        const int b0 = corr_b0(w->d, w->numel());
+        L.sbyte = 127 - SFD2_C_XL_SHIFT - b0;
+        for (int ch = 0; ch < nch32; ++ch)
+            for (int t = 0; t < T; ++t)
+                for (int oc = 0; oc < cout; ++oc)
+                    for (int k = 0; k < 32; ++k) {
+                        const float v = w->d[(((size_t)oc * cin + ch * 32 + k) * ks + t / ks) * ks + t % ks];
+                        const half_t h = (half_t)v;
+                        const size_t o = (((size_t)ch * T + t) * cout_pad + oc) * 32 + k;
+                        unsigned short hb;
+                        std::memcpy(&hb, &h, 2);
+                        pc[o] = hb;
+                        const unsigned char w8 = f32_to_e4m3(std::ldexp(v, b0));
+                        const unsigned char l8 = f32_to_e4m3(std::ldexp(v - (float)h, b0 + 11));
+                        pc[plane + o] = (unsigned short)(w8 | (l8 << 8));   // pairs with the pixel unit (residual byte, value byte)
+                    }
+        if (upload(L.wc, pc.data(), pc.size() * 2, c->stream)) return -1;
+    }
     return 0;
 }
 
@@ -350,6 +408,22 @@ static int pack_conv1a(sfd2_ctx *c, const TMap &m)
     if (upload(L.w, pk.data(), pk.size() * sizeof(half_t), c->stream)) return -1;
     if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
     if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+    {   // SFD2_PREC_F16C: the same fragments (hi) followed by fp16(w - hi) (lo)
+        std::vector<half_t> pc(2 * pk.size(), (half_t)0.0f);
+        for (int ct = 0; ct < 2; ++ct)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int oc = ct * 32 + (lane & 31), g = lane >> 5;
+                        const int kx = 2 * g + (j >> 2), ch = j & 3;
+                        float v = 0.0f;
+                        if (kx < 3 && ch < 3) v = w->d[(((size_t)oc * 3 + ch) * 3 + ky) * 3 + kx];
+                        const size_t o = (((size_t)ct * 3 + ky) * 64 + lane) * 8 + j;
+                        pc[o] = (half_t)v;
+                        pc[pk.size() + o] = (half_t)(v - (float)pc[o]);
+                    }
+        if (upload(L.wc, pc.data(), pc.size() * sizeof(half_t), c->stream)) return -1;
+    }
     return 0;
 }
 
@@ -385,6 +459,23 @@ static int pack_gconv(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
             for (int j = 0; j < 8; ++j)
                 cp[((size_t)oc * 9 + tap) * 8 + j] = (half_t)w->d[(((size_t)oc * 8 + j) * 3 + tap / 3) * 3 + tap % 3];
     if (upload(L.wgc, cp.data(), cp.size() * sizeof(half_t), c->stream)) return -1;
+    {   // SFD2_PREC_F16C: hi fragments (= pk) then lo fragments
+        std::vector<half_t> pc(2 * pk.size(), (half_t)0.0f);
+        for (int pair = 0; pair < 16; ++pair)
+            for (int s2 = 0; s2 < 5; ++s2)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = lane & 15, g = lane >> 4;
+                        const int tap = 2 * s2 + (g >> 1);
+                        const int oc = pair * 16 + i;
+                        float v = 0.0f;
+                        if (tap <= 8 && (i >> 3) == (g & 1)) v = w->d[(((size_t)oc * 8 + j) * 3 + tap / 3) * 3 + tap % 3];
+                        const size_t o = (((size_t)pair * 5 + s2) * 64 + lane) * 8 + j;
+                        pc[o] = (half_t)v;
+                        pc[pk.size() + o] = (half_t)(v - (float)pc[o]);
+                    }
+        if (upload(L.wc, pc.data(), pc.size() * sizeof(half_t), c->stream)) return -1;
+    }
     return 0;
 }
 
@@ -457,6 +548,13 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
     c->weights_loaded = false;   // a failure part-way must not leave a half-replaced set usable
+    graphs_release(c);           // captured units hold pointers into the filter buffers
+    {   // SFD2_PREC_F16X3 keeps split copies of the fp32 filters, made on first use: they belong to the OLD weights
+        ConvW *fl[] = {&c->f1a, &c->f1b, &c->f2a, &c->f2b, &c->f3a, &c->f3b, &c->frb1[0], &c->frb1[1], &c->frb1[2], &c->frb2[0],
+                       &c->frb2[1], &c->frb2[2], &c->frb3[0], &c->frb3[1], &c->frb3[2], &c->fpa0, &c->fpa3, &c->fda0, &c->fda3,
+                       &c->fpb, &c->fdb};
+        for (ConvW *L : fl) L->wx3.release();
+    }
     TMap m;
     for (int i = 0; i < n; ++i) {
         if (!tensors[i].name || !tensors[i].data) continue;
@@ -514,7 +612,7 @@ static int down2(int n) { return (n - 1) / 2 + 1; }  // 3x3 stride 2 pad 1
 // which kernels / buffers the next network pass uses; call before ensure_workspace
 static void set_path(sfd2_ctx *c, bool parity_entry)
 {
-    const bool f16 = c->precision == SFD2_PREC_F16;
+    const bool f16 = c->precision == SFD2_PREC_F16 || c->precision == SFD2_PREC_F16C;
     c->fuse_now = f16 && (parity_entry ? c->fuse_det : c->fuse);
     c->alias_now = c->fuse_now && !parity_entry && c->opt_alias;
 }
@@ -531,21 +629,26 @@ static int ensure_workspace(sfd2_ctx *c, int H, int W)
     c->H8 = down2(c->H4); c->W8 = down2(c->W4);
     const size_t P1 = (size_t)H * W, P2 = (size_t)c->H2 * c->W2, P4 = (size_t)c->H4 * c->W4, P8 = (size_t)c->H8 * c->W8;
     const size_t hb = sizeof(half_t);
-    const bool f32 = c->precision != SFD2_PREC_F16;   // SFD2_PREC_F32 and SFD2_PREC_F16X3 share the fp32 buffers
+    const bool f32 = c->precision == SFD2_PREC_F32 || c->precision == SFD2_PREC_F16X3;   // they share the fp32 buffers
+    const bool comp = c->precision == SFD2_PREC_F16C;
     const bool layers = !f32 && !c->alias_now;      // private fp16 buffer per activation
+    // SFD2_PREC_F16C: every backbone activation is a hi plane followed by its corr plane (same geometry)
+    const size_t bb = comp ? 2 * hb : hb;
+    const bool fused_stem = c->fuse_now && !comp;   // (no compensated fused stem yet: conv1a's planes go through memory)
+    const bool fused_rb = c->fuse_now && !comp;
+    if (!f32 && !fused_stem) HIPCHECK(c->a1a.ensure(P1 * 64 * bb));
     if (layers) {
-        if (!c->fuse_now) HIPCHECK(c->a1a.ensure(P1 * 64 * hb));
-        HIPCHECK(c->a1b.ensure(P2 * 64 * hb));
-        HIPCHECK(c->a2a.ensure(P2 * 128 * hb));
-        HIPCHECK(c->a2b.ensure(P4 * 128 * hb));
-        HIPCHECK(c->a3a.ensure(P4 * 256 * hb));
-        HIPCHECK(c->a3b.ensure(P4 * 256 * hb));
+        HIPCHECK(c->a1b.ensure(P2 * 64 * bb));
+        HIPCHECK(c->a2a.ensure(P2 * 128 * bb));
+        HIPCHECK(c->a2b.ensure(P4 * 128 * bb));
+        HIPCHECK(c->a3a.ensure(P4 * 256 * bb));
+        HIPCHECK(c->a3b.ensure(P4 * 256 * bb));
         for (int b = 0; b < 3; ++b) {
-            if (!c->fuse_now) {
-                HIPCHECK(c->rt1[b].ensure(P4 * 256 * hb));
-                HIPCHECK(c->rt2[b].ensure(P4 * 256 * hb));
+            if (!fused_rb) {
+                HIPCHECK(c->rt1[b].ensure(P4 * 256 * bb));
+                HIPCHECK(c->rt2[b].ensure(P4 * 256 * bb));
             }
-            HIPCHECK(c->ro[b].ensure(P4 * 256 * hb));
+            HIPCHECK(c->ro[b].ensure(P4 * 256 * bb));
         }
         HIPCHECK(c->pa0_o.ensure(P8 * 256 * hb));
         HIPCHECK(c->pa_o.ensure(P8 * 256 * hb));
@@ -565,7 +668,11 @@ static int ensure_workspace(sfd2_ctx *c, int H, int W)
     HIPCHECK(c->counters.ensure(SFD2_COUNTER_BYTES));
     c->acts.clear();
     auto reg = [&](const char *nm, const void *ptr, int is_f32, int planar, int ch, int pitch, int h, int w) {
-        c->acts[nm] = ActInfo{ptr, is_f32, planar, ch, pitch, h, w};
+        ActInfo ai{ptr, is_f32, planar, ch, pitch, h, w};
+        // backbone activations of SFD2_PREC_F16C: the corr plane follows the hi plane
+        if (comp && !is_f32 && std::strncmp(nm, "convP", 5) != 0 && std::strncmp(nm, "convD", 5) != 0)
+            ai.pc = reinterpret_cast<const half_t *>(ptr) + (size_t)pitch * h * w;
+        c->acts[nm] = ai;
     };
     static const char *n1[3] = {"conv4.0.bn1", "conv4.1.bn1", "conv4.2.bn1"};
     static const char *n2[3] = {"conv4.0.bn2", "conv4.1.bn2", "conv4.2.bn2"};
@@ -608,14 +715,14 @@ static int ensure_workspace(sfd2_ctx *c, int H, int W)
         return 0;
     }
     if (!layers) return 0;   // throughput path: intermediates live in aliased arena slots and are not readable
-    if (!c->fuse_now) reg("conv1a", c->a1a.p, 0, 0, 64, 64, H, W);
+    if (!fused_stem) reg("conv1a", c->a1a.p, 0, 0, 64, 64, H, W);
     reg("bn1b", c->a1b.p, 0, 0, 64, 64, c->H2, c->W2);
     reg("conv2a", c->a2a.p, 0, 0, 128, 128, c->H2, c->W2);
     reg("bn2b", c->a2b.p, 0, 0, 128, 128, c->H4, c->W4);
     reg("conv3a", c->a3a.p, 0, 0, 256, 256, c->H4, c->W4);
     reg("bn3b", c->a3b.p, 0, 0, 256, 256, c->H4, c->W4);
     for (int b = 0; b < 3; ++b) {
-        if (!c->fuse_now) {
+        if (!fused_rb) {
             reg(n1[b], c->rt1[b].p, 0, 0, 256, 256, c->H4, c->W4);
             reg(n2[b], c->rt2[b].p, 0, 0, 256, 256, c->H4, c->W4);
         }
@@ -652,6 +759,25 @@ static void conv(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &in
     launch_conv_igemm(c->cur_stream, in.as<half_t>(), H, W, L.cin, L.w.as<half_t>(), L.scale.as<float>(),
                       L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu, res, out.p, out_f32, Ho, Wo,
                       c->zero_page.as<half_t>());
+}
+
+// SFD2_PREC_F16C: one compensated layer.  A compensated tensor = hi plane followed by its corr plane; in_comp / out_comp
+// say which of the two tensors have one (a plain-fp16 consumer just reads the hi plane).
+static half_t *corr_of(const DevBuf &b, size_t px, int pitch) { return b.as<half_t>() + px * (size_t)pitch; }
+static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &in, int H, int W, const DevBuf &out,
+                  int Ho, int Wo, int relu, bool in_comp, bool out_comp, const DevBuf *res = nullptr)
+{
+    char kn[48];
+    snprintf(kn, sizeof(kn), "convc_igemm<%d,%d>", L.ks, L.stride);
+    const double px = (double)Ho * Wo;
+    const double flops = 2.0 * px * L.cout * L.cin * L.ks * L.ks;
+    const double bytes = (in_comp ? 4.0 : 2.0) * ((double)H * W * L.cin + (double)L.cout * L.cin * L.ks * L.ks) +
+                         px * L.cout_pad * (out_comp ? 4.0 : 2.0) + (res ? px * L.cout_pad * 4.0 : 0.0);
+    ProfScope ps(c, name, kn, flops, bytes);
+    launch_convc_igemm(c->cur_stream, in.as<half_t>(), in_comp ? corr_of(in, (size_t)H * W, L.cin) : nullptr, H, W, L.cin,
+                       L.wc.as<half_t>(), L.scale.as<float>(), L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu,
+                       res ? res->as<half_t>() : nullptr, res ? corr_of(*res, (size_t)Ho * Wo, L.cout_pad) : nullptr,
+                       out.as<half_t>(), out_comp ? corr_of(out, (size_t)Ho * Wo, L.cout_pad) : nullptr, Ho, Wo, L.sbyte);
 }
 
 static void convf(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &in, int H, int W, const DevBuf &out,
@@ -735,7 +861,8 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
 static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
 {
     c->cur_stream = c->stream;
-    if (c->precision != SFD2_PREC_F16) return run_network_f32(c, img_dev, normalise);
+    if (c->precision == SFD2_PREC_F32 || c->precision == SFD2_PREC_F16X3) return run_network_f32(c, img_dev, normalise);
+    const bool comp = c->precision == SFD2_PREC_F16C;
     hipStream_t st = c->stream;
     const int H = c->H, W = c->W, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
     const double P1 = (double)H * W, P4 = (double)H4 * W4, P8 = (double)H8 * W8;
@@ -754,6 +881,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         size_t S = std::max(P2 * 64 * 2, P4s * 256 * 2);
         S = std::max(S, (P2 * 128 * 2 + 1) / 2);
         S = std::max(S, 2 * (P8s * 256 * 2 + 256));
+        if (comp) S *= 2;   // hi plane + corr plane per tensor (the corr plane follows the hi plane inside the slot)
         S = (S + 255) & ~(size_t)255;
         HIPCHECK(c->arena.ensure((c->opt_branches ? 4 : 3) * S));
         char *base = c->arena.as<char>();
@@ -773,6 +901,35 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
             if (c->skip_pb_now) da_o = slot(0);
         }
     }
+    const DevBuf *x = &a3b;
+    static const char *nm1[3] = {"conv4.0.conv1", "conv4.1.conv1", "conv4.2.conv1"};
+    static const char *nm2[3] = {"conv4.0.conv2", "conv4.1.conv2", "conv4.2.conv2"};
+    static const char *nm3[3] = {"conv4.0.conv3", "conv4.1.conv3", "conv4.2.conv3"};
+    if (comp) {
+        // SFD2_PREC_F16C backbone: every activation carries a corr plane, every layer adds the fp8 correction terms
+        {
+            ProfScope ps(c, "conv1a", "conv1a_c_kernel", 2.0 * P1 * 64 * 27, P1 * (12 + 256));
+            launch_conv1a_c(st, img_dev, H, W, normalise, c->c1a.wc.as<half_t>(), c->c1a.scale.as<float>(),
+                            c->c1a.shift.as<float>(), c->a1a.as<half_t>(), corr_of(c->a1a, (size_t)H * W, 64));
+        }
+        convc(c, "conv1b", c->c1b, c->a1a, H, W, a1b, H2, W2, 1, true, true);
+        convc(c, "conv2a", c->c2a, a1b, H2, W2, a2a, H2, W2, 1, true, true);
+        convc(c, "conv2b", c->c2b, a2a, H2, W2, a2b, H4, W4, 1, true, true);
+        convc(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1, true, true);
+        convc(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1, true, true);
+        for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
+            DevBuf &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];
+            convc(c, nm1[b], c->rb1[b], *x, H4, W4, t1, H4, W4, 1, true, true);
+            {
+                ProfScope ps(c, nm2[b], "gconv_c_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 8);
+                launch_gconv_c(st, t1.as<half_t>(), corr_of(t1, (size_t)H4 * W4, 256), H4, W4, c->rb2[b].wc.as<half_t>(),
+                               c->rb2[b].scale.as<float>(), c->rb2[b].shift.as<float>(), t2.as<half_t>(),
+                               corr_of(t2, (size_t)H4 * W4, 256));
+            }
+            convc(c, nm3[b], c->rb3[b], t2, H4, W4, ob, H4, W4, 1, true, true, x);
+            x = &ob;
+        }
+    } else {
     if (c->fuse_now) {
         ProfScope ps(c, "conv1a+conv1b", "fused_stem_kernel", 2.0 * P1 * 64 * 27 + 2.0 * (double)H2 * W2 * 64 * 576,
                      P1 * 12 + (double)H2 * W2 * 128);
@@ -791,10 +948,6 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     conv(c, "conv2b", c->c2b, a2a, H2, W2, a2b, H4, W4, 1);
     conv(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1);
     conv(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1);
-    const DevBuf *x = &a3b;
-    static const char *nm1[3] = {"conv4.0.conv1", "conv4.1.conv1", "conv4.2.conv1"};
-    static const char *nm2[3] = {"conv4.0.conv2", "conv4.1.conv2", "conv4.2.conv2"};
-    static const char *nm3[3] = {"conv4.0.conv3", "conv4.1.conv3", "conv4.2.conv3"};
     // fused ResBlock kernel wherever the fused path runs (SFD2_FUSED_RB=0 in experiment builds: three kernels per block)
     const char *frb = sfd2_env("SFD2_FUSED_RB");
     const bool fused_rb = c->fuse_now != 0 && !(frb && frb[0] == '0');
@@ -818,6 +971,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         }
         conv(c, nm3[b], c->rb3[b], t2, H4, W4, ob, H4, W4, 1, x->as<half_t>());
         x = &ob;
+    }
     }
     // The two head branches read the backbone output and nothing of each other (nets/sfd2.py:328-342).  The detector
     // branch works on the 1/8 map (convPa.3: 133 tiles for 256 CUs at 1600x1200), so on its own it leaves part of the
@@ -1483,6 +1637,7 @@ extern "C" int sfd2_debug_activation(sfd2_ctx *c, const char *name, float *out, 
     } else {
         HIPCHECK(c->tmp_f32.ensure(n * sizeof(float)));
         if (a.f32) launch_nhwc_f_to_nchw_f(c->stream, reinterpret_cast<const float *>(a.p), np, a.pitch, a.c, c->tmp_f32.as<float>());
+        else if (a.pc) launch_nhwc_hc_to_nchw_f(c->stream, reinterpret_cast<const half_t *>(a.p), reinterpret_cast<const half_t *>(a.pc), np, a.pitch, a.c, c->tmp_f32.as<float>());
         else launch_nhwc_h_to_nchw_f(c->stream, reinterpret_cast<const half_t *>(a.p), np, a.pitch, a.c, c->tmp_f32.as<float>());
         if (copy_out(c, out, c->tmp_f32.p, n * sizeof(float), 0)) return -1;
     }
@@ -1982,7 +2137,7 @@ extern "C" int sfd2_extract_match(sfd2_ctx *c, const void *img_dev, int H, int W
     }
     HIPCHECK(hipStreamSynchronize(c->stream));
     HIPCHECK(hipEventSynchronize(c->ev_jobs));
-    const unsigned long long gen0 = g_alloc_gen;
+    const unsigned long long gen0 = g_alloc_gen.load();
     std::swap(c->pin_jobs, e->pin); std::swap(c->pin_cap, e->pin_cap);
     std::swap(c->m_jobs, e->jobs); std::swap(c->m_fins, e->fins);
     hipError_t be = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
@@ -2013,9 +2168,11 @@ extern "C" int sfd2_extract_match(sfd2_ctx *c, const void *img_dev, int H, int W
 extern "C" int sfd2_set_precision(sfd2_ctx *c, int mode)
 {
     if (!c) return fail("sfd2_set_precision: null ctx");
-    if (mode != SFD2_PREC_F16 && mode != SFD2_PREC_F32 && mode != SFD2_PREC_F16X3) return fail("sfd2_set_precision: unknown mode");
+    if (mode != SFD2_PREC_F16 && mode != SFD2_PREC_F32 && mode != SFD2_PREC_F16X3 && mode != SFD2_PREC_F16C)
+        return fail("sfd2_set_precision: unknown mode");
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
+    if (mode != c->precision) graphs_release(c);   // a captured unit holds the kernels of the precision it was captured in
     c->precision = mode;
     return 0;
 }
@@ -2026,6 +2183,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
     const std::string k(key);
+    graphs_release(c);   // every option below decides which kernels a captured unit contains
     if (k == "fuse") c->fuse = value ? 1 : 0;
     else if (k == "fuse_det") c->fuse_det = value ? 1 : 0;
     else if (k == "alias") c->opt_alias = value ? 1 : 0;

@@ -39,6 +39,65 @@ __device__ __forceinline__ float4 sfd2_lds_f4(const float *p)
 #endif
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+// ------------------------------------------------------------------ compensated fp16 ("f16c", SFD2_PREC_F16C)
+// A compensated tensor is TWO planes of 2-byte units with the same NHWC geometry: `hi` = fp16(x) and `corr`, whose unit
+// for a channel is the byte pair (fp8 e4m3 of (x - hi) * 2^9, fp8 e4m3 of x * 2^-2).  A compensated filter array is the
+// fp16 filters followed by the same number of units (fp8 of w * 2^b0, fp8 of (w - fp16(w)) * 2^(b0 + 11)), b0 chosen per
+// layer so that max|w| * 2^b0 <= 448.  A compensated layer then computes, for every tap and 32-channel chunk,
+//     acc += hi_x . hi_w                      two v_mfma_f32_32x32x16_f16          (K = 32 channels)
+//     acc += corr_x . corr_w * 2^-(9 + b0)     ONE v_mfma_scale_f32_32x32x64_f8f6f4 (K = 32 channels x 2 terms:
+//                                              lo_x * w  +  x * lo_w, byte-wise pairing of the two units)
+// i.e. the two first-order rounding terms of the fp16 product at fp8 precision: both operands then carry ~15
+// significant bits instead of 11 for 1.65x the matrix time of the plain fp16 layer (a hi / lo fp16 split needs 3x).
+// The scale is uniform over K (E8M0 byte 127 - 9 - b0 on the A operand), so no block layout of the scales matters; and
+// because A and B map lane bytes to K identically, any arrangement of a chunk's 64 bytes is valid as long as filters
+// and pixels use the same one -- the corr records are read with exactly the addresses of the fp16 records.
+#define SFD2_C_XL_SHIFT 9            // corr unit byte 0: fp8((x - hi) * 2^9)
+#define SFD2_C_XH_SCALE 0.25f        // corr unit byte 1: fp8(x * 2^-2)
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+#ifdef __HIPCC__
+__device__ __forceinline__ v8i_t sfd2_cat8(h8_t a, h8_t b)
+{
+    v4i_t x, y;
+    __builtin_memcpy(&x, &a, 16);
+    __builtin_memcpy(&y, &b, 16);
+    return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// fp8 MFMA of one 32-channel corr chunk: a0 / a1 and b0 / b1 are the two 16-byte fragments the fp16 path would feed to
+// its two K = 16 MFMAs; sa = the layer's scale byte replicated into all four bytes
+__device__ __forceinline__ f32x16_t sfd2_mfma_corr(h8_t a0, h8_t a1, h8_t b0, h8_t b1, f32x16_t acc, int sa)
+{
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(sfd2_cat8(a0, a1), sfd2_cat8(b0, b1), acc, 0, 0, 0, sa, 0, 0x7f7f7f7f);
+}
+// corr units of two channels (values v0, v1 with fp16 parts h0, h1) as one dword: bytes (lo8_0, x8_0, lo8_1, x8_1).
+// v_cvt_pk_fp8_f32 returns NaN above 464, hence the clamps (x saturates at 1792, its residual then too).
+__device__ __forceinline__ unsigned sfd2_corr2(float v0, half_t h0, float v1, half_t h1)
+{
+    const float l0 = __builtin_amdgcn_fmed3f((v0 - (float)h0) * (float)(1 << SFD2_C_XL_SHIFT), -448.0f, 448.0f);
+    const float l1 = __builtin_amdgcn_fmed3f((v1 - (float)h1) * (float)(1 << SFD2_C_XL_SHIFT), -448.0f, 448.0f);
+    const float x0 = __builtin_amdgcn_fmed3f(v0 * SFD2_C_XH_SCALE, -448.0f, 448.0f);
+    const float x1 = __builtin_amdgcn_fmed3f(v1 * SFD2_C_XH_SCALE, -448.0f, 448.0f);
+    int d = __builtin_amdgcn_cvt_pk_fp8_f32(l0, x0, 0, false);
+    d = __builtin_amdgcn_cvt_pk_fp8_f32(l1, x1, d, true);
+    return (unsigned)d;
+}
+// hi + corr planes of four consecutive channels: hv (8 bytes of fp16) and cv (8 bytes of corr units)
+__device__ __forceinline__ void sfd2_split4(float v0, float v1, float v2, float v3, uint2 &hv, uint2 &cv)
+{
+    h4_t h;
+    h[0] = (half_t)v0; h[1] = (half_t)v1; h[2] = (half_t)v2; h[3] = (half_t)v3;
+    __builtin_memcpy(&hv, &h, 8);
+    cv.x = sfd2_corr2(v0, h[0], v1, h[1]);
+    cv.y = sfd2_corr2(v2, h[2], v3, h[3]);
+}
+// the residual (x - hi) two corr units of a dword carry, as floats
+__device__ __forceinline__ float sfd2_corr_lo(unsigned d, int ch /*0 or 1*/)
+{
+    return (ch ? __builtin_amdgcn_cvt_f32_fp8((int)d, 2) : __builtin_amdgcn_cvt_f32_fp8((int)d, 0)) * (1.0f / (float)(1 << SFD2_C_XL_SHIFT));
+}
+#endif
+
 // ------------------------------------------------------------------ conv stack
 // Activations live in HBM as NHWC fp16 (channel pitch = padded Cout of the producer).
 
@@ -74,6 +133,18 @@ void launch_gconv3x3_g8(hipStream_t st, const half_t *in, int H, int W, const ha
 // 1x1 conv 256 -> 3 (ConvSta), fp32 planar output [3][H][W]
 void launch_convsta(hipStream_t st, const half_t *in, int npix, const float *w /*[3][256]*/, const float *b,
                     float *out /*[3][npix]*/);
+
+// ---- compensated fp16 (convc_kernels.hip; SFD2_PREC_F16C): hi plane + corr plane per tensor, see the top of this file
+//   wpk: [2 * Cin / 32][ks * ks][Cout_pad][32] units (fp16 chunks, then corr chunks; the first half only when in_c is null)
+//   in_c / res_c / out_c: corr planes (null = that tensor is plain fp16);  sbyte: the layer's E8M0 scale byte
+void launch_convc_igemm(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
+                        const float *scale, const float *shift, int Cout_pad, int ks, int stride, int relu,
+                        const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, int Ho, int Wo, int sbyte);
+void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *wpk /*hi, lo fragments*/,
+                     const float *scale, const float *shift, half_t *out, half_t *out_c);
+void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk /*hi, lo fragments*/,
+                    const float *scale, const float *shift, half_t *out, half_t *out_c);
+void launch_nhwc_hc_to_nchw_f(hipStream_t st, const half_t *in, const half_t *in_c, int npix, int pitch, int c, float *out);
 
 // ---- strict fp32 mode (conv_f32_kernels.hip): fp32 NHWC activations, f32-input MFMA
 //   wpk [Cin/32][ks*ks][Cout_pad][32] fp32
