@@ -125,6 +125,11 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *               0: dense map, then sampling.  Bit-identical descriptors either way.
  *   "branches"  0 (default) / 1: the detector branch (convPa, convPb, soft-max) runs on a second HIP stream beside
  *               the descriptor branch (convDa, convDb) -- they share only the backbone output (-1.7 % per extract).
+ *   "comp_rb"   1 (default) / 0: SFD2_PREC_F16C compensates the three ResBlocks as well (descriptors within ~3e-4 of
+ *               the fp32 reference); 0 runs them on the fused fp16 ResBlock kernel (~7e-4, still inside 1e-3, and faster).
+ *   "generic_c" 0 (default) / 1: SFD2_PREC_F16C layers all run on the generic compensated kernel (the reference
+ *               implementation of that arithmetic) instead of the tuned kernels' compensated instantiations; the two
+ *               differ by fp32 summation order only.
  * Unknown keys are an error. */
 int sfd2_set_option(sfd2_ctx *ctx, const char *key, int value);
 

@@ -35,14 +35,21 @@ __device__ __forceinline__ h4_t cvt4b(float a, float b, float c, float d)
     return r;
 }
 
-template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0, int WBUF = 2, int TPS = 1>
+// COMP (SFD2_PREC_F16C, sfd2_internal.h; CC = 32 only): bit 0 = the input has a corr plane (in_c) and wpk holds
+// 2 * Cin / 32 chunks -- the step loop runs on through the corr plane's chunks, whose units go to one
+// v_mfma_scale_f32_32x32x64_f8f6f4 per (channel tile, pixel tile); bit 1 = the output's corr plane is written (out_c);
+// the residual is hi + corr (res_c) when given.
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0, int WBUF = 2, int TPS = 1, int COMP = 0>
 __global__ __launch_bounds__(NW * 64, (XBUF == 1 && BN == 128 && STRIDE == 1) ? 4 : ((NW == 8 || ROWS != 0) ? 2 : 1))
 void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                         const half_t *__restrict__ wpk, const float *__restrict__ scale,
                         const float *__restrict__ shift, int CoutP, int relu,
                         const half_t *__restrict__ res, void *__restrict__ outv,
-                        int Ho, int Wo, int tiles_x, const half_t *__restrict__ zero_page)
+                        int Ho, int Wo, int tiles_x, const half_t *__restrict__ zero_page,
+                        const half_t *__restrict__ in_c = nullptr, const half_t *__restrict__ res_c = nullptr,
+                        half_t *__restrict__ out_c = nullptr, int sa = 0)
 {
+    static_assert(COMP == 0 || (CC == 32 && TPS == 1 && WBUF == 2 && XBUF != 3 && !OUT_F32 && ABL == 0), "compensated instantiations: 32-wide chunks, plain pipeline");
     constexpr int T = KS * KS;
     constexpr int PAD = KS / 2;
     constexpr int THT = ROWS ? ROWS : ((STRIDE == 1) ? TH2 : 4);   // output rows per tile: 8 (stride 1) or 4 (stride 2: the patch is 2x larger)
@@ -117,11 +124,13 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         woff[i] = ((r / BN) * CoutP + n0 + (r % BN)) * CC + slot * 8;
     }
 
+    const int NCHP = Cin / CC;                         // chunks per plane
 #define ISSUE_X(chunk_, buf_)                                                                          \
     _Pragma("unroll") for (int i = 0; i < XPW; ++i) {                                                  \
         if (ABL != 3 && !(ABL == 7 && (chunk_) != 0) && (WBUF == 3 || wave + NW * i < XCH)) {           \
             const int xc = (WBUF == 3 && wave + NW * i >= XCH) ? XCH - 1 : wave + NW * i;              \
-            const half_t *src = xoff[i] >= 0 ? in + (size_t)xoff[i] + (chunk_)*CC : zero_page + (lane % SPR) * 8; \
+            const half_t *pl_ = ((COMP & 1) && (chunk_) >= NCHP) ? in_c - (size_t)NCHP * CC : in;       \
+            const half_t *src = xoff[i] >= 0 ? pl_ + (size_t)xoff[i] + (chunk_)*CC : zero_page + (lane % SPR) * 8; \
             __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                        \
                                              (lds_void_t *)(Xs + (buf_)*XBYTES + xc * 1024), 16, 0, 0); \
         }                                                                                              \
@@ -141,7 +150,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    const int NS = (Cin / CC) * (T / TPS);             // pipeline stages
+    const int NS = ((COMP & 1) ? 2 : 1) * (Cin / CC) * (T / TPS);   // pipeline stages (COMP: the hi plane's chunks, then the corr plane's)
     // barrier that lets the XPW most recently issued copies (the chunk two steps ahead) stay in flight
 #define BARRIER_KEEP_X() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XPW) : "memory")
 #define BARRIER_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -178,7 +187,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         const bool new_chunk = has_next && (ntap == 0);
         bool x_now = false, w_now = false;
         if (WBUF == 3) {
-            x_now = (tap == 0) && (chunk + 1 < Cin / CC);
+            x_now = (tap == 0) && (chunk + 1 < ((COMP & 1) ? 2 : 1) * (Cin / CC));
             w_now = s + 2 < NS;
             if (x_now) { ISSUE_X(chunk + 1, xb ^ 1) }        // nine steps ahead; older than every later filter copy
             if (w_now) { ISSUE_W(s + 2, (s + 2) % 3) }      // into the ring slot step s - 1 read
@@ -204,6 +213,28 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             // software-pipelined fragment reads: the ds_reads of k-slice kk+1 are in flight while the
             // MFMAs of slice kk issue (two register sets, static indices)
             constexpr int NK = (ABL == 1) ? 0 : CC / 16;
+            if ((COMP & 1) && chunk >= NCHP) {   // block-uniform: a corr chunk = both K slices of every fragment, one fp8 MFMA each
+                v8i_t a8[CH_T], b8[PX_T];
+#pragma unroll
+                for (int ct = 0; ct < CH_T; ++ct)
+                    a8[ct] = sfd2_cat8(*reinterpret_cast<const h8_t *>(ws + a_off[ct] + ((lhi ^ a_sw[ct]) << 4)),
+                                       *reinterpret_cast<const h8_t *>(ws + a_off[ct] + (((2 + lhi) ^ a_sw[ct]) << 4)));
+#pragma unroll
+                for (int pr = 0; pr < PX_T; ++pr)
+                    b8[pr] = sfd2_cat8(*reinterpret_cast<const h8_t *>(xs + b_off[pr] + ((lhi ^ b_sw[pr]) << 4)),
+                                       *reinterpret_cast<const h8_t *>(xs + b_off[pr] + (((2 + lhi) ^ b_sw[pr]) << 4)));
+#pragma unroll
+                for (int ct = 0; ct < CH_T; ++ct)
+#pragma unroll
+                    for (int pr = 0; pr < PX_T; ++pr)
+                        acc[ct][pr] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[ct], b8[pr], acc[ct][pr], 0, 0, 0, sa, 0, 0x7f7f7f7f);
+                // (the scaled MFMA is a pure node to instruction selection: without a use it may sink below the step's barrier)
+#pragma unroll
+                for (int ct = 0; ct < CH_T; ++ct)
+#pragma unroll
+                    for (int pr = 0; pr < PX_T; ++pr) asm volatile("" : "+v"(acc[ct][pr]));
+                continue;
+            }
             h8_t fa[2][CH_T], fb[2][PX_T];
 #pragma unroll
             for (int ct = 0; ct < CH_T; ++ct)
@@ -308,7 +339,16 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                         rq[0] = make_uint2(s0[0], s1[0]);
                         rq[1] = make_uint2(s0[1], s1[1]);
                     }
-                    uint2 pk[2];
+                    uint2 rcq[2] = {make_uint2(0, 0), make_uint2(0, 0)};
+                    if (HAS_RES && COMP) {   // the residual's corr units, regrouped like its hi plane
+                        uint4 c16 = make_uint4(0, 0, 0, 0);
+                        if (inb && res_c) c16 = *reinterpret_cast<const uint4 *>(res_c + o16);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(c16.x, c16.z, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(c16.y, c16.w, false, false);
+                        rcq[0] = make_uint2(s0[0], s1[0]);
+                        rcq[1] = make_uint2(s0[1], s1[1]);
+                    }
+                    uint2 pk[2], ck[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int q = 2 * m + j;
@@ -322,27 +362,41 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                             h4_t r;
                             __builtin_memcpy(&r, &rq[j], 8);
                             v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+                            if (COMP) {
+                                v0 += sfd2_corr_lo(rcq[j].x, 0); v1 += sfd2_corr_lo(rcq[j].x, 1);
+                                v2 += sfd2_corr_lo(rcq[j].y, 0); v3 += sfd2_corr_lo(rcq[j].y, 1);
+                            }
                         }
                         if (relu) {
                             v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
                         }
-                        const h4_t hv = cvt4b(v0, v1, v2, v3);
-                        __builtin_memcpy(&pk[j], &hv, 8);
+                        if (COMP & 2) {
+                            sfd2_split4(v0, v1, v2, v3, pk[j], ck[j]);
+                        } else {
+                            const h4_t hv = cvt4b(v0, v1, v2, v3);
+                            __builtin_memcpy(&pk[j], &hv, 8);
+                        }
                     }
                     const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                     const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
                     if (inb && (ABL != 2 || t0[0] == 0x12345678u))
                         *reinterpret_cast<uint4 *>(reinterpret_cast<half_t *>(outv) + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                    if (COMP & 2) {
+                        const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
+                        const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
+                        if (inb) *reinterpret_cast<uint4 *>(out_c + o16) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
+                    }
                 }
             }
         }
     }
 }
 
-template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0, int WBUF = 2, int TPS = 1>
+template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0, int WBUF = 2, int TPS = 1, int COMP = 0>
 static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                             const float *scale, const float *shift, int CoutP, int relu, const half_t *res,
-                            void *out, int Ho, int Wo, const half_t *zero_page)
+                            void *out, int Ho, int Wo, const half_t *zero_page, const half_t *in_c = nullptr,
+                            const half_t *res_c = nullptr, half_t *out_c = nullptr, int sa = 0)
 {
     constexpr int THT = ROWS ? ROWS : ((STRIDE == 1) ? TH2 : 4);
     constexpr int PH = (THT - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
@@ -351,7 +405,7 @@ static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int 
     constexpr bool SS_LDS = !(XBUF == 3 && BN == 256 && CC == 64);
     constexpr size_t lds = (size_t)XBUF * XCH * 1024 + (size_t)WBUF * TPS * BN * CC * 2 + (SS_LDS ? (size_t)2 * BN * sizeof(float) : 0);
     static bool attr_done = false;
-    auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES, NW, ROWS, XBUF, ABL, WBUF, TPS>;
+    auto kern = conv_igemm2_kernel<KS, STRIDE, BN, CC, OUT_F32, HAS_RES, NW, ROWS, XBUF, ABL, WBUF, TPS, COMP>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
@@ -359,7 +413,29 @@ static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int 
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + THT - 1) / THT;
     const int grid = tiles_x * tiles_y * (CoutP / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, res, out,
-                       Ho, Wo, tiles_x, zero_page);
+                       Ho, Wo, tiles_x, zero_page, in_c, res_c, out_c, sa);
+}
+
+// compensated instantiations (SFD2_PREC_F16C; in and out compensated): 1x1 256 -> 256 (+ residual) of the ResBlocks and the
+// stride-2 3x3 layers with 128 / 256 output channels.  wpk = the layer's wc array (32-wide chunks).  false = no instantiation.
+bool launch_conv_igemm2_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
+                          const float *scale, const float *shift, int CoutP, int ks, int stride, int relu,
+                          const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, int Ho, int Wo,
+                          const half_t *zero_page, int sbyte)
+{
+    const int sa = (sbyte & 255) * 0x01010101;
+    if (!in_c || !out_c) return false;
+    if (ks == 1 && stride == 1 && CoutP % 128 == 0) {   // 128-channel tiles: the 256-channel tile's compensated epilogue spills
+        if (res) launch_igemm2_t<1, 1, 128, 32, false, true, 8, 0, 2, 0, 2, 1, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, res, out, Ho, Wo, zero_page, in_c, res_c, out_c, sa);
+        else launch_igemm2_t<1, 1, 128, 32, false, false, 8, 0, 2, 0, 2, 1, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page, in_c, nullptr, out_c, sa);
+        return true;
+    }
+    if (ks == 3 && stride == 2 && !res && CoutP % 128 == 0) {
+        if (CoutP % 256 == 0) launch_igemm2_t<3, 2, 256, 32, false, false, 8, 0, 1, 0, 2, 1, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page, in_c, nullptr, out_c, sa);
+        else launch_igemm2_t<3, 2, 128, 32, false, false, 8, 0, 1, 0, 2, 1, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page, in_c, nullptr, out_c, sa);
+        return true;
+    }
+    return false;
 }
 
 bool conv3x3_pp_serves(int ks, int stride, int CoutP, int Cin);

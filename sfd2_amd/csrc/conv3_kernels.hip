@@ -68,13 +68,18 @@ __device__ __forceinline__ h4_t cvt4c(float a, float b, float c, float d)
 // KXM = 1: the nine taps of a chunk run column by column (stage = one filter COLUMN kx, units ky = 0, 1, 2), so that the
 // pixel fragments of patch row r serve output rows r, r - 1, r - 2 of the same stage from registers: a stage reads six
 // patch rows once (4 + 1 + 1 over its three units) instead of four rows per unit -- 8 fragment reads per unit instead of 12.
-template <int STAGGER, int PRIO, int ABL = 0, int KXM = SFD2_PP_KXM>
+// COMP (SFD2_PREC_F16C, sfd2_internal.h): bit 0 = the input has a corr plane (in_c) and wpk holds 2 * Cin / 32 chunks --
+// the chunk loop simply runs on through the corr plane's chunks, whose units go to ONE v_mfma_scale_f32_32x32x64_f8f6f4 per
+// (channel tile, pixel tile) instead of two fp16 MFMAs (same LDS records, same fragment reads); bit 1 = the corr plane of
+// the output is written (out_c).
+template <int STAGGER, int PRIO, int ABL = 0, int KXM = SFD2_PP_KXM, int COMP = 0>
 __global__ __launch_bounds__(512, 2)
 void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                        const half_t *__restrict__ wpk, const float *__restrict__ scale,
                        const float *__restrict__ shift, int CoutP, int relu,
                        half_t *__restrict__ out, int Ho, int Wo, int tiles_x, int n_tiles,
-                       const half_t *__restrict__ zero_page)
+                       const half_t *__restrict__ zero_page,
+                       const half_t *__restrict__ in_c = nullptr, half_t *__restrict__ out_c = nullptr, int sa = 0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Xs = smem;                              // [2][PP_XBYTES]
@@ -122,11 +127,13 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     }
     int tile = blockIdx.x;
     PP_SETUP(tile)
+    const int NCH = Cin / PP_CC;                           // chunks per plane
 
 #define PP_ISSUE_X1(chunk_, buf_, i_)                                                                  \
     do {                                                                                               \
         const int pc_ = (wave + 8 * (i_) < PP_XCH) ? wave + 8 * (i_) : PP_XCH - 1;                     \
-        const half_t *src_ = xoff[i_] >= 0 ? in + (size_t)xoff[i_] + (chunk_)*PP_CC : zero_page + (lane & 3) * 8; \
+        const half_t *pl_ = ((COMP & 1) && (chunk_) >= NCH) ? in_c - (size_t)NCH * PP_CC : in;         \
+        const half_t *src_ = xoff[i_] >= 0 ? pl_ + (size_t)xoff[i_] + (chunk_)*PP_CC : zero_page + (lane & 3) * 8; \
         __builtin_amdgcn_global_load_lds((gbl_void3_t *)src_,                                          \
                                          (lds_void3_t *)(Xs + (buf_)*PP_XBYTES + pc_ * 1024), 16, 0, 0); \
     } while (0)
@@ -137,8 +144,8 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                                          (lds_void3_t *)(Fs + (buf_)*PP_FBYTES + (wave * PP_FPW + i_) * 1024), 16, 0, 0); \
     }
 
-    const int NCH = Cin / PP_CC;
-    const int NST = NCH * 3;
+    const int NCT = ((COMP & 1) ? 2 : 1) * NCH;            // chunks of the K loop: the hi plane's, then the corr plane's
+    const int NST = NCT * 3;
 
 #pragma unroll
     for (int i = 0; i < PP_XPW; ++i) PP_ISSUE_X1(0, 0, i);
@@ -167,84 +174,121 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     SFD2_BARRIER_DRAIN();
     if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
 
-    for (int c = 0; c < NCH; ++c) {
-        const unsigned char *xs = Xs + (c & 1) * PP_XBYTES;
-        const bool more_x = c + 1 < NCH;
-        h8_t fr[2][6];                                     // KXM: the stage's six patch rows
-#pragma unroll
-        for (int t9 = 0; t9 < 9; ++t9) {
-            // u3 = unit within the stage (the stage's last unit carries the waits), sg = stage within the chunk
-            const int sg = t9 / 3, u3 = t9 % 3;
-            const int ky = KXM ? u3 : sg, kx = KXM ? sg : u3;
-            const int st = c * 3 + sg;
-            const unsigned char *fs = Fs + (st & 1) * PP_FBYTES + u3 * (PP_BN * 64);
-            // ---------------- LOAD section
-            h8_t fa[2][2], fb[2][4];
-            if (ABL & 2) {   // timing ablation: no fragment reads
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) fb[kk][pr] = h8_t{(half_t)(float)lane, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) fa[kk][ct] = h8_t{(half_t)(float)c, 0, 0, 0, 0, 0, 0, 0};
-                }
-            }
-            int qv = qb;
-            asm volatile("" : "+v"(qv));   // recompute the 8 patch addresses per unit (hoisted out of the loop they are 72 registers)
-            if (KXM && !(ABL & 2)) {
-#pragma unroll
-                for (int j = (u3 == 0 ? 0 : 3 + u3); j < 4 + u3; ++j) {   // rows 0..3, then 4, then 5
-                    const int q = qv + j * PP_PW + kx;
-                    const int sw = (q >> 2) & 3;
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-                        fr[kk][j] = *reinterpret_cast<const h8_t *>(xs + q * 64 + (((kk * 2 + lhi) ^ sw) << 4));
-                }
-            }
-#pragma unroll
-            for (int pr = 0; pr < ((ABL & 2) || KXM ? 0 : 4); ++pr) {
-                const int q = qv + (pr + ky) * PP_PW + kx;
-                const int sw = (q >> 2) & 3;
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-                    fb[kk][pr] = *reinterpret_cast<const h8_t *>(xs + q * 64 + (((kk * 2 + lhi) ^ sw) << 4));
-            }
-#pragma unroll
-            for (int ct = 0; ct < ((ABL & 2) ? 0 : 2); ++ct)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-                    fa[kk][ct] = *reinterpret_cast<const h8_t *>(fs + a_off[ct] + (((kk * 2 + lhi) ^ a_sw[ct]) << 4));
-            if (!(ABL & 1) && u3 == 0 && st + 1 < NST) { PP_ISSUE_F(st + 1, (st + 1) & 1) }
-            if (!(ABL & 1) && more_x) {
-                if (t9 == 0) PP_ISSUE_X1(c + 1, (c + 1) & 1, 0);
-                if (t9 == 1) PP_ISSUE_X1(c + 1, (c + 1) & 1, 1);
-                if (t9 == 3) PP_ISSUE_X1(c + 1, (c + 1) & 1, 2);
-                if (t9 == 4) PP_ISSUE_X1(c + 1, (c + 1) & 1, 3);
-                if (t9 == 6) PP_ISSUE_X1(c + 1, (c + 1) & 1, 4);
-            }
-            if (u3 == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_barrier" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------------- MFMA section
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr)
-                        acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][ct], KXM && !(ABL & 2) ? fr[kk][pr + u3] : fb[kk][pr],
-                                                                             acc[ct][pr], 0, 0, 0);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (u3 == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // group 1's last MFMA section has nobody left to hand the pipe to
-            if (!(STAGGER && grp == 1 && t9 == 8 && c + 1 == NCH)) asm volatile("s_barrier" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+#define PP_CHUNK_BODY(F8_)  /* one 32-channel chunk of the K loop; F8_: a corr-plane chunk (fp8 MFMA) */ \
+        const unsigned char *xs = Xs + (c & 1) * PP_XBYTES; \
+        const bool more_x = c + 1 < NCT; \
+        constexpr bool f8 = (F8_) != 0; /* block-uniform */ \
+        h8_t fr[2][6]; /* KXM: the stage's six patch rows */ \
+_Pragma("unroll") \
+        for (int t9 = 0; t9 < 9; ++t9) { \
+/* u3 = unit within the stage (the stage's last unit carries the waits), sg = stage within the chunk */ \
+            const int sg = t9 / 3, u3 = t9 % 3; \
+            const int ky = KXM ? u3 : sg, kx = KXM ? sg : u3; \
+            const int st = c * 3 + sg; \
+            const unsigned char *fs = Fs + (st & 1) * PP_FBYTES + u3 * (PP_BN * 64); \
+/* ---------------- LOAD section */ \
+            h8_t fa[2][2], fb[2][4]; \
+            v8i_t frc[4]; \
+            if (ABL & 2) { /* timing ablation: no fragment reads */ \
+_Pragma("unroll") \
+                for (int kk = 0; kk < 2; ++kk) { \
+_Pragma("unroll") \
+                    for (int pr = 0; pr < 4; ++pr) fb[kk][pr] = h8_t{(half_t)(float)lane, 0, 0, 0, 0, 0, 0, 0}; \
+_Pragma("unroll") \
+                    for (int ct = 0; ct < 2; ++ct) fa[kk][ct] = h8_t{(half_t)(float)c, 0, 0, 0, 0, 0, 0, 0}; \
+                } \
+            } \
+            int qv = qb; \
+            asm volatile("" : "+v"(qv)); /* recompute the 8 patch addresses per unit (hoisted out of the loop they are 72 registers) */ \
+            if (f8) { /* corr chunk: four 8-dword pixel fragments per unit (K slices 0 and 1 adjacent), not carried across units */ \
+_Pragma("unroll") \
+                for (int pr = 0; pr < 4; ++pr) { \
+                    const int q = qv + (pr + ky) * PP_PW + kx; \
+                    const int sw = (q >> 2) & 3; \
+                    frc[pr] = sfd2_cat8(*reinterpret_cast<const h8_t *>(xs + q * 64 + (((0 * 2 + lhi) ^ sw) << 4)), \
+                                        *reinterpret_cast<const h8_t *>(xs + q * 64 + (((1 * 2 + lhi) ^ sw) << 4))); \
+                } \
+            } else if (KXM && !(ABL & 2)) { \
+_Pragma("unroll") \
+                for (int j = (u3 == 0 ? 0 : 3 + u3); j < 4 + u3; ++j) { /* rows 0..3, then 4, then 5 */ \
+                    const int q = qv + j * PP_PW + kx; \
+                    const int sw = (q >> 2) & 3; \
+_Pragma("unroll") \
+                    for (int kk = 0; kk < 2; ++kk) \
+                        fr[kk][j] = *reinterpret_cast<const h8_t *>(xs + q * 64 + (((kk * 2 + lhi) ^ sw) << 4)); \
+                } \
+            } \
+_Pragma("unroll") \
+            for (int pr = 0; pr < ((ABL & 2) || KXM ? 0 : 4); ++pr) { \
+                const int q = qv + (pr + ky) * PP_PW + kx; \
+                const int sw = (q >> 2) & 3; \
+_Pragma("unroll") \
+                for (int kk = 0; kk < 2; ++kk) \
+                    fb[kk][pr] = *reinterpret_cast<const h8_t *>(xs + q * 64 + (((kk * 2 + lhi) ^ sw) << 4)); \
+            } \
+            v8i_t fac[2]; \
+            if (f8) { \
+_Pragma("unroll") \
+                for (int ct = 0; ct < 2; ++ct) \
+                    fac[ct] = sfd2_cat8(*reinterpret_cast<const h8_t *>(fs + a_off[ct] + (((0 * 2 + lhi) ^ a_sw[ct]) << 4)), \
+                                        *reinterpret_cast<const h8_t *>(fs + a_off[ct] + (((1 * 2 + lhi) ^ a_sw[ct]) << 4))); \
+            } else { \
+_Pragma("unroll") \
+            for (int ct = 0; ct < ((ABL & 2) ? 0 : 2); ++ct) \
+_Pragma("unroll") \
+                for (int kk = 0; kk < 2; ++kk) \
+                    fa[kk][ct] = *reinterpret_cast<const h8_t *>(fs + a_off[ct] + (((kk * 2 + lhi) ^ a_sw[ct]) << 4)); \
+            } \
+            if (!(ABL & 1) && u3 == 0 && st + 1 < NST) { PP_ISSUE_F(st + 1, (st + 1) & 1) } \
+            if (!(ABL & 1) && more_x) { \
+                if (t9 == 0) PP_ISSUE_X1(c + 1, (c + 1) & 1, 0); \
+                if (t9 == 1) PP_ISSUE_X1(c + 1, (c + 1) & 1, 1); \
+                if (t9 == 3) PP_ISSUE_X1(c + 1, (c + 1) & 1, 2); \
+                if (t9 == 4) PP_ISSUE_X1(c + 1, (c + 1) & 1, 3); \
+                if (t9 == 6) PP_ISSUE_X1(c + 1, (c + 1) & 1, 4); \
+            } \
+            if (u3 == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+            __builtin_amdgcn_sched_barrier(0); \
+            asm volatile("s_barrier" ::: "memory"); \
+            __builtin_amdgcn_sched_barrier(0); \
+/* ---------------- MFMA section */ \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+            if (PRIO) __builtin_amdgcn_s_setprio(1); \
+            if (f8) { \
+                static_assert(!(COMP & 1) || KXM, "the compensated instantiations use the column-major tap order"); \
+_Pragma("unroll") \
+                for (int ct = 0; ct < 2; ++ct) \
+_Pragma("unroll") \
+                    for (int pr = 0; pr < 4; ++pr) \
+                        acc[ct][pr] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fac[ct], frc[pr], acc[ct][pr], 0, 0, 0, sa, 0, 0x7f7f7f7f); \
+                /* the scaled MFMA is a pure node to instruction selection, which otherwise sinks all 72 of a chunk below its last \
+                   barrier (every fragment of nine units live at once); an empty asm on the accumulators keeps each unit's in its section */ \
+_Pragma("unroll") \
+                for (int ct = 0; ct < 2; ++ct) \
+_Pragma("unroll") \
+                    for (int pr = 0; pr < 4; ++pr) asm volatile("" : "+v"(acc[ct][pr])); \
+            } else { \
+_Pragma("unroll") \
+            for (int kk = 0; kk < 2; ++kk) \
+_Pragma("unroll") \
+                for (int ct = 0; ct < 2; ++ct) \
+_Pragma("unroll") \
+                    for (int pr = 0; pr < 4; ++pr) \
+                        acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][ct], KXM && !(ABL & 2) ? fr[kk][pr + u3] : fb[kk][pr], \
+                                                                             acc[ct][pr], 0, 0, 0); \
+            } \
+            if (PRIO) __builtin_amdgcn_s_setprio(0); \
+            __builtin_amdgcn_sched_barrier(0); \
+            if (u3 == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+/* group 1's last MFMA section has nobody left to hand the pipe to */ \
+            if (!(STAGGER && grp == 1 && t9 == 8 && c + 1 == NCT)) asm volatile("s_barrier" ::: "memory"); \
+            __builtin_amdgcn_sched_barrier(0); \
+        } \
+    /* end of PP_CHUNK_BODY */
+    for (int c = 0; c < NCH; ++c) { PP_CHUNK_BODY(0) }
+    if (COMP & 1)
+        for (int c = NCH; c < NCT; ++c) { PP_CHUNK_BODY(1) }
+#undef PP_CHUNK_BODY
     // the next tile's first copies go out before this tile's epilogue (buffers 0: last read a chunk / a stage ago)
     const int eoy0 = oy0, eox0 = ox0, en0 = n0;
     const int next = tile + (int)gridDim.x;
@@ -273,7 +317,7 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const size_t o16 = pix * CoutP + en0 + wch + ct * 32 + 8 * (2 * m + lhi);
-                uint2 pk[2];
+                uint2 pk[2], ck[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int q = 2 * m + j;
@@ -284,12 +328,21 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                     float v2 = acc[ct][pr][4 * q + 2] * sc.z + sh.z;
                     float v3 = acc[ct][pr][4 * q + 3] * sc.w + sh.w;
                     v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
-                    const h4_t hv = cvt4c(v0, v1, v2, v3);
-                    __builtin_memcpy(&pk[j], &hv, 8);
+                    if (COMP & 2) {
+                        sfd2_split4(v0, v1, v2, v3, pk[j], ck[j]);
+                    } else {
+                        const h4_t hv = cvt4c(v0, v1, v2, v3);
+                        __builtin_memcpy(&pk[j], &hv, 8);
+                    }
                 }
                 const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                 const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
                 if (inb && (!(ABL & 4) || t0[0] == 0x12345678u)) *reinterpret_cast<uint4 *>(out + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                if (COMP & 2) {
+                    const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
+                    const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
+                    if (inb) *reinterpret_cast<uint4 *>(out_c + o16) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
+                }
             }
         }
     }
@@ -301,14 +354,14 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #undef PP_SETUP
 }
 
-template <int STAGGER, int PRIO, int ABL = 0>
+template <int STAGGER, int PRIO, int ABL = 0, int COMP = 0>
 static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                         const float *scale, const float *shift, int CoutP, int relu, half_t *out,
-                        int Ho, int Wo, const half_t *zero_page)
+                        int Ho, int Wo, const half_t *zero_page, const half_t *in_c = nullptr, half_t *out_c = nullptr, int sa = 0)
 {
     constexpr size_t lds = (size_t)2 * PP_XBYTES + (size_t)2 * PP_FBYTES + 4 * PP_BN * sizeof(float);
     static bool attr_done = false;
-    auto kern = conv3x3_pp_kernel<STAGGER, PRIO, ABL>;
+    auto kern = conv3x3_pp_kernel<STAGGER, PRIO, ABL, SFD2_PP_KXM, COMP>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
@@ -323,7 +376,18 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
     const int n_tiles = tiles_x * tiles_y * (CoutP / PP_BN);
     const int grid = n_tiles < slots ? n_tiles : slots;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out,
-                       Ho, Wo, tiles_x, n_tiles, zero_page);
+                       Ho, Wo, tiles_x, n_tiles, zero_page, in_c, out_c, sa);
+}
+
+// compensated instantiations (SFD2_PREC_F16C): wpk = the layer's wc array, sbyte its scale byte
+void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
+                         const float *scale, const float *shift, int CoutP, int relu, half_t *out, half_t *out_c,
+                         int Ho, int Wo, const half_t *zero_page, int sbyte)
+{
+    const int sa = (sbyte & 255) * 0x01010101;
+    if (in_c && out_c) launch_pp_t<1, 1, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
+    else if (in_c) launch_pp_t<1, 1, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
+    else launch_pp_t<1, 1, 0, 2>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
 }
 
 // does conv3x3_pp serve this layer?  (decided from the layer's shape alone: the filters are packed for it)

@@ -399,7 +399,7 @@ void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normali
 #define GCP 72
 #define GC_PH 6
 #define GC_PW 34
-__global__ __launch_bounds__(CNT)
+__global__ __launch_bounds__(CNT, 2)   // two blocks (59 KB of LDS each) per CU
 void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in_c, int H, int W,
                     const half_t *__restrict__ wpk /*[2 hi/lo][16][5][64][8]*/, const float *__restrict__ scale,
                     const float *__restrict__ shift, half_t *__restrict__ out, half_t *__restrict__ out_c, int tiles_x)

@@ -93,6 +93,8 @@ struct sfd2_ctx {
     int opt_fuse_pb = 1;               // sfd2_set_option "fuse_pb": convPb inside the fused detector-head / heat-map kernel
     const half_t *pa_cur = nullptr;    // convPa.3 output of the last fp16 network pass
     const half_t *da_cur = nullptr;    // convDa.3 output of the last fp16 network pass
+    int opt_comp_rb = 1;               // sfd2_set_option "comp_rb": SFD2_PREC_F16C compensates the ResBlocks too (0: fused fp16 ResBlock kernel)
+    int opt_generic_c = 0;             // sfd2_set_option "generic_c": SFD2_PREC_F16C layers on the generic reference kernel (tests)
     int opt_branches = 0;              // sfd2_set_option "branches": detector branch on a second stream beside the descriptor branch
     hipStream_t side_stream = nullptr; // the detector branch (convPa.0 -> convPa.3 -> convPb -> detector_head)
     hipStream_t cur_stream = nullptr;  // stream the conv()/ProfScope helpers launch on (main or side)
@@ -635,7 +637,7 @@ static int ensure_workspace(sfd2_ctx *c, int H, int W)
     // SFD2_PREC_F16C: every backbone activation is a hi plane followed by its corr plane (same geometry)
     const size_t bb = comp ? 2 * hb : hb;
     const bool fused_stem = c->fuse_now && !comp;   // (no compensated fused stem yet: conv1a's planes go through memory)
-    const bool fused_rb = c->fuse_now && !comp;
+    const bool fused_rb = c->fuse_now && (!comp || !c->opt_comp_rb);
     if (!f32 && !fused_stem) HIPCHECK(c->a1a.ensure(P1 * 64 * bb));
     if (layers) {
         HIPCHECK(c->a1b.ensure(P2 * 64 * bb));
@@ -773,6 +775,24 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &i
     const double flops = 2.0 * px * L.cout * L.cin * L.ks * L.ks;
     const double bytes = (in_comp ? 4.0 : 2.0) * ((double)H * W * L.cin + (double)L.cout * L.cin * L.ks * L.ks) +
                          px * L.cout_pad * (out_comp ? 4.0 : 2.0) + (res ? px * L.cout_pad * 4.0 : 0.0);
+    const half_t *in_c = in_comp ? corr_of(in, (size_t)H * W, L.cin) : nullptr;
+    half_t *out_c = out_comp ? corr_of(out, (size_t)Ho * Wo, L.cout_pad) : nullptr;
+    // conv3x3_pp's tile is 128 channels wide: in its compensated form it also takes conv2a (64 -> 128 channels, four chunks)
+    if (!res && !c->opt_generic_c && L.ks == 3 && L.stride == 1 && L.cout_pad % 128 == 0 && L.cin % 64 == 0) {
+        ProfScope ps(c, name, "conv3x3_pp<comp>", flops, bytes);
+        launch_conv3x3_pp_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, L.wc.as<half_t>(), L.scale.as<float>(),
+                            L.shift.as<float>(), L.cout_pad, relu, out.as<half_t>(), out_c, Ho, Wo, c->zero_page.as<half_t>(), L.sbyte);
+        return;
+    }
+    if (!c->opt_generic_c && in_c && out_c && L.cout_pad % 128 == 0 && ((L.ks == 1 && L.stride == 1) || (L.ks == 3 && L.stride == 2 && !res))) {
+        snprintf(kn, sizeof(kn), "conv_igemm2<%d,%d,comp>%s", L.ks, L.stride, res ? "+res" : "");
+        ProfScope ps(c, name, kn, flops, bytes);
+        if (launch_conv_igemm2_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, L.wc.as<half_t>(), L.scale.as<float>(),
+                                 L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu, res ? res->as<half_t>() : nullptr,
+                                 res ? corr_of(*res, (size_t)Ho * Wo, L.cout_pad) : nullptr, out.as<half_t>(), out_c, Ho, Wo,
+                                 c->zero_page.as<half_t>(), L.sbyte))
+            return;
+    }
     ProfScope ps(c, name, kn, flops, bytes);
     launch_convc_igemm(c->cur_stream, in.as<half_t>(), in_comp ? corr_of(in, (size_t)H * W, L.cin) : nullptr, H, W, L.cin,
                        L.wc.as<half_t>(), L.scale.as<float>(), L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu,
@@ -905,6 +925,31 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     static const char *nm1[3] = {"conv4.0.conv1", "conv4.1.conv1", "conv4.2.conv1"};
     static const char *nm2[3] = {"conv4.0.conv2", "conv4.1.conv2", "conv4.2.conv2"};
     static const char *nm3[3] = {"conv4.0.conv3", "conv4.1.conv3", "conv4.2.conv3"};
+    // one ResBlock (nets/sfd2.py:25-55) in plain fp16: the fused kernel wherever the fused path runs (SFD2_FUSED_RB=0 in
+    // experiment builds: three kernels per block)
+    const char *frb = sfd2_env("SFD2_FUSED_RB");
+    const bool fused_rb = c->fuse_now != 0 && !(frb && frb[0] == '0');
+    static const char *nmf[3] = {"conv4.0", "conv4.1", "conv4.2"};
+    auto rb_f16 = [&](int b) {
+        DevBuf &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];
+        if (fused_rb && c->rb1[b].wrm.p && c->rb3[b].wrm.p) {
+            ProfScope ps(c, nmf[b], "resblock_kernel", 2.0 * P4 * 256 * (256 + 72 + 256), P4 * 256 * 4);
+            launch_resblock(st, x->as<half_t>(), H4, W4, c->rb1[b].wrm.as<half_t>(), c->rb1[b].scale.as<float>(),
+                            c->rb1[b].shift.as<float>(), c->rb2[b].wgc.as<half_t>(), c->rb2[b].scale.as<float>(),
+                            c->rb2[b].shift.as<float>(), c->rb3[b].wrm.as<half_t>(), c->rb3[b].scale.as<float>(),
+                            c->rb3[b].shift.as<float>(), alias ? t1.as<half_t>() : ob.as<half_t>(), c->zero_page.as<half_t>());
+            x = alias ? &t1 : &ob;   // the fused kernel must not write over its own input: with the arena the output takes t1's slot
+            return;
+        }
+        conv(c, nm1[b], c->rb1[b], *x, H4, W4, t1, H4, W4, 1);
+        {
+            ProfScope ps(c, nm2[b], "gconv3x3_g8_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 4);
+            launch_gconv3x3_g8(st, t1.as<half_t>(), H4, W4, c->rb2[b].w.as<half_t>(),
+                               c->rb2[b].scale.as<float>(), c->rb2[b].shift.as<float>(), t2.as<half_t>());
+        }
+        conv(c, nm3[b], c->rb3[b], t2, H4, W4, ob, H4, W4, 1, x->as<half_t>());
+        x = &ob;
+    };
     if (comp) {
         // SFD2_PREC_F16C backbone: every activation carries a corr plane, every layer adds the fp8 correction terms
         {
@@ -918,6 +963,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         convc(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1, true, true);
         convc(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1, true, true);
         for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
+            if (!c->opt_comp_rb) { rb_f16(b); continue; }   // option "comp_rb" = 0: this block in plain fp16 on the hi planes
             DevBuf &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];
             convc(c, nm1[b], c->rb1[b], *x, H4, W4, t1, H4, W4, 1, true, true);
             {
@@ -948,30 +994,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     conv(c, "conv2b", c->c2b, a2a, H2, W2, a2b, H4, W4, 1);
     conv(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1);
     conv(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1);
-    // fused ResBlock kernel wherever the fused path runs (SFD2_FUSED_RB=0 in experiment builds: three kernels per block)
-    const char *frb = sfd2_env("SFD2_FUSED_RB");
-    const bool fused_rb = c->fuse_now != 0 && !(frb && frb[0] == '0');
-    static const char *nmf[3] = {"conv4.0", "conv4.1", "conv4.2"};
-    for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
-        DevBuf &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];
-        if (fused_rb && c->rb1[b].wrm.p && c->rb3[b].wrm.p) {
-            ProfScope ps(c, nmf[b], "resblock_kernel", 2.0 * P4 * 256 * (256 + 72 + 256), P4 * 256 * 4);
-            launch_resblock(st, x->as<half_t>(), H4, W4, c->rb1[b].wrm.as<half_t>(), c->rb1[b].scale.as<float>(),
-                            c->rb1[b].shift.as<float>(), c->rb2[b].wgc.as<half_t>(), c->rb2[b].scale.as<float>(),
-                            c->rb2[b].shift.as<float>(), c->rb3[b].wrm.as<half_t>(), c->rb3[b].scale.as<float>(),
-                            c->rb3[b].shift.as<float>(), alias ? t1.as<half_t>() : ob.as<half_t>(), c->zero_page.as<half_t>());
-            x = alias ? &t1 : &ob;   // the fused kernel must not write over its own input: with the arena the output takes t1's slot
-            continue;
-        }
-        conv(c, nm1[b], c->rb1[b], *x, H4, W4, t1, H4, W4, 1);
-        {
-            ProfScope ps(c, nm2[b], "gconv3x3_g8_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 4);
-            launch_gconv3x3_g8(st, t1.as<half_t>(), H4, W4, c->rb2[b].w.as<half_t>(),
-                               c->rb2[b].scale.as<float>(), c->rb2[b].shift.as<float>(), t2.as<half_t>());
-        }
-        conv(c, nm3[b], c->rb3[b], t2, H4, W4, ob, H4, W4, 1, x->as<half_t>());
-        x = &ob;
-    }
+    for (int b = 0; b < 3; ++b) rb_f16(b);
     }
     // The two head branches read the backbone output and nothing of each other (nets/sfd2.py:328-342).  The detector
     // branch works on the 1/8 map (convPa.3: 133 tiles for 256 CUs at 1600x1200), so on its own it leaves part of the
@@ -2192,6 +2215,8 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "fuse_post") c->opt_fuse_post = value ? 1 : 0;
     else if (k == "sparse_desc") c->opt_sparse_desc = value ? 1 : 0;
     else if (k == "fuse_pb") c->opt_fuse_pb = value ? 1 : 0;
+    else if (k == "generic_c") c->opt_generic_c = value ? 1 : 0;
+    else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;
     else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;
 }

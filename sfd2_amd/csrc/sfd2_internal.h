@@ -64,6 +64,14 @@ __device__ __forceinline__ v8i_t sfd2_cat8(h8_t a, h8_t b)
     __builtin_memcpy(&y, &b, 16);
     return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// K slice kk (0 / 1) of an 8-dword fragment tuple, as the fp16 MFMA's operand (a sub-register reference, no copy)
+__device__ __forceinline__ h8_t sfd2_half8(v8i_t v, int kk)
+{
+    const v4i_t x = kk ? __builtin_shufflevector(v, v, 4, 5, 6, 7) : __builtin_shufflevector(v, v, 0, 1, 2, 3);
+    h8_t r;
+    __builtin_memcpy(&r, &x, 16);
+    return r;
+}
 // fp8 MFMA of one 32-channel corr chunk: a0 / a1 and b0 / b1 are the two 16-byte fragments the fp16 path would feed to
 // its two K = 16 MFMAs; sa = the layer's scale byte replicated into all four bytes
 __device__ __forceinline__ f32x16_t sfd2_mfma_corr(h8_t a0, h8_t a1, h8_t b0, h8_t b1, f32x16_t acc, int sa)
@@ -140,6 +148,14 @@ void launch_convsta(hipStream_t st, const half_t *in, int npix, const float *w /
 void launch_convc_igemm(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                         const float *scale, const float *shift, int Cout_pad, int ks, int stride, int relu,
                         const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, int Ho, int Wo, int sbyte);
+// the tuned kernels' compensated instantiations (same wpk / planes / sbyte as launch_convc_igemm; null plane = plain fp16)
+void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
+                         const float *scale, const float *shift, int CoutP, int relu, half_t *out, half_t *out_c,
+                         int Ho, int Wo, const half_t *zero_page, int sbyte);
+bool launch_conv_igemm2_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
+                          const float *scale, const float *shift, int CoutP, int ks, int stride, int relu,
+                          const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, int Ho, int Wo,
+                          const half_t *zero_page, int sbyte);
 void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *wpk /*hi, lo fragments*/,
                      const float *scale, const float *shift, half_t *out, half_t *out_c);
 void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk /*hi, lo fragments*/,

@@ -152,3 +152,53 @@ def test_f16c_reload_weights_and_mode_switch(synth_sd):
         _, _, desc = m.det(x[None])
         _, _, o_desc = orc.det(sd2, x, {})
         assert np.abs(desc[0] - o_desc).max() <= tol, prec
+
+
+@pytest.mark.parametrize("h,w,seed", [(64, 96, 11), (100, 130, 12), (200, 264, 14)])
+def test_f16c_tuned_kernels_vs_generic_kernel(synth_sd, h, w, seed):
+    """The tuned kernels' compensated instantiations (conv3x3_pp, conv_igemm2, ...) against the generic compensated
+    kernel (option 'generic_c'), which is the reference implementation of the arithmetic: same operands, same products,
+    fp32 summation order differs -- every backbone activation within 5e-5 of max|layer|."""
+    from sfd2_amd.model import ResSegNetV2
+    x = orc.norm_rgb(synth.make_image(h, w, seed))
+    outs = []
+    for generic in (1, 0):
+        m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
+        m.load_state_dict(synth_sd)
+        m.cuda(0)
+        m.context.set_option("generic_c", generic)
+        score, stab, desc = m.det(x[None])
+        names = ["conv1a", "bn1b", "conv2a", "bn2b", "conv3a", "bn3b", "conv4.0.bn1", "conv4.0.bn2", "conv4.0", "conv4.1", "conv4.2"]
+        outs.append(({n: m.context.debug_activation(n) for n in names}, desc))
+    worst = 0.0
+    for n in outs[0][0]:
+        a, b = outs[0][0][n], outs[1][0][n]
+        err = np.abs(a - b).max() / np.abs(a).max()
+        worst = max(worst, err)
+        assert err <= 5e-5, (n, err)
+    dd = np.abs(outs[0][1] - outs[1][1]).max()
+    assert dd <= 5e-4, dd      # (the heads are plain fp16: a one-ulp flip of a backbone hi value is fp16-level noise behind them)
+    _record(f"f16c tuned vs generic {h}x{w}: worst activation diff {worst:.2e} of max, dense desc diff {dd:.2e}")
+
+
+@pytest.fixture(scope="module")
+def model_c_rb16(synth_sd):
+    """f16c with option comp_rb = 0: stem .. conv3b compensated, the three ResBlocks on the fused fp16 kernel."""
+    from sfd2_amd.model import ResSegNetV2
+    m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
+    m.load_state_dict(synth_sd)
+    m.cuda(0)
+    m.context.set_option("comp_rb", 0)
+    return m
+
+
+@pytest.mark.parametrize("h,w,seed,topk", [(480, 640, 0, 1024), (1200, 1600, 31, 4096), (1024, 1024, 61, 4096), (768, 1024, 62, 4096),
+                                            (1536, 2048, 63, 4096)])
+def test_f16c_fp16_resblocks_extract_vs_oracle(model_c_rb16, synth_sd, h, w, seed, topk):
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    img = synth.make_image(h, w, seed)
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk)
+    got = extract_resnet_return(model_c_rb16, torch.from_numpy(img)[None].cuda(), conf_th=0.001, topK=topk, scales=[1.0])
+    iou, dd, shift, same, n = _compare(got, want, 0.97)
+    _record(f"f16c comp_rb=0 extract {w}x{h} top{topk}: IoU {iou:.4f}, desc {dd:.2e}, same rank {same}/{n}, max rank shift {shift}")
