@@ -1,0 +1,364 @@
+// Fused stem, compensated (SFD2_PREC_F16C): norm_RGB + conv1a (3->64) + BN + ReLU + conv1b (64->64, stride 2) + BN + ReLU
+// in one kernel, with conv1a's output kept in LDS as a hi plane AND a corr plane (sfd2_internal.h) and conv1b
+// compensated like every other backbone layer.  nets/extractor.py:104, nets/sfd2.py:268-270,314-316.
+//
+// Same tiling as fused_stem_kernel (a block computes the 9 x 65 conv1a pixels its 4 x 32 conv1b outputs need), but the
+// two planes of that region are 146 KB of the CU's 160 KB, so the conv1b filters (147 KB for hi + corr) cannot live in
+// LDS beside them.  They live in REGISTERS instead, which only works if a wave needs few of them: the K dimension of
+// conv1b (9 taps x 2 halves of 32 input channels = 18 units) is split over four wave groups (5 + 5 + 4 + 4 units; a unit
+// = 8 + 8 registers of hi and corr fragments), each wave accumulating a PARTIAL sum of all four output rows for its
+// 32-channel half.  The partials of the three rows a wave does not finish go through LDS (over the dead conv1a region)
+// and are added in a fixed order -- wave group 0, 1, 2, 3 -- so results do not depend on timing.
+//
+//   phase 1  conv1a on the 585 region pixels: image = hi + lo fp16, filters = hi + lo fp16, three fp16 MFMA passes;
+//            epilogue -> X1h (fp16) and X1c (corr units)                                   [barrier]
+//   phase 2  conv1b partial sums: per unit and output row two fp16 MFMAs on X1h and one fp8 MFMA on X1c  [barrier]
+//   phase 3  partials -> LDS                                                                [barrier]
+//   phase 4  row (wave >> 1) of this wave's channel half: sum of the four partials, BN + ReLU, hi + corr planes out;
+//            the next tile's image patch (fetched into registers a tile ago) -> LDS         [barrier]
+// Persistent blocks, one per CU.  HBM traffic: image in, H/2 x W/2 x 64 x 4 B out (the unfused compensated pair moves
+// 1 GB through HBM for the full-resolution planes: 650 us at 1600x1200).
+#include "sfd2_internal.h"
+#include <stdlib.h>
+
+#define SC_NT 512
+#define SC_TH 4
+#define SC_TW 32
+#define SC_RH 9
+#define SC_RW 65
+#define SC_RP (SC_RH * SC_RW)          // 585 conv1a pixels
+#define SC_IH 11
+#define SC_IW 68
+#define SC_IPT ((SC_IH * SC_IW + SC_NT - 1) / SC_NT)
+#define SC_X1 (SC_RP * 128)            // bytes of one plane of the region
+#define SC_IM (SC_IH * SC_IW * 8)      // bytes of one image plane ([px][4] fp16)
+#define SC_LDS (2 * SC_X1 + 2 * SC_IM + 1024)
+#define SC_NU 5                        // units per wave (the last two wave groups run four)
+
+__device__ __forceinline__ float sc_div_const(float a, float d, float r)   // see fused_stem_kernel.hip (exact for these constants)
+{
+    const float m = fabsf(a);
+    if (__builtin_expect(!(m >= 1e-20f && m <= 1e20f), 0)) {
+        asm volatile("" ::: "memory");
+        return __fdiv_rn(a, d);
+    }
+    const float q = __fmul_rn(a, r);
+    return __fmaf_rn(__fmaf_rn(-q, d, a), r, q);
+}
+
+#define SC_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__global__ __launch_bounds__(SC_NT, 2)
+void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normalise,
+                         const half_t *__restrict__ w1 /*[2 hi/lo][2][3][64][8] conv1a A fragments*/,
+                         const float *__restrict__ sc1, const float *__restrict__ sh1,
+                         const unsigned char *__restrict__ w2 /*[2 cth][18 units][64 lanes][64 B]: hi K slices 0, 1, then the corr fragment*/,
+                         const float *__restrict__ sc2, const float *__restrict__ sh2,
+                         half_t *__restrict__ out, half_t *__restrict__ out_c /*[H2][W2][64] each*/, int H2, int W2,
+                         int tiles_x, int n_tiles, int sa)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *X1h = smem;                                   // [SC_RP][128 B], 16-B slots swizzled with (rec >> 1) & 7, records pair-swapped
+    unsigned char *X1c = smem + SC_X1;                           // the corr plane, same addressing
+    half_t *IMh = reinterpret_cast<half_t *>(smem + 2 * SC_X1);  // [SC_IH][SC_IW][4]
+    half_t *IMl = IMh + SC_IH * SC_IW * 4;
+    float *SS = reinterpret_cast<float *>(smem + 2 * SC_X1 + 2 * SC_IM);   // sc1, sh1, sc2, sh2
+    float *PT = reinterpret_cast<float *>(smem);                 // phase 3 / 4: partial tiles [cth][row][group][4 quads][64 lanes] float4, over X1
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhi = lane >> 5;
+    const size_t plane = (size_t)H * W;
+    const int cth = wave & 1, kg = wave >> 1;                    // channel half; K group (= the output row this wave finishes)
+    const int u0 = kg < 2 ? kg * 5 : 10 + (kg - 2) * 4;
+    const int nu = kg < 2 ? 5 : 4;
+
+    if (tid < 64) { SS[tid] = sc1[tid]; SS[64 + tid] = sh1[tid]; SS[128 + tid] = sc2[tid]; SS[192 + tid] = sh2[tid]; }
+
+    // ---- conv1b filter fragments of this wave's units, resident
+    h8_t wa[SC_NU][2];
+    v8i_t wc[SC_NU];
+#pragma unroll
+    for (int i = 0; i < SC_NU; ++i) {
+        const int u = i < nu ? u0 + i : u0;                      // (the fifth slot of a four-unit wave is never used)
+        const unsigned char *p = w2 + ((size_t)(cth * 18 + u) * 64 + lane) * 64;
+        wa[i][0] = *reinterpret_cast<const h8_t *>(p);
+        wa[i][1] = *reinterpret_cast<const h8_t *>(p + 16);
+        wc[i] = sfd2_cat8(*reinterpret_cast<const h8_t *>(p + 32), *reinterpret_cast<const h8_t *>(p + 48));
+    }
+    // ---- conv1a filter fragments (this wave's 32-channel half), hi and lo: re-requested per tile right after phase 2 (from
+    // L2, 96 B per lane) instead of held across it -- phase 2 needs the 24 registers for its accumulators
+    h8_t a1h[3], a1l[3];
+#define SC_LOAD_A1()                                                                                       \
+    {                                                                                                      \
+        int ao_ = (cth * 3 * 64 + lane) * 8;                                                               \
+        asm volatile("" : "+v"(ao_));   /* (opaque: not hoisted back out of the tile loop) */               \
+        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                                 \
+            a1h[ky] = *reinterpret_cast<const h8_t *>(w1 + ao_ + ky * 512);                                \
+            a1l[ky] = *reinterpret_cast<const h8_t *>(w1 + ao_ + 3072 + ky * 512);                         \
+        }                                                                                                  \
+    }
+    SC_LOAD_A1()
+
+    // ---- image patch of a tile: raw values fetched one tile ahead, normalised and split when they are written to LDS
+    unsigned int pr[SC_IPT][3];
+    unsigned pr_inside = 0;
+    int fpy[SC_IPT], fpx[SC_IPT];
+#pragma unroll
+    for (int k = 0; k < SC_IPT; ++k) {
+        const int p = tid + k * SC_NT;
+        fpy[k] = p / SC_IW;
+        fpx[k] = p - fpy[k] * SC_IW;
+    }
+#define SC_FETCH_IMG(tile_)                                                                                \
+    {                                                                                                      \
+        const int ftx = (tile_) % tiles_x, fty = (tile_) / tiles_x;                                        \
+        const int fy0 = 2 * (fty * SC_TH) - 2, fx0 = 2 * (ftx * SC_TW) - 2;                                \
+        pr_inside = 0;                                                                                     \
+        _Pragma("unroll") for (int k = 0; k < SC_IPT; ++k) {                                               \
+            const int p = tid + k * SC_NT;                                                                 \
+            const int iy = fy0 + fpy[k], ix = fx0 + fpx[k];                                                \
+            unsigned int r = 0u, g = 0u, b = 0u;                                                           \
+            if (p < SC_IH * SC_IW && iy >= 0 && iy < H && ix >= 0 && ix < W) {                             \
+                const size_t o = (size_t)iy * W + ix;                                                      \
+                pr_inside |= 1u << k;                                                                      \
+                if (normalise & 2) { /* uint8 HWC ingest (extract_localization.py:165-186) */              \
+                    const unsigned char *u = reinterpret_cast<const unsigned char *>(img) + o * 3;         \
+                    const int sw = (normalise & 4) ? 2 : 0;                                                \
+                    r = u[sw]; g = u[1]; b = u[2 - sw];                                                    \
+                } else {                                                                                   \
+                    const unsigned int *iu = reinterpret_cast<const unsigned int *>(img);                  \
+                    r = iu[o]; g = iu[plane + o]; b = iu[2 * plane + o];                                   \
+                }                                                                                          \
+            }                                                                                              \
+            pr[k][0] = r; pr[k][1] = g; pr[k][2] = b;                                                      \
+        }                                                                                                  \
+    }
+#define SC_STORE_IMG()                                                                                     \
+    _Pragma("unroll") for (int k = 0; k < SC_IPT; ++k) {                                                   \
+        const int p = tid + k * SC_NT;                                                                     \
+        float r, g, b;                                                                                     \
+        if (normalise & 2) { r = (float)pr[k][0]; g = (float)pr[k][1]; b = (float)pr[k][2]; }              \
+        else { r = __uint_as_float(pr[k][0]); g = __uint_as_float(pr[k][1]); b = __uint_as_float(pr[k][2]); } \
+        if (pr_inside & (1u << k)) {                                                                       \
+            if (normalise & 2) {                                                                           \
+                r = sc_div_const(r, 255.0f, 1.0f / 255.0f); g = sc_div_const(g, 255.0f, 1.0f / 255.0f);    \
+                b = sc_div_const(b, 255.0f, 1.0f / 255.0f);                                                \
+            }                                                                                              \
+            if (normalise & 1) {                                                                           \
+                r = sc_div_const(__fsub_rn(r, 0.485f), 0.229f, 1.0f / 0.229f);                             \
+                g = sc_div_const(__fsub_rn(g, 0.456f), 0.224f, 1.0f / 0.224f);                             \
+                b = sc_div_const(__fsub_rn(b, 0.406f), 0.225f, 1.0f / 0.225f);                             \
+            }                                                                                              \
+        }                                                                                                  \
+        if (p < SC_IH * SC_IW) {                                                                           \
+            h4_t hh, hl;                                                                                   \
+            hh[0] = (half_t)r; hh[1] = (half_t)g; hh[2] = (half_t)b; hh[3] = (half_t)0.0f;                 \
+            hl[0] = (half_t)(r - (float)hh[0]); hl[1] = (half_t)(g - (float)hh[1]); hl[2] = (half_t)(b - (float)hh[2]); hl[3] = (half_t)0.0f; \
+            *reinterpret_cast<h4_t *>(IMh + p * 4) = hh;                                                   \
+            *reinterpret_cast<h4_t *>(IMl + p * 4) = hl;                                                   \
+        }                                                                                                  \
+    }
+
+    // ---- phase 1 geometry (the same for every tile): unit = (32-pixel block of the region, this wave's channel half)
+    constexpr int P1_UNITS = ((SC_RP + 31) / 32 + 3) / 4;
+    const int p1_n = ((SC_RP + 31) / 32 - kg + 3) / 4;
+    int p1_im[P1_UNITS], p1_x[P1_UNITS], p1_yx[P1_UNITS];
+    unsigned p1_ok = 0;
+#pragma unroll
+    for (int i = 0; i < P1_UNITS; ++i) {
+        const int p = (kg + 4 * i) * 32 + lrow;
+        const int pc = p < SC_RP ? p : SC_RP - 1;
+        const int ry = pc / SC_RW, rx = pc - ry * SC_RW;
+        if (p < SC_RP) p1_ok |= 1u << i;
+        p1_yx[i] = (ry << 8) | rx;
+        p1_im[i] = (ry * SC_IW + rx + 2 * lhi) * 4;                      // halfs
+        // byte offset of this lane's 8 bytes of channel quad 0 in the pixel's record, swizzle of the record folded in per quad below
+        p1_x[i] = ((p ^ ((p >> 4) & 1)) * 128 + 8 * lhi) | (((p >> 1) & 7) << 20);
+    }
+
+    int tile = blockIdx.x;
+    SC_FETCH_IMG(tile)
+    SC_STORE_IMG()
+    if (tile + (int)gridDim.x < n_tiles) SC_FETCH_IMG(tile + (int)gridDim.x)
+    SFD2_BARRIER_DRAIN();
+
+    for (;;) {
+        const int tx = tile % tiles_x, ty = tile / tiles_x;
+        const int oy0 = ty * SC_TH, ox0 = tx * SC_TW;
+        const int ry0 = 2 * oy0 - 1, rx0 = 2 * ox0 - 1;
+
+        // ---- phase 1: conv1a -> X1h / X1c
+#pragma unroll
+        for (int i = 0; i < P1_UNITS; ++i) {
+            if (i < p1_n) {
+                f32x16_t acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                // per-lane offsets are recomputed from one opaque register per unit: hoisted out of the tile loop (they are all
+                // tile-invariant) they are ~100 registers, spilled and reloaded behind s_waitcnt vmcnt(0)
+                int imo = p1_im[i];
+                asm volatile("" : "+v"(imo));
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int o = imo + ky * (SC_IW * 4);
+                    h8_t bh, bl;
+                    {
+                        const h4_t lo = *reinterpret_cast<const h4_t *>(IMh + o);
+                        const h4_t hi = *reinterpret_cast<const h4_t *>(IMh + o + 4);
+                        bh[0] = lo[0]; bh[1] = lo[1]; bh[2] = lo[2]; bh[3] = lo[3];
+                        bh[4] = hi[0]; bh[5] = hi[1]; bh[6] = hi[2]; bh[7] = hi[3];
+                    }
+                    {
+                        const h4_t lo = *reinterpret_cast<const h4_t *>(IMl + o);
+                        const h4_t hi = *reinterpret_cast<const h4_t *>(IMl + o + 4);
+                        bl[0] = lo[0]; bl[1] = lo[1]; bl[2] = lo[2]; bl[3] = lo[3];
+                        bl[4] = hi[0]; bl[5] = hi[1]; bl[6] = hi[2]; bl[7] = hi[3];
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l[ky], bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[ky], bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[ky], bh, acc, 0, 0, 0);
+                }
+                // conv1b zero-pads conv1a's OUTPUT: region pixels outside the image are zeros, not conv1a(0)
+                const int gy = ry0 + (p1_yx[i] >> 8), gx = rx0 + (p1_yx[i] & 255);
+                const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                int xo = p1_x[i] & 0xFFFFF, xsw = (p1_x[i] >> 20) << 4;
+                asm volatile("" : "+v"(xo), "+v"(xsw));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 s = sfd2_lds_f4(SS + cth * 32 + 8 * q + 4 * lhi);
+                    const float4 h = sfd2_lds_f4(SS + 64 + cth * 32 + 8 * q + 4 * lhi);
+                    uint2 hv, cv;
+                    sfd2_split4(fmaxf(acc[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc[4 * q + 1] * s.y + h.y, 0.0f),
+                                fmaxf(acc[4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc[4 * q + 3] * s.w + h.w, 0.0f), hv, cv);
+                    if (!inside) { hv = make_uint2(0u, 0u); cv = make_uint2(0u, 0u); }
+                    if (p1_ok & (1u << i)) {
+                        const int o = xo + (((cth * 4 + q) << 4) ^ xsw);
+                        *reinterpret_cast<uint2 *>(X1h + o) = hv;
+                        *reinterpret_cast<uint2 *>(X1c + o) = cv;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (units are not interleaved: the resident conv1b filters leave no registers for it)
+        }
+        const int next = tile + (int)gridDim.x, next2 = next + (int)gridDim.x;
+        const bool has_next = next < n_tiles;
+        SC_LDS_BARRIER();                     // X1 complete; IM is free from here on
+
+        // ---- phase 2: partial sums of conv1b over this wave's units, all four output rows
+        f32x16_t acc2[SC_TH];
+#pragma unroll
+        for (int r = 0; r < SC_TH; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[r][e] = 0.0f;
+        int l2 = 2 * lrow;
+        asm volatile("" : "+v"(l2));          // (the 40 fragment addresses of phase 2 are tile-invariant too)
+#pragma unroll
+        for (int i = 0; i < SC_NU; ++i) {
+            if (i < nu) {                     // wave-uniform
+                const int u = u0 + i, tap = u >> 1, ih = u & 1;
+                const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                for (int r = 0; r < SC_TH; ++r) {
+                    const int q = (2 * r + ky) * SC_RW + l2 + kx;
+                    const int ro = (q ^ ((q >> 4) & 1)) * 128;
+                    const int bsw = (q >> 1) & 7;
+                    const int o0 = ro + (((ih * 4 + lhi) ^ bsw) << 4), o1 = ro + (((ih * 4 + 2 + lhi) ^ bsw) << 4);
+                    const h8_t b0 = *reinterpret_cast<const h8_t *>(X1h + o0);
+                    const h8_t b1 = *reinterpret_cast<const h8_t *>(X1h + o1);
+                    const v8i_t bc = sfd2_cat8(*reinterpret_cast<const h8_t *>(X1c + o0), *reinterpret_cast<const h8_t *>(X1c + o1));
+                    acc2[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[i][0], b0, acc2[r], 0, 0, 0);
+                    acc2[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[i][1], b1, acc2[r], 0, 0, 0);
+                    acc2[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wc[i], bc, acc2[r], 0, 0, 0, sa, 0, 0x7f7f7f7f);
+                }
+            }
+        }
+        // (the scaled MFMA is a pure node to instruction selection: pin the partial sums in front of the barrier)
+#pragma unroll
+        for (int r = 0; r < SC_TH; ++r) asm volatile("" : "+v"(acc2[r]));
+        if (has_next) SC_LOAD_A1()            // conv1a filters of the next tile's phase 1
+        SC_LDS_BARRIER();                     // every wave is done reading X1
+
+        // ---- phase 3: this wave's partials of all four rows -> LDS (its own row too: phase 4 then reads four tiles in a
+        // fixed order with static register indices)
+#pragma unroll
+        for (int r = 0; r < SC_TH; ++r) {
+            float *pt = PT + (size_t)((cth * 4 + r) * 4 + kg) * 1024 + lane * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4 *>(pt + q * 256) = make_float4(acc2[r][4 * q], acc2[r][4 * q + 1], acc2[r][4 * q + 2], acc2[r][4 * q + 3]);
+        }
+        SC_LDS_BARRIER();                     // partials visible
+
+        // ---- phase 4: row kg of this wave's channel half = partials of groups 0, 1, 2, 3 added in that order
+        f32x16_t tot;
+        {
+            const float *pt = PT + (size_t)((cth * 4 + kg) * 4) * 1024 + lane * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v0 = sfd2_lds_f4(pt + q * 256), v1 = sfd2_lds_f4(pt + 1024 + q * 256);
+                const float4 v2 = sfd2_lds_f4(pt + 2048 + q * 256), v3 = sfd2_lds_f4(pt + 3072 + q * 256);
+                tot[4 * q + 0] = ((v0.x + v1.x) + v2.x) + v3.x;
+                tot[4 * q + 1] = ((v0.y + v1.y) + v2.y) + v3.y;
+                tot[4 * q + 2] = ((v0.z + v1.z) + v2.z) + v3.z;
+                tot[4 * q + 3] = ((v0.w + v1.w) + v2.w) + v3.w;
+            }
+        }
+
+        if (has_next) SC_STORE_IMG()          // the next tile's patch (requested a tile ago) -> IM, in front of the output stores
+        const int oy = oy0 + kg, ox = ox0 + lrow;
+        const bool inb = oy < H2 && ox < W2;
+        const size_t ob = ((size_t)(inb ? oy : 0) * W2 + (inb ? ox : 0)) * 64;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            uint2 pk[2], ck[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = 2 * m + j;
+                const int c0 = cth * 32 + 8 * q + 4 * lhi;
+                const float4 s = sfd2_lds_f4(SS + 128 + c0);
+                const float4 h = sfd2_lds_f4(SS + 192 + c0);
+                sfd2_split4(fmaxf(tot[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(tot[4 * q + 1] * s.y + h.y, 0.0f),
+                            fmaxf(tot[4 * q + 2] * s.z + h.z, 0.0f), fmaxf(tot[4 * q + 3] * s.w + h.w, 0.0f), pk[j], ck[j]);
+            }
+            const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+            const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+            const auto u0s = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
+            const auto u1s = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
+            if (inb) {
+                const size_t o = ob + cth * 32 + 8 * (2 * m + lhi);
+                *reinterpret_cast<uint4 *>(out + o) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                *reinterpret_cast<uint4 *>(out_c + o) = make_uint4(u0s[0], u1s[0], u0s[1], u1s[1]);
+            }
+        }
+        if (!has_next) break;
+        if (next2 < n_tiles) SC_FETCH_IMG(next2)
+        SC_LDS_BARRIER();                     // IM complete; every wave is done with the partials (phase 1 writes X1 again)
+        tile = next;
+    }
+#undef SC_LOAD_A1
+#undef SC_FETCH_IMG
+#undef SC_STORE_IMG
+}
+
+void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *w1, const float *sc1,
+                         const float *sh1, const void *w2, const float *sc2, const float *sh2, half_t *out, half_t *out_c,
+                         int H2, int W2, int sbyte)
+{
+    static bool attr_done = false;
+    static int slots = 256;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stem_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            slots = cus;   // 159 KB of LDS: one resident block per CU
+        attr_done = true;
+    }
+    const int tiles_x = (W2 + SC_TW - 1) / SC_TW, tiles_y = (H2 + SC_TH - 1) / SC_TH;
+    const int n_tiles = tiles_x * tiles_y;
+    const int grid = n_tiles < slots ? n_tiles : slots;
+    hipLaunchKernelGGL(fused_stem_c_kernel, dim3(grid), dim3(SC_NT), SC_LDS, st, img, H, W, normalise, w1, sc1, sh1,
+                       reinterpret_cast<const unsigned char *>(w2), sc2, sh2, out, out_c, H2, W2, tiles_x, n_tiles,
+                       (sbyte & 255) * 0x01010101);
+}

@@ -105,6 +105,7 @@ struct sfd2_ctx {
     // weights
     ConvW c1a, c1b, c2a, c2b, c3a, c3b, rb1[3], rb2[3], rb3[3], pa0, pa3, da0, da3, pb, db;
     DevBuf sta_w, sta_b, zero_page, w1b_fused;   // w1b_fused: conv1b filters as [9][64][64] for the fused stem
+    DevBuf w1b_stem_c;                             // the same as register fragments (hi K slices + corr) for the compensated fused stem
     int fuse = 1;                                  // fused kernels on the extract path (SFD2_NO_FUSE=1 disables)
     int fuse_now = 0;                              // set per call: sfd2_det keeps every intermediate readable
     // strict fp32 mode
@@ -575,6 +576,27 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
                 for (int ic = 0; ic < 64; ++ic) pk[((size_t)t * 64 + oc) * 64 + ic] = (half_t)w->d[((size_t)oc * 64 + ic) * 9 + t];
         if (upload(c->w1b_fused, pk.data(), pk.size() * sizeof(half_t), c->stream)) return -1;
     }
+    {   // ... and as register fragments of the compensated fused stem (fused_stem_c_kernel.hip): [channel half][unit = tap * 2 +
+        // half of the input channels][lane][K slice 0 | K slice 1 | corr fragment]
+        const TView *w = find_t(m, "conv1b.0.weight");
+        const int b0 = 127 - SFD2_C_XL_SHIFT - c->c1b.sbyte;
+        std::vector<unsigned short> pk((size_t)2 * 18 * 64 * 32, 0);
+        for (int cth = 0; cth < 2; ++cth)
+            for (int u = 0; u < 18; ++u)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int kk = 0; kk < 2; ++kk)
+                        for (int j = 0; j < 8; ++j) {
+                            const int oc = cth * 32 + (lane & 31), ic = (u & 1) * 32 + kk * 16 + (lane >> 5) * 8 + j, tap = u >> 1;
+                            const float v = w->d[((size_t)oc * 64 + ic) * 9 + tap];
+                            const half_t h = (half_t)v;
+                            unsigned short hb;
+                            std::memcpy(&hb, &h, 2);
+                            const size_t base = ((size_t)(cth * 18 + u) * 64 + lane) * 32;
+                            pk[base + kk * 8 + j] = hb;
+                            pk[base + 16 + kk * 8 + j] = (unsigned short)(f32_to_e4m3(std::ldexp(v, b0)) | (f32_to_e4m3(std::ldexp(v - (float)h, b0 + 11)) << 8));
+                        }
+        if (upload(c->w1b_stem_c, pk.data(), pk.size() * 2, c->stream)) return -1;
+    }
     if (pack_igemm(c, m, c->c2a, "conv2a.0", "conv2a.1", 64, 128, 3, 1)) return -1;
     if (pack_igemm(c, m, c->c2b, "conv2b.0", "bn2b.0", 128, 128, 3, 2)) return -1;
     if (pack_igemm(c, m, c->c3a, "conv3a.0", "conv3a.1", 128, 256, 3, 1)) return -1;
@@ -636,7 +658,7 @@ static int ensure_workspace(sfd2_ctx *c, int H, int W)
     const bool layers = !f32 && !c->alias_now;      // private fp16 buffer per activation
     // SFD2_PREC_F16C: every backbone activation is a hi plane followed by its corr plane (same geometry)
     const size_t bb = comp ? 2 * hb : hb;
-    const bool fused_stem = c->fuse_now && !comp;   // (no compensated fused stem yet: conv1a's planes go through memory)
+    const bool fused_stem = c->fuse_now && !(comp && c->opt_generic_c);
     const bool fused_rb = c->fuse_now && (!comp || !c->opt_comp_rb);
     if (!f32 && !fused_stem) HIPCHECK(c->a1a.ensure(P1 * 64 * bb));
     if (layers) {
@@ -952,12 +974,20 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     };
     if (comp) {
         // SFD2_PREC_F16C backbone: every activation carries a corr plane, every layer adds the fp8 correction terms
-        {
-            ProfScope ps(c, "conv1a", "conv1a_c_kernel", 2.0 * P1 * 64 * 27, P1 * (12 + 256));
-            launch_conv1a_c(st, img_dev, H, W, normalise, c->c1a.wc.as<half_t>(), c->c1a.scale.as<float>(),
-                            c->c1a.shift.as<float>(), c->a1a.as<half_t>(), corr_of(c->a1a, (size_t)H * W, 64));
+        if (c->fuse_now && !c->opt_generic_c) {
+            ProfScope ps(c, "conv1a+conv1b", "fused_stem_c_kernel", 2.0 * P1 * 64 * 27 + 2.0 * (double)H2 * W2 * 64 * 576,
+                         P1 * 12 + (double)H2 * W2 * 256);
+            launch_fused_stem_c(st, img_dev, H, W, normalise, c->c1a.wc.as<half_t>(), c->c1a.scale.as<float>(),
+                                c->c1a.shift.as<float>(), c->w1b_stem_c.p, c->c1b.scale.as<float>(), c->c1b.shift.as<float>(),
+                                a1b.as<half_t>(), corr_of(a1b, (size_t)H2 * W2, 64), H2, W2, c->c1b.sbyte);
+        } else {
+            {
+                ProfScope ps(c, "conv1a", "conv1a_c_kernel", 2.0 * P1 * 64 * 27, P1 * (12 + 256));
+                launch_conv1a_c(st, img_dev, H, W, normalise, c->c1a.wc.as<half_t>(), c->c1a.scale.as<float>(),
+                                c->c1a.shift.as<float>(), c->a1a.as<half_t>(), corr_of(c->a1a, (size_t)H * W, 64));
+            }
+            convc(c, "conv1b", c->c1b, c->a1a, H, W, a1b, H2, W2, 1, true, true);
         }
-        convc(c, "conv1b", c->c1b, c->a1a, H, W, a1b, H2, W2, 1, true, true);
         convc(c, "conv2a", c->c2a, a1b, H2, W2, a2a, H2, W2, 1, true, true);
         convc(c, "conv2b", c->c2b, a2a, H2, W2, a2b, H4, W4, 1, true, true);
         convc(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1, true, true);

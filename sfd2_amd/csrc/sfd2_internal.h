@@ -156,6 +156,10 @@ bool launch_conv_igemm2_c(hipStream_t st, const half_t *in, const half_t *in_c, 
                           const float *scale, const float *shift, int CoutP, int ks, int stride, int relu,
                           const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, int Ho, int Wo,
                           const half_t *zero_page, int sbyte);
+// compensated fused stem (fused_stem_c_kernel.hip): w1 = conv1a hi, lo fragments; w2 = conv1b register fragments
+void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *w1, const float *sc1,
+                         const float *sh1, const void *w2, const float *sc2, const float *sh2, half_t *out, half_t *out_c,
+                         int H2, int W2, int sbyte);
 void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *wpk /*hi, lo fragments*/,
                      const float *scale, const float *shift, half_t *out, half_t *out_c);
 void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk /*hi, lo fragments*/,

@@ -154,24 +154,26 @@ def test_f16c_reload_weights_and_mode_switch(synth_sd):
         assert np.abs(desc[0] - o_desc).max() <= tol, prec
 
 
-@pytest.mark.parametrize("h,w,seed", [(64, 96, 11), (100, 130, 12), (200, 264, 14)])
+@pytest.mark.parametrize("h,w,seed", [(64, 96, 11), (100, 130, 12), (200, 264, 14), (37, 53, 13)])
 def test_f16c_tuned_kernels_vs_generic_kernel(synth_sd, h, w, seed):
-    """The tuned kernels' compensated instantiations (conv3x3_pp, conv_igemm2, ...) against the generic compensated
-    kernel (option 'generic_c'), which is the reference implementation of the arithmetic: same operands, same products,
-    fp32 summation order differs -- every backbone activation within 5e-5 of max|layer|."""
+    """The tuned kernels' compensated forms (fused stem, conv3x3_pp, conv_igemm2; option 'fuse_det' routes sfd2_det through
+    the fused stem) against the generic compensated kernel (option 'generic_c'), the reference implementation of the
+    arithmetic: same operands, same products, fp32 summation order differs -- every backbone activation within 5e-5 of
+    max|layer|."""
     from sfd2_amd.model import ResSegNetV2
     x = orc.norm_rgb(synth.make_image(h, w, seed))
+    names = ["bn1b", "conv2a", "bn2b", "conv3a", "bn3b", "conv4.0.bn1", "conv4.0.bn2", "conv4.0", "conv4.1", "conv4.2"]
     outs = []
     for generic in (1, 0):
         m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
         m.load_state_dict(synth_sd)
         m.cuda(0)
         m.context.set_option("generic_c", generic)
+        m.context.set_option("fuse_det", 0 if generic else 1)
         score, stab, desc = m.det(x[None])
-        names = ["conv1a", "bn1b", "conv2a", "bn2b", "conv3a", "bn3b", "conv4.0.bn1", "conv4.0.bn2", "conv4.0", "conv4.1", "conv4.2"]
         outs.append(({n: m.context.debug_activation(n) for n in names}, desc))
     worst = 0.0
-    for n in outs[0][0]:
+    for n in names:
         a, b = outs[0][0][n], outs[1][0][n]
         err = np.abs(a - b).max() / np.abs(a).max()
         worst = max(worst, err)
