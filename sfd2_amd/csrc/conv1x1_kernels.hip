@@ -189,3 +189,184 @@ void launch_conv1x1_c256(hipStream_t st, const half_t *in, int npix, const half_
     if (res) hipLaunchKernelGGL(conv1x1_c256_kernel<true>, dim3(grid), dim3(NT1), lds, st, in, npix, w_rowmajor, scale, shift, relu, res, out, gpb, zero_page);
     else hipLaunchKernelGGL(conv1x1_c256_kernel<false>, dim3(grid), dim3(NT1), lds, st, in, npix, w_rowmajor, scale, shift, relu, res, out, gpb, zero_page);
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same layers compensated (SFD2_PREC_F16C, sfd2_internal.h): activations are a hi plane and a corr plane, filters the
+// fp16 matrix and a matrix of corr units.  Same streaming structure; what changes is the split: a wave owns 32 output
+// channels (64 registers of fp16 fragments + 64 of corr fragments, the same 128 as the fp16 kernel's 64 channels) and ALL
+// 32 pixels of a group; a group = 32 pixels = 16 KB of hi + 16 KB of corr records, so the four-stage ring, the four copies
+// per wave and group and the counted waits are those of the fp16 kernel.  Per group and wave: 16 fp16 MFMAs + 8 fp8 MFMAs.
+#define GPXC 32
+#define STAGE_C (2 * GPXC * 512)
+
+template <bool HAS_RES>
+__global__ __launch_bounds__(NT1, 2)
+void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in_c, int npix,
+                           const half_t *__restrict__ w /*[256 out][256 in] fp16*/, const half_t *__restrict__ wc /*[256][256] corr units*/,
+                           const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                           const half_t *__restrict__ res, const half_t *__restrict__ res_c,
+                           half_t *__restrict__ out, half_t *__restrict__ out_c, int groups_per_block,
+                           const half_t *__restrict__ zero_page, int sa)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Xs = smem;                                              // [NST][hi 32 x 512 B | corr 32 x 512 B]
+    float *SS = reinterpret_cast<float *>(smem + NST * STAGE_C);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhi = lane >> 5;
+    const int ngroups = (npix + GPXC - 1) / GPXC;
+    const int g0 = blockIdx.x * groups_per_block;
+    int g1 = g0 + groups_per_block;
+    if (g1 > ngroups) g1 = ngroups;
+    if (g0 >= g1) return;
+
+    h8_t ah[16];
+    v8i_t ac[8];
+    {
+        const size_t ro = (size_t)(wave * 32 + lrow) * 256 + lhi * 8;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) ah[kk] = *reinterpret_cast<const h8_t *>(w + ro + kk * 16);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            ac[c] = sfd2_cat8(*reinterpret_cast<const h8_t *>(wc + ro + c * 32), *reinterpret_cast<const h8_t *>(wc + ro + c * 32 + 16));
+    }
+    for (int t = tid; t < 256; t += NT1) { SS[t] = scale[t]; SS[256 + t] = shift[t]; }
+
+    // group g -> ring stage: 16 + 16 one-KB chunks (2 pixel records each): 2 of each plane per wave
+#define ISSUE_GC(g_)                                                                                       \
+    {                                                                                                      \
+        unsigned char *st = Xs + ((g_) & (NST - 1)) * STAGE_C;                                             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
+            const int ch = wave * 2 + i;                                                                   \
+            const int p = ch * 2 + lhi;                                                                    \
+            const long long gp = (long long)(g_)*GPXC + p;                                                 \
+            const size_t so = (size_t)gp * 256 + ((lrow ^ (p & 31)) << 3);                                 \
+            const half_t *s0 = gp < npix ? in + so : zero_page + (lrow << 3);                              \
+            const half_t *s1 = gp < npix ? in_c + so : zero_page + (lrow << 3);                            \
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)s0, (lds_void_t *)(st + ch * 1024), 16, 0, 0);  \
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)s1, (lds_void_t *)(st + GPXC * 512 + ch * 1024), 16, 0, 0); \
+        }                                                                                                  \
+    }
+#define WAIT_GROUP_C()                                                                                     \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(HAS_RES ? 12 : 8) : "memory")
+
+    ISSUE_GC(g0)
+    if (g0 + 1 < g1) { ISSUE_GC(g0 + 1) }
+    if (g0 + 2 < g1) { ISSUE_GC(g0 + 2) }
+    SFD2_BARRIER_DRAIN();
+
+    for (int g = g0; g < g1; ++g) {
+        if (g != g0) {
+            if (g + 2 < g1) WAIT_GROUP_C(); else SFD2_BARRIER_DRAIN();
+        }
+        const unsigned char *st = Xs + (g & (NST - 1)) * STAGE_C;
+        const int p = lrow;
+        const long long gp = (long long)g * GPXC + p;
+        const bool inb = gp < npix;
+        const size_t obase = (size_t)(inb ? gp : 0) * 256 + wave * 32;
+
+        uint4 rq[2], rc[2];
+        if (HAS_RES) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                rq[m] = make_uint4(0, 0, 0, 0);
+                rc[m] = make_uint4(0, 0, 0, 0);
+                if (inb) {
+                    rq[m] = *reinterpret_cast<const uint4 *>(res + obase + 8 * (2 * m + lhi));
+                    rc[m] = *reinterpret_cast<const uint4 *>(res_c + obase + 8 * (2 * m + lhi));
+                }
+            }
+            asm volatile("" ::: "memory");       // keep the residual loads ahead of the copies below in program order
+        }
+        if (g + 3 < g1) { ISSUE_GC(g + 3) }
+
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const unsigned char *xp = st + p * 512;
+        const int sw = p & 31;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const h8_t b = *reinterpret_cast<const h8_t *>(xp + (((kk * 2 + lhi) ^ sw) << 4));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const v8i_t b = sfd2_cat8(*reinterpret_cast<const h8_t *>(xp + GPXC * 512 + (((c * 4 + lhi) ^ sw) << 4)),
+                                      *reinterpret_cast<const h8_t *>(xp + GPXC * 512 + (((c * 4 + 2 + lhi) ^ sw) << 4)));
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ac[c], b, acc, 0, 0, 0, sa, 0, 0x7f7f7f7f);
+        }
+        asm volatile("" : "+v"(acc));   // (the scaled MFMA is a pure node to instruction selection: keep it in front of the epilogue)
+
+        const int cl = wave * 32 + 4 * lhi;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            uint2 rp[2] = {make_uint2(0, 0), make_uint2(0, 0)}, rcp[2] = {make_uint2(0, 0), make_uint2(0, 0)};
+            if (HAS_RES) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(rq[m].x, rq[m].z, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(rq[m].y, rq[m].w, false, false);
+                rp[0] = make_uint2(s0[0], s1[0]);
+                rp[1] = make_uint2(s0[1], s1[1]);
+                const auto c0 = __builtin_amdgcn_permlane32_swap(rc[m].x, rc[m].z, false, false);
+                const auto c1 = __builtin_amdgcn_permlane32_swap(rc[m].y, rc[m].w, false, false);
+                rcp[0] = make_uint2(c0[0], c1[0]);
+                rcp[1] = make_uint2(c0[1], c1[1]);
+            }
+            uint2 pk[2], ck[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = 2 * m + j;
+                const float4 sc = sfd2_lds_f4(SS + cl + 8 * q);
+                const float4 sh = sfd2_lds_f4(SS + 256 + cl + 8 * q);
+                float v0 = acc[4 * q + 0] * sc.x + sh.x;
+                float v1 = acc[4 * q + 1] * sc.y + sh.y;
+                float v2 = acc[4 * q + 2] * sc.z + sh.z;
+                float v3 = acc[4 * q + 3] * sc.w + sh.w;
+                if (HAS_RES) {
+                    h4_t r;
+                    __builtin_memcpy(&r, &rp[j], 8);
+                    v0 += (float)r[0] + sfd2_corr_lo(rcp[j].x, 0); v1 += (float)r[1] + sfd2_corr_lo(rcp[j].x, 1);
+                    v2 += (float)r[2] + sfd2_corr_lo(rcp[j].y, 0); v3 += (float)r[3] + sfd2_corr_lo(rcp[j].y, 1);
+                }
+                if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
+                sfd2_split4(v0, v1, v2, v3, pk[j], ck[j]);
+            }
+            const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+            const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+            const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
+            const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
+            if (inb) {
+                *reinterpret_cast<uint4 *>(out + obase + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                *reinterpret_cast<uint4 *>(out_c + obase + 8 * (2 * m + lhi)) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
+            }
+        }
+    }
+#undef ISSUE_GC
+#undef WAIT_GROUP_C
+}
+
+void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c, int npix, const half_t *w_rowmajor,
+                           const half_t *wc_rowmajor, const float *scale, const float *shift, int relu, const half_t *res,
+                           const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte)
+{
+    static bool attr_done = false;
+    static int slots = 256;
+    const size_t lds = (size_t)NST * STAGE_C + 512 * sizeof(float);
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_c256_c_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_c256_c_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            slots = cus;
+        attr_done = true;
+    }
+    const int ngroups = (npix + GPXC - 1) / GPXC;
+    if (ngroups == 0) return;
+    const int gpb = (ngroups + slots - 1) / slots;
+    const int grid = (ngroups + gpb - 1) / gpb;
+    const int sa = (sbyte & 255) * 0x01010101;
+    if (res) hipLaunchKernelGGL(conv1x1_c256_c_kernel<true>, dim3(grid), dim3(NT1), lds, st, in, in_c, npix, w_rowmajor, wc_rowmajor, scale, shift, relu, res, res_c, out, out_c, gpb, zero_page, sa);
+    else hipLaunchKernelGGL(conv1x1_c256_c_kernel<false>, dim3(grid), dim3(NT1), lds, st, in, in_c, npix, w_rowmajor, wc_rowmajor, scale, shift, relu, res, res_c, out, out_c, gpb, zero_page, sa);
+}

@@ -55,6 +55,7 @@ struct ConvW {                 // one folded + packed layer
     int cin = 0, cout = 0, cout_pad = 0, ks = 0, stride = 1;
     DevBuf w, scale, shift;    // fp16 packed filters, fp32 [cout_pad]
     DevBuf wrm;                // 1x1 256 -> 256 layers: the same filters as plain [cout][cin] fp16 (conv1x1_c256_kernel)
+    DevBuf wrmc;               // ... and their corr units, [cout][cin] (conv1x1_c256_c_kernel)
     DevBuf wgc;                // grouped 3x3: compact [256 oc][9 taps][8 in] fp16 (resblock_kernel)
     DevBuf wx3;                // fp32 layers, SFD2_PREC_F16X3: every float4 of w as (4 hi, 4 lo) fp16, made on first use
     DevBuf wc;                 // SFD2_PREC_F16C: [2 * cin / 32][taps][cout_pad][32] units -- the fp16 filters in 32-wide chunks, then the
@@ -382,6 +383,14 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
                         pc[plane + o] = (unsigned short)(w8 | (l8 << 8));   // pairs with the pixel unit (residual byte, value byte)
                     }
         if (upload(L.wc, pc.data(), pc.size() * 2, c->stream)) return -1;
+        if (ks == 1 && stride == 1 && cin == 256 && cout == 256) {
+            std::vector<unsigned short> rc((size_t)256 * 256);
+            for (size_t i = 0; i < rc.size(); ++i) {
+                const float v = w->d[i];
+                rc[i] = (unsigned short)(f32_to_e4m3(std::ldexp(v, b0)) | (f32_to_e4m3(std::ldexp(v - (float)(half_t)v, b0 + 11)) << 8));
+            }
+            if (upload(L.wrmc, rc.data(), rc.size() * 2, c->stream)) return -1;
+        }
     }
     return 0;
 }
@@ -804,6 +813,15 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &i
         ProfScope ps(c, name, "conv3x3_pp<comp>", flops, bytes);
         launch_conv3x3_pp_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, L.wc.as<half_t>(), L.scale.as<float>(),
                             L.shift.as<float>(), L.cout_pad, relu, out.as<half_t>(), out_c, Ho, Wo, c->zero_page.as<half_t>(), L.sbyte);
+        return;
+    }
+    if (!c->opt_generic_c && in_c && out_c && L.wrm.p && L.wrmc.p) {   // the ResBlocks' 1x1 layers: persistent streaming kernel
+        snprintf(kn, sizeof(kn), "conv1x1_c256<comp>%s", res ? "+res" : "");
+        ProfScope ps(c, name, kn, flops, bytes);
+        launch_conv1x1_c256_c(c->cur_stream, in.as<half_t>(), in_c, Ho * Wo, L.wrm.as<half_t>(), L.wrmc.as<half_t>(), L.scale.as<float>(),
+                              L.shift.as<float>(), relu, res ? res->as<half_t>() : nullptr,
+                              res ? corr_of(*res, (size_t)Ho * Wo, L.cout_pad) : nullptr, out.as<half_t>(), out_c,
+                              c->zero_page.as<half_t>(), L.sbyte);
         return;
     }
     if (!c->opt_generic_c && in_c && out_c && L.cout_pad % 128 == 0 && ((L.ks == 1 && L.stride == 1) || (L.ks == 3 && L.stride == 2 && !res))) {
