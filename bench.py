@@ -14,11 +14,13 @@ Multi-GPU: one process per GPU, images sharded, no collective on the data path
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-`value` is the throughput mode (precision 'f16': descriptors within 3e-3 of the reference, key-point IoU >= 0.95;
-profiles/r02_error_budget.txt shows why no cheaper-than-1.3x mixed mode reaches 1e-3).  The same workload in the
-strict parity mode (precision 'f32': descriptors within 2e-5, key-point list equal up to near-ties) is timed right
-after it and reported as `strict_f32` in the same line, and again with the convolutions on the fp16 matrix path in three
-hi / lo passes (precision 'f16x3', same tolerances) as `strict_f16x3`; tolerances are asserted by tests/, not here.
+`value` is the fastest mode whose tests assert BASELINE.json north_star's tolerance (descriptors within 1e-3 of the fp32
+reference): precision 'f16c', compensated fp16 -- fp16 MFMA operands plus one block-scaled fp8 MFMA per 32 channels that
+adds the two first-order rounding terms (tests/test_gpu_f16c.py asserts 1e-3 at every BASELINE geometry; measured
+<= 3.5e-4).  Other modes of the same workload, same bracket, in the same line: `approx_f16` (plain fp16, descriptors within
+3e-3: OUTSIDE the tolerance, reported for reference only), `strict_f32` (fp32 on the f32-input MFMA: descriptors within
+2e-5, key-point list equal up to near-ties) and `strict_f16x3` (three hi / lo fp16 passes, same tolerances as f32).
+Tolerances are asserted by tests/, not here.
 """
 import argparse
 import ctypes
@@ -186,6 +188,9 @@ def main():
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-f32 leg")
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the extra untimed-by-contract sustained leg (0 = off)")
     ap.add_argument("--lib", default=None, help="kernel A/B runs: another build of libsfd2hip.so (sfd2_amd/build.py build_lib(out=...))")
+    ap.add_argument("--precision", default="f16c", choices=["f16c", "f16"], help="mode of the headline legs (default f16c: the "
+                    "tolerance-conformant throughput mode; f16 = the 3e-3 approximation, for kernel A/Bs of that path)")
+    ap.add_argument("--comp-rb", type=int, default=1, help="f16c option comp_rb (0: ResBlocks on the fused fp16 kernel; descriptors ~7e-4)")
     ap.add_argument("--size", default=None, help="WxH of the synthetic query images (default 1600x1200, the size the metric "
                                                  "is quoted on; e.g. 1024x1024 for BASELINE configs[3])")
     args = ap.parse_args()
@@ -231,7 +236,7 @@ def main():
     use_graphs = not args.no_graphs
     class Lane:   # one context = one HIP stream, its packed weights, workspace and output buffers
         def __init__(self):
-            self.model = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval()
+            self.model = ResSegNetV2(outdim=128, require_stability=True, precision=args.precision).eval()
             self.model.load_state_dict(sd)
             self.model.cuda(local_rank)
             self.ctx = self.model.context
@@ -244,6 +249,8 @@ def main():
             self.n_out = ctypes.c_int(0)
             if use_graphs:
                 self.ctx.set_option("graphs", 1)
+            if args.precision == "f16c" and not args.comp_rb:
+                self.ctx.set_option("comp_rb", 0)
             if args.branches:
                 self.ctx.set_option("branches", 1)
 
@@ -393,16 +400,19 @@ def main():
         barrier()
         dst = max_over_ranks(time.perf_counter() - t0)
         for ln in lanes:
-            ln.ctx.set_precision("f16")
+            ln.ctx.set_precision(args.precision)
+        par = {"f32": "descriptors <= 2e-5, ordered key-point list equal up to near-ties (tests/test_gpu_parity.py::test_strict_*)",
+               "f16x3": "descriptors <= 2e-5, ordered key-point list equal up to near-ties (tests/test_gpu_baseline_configs.py::test_f16x3_*)",
+               "f16": "OUTSIDE north_star's tolerance: descriptors <= 3e-3 (measured 1.8e-3), key-point set IoU >= 0.93 (tests/test_gpu_parity.py)",
+               "f16c": "descriptors <= 1e-3 asserted (measured <= 3.5e-4), key-point set IoU >= 0.985 (tests/test_gpu_f16c.py)"}[mode]
         return {"value": round(n_st * world / dst, 3), "unit": "images/sec", "ms_per_step": round(dst / n_st * 1e3, 3),
-                "steps": n_st, "dtype": mode, "streams_per_gpu": len(lanes),
-                "parity": "descriptors <= 2e-5, ordered key-point list equal up to near-ties "
-                          + ("(tests/test_gpu_parity.py::test_strict_*)" if mode == "f32" else "(tests/test_gpu_baseline_configs.py::test_f16x3_*)")}
+                "steps": n_st, "dtype": mode, "streams_per_gpu": len(lanes), "launch": "eager", "parity": par}
 
-    strict = strict_x3 = None
+    strict = strict_x3 = approx = None
     if not args.no_strict:
         strict = parity_leg("f32")
         strict_x3 = parity_leg("f16x3")
+        approx = parity_leg("f16" if args.precision == "f16c" else "f16c")
 
     if rank == 0:
         # dominant kernel family = largest summed device time
@@ -424,6 +434,13 @@ def main():
                     "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 5), "launches": dom["launches"],
                     "traffic": pmc_traffic(dom_name),
                     "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this command; not re-measured in this run)"}
+            if "comp" in dom_name:
+                # a compensated layer issues, per algorithmic FLOP, one fp16 MFMA FLOP and two fp8 MFMA FLOPs (K = 64 bytes per 32
+                # channels) at twice the fp16 rate: 2x the fp16 layer's matrix time at nominal rates
+                roof["note"] = ("achieved / frac count ALGORITHMIC FLOPs (2 * MAC of the layer) against the fp16 peak; the kernel also issues "
+                                "the fp8 correction MFMAs (one 32x32x64 per two 32x32x16), i.e. 2x the matrix time of the plain fp16 layer at "
+                                "nominal rates: 'frac_of_issued_peak' = frac * 2")
+                roof["frac_of_issued_peak"] = round(2 * achieved / PEAK_TFLOPS_F16, 4)
             if single is not None:
                 roof["measured_in"] = ("single-stream timed leg of this run (same K steps and bracketing, one stream per GPU, eager "
                                        "launches: see 'single_stream').  The headline region replays one hipGraph per image on "
@@ -454,7 +471,7 @@ def main():
             "metric": "images/sec extract" + ("" if args.extract_only else "+match") + f" ({W}x{H}, n4096)",
             "value": round(args.steps * world / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": ("aachen_v1.1 day query, extract-only (BASELINE configs[1])" if args.extract_only else
                                     "aachen_v1.1 query extract + NNM match vs netvlad-50 resident db sets (BASELINE configs[2])"),
                        "image": f"{W}x{H}", "max_keypoints": TOPK, "db_sets_per_query": 0 if args.extract_only else K_DB,
@@ -463,9 +480,16 @@ def main():
                        "launch": "hipGraph replay per image (sfd2_extract_match)" if use_graphs else "eager"},
             "roofline": roof, "kernel_ms_per_step": breakdown, "device_ms_per_step": round(total_ms, 4),
             "mutual_matches_last_step": n_matched,
-            "parity": {"mode": "f16 throughput", "descriptors_max_abs": "<= 3e-3 (measured 1.8e-3)", "keypoint_set_iou": ">= 0.95",
-                       "selection_given_heat_map": "bit-exact", "asserted_in": "tests/test_gpu_parity.py"},
+            "parity": ({"mode": "f16c: compensated fp16 (fp16 MFMA + one block-scaled fp8 MFMA of the rounding residuals per 32 channels, fp32 accumulate)"
+                                + ("" if args.comp_rb else "; option comp_rb = 0 (ResBlocks plain fp16)"),
+                        "descriptors_max_abs": "<= 1e-3 asserted = north_star's tolerance (measured " + ("<= 3.5e-4" if args.comp_rb else "<= 8.1e-4") + " at 480x640 .. 2048x1536)",
+                        "keypoint_set_iou": ">= 0.985 asserted (measured 0.997 - 1.0)" if args.comp_rb else ">= 0.97 asserted (measured 0.991 - 0.996)",
+                        "selection_given_heat_map": "bit-exact", "asserted_in": "tests/test_gpu_f16c.py",
+                        "measured_in": "profiles/r03*_f16c_parity_measured.txt"} if args.precision == "f16c" else
+                       {"mode": "f16 throughput (OUTSIDE north_star's 1e-3)", "descriptors_max_abs": "<= 3e-3 (measured 1.8e-3)", "keypoint_set_iou": ">= 0.93",
+                        "selection_given_heat_map": "bit-exact", "asserted_in": "tests/test_gpu_parity.py"}),
             "single_stream": single, "sustained": sustained, "strict_f32": strict, "strict_f16x3": strict_x3,
+            ("approx_f16" if args.precision == "f16c" else "f16c"): approx,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
