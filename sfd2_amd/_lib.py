@@ -79,9 +79,19 @@ def load():
     if LIB_PATH == os.path.join(_HERE, "libsfd2hip.so"):
         # (re)build when the shared object is missing or older than its sources and a hipcc is at hand; on a box
         # without hipcc the shipped .so is used as it is
+        # One process per GPU means several ranks may get here at once: the build runs under an exclusive
+        # file lock, the loser(s) re-check and find the library up to date; build_lib links to a temporary name and
+        # renames, so a concurrent CDLL never sees a half-written file.
         from . import build as _build
         if _build.needs_build() and _build.have_hipcc():
-            _build.build_lib()
+            import fcntl
+            with open(os.path.join(_HERE, ".build.lock"), "w") as lk:
+                fcntl.flock(lk, fcntl.LOCK_EX)
+                try:
+                    if _build.needs_build():
+                        _build.build_lib()
+                finally:
+                    fcntl.flock(lk, fcntl.LOCK_UN)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing and no hipcc was found to build it "
                            "(hipcc --offload-arch=gfx950; `python -c 'import __graft_entry__ as g; g.build()'`). "

@@ -46,10 +46,14 @@ class BaseModel(metaclass=ABCMeta):
 
 
 def dynamic_load(root, model):
-    module_path = f'{root.__name__}.{model}'
-    module = __import__(module_path, fromlist=[''])
-    classes = inspect.getmembers(module, inspect.isclass)
-    classes = [c for c in classes if c[1].__module__ == module_path]
-    classes = [c for c in classes if issubclass(c[1], BaseModel)]
-    assert len(classes) == 1, classes
-    return classes[0][1]
+    """The plugin lookup of the hloc drivers (hloc/utils/base_model.py:40-49, called from hloc/match_features.py:78):
+    `root` is a package (e.g. sfd2_amd.matchers), `model` the name of one of its modules; the module must define exactly
+    one BaseModel subclass of its own, which is returned."""
+    import importlib
+    name = root.__name__ + "." + model
+    mod = importlib.import_module(name)
+    own = [obj for obj in vars(mod).values()
+           if inspect.isclass(obj) and obj.__module__ == name and issubclass(obj, BaseModel)]
+    if len(own) != 1:
+        raise AssertionError(f"{name} must define exactly one BaseModel subclass, found {[c.__name__ for c in own]}")
+    return own[0]

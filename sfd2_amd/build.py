@@ -62,10 +62,12 @@ def build_lib(force=False, verbose=False, out=None, extra_flags=()):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
     if force or procs or not os.path.exists(lib) or any(_newer(o, lib) for o in objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+        tmp = lib + ".tmp.%d" % os.getpid()
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        os.replace(tmp, lib)   # atomic: a process loading the library meanwhile sees the old or the new file, never a partial one
     return lib
 
 

@@ -106,13 +106,23 @@ def extrat_spp_feats_multiscale(model, img, conf_th=0.0050, scale_f=2 ** 0.25,
     nh = (ctypes.c_int32 * nl)(*[l[0] for l in levels])
     nw = (ctypes.c_int32 * nl)(*[l[1] for l in levels])
     em = (ctypes.c_int32 * nl)(*[int(l[2]) for l in levels])
-    cap = sum(l[0] * l[1] for l in levels if l[2])
-    kp = np.empty((cap, 2), dtype=np.float32)
-    sc = np.empty((cap,), dtype=np.float32)
-    de = np.empty((cap, 128), dtype=np.float32)
-    cnt = (ctypes.c_int32 * nl)()
-    _lib.check(ctx.lib.sfd2_extract_spp_levels(ctx.h, a.ctypes.data, 0, H, W, nl, nh, nw, em, float(conf_th), 0,
-                                               kp.ctypes.data, sc.ctypes.data, de.ctypes.data, cap, cnt))
+    # Output capacity: the greedy grid NMS (extract.py:17-84, dist 4) keeps at most one point per 5 x 5 pixels,
+    # so one slot per 4 x 4 cell of every emitted level always suffices -- 1/16 of the worst case "every pixel" (6.3 M rows,
+    # 3.2 GB of descriptors, for one 1600x1200 pyramid).  The library reports "capacity exceeded" should that ever be wrong;
+    # the call is then repeated once with the worst case.
+    cap = sum(((l[0] + 3) // 4) * ((l[1] + 3) // 4) for l in levels if l[2])
+    for attempt in range(2):
+        kp = np.empty((cap, 2), dtype=np.float32)
+        sc = np.empty((cap,), dtype=np.float32)
+        de = np.empty((cap, 128), dtype=np.float32)
+        cnt = (ctypes.c_int32 * nl)()
+        rc = ctx.lib.sfd2_extract_spp_levels(ctx.h, a.ctypes.data, 0, H, W, nl, nh, nw, em, float(conf_th), 0,
+                                             kp.ctypes.data, sc.ctypes.data, de.ctypes.data, cap, cnt)
+        if rc != 0 and attempt == 0 and b"capacity exceeded" in (ctx.lib.sfd2_last_error() or b""):
+            cap = sum(l[0] * l[1] for l in levels if l[2])
+            continue
+        _lib.check(rc)
+        break
     all_pts, all_descs = [], []
     off = 0
     for (lh, lw, emit), n in zip(levels, cnt):

@@ -29,11 +29,11 @@ def _conf(n, r):
 confs = dict(_conf(n, r) for n, r in ((4096, 1600), (3000, 1600), (2000, 1600), (4096, 1024), (3000, 1024), (2000, 1024)))
 
 
-def get_model(model_name, weight_path=None, use_stability=False, state_dict=None, device=0, precision="f32"):
+def get_model(model_name, weight_path=None, use_stability=False, state_dict=None, device=0, precision="f16x3"):
     """extract_localization.py:208-218.  state_dict may be given directly (numpy / torch dict)
     when the checkpoint is not a file; otherwise weight_path is read with torch.load (the reference's
     {'model': state_dict, ...} checkpoint layout, :213-215).  precision: see ResSegNetV2 -- the drop-in default
-    is the strict parity mode, 'f16' is the explicit throughput switch."""
+    is 'f16x3' (the strict mode's tolerances on the fp16 matrix path), 'f16c' the tolerance-conformant throughput mode, 'f16' an approximation."""
     if model_name != 'ressegnetv2':
         raise NotImplementedError("only 'ressegnetv2' is on the hot path (SURVEY.md section 2 #1)")
     model = ResSegNetV2(outdim=128, require_stability=use_stability, precision=precision).eval()
@@ -148,7 +148,7 @@ def _part_path(export_dir, conf, rank, world):
     return base + '.h5' if world == 1 else f'{base}.part{rank}of{world}.h5'
 
 
-def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precision="f32", world=1, rank=0,
+def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precision="f16x3", world=1, rank=0,
          barrier=None, model_and_extractor=None):
     """extract_localization.py:221-279.  ``images``: an ImageDataset (decoded from files, resized per
     conf['preprocessing']) or any indexable / iterable of {'name', 'image': uint8 [H,W,3] RGB or float [3,H,W] in

@@ -25,9 +25,10 @@ class ResSegNetV2:
     """Drop-in for nets.sfd2.ResSegNetV2 on the inference path (det)."""
 
     def __init__(self, outdim=128, require_feature=False, require_stability=False, ms_detector=True,
-                 precision="f32"):
-        """precision (extension).  'f32' (default) = strict parity mode: fp32 activations on the f32-input MFMA,
-        descriptors within 2e-5 of the reference, key-point list equal up to near-ties.  'f16' = throughput mode
+                 precision="f16x3"):
+        """precision (extension).  Default 'f16x3' (below): the strict tolerances at 1.9x the speed of 'f32'.
+        'f32' = strict parity mode: fp32 activations on the f32-input MFMA,
+        descriptors within 2e-5 of the reference, key-point list equal up to near-ties.  'f16' = approximate mode
         (fp16 MFMA operands, fp16 activation storage): ~6.5x faster, but only an approximation of the reference --
         descriptors within 3e-3 (measured 1.8e-3), key-point set IoU >= 0.95 on the synthetic weights
         (profiles/r02_error_budget.txt); ask for it explicitly.  'f16x3' = the strict mode's buffers and layer sequence with

@@ -313,7 +313,7 @@ def test_uint8_ingest_vs_oracle(model_f32, synth_sd):
 
 
 # ------------------------------------------------------------------ checkpoint files, ConvSta-less state_dicts
-def test_checkpoint_file_roundtrip(tmp_path, synth_sd, model_f32):
+def test_checkpoint_file_roundtrip(tmp_path, synth_sd, model_x3):
     """extract_localization.py:213-215: torch.load(p)['model'] with strict=False.  A checkpoint written with torch.save in
     the reference's layout ({'model': state_dict of tensors incl. num_batches_tracked, 'epoch': ...}) loads through
     get_model(weight_path=...) and yields the state_dict path's outputs bit for bit."""
@@ -323,10 +323,10 @@ def test_checkpoint_file_roundtrip(tmp_path, synth_sd, model_f32):
     p = tmp_path / "20220810_ressegnetv2_synth.pth"
     torch.save(ck, p)
     m, extractor = el.get_model("ressegnetv2", weight_path=str(p), use_stability=True)
-    assert m.precision == "f32"                              # the drop-in default is the parity mode
+    assert m.precision == "f16x3"                            # the drop-in default passes the strict tolerances
     img = synth.make_image(96, 128, 21)
     a = extractor(m, img[None], conf_th=0.001, topK=150, scales=[1.0])
-    b = extractor(model_f32, img[None], conf_th=0.001, topK=150, scales=[1.0])
+    b = extractor(model_x3, img[None], conf_th=0.001, topK=150, scales=[1.0])
     for k in ("keypoints", "scores", "descriptors"):
         np.testing.assert_array_equal(a[k], b[k])
     with pytest.raises(FileNotFoundError):

@@ -1,0 +1,113 @@
+"""The N > 1 code paths, executed on ONE MI355X: no 8-GPU node has been available to any round, so what
+can be run is run here -- bench.py's distributed bracket (NCCL init, barrier, MAX all-reduce) on a world of one, bench.py
+as torch.distributed.run launches it, and the sharded drivers with the REAL extractor and matcher in two processes that
+share the device (rendezvous over gloo: the data path has no collective, extract_localization.py:240,
+hloc/match_features.py:90)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+         "--no-strict", "--sustain", "0"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _one_json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_distributed_bracket_on_one_gpu():
+    """SFD2_BENCH_FORCE_DIST=1: the N > 1 branch of bench.py (init_process_group('nccl'), dist.barrier around the timed
+    region, all_reduce(MAX) of the elapsed time) with WORLD_SIZE = 1."""
+    env = dict(os.environ, SFD2_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(BENCH, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = _one_json_line(r.stdout.decode())
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["dtype"] == "f16c" and "roofline" in d
+
+
+def test_bench_under_torch_distributed_run():
+    """Exactly the driver's launch line for N > 1, with N = 1."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + BENCH[1:]
+    r = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = _one_json_line(r.stdout.decode())
+    assert d["n_gpus"] == 1 and d["value"] > 0
+
+
+def test_bench_refuses_unrequested_world():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run(BENCH, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b"refusing" in r.stderr
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch.distributed as dist
+    from sfd2_amd import extract_localization as el, match_features as mf, synth
+    from sfd2_amd.feature_io import open_store
+    rank, world = int(os.environ["RANK"]), 2
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% os.environ["PORT"], rank=rank, world_size=world)
+    out = os.environ["OUT"]
+    sd = synth.make_state_dict(0)
+    images = [{"name": "db/img%%02d.jpg" %% i, "image": synth.make_image(96, 128, 40 + i), "original_size": (128, 96)} for i in range(5)]
+    conf = dict(el.confs["ressegnetv2-20220810-wapv2-sd2mfsf-uspg-0001-n4096-r1600"])
+    conf["model"] = dict(conf["model"], max_keypoints=150)
+    # the real HIP extractor: each process creates its own context (one per process, as on N GPUs) on device 0
+    path = el.main(conf, images, out, state_dict=sd, precision="f16c", world=world, rank=rank, barrier=dist.barrier)
+    dist.barrier()
+    pairs = ["db/img00.jpg db/img01.jpg", "db/img02.jpg db/img03.jpg", "db/img04.jpg db/img00.jpg", "db/img01.jpg db/img00.jpg"]
+    mpath = mf.main(mf.confs["NNM"], pairs, conf["output"], out, world=world, rank=rank, barrier=dist.barrier)
+    dist.barrier()
+    if rank == 0:
+        solo = os.path.join(out, "solo")
+        p1 = el.main(conf, images, solo, state_dict=sd, precision="f16c")
+        m1 = mf.main(mf.confs["NNM"], pairs, conf["output"], solo)
+        for got, want in ((path, p1), (mpath, m1)):
+            a, b = open_store(got, "r"), open_store(want, "r")
+            assert list(a.keys()) == list(b.keys()) and len(list(a.keys())) > 0
+            for k in a.keys():
+                for ds in b[k].keys():
+                    x, y = np.asarray(a[k][ds].__array__()), np.asarray(b[k][ds].__array__())
+                    assert x.dtype == y.dtype and np.array_equal(x, y), (k, ds)   # same kernels, same inputs: bit-identical
+        assert len(list(open_store(mpath, "r").keys())) == 3
+        print("GPU_DRIVERS_OK")
+    dist.barrier()
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def test_sharded_drivers_two_processes_one_device(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=str(port), OUT=str(tmp_path / "out"))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GPU_DRIVERS_OK" in outs[0]
