@@ -391,23 +391,27 @@ void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normali
 }
 
 // ---------------------------------------------------------------------------------------------
-// ResBlock.conv2 (3x3, 256 -> 256, groups = 32), compensated.  Same 16x16x32 block-diagonal formulation as
-// gconv3x3_g8_kernel; the patch is register-staged, and while a 16-byte piece of the corr plane (8 channels x 2 bytes)
-// passes through the registers its residual bytes become eight fp16 `lo` values, so the three passes
-// wh xh + wl xh + wh xl all run on the fp16 instruction (the layer is 4 GFLOP: the passes are free, the tensor
-// traffic is what it costs).
+// ResBlock.conv2 (3x3, 256 -> 256, groups = 32), compensated.  Same 16x16 block-diagonal formulation as
+// gconv3x3_g8_kernel for the hi plane (two groups = one 16-channel pair per MFMA row block, K step = 2 taps x 16 input
+// channels on v_mfma_f32_16x16x32_f16, 5 steps); the corr plane goes to v_mfma_scale_f32_16x16x128_f8f6f4: a lane's 32
+// bytes are the 16 corr units of the pair at ONE tap (contiguous in the pixel's record), the four lane groups are four
+// taps, so 3 steps cover the 9 taps (12 slots, the last three with zero filters).  No conversion anywhere: both planes are
+// staged as they are.  The layer moves 246 MB for 4 GFLOP: what it costs is the traffic.
 #define GCP 72
 #define GC_PH 6
 #define GC_PW 34
+typedef float f32x4c_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(CNT, 2)   // two blocks (59 KB of LDS each) per CU
 void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in_c, int H, int W,
-                    const half_t *__restrict__ wpk /*[2 hi/lo][16][5][64][8]*/, const float *__restrict__ scale,
-                    const float *__restrict__ shift, half_t *__restrict__ out, half_t *__restrict__ out_c, int tiles_x)
+                    const half_t *__restrict__ wpk /*[16 pairs][5 steps][64 lanes][8] fp16*/,
+                    const unsigned char *__restrict__ wck /*[16 pairs][3 steps][64 lanes][32 B] corr units*/,
+                    const float *__restrict__ scale, const float *__restrict__ shift, half_t *__restrict__ out,
+                    half_t *__restrict__ out_c, int tiles_x, int sa)
 {
     constexpr int NPIX = GC_PH * GC_PW;
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     half_t *Xh = reinterpret_cast<half_t *>(gsm);      // [NPIX][GCP]
-    half_t *Xl = Xh + NPIX * GCP;
+    half_t *Xc = Xh + NPIX * GCP;                      // corr units, same records
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int swz = xcd_swizzle_c(blockIdx.x, gridDim.x);
     const int tx = swz % tiles_x, ty = swz / tiles_x;
@@ -438,29 +442,26 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
             const int p = tid + k * CNT;
             if (p < NPIX * 8) {
                 *reinterpret_cast<uint4 *>(Xh + (p >> 3) * GCP + (p & 7) * 8) = pre[k];
-                const unsigned d[4] = {prc[k].x, prc[k].y, prc[k].z, prc[k].w};
-                h8_t lo;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    lo[2 * j] = (half_t)sfd2_corr_lo(d[j], 0);
-                    lo[2 * j + 1] = (half_t)sfd2_corr_lo(d[j], 1);
-                }
-                *reinterpret_cast<h8_t *>(Xl + (p >> 3) * GCP + (p & 7) * 8) = lo;
+                *reinterpret_cast<uint4 *>(Xc + (p >> 3) * GCP + (p & 7) * 8) = prc[k];
             }
         }
         const int pair = chunk * 4 + wave;
-        h8_t wh[5], wl[5];
+        h8_t wh[5];
+        v8i_t wc8[3];
 #pragma unroll
-        for (int s = 0; s < 5; ++s) {
+        for (int s = 0; s < 5; ++s)
             wh[s] = *reinterpret_cast<const h8_t *>(wpk + ((size_t)(pair * 5 + s) * 64 + lane) * 8);
-            wl[s] = *reinterpret_cast<const h8_t *>(wpk + ((size_t)((16 + pair) * 5 + s) * 64 + lane) * 8);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const unsigned char *p = wck + ((size_t)(pair * 3 + m) * 64 + lane) * 32;
+            wc8[m] = sfd2_cat8(*reinterpret_cast<const h8_t *>(p), *reinterpret_cast<const h8_t *>(p + 16));
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (chunk + 1 < 4) { GC_FETCH(chunk + 1) }
 
-        f32x4_t acc[8];
+        f32x4c_t acc[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int t = 0; t < 8; ++t) acc[t] = (f32x4c_t){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
             int tap = 2 * s + (g >> 1);
@@ -470,38 +471,62 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
             for (int t = 0; t < 8; ++t) {
                 const int q = ((t >> 1) + ky) * GC_PW + (t & 1) * 16 + lcol + kx;
                 const h8_t bh = *reinterpret_cast<const h8_t *>(Xh + q * GCP + wave * 16 + (g & 1) * 8);
-                const h8_t bl = *reinterpret_cast<const h8_t *>(Xl + q * GCP + wave * 16 + (g & 1) * 8);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bl, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bh, acc[t], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            int tap = 4 * m + g;
+            if (tap > 8) tap = 8;
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int q = ((t >> 1) + ky) * GC_PW + (t & 1) * 16 + lcol + kx;
+                const half_t *bp = Xc + q * GCP + wave * 16;
+                const v8i_t bc = sfd2_cat8(*reinterpret_cast<const h8_t *>(bp), *reinterpret_cast<const h8_t *>(bp + 8));
+                acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wc8[m], bc, acc[t], 0, 0, 0, sa, 0, 0x7f7f7f7f);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(acc[t]));   // (scaled MFMAs are pure nodes: keep them in front of the barrier)
         const int c0 = pair * 16 + g * 4;
         const float4 sc = *reinterpret_cast<const float4 *>(scale + c0);
         const float4 sh = *reinterpret_cast<const float4 *>(shift + c0);
+        // lane groups g and g^1 (16 lanes apart) hold adjacent 8-byte channel runs of the same pixel: exchange across two
+        // pixel tiles so that every lane issues one 16-byte store per tile pair and plane
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int oy = oy0 + (t >> 1), ox = ox0 + (t & 1) * 16 + lcol;
-            uint2 hv, cv;
-            sfd2_split4(fmaxf(acc[t][0] * sc.x + sh.x, 0.0f), fmaxf(acc[t][1] * sc.y + sh.y, 0.0f),
-                        fmaxf(acc[t][2] * sc.z + sh.z, 0.0f), fmaxf(acc[t][3] * sc.w + sh.w, 0.0f), hv, cv);
+        for (int t = 0; t < 8; t += 2) {
+            uint2 pk[2], ck[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                sfd2_split4(fmaxf(acc[t + j][0] * sc.x + sh.x, 0.0f), fmaxf(acc[t + j][1] * sc.y + sh.y, 0.0f),
+                            fmaxf(acc[t + j][2] * sc.z + sh.z, 0.0f), fmaxf(acc[t + j][3] * sc.w + sh.w, 0.0f), pk[j], ck[j]);
+            const bool odd = g & 1;
+            const uint2 send = odd ? pk[0] : pk[1], sendc = odd ? ck[0] : ck[1];
+            uint2 recv, recvc;
+            recv.x = __shfl_xor(send.x, 16); recv.y = __shfl_xor(send.y, 16);
+            recvc.x = __shfl_xor(sendc.x, 16); recvc.y = __shfl_xor(sendc.y, 16);
+            const int tt = odd ? t + 1 : t;                         // the tile this lane stores
+            const int oy = oy0 + (tt >> 1), ox = ox0 + (tt & 1) * 16 + lcol;
+            const uint4 v = odd ? make_uint4(recv.x, recv.y, pk[1].x, pk[1].y) : make_uint4(pk[0].x, pk[0].y, recv.x, recv.y);
+            const uint4 vc = odd ? make_uint4(recvc.x, recvc.y, ck[1].x, ck[1].y) : make_uint4(ck[0].x, ck[0].y, recvc.x, recvc.y);
             if (oy < H && ox < W) {
-                const size_t o = ((size_t)oy * W + ox) * 256 + c0;
-                *reinterpret_cast<uint2 *>(out + o) = hv;
-                *reinterpret_cast<uint2 *>(out_c + o) = cv;
+                const size_t o = ((size_t)oy * W + ox) * 256 + pair * 16 + (g & ~1) * 4;
+                *reinterpret_cast<uint4 *>(out + o) = v;
+                *reinterpret_cast<uint4 *>(out_c + o) = vc;
             }
         }
     }
 #undef GC_FETCH
 }
 
-void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk, const float *scale,
-                    const float *shift, half_t *out, half_t *out_c)
+void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk, const void *wck,
+                    const float *scale, const float *shift, half_t *out, half_t *out_c, int sbyte)
 {
     constexpr size_t lds = (size_t)2 * GC_PH * GC_PW * GCP * sizeof(half_t);
     const int tiles_x = (W + CTW - 1) / CTW, tiles_y = (H + CTH - 1) / CTH;
-    hipLaunchKernelGGL(gconv_c_kernel, dim3(tiles_x * tiles_y), dim3(CNT), lds, st, in, in_c, H, W, wpk, scale, shift, out,
-                       out_c, tiles_x);
+    hipLaunchKernelGGL(gconv_c_kernel, dim3(tiles_x * tiles_y), dim3(CNT), lds, st, in, in_c, H, W, wpk,
+                       reinterpret_cast<const unsigned char *>(wck), scale, shift, out, out_c, tiles_x, (sbyte & 255) * 0x01010101);
 }
 
 // hi + corr planes -> NCHW fp32 (sfd2_debug_activation): hi + the residual the corr unit carries

@@ -30,12 +30,23 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 #define MQ_MAX_CHUNK (32 << MQ_TILE_BITS)   // candidates per split: the tile id must fit MQ_TILE_BITS
 
 __global__ __launch_bounds__(NT, 2)
-void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const half_t *__restrict__ zero_page)
+void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qblocks, const half_t *__restrict__ zero_page)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][TA2][256 B]; at the end [4][64][32] floats
-    const MatchJob2 job = jobs[blockIdx.z];
+    // XCD-aware work order.  Blocks are dealt round-robin to the 8 XCDs (each with its own L2); with the natural order the
+    // query strips that share one candidate chunk (x fastest) land on all eight of them and the chunk is fetched into eight
+    // L2s: 424 MB of HBM-side reads per 50 x 4096^2 against 52 MB of database sets (profiles/r02_match_pmc.txt).  Here every
+    // XCD gets one contiguous run of the (pair, split, strip) list, so the strips of a chunk run back to back on one L2.
+    int swz;
+    {
+        const int bid = (int)blockIdx.x, nblk = (int)gridDim.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int bx = swz % qblocks, by = (swz / qblocks) % splits, bz = swz / (qblocks * splits);
+    const MatchJob2 job = jobs[bz];
     const int n1 = job.n1, n0 = job.n0;          // candidates, queries
-    const int i_base = blockIdx.x * 256;
+    const int i_base = bx * 256;
     if (i_base >= n0) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -43,7 +54,7 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const h
 
     int chunk = (n1 + splits - 1) / splits;
     chunk = (chunk + 31) & ~31;
-    const int ja0 = blockIdx.y * chunk;
+    const int ja0 = by * chunk;
     int ja1 = ja0 + chunk;
     if (ja1 > n1) ja1 = n1;
 
@@ -76,7 +87,7 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const h
     const unsigned int cb[2] = {0x20u | ((1u - (unsigned)lhi) << 4), (1u - (unsigned)lhi) << 4};
     // this wave's row of the reverse partials as a buffer resource covering candidates [0, ja1)
     const __amdgpu_buffer_rsrc_t rk_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        job.rkeys + (size_t)(blockIdx.x * 4 + wave) * n1, 0, ja1 * 4, 0x00020000);
+        job.rkeys + (size_t)(bx * 4 + wave) * n1, 0, ja1 * 4, 0x00020000);
     // the mask lives in a VGPR so that (x & keep) | code is ONE v_and_or_b32 (VOP3 on gfx950 takes no literal, and the
     // tile code is already the one scalar operand)
     unsigned int keep = ~((1u << MQ_TILE_BITS) - 1u);
@@ -190,7 +201,7 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, const h
         }
         const unsigned int bits = __float_as_uint(best);
         const int tile = (1 << MQ_TILE_BITS) - 1 - (int)(bits & ((1u << MQ_TILE_BITS) - 1u));
-        const size_t o = (size_t)blockIdx.y * n0 + q0 + lane;
+        const size_t o = (size_t)by * n0 + q0 + lane;
         const bool any = best > MQ_NEG;
         job.part_v1[o] = any ? __uint_as_float(bits & ~((1u << MQ_TILE_BITS) - 1u)) : -INFINITY;
         job.part_i1[o] = any ? ja0 + tile * 32 + col : 0;
@@ -209,7 +220,8 @@ void launch_match_mutual_gemm(hipStream_t st, const MatchJob2 *jobs_dev, int npa
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_mutual_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL(match_mutual_kernel, dim3((max_n0 + 255) / 256, splits, npairs), dim3(NT), lds, st, jobs_dev, splits, zero_page);
+    const int qblocks = (max_n0 + 255) / 256;
+    hipLaunchKernelGGL(match_mutual_kernel, dim3(qblocks * splits * npairs), dim3(NT), lds, st, jobs_dev, splits, qblocks, zero_page);
 }
 
 int match_mutual_max_chunk(void) { return MQ_MAX_CHUNK; }

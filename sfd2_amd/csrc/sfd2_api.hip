@@ -471,22 +471,24 @@ static int pack_gconv(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
             for (int j = 0; j < 8; ++j)
                 cp[((size_t)oc * 9 + tap) * 8 + j] = (half_t)w->d[(((size_t)oc * 8 + j) * 3 + tap / 3) * 3 + tap % 3];
     if (upload(L.wgc, cp.data(), cp.size() * sizeof(half_t), c->stream)) return -1;
-    {   // SFD2_PREC_F16C: hi fragments (= pk) then lo fragments
-        std::vector<half_t> pc(2 * pk.size(), (half_t)0.0f);
+    {   // SFD2_PREC_F16C: corr fragments of v_mfma_scale_f32_16x16x128_f8f6f4 (gconv_c_kernel): [pair][step m][lane][32 B] --
+        // lane -> out channel (lane & 15) of the pair, tap 4 * m + (lane >> 4); its 32 bytes = the 16 input channels of the
+        // pair x (fp8 of w * 2^b0, fp8 of (w - fp16(w)) * 2^(b0 + 11)), zero outside the channel's own group
+        const int b0 = corr_b0(w->d, w->numel());
+        L.sbyte = 127 - SFD2_C_XL_SHIFT - b0;
+        std::vector<unsigned short> pc((size_t)16 * 3 * 64 * 16, 0);
         for (int pair = 0; pair < 16; ++pair)
-            for (int s2 = 0; s2 < 5; ++s2)
+            for (int mm = 0; mm < 3; ++mm)
                 for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int i = lane & 15, g = lane >> 4;
-                        const int tap = 2 * s2 + (g >> 1);
+                    for (int ch = 0; ch < 16; ++ch) {
+                        const int i = lane & 15, tap = 4 * mm + (lane >> 4);
                         const int oc = pair * 16 + i;
-                        float v = 0.0f;
-                        if (tap <= 8 && (i >> 3) == (g & 1)) v = w->d[(((size_t)oc * 8 + j) * 3 + tap / 3) * 3 + tap % 3];
-                        const size_t o = (((size_t)pair * 5 + s2) * 64 + lane) * 8 + j;
-                        pc[o] = (half_t)v;
-                        pc[pk.size() + o] = (half_t)(v - (float)pc[o]);
+                        if (tap > 8 || (i >> 3) != (ch >> 3)) continue;
+                        const float v = w->d[(((size_t)oc * 8 + (ch & 7)) * 3 + tap / 3) * 3 + tap % 3];
+                        pc[(((size_t)pair * 3 + mm) * 64 + lane) * 16 + ch] =
+                            (unsigned short)(f32_to_e4m3(std::ldexp(v, b0)) | (f32_to_e4m3(std::ldexp(v - (float)(half_t)v, b0 + 11)) << 8));
                     }
-        if (upload(L.wc, pc.data(), pc.size() * sizeof(half_t), c->stream)) return -1;
+        if (upload(L.wc, pc.data(), pc.size() * 2, c->stream)) return -1;
     }
     return 0;
 }
@@ -1016,9 +1018,9 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
             convc(c, nm1[b], c->rb1[b], *x, H4, W4, t1, H4, W4, 1, true, true);
             {
                 ProfScope ps(c, nm2[b], "gconv_c_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 8);
-                launch_gconv_c(st, t1.as<half_t>(), corr_of(t1, (size_t)H4 * W4, 256), H4, W4, c->rb2[b].wc.as<half_t>(),
-                               c->rb2[b].scale.as<float>(), c->rb2[b].shift.as<float>(), t2.as<half_t>(),
-                               corr_of(t2, (size_t)H4 * W4, 256));
+                launch_gconv_c(st, t1.as<half_t>(), corr_of(t1, (size_t)H4 * W4, 256), H4, W4, c->rb2[b].w.as<half_t>(),
+                               c->rb2[b].wc.p, c->rb2[b].scale.as<float>(), c->rb2[b].shift.as<float>(), t2.as<half_t>(),
+                               corr_of(t2, (size_t)H4 * W4, 256), c->rb2[b].sbyte);
             }
             convc(c, nm3[b], c->rb3[b], t2, H4, W4, ob, H4, W4, 1, true, true, x);
             x = &ob;
