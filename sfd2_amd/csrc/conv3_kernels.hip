@@ -179,6 +179,7 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         const bool more_x = c + 1 < NCT; \
         constexpr bool f8 = (F8_) != 0; /* block-uniform */ \
         h8_t fr[2][6]; /* KXM: the stage's six patch rows */ \
+        v8i_t frc[6]; \
 _Pragma("unroll") \
         for (int t9 = 0; t9 < 9; ++t9) { \
 /* u3 = unit within the stage (the stage's last unit carries the waits), sg = stage within the chunk */ \
@@ -188,7 +189,6 @@ _Pragma("unroll") \
             const unsigned char *fs = Fs + (st & 1) * PP_FBYTES + u3 * (PP_BN * 64); \
 /* ---------------- LOAD section */ \
             h8_t fa[2][2], fb[2][4]; \
-            v8i_t frc[4]; \
             if (ABL & 2) { /* timing ablation: no fragment reads */ \
 _Pragma("unroll") \
                 for (int kk = 0; kk < 2; ++kk) { \
@@ -200,13 +200,13 @@ _Pragma("unroll") \
             } \
             int qv = qb; \
             asm volatile("" : "+v"(qv)); /* recompute the 8 patch addresses per unit (hoisted out of the loop they are 72 registers) */ \
-            if (f8) { /* corr chunk: four 8-dword pixel fragments per unit (K slices 0 and 1 adjacent), not carried across units */ \
+            if (f8) { /* corr chunk: 8-dword pixel fragments (K slices 0 and 1 adjacent), the stage's six patch rows as in the fp16 loop */ \
 _Pragma("unroll") \
-                for (int pr = 0; pr < 4; ++pr) { \
-                    const int q = qv + (pr + ky) * PP_PW + kx; \
+                for (int j = (u3 == 0 ? 0 : 3 + u3); j < 4 + u3; ++j) { \
+                    const int q = qv + j * PP_PW + kx; \
                     const int sw = (q >> 2) & 3; \
-                    frc[pr] = sfd2_cat8(*reinterpret_cast<const h8_t *>(xs + q * 64 + (((0 * 2 + lhi) ^ sw) << 4)), \
-                                        *reinterpret_cast<const h8_t *>(xs + q * 64 + (((1 * 2 + lhi) ^ sw) << 4))); \
+                    frc[j] = sfd2_cat8(*reinterpret_cast<const h8_t *>(xs + q * 64 + (((0 * 2 + lhi) ^ sw) << 4)), \
+                                       *reinterpret_cast<const h8_t *>(xs + q * 64 + (((1 * 2 + lhi) ^ sw) << 4))); \
                 } \
             } else if (KXM && !(ABL & 2)) { \
 _Pragma("unroll") \
@@ -260,7 +260,7 @@ _Pragma("unroll") \
                 for (int ct = 0; ct < 2; ++ct) \
 _Pragma("unroll") \
                     for (int pr = 0; pr < 4; ++pr) \
-                        acc[ct][pr] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fac[ct], frc[pr], acc[ct][pr], 0, 0, 0, sa, 0, 0x7f7f7f7f); \
+                        acc[ct][pr] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fac[ct], frc[pr + u3], acc[ct][pr], 0, 0, 0, sa, 0, 0x7f7f7f7f); \
                 /* the scaled MFMA is a pure node to instruction selection, which otherwise sinks all 72 of a chunk below its last \
                    barrier (every fragment of nine units live at once); an empty asm on the accumulators keeps each unit's in its section */ \
 _Pragma("unroll") \

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 WORKER = r'''
-import sys, ctypes, time, json
+import sys, ctypes, time, json, os
 sys.path.insert(0, %r)
 from sfd2_amd import _lib
 lib_path = sys.argv[1]
@@ -19,7 +19,7 @@ if lib_path != "default":
 import torch
 from sfd2_amd import synth
 from sfd2_amd.model import ResSegNetV2
-m = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval(); m.load_state_dict(synth.make_state_dict(0)); m.cuda(0)
+m = ResSegNetV2(outdim=128, require_stability=True, precision=os.environ.get("SFD2_AB_PREC", "f16c")).eval(); m.load_state_dict(synth.make_state_dict(0)); m.cuda(0)
 ctx = m.context; lib = ctx.lib
 H, W, K = 1200, 1600, 4096
 imgs = [torch.from_numpy(synth.make_image(H, W, 100 + i)).cuda() for i in range(4)]
