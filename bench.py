@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--precision", default="f16c", choices=["f16c", "f16"], help="mode of the headline legs (default f16c: the "
                     "tolerance-conformant throughput mode; f16 = the 3e-3 approximation, for kernel A/Bs of that path)")
     ap.add_argument("--comp-rb", type=int, default=1, help="f16c option comp_rb (0: ResBlocks on the fused fp16 kernel; descriptors ~7e-4)")
+    ap.add_argument("--mix", action="store_true", help="every fifth query image in portrait orientation (SURVEY C2: the Aachen query set "
+                    "is ~80 %% landscape / 20 %% portrait); the hipGraph cache then holds two geometries per stream")
     ap.add_argument("--size", default=None, help="WxH of the synthetic query images (default 1600x1200, the size the metric "
                                                  "is quoted on; e.g. 1024x1024 for BASELINE configs[3])")
     args = ap.parse_args()
@@ -223,8 +225,9 @@ def main():
 
     sd = synth.make_state_dict(0)
     # ---- resident inputs: a few distinct query images per rank + K database descriptor sets (fp16)
-    n_img = 4
-    imgs = [torch.from_numpy(synth.make_image(H, W, 100 + rank * n_img + i)).to(dev) for i in range(n_img)]
+    n_img = 5 if args.mix else 4
+    geo = [(W, H) if (args.mix and i == 4) else (H, W) for i in range(n_img)]          # (rows, cols) of image i
+    imgs = [torch.from_numpy(synth.make_image(geo[i][0], geo[i][1], 100 + rank * n_img + i)).to(dev) for i in range(n_img)]
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     db = []
     for _ in range(K_DB):
@@ -263,11 +266,11 @@ def main():
     def step(i, only=None, eager=False):
         ln = lanes[i % len(lanes)] if only is None else only
         if use_graphs and not eager:
-            _lib.check(lib.sfd2_extract_match(ln.ctx.h, imgs[i % n_img].data_ptr(), H, W, 0.001, TOPK, 0, ln.kpts.data_ptr(),
+            _lib.check(lib.sfd2_extract_match(ln.ctx.h, imgs[i % n_img].data_ptr(), geo[i % n_img][0], geo[i % n_img][1], 0.001, TOPK, 0, ln.kpts.data_ptr(),
                                               ln.scores.data_ptr(), ln.desc.data_ptr(), dbs, 0 if args.extract_only else K_DB, 128,
                                               ctypes.byref(mconf), ln.matches.data_ptr(), ln.mscores.data_ptr()))
             return
-        _lib.check(lib.sfd2_extract(ln.ctx.h, imgs[i % n_img].data_ptr(), 1, H, W, 0.001, TOPK, _lib.FLAG_ASYNC,
+        _lib.check(lib.sfd2_extract(ln.ctx.h, imgs[i % n_img].data_ptr(), 1, geo[i % n_img][0], geo[i % n_img][1], 0.001, TOPK, _lib.FLAG_ASYNC,
                                     ln.kpts.data_ptr(), ln.scores.data_ptr(), ln.desc.data_ptr(), 1, TOPK, ctypes.byref(ln.n_out)))
         if not args.extract_only:
             _lib.check(lib.sfd2_match_batch(ln.ctx.h, ctypes.byref(ln.q), dbs, K_DB, 128, ctypes.byref(mconf),
@@ -384,7 +387,7 @@ def main():
 
         def sstep(i):
             sl = lanes[i % len(lanes)]
-            _lib.check(lib.sfd2_extract(sl.ctx.h, imgs[i % n_img].data_ptr(), 1, H, W, 0.001, TOPK, _lib.FLAG_ASYNC,
+            _lib.check(lib.sfd2_extract(sl.ctx.h, imgs[i % n_img].data_ptr(), 1, geo[i % n_img][0], geo[i % n_img][1], 0.001, TOPK, _lib.FLAG_ASYNC,
                                         sl.kpts.data_ptr(), sl.scores.data_ptr(), sl.desc.data_ptr(), 1, TOPK, ctypes.byref(sl.n_out)))
             if not args.extract_only:
                 _lib.check(lib.sfd2_match_batch(sl.ctx.h, ctypes.byref(sl.q), dbs, K_DB, 128, ctypes.byref(mconf),
@@ -474,7 +477,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": ("aachen_v1.1 day query, extract-only (BASELINE configs[1])" if args.extract_only else
                                     "aachen_v1.1 query extract + NNM match vs netvlad-50 resident db sets (BASELINE configs[2])"),
-                       "image": f"{W}x{H}", "max_keypoints": TOPK, "db_sets_per_query": 0 if args.extract_only else K_DB,
+                       "image": f"{W}x{H}" + (" (every fifth image portrait)" if args.mix else ""), "max_keypoints": TOPK, "db_sets_per_query": 0 if args.extract_only else K_DB,
                        "db_keypoints": N_DB, "weights": "synthetic seeded ResSegNetV2 (checkpoint not shipped)",
                        "parallelism": f"images sharded over {world} GPU(s), no collective", "streams_per_gpu": len(lanes),
                        "launch": "hipGraph replay per image (sfd2_extract_match)" if use_graphs else "eager"},

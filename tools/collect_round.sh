@@ -1,22 +1,30 @@
 #!/bin/bash
 # Collects one round's evidence on the GPU box into gpurun_out/$1/ (run through gpurun from the repository root):
-#   GPU test suite, default bench line (+ CPU baseline), extract-only / hipGraph / other-size lines, per-layer table,
+#   GPU test suite, smoke, race screen, default bench line (+ CPU baseline), the other bench legs, per-layer tables,
 #   rocprofv3 kernel stats of the bench command, PMC passes (FETCH_SIZE, WRITE_SIZE, SQ busy) of the same command.
 tag=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd $R
+rm -f gpurun_out/f16c_parity_measured.txt gpurun_out/strict_parity_measured.txt
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/pytest_gpu.txt
+cp gpurun_out/f16c_parity_measured.txt $out/f16c_parity_measured.txt 2>/dev/null
+cp gpurun_out/strict_parity_measured.txt $out/strict_parity_measured.txt 2>/dev/null
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.txt 2>&1
-python tools/determinism_check.py 2000 > $out/determinism.txt 2>&1
-python bench.py --steps 20 --warmup 5 --dump-layers > $out/bench.json 2> $out/layer_table.txt
-python bench.py --steps 20 --warmup 5 --extract-only --no-cpu-baseline > $out/bench_extract_only.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 --no-graphs --no-cpu-baseline --no-strict > $out/bench_eager.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 --streams 1 --no-cpu-baseline --no-strict > $out/bench_streams1.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 --size 1024x1024 --no-cpu-baseline > $out/bench_1024x1024.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 --size 1024x768 --no-cpu-baseline > $out/bench_1024x768.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 --size 640x480 --no-cpu-baseline --dump-layers > $out/bench_640x480.json 2> $out/layer_table_640x480.txt
+python tools/determinism_check.py 1500 f16c > $out/determinism.txt 2>&1
+python tools/determinism_check.py 500 f16 >> $out/determinism.txt 2>&1
+python bench.py > $out/bench.json 2> $out/bench.err
+python bench.py --steps 20 --warmup 5 --streams 1 --no-graphs --no-cpu-baseline --no-strict --dump-layers > $out/bench_streams1_eager.json 2> $out/layer_table.txt
+python bench.py --extract-only --no-cpu-baseline --no-strict > $out/bench_extract_only.json 2>/dev/null
+python bench.py --no-graphs --no-cpu-baseline --no-strict > $out/bench_eager.json 2>/dev/null
+python bench.py --comp-rb 0 --no-cpu-baseline --no-strict > $out/bench_comp_rb0.json 2>/dev/null
+python bench.py --precision f16 --no-cpu-baseline --no-strict > $out/bench_f16.json 2>/dev/null
+python bench.py --mix --no-cpu-baseline --no-strict > $out/bench_mix.json 2>/dev/null
+python bench.py --size 1024x1024 --no-cpu-baseline --no-strict > $out/bench_1024x1024.json 2>/dev/null
+python bench.py --size 1024x768 --no-cpu-baseline --no-strict > $out/bench_1024x768.json 2>/dev/null
+python bench.py --size 640x480 --no-cpu-baseline --no-strict --steps 20 --warmup 5 --streams 1 --no-graphs --dump-layers > $out/bench_640x480_streams1.json 2> $out/layer_table_640x480.txt
+python tools/strict_layers.py f16x3 > $out/strict_layers_f16x3.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strict --sustain 0"
 rocprofv3 --kernel-trace --stats -d $out/prof -o $tag -- $B > $out/prof_bench.json 2> $out/prof.err
@@ -30,5 +38,6 @@ rocprofv3 --pmc FETCH_SIZE -d $out/pmc1 -o x --output-format csv -- $S > /dev/nu
 rocprofv3 --pmc WRITE_SIZE -d $out/pmc2 -o x --output-format csv -- $S > /dev/null 2> $out/pmc2.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $out/pmc3 -o x --output-format csv -- $S > /dev/null 2> $out/pmc3.err
 python $R/tools/pmc_summary.py $out/pmc1 $out/pmc2 $out/pmc3 > $out/pmc_summary.txt 2> $out/pmc_summary.err
-rm -rf $out/prof/*/*.db $out/prof/*.db   # the database is large; the summary is what gets committed
+python $R/tools/pmc_to_json.py $tag $out/pmc_summary.txt > $out/pmc_traffic.json 2>> $out/pmc_summary.err
+rm -rf $out/prof/*/*.db $out/prof/*.db $out/pmc1 $out/pmc2 $out/pmc3   # the databases / raw CSVs are large; the summaries are what gets committed
 ls $out

@@ -11,12 +11,13 @@ from sfd2_amd import _lib, synth
 from sfd2_amd.model import ResSegNetV2
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+PREC = sys.argv[2] if len(sys.argv) > 2 else "f16c"      # python tools/determinism_check.py 1000 [f16c | f16 | f16x3 | f32]
 dev = torch.device("cuda", 0)
 sd = synth.make_state_dict(0)
 
 
 def lane(seed, H, W, K, KDB):
-    m = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval()
+    m = ResSegNetV2(outdim=128, require_stability=True, precision=PREC).eval()
     m.load_state_dict(sd)
     m.cuda(0)
     img = torch.from_numpy(synth.make_image(H, W, seed)).to(dev)
@@ -55,7 +56,7 @@ for (H, W, K, KDB) in [(1200, 1600, 4096, 8), (1024, 1024, 4096, 4), (477, 635, 
             if any(not torch.equal(out[k], ref[k]) for k in ref):
                 diffs += 1
         ctx2.sync()
-        print(f"{W}x{H} top-{K}, {KDB} db sets, {N} runs {phase}: {diffs} differing")
+        print(f"[{PREC}] {W}x{H} top-{K}, {KDB} db sets, {N} runs {phase}: {diffs} differing")
         bad += diffs
 print("DETERMINISTIC" if bad == 0 else f"NON-DETERMINISTIC: {bad}")
 sys.exit(1 if bad else 0)
