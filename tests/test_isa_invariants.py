@@ -92,7 +92,7 @@ def test_conv3x3_pp_loop_has_only_its_own_drains(asm):
             runs = 1 + sum(1 for a, b in zip(idx, idx[1:]) if any("s_barrier" in l for l in span[a:b]))
             assert runs == 9, (name, runs)
             assert _count(span, r"s_waitcnt.*vmcnt\(0\)") == 11, name
-            assert _count(span, r"ds_read_b128") == 60 + 108           # + 12 fragment reads per fp8 unit (no row reuse there)
+            assert _count(span, r"ds_read_b128") in (60 + 60, 60 + 72)   # the fp8 loop reads like the fp16 loop (row reuse; its first unit's LOAD section lies inside the span)
             continue
         assert _count(span, r"v_mfma_f32_32x32x16_f16") == 144          # 9 units x 16
         # (the span runs from the first to the last MFMA of the unrolled chunk body: the first unit's LOAD section and the
