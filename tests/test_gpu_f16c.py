@@ -204,3 +204,93 @@ def test_f16c_fp16_resblocks_extract_vs_oracle(model_c_rb16, synth_sd, h, w, see
     got = extract_resnet_return(model_c_rb16, torch.from_numpy(img)[None].cuda(), conf_th=0.001, topK=topk, scales=[1.0])
     iou, dd, shift, same, n = _compare(got, want, 0.97)
     _record(f"f16c comp_rb=0 extract {w}x{h} top{topk}: IoU {iou:.4f}, desc {dd:.2e}, same rank {same}/{n}, max rank shift {shift}")
+
+
+def test_f16c_uint8_hwc_ingest_equals_float_path(model_c):
+    """extract_localization.py:157-186 in the compensated mode: the uint8 HWC image (RGB, BGR, device-resident) converted
+    inside the compensated fused stem equals the host-side astype(float32) / 255, bit for bit, also through the pyramid."""
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    rs = np.random.RandomState(7)
+    base = (synth.make_image(120, 168, 9).transpose(1, 2, 0) * 255.0 + rs.uniform(-0.5, 0.5, (120, 168, 3)))
+    u8 = np.clip(np.rint(base), 0, 255).astype(np.uint8)
+    f = (u8.astype(np.float32).transpose(2, 0, 1) / 255.).astype(np.float32)
+    want = extract_resnet_return(model_c, f[None], conf_th=0.001, topK=300, scales=[1.0])
+    for arr, kw in [(u8, {}), (np.ascontiguousarray(u8[:, :, ::-1]), {"bgr": True}), (torch.from_numpy(u8).cuda(), {})]:
+        got = extract_resnet_return(model_c, arr, conf_th=0.001, topK=300, scales=[1.0], **kw)
+        for k in ("keypoints", "scores", "descriptors"):
+            np.testing.assert_array_equal(got[k], want[k])
+    want = extract_resnet_return(model_c, f[None], conf_th=0.001, topK=300, scales=[1.0, 0.75])
+    got = extract_resnet_return(model_c, u8, conf_th=0.001, topK=300, scales=[1.0, 0.75])
+    for k in ("keypoints", "scores", "descriptors"):
+        np.testing.assert_array_equal(got[k], want[k])
+
+
+@pytest.mark.parametrize("tag,h,w,seed,topk,scales", [("96x128_k150", 96, 128, 21, 150, [1.0, 0.5])])
+def test_f16c_multiscale_vs_oracle_and_reference_golden(model_c, synth_sd, golden_dir, tag, h, w, seed, topk, scales):
+    """The scale pyramid of extract_resnet_return (nets/extractor.py:113-124, 211-236, 322-330) in the compensated mode."""
+    from sfd2_amd.extractor import extract_resnet_return
+    img = synth.make_image(h, w, seed)
+    got = extract_resnet_return(model_c, img[None], conf_th=0.001, topK=topk, scales=scales)
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk, scales=tuple(scales))
+    iou, dd, shift, same, n = _compare(got, want, 0.97)
+    g = np.load(os.path.join(golden_dir, f"extract_ms_{tag}.npz"), allow_pickle=False)
+    ref = {"keypoints": g["keypoints"], "scores": g["scores"], "descriptors": g["descriptors"].astype(np.float64)}
+    iou2, dd2, _, _, _ = _compare(got, ref, 0.97)
+    _record(f"f16c pyramid {tag}: vs oracle IoU {iou:.4f} desc {dd:.2e}; vs reference golden IoU {iou2:.4f} desc {dd2:.2e}")
+
+
+def test_f16c_spp_variant_vs_oracle(model_c, synth_sd):
+    """extract.py's variant (greedy nms_fast, extract_spp_feats_singlescale: extract.py:17-84, 204-277) on the compensated
+    conv stack: same points up to near-threshold ones, descriptors within 1e-3."""
+    from sfd2_amd.extract import extract_spp_feats_singlescale
+    x = orc.norm_rgb(synth.make_image(96, 128, 21))
+    pts, desc, sc = extract_spp_feats_singlescale(model_c, x[None], conf_th=0.1)[:3]
+    wpts, wdesc, wsc = orc.extract_spp_feats_singlescale(synth_sd, x, conf_th=0.1)[:3]
+    a = {(float(p[0]), float(p[1])): i for i, p in enumerate(np.asarray(pts)[:, :2])}
+    b = {(float(p[0]), float(p[1])): i for i, p in enumerate(np.asarray(wpts)[:, :2])}
+    common = sorted(set(a) & set(b))
+    assert len(common) >= 0.97 * max(len(a), len(b))
+    dd = max(np.abs(np.asarray(desc)[a[k]] - np.asarray(wdesc)[b[k]]).max() for k in common)
+    assert dd <= DESC_TOL, dd
+    _record(f"f16c extract.py variant 128x96: {len(common)} of {len(b)} points in common, desc {dd:.2e}")
+
+
+def test_f16c_hipgraph_cache_equals_eager(model_c):
+    """sfd2_extract_match with option 'graphs' in the compensated mode (what bench.py's headline replays): captured and
+    replayed units equal the eager calls bit for bit, and a precision switch in between drops the cached graphs."""
+    import ctypes
+    import torch
+    from sfd2_amd import _lib
+    ctx = model_c.context
+    lib = ctx.lib
+    H, W, K, KDB, N = 480, 640, 2048, 4, 2048
+    imgs = [torch.from_numpy(synth.make_image(H, W, 71 + i)).cuda() for i in range(2)]
+    db = [torch.from_numpy(synth.make_descriptors(N, seed=80 + i)).to(torch.float16).cuda().contiguous() for i in range(KDB)]
+    dbs = (_lib.DescSet * KDB)(*[_lib.DescSet(d.data_ptr(), N, _lib.DT_F16, _lib.LAYOUT_ND, 1) for d in db])
+    mconf = _lib.MatchConf(_lib.MATCH_HLOC, 1, 0.0, 0.0, _lib.SIM_F16)
+    kp = torch.zeros((K, 2), device="cuda"); sc = torch.zeros((K,), device="cuda"); de = torch.zeros((K, 128), device="cuda")
+    mt = torch.full((KDB, K), -7, dtype=torch.int64, device="cuda"); ms = torch.zeros((KDB, K), device="cuda")
+
+    def unit(i):
+        _lib.check(lib.sfd2_extract_match(ctx.h, imgs[i].data_ptr(), H, W, 0.001, K, 0, kp.data_ptr(), sc.data_ptr(), de.data_ptr(),
+                                          dbs, KDB, 128, ctypes.byref(mconf), mt.data_ptr(), ms.data_ptr()))
+        ctx.sync()
+        return tuple(t.clone() for t in (kp, sc, de, mt, ms))
+
+    want = [unit(0), unit(1)]
+    ctx.set_option("graphs", 1)
+    try:
+        for rnd in range(3):
+            for i in (0, 1):
+                got = unit(i)
+                assert all(torch.equal(g, w) for g, w in zip(got, want[i])), (rnd, i)
+        ctx.set_precision("f16")          # (ADVICE r2: a cached graph must not survive a precision switch)
+        f16 = unit(0)
+        assert not torch.equal(f16[2], want[0][2])
+        ctx.set_precision("f16c")
+        got = unit(0)
+        assert all(torch.equal(g, w) for g, w in zip(got, want[0]))
+    finally:
+        ctx.set_option("graphs", 0)
+        ctx.set_precision("f16c")
