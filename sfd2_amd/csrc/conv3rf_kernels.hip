@@ -89,14 +89,21 @@ __device__ __forceinline__ void rf_copy_piece(const half_t *base, int nbytes, un
 // 144 registers per wave), so the filters are loaded once per block and never again -- the 128-pixel tile that cannot
 // afford to stream 295 KB of filters per tile does not have to.  The chunk loop is unrolled over the two chunks so that the
 // fragment index is a compile-time constant.
-template <int S, int BN = RF_BN, int ABL = 0, bool RES = false>
+// COMP (SFD2_PREC_F16C, sfd2_internal.h): bit 0 = the input has a corr plane (in_c) and wpk holds 2 * Cin / 32 chunks: a tile's
+// chunk sequence simply continues through the corr plane's chunks, whose units issue ONE v_mfma_scale_f32_32x32x64_f8f6f4 per
+// pixel fragment instead of two fp16 MFMAs; bit 1 = the output's corr plane is written.  In these instantiations the filter
+// ring and the pixel-fragment ring hold 8-dword tuples (both K slices of a unit adjacent: the fp8 MFMA's operand; the fp16
+// MFMAs take the two halves), the pixel ring is two units deep and is prefetched one unit ahead.
+template <int S, int BN = RF_BN, int ABL = 0, bool RES = false, int COMP = 0>
 __global__ __launch_bounds__(512, 2)
 void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                        const half_t *__restrict__ wpk, const float *__restrict__ scale,
                        const float *__restrict__ shift, int CoutP, int relu,
                        half_t *__restrict__ out, int Ho, int Wo, int tiles_x, int n_tiles,
-                       const half_t *__restrict__ zero_page)
+                       const half_t *__restrict__ zero_page,
+                       const half_t *__restrict__ in_c = nullptr, half_t *__restrict__ out_c = nullptr, int sa = 0)
 {
+    static_assert(COMP == 0 || (!RES && ABL == 0), "compensated instantiations: streamed filters");
     using G = RfGeom<S>;
     constexpr int NWC = BN / 32, NF = 4 / (8 / NWC);       // channel groups; pixel fragments per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -114,7 +121,8 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     const int f0 = (wave / NWC) * NF;
     const int n0 = (wave % NWC) * 32;                      // CoutP == BN: one channel tile (launcher)
 
-    const int NCH = Cin / RF_CC;
+    const int NCP = Cin / RF_CC;                           // chunks per plane
+    const int NCH = ((COMP & 1) ? 2 : 1) * NCP;            // chunks per tile: the hi plane's, then (COMP & 1) the corr plane's
     const int NU = NCH * 9;
     const int n_my = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this block
     const int TC = n_my * NCH;                             // chunks of this block
@@ -129,11 +137,13 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         const int swz_ = xcd_swizzle4((int)blockIdx.x + (seq_) * (int)gridDim.x, n_tiles);             \
         const int tx_ = swz_ % tiles_x, ty_ = swz_ / tiles_x;                                          \
         const int poy0_ = ty_ * RF_TH, pox0_ = tx_ * RF_TW;                                            \
+        int lane_ = lane;                                                                              \
+        if (COMP != 0) asm volatile("" : "+v"(lane_));   /* (per-lane piece geometry recomputed per tile, not hoisted into registers) */ \
         _Pragma("unroll") for (int i = 0; i < G::PPW; ++i) {                                           \
             int piece = wave + 8 * i;                                                                  \
             if (piece >= G::NPIECE) piece = G::NPIECE - 1;                                             \
-            const int q = piece * 16 + (lane >> 2);                                                    \
-            const int slot = (lane & 3) ^ ((q >> 2) & 3);                                              \
+            const int q = piece * 16 + (lane_ >> 2);                                                   \
+            const int slot = (lane_ & 3) ^ ((q >> 2) & 3);                                             \
             const int row = q / G::P, ir = q - row * G::P;                                             \
             int off = (int)0x80000000;                                                                 \
             if (row < G::PH && ir < G::PWU) {                                                          \
@@ -149,7 +159,9 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #define RF_ISSUE_X1(chunk_, buf_, i_)                                                                  \
     do {                                                                                               \
         const int pc_ = (wave + 8 * (i_) < G::NPIECE) ? wave + 8 * (i_) : G::NPIECE - 1;               \
-        rf_copy_piece(in, in_bytes, Xs + (buf_)*G::XBYTES + pc_ * 1024, xoff[i_], (chunk_)*RF_CC * (int)sizeof(half_t)); \
+        const bool cp_ = (COMP & 1) && (chunk_) >= NCP;                                                \
+        rf_copy_piece(cp_ ? in_c : in, in_bytes, Xs + (buf_)*G::XBYTES + pc_ * 1024, xoff[i_],         \
+                      ((chunk_) - (cp_ ? NCP : 0)) * RF_CC * (int)sizeof(half_t));                     \
     } while (0)
 #define RF_ISSUE_X(chunk_, buf_)                                                                       \
     _Pragma("unroll") for (int i_ = 0; i_ < G::PPW; ++i_) RF_ISSUE_X1(chunk_, buf_, i_);
@@ -179,18 +191,42 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             dst_[f_] = *reinterpret_cast<const h8_t *>(bp_ + (f0 + f_) * (G::DF * 64));                \
     } while (0)
 
+    // the same as 8-dword tuples (COMP): K slices 0 and 1 of a fragment in adjacent registers
+#define RF_LOAD_A8(u_, dst_)                                                                           \
+    do {                                                                                               \
+        int ao_ = aoff;                                                                                \
+        asm volatile("" : "+v"(ao_));                                                                  \
+        const half_t *ap_ = wpk + (size_t)(u_)*CoutP * RF_CC + ao_;                                    \
+        dst_ = sfd2_cat8(*reinterpret_cast<const h8_t *>(ap_), *reinterpret_cast<const h8_t *>(ap_ + 16)); \
+    } while (0)
+#define RF_READ_B8(xs_, t_, dst_)                                                                      \
+    do {                                                                                               \
+        const int ky_ = (t_) / 3, kx_ = (t_) % 3;                                                      \
+        const int to_ = ky_ * G::P + (S == 2 ? (kx_ == 0 ? 0 : (kx_ == 1 ? RF_TW + 1 : 1)) : kx_);     \
+        int q_ = qb;                                                                                   \
+        asm volatile("" : "+v"(q_));                                                                   \
+        q_ += to_;                                                                                     \
+        const unsigned char *b0_ = (xs_) + q_ * 64 + (((lhi) ^ ((q_ >> 2) & 3)) << 4);                 \
+        const unsigned char *b1_ = (xs_) + q_ * 64 + (((2 + lhi) ^ ((q_ >> 2) & 3)) << 4);             \
+        _Pragma("unroll") for (int f_ = 0; f_ < NF; ++f_)                                              \
+            dst_[f_] = sfd2_cat8(*reinterpret_cast<const h8_t *>(b0_ + (f0 + f_) * (G::DF * 64)),      \
+                                 *reinterpret_cast<const h8_t *>(b1_ + (f0 + f_) * (G::DF * 64)));     \
+    } while (0)
+
     f32x16_t acc[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
     constexpr int NFA = RES ? 18 : 9;
-    h8_t fa[NFA][2], fb[3][NF];
+    h8_t fa[NFA][2], fb[3][COMP ? 1 : NF];                // (COMP: the filter ring stays in K-slice halves -- 4-register pieces
+    v8i_t fb8[2][COMP ? NF : 1];                          //  allocate where 8-register tuples spill -- and is joined per fp8 unit)
 
     // scale / shift of this wave's 32 channels stay in registers (one channel tile: the same for every tile); RES has no
     // registers to spare and re-reads them per tile
     float4 sc[4], sh[4];
-    if (!RES) {
+    constexpr bool SS_RELOAD = RES || COMP != 0;   // (the compensated forms neither: two chunk bodies)
+    if (!SS_RELOAD) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             sc[q] = *reinterpret_cast<const float4 *>(scale + n0 + 4 * lhi + 8 * q);
@@ -206,14 +242,21 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     for (int u = 0; u < NFA; ++u) RF_LOAD_A(u, fa[u]);
     // (waiting for the first patch only and letting the rest land behind counted waits was measured: no gain)
     SFD2_BARRIER_DRAIN();
-    RF_READ_B(Xs, 0, 0, fb[0]);
-    RF_READ_B(Xs, 0, 1, fb[1]);
+    if constexpr (COMP != 0) {
+        RF_READ_B8(Xs, 0, fb8[0]);
+    } else {
+        RF_READ_B(Xs, 0, 0, fb[0]);
+        RF_READ_B(Xs, 0, 1, fb[1]);
+    }
 
     int bc = 0;                                            // C % 3: three patch buffers
     int c = 0, seq = 0, C = 0;                             // chunk within the tile, tile of this block, chunk of this block
     // one chunk; CC = the chunk's index within the tile as a constant (RES), or -1 (runtime c)
     auto chunk = [&](auto cc_tag) {
         constexpr int CC = decltype(cc_tag)::value;
+        // a corr-plane chunk (COMP & 1)?  A wave-uniform RUNTIME flag: two instantiations of this body (one per chunk type) cost
+        // 70 more registers than one (each copy keeps its own hoisted state across the shared rings) and spill in the unit loop
+        const bool F8 = (COMP & 1) && c >= NCP;
         const int bn = bc == 2 ? 0 : bc + 1, bnn = bn == 2 ? 0 : bn + 1;
         const unsigned char *xs = Xs + bc * G::XBYTES;
         const unsigned char *xn = Xs + bn * G::XBYTES;
@@ -223,7 +266,9 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         // the in-flight counts stay what the waits assume).
         const int Cx = C + 2 < TC ? C + 2 : TC - 1;
         const int seq_x = Cx / NCH, cx = Cx - seq_x * NCH;
-        if (seq_x != xoff_seq) RF_SETUP_X(seq_x)
+        if constexpr (COMP == 0) {   // (the compensated forms have two chunk bodies: their caller does this once)
+            if (seq_x != xoff_seq) RF_SETUP_X(seq_x)
+        }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             if (t < G::PPW && !(ABL & 4)) RF_ISSUE_X1(cx, bnn, t);
@@ -237,6 +282,36 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                 else if (S == 2) asm volatile("s_waitcnt vmcnt(30) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(33) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (COMP != 0) {
+                // the pixel fragments of unit t + 1 (of the next chunk's first unit at t = 8: its patch has landed, see above)
+                if (t + 1 < 9) RF_READ_B8(xs, t + 1, fb8[(t + 1) & 1]);
+                else RF_READ_B8(xn, 0, fb8[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (F8) {
+                    // the ring holds K-slice halves (4-register values); the fp8 operand is joined HERE: left to itself hipcc keeps a second,
+                    // tuple-shaped copy of the whole ring alive across the chunk (72 more registers, spills in the unit loop)
+                    h8_t x0 = fa[t][0], x1 = fa[t][1];
+                    asm volatile("" : "+v"(x0), "+v"(x1));
+                    const v8i_t a8 = sfd2_cat8(x0, x1);
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+                        acc[f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, fb8[t & 1][f], acc[f], 0, 0, 0, sa, 0, 0x7f7f7f7f);
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(acc[f]));   // (pure nodes to instruction selection: keep them here)
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int f = 0; f < NF; ++f)
+                            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][kk], sfd2_half8(fb8[t & 1][f], kk), acc[f], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                int ua = c * 9 + t + 9;
+                if (ua >= NU) ua -= NU;
+                RF_LOAD_A(ua, fa[t]);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -258,13 +333,18 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (COMP != 0) {
+            // nine units per chunk: the next chunk's first fragments were read into slot 1; its units index from slot 0
+#pragma unroll
+            for (int f = 0; f < NF; ++f) fb8[0][f] = fb8[1][f];
+        }
         bc = bn;
         ++C;
     };
     // a tile's epilogue: y = acc * scale + shift (ReLU), regrouped with v_permlane32_swap into 16-byte stores
     // (conv2_kernels.hip); the next tile's first operands are already in registers / in flight
     auto epilogue = [&]() {
-        if (RES) {
+        if (SS_RELOAD) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 sc[q] = *reinterpret_cast<const float4 *>(scale + n0 + 4 * lhi + 8 * q);
@@ -282,7 +362,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const size_t o16 = pix * CoutP + n0 + 8 * (2 * m + lhi);
-                uint2 pk[2];
+                uint2 pk[2], ck[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int q = 2 * m + j;
@@ -291,8 +371,17 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                     float v2 = acc[f][4 * q + 2] * sc[q].z + sh[q].z;
                     float v3 = acc[f][4 * q + 3] * sc[q].w + sh[q].w;
                     v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
-                    const h4_t hv = cvt4r(v0, v1, v2, v3);
-                    __builtin_memcpy(&pk[j], &hv, 8);
+                    if constexpr ((COMP & 2) != 0) {
+                        sfd2_split4(v0, v1, v2, v3, pk[j], ck[j]);
+                    } else {
+                        const h4_t hv = cvt4r(v0, v1, v2, v3);
+                        __builtin_memcpy(&pk[j], &hv, 8);
+                    }
+                }
+                if constexpr ((COMP & 2) != 0) {
+                    const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
+                    const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
+                    if (inb) *reinterpret_cast<uint4 *>(out_c + o16) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
                 }
                 const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                 const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
@@ -335,6 +424,16 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             chunk(std::integral_constant<int, 1>{});
             epilogue();
         }
+    } else if constexpr ((COMP & 1) != 0) {
+        while (C < TC) {
+            {
+                const int Cx = C + 2 < TC ? C + 2 : TC - 1;
+                const int seq_x = Cx / NCH;
+                if (seq_x != xoff_seq) RF_SETUP_X(seq_x)
+            }
+            chunk(std::integral_constant<int, -1>{});
+            if (++c == NCH) epilogue();
+        }
     } else {
         while (C < TC) {
             chunk(std::integral_constant<int, -1>{});
@@ -345,18 +444,20 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #undef RF_ISSUE_X1
 #undef RF_LOAD_A
 #undef RF_READ_B
+#undef RF_LOAD_A8
+#undef RF_READ_B8
 #undef RF_SETUP_X
 }
 
-template <int S, int BN = RF_BN, int ABL = 0, bool RES = false>
+template <int S, int BN = RF_BN, int ABL = 0, bool RES = false, int COMP = 0>
 static void launch_rf_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                         const float *scale, const float *shift, int CoutP, int relu, half_t *out,
-                        int Ho, int Wo, const half_t *zero_page)
+                        int Ho, int Wo, const half_t *zero_page, const half_t *in_c = nullptr, half_t *out_c = nullptr, int sa = 0)
 {
     constexpr size_t lds = (size_t)3 * RfGeom<S>::XBYTES;
     static bool attr_done = false;
     static int slots = 256;
-    auto kern = conv3x3_rf_kernel<S, BN, ABL, RES>;
+    auto kern = conv3x3_rf_kernel<S, BN, ABL, RES, COMP>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int dev = 0, cus = 0;
@@ -368,7 +469,23 @@ static void launch_rf_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
     const int n_tiles = tiles_x * tiles_y;                 // CoutP == BN: one channel tile
     const int grid = n_tiles < slots ? n_tiles : slots;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out,
-                       Ho, Wo, tiles_x, n_tiles, zero_page);
+                       Ho, Wo, tiles_x, n_tiles, zero_page, in_c, out_c, sa);
+}
+
+// compensated instantiations (SFD2_PREC_F16C): the stride-2 layer with 128 output channels (conv2b).  wpk = the layer's wc
+// array (32-wide chunks, hi then corr), sbyte its scale byte.  false = no instantiation for this shape.
+bool launch_conv3x3_rf_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
+                         const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out, half_t *out_c,
+                         int Ho, int Wo, const half_t *zero_page, int sbyte)
+{
+    if (!in_c || !out_c || Cin % 64 != 0) return false;
+    if ((long long)(Ho * stride + 2) * (Wo * stride + 2) * Cin * (long long)sizeof(half_t) >= (1ll << 31)) return false;
+    const int sa = (sbyte & 255) * 0x01010101;
+    if (CoutP == 128 && stride == 2) {
+        launch_rf_t<2, 128, 0, false, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
+        return true;
+    }
+    return false;
 }
 
 // does conv3x3_rf serve this layer?  Shape AND output size decide (the filter packing is the 32-channel-chunk one that

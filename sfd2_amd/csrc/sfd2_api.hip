@@ -95,6 +95,7 @@ struct sfd2_ctx {
     const half_t *pa_cur = nullptr;    // convPa.3 output of the last fp16 network pass
     const half_t *da_cur = nullptr;    // convDa.3 output of the last fp16 network pass
     int opt_comp_rb = 1;               // sfd2_set_option "comp_rb": SFD2_PREC_F16C compensates the ResBlocks too (0: fused fp16 ResBlock kernel)
+    int opt_no_rf_c = 0;               // sfd2_set_option "no_rf_c": conv2b on conv_igemm2<comp> instead of conv3x3_rf<comp> (A/B switch)
     int opt_generic_c = 0;             // sfd2_set_option "generic_c": SFD2_PREC_F16C layers on the generic reference kernel (tests)
     int opt_branches = 0;              // sfd2_set_option "branches": detector branch on a second stream beside the descriptor branch
     hipStream_t side_stream = nullptr; // the detector branch (convPa.0 -> convPa.3 -> convPb -> detector_head)
@@ -816,6 +817,13 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &i
         launch_conv3x3_pp_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, L.wc.as<half_t>(), L.scale.as<float>(),
                             L.shift.as<float>(), L.cout_pad, relu, out.as<half_t>(), out_c, Ho, Wo, c->zero_page.as<half_t>(), L.sbyte);
         return;
+    }
+    if (!c->opt_generic_c && !c->opt_no_rf_c && in_c && out_c && !res && L.ks == 3 && L.stride == 2 && L.cout_pad == 128) {   // conv2b
+        ProfScope ps(c, name, "conv3x3_rf<2,comp>", flops, bytes);
+        if (launch_conv3x3_rf_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, L.wc.as<half_t>(), L.scale.as<float>(),
+                                L.shift.as<float>(), L.cout_pad, L.stride, relu, out.as<half_t>(), out_c, Ho, Wo,
+                                c->zero_page.as<half_t>(), L.sbyte))
+            return;
     }
     if (!c->opt_generic_c && in_c && out_c && L.wrm.p && L.wrmc.p) {   // the ResBlocks' 1x1 layers: persistent streaming kernel
         snprintf(kn, sizeof(kn), "conv1x1_c256<comp>%s", res ? "+res" : "");
@@ -2267,6 +2275,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "fuse_pb") c->opt_fuse_pb = value ? 1 : 0;
     else if (k == "generic_c") c->opt_generic_c = value ? 1 : 0;
     else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;
+    else if (k == "no_rf_c") c->opt_no_rf_c = value ? 1 : 0;
     else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;
 }

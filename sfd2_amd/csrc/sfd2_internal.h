@@ -152,6 +152,9 @@ void launch_convc_igemm(hipStream_t st, const half_t *in, const half_t *in_c, in
 void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int relu, half_t *out, half_t *out_c,
                          int Ho, int Wo, const half_t *zero_page, int sbyte);
+bool launch_conv3x3_rf_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
+                         const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out, half_t *out_c,
+                         int Ho, int Wo, const half_t *zero_page, int sbyte);
 bool launch_conv_igemm2_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                           const float *scale, const float *shift, int CoutP, int ks, int stride, int relu,
                           const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, int Ho, int Wo,
