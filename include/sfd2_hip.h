@@ -127,6 +127,9 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *               the descriptor branch (convDa, convDb) -- they share only the backbone output (-1.7 % per extract).
  *   "comp_rb"   1 (default) / 0: SFD2_PREC_F16C compensates the three ResBlocks as well (descriptors within ~3e-4 of
  *               the fp32 reference); 0 runs them on the fused fp16 ResBlock kernel (~7e-4, still inside 1e-3, and faster).
+ *   "rb_split"  1 (default) .. 8: experiment -- the compensated ResBlocks in that many spatial parts (cache-sized working
+ *               set); bit-identical, measured slower (the launches are ramp-bound, not bandwidth-bound).
+ *   "no_rf_c"   0 (default) / 1: conv2b of SFD2_PREC_F16C on conv_igemm2<comp> instead of conv3x3_rf<comp> (A/B switch).
  *   "generic_c" 0 (default) / 1: SFD2_PREC_F16C layers all run on the generic compensated kernel (the reference
  *               implementation of that arithmetic) instead of the tuned kernels' compensated instantiations; the two
  *               differ by fp32 summation order only.

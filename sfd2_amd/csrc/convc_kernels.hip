@@ -406,7 +406,7 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
                     const half_t *__restrict__ wpk /*[16 pairs][5 steps][64 lanes][8] fp16*/,
                     const unsigned char *__restrict__ wck /*[16 pairs][3 steps][64 lanes][32 B] corr units*/,
                     const float *__restrict__ scale, const float *__restrict__ shift, half_t *__restrict__ out,
-                    half_t *__restrict__ out_c, int tiles_x, int sa)
+                    half_t *__restrict__ out_c, int tiles_x, int sa, int row0, int row1 /* output rows [row0, row1) of the image */)
 {
     constexpr int NPIX = GC_PH * GC_PW;
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
@@ -415,7 +415,7 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int swz = xcd_swizzle_c(blockIdx.x, gridDim.x);
     const int tx = swz % tiles_x, ty = swz / tiles_x;
-    const int oy0 = ty * CTH, ox0 = tx * CTW;
+    const int oy0 = row0 + ty * CTH, ox0 = tx * CTW;
     const int g = lane >> 4, lcol = lane & 15;
 
     constexpr int NLD = (NPIX * 8 + CNT - 1) / CNT;
@@ -510,7 +510,7 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
             const int oy = oy0 + (tt >> 1), ox = ox0 + (tt & 1) * 16 + lcol;
             const uint4 v = odd ? make_uint4(recv.x, recv.y, pk[1].x, pk[1].y) : make_uint4(pk[0].x, pk[0].y, recv.x, recv.y);
             const uint4 vc = odd ? make_uint4(recvc.x, recvc.y, ck[1].x, ck[1].y) : make_uint4(ck[0].x, ck[0].y, recvc.x, recvc.y);
-            if (oy < H && ox < W) {
+            if (oy < row1 && ox < W) {
                 const size_t o = ((size_t)oy * W + ox) * 256 + pair * 16 + (g & ~1) * 4;
                 *reinterpret_cast<uint4 *>(out + o) = v;
                 *reinterpret_cast<uint4 *>(out_c + o) = vc;
@@ -520,13 +520,16 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
 #undef GC_FETCH
 }
 
+// row0 / row1: the output rows to produce (the whole image: 0, H); input rows outside [0, H) are the conv's zero padding
 void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk, const void *wck,
-                    const float *scale, const float *shift, half_t *out, half_t *out_c, int sbyte)
+                    const float *scale, const float *shift, half_t *out, half_t *out_c, int sbyte, int row0, int row1)
 {
     constexpr size_t lds = (size_t)2 * GC_PH * GC_PW * GCP * sizeof(half_t);
-    const int tiles_x = (W + CTW - 1) / CTW, tiles_y = (H + CTH - 1) / CTH;
+    if (row1 > H) row1 = H;
+    if (row0 >= row1) return;
+    const int tiles_x = (W + CTW - 1) / CTW, tiles_y = (row1 - row0 + CTH - 1) / CTH;
     hipLaunchKernelGGL(gconv_c_kernel, dim3(tiles_x * tiles_y), dim3(CNT), lds, st, in, in_c, H, W, wpk,
-                       reinterpret_cast<const unsigned char *>(wck), scale, shift, out, out_c, tiles_x, (sbyte & 255) * 0x01010101);
+                       reinterpret_cast<const unsigned char *>(wck), scale, shift, out, out_c, tiles_x, (sbyte & 255) * 0x01010101, row0, row1);
 }
 
 // hi + corr planes -> NCHW fp32 (sfd2_debug_activation): hi + the residual the corr unit carries

@@ -95,6 +95,7 @@ struct sfd2_ctx {
     const half_t *pa_cur = nullptr;    // convPa.3 output of the last fp16 network pass
     const half_t *da_cur = nullptr;    // convDa.3 output of the last fp16 network pass
     int opt_comp_rb = 1;               // sfd2_set_option "comp_rb": SFD2_PREC_F16C compensates the ResBlocks too (0: fused fp16 ResBlock kernel)
+    int opt_rb_split = 1;              // sfd2_set_option "rb_split": spatial parts per compensated ResBlock (cache-sized working set); measured slower, off
     int opt_no_rf_c = 0;               // sfd2_set_option "no_rf_c": conv2b on conv_igemm2<comp> instead of conv3x3_rf<comp> (A/B switch)
     int opt_generic_c = 0;             // sfd2_set_option "generic_c": SFD2_PREC_F16C layers on the generic reference kernel (tests)
     int opt_branches = 0;              // sfd2_set_option "branches": detector branch on a second stream beside the descriptor branch
@@ -953,7 +954,8 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         S = std::max(S, 2 * (P8s * 256 * 2 + 256));
         if (comp) S *= 2;   // hi plane + corr plane per tensor (the corr plane follows the hi plane inside the slot)
         S = (S + 255) & ~(size_t)255;
-        HIPCHECK(c->arena.ensure((c->opt_branches ? 4 : 3) * S));
+        const bool split4 = comp && c->opt_comp_rb && c->opt_rb_split > 1;   // spatially split ResBlocks: output in its own slot (below)
+        HIPCHECK(c->arena.ensure((c->opt_branches || split4 ? 4 : 3) * S));
         char *base = c->arena.as<char>();
         auto slot = [&](int i, size_t off = 0) { DevBuf v; v.p = base + (size_t)i * S + off; v.cap = 0; return v; };
         {
@@ -969,6 +971,15 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
             // convPb fused into the detector-head kernel: convPa.3's output must outlive the network pass, so convDa.3
             // writes over the backbone output instead (slot 0) -- ConvSta, its last reader, then runs before the heads
             if (c->skip_pb_now) da_o = slot(0);
+            if (split4) {
+                // A block run in spatial parts writes the output rows of one part while the next part's grouped conv still reads
+                // the t1 row above its first output row: the output cannot take t1's slot.  x / out alternate between slots 2
+                // and 3, t1 / t2 stay in 0 / 1; the final backbone output is slot 3, slot 0 is free for convDa.3 as before.
+                t1v[0] = slot(0); t2v[0] = slot(1); rov[0] = slot(3);    // x = slot 2
+                t1v[1] = slot(0); t2v[1] = slot(1); rov[1] = slot(2);    // x = slot 3
+                t1v[2] = slot(0); t2v[2] = slot(1); rov[2] = slot(3);    // x = slot 2 -> final x = slot 3
+                if (c->opt_branches) da_o = slot(0);                     // (slot 3 holds x here; slot 0 is free and not used by the detector branch)
+            }
         }
     }
     const DevBuf *x = &a3b;
@@ -1023,14 +1034,55 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
             if (!c->opt_comp_rb) { rb_f16(b); continue; }   // option "comp_rb" = 0: this block in plain fp16 on the hi planes
             DevBuf &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];
-            convc(c, nm1[b], c->rb1[b], *x, H4, W4, t1, H4, W4, 1, true, true);
-            {
-                ProfScope ps(c, nm2[b], "gconv_c_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 8);
-                launch_gconv_c(st, t1.as<half_t>(), corr_of(t1, (size_t)H4 * W4, 256), H4, W4, c->rb2[b].w.as<half_t>(),
-                               c->rb2[b].wc.p, c->rb2[b].scale.as<float>(), c->rb2[b].shift.as<float>(), t2.as<half_t>(),
-                               corr_of(t2, (size_t)H4 * W4, 256), c->rb2[b].sbyte);
+            // Option "rb_split" (experiment, default 1 = off).  The block's three tensors (x, t1, t2: 123 MB each with their corr
+            // planes at 1600x1200) are 369 MB, more than the 256 MB Infinity Cache; run in spatial parts, each part's chain --
+            // conv1 -> grouped conv -> conv3 + residual -- would read what the kernel before it just wrote out of the cache.
+            // Bit-identical (the layers are pointwise / row-windowed; conv1 of a part also produces the halo row below it), but
+            // measured SLOWER: 1.94 -> 2.06 (2 parts) -> 2.18 ms (3 parts) per extract.  A half-size launch of the streaming 1x1
+            // kernel takes 41 us against 62 for the whole map: these launches are bound by their ramp (every block first pulls the
+            // 256 KB of fp16 + corr filters into registers and fills a three-group pipeline), not by HBM bandwidth.
+            const int nsplit = (c->opt_rb_split > 1 && !c->opt_generic_c && c->rb1[b].wrmc.p && c->rb3[b].wrmc.p && H4 >= 8 * c->opt_rb_split) ? c->opt_rb_split : 1;
+            if (nsplit == 1) {
+                convc(c, nm1[b], c->rb1[b], *x, H4, W4, t1, H4, W4, 1, true, true);
+                {
+                    ProfScope ps(c, nm2[b], "gconv_c_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 8);
+                    launch_gconv_c(st, t1.as<half_t>(), corr_of(t1, (size_t)H4 * W4, 256), H4, W4, c->rb2[b].w.as<half_t>(),
+                                   c->rb2[b].wc.p, c->rb2[b].scale.as<float>(), c->rb2[b].shift.as<float>(), t2.as<half_t>(),
+                                   corr_of(t2, (size_t)H4 * W4, 256), c->rb2[b].sbyte, 0, H4);
+                }
+                convc(c, nm3[b], c->rb3[b], t2, H4, W4, ob, H4, W4, 1, true, true, x);
+            } else {
+                const size_t PP = (size_t)H4 * W4;
+                half_t *xh = x->as<half_t>(), *xc = corr_of(*x, PP, 256), *t1h = t1.as<half_t>(), *t1c = corr_of(t1, PP, 256);
+                half_t *t2h = t2.as<half_t>(), *t2c = corr_of(t2, PP, 256), *oh = ob.as<half_t>(), *oc = corr_of(ob, PP, 256);
+                const ConvW &L1 = c->rb1[b], &L3 = c->rb3[b];
+                int done1 = 0;                                        // conv1 rows produced so far
+                for (int part = 0; part < nsplit; ++part) {
+                    const int r0 = (int)((long long)H4 * part / nsplit), r1 = (int)((long long)H4 * (part + 1) / nsplit);
+                    const int need1 = std::min(H4, r1 + 1);           // the grouped conv reads one row below its last output row
+                    const double frac = (double)(r1 - r0) / H4;
+                    if (need1 > done1) {
+                        const size_t o = (size_t)done1 * W4 * 256;
+                        const int np = (need1 - done1) * W4;
+                        ProfScope ps(c, nm1[b], "conv1x1_c256<comp>", 2.0 * np * 256.0 * 256.0, np * 256.0 * 8);
+                        launch_conv1x1_c256_c(st, xh + o, xc + o, np, L1.wrm.as<half_t>(), L1.wrmc.as<half_t>(), L1.scale.as<float>(),
+                                              L1.shift.as<float>(), 1, nullptr, nullptr, t1h + o, t1c + o, c->zero_page.as<half_t>(), L1.sbyte);
+                        done1 = need1;
+                    }
+                    {
+                        ProfScope ps(c, nm2[b], "gconv_c_kernel", 2.0 * P4 * 256 * 72 * frac, P4 * 256 * 8 * frac);
+                        launch_gconv_c(st, t1h, t1c, H4, W4, c->rb2[b].w.as<half_t>(), c->rb2[b].wc.p, c->rb2[b].scale.as<float>(),
+                                       c->rb2[b].shift.as<float>(), t2h, t2c, c->rb2[b].sbyte, r0, r1);
+                    }
+                    {
+                        const size_t o = (size_t)r0 * W4 * 256;
+                        const int np = (r1 - r0) * W4;
+                        ProfScope ps(c, nm3[b], "conv1x1_c256<comp>+res", 2.0 * np * 256.0 * 256.0, np * 256.0 * 12);
+                        launch_conv1x1_c256_c(st, t2h + o, t2c + o, np, L3.wrm.as<half_t>(), L3.wrmc.as<half_t>(), L3.scale.as<float>(),
+                                              L3.shift.as<float>(), 1, xh + o, xc + o, oh + o, oc + o, c->zero_page.as<half_t>(), L3.sbyte);
+                    }
+                }
             }
-            convc(c, nm3[b], c->rb3[b], t2, H4, W4, ob, H4, W4, 1, true, true, x);
             x = &ob;
         }
     } else {
@@ -2276,6 +2328,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "generic_c") c->opt_generic_c = value ? 1 : 0;
     else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;
     else if (k == "no_rf_c") c->opt_no_rf_c = value ? 1 : 0;
+    else if (k == "rb_split") c->opt_rb_split = std::max(1, std::min(value, 8));
     else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;
 }

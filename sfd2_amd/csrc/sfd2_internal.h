@@ -169,7 +169,8 @@ void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c,
 void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *wpk /*hi, lo fragments*/,
                      const float *scale, const float *shift, half_t *out, half_t *out_c);
 void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk /*fp16 fragments*/,
-                    const void *wck /*corr fragments*/, const float *scale, const float *shift, half_t *out, half_t *out_c, int sbyte);
+                    const void *wck /*corr fragments*/, const float *scale, const float *shift, half_t *out, half_t *out_c, int sbyte,
+                    int row0, int row1 /*output rows [row0, row1)*/);
 void launch_nhwc_hc_to_nchw_f(hipStream_t st, const half_t *in, const half_t *in_c, int npix, int pitch, int c, float *out);
 
 // ---- strict fp32 mode (conv_f32_kernels.hip): fp32 NHWC activations, f32-input MFMA

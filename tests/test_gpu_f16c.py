@@ -294,3 +294,24 @@ def test_f16c_hipgraph_cache_equals_eager(model_c):
     finally:
         ctx.set_option("graphs", 0)
         ctx.set_precision("f16c")
+
+
+@pytest.mark.parametrize("h,w,topk", [(480, 640, 1024), (1200, 1600, 4096), (333, 517, 300)])
+def test_f16c_resblock_spatial_split_bit_identical(synth_sd, h, w, topk):
+    """Option 'rb_split' (default 2): the compensated ResBlocks run as spatial parts so that a part's tensors fit the
+    Infinity Cache.  The layers are pointwise / row-windowed, so the result equals the unsplit launches bit for bit -- on
+    the arena path of sfd2_extract (where the block output must not alias t1 any more) and for 1, 2 and 3 parts."""
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    from sfd2_amd.model import ResSegNetV2
+    img = torch.from_numpy(synth.make_image(h, w, 77)).cuda()
+    outs = []
+    for parts in (1, 2, 3):
+        m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
+        m.load_state_dict(synth_sd)
+        m.cuda(0)
+        m.context.set_option("rb_split", parts)
+        outs.append(extract_resnet_return(m, img[None], conf_th=0.001, topK=topk, scales=[1.0]))
+    for o in outs[1:]:
+        for k in ("keypoints", "scores", "descriptors"):
+            np.testing.assert_array_equal(o[k], outs[0][k])
