@@ -105,9 +105,16 @@ def test_conv3x3_pp_loop_has_only_its_own_drains(asm):
 
 def test_conv3x3_rf_loop_keeps_counted_waits(asm):
     ks = {n: k for n, k in asm("conv3rf_kernels.hip").items() if "conv3x3_rf_kernel" in n}
-    assert len(ks) == 4                      # stride 1, stride 2, stride 2 with 128-channel blocks, conv2a's resident filters
+    assert len(ks) == 5                      # stride 1, stride 2, stride 2 with 128-channel blocks, conv2a's resident filters, conv2b compensated
     for name, k in ks.items():
         span = _mfma_span(k["body"])
+        if name.split("EEv")[0].endswith("ELi3"):                        # COMP = 3: one chunk body, fp16 and fp8 MFMAs behind a wave-uniform flag
+            assert _count(span, r"v_mfma_f32_32x32x16_f16") == 36 and _count(span, r"v_mfma_scale_f32_32x32x64_f8f6f4") == 18
+            assert _count(span, r"s_waitcnt.*vmcnt\(0\)") == 0, name    # the counted waits survive (no spill reload, no drain)
+            assert _count(span, r"\bscratch_") == 0, name
+            assert _count(span, r"global_load_dwordx4") == 16 and _count(k["body"], r"global_load_lds") == 0
+            assert _count(span, r"s_barrier") == 1
+            continue
         if "ELb1E" in name:                                              # resident filters: two unrolled chunks, no loads in the loop
             assert _count(span, r"v_mfma_f32_32x32x16_f16") == 72 and _count(span, r"global_load_dwordx4") == 0
             assert _count(span, r"s_waitcnt.*vmcnt\(0\)") == 0 and _count(span, r"s_barrier") == 2
