@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--lib", default=None, help="kernel A/B runs: another build of libsfd2hip.so (sfd2_amd/build.py build_lib(out=...))")
     ap.add_argument("--precision", default="f16c", choices=["f16c", "f16"], help="mode of the headline legs (default f16c: the "
                     "tolerance-conformant throughput mode; f16 = the 3e-3 approximation, for kernel A/Bs of that path)")
+    ap.add_argument("--comp-heads", type=int, default=0, help="f16c option comp_heads (1: the head branches' 3x3 layers compensated as well)")
     ap.add_argument("--comp-rb", type=int, default=1, help="f16c option comp_rb (0: ResBlocks on the fused fp16 kernel; descriptors ~7e-4)")
     ap.add_argument("--mix", action="store_true", help="every fifth query image in portrait orientation (SURVEY C2: the Aachen query set "
                     "is ~80 %% landscape / 20 %% portrait); the hipGraph cache then holds two geometries per stream")
@@ -254,6 +255,8 @@ def main():
                 self.ctx.set_option("graphs", 1)
             if args.precision == "f16c" and not args.comp_rb:
                 self.ctx.set_option("comp_rb", 0)
+            if args.precision == "f16c" and args.comp_heads:
+                self.ctx.set_option("comp_heads", 1)
             if args.branches:
                 self.ctx.set_option("branches", 1)
 

@@ -127,6 +127,8 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *               the descriptor branch (convDa, convDb) -- they share only the backbone output (-1.7 % per extract).
  *   "comp_rb"   1 (default) / 0: SFD2_PREC_F16C compensates the three ResBlocks as well (descriptors within ~3e-4 of
  *               the fp32 reference); 0 runs them on the fused fp16 ResBlock kernel (~7e-4, still inside 1e-3, and faster).
+ *   "comp_heads" 0 (default) / 1: SFD2_PREC_F16C compensates the four 3x3 layers of the two head branches as well
+ *               (descriptors ~1.5e-4 instead of ~3e-4, key points closer to the reference's list; ~0.25 ms more per image).
  *   "rb_split"  1 (default) .. 8: experiment -- the compensated ResBlocks in that many spatial parts (cache-sized working
  *               set); bit-identical, measured slower (the launches are ramp-bound, not bandwidth-bound).
  *   "no_rf_c"   0 (default) / 1: conv2b of SFD2_PREC_F16C on conv_igemm2<comp> instead of conv3x3_rf<comp> (A/B switch).

@@ -95,6 +95,7 @@ struct sfd2_ctx {
     const half_t *pa_cur = nullptr;    // convPa.3 output of the last fp16 network pass
     const half_t *da_cur = nullptr;    // convDa.3 output of the last fp16 network pass
     int opt_comp_rb = 1;               // sfd2_set_option "comp_rb": SFD2_PREC_F16C compensates the ResBlocks too (0: fused fp16 ResBlock kernel)
+    int opt_comp_heads = 0;            // sfd2_set_option "comp_heads": SFD2_PREC_F16C compensates the 3x3 layers of the two head branches too
     int opt_rb_split = 1;              // sfd2_set_option "rb_split": spatial parts per compensated ResBlock (cache-sized working set); measured slower, off
     int opt_no_rf_c = 0;               // sfd2_set_option "no_rf_c": conv2b on conv_igemm2<comp> instead of conv3x3_rf<comp> (A/B switch)
     int opt_generic_c = 0;             // sfd2_set_option "generic_c": SFD2_PREC_F16C layers on the generic reference kernel (tests)
@@ -687,9 +688,9 @@ static int ensure_workspace(sfd2_ctx *c, int H, int W)
             }
             HIPCHECK(c->ro[b].ensure(P4 * 256 * bb));
         }
-        HIPCHECK(c->pa0_o.ensure(P8 * 256 * hb));
+        HIPCHECK(c->pa0_o.ensure(P8 * 256 * bb));   // (corr planes too with option "comp_heads")
         HIPCHECK(c->pa_o.ensure(P8 * 256 * hb));
-        HIPCHECK(c->da0_o.ensure(P4 * 256 * hb));
+        HIPCHECK(c->da0_o.ensure(P4 * 256 * bb));
         HIPCHECK(c->da_o.ensure(P4 * 256 * hb));
     }
     HIPCHECK(c->logits.ensure(P8 * 128 * sizeof(float)));
@@ -965,7 +966,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
             t1v[0] = slot(0); t2v[0] = slot(1); rov[0] = slot(0);    // x = slot 2
             t1v[1] = slot(2); t2v[1] = slot(1); rov[1] = slot(2);    // x = slot 0
             t1v[2] = slot(0); t2v[2] = slot(1); rov[2] = slot(0);    // x = slot 2 -> final x = slot 0
-            pa0_o = slot(1); pa_o = slot(1, (P8s * 256 * 2 + 255) & ~(size_t)255);
+            pa0_o = slot(1); pa_o = slot(1, (P8s * 256 * 2 * (comp ? 2 : 1) + 255) & ~(size_t)255);   // (convPa.0's corr plane with "comp_heads")
             da0_o = slot(2); da_o = slot(1);   // convDa.3 runs after convPb has consumed slot 1
             if (c->opt_branches) da_o = slot(3);   // the two head branches run concurrently: no slot is shared between them
             // convPb fused into the detector-head kernel: convPa.3's output must outlive the network pass, so convDa.3
@@ -1123,8 +1124,16 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         HIPCHECK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
         c->cur_stream = c->side_stream;
     }
-    conv(c, "convPa.0", c->pa0, *x, H4, W4, pa0_o, H8, W8, 1);
-    conv(c, "convPa.3", c->pa3, pa0_o, H8, W8, pa_o, H8, W8, 0);
+    // option "comp_heads": the four 3x3 layers of the head branches compensated as well (their inputs then need corr planes: the
+    // backbone output has one when the ResBlocks are compensated); convPb / convDb / ConvSta read hi planes either way
+    const bool ch = comp && c->opt_comp_heads && c->opt_comp_rb;
+    if (ch) {
+        convc(c, "convPa.0", c->pa0, *x, H4, W4, pa0_o, H8, W8, 1, true, true);
+        convc(c, "convPa.3", c->pa3, pa0_o, H8, W8, pa_o, H8, W8, 0, true, false);
+    } else {
+        conv(c, "convPa.0", c->pa0, *x, H4, W4, pa0_o, H8, W8, 1);
+        conv(c, "convPa.3", c->pa3, pa0_o, H8, W8, pa_o, H8, W8, 0);
+    }
     c->pa_cur = pa_o.as<half_t>();
     if (!c->skip_pb_now) conv(c, "convPb", c->pb, pa_o, H8, W8, c->logits, H8, W8, 0, nullptr, 1);
     if (!c->skip_head_now) {
@@ -1135,8 +1144,13 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         HIPCHECK(hipEventRecord(c->ev_join, c->side_stream));
         c->cur_stream = st;
     }
-    conv(c, "convDa.0", c->da0, *x, H4, W4, da0_o, H4, W4, 1);
-    conv(c, "convDa.3", c->da3, da0_o, H4, W4, da_o, H4, W4, 0);
+    if (ch) {
+        convc(c, "convDa.0", c->da0, *x, H4, W4, da0_o, H4, W4, 1, true, true);
+        convc(c, "convDa.3", c->da3, da0_o, H4, W4, da_o, H4, W4, 0, true, false);
+    } else {
+        conv(c, "convDa.0", c->da0, *x, H4, W4, da0_o, H4, W4, 1);
+        conv(c, "convDa.3", c->da3, da0_o, H4, W4, da_o, H4, W4, 0);
+    }
     c->da_cur = da_o.as<half_t>();
     if (!c->skip_db_now) conv(c, "convDb", c->db, da_o, H4, W4, c->draw, H4, W4, 0, nullptr, 1);
     if (c->has_sta && !sta_early) {
@@ -2328,6 +2342,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "generic_c") c->opt_generic_c = value ? 1 : 0;
     else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;
     else if (k == "no_rf_c") c->opt_no_rf_c = value ? 1 : 0;
+    else if (k == "comp_heads") c->opt_comp_heads = value ? 1 : 0;
     else if (k == "rb_split") c->opt_rb_split = std::max(1, std::min(value, 8));
     else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;

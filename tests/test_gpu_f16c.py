@@ -315,3 +315,42 @@ def test_f16c_resblock_spatial_split_bit_identical(synth_sd, h, w, topk):
     for o in outs[1:]:
         for k in ("keypoints", "scores", "descriptors"):
             np.testing.assert_array_equal(o[k], outs[0][k])
+
+
+@pytest.fixture(scope="module")
+def model_c_heads(synth_sd):
+    """f16c with option comp_heads = 1: the 3x3 layers of the two head branches compensated as well."""
+    from sfd2_amd.model import ResSegNetV2
+    m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
+    m.load_state_dict(synth_sd)
+    m.cuda(0)
+    m.context.set_option("comp_heads", 1)
+    return m
+
+
+@pytest.mark.parametrize("h,w,seed,topk", [(100, 130, 22, -1), (480, 640, 0, 1024), (1200, 1600, 31, 4096)])
+def test_f16c_compensated_heads_extract_vs_oracle(model_c_heads, synth_sd, h, w, seed, topk):
+    """With the head branches compensated too the conv stack's only fp16-class roundings left are convPb / convDb:
+    descriptors within 5e-4 (CPU-twin prediction 1.3e-4), key-point sets equal up to a handful of near-ties."""
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    img = synth.make_image(h, w, seed)
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk)
+    got = extract_resnet_return(model_c_heads, torch.from_numpy(img)[None].cuda(), conf_th=0.001, topK=topk, scales=[1.0])
+    iou, dd, shift, same, n = _compare(got, want, 0.99)
+    assert dd <= 5e-4, dd
+    _record(f"f16c comp_heads=1 extract {w}x{h} top{topk}: IoU {iou:.4f}, desc {dd:.2e}, same rank {same}/{n}, max rank shift {shift}")
+
+
+def test_f16c_compensated_heads_det_vs_oracle(model_c_heads, synth_sd):
+    x = orc.norm_rgb(synth.make_image(100, 130, 12))
+    taps = {}
+    o_score, o_stab, o_desc = orc.det(synth_sd, x, taps)
+    score, stab, desc = model_c_heads.det(x[None])
+    for name in ("convPa", "convDa"):
+        got = model_c_heads.context.debug_activation(name)
+        err = np.abs(got - taps[name]).max() / np.abs(taps[name]).max()
+        assert err <= 6e-4, (name, err)      # (the branch outputs are stored as plain fp16: half an ulp is up to 4.9e-4 of max)
+    dd = np.abs(desc[0] - o_desc).max()
+    assert dd <= 5e-4, dd
+    _record(f"f16c comp_heads=1 det 130x100: dense desc {dd:.2e}")
