@@ -319,18 +319,14 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
                 const int q = 2 * m + j;
                 const float4 sc = sfd2_lds_f4(SS + cl + 8 * q);
                 const float4 sh = sfd2_lds_f4(SS + 256 + cl + 8 * q);
-                float v0 = acc[4 * q + 0] * sc.x + sh.x;
-                float v1 = acc[4 * q + 1] * sc.y + sh.y;
-                float v2 = acc[4 * q + 2] * sc.z + sh.z;
-                float v3 = acc[4 * q + 3] * sc.w + sh.w;
+                float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (HAS_RES) {
                     h4_t r;
                     __builtin_memcpy(&r, &rp[j], 8);
-                    v0 += (float)r[0] + sfd2_corr_lo(rcp[j].x, 0); v1 += (float)r[1] + sfd2_corr_lo(rcp[j].x, 1);
-                    v2 += (float)r[2] + sfd2_corr_lo(rcp[j].y, 0); v3 += (float)r[3] + sfd2_corr_lo(rcp[j].y, 1);
+                    ad = make_float4((float)r[0] + sfd2_corr_lo(rcp[j].x, 0), (float)r[1] + sfd2_corr_lo(rcp[j].x, 1),
+                                     (float)r[2] + sfd2_corr_lo(rcp[j].y, 0), (float)r[3] + sfd2_corr_lo(rcp[j].y, 1));
                 }
-                if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
-                sfd2_split4(v0, v1, v2, v3, pk[j], ck[j]);
+                sfd2_epi4<HAS_RES>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], sc, sh, ad, relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j]);
             }
             const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
             const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);

@@ -354,6 +354,18 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                         const int q = 2 * m + j;
                         const float4 sc = SS_LDS ? *reinterpret_cast<const float4 *>(SS + cl + 8 * q) : *reinterpret_cast<const float4 *>(scale + n0 + cl + 8 * q);
                         const float4 sh = SS_LDS ? *reinterpret_cast<const float4 *>(SS + BN + cl + 8 * q) : *reinterpret_cast<const float4 *>(shift + n0 + cl + 8 * q);
+                        if (COMP & 2) {   // compensated output: packed-fp32 epilogue, one med3 per value (sfd2_internal.h)
+                            float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (HAS_RES) {
+                                h4_t r;
+                                __builtin_memcpy(&r, &rq[j], 8);
+                                ad = make_float4((float)r[0] + sfd2_corr_lo(rcq[j].x, 0), (float)r[1] + sfd2_corr_lo(rcq[j].x, 1),
+                                                 (float)r[2] + sfd2_corr_lo(rcq[j].y, 0), (float)r[3] + sfd2_corr_lo(rcq[j].y, 1));
+                            }
+                            sfd2_epi4<HAS_RES>(acc[ct][pr][4 * q + 0], acc[ct][pr][4 * q + 1], acc[ct][pr][4 * q + 2], acc[ct][pr][4 * q + 3], sc, sh, ad,
+                                               relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j]);
+                            continue;
+                        }
                         float v0 = acc[ct][pr][4 * q + 0] * sc.x + sh.x;
                         float v1 = acc[ct][pr][4 * q + 1] * sc.y + sh.y;
                         float v2 = acc[ct][pr][4 * q + 2] * sc.z + sh.z;

@@ -323,14 +323,15 @@ _Pragma("unroll") \
                     const int q = 2 * m + j;
                     const float4 sc = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
                     const float4 sh = *reinterpret_cast<const float4 *>(SS + PP_BN + cl + 8 * q);
-                    float v0 = acc[ct][pr][4 * q + 0] * sc.x + sh.x;
-                    float v1 = acc[ct][pr][4 * q + 1] * sc.y + sh.y;
-                    float v2 = acc[ct][pr][4 * q + 2] * sc.z + sh.z;
-                    float v3 = acc[ct][pr][4 * q + 3] * sc.w + sh.w;
-                    v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
                     if (COMP & 2) {
-                        sfd2_split4(v0, v1, v2, v3, pk[j], ck[j]);
+                        sfd2_epi4<false>(acc[ct][pr][4 * q + 0], acc[ct][pr][4 * q + 1], acc[ct][pr][4 * q + 2], acc[ct][pr][4 * q + 3], sc, sh,
+                                         sc, relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j]);
                     } else {
+                        float v0 = acc[ct][pr][4 * q + 0] * sc.x + sh.x;
+                        float v1 = acc[ct][pr][4 * q + 1] * sc.y + sh.y;
+                        float v2 = acc[ct][pr][4 * q + 2] * sc.z + sh.z;
+                        float v3 = acc[ct][pr][4 * q + 3] * sc.w + sh.w;
+                        v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
                         const h4_t hv = cvt4c(v0, v1, v2, v3);
                         __builtin_memcpy(&pk[j], &hv, 8);
                     }

@@ -366,14 +366,15 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int q = 2 * m + j;
-                    float v0 = acc[f][4 * q + 0] * sc[q].x + sh[q].x;
-                    float v1 = acc[f][4 * q + 1] * sc[q].y + sh[q].y;
-                    float v2 = acc[f][4 * q + 2] * sc[q].z + sh[q].z;
-                    float v3 = acc[f][4 * q + 3] * sc[q].w + sh[q].w;
-                    v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
                     if constexpr ((COMP & 2) != 0) {
-                        sfd2_split4(v0, v1, v2, v3, pk[j], ck[j]);
+                        sfd2_epi4<false>(acc[f][4 * q + 0], acc[f][4 * q + 1], acc[f][4 * q + 2], acc[f][4 * q + 3], sc[q], sh[q], sc[q],
+                                         relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j]);
                     } else {
+                        float v0 = acc[f][4 * q + 0] * sc[q].x + sh[q].x;
+                        float v1 = acc[f][4 * q + 1] * sc[q].y + sh[q].y;
+                        float v2 = acc[f][4 * q + 2] * sc[q].z + sh[q].z;
+                        float v3 = acc[f][4 * q + 3] * sc[q].w + sh[q].w;
+                        v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
                         const h4_t hv = cvt4r(v0, v1, v2, v3);
                         __builtin_memcpy(&pk[j], &hv, 8);
                     }

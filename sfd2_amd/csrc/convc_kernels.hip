@@ -207,8 +207,10 @@ void convc_igemm_kernel(const half_t *__restrict__ in, const half_t *__restrict_
                             v2 += sfd2_corr_lo(rc.y, 0); v3 += sfd2_corr_lo(rc.y, 1);
                         }
                     }
-                    if (relu) {
-                        v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
+                    {   // ReLU and the saturation of compensated tensors at +-SFD2_C_SAT in one (as sfd2_epi4 in the tuned kernels)
+                        const float lo = relu ? 0.0f : -SFD2_C_SAT;
+                        v0 = __builtin_amdgcn_fmed3f(v0, lo, SFD2_C_SAT); v1 = __builtin_amdgcn_fmed3f(v1, lo, SFD2_C_SAT);
+                        v2 = __builtin_amdgcn_fmed3f(v2, lo, SFD2_C_SAT); v3 = __builtin_amdgcn_fmed3f(v3, lo, SFD2_C_SAT);
                     }
                     uint2 hv, cv;
                     sfd2_split4(v0, v1, v2, v3, hv, cv);
@@ -369,10 +371,10 @@ void conv1a_c_kernel(const float *__restrict__ img, int H, int W, int normalise,
                     const int c0 = ct * 32 + 8 * q + 4 * lg;
                     const float4 sc = *reinterpret_cast<const float4 *>(scale + c0);
                     const float4 sh = *reinterpret_cast<const float4 *>(shift + c0);
-                    const float v0 = fmaxf(acc[ct][pr][4 * q + 0] * sc.x + sh.x, 0.0f);
-                    const float v1 = fmaxf(acc[ct][pr][4 * q + 1] * sc.y + sh.y, 0.0f);
-                    const float v2 = fmaxf(acc[ct][pr][4 * q + 2] * sc.z + sh.z, 0.0f);
-                    const float v3 = fmaxf(acc[ct][pr][4 * q + 3] * sc.w + sh.w, 0.0f);
+                    const float v0 = __builtin_amdgcn_fmed3f(acc[ct][pr][4 * q + 0] * sc.x + sh.x, 0.0f, SFD2_C_SAT);
+                    const float v1 = __builtin_amdgcn_fmed3f(acc[ct][pr][4 * q + 1] * sc.y + sh.y, 0.0f, SFD2_C_SAT);
+                    const float v2 = __builtin_amdgcn_fmed3f(acc[ct][pr][4 * q + 2] * sc.z + sh.z, 0.0f, SFD2_C_SAT);
+                    const float v3 = __builtin_amdgcn_fmed3f(acc[ct][pr][4 * q + 3] * sc.w + sh.w, 0.0f, SFD2_C_SAT);
                     uint2 hv, cv;
                     sfd2_split4(v0, v1, v2, v3, hv, cv);
                     *reinterpret_cast<uint2 *>(out + pix * 64 + c0) = hv;
@@ -499,8 +501,7 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
             uint2 pk[2], ck[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                sfd2_split4(fmaxf(acc[t + j][0] * sc.x + sh.x, 0.0f), fmaxf(acc[t + j][1] * sc.y + sh.y, 0.0f),
-                            fmaxf(acc[t + j][2] * sc.z + sh.z, 0.0f), fmaxf(acc[t + j][3] * sc.w + sh.w, 0.0f), pk[j], ck[j]);
+                sfd2_epi4<false>(acc[t + j][0], acc[t + j][1], acc[t + j][2], acc[t + j][3], sc, sh, sc, 0.0f, pk[j], ck[j]);
             const bool odd = g & 1;
             const uint2 send = odd ? pk[0] : pk[1], sendc = odd ? ck[0] : ck[1];
             uint2 recv, recvc;

@@ -48,6 +48,18 @@ __device__ __forceinline__ float sc_div_const(float a, float d, float r)   // se
 
 #define SC_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// -DSFD2_STEMC_TRACE: cycle stamps of one block's waves 0 and 7 at the section boundaries of its first tiles, printed by the
+// launcher after a few launches
+#ifdef SFD2_STEMC_TRACE
+#include <stdio.h>
+__device__ unsigned long long g_stemc_trace[2][16][12];
+#define SC_STAMP(k_)                                                                          \
+    if (blockIdx.x == 3 && (wave == 0 || wave == 7) && lane == 0 && tcount < 16)              \
+        g_stemc_trace[wave == 7][tcount][k_] = __builtin_readcyclecounter();
+#else
+#define SC_STAMP(k_)
+#endif
+
 __global__ __launch_bounds__(SC_NT, 2)
 void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normalise,
                          const half_t *__restrict__ w1 /*[2 hi/lo][2][3][64][8] conv1a A fragments*/,
@@ -164,17 +176,18 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
     constexpr int P1_UNITS = ((SC_RP + 31) / 32 + 3) / 4;
     const int p1_n = ((SC_RP + 31) / 32 - kg + 3) / 4;
     int p1_im[P1_UNITS], p1_x[P1_UNITS], p1_yx[P1_UNITS];
-    unsigned p1_ok = 0;
 #pragma unroll
     for (int i = 0; i < P1_UNITS; ++i) {
         const int p = (kg + 4 * i) * 32 + lrow;
+        // the lanes past the region's last pixel (the last block has 9 of 32) compute that last pixel again and store the
+        // same bytes to the same place: no predicate around the stores, so the four channel quads of a unit are ONE
+        // straight-line block (predicated, each quad was its own exec-masked block with its LDS round trips exposed)
         const int pc = p < SC_RP ? p : SC_RP - 1;
         const int ry = pc / SC_RW, rx = pc - ry * SC_RW;
-        if (p < SC_RP) p1_ok |= 1u << i;
         p1_yx[i] = (ry << 8) | rx;
         p1_im[i] = (ry * SC_IW + rx + 2 * lhi) * 4;                      // halfs
         // byte offset of this lane's 8 bytes of channel quad 0 in the pixel's record, swizzle of the record folded in per quad below
-        p1_x[i] = ((p ^ ((p >> 4) & 1)) * 128 + 8 * lhi) | (((p >> 1) & 7) << 20);
+        p1_x[i] = ((pc ^ ((pc >> 4) & 1)) * 128 + 8 * lhi) | (((pc >> 1) & 7) << 20);
     }
 
     int tile = blockIdx.x;
@@ -182,19 +195,41 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
     SC_STORE_IMG()
     if (tile + (int)gridDim.x < n_tiles) SC_FETCH_IMG(tile + (int)gridDim.x)
     SFD2_BARRIER_DRAIN();
+    // (the first tile's conv1a filters have landed behind that drain; tell the wait-count bookkeeping so -- merged with the
+    // loop's back edge, a still-pending prologue load would turn the first MFMA of EVERY tile into a wait that also covers
+    // the previous tile's stores and the image request in flight)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) asm volatile("" : "+v"(a1h[ky]), "+v"(a1l[ky]));
 
-    for (;;) {
+    int tcount = 0;
+    (void)tcount;
+    for (;; ++tcount) {
+        SC_STAMP(0)
         const int tx = tile % tiles_x, ty = tile / tiles_x;
         const int oy0 = ty * SC_TH, ox0 = tx * SC_TW;
         const int ry0 = 2 * oy0 - 1, rx0 = 2 * ox0 - 1;
 
         // ---- phase 1: conv1a -> X1h / X1c
+        // conv1a's scale / shift of this wave's channels: read once per tile (they must not be live across phase 2)
+        float4 s1[4], h1[4];
+        {
+            int sso = cth * 32 + 4 * lhi;
+            asm volatile("" : "+v"(sso));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s1[q] = sfd2_lds_f4(SS + sso + 8 * q);
+                h1[q] = sfd2_lds_f4(SS + 64 + sso + 8 * q);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < P1_UNITS; ++i) {
             if (i < p1_n) {
                 f32x16_t acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#ifdef SFD2_STEMC_ACC3
+                f32x16_t accb = acc, accc = acc;   // (experiment: one accumulator chain per pass)
+#endif
                 // per-lane offsets are recomputed from one opaque register per unit: hoisted out of the tile loop (they are all
                 // tile-invariant) they are ~100 registers, spilled and reloaded behind s_waitcnt vmcnt(0)
                 int imo = p1_im[i];
@@ -215,35 +250,48 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                         bl[0] = lo[0]; bl[1] = lo[1]; bl[2] = lo[2]; bl[3] = lo[3];
                         bl[4] = hi[0]; bl[5] = hi[1]; bl[6] = hi[2]; bl[7] = hi[3];
                     }
+#ifdef SFD2_STEMC_ACC3
+                    accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l[ky], bh, accb, 0, 0, 0);
+                    accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[ky], bl, accc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[ky], bh, acc, 0, 0, 0);
+#else
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l[ky], bh, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[ky], bl, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[ky], bh, acc, 0, 0, 0);
+#endif
                 }
+#ifdef SFD2_STEMC_ACC3
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += accb[r] + accc[r];
+#endif
                 // conv1b zero-pads conv1a's OUTPUT: region pixels outside the image are zeros, not conv1a(0)
                 const int gy = ry0 + (p1_yx[i] >> 8), gx = rx0 + (p1_yx[i] & 255);
                 const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                // (interior tiles: a wave-uniform flag lets the selects below fold away)
+                const bool all_inside = __builtin_amdgcn_ballot_w64(!inside) == 0;
                 int xo = p1_x[i] & 0xFFFFF, xsw = (p1_x[i] >> 20) << 4;
                 asm volatile("" : "+v"(xo), "+v"(xsw));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 s = sfd2_lds_f4(SS + cth * 32 + 8 * q + 4 * lhi);
-                    const float4 h = sfd2_lds_f4(SS + 64 + cth * 32 + 8 * q + 4 * lhi);
                     uint2 hv, cv;
-                    sfd2_split4(fmaxf(acc[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(acc[4 * q + 1] * s.y + h.y, 0.0f),
-                                fmaxf(acc[4 * q + 2] * s.z + h.z, 0.0f), fmaxf(acc[4 * q + 3] * s.w + h.w, 0.0f), hv, cv);
-                    if (!inside) { hv = make_uint2(0u, 0u); cv = make_uint2(0u, 0u); }
-                    if (p1_ok & (1u << i)) {
+                    sfd2_epi4<false>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], s1[q], h1[q], s1[q], 0.0f, hv, cv);
+                    if (!all_inside && !inside) { hv = make_uint2(0u, 0u); cv = make_uint2(0u, 0u); }
+                    {
                         const int o = xo + (((cth * 4 + q) << 4) ^ xsw);
                         *reinterpret_cast<uint2 *>(X1h + o) = hv;
                         *reinterpret_cast<uint2 *>(X1c + o) = cv;
                     }
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);   // (units are not interleaved: the resident conv1b filters leave no registers for it)
+#ifdef SFD2_STEMC_SCHEDB
+            __builtin_amdgcn_sched_barrier(0);   // (experiment: units not interleaved)
+#endif
         }
         const int next = tile + (int)gridDim.x, next2 = next + (int)gridDim.x;
         const bool has_next = next < n_tiles;
+        SC_STAMP(1)
         SC_LDS_BARRIER();                     // X1 complete; IM is free from here on
+        SC_STAMP(2)
 
         // ---- phase 2: partial sums of conv1b over this wave's units, all four output rows
         f32x16_t acc2[SC_TH];
@@ -277,7 +325,9 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
 #pragma unroll
         for (int r = 0; r < SC_TH; ++r) asm volatile("" : "+v"(acc2[r]));
         if (has_next) SC_LOAD_A1()            // conv1a filters of the next tile's phase 1
+        SC_STAMP(3)
         SC_LDS_BARRIER();                     // every wave is done reading X1
+        SC_STAMP(4)
 
         // ---- phase 3: this wave's partials of all four rows -> LDS (its own row too: phase 4 then reads four tiles in a
         // fixed order with static register indices)
@@ -288,8 +338,17 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
             for (int q = 0; q < 4; ++q)
                 *reinterpret_cast<float4 *>(pt + q * 256) = make_float4(acc2[r][4 * q], acc2[r][4 * q + 1], acc2[r][4 * q + 2], acc2[r][4 * q + 3]);
         }
+        SC_STAMP(5)
         SC_LDS_BARRIER();                     // partials visible
+        SC_STAMP(6)
 
+        // The conv1a filters requested after phase 2 are taken into registers HERE, where they are the only vector-memory
+        // operations in flight: left to the first MFMA of the next tile's phase 1, hipcc waits for them with vmcnt(0) behind
+        // this tile's output stores and the image request of the tile after next (one exposed memory latency per tile).
+        if (has_next) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) asm volatile("" : "+v"(a1h[ky]), "+v"(a1l[ky]));
+        }
         // ---- phase 4: row kg of this wave's channel half = partials of groups 0, 1, 2, 3 added in that order
         f32x16_t tot;
         {
@@ -305,7 +364,9 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
             }
         }
 
+        SC_STAMP(7)
         if (has_next) SC_STORE_IMG()          // the next tile's patch (requested a tile ago) -> IM, in front of the output stores
+        SC_STAMP(8)
         const int oy = oy0 + kg, ox = ox0 + lrow;
         const bool inb = oy < H2 && ox < W2;
         const size_t ob = ((size_t)(inb ? oy : 0) * W2 + (inb ? ox : 0)) * 64;
@@ -318,8 +379,7 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                 const int c0 = cth * 32 + 8 * q + 4 * lhi;
                 const float4 s = sfd2_lds_f4(SS + 128 + c0);
                 const float4 h = sfd2_lds_f4(SS + 192 + c0);
-                sfd2_split4(fmaxf(tot[4 * q + 0] * s.x + h.x, 0.0f), fmaxf(tot[4 * q + 1] * s.y + h.y, 0.0f),
-                            fmaxf(tot[4 * q + 2] * s.z + h.z, 0.0f), fmaxf(tot[4 * q + 3] * s.w + h.w, 0.0f), pk[j], ck[j]);
+                sfd2_epi4<false>(tot[4 * q + 0], tot[4 * q + 1], tot[4 * q + 2], tot[4 * q + 3], s, h, s, 0.0f, pk[j], ck[j]);
             }
             const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
             const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
@@ -331,9 +391,12 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                 *reinterpret_cast<uint4 *>(out_c + o) = make_uint4(u0s[0], u1s[0], u0s[1], u1s[1]);
             }
         }
+        SC_STAMP(9)
         if (!has_next) break;
         if (next2 < n_tiles) SC_FETCH_IMG(next2)
+        SC_STAMP(10)
         SC_LDS_BARRIER();                     // IM complete; every wave is done with the partials (phase 1 writes X1 again)
+        SC_STAMP(11)
         tile = next;
     }
 #undef SC_LOAD_A1
@@ -361,4 +424,21 @@ void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int nor
     hipLaunchKernelGGL(fused_stem_c_kernel, dim3(grid), dim3(SC_NT), SC_LDS, st, img, H, W, normalise, w1, sc1, sh1,
                        reinterpret_cast<const unsigned char *>(w2), sc2, sh2, out, out_c, H2, W2, tiles_x, n_tiles,
                        (sbyte & 255) * 0x01010101);
+#ifdef SFD2_STEMC_TRACE
+    {
+        static int dumps = 0;
+        if (H >= 1000 && ++dumps == 40) {
+            (void)hipStreamSynchronize(st);
+            static unsigned long long h[2][16][12];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stemc_trace), sizeof(h));
+            fprintf(stderr, "stemc columns: phase 1 | B1 wait | phase 2 (+A1 reload issue) | B2 wait | phase 3 partial writes | B3 wait | phase 4 sum | image -> LDS | epilogue + stores | fetch issue | B4 wait\n");
+            for (int w = 0; w < 2; ++w)
+                for (int t = 2; t < 10; ++t) {
+                    fprintf(stderr, "stemc wave %d tile %2d:", w * 7, t);
+                    for (int k = 1; k < 12; ++k) fprintf(stderr, " %6lld", (long long)(h[w][t][k] - h[w][t][k - 1]));
+                    fprintf(stderr, "  (tile %lld)\n", (long long)(h[w][t + 1][0] - h[w][t][0]));
+                }
+        }
+    }
+#endif
 }

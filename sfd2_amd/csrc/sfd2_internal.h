@@ -52,6 +52,8 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // The scale is uniform over K (E8M0 byte 127 - 9 - b0 on the A operand), so no block layout of the scales matters; and
 // because A and B map lane bytes to K identically, any arrangement of a chunk's 64 bytes is valid as long as filters
 // and pixels use the same one -- the corr records are read with exactly the addresses of the fp16 records.
+// Compensated tensors SATURATE at +-1792 (SFD2_C_SAT; the plain fp16 path: +-65504): with the value bounded neither corr
+// byte can overflow fp8's 448, and the bound costs nothing (it is the third operand of the ReLU's v_med3_f32).
 #define SFD2_C_XL_SHIFT 9            // corr unit byte 0: fp8((x - hi) * 2^9)
 #define SFD2_C_XH_SCALE 0.25f        // corr unit byte 1: fp8(x * 2^-2)
 typedef int v8i_t __attribute__((ext_vector_type(8)));
@@ -98,6 +100,39 @@ __device__ __forceinline__ void sfd2_split4(float v0, float v1, float v2, float 
     __builtin_memcpy(&hv, &h, 8);
     cv.x = sfd2_corr2(v0, h[0], v1, h[1]);
     cv.y = sfd2_corr2(v2, h[2], v3, h[3]);
+}
+// The epilogue of a compensated layer for four consecutive channels, written for the VALU budget (the compensated stem's
+// conv1a phase was bound by it: 216 VALU per 16 outputs): y = acc * scale + shift (+ add) as packed-fp32 FMAs / adds
+// (v_pk_fma_f32 / v_pk_add_f32), ONE v_med3_f32 per value that is both the ReLU (lo = 0; lo = -SFD2_C_SAT without) and the
+// saturation of the compensated tensors at +-1792 -- with the value bounded, its fp16 residual (<= 0.5) and its quarter
+// (<= 448) need no clamps of their own in front of v_cvt_pk_fp8_f32 (which returns NaN above 464) -- then packed multiplies
+// for the two unit scalings.  Identical results to sfd2_split4 behind a scalar epilogue for |y| <= 1792.
+#define SFD2_C_SAT 1792.0f
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned sfd2_corr2v(f32x2_t v, h2_t h)
+{
+    const f32x2_t hf = {(float)h[0], (float)h[1]};
+    const f32x2_t l = (v - hf) * (float)(1 << SFD2_C_XL_SHIFT);
+    const f32x2_t x = v * SFD2_C_XH_SCALE;
+    int d = __builtin_amdgcn_cvt_pk_fp8_f32(l[0], x[0], 0, false);
+    d = __builtin_amdgcn_cvt_pk_fp8_f32(l[1], x[1], d, true);
+    return (unsigned)d;
+}
+template <bool ADD>
+__device__ __forceinline__ void sfd2_epi4(float a0, float a1, float a2, float a3, float4 sc, float4 sh, float4 add, float lo,
+                                          uint2 &hv, uint2 &cv)
+{
+    f32x2_t v01 = f32x2_t{a0, a1} * f32x2_t{sc.x, sc.y} + f32x2_t{sh.x, sh.y};
+    f32x2_t v23 = f32x2_t{a2, a3} * f32x2_t{sc.z, sc.w} + f32x2_t{sh.z, sh.w};
+    if (ADD) { v01 += f32x2_t{add.x, add.y}; v23 += f32x2_t{add.z, add.w}; }
+    v01[0] = __builtin_amdgcn_fmed3f(v01[0], lo, SFD2_C_SAT); v01[1] = __builtin_amdgcn_fmed3f(v01[1], lo, SFD2_C_SAT);
+    v23[0] = __builtin_amdgcn_fmed3f(v23[0], lo, SFD2_C_SAT); v23[1] = __builtin_amdgcn_fmed3f(v23[1], lo, SFD2_C_SAT);
+    const h2_t h01 = {(half_t)v01[0], (half_t)v01[1]}, h23 = {(half_t)v23[0], (half_t)v23[1]};
+    __builtin_memcpy(&hv.x, &h01, 4);
+    __builtin_memcpy(&hv.y, &h23, 4);
+    cv.x = sfd2_corr2v(v01, h01);
+    cv.y = sfd2_corr2v(v23, h23);
 }
 // the residual (x - hi) two corr units of a dword carry, as floats
 __device__ __forceinline__ float sfd2_corr_lo(unsigned d, int ch /*0 or 1*/)
