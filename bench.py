@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--precision", default="f16c", choices=["f16c", "f16"], help="mode of the headline legs (default f16c: the "
                     "tolerance-conformant throughput mode; f16 = the 3e-3 approximation, for kernel A/Bs of that path)")
     ap.add_argument("--comp-heads", type=int, default=0, help="f16c option comp_heads (1: the head branches' 3x3 layers compensated as well)")
+    ap.add_argument("--rb-inner", type=int, default=2, help="f16c option rb_inner (2: the tensors inside the ResBlocks plain fp16, the shipped default; "
+                    "1: only the grouped conv's output; 0: both compensated, descriptors <= 3.5e-4)")
     ap.add_argument("--comp-rb", type=int, default=1, help="f16c option comp_rb (0: ResBlocks on the fused fp16 kernel; descriptors ~7e-4)")
     ap.add_argument("--mix", action="store_true", help="every fifth query image in portrait orientation (SURVEY C2: the Aachen query set "
                     "is ~80 %% landscape / 20 %% portrait); the hipGraph cache then holds two geometries per stream")
@@ -255,6 +257,8 @@ def main():
                 self.ctx.set_option("graphs", 1)
             if args.precision == "f16c" and not args.comp_rb:
                 self.ctx.set_option("comp_rb", 0)
+            if args.precision == "f16c" and args.rb_inner != 2:
+                self.ctx.set_option("rb_inner", args.rb_inner)
             if args.precision == "f16c" and args.comp_heads:
                 self.ctx.set_option("comp_heads", 1)
             if args.branches:
@@ -487,8 +491,9 @@ def main():
             "roofline": roof, "kernel_ms_per_step": breakdown, "device_ms_per_step": round(total_ms, 4),
             "mutual_matches_last_step": n_matched,
             "parity": ({"mode": "f16c: compensated fp16 (fp16 MFMA + one block-scaled fp8 MFMA of the rounding residuals per 32 channels, fp32 accumulate)"
-                                + ("" if args.comp_rb else "; option comp_rb = 0 (ResBlocks plain fp16)"),
-                        "descriptors_max_abs": "<= 1e-3 asserted = north_star's tolerance (measured " + ("<= 3.5e-4" if args.comp_rb else "<= 8.1e-4") + " at 480x640 .. 2048x1536)",
+                                + (f"; backbone compensated, tensors inside the ResBlocks per option rb_inner = {args.rb_inner}" if args.comp_rb else "; option comp_rb = 0 (ResBlocks plain fp16)"),
+                        "descriptors_max_abs": "<= 1e-3 asserted = north_star's tolerance (measured "
+                                               + (("<= 4.9e-4", "<= 3.8e-4", "<= 3.5e-4")[2 - max(0, min(2, args.rb_inner))] if args.comp_rb else "<= 8.1e-4") + " at 480x640 .. 2048x1536)",
                         "keypoint_set_iou": ">= 0.985 asserted (measured 0.997 - 1.0)" if args.comp_rb else ">= 0.97 asserted (measured 0.991 - 0.996)",
                         "selection_given_heat_map": "bit-exact", "asserted_in": "tests/test_gpu_f16c.py",
                         "measured_in": "profiles/r03*_f16c_parity_measured.txt"} if args.precision == "f16c" else

@@ -127,10 +127,12 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *               the descriptor branch (convDa, convDb) -- they share only the backbone output (-1.7 % per extract).
  *   "comp_rb"   1 (default) / 0: SFD2_PREC_F16C compensates the three ResBlocks as well (descriptors within ~3e-4 of
  *               the fp32 reference); 0 runs them on the fused fp16 ResBlock kernel (~7e-4, still inside 1e-3, and faster).
+ *   "rb_inner"  2 (default) / 1 / 0: SFD2_PREC_F16C stores the tensors INSIDE the ResBlocks as plain fp16 (1: the grouped
+ *               conv's output, 2: conv1's output too, 0: both compensated); the block's input / output / skip path and all
+ *               filters stay compensated.  These layers are bound by HBM bytes: 1.82 / 1.75 / 1.67 ms per 1600x1200 extract
+ *               for 0 / 1 / 2, descriptors <= 3.5e-4 / 3.8e-4 / 4.9e-4 (tests assert 7e-4 for 1 and 2, 1e-3 everywhere).
  *   "comp_heads" 0 (default) / 1: SFD2_PREC_F16C compensates the four 3x3 layers of the two head branches as well
  *               (descriptors ~1.5e-4 instead of ~3e-4, key points closer to the reference's list; ~0.25 ms more per image).
- *   "rb_split"  1 (default) .. 8: experiment -- the compensated ResBlocks in that many spatial parts (cache-sized working
- *               set); bit-identical, measured slower (the launches are ramp-bound, not bandwidth-bound).
  *   "no_rf_c"   0 (default) / 1: conv2b of SFD2_PREC_F16C on conv_igemm2<comp> instead of conv3x3_rf<comp> (A/B switch).
  *   "generic_c" 0 (default) / 1: SFD2_PREC_F16C layers all run on the generic compensated kernel (the reference
  *               implementation of that arithmetic) instead of the tuned kernels' compensated instantiations; the two

@@ -199,7 +199,10 @@ void launch_conv1x1_c256(hipStream_t st, const half_t *in, int npix, const half_
 #define GPXC 32
 #define STAGE_C (2 * GPXC * 512)
 
-template <bool HAS_RES>
+// IN_C = false: the input is a plain fp16 tensor (ResBlock-internal tensors under option "rb_inner", sfd2_api.hip): no corr
+// plane to stage, and the filter residuals arrive as fp16 (w - fp16(w)) * 2^11 (`wc` = [256][256] halves) for a second fp16
+// pass into its own accumulator.  OUT_C = false: only the hi plane is written.
+template <bool HAS_RES, bool IN_C, bool OUT_C>
 __global__ __launch_bounds__(NT1, 2)
 void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in_c, int npix,
                            const half_t *__restrict__ w /*[256 out][256 in] fp16*/, const half_t *__restrict__ wc /*[256][256] corr units*/,
@@ -222,7 +225,7 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
     if (g0 >= g1) return;
 
     h8_t ah[16];
-    v8i_t ac[8];
+    v8i_t ac[8];               // IN_C: corr units; otherwise the 16 fp16 fragments of the scaled filter residuals, two per entry
     {
         const size_t ro = (size_t)(wave * 32 + lrow) * 256 + lhi * 8;
 #pragma unroll
@@ -243,13 +246,15 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
             const long long gp = (long long)(g_)*GPXC + p;                                                 \
             const size_t so = (size_t)gp * 256 + ((lrow ^ (p & 31)) << 3);                                 \
             const half_t *s0 = gp < npix ? in + so : zero_page + (lrow << 3);                              \
-            const half_t *s1 = gp < npix ? in_c + so : zero_page + (lrow << 3);                            \
             __builtin_amdgcn_global_load_lds((gbl_void_t *)s0, (lds_void_t *)(st + ch * 1024), 16, 0, 0);  \
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)s1, (lds_void_t *)(st + GPXC * 512 + ch * 1024), 16, 0, 0); \
+            if (IN_C) {                                                                                    \
+                const half_t *s1 = gp < npix ? in_c + so : zero_page + (lrow << 3);                        \
+                __builtin_amdgcn_global_load_lds((gbl_void_t *)s1, (lds_void_t *)(st + GPXC * 512 + ch * 1024), 16, 0, 0); \
+            }                                                                                              \
         }                                                                                                  \
     }
 #define WAIT_GROUP_C()                                                                                     \
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(HAS_RES ? 12 : 8) : "memory")
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((IN_C ? 4 : 2) + (OUT_C ? 4 : 2) + (HAS_RES ? 4 : 0)) : "memory")
 
     ISSUE_GC(g0)
     if (g0 + 1 < g1) { ISSUE_GC(g0 + 1) }
@@ -286,18 +291,29 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         const unsigned char *xp = st + p * 512;
         const int sw = p & 31;
+        f32x16_t acl;
+        if (!IN_C) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acl[r] = 0.0f;
+        }
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const h8_t b = *reinterpret_cast<const h8_t *>(xp + (((kk * 2 + lhi) ^ sw) << 4));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], b, acc, 0, 0, 0);
+            if (!IN_C) acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(sfd2_half8(ac[kk >> 1], kk & 1), b, acl, 0, 0, 0);
         }
+        if (IN_C) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const v8i_t b = sfd2_cat8(*reinterpret_cast<const h8_t *>(xp + GPXC * 512 + (((c * 4 + lhi) ^ sw) << 4)),
-                                      *reinterpret_cast<const h8_t *>(xp + GPXC * 512 + (((c * 4 + 2 + lhi) ^ sw) << 4)));
-            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ac[c], b, acc, 0, 0, 0, sa, 0, 0x7f7f7f7f);
+            for (int c = 0; c < 8; ++c) {
+                const v8i_t b = sfd2_cat8(*reinterpret_cast<const h8_t *>(xp + GPXC * 512 + (((c * 4 + lhi) ^ sw) << 4)),
+                                          *reinterpret_cast<const h8_t *>(xp + GPXC * 512 + (((c * 4 + 2 + lhi) ^ sw) << 4)));
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ac[c], b, acc, 0, 0, 0, sa, 0, 0x7f7f7f7f);
+            }
+            asm volatile("" : "+v"(acc));   // (the scaled MFMA is a pure node to instruction selection: keep it in front of the epilogue)
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(acl[r], 1.0f / 2048.0f, acc[r]);
         }
-        asm volatile("" : "+v"(acc));   // (the scaled MFMA is a pure node to instruction selection: keep it in front of the epilogue)
 
         const int cl = wave * 32 + 4 * lhi;
 #pragma unroll
@@ -330,11 +346,11 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
             }
             const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
             const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
-            const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
-            const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
-            if (inb) {
-                *reinterpret_cast<uint4 *>(out + obase + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
-                *reinterpret_cast<uint4 *>(out_c + obase + 8 * (2 * m + lhi)) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
+            if (inb) *reinterpret_cast<uint4 *>(out + obase + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+            if (OUT_C) {
+                const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
+                const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
+                if (inb) *reinterpret_cast<uint4 *>(out_c + obase + 8 * (2 * m + lhi)) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
             }
         }
     }
@@ -345,13 +361,15 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
 void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c, int npix, const half_t *w_rowmajor,
                            const half_t *wc_rowmajor, const float *scale, const float *shift, int relu, const half_t *res,
                            const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte)
+// in_c == null: plain fp16 input, wc_rowmajor = the fp16 filter residuals * 2^11; out_c == null: only the hi plane is written
 {
     static bool attr_done = false;
     static int slots = 256;
     const size_t lds = (size_t)NST * STAGE_C + 512 * sizeof(float);
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_c256_c_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_c256_c_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#define C256C_ATTR(R_, I_, O_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_c256_c_kernel<R_, I_, O_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        C256C_ATTR(true, true, true) C256C_ATTR(false, true, true) C256C_ATTR(false, true, false) C256C_ATTR(true, false, true)
+#undef C256C_ATTR
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
@@ -363,6 +381,10 @@ void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c,
     const int gpb = (ngroups + slots - 1) / slots;
     const int grid = (ngroups + gpb - 1) / gpb;
     const int sa = (sbyte & 255) * 0x01010101;
-    if (res) hipLaunchKernelGGL(conv1x1_c256_c_kernel<true>, dim3(grid), dim3(NT1), lds, st, in, in_c, npix, w_rowmajor, wc_rowmajor, scale, shift, relu, res, res_c, out, out_c, gpb, zero_page, sa);
-    else hipLaunchKernelGGL(conv1x1_c256_c_kernel<false>, dim3(grid), dim3(NT1), lds, st, in, in_c, npix, w_rowmajor, wc_rowmajor, scale, shift, relu, res, res_c, out, out_c, gpb, zero_page, sa);
+#define C256C_GO(R_, I_, O_) hipLaunchKernelGGL((conv1x1_c256_c_kernel<R_, I_, O_>), dim3(grid), dim3(NT1), lds, st, in, in_c, npix, w_rowmajor, wc_rowmajor, scale, shift, relu, res, res_c, out, out_c, gpb, zero_page, sa)
+    if (in_c && out_c) { if (res) C256C_GO(true, true, true); else C256C_GO(false, true, true); }
+    else if (in_c && !res) C256C_GO(false, true, false);           // ResBlock.conv1 writing a plain t1
+    else if (!in_c && out_c && res) C256C_GO(true, false, true);   // ResBlock.conv3 reading a plain t2
+    else abort();                                                   // no other combination is dispatched
+#undef C256C_GO
 }

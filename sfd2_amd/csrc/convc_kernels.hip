@@ -403,6 +403,10 @@ void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normali
 #define GC_PH 6
 #define GC_PW 34
 typedef float f32x4c_t __attribute__((ext_vector_type(4)));
+// IN_C = false: plain fp16 input (option "rb_inner" = 2: ResBlock.conv1 wrote only a hi plane) -- no corr records; the filter
+// residuals arrive as fp16 fragments (w - fp16(w)) * 2^11 in wpk's layout (`wck`) for a second fp16 pass into its own
+// accumulators.  OUT_C = false: only the hi plane is written ("rb_inner" >= 1).
+template <bool IN_C, bool OUT_C>
 __global__ __launch_bounds__(CNT, 2)   // two blocks (59 KB of LDS each) per CU
 void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in_c, int H, int W,
                     const half_t *__restrict__ wpk /*[16 pairs][5 steps][64 lanes][8] fp16*/,
@@ -432,7 +436,7 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
         if (p < NPIX * 8 && iy >= 0 && iy < H && ix >= 0 && ix < W) {                                     \
             const size_t o = (size_t)(iy * W + ix) * 256 + (chunk_)*64 + part * 8;                        \
             v = *reinterpret_cast<const uint4 *>(in + o);                                                 \
-            vc = *reinterpret_cast<const uint4 *>(in_c + o);                                              \
+            if (IN_C) vc = *reinterpret_cast<const uint4 *>(in_c + o);                                    \
         }                                                                                                 \
         pre[k] = v; prc[k] = vc;                                                                          \
     }
@@ -444,7 +448,7 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
             const int p = tid + k * CNT;
             if (p < NPIX * 8) {
                 *reinterpret_cast<uint4 *>(Xh + (p >> 3) * GCP + (p & 7) * 8) = pre[k];
-                *reinterpret_cast<uint4 *>(Xc + (p >> 3) * GCP + (p & 7) * 8) = prc[k];
+                if (IN_C) *reinterpret_cast<uint4 *>(Xc + (p >> 3) * GCP + (p & 7) * 8) = prc[k];
             }
         }
         const int pair = chunk * 4 + wave;
@@ -453,17 +457,24 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
 #pragma unroll
         for (int s = 0; s < 5; ++s)
             wh[s] = *reinterpret_cast<const h8_t *>(wpk + ((size_t)(pair * 5 + s) * 64 + lane) * 8);
+        h8_t wl[5];
+        if (IN_C) {
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            const unsigned char *p = wck + ((size_t)(pair * 3 + m) * 64 + lane) * 32;
-            wc8[m] = sfd2_cat8(*reinterpret_cast<const h8_t *>(p), *reinterpret_cast<const h8_t *>(p + 16));
+            for (int m = 0; m < 3; ++m) {
+                const unsigned char *p = wck + ((size_t)(pair * 3 + m) * 64 + lane) * 32;
+                wc8[m] = sfd2_cat8(*reinterpret_cast<const h8_t *>(p), *reinterpret_cast<const h8_t *>(p + 16));
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 5; ++s)
+                wl[s] = *reinterpret_cast<const h8_t *>(reinterpret_cast<const half_t *>(wck) + ((size_t)(pair * 5 + s) * 64 + lane) * 8);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (chunk + 1 < 4) { GC_FETCH(chunk + 1) }
 
-        f32x4c_t acc[8];
+        f32x4c_t acc[8], acl[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = (f32x4c_t){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int t = 0; t < 8; ++t) { acc[t] = (f32x4c_t){0.0f, 0.0f, 0.0f, 0.0f}; acl[t] = acc[t]; }
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
             int tap = 2 * s + (g >> 1);
@@ -474,10 +485,17 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
                 const int q = ((t >> 1) + ky) * GC_PW + (t & 1) * 16 + lcol + kx;
                 const h8_t bh = *reinterpret_cast<const h8_t *>(Xh + q * GCP + wave * 16 + (g & 1) * 8);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bh, acc[t], 0, 0, 0);
+                if (!IN_C) acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], bh, acl[t], 0, 0, 0);
             }
         }
+        if (!IN_C) {
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_fmaf(acl[t][r], 1.0f / 2048.0f, acc[t][r]);
+        }
+#pragma unroll
+        for (int m = 0; m < (IN_C ? 3 : 0); ++m) {
             int tap = 4 * m + g;
             if (tap > 8) tap = 8;
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -504,9 +522,9 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
                 sfd2_epi4<false>(acc[t + j][0], acc[t + j][1], acc[t + j][2], acc[t + j][3], sc, sh, sc, 0.0f, pk[j], ck[j]);
             const bool odd = g & 1;
             const uint2 send = odd ? pk[0] : pk[1], sendc = odd ? ck[0] : ck[1];
-            uint2 recv, recvc;
+            uint2 recv, recvc = make_uint2(0, 0);
             recv.x = __shfl_xor(send.x, 16); recv.y = __shfl_xor(send.y, 16);
-            recvc.x = __shfl_xor(sendc.x, 16); recvc.y = __shfl_xor(sendc.y, 16);
+            if (OUT_C) { recvc.x = __shfl_xor(sendc.x, 16); recvc.y = __shfl_xor(sendc.y, 16); }
             const int tt = odd ? t + 1 : t;                         // the tile this lane stores
             const int oy = oy0 + (tt >> 1), ox = ox0 + (tt & 1) * 16 + lcol;
             const uint4 v = odd ? make_uint4(recv.x, recv.y, pk[1].x, pk[1].y) : make_uint4(pk[0].x, pk[0].y, recv.x, recv.y);
@@ -514,7 +532,7 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
             if (oy < row1 && ox < W) {
                 const size_t o = ((size_t)oy * W + ox) * 256 + pair * 16 + (g & ~1) * 4;
                 *reinterpret_cast<uint4 *>(out + o) = v;
-                *reinterpret_cast<uint4 *>(out_c + o) = vc;
+                if (OUT_C) *reinterpret_cast<uint4 *>(out_c + o) = vc;
             }
         }
     }
@@ -525,12 +543,18 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
 void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk, const void *wck,
                     const float *scale, const float *shift, half_t *out, half_t *out_c, int sbyte, int row0, int row1)
 {
-    constexpr size_t lds = (size_t)2 * GC_PH * GC_PW * GCP * sizeof(half_t);
+    // in_c == null: plain input, wck = fp16 residual fragments; out_c == null: hi plane only
+    const size_t lds = (size_t)(in_c ? 2 : 1) * GC_PH * GC_PW * GCP * sizeof(half_t);
     if (row1 > H) row1 = H;
     if (row0 >= row1) return;
     const int tiles_x = (W + CTW - 1) / CTW, tiles_y = (row1 - row0 + CTH - 1) / CTH;
-    hipLaunchKernelGGL(gconv_c_kernel, dim3(tiles_x * tiles_y), dim3(CNT), lds, st, in, in_c, H, W, wpk,
-                       reinterpret_cast<const unsigned char *>(wck), scale, shift, out, out_c, tiles_x, (sbyte & 255) * 0x01010101, row0, row1);
+#define GCC_GO(I_, O_) hipLaunchKernelGGL((gconv_c_kernel<I_, O_>), dim3(tiles_x * tiles_y), dim3(CNT), lds, st, in, in_c, H, W, wpk, \
+                       reinterpret_cast<const unsigned char *>(wck), scale, shift, out, out_c, tiles_x, (sbyte & 255) * 0x01010101, row0, row1)
+    if (in_c && out_c) GCC_GO(true, true);
+    else if (in_c) GCC_GO(true, false);
+    else if (!out_c) GCC_GO(false, false);
+    else abort();
+#undef GCC_GO
 }
 
 // hi + corr planes -> NCHW fp32 (sfd2_debug_activation): hi + the residual the corr unit carries

