@@ -199,13 +199,21 @@ void launch_conv1x1_c256(hipStream_t st, const half_t *in, int npix, const half_
 #define GPXC 32
 #define STAGE_C (2 * GPXC * 512)
 
+// Blocks take a static contiguous share of the groups.  A wall-clock trace (-DSFD2_C256_TRACE) shows the blocks of one launch
+// finishing between 55 and 70 us for identical work (mean 64), so handing groups out dynamically (an atomic claim counter,
+// claims five ahead through an LDS ring) was tried: the blocks then finish within 2 us of each other, but LATER (mean 73) --
+// with one counter or with eight -- and the launch is slower (conv1 47 -> 66 us, conv3 78 -> 84): not kept.
 // IN_C = false: the input is a plain fp16 tensor (ResBlock-internal tensors under option "rb_inner", sfd2_api.hip): no corr
 // plane to stage, and the filter residuals arrive as fp16 (w - fp16(w)) * 2^11 (`wc` = [256][256] halves) for a second fp16
 // pass into its own accumulator.  OUT_C = false: only the hi plane is written.
 template <bool HAS_RES, bool IN_C, bool OUT_C>
 __global__ __launch_bounds__(NT1, 2)
 void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in_c, int npix,
-                           const half_t *__restrict__ w /*[256 out][256 in] fp16*/, const half_t *__restrict__ wc /*[256][256] corr units*/,
+                           const half_t *__restrict__ w /*fp16 filters*/, const half_t *__restrict__ wc /*corr units, or fp16 residuals*/,
+                           /* both in fragment order [8 waves][8 c][64 lanes][16]: element e of lane l = filter row wave * 32 + (l & 31),
+                              column c * 32 + (e >> 3) * 16 + (l >> 5) * 8 + (e & 7) -- every load instruction reads whole lines
+                              (row-major filters cost each CU ~1 MB of 32-byte pieces through its L1: 7.6 us before the first group
+                              was staged, 4.7 us now) */
                            const float *__restrict__ scale, const float *__restrict__ shift, int relu,
                            const half_t *__restrict__ res, const half_t *__restrict__ res_c,
                            half_t *__restrict__ out, half_t *__restrict__ out_c, int groups_per_block,
@@ -227,12 +235,13 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
     h8_t ah[16];
     v8i_t ac[8];               // IN_C: corr units; otherwise the 16 fp16 fragments of the scaled filter residuals, two per entry
     {
-        const size_t ro = (size_t)(wave * 32 + lrow) * 256 + lhi * 8;
+        const size_t fo = ((size_t)wave * 8 * 64 + lane) * 16;
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) ah[kk] = *reinterpret_cast<const h8_t *>(w + ro + kk * 16);
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            ac[c] = sfd2_cat8(*reinterpret_cast<const h8_t *>(wc + ro + c * 32), *reinterpret_cast<const h8_t *>(wc + ro + c * 32 + 16));
+        for (int c = 0; c < 8; ++c) {
+            ah[2 * c] = *reinterpret_cast<const h8_t *>(w + fo + (size_t)c * 64 * 16);
+            ah[2 * c + 1] = *reinterpret_cast<const h8_t *>(w + fo + (size_t)c * 64 * 16 + 8);
+            ac[c] = sfd2_cat8(*reinterpret_cast<const h8_t *>(wc + fo + (size_t)c * 64 * 16), *reinterpret_cast<const h8_t *>(wc + fo + (size_t)c * 64 * 16 + 8));
+        }
     }
     for (int t = tid; t < 256; t += NT1) { SS[t] = scale[t]; SS[256 + t] = shift[t]; }
 
@@ -358,10 +367,10 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
 #undef WAIT_GROUP_C
 }
 
-void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c, int npix, const half_t *w_rowmajor,
-                           const half_t *wc_rowmajor, const float *scale, const float *shift, int relu, const half_t *res,
+void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c, int npix, const half_t *w_frag,
+                           const half_t *wc_frag, const float *scale, const float *shift, int relu, const half_t *res,
                            const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte)
-// in_c == null: plain fp16 input, wc_rowmajor = the fp16 filter residuals * 2^11; out_c == null: only the hi plane is written
+// in_c == null: plain fp16 input, wc_frag = the fp16 filter residuals * 2^11; out_c == null: only the hi plane is written
 {
     static bool attr_done = false;
     static int slots = 256;
@@ -381,7 +390,7 @@ void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c,
     const int gpb = (ngroups + slots - 1) / slots;
     const int grid = (ngroups + gpb - 1) / gpb;
     const int sa = (sbyte & 255) * 0x01010101;
-#define C256C_GO(R_, I_, O_) hipLaunchKernelGGL((conv1x1_c256_c_kernel<R_, I_, O_>), dim3(grid), dim3(NT1), lds, st, in, in_c, npix, w_rowmajor, wc_rowmajor, scale, shift, relu, res, res_c, out, out_c, gpb, zero_page, sa)
+#define C256C_GO(R_, I_, O_) hipLaunchKernelGGL((conv1x1_c256_c_kernel<R_, I_, O_>), dim3(grid), dim3(NT1), lds, st, in, in_c, npix, w_frag, wc_frag, scale, shift, relu, res, res_c, out, out_c, gpb, zero_page, sa)
     if (in_c && out_c) { if (res) C256C_GO(true, true, true); else C256C_GO(false, true, true); }
     else if (in_c && !res) C256C_GO(false, true, false);           // ResBlock.conv1 writing a plain t1
     else if (!in_c && out_c && res) C256C_GO(true, false, true);   // ResBlock.conv3 reading a plain t2

@@ -55,8 +55,8 @@ struct ConvW {                 // one folded + packed layer
     int cin = 0, cout = 0, cout_pad = 0, ks = 0, stride = 1;
     DevBuf w, scale, shift;    // fp16 packed filters, fp32 [cout_pad]
     DevBuf wrm;                // 1x1 256 -> 256 layers: the same filters as plain [cout][cin] fp16 (conv1x1_c256_kernel)
-    DevBuf wrmc;               // ... and their corr units, [cout][cin] (conv1x1_c256_c_kernel)
-    DevBuf wrml;               // ... and fp16 of (w - fp16(w)) * 2^11, [cout][cin]: the second fp16 pass over a PLAIN input (option "rb_inner")
+    DevBuf wfh, wfc, wfl;      // conv1x1_c256_c_kernel: the same filters, their corr units and fp16 of (w - fp16(w)) * 2^11 (the second
+                               // fp16 pass over a PLAIN input, option "rb_inner") in the kernel's fragment order [8 waves][8][64 lanes][16]
     DevBuf wlk;                // grouped 3x3: the same residuals in w's fragment layout (gconv_c_kernel<false, false>)
     DevBuf wgc;                // grouped 3x3: compact [256 oc][9 taps][8 in] fp16 (resblock_kernel)
     DevBuf wx3;                // fp32 layers, SFD2_PREC_F16X3: every float4 of w as (4 hi, 4 lo) fp16, made on first use
@@ -392,15 +392,22 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
                     }
         if (upload(L.wc, pc.data(), pc.size() * 2, c->stream)) return -1;
         if (ks == 1 && stride == 1 && cin == 256 && cout == 256) {
-            std::vector<unsigned short> rc((size_t)256 * 256);
-            for (size_t i = 0; i < rc.size(); ++i) {
-                const float v = w->d[i];
-                rc[i] = (unsigned short)(f32_to_e4m3(std::ldexp(v, b0)) | (f32_to_e4m3(std::ldexp(v - (float)(half_t)v, b0 + 11)) << 8));
-            }
-            if (upload(L.wrmc, rc.data(), rc.size() * 2, c->stream)) return -1;
-            std::vector<half_t> rl((size_t)256 * 256);
-            for (size_t i = 0; i < rl.size(); ++i) rl[i] = (half_t)((w->d[i] - (float)(half_t)w->d[i]) * 2048.0f);
-            if (upload(L.wrml, rl.data(), rl.size() * sizeof(half_t), c->stream)) return -1;
+            std::vector<half_t> fh((size_t)256 * 256), fl(fh.size());
+            std::vector<unsigned short> fc(fh.size());
+            for (int wv = 0; wv < 8; ++wv)
+                for (int cc = 0; cc < 8; ++cc)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 16; ++e) {
+                            const int row = wv * 32 + (l & 31), col = cc * 32 + (e >> 3) * 16 + (l >> 5) * 8 + (e & 7);
+                            const float v = w->d[(size_t)row * 256 + col];
+                            const size_t o = (((size_t)wv * 8 + cc) * 64 + l) * 16 + e;
+                            fh[o] = (half_t)v;
+                            fl[o] = (half_t)((v - (float)(half_t)v) * 2048.0f);
+                            fc[o] = (unsigned short)(f32_to_e4m3(std::ldexp(v, b0)) | (f32_to_e4m3(std::ldexp(v - (float)(half_t)v, b0 + 11)) << 8));
+                        }
+            if (upload(L.wfh, fh.data(), fh.size() * 2, c->stream)) return -1;
+            if (upload(L.wfl, fl.data(), fl.size() * 2, c->stream)) return -1;
+            if (upload(L.wfc, fc.data(), fc.size() * 2, c->stream)) return -1;
         }
     }
     return 0;
@@ -837,10 +844,10 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &i
                                 c->zero_page.as<half_t>(), L.sbyte))
             return;
     }
-    if (!c->opt_generic_c && in_c && out_c && L.wrm.p && L.wrmc.p) {   // the ResBlocks' 1x1 layers: persistent streaming kernel
+    if (!c->opt_generic_c && in_c && out_c && L.wfh.p && L.wfc.p) {   // the ResBlocks' 1x1 layers: persistent streaming kernel
         snprintf(kn, sizeof(kn), "conv1x1_c256<comp>%s", res ? "+res" : "");
         ProfScope ps(c, name, kn, flops, bytes);
-        launch_conv1x1_c256_c(c->cur_stream, in.as<half_t>(), in_c, Ho * Wo, L.wrm.as<half_t>(), L.wrmc.as<half_t>(), L.scale.as<float>(),
+        launch_conv1x1_c256_c(c->cur_stream, in.as<half_t>(), in_c, Ho * Wo, L.wfh.as<half_t>(), L.wfc.as<half_t>(), L.scale.as<float>(),
                               L.shift.as<float>(), relu, res ? res->as<half_t>() : nullptr,
                               res ? corr_of(*res, (size_t)Ho * Wo, L.cout_pad) : nullptr, out.as<half_t>(), out_c,
                               c->zero_page.as<half_t>(), L.sbyte);
@@ -1035,7 +1042,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
             if (!c->opt_comp_rb) { rb_f16(b); continue; }   // option "comp_rb" = 0: this block in plain fp16 on the hi planes
             DevBuf &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];
-            const int inner = (!c->opt_generic_c && c->rb1[b].wrml.p && c->rb3[b].wrml.p && c->rb2[b].wlk.p) ? c->opt_rb_inner : 0;
+            const int inner = (!c->opt_generic_c && c->rb1[b].wfl.p && c->rb3[b].wfl.p && c->rb2[b].wlk.p) ? c->opt_rb_inner : 0;
             if (inner) {
                 // Option "rb_inner": the tensors INSIDE the block as plain fp16 (1: t2, 2: t1 and t2).  These kernels are bound
                 // by HBM bytes, a plain tensor is half of a compensated one; the filters stay compensated (over a plain input the
@@ -1050,7 +1057,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                 }
                 if (t1p) {
                     ProfScope ps(c, nm1[b], "conv1x1_c256<comp,plain out>", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 6);
-                    launch_conv1x1_c256_c(st, x->as<half_t>(), corr_of(*x, PP, 256), (int)PP, L1.wrm.as<half_t>(), L1.wrmc.as<half_t>(),
+                    launch_conv1x1_c256_c(st, x->as<half_t>(), corr_of(*x, PP, 256), (int)PP, L1.wfh.as<half_t>(), L1.wfc.as<half_t>(),
                                           L1.scale.as<float>(), L1.shift.as<float>(), 1, nullptr, nullptr, t1.as<half_t>(), nullptr,
                                           c->zero_page.as<half_t>(), L1.sbyte);
                 } else {
@@ -1063,7 +1070,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                 }
                 {
                     ProfScope ps(c, nm3[b], "conv1x1_c256<comp,plain in>+res", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 10);
-                    launch_conv1x1_c256_c(st, t2.as<half_t>(), nullptr, (int)PP, L3.wrm.as<half_t>(), L3.wrml.as<half_t>(), L3.scale.as<float>(),
+                    launch_conv1x1_c256_c(st, t2.as<half_t>(), nullptr, (int)PP, L3.wfh.as<half_t>(), L3.wfl.as<half_t>(), L3.scale.as<float>(),
                                           L3.shift.as<float>(), 1, x->as<half_t>(), corr_of(*x, PP, 256), ob.as<half_t>(), corr_of(ob, PP, 256),
                                           c->zero_page.as<half_t>(), L3.sbyte);
                 }

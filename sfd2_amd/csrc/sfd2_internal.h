@@ -198,8 +198,8 @@ bool launch_conv_igemm2_c(hipStream_t st, const half_t *in, const half_t *in_c, 
 void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *w1, const float *sc1,
                          const float *sh1, const void *w2, const float *sc2, const float *sh2, half_t *out, half_t *out_c,
                          int H2, int W2, int sbyte);
-void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c, int npix, const half_t *w_rowmajor,
-                           const half_t *wc_rowmajor, const float *scale, const float *shift, int relu, const half_t *res,
+void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c, int npix, const half_t *w_frag,
+                           const half_t *wc_frag, const float *scale, const float *shift, int relu, const half_t *res,
                            const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte);
 void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *wpk /*hi, lo fragments*/,
                      const float *scale, const float *shift, half_t *out, half_t *out_c);
