@@ -72,6 +72,19 @@ __device__ __forceinline__ h4_t cvt4c(float a, float b, float c, float d)
 // the chunk loop simply runs on through the corr plane's chunks, whose units go to ONE v_mfma_scale_f32_32x32x64_f8f6f4 per
 // (channel tile, pixel tile) instead of two fp16 MFMAs (same LDS records, same fragment reads); bit 1 = the corr plane of
 // the output is written (out_c).
+// -DSFD2_PP_TRACE: wall-clock stamps (s_memrealtime, 100 MHz) of every block (entry, exit) and cycle stamps of block 3's waves 0
+// and 4 around the sections of its tiles, printed by the launcher for the compensated instantiations
+#ifdef SFD2_PP_TRACE
+#include <stdio.h>
+__device__ unsigned long long g_pp_wall[1024][2];
+__device__ unsigned long long g_pp_cyc[2][8][4];
+#define PP_WALL(k_) if (tid == 0) g_pp_wall[blockIdx.x][k_] = __builtin_amdgcn_s_memrealtime();
+#define PP_CYC(k_) if (blockIdx.x == 3 && (wave == 0 || wave == 4) && lane == 0 && it < 8) g_pp_cyc[wave == 4][it][k_] = __builtin_readcyclecounter();
+#else
+#define PP_WALL(k_)
+#define PP_CYC(k_)
+#endif
+
 template <int STAGGER, int PRIO, int ABL = 0, int KXM = SFD2_PP_KXM, int COMP = 0>
 __global__ __launch_bounds__(512, 2)
 void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
@@ -126,6 +139,7 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         }                                                                                              \
     }
     int tile = blockIdx.x;
+    PP_WALL(0)
     PP_SETUP(tile)
     const int NCH = Cin / PP_CC;                           // chunks per plane
 
@@ -171,8 +185,10 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    PP_CYC(0)
     SFD2_BARRIER_DRAIN();
     if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
+    PP_CYC(1)
 
 #define PP_CHUNK_BODY(F8_)  /* one 32-channel chunk of the K loop; F8_: a corr-plane chunk (fp8 MFMA) */ \
         const unsigned char *xs = Xs + (c & 1) * PP_XBYTES; \
@@ -289,6 +305,7 @@ _Pragma("unroll") \
     if (COMP & 1)
         for (int c = NCH; c < NCT; ++c) { PP_CHUNK_BODY(1) }
 #undef PP_CHUNK_BODY
+    PP_CYC(2)
     // the next tile's first copies go out before this tile's epilogue (buffers 0: last read a chunk / a stage ago)
     const int eoy0 = oy0, eox0 = ox0, en0 = n0;
     const int next = tile + (int)gridDim.x;
@@ -347,9 +364,14 @@ _Pragma("unroll") \
             }
         }
     }
+    PP_CYC(3)
     if (!has_next) break;
     tile = next;
     }
+#ifdef SFD2_PP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_WALL(1)
+#endif
 #undef PP_ISSUE_X1
 #undef PP_ISSUE_F
 #undef PP_SETUP
@@ -378,6 +400,25 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
     const int grid = n_tiles < slots ? n_tiles : slots;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out,
                        Ho, Wo, tiles_x, n_tiles, zero_page, in_c, out_c, sa);
+#ifdef SFD2_PP_TRACE
+    {
+        static int dumps = 0;
+        if (H >= 250 && ++dumps == 40) {
+            (void)hipStreamSynchronize(st);
+            static unsigned long long hw[1024][2], hc[2][8][4];
+            (void)hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_pp_wall), sizeof(hw));
+            (void)hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_pp_cyc), sizeof(hc));
+            unsigned long long t0 = ~0ull, e0 = ~0ull, e1 = 0; double es = 0;
+            for (int b = 0; b < grid; ++b) t0 = hw[b][0] < t0 ? hw[b][0] : t0;
+            for (int b = 0; b < grid; ++b) { const unsigned long long e = hw[b][1] - t0; e0 = e < e0 ? e : e0; e1 = e > e1 ? e : e1; es += (double)e; }
+            fprintf(stderr, "pp trace COMP %d  %dx%d Cin %d CoutP %d: %d tiles on %d blocks; exit (10 ns) min %llu mean %.0f max %llu\n", COMP, H, W, Cin, CoutP, n_tiles, grid, e0, es / grid, e1);
+            for (int w = 0; w < 2; ++w)
+                for (int t = 0; t < (n_tiles + grid - 1) / grid && t < 8; ++t)
+                    fprintf(stderr, "  wave %d tile %d: wait %lld  K loop %lld  next-tile issue %lld  epilogue %lld   (cycles)\n", w * 4, t,
+                            (long long)(hc[w][t][1] - hc[w][t][0]), (long long)(hc[w][t][2] - hc[w][t][1]), 0ll, (long long)(hc[w][t][3] - hc[w][t][2]));
+        }
+    }
+#endif
 }
 
 // compensated instantiations (SFD2_PREC_F16C): wpk = the layer's wc array, sbyte its scale byte
