@@ -101,6 +101,7 @@ struct sfd2_ctx {
                                        // fp16, 2 (default) = t1 and t2, 0 = both compensated; the filters stay compensated either way
                                        // (second fp16 pass with their residuals).  Measured at 1600x1200: 1.82 / 1.75 / 1.67 ms per
                                        // extract for 0 / 1 / 2, descriptors <= 3.5e-4 / 3.8e-4 / 4.9e-4 over the BASELINE geometries.
+    int opt_fuse_rb23 = 1;             // sfd2_set_option "fuse_rb23": with rb_inner = 2, ResBlock.conv2 + conv3 + residual in one kernel (t2 stays in LDS)
     int opt_comp_heads = 0;            // sfd2_set_option "comp_heads": SFD2_PREC_F16C compensates the 3x3 layers of the two head branches too
     int opt_no_rf_c = 0;               // sfd2_set_option "no_rf_c": conv2b on conv_igemm2<comp> instead of conv3x3_rf<comp> (A/B switch)
     int opt_generic_c = 0;             // sfd2_set_option "generic_c": SFD2_PREC_F16C layers on the generic reference kernel (tests)
@@ -982,6 +983,13 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
             t1v[0] = slot(0); t2v[0] = slot(1); rov[0] = slot(0);    // x = slot 2
             t1v[1] = slot(2); t2v[1] = slot(1); rov[1] = slot(2);    // x = slot 0
             t1v[2] = slot(0); t2v[2] = slot(1); rov[2] = slot(0);    // x = slot 2 -> final x = slot 0
+            if (comp && c->opt_comp_rb && !c->opt_generic_c && c->opt_rb_inner >= 2 && c->opt_fuse_rb23) {
+                // rb23_c_kernel reads t1 (with the halo rows of neighbouring tiles) while other tiles already write the block's
+                // output: the output cannot take t1's slot.  No t2 in HBM on this path, so three slots still do.
+                t1v[0] = slot(0); rov[0] = slot(1);    // x = slot 2
+                t1v[1] = slot(0); rov[1] = slot(2);    // x = slot 1
+                t1v[2] = slot(1); rov[2] = slot(0);    // x = slot 2 -> final x = slot 0
+            }
             pa0_o = slot(1); pa_o = slot(1, (P8s * 256 * 2 * (comp ? 2 : 1) + 255) & ~(size_t)255);   // (convPa.0's corr plane with "comp_heads")
             da0_o = slot(2); da_o = slot(1);   // convDa.3 runs after convPb has consumed slot 1
             if (c->opt_branches) da_o = slot(3);   // the two head branches run concurrently: no slot is shared between them
@@ -1062,6 +1070,14 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                                           c->zero_page.as<half_t>(), L1.sbyte);
                 } else {
                     convc(c, nm1[b], L1, *x, H4, W4, t1, H4, W4, 1, true, true);
+                }
+                if (t1p && c->opt_fuse_rb23) {
+                    ProfScope ps(c, nm3[b], "rb23_c_kernel", 2.0 * P4 * 256 * 72 + 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 10);
+                    launch_rb23_c(st, t1.as<half_t>(), H4, W4, L2.w.as<half_t>(), L2.wlk.as<half_t>(), L2.scale.as<float>(), L2.shift.as<float>(),
+                                  L3.wfh.as<half_t>(), L3.wfl.as<half_t>(), L3.scale.as<float>(), L3.shift.as<float>(), x->as<half_t>(),
+                                  corr_of(*x, PP, 256), ob.as<half_t>(), corr_of(ob, PP, 256));
+                    x = &ob;
+                    continue;
                 }
                 {
                     ProfScope ps(c, nm2[b], t1p ? "gconv_c_kernel<plain>" : "gconv_c_kernel<plain out>", 2.0 * P4 * 256 * 72, P4 * 256 * (t1p ? 4 : 6));
@@ -2348,6 +2364,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;
     else if (k == "no_rf_c") c->opt_no_rf_c = value ? 1 : 0;
     else if (k == "comp_heads") c->opt_comp_heads = value ? 1 : 0;
+    else if (k == "fuse_rb23") c->opt_fuse_rb23 = value ? 1 : 0;
     else if (k == "rb_inner") c->opt_rb_inner = value < 0 ? 0 : (value > 2 ? 2 : value);
     else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;
