@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--precision", default="f16c", choices=["f16c", "f16"], help="mode of the headline legs (default f16c: the "
                     "tolerance-conformant throughput mode; f16 = the 3e-3 approximation, for kernel A/Bs of that path)")
     ap.add_argument("--comp-heads", type=int, default=0, help="f16c option comp_heads (1: the head branches' 3x3 layers compensated as well)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="sfd2_set_option on every context (A/B switches, e.g. fuse_rb23=0)")
     ap.add_argument("--rb-inner", type=int, default=2, help="f16c option rb_inner (2: the tensors inside the ResBlocks plain fp16, the shipped default; "
                     "1: only the grouped conv's output; 0: both compensated, descriptors <= 3.5e-4)")
     ap.add_argument("--comp-rb", type=int, default=1, help="f16c option comp_rb (0: ResBlocks on the fused fp16 kernel; descriptors ~7e-4)")
@@ -263,6 +264,9 @@ def main():
                 self.ctx.set_option("comp_heads", 1)
             if args.branches:
                 self.ctx.set_option("branches", 1)
+            for kv in args.opt:
+                k, _, v = kv.partition("=")
+                self.ctx.set_option(k, int(v))
 
     lanes = [Lane() for _ in range(max(1, args.streams))]
     ctx = lanes[0].ctx

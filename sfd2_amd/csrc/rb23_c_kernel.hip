@@ -3,8 +3,8 @@
 // channels is 64 KB: it stays in LDS, in the record layout conv1x1_c256_c_kernel stages its input in, and never travels to
 // HBM (2 x 61 MB per block at 1600x1200) -- and the block is one launch shorter.
 //
-//   phase G  gconv_c_kernel<false, false>'s arithmetic: 64-channel chunks of the 6 x 34 patch of t1 staged through registers
-//            into LDS (double buffered, one barrier per chunk), two groups per 16x16x32 MFMA with block-diagonal filter
+//   phase G  gconv_c_kernel<false, false>'s arithmetic: 64-channel chunks of the 6 x 34 patch of t1 copied into an LDS ring
+//            (one barrier per chunk), two groups per 16x16x32 MFMA with block-diagonal filter
 //            fragments, second fp16 pass with the filter residuals; a wave = one group pair of the chunk x two tile rows
 //   phase C  conv1x1_c256_c_kernel<true, false, true>'s arithmetic on the tile's four 32-pixel rows: a wave owns 32 output
 //            channels, filters (fp16 + fp16 residuals, fragment order) in 128 registers for the life of the block
@@ -18,13 +18,13 @@
 #define R23_TW 32
 #define R23_PH 6
 #define R23_PW 34
-#define R23_NPIX (R23_PH * R23_PW)
-#define R23_GCP 72                                  // halves per patch record: 64 channels + 8 of padding
-#define R23_XB (R23_NPIX * R23_GCP * 2)             // bytes of one patch buffer
+#define R23_NPIX (R23_PH * R23_PW)                  // 204 patch pixels x 128 B (one 64-channel chunk) = 25.5 KB
+#define R23_XB (26 * 1024)                          // a patch buffer: 26 copy instructions of 1 KB (the last one half used)
 #define R23_T2B (R23_TH * R23_TW * 512)
-#define R23_NLD ((R23_NPIX * 8 + R23_NT - 1) / R23_NT)
 
 typedef float r23_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void r23_lds_t;
+typedef const __attribute__((address_space(1))) void r23_gbl_t;
 
 __device__ __forceinline__ int r23_xcd_swizzle(int bid, int nblk)
 {
@@ -33,6 +33,28 @@ __device__ __forceinline__ int r23_xcd_swizzle(int bid, int nblk)
     return base + local;
 }
 
+// -DSFD2_RB23_TRACE: cycle stamps of block 3's waves 0 and 7 (chunk tops, phase C start, rows, tile end) and the wall-clock exit
+// of every block, printed by the launcher
+#ifdef SFD2_RB23_TRACE
+#include <stdio.h>
+__device__ unsigned long long g_r23_cyc[2][6][12];
+__device__ unsigned long long g_r23_wall[1024][2];
+#define R23_CYC(k_) if (blockIdx.x == 3 && (wave == 0 || wave == 7) && lane == 0 && tcount < 6) g_r23_cyc[wave == 7][tcount][k_] = __builtin_readcyclecounter();
+#define R23_WALL(k_) if (tid == 0) g_r23_wall[blockIdx.x][k_] = __builtin_amdgcn_s_memrealtime();
+#else
+#define R23_CYC(k_)
+#define R23_WALL(k_)
+#endif
+
+// Pipeline.  Patch chunks travel global -> LDS by direct copies (global_load_lds), TWO chunks ahead of their use, into a ring of
+// three buffers (a chunk's compute, ~1.5k cycles, is shorter than an HBM round trip); a 128-byte pixel record's eight 16-byte
+// parts sit at slot part ^ ((pixel >> 1) & 7), so the 16 pixels a fragment read touches fall into 16 different bank groups
+// without padding.  The grouped conv's filter fragments of the NEXT chunk are loaded into the registers of the step that has
+// just issued its MFMAs; the copies for chunk n + 2 go out after chunk n's MFMAs, i.e. BEHIND those loads in the wave's
+// memory queue, so `vmcnt(4)` at the top of a chunk (every wave issues exactly four copies per chunk) covers the filters and
+// the chunk's own patch and leaves the newest copies in flight.  Phase C: a row's residual is loaded during the previous row's
+// epilogue (into the registers the second accumulator has just left), the next tile's first filter fragments before the last
+// row's stores; those four stores are all that is still in flight at the top of the next tile.
 __global__ __launch_bounds__(R23_NT, 2)
 void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                    const half_t *__restrict__ w2h /*[16 pairs][5 steps][64 lanes][8]*/, const half_t *__restrict__ w2l /*residuals * 2^11, same layout*/,
@@ -40,12 +62,14 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                    const half_t *__restrict__ w3h /*fragment order [8 waves][8][64 lanes][16]*/, const half_t *__restrict__ w3l,
                    const float *__restrict__ sc3, const float *__restrict__ sh3,
                    const half_t *__restrict__ res, const half_t *__restrict__ res_c,
-                   half_t *__restrict__ out, half_t *__restrict__ out_c, int tiles_x, int n_tiles)
+                   half_t *__restrict__ out, half_t *__restrict__ out_c, int tiles_x, int n_tiles, const half_t *__restrict__ zero_page)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *T2 = smem;                                              // [128 pixels][512 B], 16-byte slots XOR (pixel & 31)
-    half_t *XP = reinterpret_cast<half_t *>(smem + R23_T2B);               // [2][R23_NPIX][R23_GCP]
-    float *SS = reinterpret_cast<float *>(smem + R23_T2B + 2 * R23_XB);    // sc2, sh2, sc3, sh3: 256 floats each
+    // Three separate LDS objects, not slices of one array: the compiler orders every LDS store behind all pending direct-to-LDS
+    // copies it cannot prove disjoint from it (`s_waitcnt vmcnt(0)` in front of the first T2 store of every chunk: the copies
+    // just issued had to land before the epilogue went on -- no prefetch at all)
+    __shared__ __attribute__((aligned(16))) unsigned char T2[R23_T2B];     // [128 pixels][512 B], 16-byte slots XOR (pixel & 31)
+    __shared__ __attribute__((aligned(16))) unsigned char XP[3 * R23_XB + 1024];   // patch ring, then 1 KB that swallows the idle copies
+    __shared__ __attribute__((aligned(16))) float SS[4 * 256];            // sc2, sh2, sc3, sh3
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,20 +91,28 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
     }
     for (int t = tid; t < 256; t += R23_NT) { SS[t] = sc2[t]; SS[256 + t] = sh2[t]; SS[512 + t] = sc3[t]; SS[768 + t] = sh3[t]; }
 
-    // a patch chunk = 204 pixels x 8 parts of 16 bytes; piece p = tid + k * 512: pixel p >> 3 (row = pixel / 34 by multiplication)
-    uint4 pre[R23_NLD];
-#define R23_FETCH(oy0_, ox0_, chunk_)                                                                     \
-    _Pragma("unroll") for (int k = 0; k < R23_NLD; ++k) {                                                 \
-        int p = tid + k * R23_NT;                                                                         \
-        asm volatile("" : "+v"(p));   /* (not hoisted out of the tile loop: 12 registers) */               \
-        const int q = p >> 3;                                                                             \
+    // copies of one chunk: instruction j = wave + 8 * i (i < 4) moves pieces j * 64 + lane (pixel = piece >> 3, slot = piece & 7);
+    // j >= 26 has nothing to move and reads the zero page into the spare KB -- every wave issues four, the counted waits rely on it
+#define R23_COPIES(oy0_, ox0_, chunk_, buf_)                                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+        const int j = wave + 8 * i;                                                                       \
+        int piece = j * 64 + lane;                                                                        \
+        asm volatile("" : "+v"(piece));   /* (recomputed per chunk: not worth four registers) */           \
+        const int q = piece >> 3;                                                                         \
         const int py = (q * 241) >> 13, px = q - py * R23_PW;                                             \
         const int iy = (oy0_)-1 + py, ix = (ox0_)-1 + px;                                                  \
-        uint4 v = make_uint4(0, 0, 0, 0);                                                                 \
-        if (p < R23_NPIX * 8 && iy >= 0 && iy < H && ix >= 0 && ix < W)                                   \
-            v = *reinterpret_cast<const uint4 *>(t1 + (size_t)(iy * W + ix) * 256 + (chunk_)*64 + (p & 7) * 8); \
-        pre[k] = v;                                                                                       \
+        const int part = (piece & 7) ^ ((q >> 1) & 7);                                                    \
+        const bool ok = j < 26 && q < R23_NPIX && iy >= 0 && iy < H && ix >= 0 && ix < W;                  \
+        const half_t *src = ok ? t1 + (size_t)(iy * W + ix) * 256 + (chunk_)*64 + part * 8 : zero_page + (lane & 7) * 8; \
+        unsigned char *dst = j < 26 ? XP + (buf_)*R23_XB + j * 1024 : XP + 3 * R23_XB;                     \
+        __builtin_amdgcn_global_load_lds((r23_gbl_t *)src, (r23_lds_t *)dst, 16, 0, 0);                    \
     }
+
+    // Filter-fragment reloads are issued by hand: a load the compiler tracks makes it wait for `vmcnt(0)` in front of the first
+    // MFMA of the next chunk (it cannot count across the loop edge), i.e. for the copies issued behind the reload as well.  The
+    // counted wait at the top of the chunk carries the registers as operands, so nothing that reads them moves above it.
+#define R23_WLOAD(dst_, ptr_) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst_) : "v"(ptr_) : "memory")
+#define R23_WTIE() asm volatile("" : "+v"(wh[0]), "+v"(wh[1]), "+v"(wh[2]), "+v"(wh[3]), "+v"(wh[4]), "+v"(wl[0]), "+v"(wl[1]), "+v"(wl[2]), "+v"(wl[3]), "+v"(wl[4]))
 
     int tile = blockIdx.x;
     int oy0, ox0;
@@ -88,12 +120,39 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
         const int swz = r23_xcd_swizzle(tile, n_tiles);
         oy0 = (swz / tiles_x) * R23_TH; ox0 = (swz % tiles_x) * R23_TW;
     }
-    R23_FETCH(oy0, ox0, 0)
+    h8_t wh[5], wl[5];                                      // grouped conv: fragments of the chunk at hand / being loaded for the next one
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        R23_WLOAD(wh[s], w2h + ((size_t)(pw * 5 + s) * 64 + lane) * 8);
+        R23_WLOAD(wl[s], w2l + ((size_t)(pw * 5 + s) * 64 + lane) * 8);
+    }
+    // (conv3's filters are waited for HERE: a load still pending at the head of the tile loop makes the compiler drain the
+    //  memory queue in front of the chunk loop of every tile)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(ah[2 * c]), "+v"(ah[2 * c + 1]), "+v"(al[c]));
+    R23_COPIES(oy0, ox0, 0, 0)
+    R23_COPIES(oy0, ox0, 1, 1)
+    int tcount = 0;
+    (void)tcount;
+    R23_WALL(0)
+    int ring = 0;                                           // buffer of the chunk at hand; the copies go to (ring + 2) % 3
+    bool drain = true;                                      // top of the first tile / behind a tile with rows below the image: full wait
 
+    uint4 rq[2], rc[2];
+#define R23_RES(r4_)                                                                                      \
+        {                                                                                                 \
+            /* (rows / columns past the image repeat its last row / column: same values, same addresses, no predicate) */ \
+            const int oy_ = oy0 + (r4_) < H ? oy0 + (r4_) : H - 1, ox_ = ox0 + lrow < W ? ox0 + lrow : W - 1; \
+            const size_t ob_ = (size_t)(oy_ * W + ox_) * 256 + wave * 32;                                 \
+            _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                               \
+                rq[m] = *reinterpret_cast<const uint4 *>(res + ob_ + 8 * (2 * m + lhi));                  \
+                rc[m] = *reinterpret_cast<const uint4 *>(res_c + ob_ + 8 * (2 * m + lhi));                \
+            }                                                                                             \
+        }
     for (;;) {
         const int next = tile + (int)gridDim.x;
         const bool has_next = next < n_tiles;
-        int noy0 = 0, nox0 = 0;
+        int noy0 = oy0, nox0 = ox0;
         if (has_next) {
             const int swz = r23_xcd_swizzle(next, n_tiles);
             noy0 = (swz / tiles_x) * R23_TH; nox0 = (swz % tiles_x) * R23_TW;
@@ -101,75 +160,86 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
         // ------------------------------------------------ phase G: grouped 3x3 -> T2
 #pragma unroll 1
         for (int chunk = 0; chunk < 4; ++chunk) {
-            half_t *Xb = XP + (chunk & 1) * (R23_NPIX * R23_GCP);
-#pragma unroll
-            for (int k = 0; k < R23_NLD; ++k) {
-                int p = tid + k * R23_NT;
-                asm volatile("" : "+v"(p));
-                if (p < R23_NPIX * 8) *reinterpret_cast<uint4 *>(Xb + (p >> 3) * R23_GCP + (p & 7) * 8) = pre[k];
-            }
+            // this chunk's patch (copied two chunks ago) and filter fragments have landed; the newest four copies may still fly.
+            // One barrier per chunk: the buffer the copies below go to was last read a chunk ago, T2 in the previous tile's phase C
+            if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            R23_WTIE();
+            R23_CYC(chunk)
+            drain = false;
+            const unsigned char *Xb = XP + ring * R23_XB;
             const int pair = chunk * 4 + pw;
-            h8_t wh[5], wl[5];
+            r23_f4 acc[4], acl[4];
 #pragma unroll
-            for (int s = 0; s < 5; ++s) {
-                wh[s] = *reinterpret_cast<const h8_t *>(w2h + ((size_t)(pair * 5 + s) * 64 + lane) * 8);
-                wl[s] = *reinterpret_cast<const h8_t *>(w2l + ((size_t)(pair * 5 + s) * 64 + lane) * 8);
-            }
-            // one barrier per chunk: the buffer just written was last read two chunks ago, and every wave has passed the
-            // barrier in between (T2: last read in the previous tile's phase C, which every wave left before this barrier)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (chunk < 3) { R23_FETCH(oy0, ox0, chunk + 1) }
-            else if (has_next) { R23_FETCH(noy0, nox0, 0) }
-
+            for (int t = 0; t < 4; ++t) { acc[t] = (r23_f4){0.0f, 0.0f, 0.0f, 0.0f}; acl[t] = acc[t]; }
             int lc = lcol;
             asm volatile("" : "+v"(lc));   // the 20 fragment addresses are recomputed per chunk (hoisted they are 20 registers)
+            const int npair = ((chunk + 1) & 3) * 4 + pw;    // the next chunk's pair (chunk 3: the next tile's chunk 0, loaded in phase C)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));   // (per-lane base addresses are recomputed, not carried through the tile loop)
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                int tap = 2 * s + (g >> 1);
+                if (tap > 8) tap = 8;                       // zero-weight slot: read any valid location
+                const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = rh * 2 + (t >> 1);
+                    const int q = (row + ky) * R23_PW + (t & 1) * 16 + lc + kx;
+                    const h8_t bh = *reinterpret_cast<const h8_t *>(Xb + q * 128 + (((pw * 2 + (g & 1)) ^ ((q >> 1) & 7)) << 4));
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bh, acc[t], 0, 0, 0);
+                    acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], bh, acl[t], 0, 0, 0);
+                }
+                if (chunk < 3) {
+                    R23_WLOAD(wh[s], w2h + ((size_t)(npair * 5 + s) * 64 + ln) * 8);
+                    R23_WLOAD(wl[s], w2l + ((size_t)(npair * 5 + s) * 64 + ln) * 8);
+                }
+            }
+            if (chunk < 3) {   // copies for the chunk after next (this tile's, or the next tile's chunk 0); chunk 3's: below
+                const int b2 = ring >= 1 ? ring - 1 : 2;    // (ring + 2) % 3
+                if (chunk < 2) { R23_COPIES(oy0, ox0, chunk + 2, b2) }
+                else { R23_COPIES(noy0, nox0, 0, b2) }      // (past the last tile: the same tile again, never read)
+            }
             const int c0 = pair * 16 + g * 4;
             const float4 sc = sfd2_lds_f4(SS + c0);
             const float4 sh = sfd2_lds_f4(SS + 256 + c0);
 #pragma unroll
-            for (int th = 0; th < 2; ++th) {               // one tile row at a time: half the accumulators live
-                const int row = rh * 2 + th;
-                r23_f4 acc[2], acl[2];
+            for (int t = 0; t < 4; ++t) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) { acc[t] = (r23_f4){0.0f, 0.0f, 0.0f, 0.0f}; acl[t] = acc[t]; }
-#pragma unroll
-                for (int s = 0; s < 5; ++s) {
-                    int tap = 2 * s + (g >> 1);
-                    if (tap > 8) tap = 8;                   // zero-weight slot: read any valid location
-                    const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int q = (row + ky) * R23_PW + t * 16 + lc + kx;
-                        const h8_t bh = *reinterpret_cast<const h8_t *>(Xb + q * R23_GCP + pw * 16 + (g & 1) * 8);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bh, acc[t], 0, 0, 0);
-                        acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], bh, acl[t], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_fmaf(acl[t][r], 1.0f / 2048.0f, acc[t][r]);
-                    uint2 hv, cv;
-                    sfd2_epi4<false>(acc[t][0], acc[t][1], acc[t][2], acc[t][3], sc, sh, sc, 0.0f, hv, cv);
-                    const int pl = row * 32 + t * 16 + lc;
-                    const int slot = (pair * 2 + (g >> 1)) ^ (pl & 31);
-                    *reinterpret_cast<uint2 *>(T2 + pl * 512 + (slot << 4) + (g & 1) * 8) = hv;
-                }
+                for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_fmaf(acl[t][r], 1.0f / 2048.0f, acc[t][r]);
+                uint2 hv, cv;
+                sfd2_epi4<false>(acc[t][0], acc[t][1], acc[t][2], acc[t][3], sc, sh, sc, 0.0f, hv, cv);
+                const int pl = (rh * 2 + (t >> 1)) * 32 + (t & 1) * 16 + lc;
+                const int slot = (pair * 2 + (g >> 1)) ^ (pl & 31);
+                *reinterpret_cast<uint2 *>(T2 + pl * 512 + (slot << 4) + (g & 1) * 8) = hv;
             }
+            ring = ring == 2 ? 0 : ring + 1;
+        }
+        // ------------------------------------------------ phase C: 1x1 + residual over the tile's four rows
+        R23_CYC(4)
+        {
+            int ln0 = lane;
+            asm volatile("" : "+v"(ln0));                   // (recomputed: a lane-derived value carried through the chunk loop is a spill)
+            const int lrow = ln0 & 31, lhi = ln0 >> 5;
+            R23_RES(0)                                      // row 0's residual IN FRONT of chunk 3's copies (below)
+        }
+
+        {
+            const int b2 = ring == 2 ? 0 : ring + 1;        // chunk 3's buffer + 2 (ring has already moved on by one)
+            R23_COPIES(noy0, nox0, 1, b2)
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // T2 complete
-        // ------------------------------------------------ phase C: 1x1 + residual over the tile's four rows
-#pragma unroll 1
-        for (int r4 = 0; r4 < R23_TH; ++r4) {
+        R23_CYC(5)
+        // one row of phase C; LAST: behind it comes the next tile (its first filter fragments are requested here, on EVERY path, so
+        // that the registers are free through the rows before), otherwise the next row's residual
+        auto row = [&](const int r4u, const bool last) __attribute__((always_inline)) {
+            const int r4 = oy0 + r4u < H ? r4u : H - 1 - oy0;     // rows past the image repeat its last row (same values to the same place)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));   // (as above)
+            const int lhi = ln >> 5;
+            const int lrow = ox0 + (ln & 31) < W ? (ln & 31) : W - 1 - ox0;   // columns past the image repeat its last column
             const int oy = oy0 + r4, ox = ox0 + lrow;
-            const bool inb = oy < H && ox < W;
-            const size_t obase = (size_t)(inb ? oy * W + ox : 0) * 256 + wave * 32;
-            uint4 rq[2], rc[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                rq[m] = *reinterpret_cast<const uint4 *>(res + obase + 8 * (2 * m + lhi));
-                rc[m] = *reinterpret_cast<const uint4 *>(res_c + obase + 8 * (2 * m + lhi));
-            }
+            const size_t obase = (size_t)(oy * W + ox) * 256 + wave * 32;
             f32x16_t acc, acl;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acl[r] = 0.0f; }
@@ -185,15 +255,27 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(acl[r], 1.0f / 2048.0f, acc[r]);
 
-            const int cl = wave * 32 + 4 * lhi;
+            uint2 rp[2][2], rcp[2][2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const auto s0 = __builtin_amdgcn_permlane32_swap(rq[m].x, rq[m].z, false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(rq[m].y, rq[m].w, false, false);
-                const uint2 rp[2] = {make_uint2(s0[0], s1[0]), make_uint2(s0[1], s1[1])};
+                rp[m][0] = make_uint2(s0[0], s1[0]); rp[m][1] = make_uint2(s0[1], s1[1]);
                 const auto c0 = __builtin_amdgcn_permlane32_swap(rc[m].x, rc[m].z, false, false);
                 const auto c1 = __builtin_amdgcn_permlane32_swap(rc[m].y, rc[m].w, false, false);
-                const uint2 rcp[2] = {make_uint2(c0[0], c1[0]), make_uint2(c0[1], c1[1])};
+                rcp[m][0] = make_uint2(c0[0], c1[0]); rcp[m][1] = make_uint2(c0[1], c1[1]);
+            }
+            if (!last) { R23_RES(r4u + 1) }
+            else {
+#pragma unroll
+                for (int s = 0; s < 5; ++s) {
+                    R23_WLOAD(wh[s], w2h + ((size_t)(pw * 5 + s) * 64 + ln) * 8);
+                    R23_WLOAD(wl[s], w2l + ((size_t)(pw * 5 + s) * 64 + ln) * 8);
+                }
+            }
+            const int cl = wave * 32 + 4 * lhi;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
                 uint2 pk[2], ck[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -201,37 +283,45 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                     const float4 sc = sfd2_lds_f4(SS + 512 + cl + 8 * q);
                     const float4 sh = sfd2_lds_f4(SS + 768 + cl + 8 * q);
                     h4_t rr;
-                    __builtin_memcpy(&rr, &rp[j], 8);
-                    const float4 ad = make_float4((float)rr[0] + sfd2_corr_lo(rcp[j].x, 0), (float)rr[1] + sfd2_corr_lo(rcp[j].x, 1),
-                                                  (float)rr[2] + sfd2_corr_lo(rcp[j].y, 0), (float)rr[3] + sfd2_corr_lo(rcp[j].y, 1));
+                    __builtin_memcpy(&rr, &rp[m][j], 8);
+                    const float4 ad = make_float4((float)rr[0] + sfd2_corr_lo(rcp[m][j].x, 0), (float)rr[1] + sfd2_corr_lo(rcp[m][j].x, 1),
+                                                  (float)rr[2] + sfd2_corr_lo(rcp[m][j].y, 0), (float)rr[3] + sfd2_corr_lo(rcp[m][j].y, 1));
                     sfd2_epi4<true>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], sc, sh, ad, 0.0f, pk[j], ck[j]);
                 }
                 const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                 const auto t1v = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
                 const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
                 const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
-                if (inb) {
-                    *reinterpret_cast<uint4 *>(out + obase + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1v[0], t0[1], t1v[1]);
-                    *reinterpret_cast<uint4 *>(out_c + obase + 8 * (2 * m + lhi)) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
-                }
+                *reinterpret_cast<uint4 *>(out + obase + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1v[0], t0[1], t1v[1]);
+                *reinterpret_cast<uint4 *>(out_c + obase + 8 * (2 * m + lhi)) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
             }
-        }
+        };
+        // four copies of the row's code: a loop would carry the residual registers around its back edge through copies, and the
+        // compiler waits for the loads in front of those
+        row(0, false); R23_CYC(6)
+        row(1, false); R23_CYC(7)
+        row(2, false); R23_CYC(8)
+        row(3, true);
+        R23_CYC(9)
+        ++tcount;
+#undef R23_RES
         if (!has_next) break;
         tile = next; oy0 = noy0; ox0 = nox0;
     }
-#undef R23_FETCH
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (copies of chunks nobody will read)
+    R23_WALL(1)
+#undef R23_COPIES
 }
 
 // t1: ResBlock.conv1's output, plain fp16 [H][W][256]; res / res_c: the block's input (hi + corr planes); out / out_c: its output
 void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t *w2h, const half_t *w2l, const float *sc2,
                    const float *sh2, const half_t *w3h, const half_t *w3l, const float *sc3, const float *sh3,
-                   const half_t *res, const half_t *res_c, half_t *out, half_t *out_c)
+                   const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page)
 {
-    constexpr size_t lds = (size_t)R23_T2B + 2 * R23_XB + 4 * 256 * sizeof(float);
+    constexpr size_t lds = 0;                               // (static LDS: 150 KB)
     static bool attr_done = false;
     static int slots = 256;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rb23_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             slots = cus;
@@ -242,5 +332,27 @@ void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t 
     if (n_tiles == 0) return;
     const int grid = n_tiles < slots ? n_tiles : slots;
     hipLaunchKernelGGL(rb23_c_kernel, dim3(grid), dim3(R23_NT), lds, st, t1, H, W, w2h, w2l, sc2, sh2, w3h, w3l, sc3, sh3, res, res_c,
-                       out, out_c, tiles_x, n_tiles);
+                       out, out_c, tiles_x, n_tiles, zero_page);
+#ifdef SFD2_RB23_TRACE
+    {
+        static int dumps = 0;
+        if (H >= 250 && ++dumps == 100) {
+            (void)hipStreamSynchronize(st);
+            static unsigned long long hc[2][6][12], hw[1024][2];
+            (void)hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_r23_cyc), sizeof(hc));
+            (void)hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_r23_wall), sizeof(hw));
+            unsigned long long t0 = ~0ull, e0 = ~0ull, e1 = 0; double es = 0;
+            for (int b = 0; b < grid; ++b) t0 = hw[b][0] < t0 ? hw[b][0] : t0;
+            for (int b = 0; b < grid; ++b) { const unsigned long long e = hw[b][1] - t0; e0 = e < e0 ? e : e0; e1 = e > e1 ? e : e1; es += (double)e; }
+            fprintf(stderr, "rb23 trace %dx%d: %d tiles on %d blocks; exit (10 ns) min %llu mean %.0f max %llu\n", H, W, n_tiles, grid, e0, es / grid, e1);
+            fprintf(stderr, "  columns: chunk 0 | 1 | 2 | 3 | residual + copies + barrier | row 0 | 1 | 2 | 3 | (next tile's wait)   cycles\n");
+            for (int w = 0; w < 2; ++w)
+                for (int t = 0; t < 4; ++t) {
+                    fprintf(stderr, "  wave %d tile %d:", w * 7, t);
+                    for (int k = 1; k < 10; ++k) fprintf(stderr, " %6lld", (long long)(hc[w][t][k] - hc[w][t][k - 1]));
+                    fprintf(stderr, " | %6lld\n", (long long)(hc[w][t + 1][0] - hc[w][t][9]));
+                }
+        }
+    }
+#endif
 }

@@ -66,7 +66,7 @@ struct ConvW {                 // one folded + packed layer
     size_t w_floats = 0;       // floats in w (fp32 layers)
 };
 
-struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; const void *pc = nullptr; /* corr plane (f16c) */ };
+struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; const void *pc = nullptr; /* corr plane (f16c) */ bool absent = false; /* stays on chip on the path taken */ };
 
 struct sfd2_ctx {
     int device = 0;
@@ -1061,7 +1061,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                 {   // sfd2_debug_activation: these tensors have no corr plane on this path
                     auto i1 = c->acts.find(std::string(nm1[b]).substr(0, 8) + "bn1"), i2 = c->acts.find(std::string(nm1[b]).substr(0, 8) + "bn2");
                     if (i1 != c->acts.end() && i1->second.p == t1.p) i1->second.pc = t1p ? nullptr : corr_of(t1, PP, 256);
-                    if (i2 != c->acts.end() && i2->second.p == t2.p) i2->second.pc = nullptr;
+                    if (i2 != c->acts.end() && i2->second.p == t2.p) { i2->second.pc = nullptr; i2->second.absent = t1p && c->opt_fuse_rb23; }
                 }
                 if (t1p) {
                     ProfScope ps(c, nm1[b], "conv1x1_c256<comp,plain out>", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 6);
@@ -1075,7 +1075,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                     ProfScope ps(c, nm3[b], "rb23_c_kernel", 2.0 * P4 * 256 * 72 + 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 10);
                     launch_rb23_c(st, t1.as<half_t>(), H4, W4, L2.w.as<half_t>(), L2.wlk.as<half_t>(), L2.scale.as<float>(), L2.shift.as<float>(),
                                   L3.wfh.as<half_t>(), L3.wfl.as<half_t>(), L3.scale.as<float>(), L3.shift.as<float>(), x->as<half_t>(),
-                                  corr_of(*x, PP, 256), ob.as<half_t>(), corr_of(ob, PP, 256));
+                                  corr_of(*x, PP, 256), ob.as<half_t>(), corr_of(ob, PP, 256), c->zero_page.as<half_t>());
                     x = &ob;
                     continue;
                 }
@@ -1094,7 +1094,7 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                 {
                     auto i1 = c->acts.find(std::string(nm1[b]).substr(0, 8) + "bn1"), i2 = c->acts.find(std::string(nm1[b]).substr(0, 8) + "bn2");
                     if (i1 != c->acts.end() && i1->second.p == t1.p) i1->second.pc = corr_of(t1, (size_t)H4 * W4, 256);
-                    if (i2 != c->acts.end() && i2->second.p == t2.p) i2->second.pc = corr_of(t2, (size_t)H4 * W4, 256);
+                    if (i2 != c->acts.end() && i2->second.p == t2.p) { i2->second.pc = corr_of(t2, (size_t)H4 * W4, 256); i2->second.absent = false; }
                 }
                 convc(c, nm1[b], c->rb1[b], *x, H4, W4, t1, H4, W4, 1, true, true);
                 {
@@ -1792,7 +1792,7 @@ extern "C" int sfd2_debug_activation(sfd2_ctx *c, const char *name, float *out, 
     auto it = c->acts.find(name);
     if (it == c->acts.end()) return fail(std::string("unknown activation: ") + name);
     const ActInfo &a = it->second;
-    if (!a.p) return fail(std::string("activation not materialised on this path: ") + name);
+    if (!a.p || a.absent) return fail(std::string("activation not materialised on this path: ") + name);
     if (ch) *ch = a.c;
     if (h) *h = a.h;
     if (w) *w = a.w;

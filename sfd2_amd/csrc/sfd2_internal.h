@@ -204,7 +204,7 @@ void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c,
 // rb23_c_kernel.hip: ResBlock.conv2 + conv3 + residual in one kernel (SFD2_PREC_F16C, option "rb_inner" = 2: t1 plain fp16 in, t2 in LDS)
 void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t *w2h, const half_t *w2l, const float *sc2,
                    const float *sh2, const half_t *w3h, const half_t *w3l, const float *sc3, const float *sh3,
-                   const half_t *res, const half_t *res_c, half_t *out, half_t *out_c);
+                   const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page);
 void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *wpk /*hi, lo fragments*/,
                      const float *scale, const float *shift, half_t *out, half_t *out_c);
 void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk /*fp16 fragments*/,

@@ -83,6 +83,8 @@ def test_f16c_det_vs_oracle(model_c, synth_sd, h, w, seed):
     score, stab, desc = model_c.det(x[None])
     worst = ("", 0.0)
     for name, want in taps.items():
+        if name.endswith(".bn2"):
+            continue      # the grouped conv's output stays in LDS (rb23_c_kernel); covered with fuse_rb23 = 0 below
         got = model_c.context.debug_activation(name)
         assert got.shape == want.shape, name
         err = np.abs(got - want).max() / np.abs(want).max()
@@ -381,3 +383,40 @@ def test_f16c_rb_inner_det_vs_oracle(model_c_inner, synth_sd):
     dd = np.abs(desc[0] - o_desc).max()
     assert dd <= DESC_TOL, dd
     _record(f"f16c rb_inner={model_c_inner.rb_inner} det 130x100: dense desc {dd:.2e}")
+
+
+@pytest.mark.parametrize("h,w,topk", [(100, 130, -1), (480, 640, 1024), (1200, 1600, 4096), (333, 517, 300), (1030, 770, 2000)])
+def test_f16c_fused_conv2_conv3_bit_identical(synth_sd, h, w, topk):
+    """rb23_c_kernel (ResBlock.conv2 + conv3 + residual in one launch, t2 in LDS; option 'fuse_rb23', default on with
+    rb_inner = 2) performs the operations of the two kernels it replaces in the same order: identical bits, on the arena path
+    of sfd2_extract (where the block's output must not take t1's slot any more), for tiles cut by the right and bottom edges
+    and for several tiles per block."""
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    from sfd2_amd.model import ResSegNetV2
+    img = torch.from_numpy(synth.make_image(h, w, 78)).cuda()
+    x = orc.norm_rgb(synth.make_image(min(h, 200), min(w, 264), 14))
+    outs = []
+    for fuse in (0, 1):
+        m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
+        m.load_state_dict(synth_sd)
+        m.cuda(0)
+        m.context.set_option("fuse_rb23", fuse)
+        o = extract_resnet_return(m, img[None], conf_th=0.001, topK=topk, scales=[1.0])
+        m.det(x[None])
+        o["acts"] = [m.context.debug_activation(f"conv4.{b}") for b in range(3)]
+        if fuse == 0:      # two launches: the grouped conv's output is in HBM and can be compared with the oracle's
+            taps = {}
+            orc.det(synth_sd, x, taps)
+            for nm in ("conv4.0.bn1", "conv4.0.bn2"):      # (the oracle taps the first block's inner tensors)
+                got = m.context.debug_activation(nm)
+                err = np.abs(got - taps[nm]).max() / np.abs(taps[nm]).max()
+                assert err <= ACT_TOL, (nm, err)
+        else:
+            with pytest.raises(RuntimeError, match="not materialised"):
+                m.context.debug_activation("conv4.0.bn2")
+        outs.append(o)
+    for k in ("keypoints", "scores", "descriptors"):
+        np.testing.assert_array_equal(outs[0][k], outs[1][k])
+    for a, b in zip(outs[0]["acts"], outs[1]["acts"]):
+        np.testing.assert_array_equal(a, b)
