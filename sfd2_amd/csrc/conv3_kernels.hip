@@ -72,6 +72,12 @@ __device__ __forceinline__ h4_t cvt4c(float a, float b, float c, float d)
 // the chunk loop simply runs on through the corr plane's chunks, whose units go to ONE v_mfma_scale_f32_32x32x64_f8f6f4 per
 // (channel tile, pixel tile) instead of two fp16 MFMAs (same LDS records, same fragment reads); bit 1 = the corr plane of
 // the output is written (out_c).
+// Measured with the trace below (conv2a compensated, 64 -> 128 channels: K loop 45k cycles, epilogue 15-22k, wait at the next
+// tile's top 2-9k): the epilogue is long because every CU writes its 256 KB tile at the same time (64 MB per round, the K loops
+// being equally long everywhere), not because of the wait the compiler puts in front of the epilogue's first LDS read (it orders
+// LDS accesses behind pending direct-to-LDS copies it cannot prove disjoint, here the next tile's first copies): with the copies
+// issued by inline asm -- no such wait -- and the next tile's scale / shift stored before them, conv2a 147.6 -> 152.9 us,
+// conv3a 119.3 -> 121.0, conv3b and convDa unchanged.  Not kept.
 // -DSFD2_PP_TRACE: wall-clock stamps (s_memrealtime, 100 MHz) of every block (entry, exit) and cycle stamps of block 3's waves 0
 // and 4 around the sections of its tiles, printed by the launcher for the compensated instantiations
 #ifdef SFD2_PP_TRACE
