@@ -131,6 +131,9 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *               conv's output, 2: conv1's output too, 0: both compensated); the block's input / output / skip path and all
  *               filters stay compensated.  These layers are bound by HBM bytes: 1.82 / 1.75 / 1.67 ms per 1600x1200 extract
  *               for 0 / 1 / 2, descriptors <= 3.5e-4 / 3.8e-4 / 4.9e-4 (tests assert 7e-4 for 1 and 2, 1e-3 everywhere).
+ *   "sparse_da3" 1 (default) / 0: on the extract path (with "sparse_desc"), convDa.3 runs on the 4 x K bilinear corner pixels of the
+ *               selected key points only instead of the whole 1/4-resolution map (-77 us per 1600x1200 / top-4096 extract;
+ *               descriptors within 4e-5 of the dense path's: another fp32 summation order).  0 = dense.
  *   "fuse_rb23" 1 (default) / 0: with rb_inner = 2, ResBlock.conv2 + conv3 + residual in one kernel (the grouped conv's output tile
  *               stays in LDS); 0 = two launches.  Bit-identical.
  *   "comp_heads" 0 (default) / 1: SFD2_PREC_F16C compensates the four 3x3 layers of the two head branches as well

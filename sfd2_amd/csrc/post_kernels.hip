@@ -720,7 +720,7 @@ __global__ __launch_bounds__(NT)
 void desc_head_kernel(const half_t *__restrict__ fmap /*[hc][wc][256]*/, int hc, int wc, float half_w, float half_h,
                       const half_t *__restrict__ wpk /*[8 chunks][CoutP][32]*/, int CoutP, const float *__restrict__ scale,
                       const float *__restrict__ shift, const float *__restrict__ kpts, const unsigned int *__restrict__ count,
-                      int n_max, float *__restrict__ out)
+                      int n_max, float *__restrict__ out, int compact /* fmap = [key point][corner][256] (sparse_da3_kernel), not the dense map */)
 {
     __shared__ __attribute__((aligned(16))) unsigned char X[4 * DH_KP * DH_XREC];
     __shared__ __attribute__((aligned(16))) float O[4 * DH_KP * DH_OREC];
@@ -759,7 +759,7 @@ void desc_head_kernel(const half_t *__restrict__ fmap /*[hc][wc][256]*/, int hc,
         const SampleGeom g = sample_geom(kx[i], ky[i], half_w, half_h, hc, wc);
         const int yy = (corner & 2) ? g.y1 : g.y0, xx = (corner & 1) ? g.x1 : g.x0;
         gok[i] = kp < n && ((corner & 2) ? g.vy1 : g.vy0) && ((corner & 1) ? g.vx1 : g.vx0);
-        const size_t pix = gok[i] ? (size_t)yy * wc + xx : 0;
+        const size_t pix = gok[i] ? (compact ? (size_t)kp * 4 + corner : (size_t)yy * wc + xx) : 0;
         gv[i] = *reinterpret_cast<const uint4 *>(fmap + pix * 256 + lrow * 8);
     }
 #pragma unroll
@@ -820,11 +820,11 @@ void desc_head_kernel(const half_t *__restrict__ fmap /*[hc][wc][256]*/, int hc,
 }
 
 void launch_desc_head(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, int CoutP,
-                      const float *scale, const float *shift, const float *kpts, const unsigned int *count, int n_max, float *out)
+                      const float *scale, const float *shift, const float *kpts, const unsigned int *count, int n_max, float *out, int compact)
 {
     if (n_max <= 0) return;
     hipLaunchKernelGGL(desc_head_kernel, dim3((n_max + DH_KP - 1) / DH_KP), dim3(NT), 0, st, fmap, hc, wc, (float)nw / 2.0f,
-                       (float)nh / 2.0f, wpk, CoutP, scale, shift, kpts, count, n_max, out);
+                       (float)nh / 2.0f, wpk, CoutP, scale, shift, kpts, count, n_max, out, compact);
 }
 
 // ---------------------------------------------------------------- dense descriptor normalise + NHWC -> NCHW

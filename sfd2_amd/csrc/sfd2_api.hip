@@ -92,6 +92,10 @@ struct sfd2_ctx {
     int skip_head_now = 0;             // set per call: run_network leaves the detector soft-max to the fused NMS kernel
     int opt_sparse_desc = 1;           // sfd2_set_option "sparse_desc": extract path runs convDb on the sampled corner pixels only
     int skip_db_now = 0;               // set per call: run_network leaves convDb to the sparse descriptor head
+    int skip_da3_now = 0;              // set per call: run_network leaves convDa.3 to the sparse descriptor path (sparse_da3_kernel)
+    const half_t *da0_cur = nullptr;   // convDa.0 output of the last fp16 network pass
+    DevBuf da3_sparse;                 // [sel_cap][4][256] fp16: convDa.3 on the sampled corner pixels
+    int opt_sparse_da3 = 1;            // sfd2_set_option "sparse_da3": with the sparse descriptor head, convDa.3 on the sampled corners only
     int skip_pb_now = 0;               // set per call: run_network leaves convPb to the fused detector head
     int opt_fuse_pb = 1;               // sfd2_set_option "fuse_pb": convPb inside the fused detector-head / heat-map kernel
     const half_t *pa_cur = nullptr;    // convPa.3 output of the last fp16 network pass
@@ -228,7 +232,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     graphs_release(c);
-    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
+    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->da3_sparse, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
                       &c->rt1[0], &c->rt1[1], &c->rt1[2], &c->rt2[0], &c->rt2[1], &c->rt2[2], &c->ro[0], &c->ro[1],
                       &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
                       &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->bnd, &c->sel, &c->sorted, &c->counters,
@@ -1170,9 +1174,10 @@ static int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         convc(c, "convDa.3", c->da3, da0_o, H4, W4, da_o, H4, W4, 0, true, false);
     } else {
         conv(c, "convDa.0", c->da0, *x, H4, W4, da0_o, H4, W4, 1);
-        conv(c, "convDa.3", c->da3, da0_o, H4, W4, da_o, H4, W4, 0);
+        if (!c->skip_da3_now) conv(c, "convDa.3", c->da3, da0_o, H4, W4, da_o, H4, W4, 0);
     }
     c->da_cur = da_o.as<half_t>();
+    c->da0_cur = da0_o.as<half_t>();
     if (!c->skip_db_now) conv(c, "convDb", c->db, da_o, H4, W4, c->draw, H4, W4, 0, nullptr, 1);
     if (c->has_sta && !sta_early) {
         ProfScope ps(c, "ConvSta", "convsta_kernel", 2.0 * P4 * 3 * 256, P4 * (512 + 12));
@@ -1336,9 +1341,15 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     const int sel_bound = top_k > 0 ? top_k : c->cand_cap;
     const bool sparse_desc = c->opt_sparse_desc && c->fuse_now && desc && top_k > 0 && (size_t)16 * sel_bound <= (size_t)c->H4 * c->W4;
     c->skip_db_now = sparse_desc ? 1 : 0;
+    // ... and convDa.3 (3x3) is needed at those corners only as well: 4 x K pixels instead of the whole map (sparse_da3_kernel).
+    // Not with compensated head branches (option "comp_heads": convDa.0's output then has a corr plane this kernel does not read).
+    const bool comp_heads_now = c->precision == SFD2_PREC_F16C && c->opt_comp_heads && c->opt_comp_rb;
+    const bool sparse_da3 = sparse_desc && c->opt_sparse_da3 && !comp_heads_now && !c->opt_branches;
+    c->skip_da3_now = sparse_da3 ? 1 : 0;
     const int net_rc = run_network(c, img_dev, in_mode);
     c->skip_head_now = 0;
     c->skip_db_now = 0;
+    c->skip_da3_now = 0;
     c->skip_pb_now = 0;
     if (net_rc) return -1;
     if (release_image_slot(c)) return -1;
@@ -1376,7 +1387,18 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
             HIPCHECK(c->kdesc.ensure((size_t)sel_cap * 128 * sizeof(float)));
             desc_dst = c->kdesc.as<float>();
         }
-        if (sparse_desc) {
+        if (sparse_da3) {
+            HIPCHECK(c->da3_sparse.ensure((size_t)sel_cap * 4 * 256 * sizeof(half_t)));
+            {
+                ProfScope ps(c, "convDa.3", "sparse_da3_kernel", 2.0 * 4 * sel_cap * 256.0 * 256.0 * 9, (double)sel_cap * (16 * 512 + 4 * 512) + 2.0 * 256 * 256 * 9);
+                launch_sparse_da3(c->stream, c->da0_cur, c->H4, c->W4, H, W, c->da3.w.as<half_t>(), c->da3.cout_pad, c->da3.scale.as<float>(),
+                                  c->da3.shift.as<float>(), 0, c->kpts_cur, c->counters.as<unsigned int>() + 1, sel_cap,
+                                  c->da3_sparse.as<half_t>(), c->zero_page.as<half_t>());
+            }
+            ProfScope ps(c, "desc_head", "desc_head_kernel", 2.0 * 4 * sel_cap * 128 * 256, (double)sel_cap * (4 * 512 + 512));
+            launch_desc_head(c->stream, c->da3_sparse.as<half_t>(), c->H4, c->W4, H, W, c->db.w.as<half_t>(), c->db.cout_pad, c->db.scale.as<float>(),
+                             c->db.shift.as<float>(), c->kpts_cur, c->counters.as<unsigned int>() + 1, sel_cap, desc_dst, 1);
+        } else if (sparse_desc) {
             ProfScope ps(c, "desc_head", "desc_head_kernel", 2.0 * 4 * sel_cap * 128 * 256, (double)sel_cap * (4 * 512 + 512));
             launch_desc_head(c->stream, c->da_cur, c->H4, c->W4, H, W, c->db.w.as<half_t>(), c->db.cout_pad, c->db.scale.as<float>(),
                              c->db.shift.as<float>(), c->kpts_cur, c->counters.as<unsigned int>() + 1, sel_cap, desc_dst);
@@ -2359,6 +2381,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "branches") c->opt_branches = value ? 1 : 0;
     else if (k == "fuse_post") c->opt_fuse_post = value ? 1 : 0;
     else if (k == "sparse_desc") c->opt_sparse_desc = value ? 1 : 0;
+    else if (k == "sparse_da3") c->opt_sparse_da3 = value ? 1 : 0;
     else if (k == "fuse_pb") c->opt_fuse_pb = value ? 1 : 0;
     else if (k == "generic_c") c->opt_generic_c = value ? 1 : 0;
     else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;

@@ -201,6 +201,10 @@ void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int nor
 void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c, int npix, const half_t *w_frag,
                            const half_t *wc_frag, const float *scale, const float *shift, int relu, const half_t *res,
                            const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte);
+// sparse_da3_kernel.hip: convDa.3 on the four bilinear corner pixels of every selected key point only -> out [n_max][4][256] fp16
+void launch_sparse_da3(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, int CoutP,
+                       const float *scale, const float *shift, int relu, const float *kpts, const unsigned int *count, int n_max,
+                       half_t *out, const half_t *zero_page);
 // rb23_c_kernel.hip: ResBlock.conv2 + conv3 + residual in one kernel (SFD2_PREC_F16C, option "rb_inner" = 2: t1 plain fp16 in, t2 in LDS)
 void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t *w2h, const half_t *w2l, const float *sc2,
                    const float *sh2, const half_t *w3h, const half_t *w3l, const float *sc3, const float *sh3,
@@ -342,7 +346,7 @@ void launch_pb_heads_heat(hipStream_t st, const half_t *fmap, int hc8, int wc8, 
                           unsigned int *zero_words /*nullable: n_zero words cleared if the grid covers them*/, int n_zero);
 bool pb_heads_heat_clears(int hc8, int wc8, int n_zero);
 void launch_desc_head(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, int CoutP,
-                      const float *scale, const float *shift, const float *kpts, const unsigned int *count, int n_max, float *out);
+                      const float *scale, const float *shift, const float *kpts, const unsigned int *count, int n_max, float *out, int compact = 0);
 // desc_raw NHWC [P][128] -> normalised NCHW [128][P]
 void launch_desc_normalise_nchw(hipStream_t st, const float *desc_nhwc, int npix, float *out_nchw);
 // layout helpers

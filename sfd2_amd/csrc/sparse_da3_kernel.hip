@@ -1,0 +1,139 @@
+// convDa.3 (3x3, 256 -> 256, no activation: nets/sfd2.py:340-342) on the SAMPLED pixels only.  extract_resnet_return samples the
+// unit-norm descriptor map at the selected key points (nets/extractor.py:199-208): bilinear, i.e. four corner pixels of the
+// 1/4-resolution map per key point.  convDb (1x1) already runs on those corners only (desc_head_kernel, post_kernels.hip); its
+// input, convDa.3's output, is needed at the same 4 x K pixels -- 16 384 of 120 000 at 1600x1200 / top-4096 -- so on the
+// extract path this kernel computes convDa.3 there and nowhere else: a key point's four corners are a 2 x 2 block whose 3x3
+// neighbourhoods are one 4 x 4 patch of convDa.0's output.
+//
+//   block   16 key points (64 output pixels = two 32-pixel MFMA tiles) x 128 output channels (grid.y = 2); 4 waves, a wave owns
+//           32 channels; up to four blocks per CU, which is what hides the gather round trips
+//   K loop  four 64-channel chunks: the 16 patches' records (16 x 16 pixels x 128 B = 32 KB) are copied global -> LDS
+//           (a record's eight 16-byte parts at slot part ^ (record & 7): conflict-free fragment reads without padding), then
+//           9 taps x 4 K-slices of v_mfma_f32_32x32x16_f16 per tile, filter fragments straight from the packed filters in L2
+//   output  compact [key point][corner][256] fp16 = what desc_head_kernel gathers from the dense map otherwise
+//
+// Same products as the dense layer (conv3x3_pp), fp32 summation order differs (chunk-major there too, taps inside): outputs
+// agree to fp32 rounding before the fp16 store, i.e. are identical except where a sum sits on an fp16 rounding boundary.
+#include "sfd2_internal.h"
+
+#define SD_KP 16
+#define SD_NT 256
+#define SD_XB (SD_KP * 16 * 128)
+
+typedef __attribute__((address_space(3))) void sd_lds_t;
+typedef const __attribute__((address_space(1))) void sd_gbl_t;
+
+// nets/extractor.py:199-208 (F.grid_sample, bilinear, align_corners=False): the top-left corner of the key point's 2 x 2 block,
+// the arithmetic of post_kernels.hip's sample_geom
+__device__ __forceinline__ void sd_corner(float kx, float ky, float half_w, float half_h, int hc, int wc, int &x0, int &y0)
+{
+    const float gx = __fsub_rn(__fdiv_rn(kx, half_w), 1.0f);
+    const float gy = __fsub_rn(__fdiv_rn(ky, half_h), 1.0f);
+    const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.0f), (float)wc), 1.0f), 2.0f);
+    const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.0f), (float)hc), 1.0f), 2.0f);
+    x0 = (int)floorf(ix);
+    y0 = (int)floorf(iy);
+}
+
+__global__ __launch_bounds__(SD_NT, 3)
+void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][wc][256]*/, int hc, int wc, float half_w, float half_h,
+                       const half_t *__restrict__ wpk /*[8 chunks of 32][9 taps][CoutP][32]*/, int CoutP,
+                       const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                       const float *__restrict__ kpts, const unsigned int *__restrict__ count, int n_max,
+                       half_t *__restrict__ out /*[n_max][4][256]*/, const half_t *__restrict__ zero_page)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char X[SD_XB];
+    __shared__ int geo[2 * SD_KP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhi = lane >> 5;
+    int n = n_max;
+    if (count) { const unsigned int c = *count; if ((unsigned int)n > c) n = (int)c; }
+    const int k0 = blockIdx.x * SD_KP;
+    if (k0 >= n) return;
+    const int n0 = blockIdx.y * 128 + wave * 32;            // this wave's output channels
+
+    if (tid < SD_KP) {
+        const int kp = k0 + tid < n ? k0 + tid : n - 1;
+        int x0, y0;
+        sd_corner(kpts[2 * kp], kpts[2 * kp + 1], half_w, half_h, hc, wc, x0, y0);
+        geo[2 * tid] = x0;
+        geo[2 * tid + 1] = y0;
+    }
+    __syncthreads();
+
+    f32x16_t acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // B fragments: lane -> pixel p = lrow of tile t: key point t * 8 + (p >> 2), corner p & 3 (row = corner >> 1, column = corner & 1)
+    int recb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) recb[t] = (t * 8 + (lrow >> 2)) * 16 + ((lrow >> 1) & 1) * 4 + (lrow & 1);
+
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        if (c) __syncthreads();                               // every wave is past its reads of the previous chunk
+        // copies: instruction j = wave + 4 * i moves records 8 j .. 8 j + 7 (half a key point's patch), lane -> (record, slot)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = wave + 4 * i;
+            const int kpl = j >> 1, ppix = (j & 1) * 8 + (lane >> 3), slot = lane & 7;
+            const int x0 = geo[2 * kpl], y0 = geo[2 * kpl + 1];
+            const int iy = y0 - 1 + (ppix >> 2), ix = x0 - 1 + (ppix & 3);
+            const int part = slot ^ (ppix & 7);
+            const bool ok = iy >= 0 && iy < hc && ix >= 0 && ix < wc;
+            const half_t *src = ok ? fmap + ((size_t)iy * wc + ix) * 256 + c * 64 + part * 8 : zero_page + slot * 8;
+            __builtin_amdgcn_global_load_lds((sd_gbl_t *)src, (sd_lds_t *)(X + j * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            h8_t a[4];
+#pragma unroll
+            for (int k16 = 0; k16 < 4; ++k16)
+                a[k16] = *reinterpret_cast<const h8_t *>(wpk + ((size_t)((c * 2 + (k16 >> 1)) * 9 + tap) * CoutP + n0 + lrow) * 32 +
+                                                         (k16 & 1) * 16 + lhi * 8);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int rec = recb[t] + ky * 4 + kx;
+#pragma unroll
+                for (int k16 = 0; k16 < 4; ++k16) {
+                    const h8_t b = *reinterpret_cast<const h8_t *>(X + rec * 128 + (((k16 * 2 + lhi) ^ (rec & 7)) << 4));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k16], b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // C layout: lane owns pixel (t * 32 + lrow), channels n0 + 8 q + 4 lhi + j
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int kp = k0 + t * 8 + (lrow >> 2);
+        if (kp >= n) continue;
+        half_t *o = out + ((size_t)kp * 4 + (lrow & 3)) * 256 + n0 + 4 * lhi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 sc = *reinterpret_cast<const float4 *>(scale + n0 + 8 * q + 4 * lhi);
+            const float4 sh = *reinterpret_cast<const float4 *>(shift + n0 + 8 * q + 4 * lhi);
+            float v0 = acc[t][4 * q + 0] * sc.x + sh.x, v1 = acc[t][4 * q + 1] * sc.y + sh.y;
+            float v2 = acc[t][4 * q + 2] * sc.z + sh.z, v3 = acc[t][4 * q + 3] * sc.w + sh.w;
+            if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
+            h4_t hv = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+            *reinterpret_cast<h4_t *>(o + 8 * q) = hv;
+        }
+    }
+}
+
+void launch_sparse_da3(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, int CoutP,
+                       const float *scale, const float *shift, int relu, const float *kpts, const unsigned int *count, int n_max,
+                       half_t *out, const half_t *zero_page)
+{
+    if (n_max <= 0) return;
+    hipLaunchKernelGGL(sparse_da3_kernel, dim3((n_max + SD_KP - 1) / SD_KP, 2), dim3(SD_NT), 0, st, fmap, hc, wc, (float)nw / 2.0f,
+                       (float)nh / 2.0f, wpk, CoutP, scale, shift, relu, kpts, count, n_max, out, zero_page);
+}

@@ -538,6 +538,7 @@ def test_sparse_descriptor_head_bit_identical(synth_sd, h, w, topk):
         m.load_state_dict(synth_sd)
         m.cuda(0)
         m.context.set_option("sparse_desc", sparse)
+        m.context.set_option("sparse_da3", 0)     # (convDa.3 dense in both: its sparse form has its own test, tests/test_gpu_f16c.py)
         img = synth.make_image(h, w, 77)
         outs.append(extract_resnet_return(m, img[None], conf_th=0.001, topK=topk, scales=[1.0]))
     a, b = outs
@@ -591,7 +592,8 @@ def test_fused_heads_edge_cases(synth_sd):
         assert len(a["keypoints"]) == len(b["keypoints"]), (img.shape, topk)
         np.testing.assert_array_equal(a["keypoints"], b["keypoints"])
         np.testing.assert_array_equal(a["scores"], b["scores"])
-        np.testing.assert_array_equal(a["descriptors"], b["descriptors"])
+        # (with the sparse head, convDa.3 runs on the sampled corners only: another fp32 summation order in front of an fp16 store)
+        np.testing.assert_allclose(a["descriptors"], b["descriptors"], rtol=0, atol=1e-4)
         assert np.isfinite(a["descriptors"]).all()
 
 

@@ -420,3 +420,38 @@ def test_f16c_fused_conv2_conv3_bit_identical(synth_sd, h, w, topk):
         np.testing.assert_array_equal(outs[0][k], outs[1][k])
     for a, b in zip(outs[0]["acts"], outs[1]["acts"]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("prec,tol", [("f16c", DESC_TOL), ("f16", 3e-3)])
+@pytest.mark.parametrize("h,w,seed,topk", [(100, 130, 22, 60), (480, 640, 0, 1024), (1200, 1600, 31, 4096), (333, 517, 5, 300), (1600, 1200, 64, 4096)])
+def test_sparse_da3_equals_dense_path_and_oracle(synth_sd, prec, tol, h, w, seed, topk):
+    """Option 'sparse_da3' (default on, extract path): convDa.3 is computed on the 4 x K bilinear corner pixels of the selected key
+    points only (sparse_da3_kernel), instead of on the whole 1/4-resolution map.  Same products as the dense layer, another fp32
+    summation order: key points and scores are untouched (they do not depend on the descriptor branch), descriptors agree with
+    the dense path to 1e-4 (an fp16 store of convDa.3's output now and then rounds the other way) and with the oracle within the
+    mode's tolerance.  Corners outside the map (key points on the border) and key-point counts that do not fill a block are in
+    the small cases."""
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    from sfd2_amd.model import ResSegNetV2
+    img = synth.make_image(h, w, seed)
+    dev = torch.from_numpy(img)[None].cuda()
+    outs = []
+    for sp in (0, 1):
+        m = ResSegNetV2(outdim=128, require_stability=True, precision=prec).eval()
+        m.load_state_dict(synth_sd)
+        m.cuda(0)
+        m.context.set_option("sparse_da3", sp)
+        outs.append(extract_resnet_return(m, dev, conf_th=0.001, topK=topk, scales=[1.0]))
+    np.testing.assert_array_equal(outs[0]["keypoints"], outs[1]["keypoints"])
+    np.testing.assert_array_equal(outs[0]["scores"], outs[1]["scores"])
+    dd = np.abs(outs[0]["descriptors"] - outs[1]["descriptors"]).max()
+    assert dd <= 1e-4, dd
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk)
+    a, b = _kp_index(outs[1]["keypoints"]), _kp_index(want["keypoints"])
+    common = sorted(set(a) & set(b))
+    ia = np.array([a[k] for k in common]); ib = np.array([b[k] for k in common])
+    do = np.abs(outs[1]["descriptors"][ia] - np.asarray(want["descriptors"], dtype=np.float64)[ib]).max()
+    assert do <= tol, do
+    np.testing.assert_allclose(np.linalg.norm(outs[1]["descriptors"], axis=1), 1.0, atol=1e-5)
+    _record(f"{prec} sparse_da3 {w}x{h} top{topk}: vs dense path {dd:.2e}, vs oracle {do:.2e} ({len(common)} common key points)")
