@@ -184,7 +184,7 @@ void launch_conv1x1_c256(hipStream_t st, const half_t *in, int npix, const half_
     }
     const int ngroups = (npix + GPX - 1) / GPX;
     if (ngroups == 0) return;
-    const int gpb = (ngroups + slots - 1) / slots;
+    const int gpb = (ngroups + sfd2_slots(slots) - 1) / sfd2_slots(slots);
     const int grid = (ngroups + gpb - 1) / gpb;
     if (res) hipLaunchKernelGGL(conv1x1_c256_kernel<true>, dim3(grid), dim3(NT1), lds, st, in, npix, w_rowmajor, scale, shift, relu, res, out, gpb, zero_page);
     else hipLaunchKernelGGL(conv1x1_c256_kernel<false>, dim3(grid), dim3(NT1), lds, st, in, npix, w_rowmajor, scale, shift, relu, res, out, gpb, zero_page);
@@ -387,7 +387,7 @@ void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c,
     }
     const int ngroups = (npix + GPXC - 1) / GPXC;
     if (ngroups == 0) return;
-    const int gpb = (ngroups + slots - 1) / slots;
+    const int gpb = (ngroups + sfd2_slots(slots) - 1) / sfd2_slots(slots);
     const int grid = (ngroups + gpb - 1) / gpb;
     const int sa = (sbyte & 255) * 0x01010101;
 #define C256C_GO(R_, I_, O_) hipLaunchKernelGGL((conv1x1_c256_c_kernel<R_, I_, O_>), dim3(grid), dim3(NT1), lds, st, in, in_c, npix, w_frag, wc_frag, scale, shift, relu, res, res_c, out, out_c, gpb, zero_page, sa)

@@ -403,7 +403,7 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
     }
     const int tiles_x = (Wo + PP_TW - 1) / PP_TW, tiles_y = (Ho + PP_TH - 1) / PP_TH;
     const int n_tiles = tiles_x * tiles_y * (CoutP / PP_BN);
-    const int grid = n_tiles < slots ? n_tiles : slots;
+    const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out,
                        Ho, Wo, tiles_x, n_tiles, zero_page, in_c, out_c, sa);
 #ifdef SFD2_PP_TRACE

@@ -468,7 +468,7 @@ static void launch_rf_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
     }
     const int tiles_x = (Wo + RF_TW - 1) / RF_TW, tiles_y = (Ho + RF_TH - 1) / RF_TH;
     const int n_tiles = tiles_x * tiles_y;                 // CoutP == BN: one channel tile
-    const int grid = n_tiles < slots ? n_tiles : slots;
+    const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out,
                        Ho, Wo, tiles_x, n_tiles, zero_page, in_c, out_c, sa);
 }

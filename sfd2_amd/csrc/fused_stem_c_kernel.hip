@@ -420,7 +420,7 @@ void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int nor
     }
     const int tiles_x = (W2 + SC_TW - 1) / SC_TW, tiles_y = (H2 + SC_TH - 1) / SC_TH;
     const int n_tiles = tiles_x * tiles_y;
-    const int grid = n_tiles < slots ? n_tiles : slots;
+    const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
     hipLaunchKernelGGL(fused_stem_c_kernel, dim3(grid), dim3(SC_NT), SC_LDS, st, img, H, W, normalise, w1, sc1, sh1,
                        reinterpret_cast<const unsigned char *>(w2), sc2, sh2, out, out_c, H2, W2, tiles_x, n_tiles,
                        (sbyte & 255) * 0x01010101);

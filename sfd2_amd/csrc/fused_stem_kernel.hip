@@ -322,7 +322,7 @@ void launch_fused_stem(hipStream_t st, const float *img, int H, int W, int norma
     }
     const int tiles_x = (W2 + F_TW - 1) / F_TW, tiles_y = (H2 + F_TH - 1) / F_TH;
     const int n_tiles = tiles_x * tiles_y;
-    const int grid = n_tiles < slots ? n_tiles : slots;
+    const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
     hipLaunchKernelGGL(fused_stem_kernel, dim3(grid), dim3(NT), lds, st, img, H, W, normalise, w1, sc1, sh1, w2, sc2, sh2, out,
                        H2, W2, tiles_x, n_tiles);
 #ifdef SFD2_STEM_TRACE

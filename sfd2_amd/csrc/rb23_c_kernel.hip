@@ -48,13 +48,17 @@ __device__ unsigned long long g_r23_wall[1024][2];
 
 // Pipeline.  Patch chunks travel global -> LDS by direct copies (global_load_lds), TWO chunks ahead of their use, into a ring of
 // three buffers (a chunk's compute, ~1.5k cycles, is shorter than an HBM round trip); a 128-byte pixel record's eight 16-byte
-// parts sit at slot part ^ ((pixel >> 1) & 7), so the 16 pixels a fragment read touches fall into 16 different bank groups
-// without padding.  The grouped conv's filter fragments of the NEXT chunk are loaded into the registers of the step that has
+// parts sit at slot part ^ ((patch column >> 1) & 7), so the 16 pixels a fragment read touches fall into 16 different bank
+// groups without padding -- and, the row not entering the swizzle, a lane's 20 fragment addresses of a chunk are five per-lane
+// offsets (one per K step: the tap differs between lane groups) plus compile-time (row, pixel half) offsets that fit the
+// ds_read immediate.  A chunk is bound by VALU issue (16-wide SIMDs: a wave64 instruction takes four cycles, 40 MFMAs per chunk
+// take 640), so what is computed per chunk is kept to the accumulator fold, the BN epilogue and a few adds.  The grouped conv's filter fragments of the NEXT chunk are loaded into the registers of the step that has
 // just issued its MFMAs; the copies for chunk n + 2 go out after chunk n's MFMAs, i.e. BEHIND those loads in the wave's
 // memory queue, so `vmcnt(4)` at the top of a chunk (every wave issues exactly four copies per chunk) covers the filters and
-// the chunk's own patch and leaves the newest copies in flight.  Phase C: a row's residual is loaded during the previous row's
-// epilogue (into the registers the second accumulator has just left), the next tile's first filter fragments before the last
-// row's stores; those four stores are all that is still in flight at the top of the next tile.
+// the chunk's own patch and leaves the newest copies in flight.  Phase C: a row's residual is loaded two rows ahead (rows 0 / 1
+// around chunk 3's copies, rows 2 / 3 during the epilogues of rows 0 / 1, into the registers those have just emptied), the next
+// tile's first filter fragments before the last row's stores; those four stores are all that is still in flight at the top of
+// the next tile.
 __global__ __launch_bounds__(R23_NT, 2)
 void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                    const half_t *__restrict__ w2h /*[16 pairs][5 steps][64 lanes][8]*/, const half_t *__restrict__ w2l /*residuals * 2^11, same layout*/,
@@ -62,7 +66,7 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                    const half_t *__restrict__ w3h /*fragment order [8 waves][8][64 lanes][16]*/, const half_t *__restrict__ w3l,
                    const float *__restrict__ sc3, const float *__restrict__ sh3,
                    const half_t *__restrict__ res, const half_t *__restrict__ res_c,
-                   half_t *__restrict__ out, half_t *__restrict__ out_c, int tiles_x, int n_tiles, const half_t *__restrict__ zero_page)
+                   half_t *__restrict__ out, half_t *__restrict__ out_c, int tiles_x, int n_tiles)
 {
     // Three separate LDS objects, not slices of one array: the compiler orders every LDS store behind all pending direct-to-LDS
     // copies it cannot prove disjoint from it (`s_waitcnt vmcnt(0)` in front of the first T2 store of every chunk: the copies
@@ -92,27 +96,55 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
     for (int t = tid; t < 256; t += R23_NT) { SS[t] = sc2[t]; SS[256 + t] = sh2[t]; SS[512 + t] = sc3[t]; SS[768 + t] = sh3[t]; }
 
     // copies of one chunk: instruction j = wave + 8 * i (i < 4) moves pieces j * 64 + lane (pixel = piece >> 3, slot = piece & 7);
-    // j >= 26 has nothing to move and reads the zero page into the spare KB -- every wave issues four, the counted waits rely on it
-#define R23_COPIES(oy0_, ox0_, chunk_, buf_)                                                              \
+    // j >= 26 has nothing to move -- every wave issues four all the same, the counted waits rely on it.  `buffer_load ... lds` with
+    // per-lane BYTE OFFSETS computed once per tile (R23_SETUP): padding, pixels outside the image and the idle instructions get
+    // an offset beyond the buffer's range, for which the hardware returns zeros; a chunk is the scalar offset chunk * 128.
+    // (As `global_load ... lds` with the address arithmetic and the bounds tests per copy, a chunk's four copies were ~240 of
+    // its ~760 instructions, and the chunk is bound by instruction issue: 40 MFMAs.)
+    const int t1_bytes = (int)((size_t)H * W * 256 * sizeof(half_t));
+    const auto t1_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(t1), 0, t1_bytes, 0x00020000);
+    int xoff[4];
+#define R23_SETUP(oy0_, ox0_)                                                                             \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
         const int j = wave + 8 * i;                                                                       \
         int piece = j * 64 + lane;                                                                        \
-        asm volatile("" : "+v"(piece));   /* (recomputed per chunk: not worth four registers) */           \
+        asm volatile("" : "+v"(piece));   /* (recomputed per tile) */                                      \
         const int q = piece >> 3;                                                                         \
         const int py = (q * 241) >> 13, px = q - py * R23_PW;                                             \
         const int iy = (oy0_)-1 + py, ix = (ox0_)-1 + px;                                                  \
-        const int part = (piece & 7) ^ ((q >> 1) & 7);                                                    \
+        const int part = (piece & 7) ^ ((px >> 1) & 7);   /* slot = part ^ ((column >> 1) & 7) */          \
         const bool ok = j < 26 && q < R23_NPIX && iy >= 0 && iy < H && ix >= 0 && ix < W;                  \
-        const half_t *src = ok ? t1 + (size_t)(iy * W + ix) * 256 + (chunk_)*64 + part * 8 : zero_page + (lane & 7) * 8; \
+        xoff[i] = ok ? ((iy * W + ix) * 256 + part * 8) * (int)sizeof(half_t) : (int)0x80000000;           \
+    }
+#define R23_COPIES(chunk_, buf_)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+        const int j = wave + 8 * i;                                                                       \
         unsigned char *dst = j < 26 ? XP + (buf_)*R23_XB + j * 1024 : XP + 3 * R23_XB;                     \
-        __builtin_amdgcn_global_load_lds((r23_gbl_t *)src, (r23_lds_t *)dst, 16, 0, 0);                    \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(t1_rs, (r23_lds_t *)dst, 16, xoff[i], (chunk_)*128, 0, 0); \
     }
 
     // Filter-fragment reloads are issued by hand: a load the compiler tracks makes it wait for `vmcnt(0)` in front of the first
     // MFMA of the next chunk (it cannot count across the loop edge), i.e. for the copies issued behind the reload as well.  The
     // counted wait at the top of the chunk carries the registers as operands, so nothing that reads them moves above it.
 #define R23_WLOAD(dst_, ptr_) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst_) : "v"(ptr_) : "memory")
+#define R23_WLOAD_S(dst_, voff_, sptr_) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst_) : "v"(voff_), "s"(sptr_) : "memory")
 #define R23_WTIE() asm volatile("" : "+v"(wh[0]), "+v"(wh[1]), "+v"(wh[2]), "+v"(wh[3]), "+v"(wh[4]), "+v"(wl[0]), "+v"(wl[1]), "+v"(wl[2]), "+v"(wl[3]), "+v"(wl[4]))
+
+    // phase G, per lane and K step s: byte offset of the fragment of (tile row 0, pixel half 0) in a patch buffer
+    int boff[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        int tap = 2 * s + (g >> 1);
+        if (tap > 8) tap = 8;                               // zero-weight slot: read any valid location
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int col = lcol + kx;                          // (+ 16 for the second pixel half: the swizzle term does not change)
+        boff[s] = ((rh * 2 + ky) * R23_PW + col) * 128 + (((pw * 2 + (g & 1)) ^ ((col >> 1) & 7)) << 4);
+    }
+    // T2 store of (tile row rh * 2, pixel half h): pixel pl = rh * 64 + 16 h + lcol, slot (pair * 2 + (g >> 1)) ^ (pl & 31) -- the
+    // pair's chunk bits (chunk * 8) and the half's bit 4 enter by XOR
+    const int t2b = (rh * 64 + lcol) * 512 + (g & 1) * 8;
+    const int t2s = (pw * 2 + (g >> 1)) ^ lcol;             // slot for chunk 0, half 0
+    const int wro = lane * 16;                              // filter fragments: byte offset of this lane in a 1 KB fragment
 
     int tile = blockIdx.x;
     int oy0, ox0;
@@ -130,23 +162,24 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
     //  memory queue in front of the chunk loop of every tile)
 #pragma unroll
     for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(ah[2 * c]), "+v"(ah[2 * c + 1]), "+v"(al[c]));
-    R23_COPIES(oy0, ox0, 0, 0)
-    R23_COPIES(oy0, ox0, 1, 1)
+    R23_SETUP(oy0, ox0)
+    R23_COPIES(0, 0)
+    R23_COPIES(1, 1)
     int tcount = 0;
     (void)tcount;
     R23_WALL(0)
     int ring = 0;                                           // buffer of the chunk at hand; the copies go to (ring + 2) % 3
     bool drain = true;                                      // top of the first tile / behind a tile with rows below the image: full wait
 
-    uint4 rq[2], rc[2];
-#define R23_RES(r4_)                                                                                      \
+    uint4 rqa[2], rca[2], rqb[2], rcb[2];   // residuals of two rows in flight (even / odd rows)
+#define R23_RES(r4_, rq_, rc_)                                                                                      \
         {                                                                                                 \
             /* (rows / columns past the image repeat its last row / column: same values, same addresses, no predicate) */ \
             const int oy_ = oy0 + (r4_) < H ? oy0 + (r4_) : H - 1, ox_ = ox0 + lrow < W ? ox0 + lrow : W - 1; \
             const size_t ob_ = (size_t)(oy_ * W + ox_) * 256 + wave * 32;                                 \
             _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                               \
-                rq[m] = *reinterpret_cast<const uint4 *>(res + ob_ + 8 * (2 * m + lhi));                  \
-                rc[m] = *reinterpret_cast<const uint4 *>(res_c + ob_ + 8 * (2 * m + lhi));                \
+                rq_[m] = *reinterpret_cast<const uint4 *>(res + ob_ + 8 * (2 * m + lhi));                  \
+                rc_[m] = *reinterpret_cast<const uint4 *>(res_c + ob_ + 8 * (2 * m + lhi));                \
             }                                                                                             \
         }
     for (;;) {
@@ -162,8 +195,15 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
         for (int chunk = 0; chunk < 4; ++chunk) {
             // this chunk's patch (copied two chunks ago) and filter fragments have landed; the newest four copies may still fly.
             // One barrier per chunk: the buffer the copies below go to was last read a chunk ago, T2 in the previous tile's phase C
+#ifdef SFD2_RB23_TRACE
+            if (chunk == 1) { R23_CYC(10) }
+            if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            if (chunk == 1) { R23_CYC(11) }
+            asm volatile("s_barrier" ::: "memory");
+#else
             if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
             R23_WTIE();
             R23_CYC(chunk)
             drain = false;
@@ -172,46 +212,45 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
             r23_f4 acc[4], acl[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) { acc[t] = (r23_f4){0.0f, 0.0f, 0.0f, 0.0f}; acl[t] = acc[t]; }
-            int lc = lcol;
-            asm volatile("" : "+v"(lc));   // the 20 fragment addresses are recomputed per chunk (hoisted they are 20 registers)
             const int npair = ((chunk + 1) & 3) * 4 + pw;    // the next chunk's pair (chunk 3: the next tile's chunk 0, loaded in phase C)
-            int ln = lane;
-            asm volatile("" : "+v"(ln));   // (per-lane base addresses are recomputed, not carried through the tile loop)
+            const half_t *nwh = w2h + (size_t)npair * 5 * 512, *nwl = w2l + (size_t)npair * 5 * 512;   // wave-uniform
 #pragma unroll
             for (int s = 0; s < 5; ++s) {
-                int tap = 2 * s + (g >> 1);
-                if (tap > 8) tap = 8;                       // zero-weight slot: read any valid location
-                const int ky = tap / 3, kx = tap - ky * 3;
+                const unsigned char *bp = Xb + boff[s];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int row = rh * 2 + (t >> 1);
-                    const int q = (row + ky) * R23_PW + (t & 1) * 16 + lc + kx;
-                    const h8_t bh = *reinterpret_cast<const h8_t *>(Xb + q * 128 + (((pw * 2 + (g & 1)) ^ ((q >> 1) & 7)) << 4));
+                    const h8_t bh = *reinterpret_cast<const h8_t *>(bp + ((t >> 1) * R23_PW + (t & 1) * 16) * 128);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bh, acc[t], 0, 0, 0);
                     acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], bh, acl[t], 0, 0, 0);
                 }
+#if !(defined(SFD2_RB23_ABL) && (SFD2_RB23_ABL & 1))   // timing ablation (wrong results): no filter reloads
                 if (chunk < 3) {
-                    R23_WLOAD(wh[s], w2h + ((size_t)(npair * 5 + s) * 64 + ln) * 8);
-                    R23_WLOAD(wl[s], w2l + ((size_t)(npair * 5 + s) * 64 + ln) * 8);
+                    R23_WLOAD_S(wh[s], wro, nwh + s * 512);
+                    R23_WLOAD_S(wl[s], wro, nwl + s * 512);
                 }
+#endif
             }
             if (chunk < 3) {   // copies for the chunk after next (this tile's, or the next tile's chunk 0); chunk 3's: below
                 const int b2 = ring >= 1 ? ring - 1 : 2;    // (ring + 2) % 3
-                if (chunk < 2) { R23_COPIES(oy0, ox0, chunk + 2, b2) }
-                else { R23_COPIES(noy0, nox0, 0, b2) }      // (past the last tile: the same tile again, never read)
+                if (chunk == 2) { R23_SETUP(noy0, nox0) }   // from here on the copies are the next tile's (past the last tile: this tile's again, never read)
+                R23_COPIES((chunk + 2) & 3, b2)
             }
             const int c0 = pair * 16 + g * 4;
             const float4 sc = sfd2_lds_f4(SS + c0);
             const float4 sh = sfd2_lds_f4(SS + 256 + c0);
+            const unsigned t2c = (unsigned)(size_t)(const r23_lds_t *)T2 + t2b;
+            const int slc = t2s ^ (chunk * 8);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_fmaf(acl[t][r], 1.0f / 2048.0f, acc[t][r]);
                 uint2 hv, cv;
                 sfd2_epi4<false>(acc[t][0], acc[t][1], acc[t][2], acc[t][3], sc, sh, sc, 0.0f, hv, cv);
-                const int pl = (rh * 2 + (t >> 1)) * 32 + (t & 1) * 16 + lc;
-                const int slot = (pair * 2 + (g >> 1)) ^ (pl & 31);
-                *reinterpret_cast<uint2 *>(T2 + pl * 512 + (slot << 4) + (g & 1) * 8) = hv;
+                // (stored by hand: in front of a compiler-visible LDS store behind pending direct-to-LDS copies the compiler puts
+                //  `s_waitcnt vmcnt(0)` -- it did here for one of the four stores although T2 is an object of its own -- i.e. the
+                //  chunk's epilogue waited for the copies issued a moment before it: one memory round trip per chunk)
+                const unsigned t2a = t2c + ((slc ^ ((t & 1) * 16)) << 4) + ((t >> 1) * 32 + (t & 1) * 16) * 512;
+                asm volatile("ds_write_b64 %0, %1" ::"v"(t2a), "v"(hv) : "memory");
             }
             ring = ring == 2 ? 0 : ring + 1;
         }
@@ -221,18 +260,25 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
             int ln0 = lane;
             asm volatile("" : "+v"(ln0));                   // (recomputed: a lane-derived value carried through the chunk loop is a spill)
             const int lrow = ln0 & 31, lhi = ln0 >> 5;
-            R23_RES(0)                                      // row 0's residual IN FRONT of chunk 3's copies (below)
+            R23_RES(0, rqa, rca)                            // row 0's residual IN FRONT of chunk 3's copies (below), row 1's behind them
         }
 
         {
             const int b2 = ring == 2 ? 0 : ring + 1;        // chunk 3's buffer + 2 (ring has already moved on by one)
-            R23_COPIES(noy0, nox0, 1, b2)
+            R23_COPIES(1, b2)
+        }
+        {
+            int ln0 = lane;
+            asm volatile("" : "+v"(ln0));
+            const int lrow = ln0 & 31, lhi = ln0 >> 5;
+            R23_RES(1, rqb, rcb)
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // T2 complete
         R23_CYC(5)
         // one row of phase C; LAST: behind it comes the next tile (its first filter fragments are requested here, on EVERY path, so
         // that the registers are free through the rows before), otherwise the next row's residual
-        auto row = [&](const int r4u, const bool last) __attribute__((always_inline)) {
+        auto row = [&](const int r4u, uint4 (&rq)[2], uint4 (&rc)[2]) __attribute__((always_inline)) {
+            const bool last = r4u == 3;
             const int r4 = oy0 + r4u < H ? r4u : H - 1 - oy0;     // rows past the image repeat its last row (same values to the same place)
             int ln = lane;
             asm volatile("" : "+v"(ln));   // (as above)
@@ -265,12 +311,12 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                 const auto c1 = __builtin_amdgcn_permlane32_swap(rc[m].y, rc[m].w, false, false);
                 rcp[m][0] = make_uint2(c0[0], c1[0]); rcp[m][1] = make_uint2(c0[1], c1[1]);
             }
-            if (!last) { R23_RES(r4u + 1) }
-            else {
+            if (r4u < 2) { R23_RES(r4u + 2, rq, rc) }       // two rows ahead, into the registers this row's residual has just left
+            else if (last) {
 #pragma unroll
                 for (int s = 0; s < 5; ++s) {
-                    R23_WLOAD(wh[s], w2h + ((size_t)(pw * 5 + s) * 64 + ln) * 8);
-                    R23_WLOAD(wl[s], w2l + ((size_t)(pw * 5 + s) * 64 + ln) * 8);
+                    R23_WLOAD_S(wh[s], wro, w2h + (size_t)(pw * 5 + s) * 512);
+                    R23_WLOAD_S(wl[s], wro, w2l + (size_t)(pw * 5 + s) * 512);
                 }
             }
             const int cl = wave * 32 + 4 * lhi;
@@ -298,10 +344,10 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
         };
         // four copies of the row's code: a loop would carry the residual registers around its back edge through copies, and the
         // compiler waits for the loads in front of those
-        row(0, false); R23_CYC(6)
-        row(1, false); R23_CYC(7)
-        row(2, false); R23_CYC(8)
-        row(3, true);
+        row(0, rqa, rca); R23_CYC(6)
+        row(1, rqb, rcb); R23_CYC(7)
+        row(2, rqa, rca); R23_CYC(8)
+        row(3, rqb, rcb);
         R23_CYC(9)
         ++tcount;
 #undef R23_RES
@@ -311,6 +357,7 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (copies of chunks nobody will read)
     R23_WALL(1)
 #undef R23_COPIES
+#undef R23_SETUP
 }
 
 // t1: ResBlock.conv1's output, plain fp16 [H][W][256]; res / res_c: the block's input (hi + corr planes); out / out_c: its output
@@ -330,9 +377,10 @@ void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t 
     const int tiles_x = (W + R23_TW - 1) / R23_TW, tiles_y = (H + R23_TH - 1) / R23_TH;
     const int n_tiles = tiles_x * tiles_y;
     if (n_tiles == 0) return;
-    const int grid = n_tiles < slots ? n_tiles : slots;
+    const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
     hipLaunchKernelGGL(rb23_c_kernel, dim3(grid), dim3(R23_NT), lds, st, t1, H, W, w2h, w2l, sc2, sh2, w3h, w3l, sc3, sh3, res, res_c,
-                       out, out_c, tiles_x, n_tiles, zero_page);
+                       out, out_c, tiles_x, n_tiles);
+    (void)zero_page;
 #ifdef SFD2_RB23_TRACE
     {
         static int dumps = 0;
@@ -350,6 +398,7 @@ void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t 
                 for (int t = 0; t < 4; ++t) {
                     fprintf(stderr, "  wave %d tile %d:", w * 7, t);
                     for (int k = 1; k < 10; ++k) fprintf(stderr, " %6lld", (long long)(hc[w][t][k] - hc[w][t][k - 1]));
+                    fprintf(stderr, " [chunk 1: own wait %lld, then barrier %lld]", (long long)(hc[w][t][11] - hc[w][t][10]), (long long)(hc[w][t][1] - hc[w][t][11]));
                     fprintf(stderr, " | %6lld\n", (long long)(hc[w][t + 1][0] - hc[w][t][9]));
                 }
         }

@@ -51,6 +51,8 @@ struct DevBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+int g_sfd2_cu_limit = 0;       // sfd2_set_option "cu_limit" (sfd2_internal.h)
+
 struct ConvW {                 // one folded + packed layer
     int cin = 0, cout = 0, cout_pad = 0, ks = 0, stride = 1;
     DevBuf w, scale, shift;    // fp16 packed filters, fp32 [cout_pad]
@@ -2382,6 +2384,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "fuse_post") c->opt_fuse_post = value ? 1 : 0;
     else if (k == "sparse_desc") c->opt_sparse_desc = value ? 1 : 0;
     else if (k == "sparse_da3") c->opt_sparse_da3 = value ? 1 : 0;
+    else if (k == "cu_limit") g_sfd2_cu_limit = value < 0 ? 0 : value;
     else if (k == "fuse_pb") c->opt_fuse_pb = value ? 1 : 0;
     else if (k == "generic_c") c->opt_generic_c = value ? 1 : 0;
     else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;

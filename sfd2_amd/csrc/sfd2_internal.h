@@ -13,6 +13,11 @@ static inline const char *sfd2_env(const char *name) { return getenv(name); }
 static inline const char *sfd2_env(const char *) { return nullptr; }
 #endif
 
+// Option "cu_limit" (process-wide): the persistent kernels launch at most this many blocks (0 = one per CU).  With two streams per
+// GPU and half the CUs each, two DIFFERENT kernels (of two images) run side by side instead of taking turns on the whole chip.
+extern int g_sfd2_cu_limit;
+static inline int sfd2_slots(int cus) { return (g_sfd2_cu_limit > 0 && g_sfd2_cu_limit < cus) ? g_sfd2_cu_limit : cus; }
+
 // Block barrier that must make other waves' LDS-DMA copies (global_load_lds) visible: the drain of the vector-memory
 // counter is written out.  A plain __syncthreads() happens to emit the same s_waitcnt vmcnt(0) today while a copy is in
 // flight, but that is hipcc's choice, not a language guarantee.
