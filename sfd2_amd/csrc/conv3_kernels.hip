@@ -152,19 +152,24 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #define PP_ISSUE_X1(chunk_, buf_, i_)                                                                  \
     do {                                                                                               \
         const int pc_ = (wave + 8 * (i_) < PP_XCH) ? wave + 8 * (i_) : PP_XCH - 1;                     \
-        const half_t *pl_ = ((COMP & 1) && (chunk_) >= NCH) ? in_c - (size_t)NCH * PP_CC : in;         \
-        const half_t *src_ = xoff[i_] >= 0 ? pl_ + (size_t)xoff[i_] + (chunk_)*PP_CC : zero_page + (lane & 3) * 8; \
+        /* X3: chunks [0, 2 NCH) read the hi plane (against the hi, then the lo' filters), [2 NCH, 3 NCH) the lo' plane */ \
+        const int pch_ = (COMP & 4) ? ((chunk_) >= NCH ? (chunk_) - NCH - ((chunk_) >= 2 * NCH ? NCH : 0) : (chunk_)) : (chunk_); \
+        const half_t *pl_ = (COMP & 4) ? ((chunk_) >= 2 * NCH ? in_c : in)                             \
+                                       : (((COMP & 1) && (chunk_) >= NCH) ? in_c - (size_t)NCH * PP_CC : in); \
+        const half_t *src_ = xoff[i_] >= 0 ? pl_ + (size_t)xoff[i_] + pch_ * PP_CC : zero_page + (lane & 3) * 8; \
         __builtin_amdgcn_global_load_lds((gbl_void3_t *)src_,                                          \
                                          (lds_void3_t *)(Xs + (buf_)*PP_XBYTES + pc_ * 1024), 16, 0, 0); \
     } while (0)
 #define PP_ISSUE_F(stage_, buf_)                                                                       \
     _Pragma("unroll") for (int i_ = 0; i_ < PP_FPW; ++i_) {                                            \
-        const half_t *src_ = wpk + (size_t)(KXM ? ((stage_) / 3) * 9 + (stage_) % 3 : (stage_)*3) * CoutP * PP_CC + woff[i_]; \
+        /* X3: the filter array is [hi chunks][lo' chunks]; the K loop's chunk sequence uses hi, lo', hi */ \
+        const int fst_ = (COMP & 4) ? ((stage_) >= 6 * NCH ? (stage_) - 6 * NCH : (stage_)) : (stage_); \
+        const half_t *src_ = wpk + (size_t)(KXM ? (fst_ / 3) * 9 + fst_ % 3 : fst_ * 3) * CoutP * PP_CC + woff[i_]; \
         __builtin_amdgcn_global_load_lds((gbl_void3_t *)src_,                                          \
                                          (lds_void3_t *)(Fs + (buf_)*PP_FBYTES + (wave * PP_FPW + i_) * 1024), 16, 0, 0); \
     }
 
-    const int NCT = ((COMP & 1) ? 2 : 1) * NCH;            // chunks of the K loop: the hi plane's, then the corr plane's
+    const int NCT = ((COMP & 4) ? 3 : ((COMP & 1) ? 2 : 1)) * NCH;   // chunks of the K loop: the hi plane's, then the corr plane's (X3: three passes)
     const int NST = NCT * 3;
 
 #pragma unroll
@@ -310,6 +315,18 @@ _Pragma("unroll") \
     for (int c = 0; c < NCH; ++c) { PP_CHUNK_BODY(0) }
     if (COMP & 1)
         for (int c = NCH; c < NCT; ++c) { PP_CHUNK_BODY(1) }
+    if (COMP & 4) {
+        // X3 (SFD2_PREC_F16X3 on pre-split planes): y = sum hi * w_hi + 2^-11 (sum hi * w_lo' + sum lo' * w_hi), the low parts
+        // being stored scaled by 2^11 -- ONE accumulator: the first pass's sums are scaled up (exactly) before the cross terms
+        // join them, 2^-11 goes into the epilogue
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] *= 2048.0f;
+        for (int c = NCH; c < NCT; ++c) { PP_CHUNK_BODY(0) }
+    }
 #undef PP_CHUNK_BODY
     PP_CYC(2)
     // the next tile's first copies go out before this tile's epilogue (buffers 0: last read a chunk / a stage ago)
@@ -346,7 +363,21 @@ _Pragma("unroll") \
                     const int q = 2 * m + j;
                     const float4 sc = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
                     const float4 sh = *reinterpret_cast<const float4 *>(SS + PP_BN + cl + 8 * q);
-                    if (COMP & 2) {
+                    if (COMP & 4) {
+                        constexpr float k = 1.0f / 2048.0f;
+                        float v0 = acc[ct][pr][4 * q + 0] * k * sc.x + sh.x, v1 = acc[ct][pr][4 * q + 1] * k * sc.y + sh.y;
+                        float v2 = acc[ct][pr][4 * q + 2] * k * sc.z + sh.z, v3 = acc[ct][pr][4 * q + 3] * k * sc.w + sh.w;
+                        v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
+                        if (COMP & 8) {          // fp32 output: this lane's four channels are 16 contiguous bytes
+                            if (inb) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(out) + pix * CoutP + en0 + cl + 8 * q) = make_float4(v0, v1, v2, v3);
+                        } else {                 // hi / lo' planes (x3_split's arithmetic)
+                            const h4_t hv = cvt4c(v0, v1, v2, v3);
+                            const h4_t lv = cvt4c((v0 - (float)hv[0]) * 2048.0f, (v1 - (float)hv[1]) * 2048.0f, (v2 - (float)hv[2]) * 2048.0f,
+                                                  (v3 - (float)hv[3]) * 2048.0f);
+                            __builtin_memcpy(&pk[j], &hv, 8);
+                            __builtin_memcpy(&ck[j], &lv, 8);
+                        }
+                    } else if (COMP & 2) {
                         sfd2_epi4<false>(acc[ct][pr][4 * q + 0], acc[ct][pr][4 * q + 1], acc[ct][pr][4 * q + 2], acc[ct][pr][4 * q + 3], sc, sh,
                                          sc, relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j]);
                     } else {
@@ -359,6 +390,7 @@ _Pragma("unroll") \
                         __builtin_memcpy(&pk[j], &hv, 8);
                     }
                 }
+                if ((COMP & 12) == 12) continue;   // (fp32 output: stored above)
                 const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                 const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
                 if (inb && (!(ABL & 4) || t0[0] == 0x12345678u)) *reinterpret_cast<uint4 *>(out + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
@@ -436,6 +468,17 @@ void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, i
     if (in_c && out_c) launch_pp_t<1, 1, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
     else if (in_c) launch_pp_t<1, 1, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
     else launch_pp_t<1, 1, 0, 2>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
+}
+
+// SFD2_PREC_F16X3 on pre-split planes (hi = fp16(x), lo' = fp16((x - hi) * 2^11), x3_split's arithmetic): in / in_lo = the input's
+// planes, wpk = the filters as [hi chunks][lo' chunks] in this kernel's packed layout; the output is either planes again
+// (out_lo != null) or fp32 [Ho][Wo][CoutP] (out_f32).  Three passes of the fp16 K loop: hi x hi, hi x lo', lo' x hi.
+void launch_conv3x3_pp_x3(hipStream_t st, const half_t *in, const half_t *in_lo, int H, int W, int Cin, const half_t *wpk,
+                          const float *scale, const float *shift, int CoutP, int relu, half_t *out_hi, half_t *out_lo, float *out_f32,
+                          int Ho, int Wo, const half_t *zero_page)
+{
+    if (out_f32) launch_pp_t<1, 1, 0, 12>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, reinterpret_cast<half_t *>(out_f32), Ho, Wo, zero_page, in_lo, nullptr, 0);
+    else launch_pp_t<1, 1, 0, 6>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out_hi, Ho, Wo, zero_page, in_lo, out_lo, 0);
 }
 
 // does conv3x3_pp serve this layer?  (decided from the layer's shape alone: the filters are packed for it)

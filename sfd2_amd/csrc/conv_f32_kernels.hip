@@ -468,6 +468,29 @@ void x3_split_kernel(const float4 *__restrict__ w, size_t n4, uint4 *__restrict_
     out[i] = o;
 }
 
+// the same split into two PLANES of n halves each (hi, then lo'): the form conv3x3_pp's three-pass instantiation stages without
+// arithmetic (activations [H][W][C] and packed filters alike)
+__global__ __launch_bounds__(NT)
+void x3_split_planes_kernel(const float4 *__restrict__ in, size_t n4, uint2 *__restrict__ hi_out, uint2 *__restrict__ lo_out)
+{
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n4) return;
+    h4_t hi, lo;
+    x3_split(in[i], hi, lo);
+    uint2 a, b;
+    __builtin_memcpy(&a, &hi, 8);
+    __builtin_memcpy(&b, &lo, 8);
+    hi_out[i] = a;
+    lo_out[i] = b;
+}
+
+void launch_x3_split_planes(hipStream_t st, const float *in, size_t n_floats, void *hi_out, void *lo_out)
+{
+    const size_t n4 = n_floats / 4;
+    hipLaunchKernelGGL(x3_split_planes_kernel, dim3((unsigned)((n4 + NT - 1) / NT)), dim3(NT), 0, st,
+                       reinterpret_cast<const float4 *>(in), n4, reinterpret_cast<uint2 *>(hi_out), reinterpret_cast<uint2 *>(lo_out));
+}
+
 void launch_x3_split(hipStream_t st, const float *w, size_t n_floats, void *out)
 {
     const size_t n4 = n_floats / 4;

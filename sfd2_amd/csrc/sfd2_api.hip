@@ -62,6 +62,7 @@ struct ConvW {                 // one folded + packed layer
     DevBuf wlk;                // grouped 3x3: the same residuals in w's fragment layout (gconv_c_kernel<false, false>)
     DevBuf wgc;                // grouped 3x3: compact [256 oc][9 taps][8 in] fp16 (resblock_kernel)
     DevBuf wx3;                // fp32 layers, SFD2_PREC_F16X3: every float4 of w as (4 hi, 4 lo) fp16, made on first use
+    DevBuf wx3p;               // ... or as two planes (hi, lo') for conv3x3_pp's three-pass instantiation (3x3 stride-1 layers)
     DevBuf wc;                 // SFD2_PREC_F16C: [2 * cin / 32][taps][cout_pad][32] units -- the fp16 filters in 32-wide chunks, then the
                                // corr units (fp8 of w * 2^b0, fp8 of (w - fp16(w)) * 2^(b0 + 11)); conv1a / grouped conv: hi then lo fragments
     int sbyte = 127;           // E8M0 scale byte of the layer's corr MFMAs: 127 - 9 - b0
@@ -97,6 +98,8 @@ struct sfd2_ctx {
     int skip_da3_now = 0;              // set per call: run_network leaves convDa.3 to the sparse descriptor path (sparse_da3_kernel)
     const half_t *da0_cur = nullptr;   // convDa.0 output of the last fp16 network pass
     DevBuf da3_sparse;                 // [sel_cap][4][256] fp16: convDa.3 on the sampled corner pixels
+    int opt_x3_pp = 1;                 // sfd2_set_option "x3_pp": SFD2_PREC_F16X3 runs its 3x3 stride-1 layers on conv3x3_pp (pre-split planes, three passes)
+    DevBuf x3_planes;                  // the input of such a layer as hi / lo' planes
     int opt_sparse_da3 = 1;            // sfd2_set_option "sparse_da3": with the sparse descriptor head, convDa.3 on the sampled corners only
     int skip_pb_now = 0;               // set per call: run_network leaves convPb to the fused detector head
     int opt_fuse_pb = 1;               // sfd2_set_option "fuse_pb": convPb inside the fused detector-head / heat-map kernel
@@ -234,7 +237,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     graphs_release(c);
-    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->da3_sparse, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
+    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->da3_sparse, &c->x3_planes, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
                       &c->rt1[0], &c->rt1[1], &c->rt1[2], &c->rt2[0], &c->rt2[1], &c->rt2[2], &c->ro[0], &c->ro[1],
                       &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
                       &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->bnd, &c->sel, &c->sorted, &c->counters,
@@ -250,7 +253,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
                    &c->da0, &c->da3, &c->pb, &c->db, &c->f1a, &c->f1b, &c->f2a, &c->f2b, &c->f3a, &c->f3b, &c->frb1[0],
                    &c->frb1[1], &c->frb1[2], &c->frb2[0], &c->frb2[1], &c->frb2[2], &c->frb3[0], &c->frb3[1], &c->frb3[2],
                    &c->fpa0, &c->fpa3, &c->fda0, &c->fda3, &c->fpb, &c->fdb};
-    for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); w->wrm.release(); w->wgc.release(); w->wx3.release(); }
+    for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); w->wrm.release(); w->wgc.release(); w->wx3.release(); w->wx3p.release(); }
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
     for (int i = 0; i < 2; ++i) {
@@ -594,7 +597,7 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
         ConvW *fl[] = {&c->f1a, &c->f1b, &c->f2a, &c->f2b, &c->f3a, &c->f3b, &c->frb1[0], &c->frb1[1], &c->frb1[2], &c->frb2[0],
                        &c->frb2[1], &c->frb2[2], &c->frb3[0], &c->frb3[1], &c->frb3[2], &c->fpa0, &c->fpa3, &c->fda0, &c->fda3,
                        &c->fpb, &c->fdb};
-        for (ConvW *L : fl) L->wx3.release();
+        for (ConvW *L : fl) { L->wx3.release(); L->wx3p.release(); }
     }
     TMap m;
     for (int i = 0; i < n; ++i) {
@@ -881,6 +884,24 @@ static void convf(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &i
 {
     char kn[48];
     const bool x3 = c->precision == SFD2_PREC_F16X3;
+    if (x3 && c->opt_x3_pp && !res && L.ks == 3 && L.stride == 1 && L.cout_pad % 128 == 0 && L.cin % 64 == 0) {
+        // The 3x3 stride-1 layers (half of this mode's time) on the throughput kernel: the input is split ONCE into hi / lo'
+        // planes (the generic kernel splits every staged piece, per tile and chunk), conv3x3_pp stages the planes by direct
+        // copies and runs its fp16 K loop three times (hi x hi, hi x lo', lo' x hi) into one accumulator; fp32 output.
+        ConvW &Lm = const_cast<ConvW &>(L);
+        const size_t nfl = (size_t)L.ks * L.ks * L.cout_pad * L.cin, nin = (size_t)H * W * L.cin;
+        if (!L.wx3p.p) {
+            if (Lm.wx3p.ensure(nfl * 2 * sizeof(half_t)) != hipSuccess) { fail("out of device memory (f16x3 filter planes)"); return; }
+            launch_x3_split_planes(c->stream, L.w.as<float>(), nfl, Lm.wx3p.p, Lm.wx3p.as<half_t>() + nfl);
+        }
+        if (c->x3_planes.ensure(nin * 2 * sizeof(half_t)) != hipSuccess) { fail("out of device memory (f16x3 activation planes)"); return; }
+        ProfScope ps(c, name, "x3_split_planes + conv3x3_pp<x3>", 2.0 * (double)Ho * Wo * L.cout * L.cin * 9, 12.0 * nin + 4.0 * (double)Ho * Wo * L.cout_pad);
+        launch_x3_split_planes(c->stream, in.as<float>(), nin, c->x3_planes.p, c->x3_planes.as<half_t>() + nin);
+        launch_conv3x3_pp_x3(c->stream, c->x3_planes.as<half_t>(), c->x3_planes.as<half_t>() + nin, H, W, L.cin, L.wx3p.as<half_t>(),
+                             L.scale.as<float>(), L.shift.as<float>(), L.cout_pad, relu, nullptr, nullptr, out.as<float>(), Ho, Wo,
+                             c->zero_page.as<half_t>());
+        return;
+    }
     if (x3 && !L.wx3.p) {      // split the packed filters once: the kernel then stages them without arithmetic
         ConvW &Lm = const_cast<ConvW &>(L);
         const size_t nfl = (size_t)L.ks * L.ks * L.cout_pad * L.cin;
@@ -2385,6 +2406,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "sparse_desc") c->opt_sparse_desc = value ? 1 : 0;
     else if (k == "sparse_da3") c->opt_sparse_da3 = value ? 1 : 0;
     else if (k == "cu_limit") g_sfd2_cu_limit = value < 0 ? 0 : value;
+    else if (k == "x3_pp") c->opt_x3_pp = value ? 1 : 0;
     else if (k == "fuse_pb") c->opt_fuse_pb = value ? 1 : 0;
     else if (k == "generic_c") c->opt_generic_c = value ? 1 : 0;
     else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;

@@ -228,6 +228,11 @@ void launch_conv_igemm_f32(hipStream_t st, const float *in, int H, int W, int Ci
                            const float *residual, float *out, int Ho, int Wo);
 // the same signature on the fp16 matrix path in three passes (SFD2_PREC_F16X3); wpk = the filters after launch_x3_split
 void launch_x3_split(hipStream_t st, const float *w, size_t n_floats, void *out);
+void launch_x3_split_planes(hipStream_t st, const float *in, size_t n_floats, void *hi_out, void *lo_out);
+// conv3_kernels.hip: SFD2_PREC_F16X3 for the 3x3 stride-1 layers on pre-split planes (three passes of conv3x3_pp's fp16 K loop)
+void launch_conv3x3_pp_x3(hipStream_t st, const half_t *in, const half_t *in_lo, int H, int W, int Cin, const half_t *wpk,
+                          const float *scale, const float *shift, int CoutP, int relu, half_t *out_hi, half_t *out_lo, float *out_f32,
+                          int Ho, int Wo, const half_t *zero_page);
 void launch_gconv_x3_pack(hipStream_t st, const float *w /*[256][8][3][3]*/, void *out /*16 * 5 * 64 * 16 halves*/);
 void launch_gconv_x3(hipStream_t st, const float *in, int H, int W, const void *wpk, const float *scale, const float *shift, float *out);
 void launch_conv_igemm_x3(hipStream_t st, const float *in, int H, int W, int Cin, const float *wpk,
