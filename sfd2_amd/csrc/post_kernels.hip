@@ -668,7 +668,7 @@ __device__ __forceinline__ SampleGeom sample_geom(float kx, float ky, float half
 __global__ __launch_bounds__(NT)
 void sample_desc_kernel(const float *__restrict__ dmap, int hc, int wc, float half_w, float half_h,
                         const float *__restrict__ kpts, const unsigned int *__restrict__ count, int n_max,
-                        float *__restrict__ out)
+                        float *__restrict__ out, int compact /* dmap = [key point][corner][128], not the dense map */)
 {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
@@ -679,7 +679,7 @@ void sample_desc_kernel(const float *__restrict__ dmap, int hc, int wc, float ha
     float a0 = 0.0f, a1 = 0.0f;
 #define SFD2_TAP(valid_, yy_, xx_, wgt_, corner_)                                                    \
     if (valid_) {                                                                                    \
-        const size_t row = (size_t)(yy_) * wc + (xx_);                                               \
+        const size_t row = compact ? (size_t)i * 4 + (corner_) : (size_t)(yy_) * wc + (xx_);         \
         const float2 v = *reinterpret_cast<const float2 *>(dmap + row * 128 + 2 * lane);             \
         const float nrm = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y)), 1e-12f);                     \
         a0 += __fdiv_rn(v.x, nrm) * (wgt_);                                                          \
@@ -695,11 +695,11 @@ void sample_desc_kernel(const float *__restrict__ dmap, int hc, int wc, float ha
 }
 
 void launch_sample_desc(hipStream_t st, const float *dmap, int hc, int wc, int nh, int nw, const float *kpts,
-                        const unsigned int *count, int n_max, float *out)
+                        const unsigned int *count, int n_max, float *out, int compact)
 {
     if (n_max <= 0) return;
     hipLaunchKernelGGL(sample_desc_kernel, dim3((n_max + 3) / 4), dim3(NT), 0, st, dmap, hc, wc, (float)nw / 2.0f,
-                       (float)nh / 2.0f, kpts, count, n_max, out);
+                       (float)nh / 2.0f, kpts, count, n_max, out, compact);
 }
 
 // Sparse descriptor head (extract path): convDb is a 1x1 convolution and only the four bilinear corners of the selected

@@ -100,6 +100,8 @@ struct sfd2_ctx {
     DevBuf da3_sparse;                 // [sel_cap][4][256] fp16: convDa.3 on the sampled corner pixels
     int opt_x3_pp = 1;                 // sfd2_set_option "x3_pp": SFD2_PREC_F16X3 runs its 3x3 stride-1 layers on conv3x3_pp (pre-split planes, three passes)
     DevBuf x3_planes;                  // the input of such a layer as hi / lo' planes
+    DevBuf x3_da0_planes;              // convDa.0's output as planes (sparse descriptor head of f16x3)
+    DevBuf db_sparse;                  // [sel_cap][4][128] fp32: convDb on the sampled corners (f16x3)
     int opt_sparse_da3 = 1;            // sfd2_set_option "sparse_da3": with the sparse descriptor head, convDa.3 on the sampled corners only
     int skip_pb_now = 0;               // set per call: run_network leaves convPb to the fused detector head
     int opt_fuse_pb = 1;               // sfd2_set_option "fuse_pb": convPb inside the fused detector-head / heat-map kernel
@@ -237,7 +239,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     graphs_release(c);
-    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->da3_sparse, &c->x3_planes, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
+    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->da3_sparse, &c->x3_planes, &c->x3_da0_planes, &c->db_sparse, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
                       &c->rt1[0], &c->rt1[1], &c->rt1[2], &c->rt2[0], &c->rt2[1], &c->rt2[2], &c->ro[0], &c->ro[1],
                       &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
                       &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->bnd, &c->sel, &c->sorted, &c->counters,
@@ -960,8 +962,15 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
     convf(c, "convPa.3", c->fpa3, c->gpa0_o, H8, W8, c->gpa_o, H8, W8, 0);
     convf(c, "convPb", c->fpb, c->gpa_o, H8, W8, c->logits, H8, W8, 0);
     convf(c, "convDa.0", c->fda0, *x, H4, W4, c->gda0_o, H4, W4, 1);
-    convf(c, "convDa.3", c->fda3, c->gda0_o, H4, W4, c->gda_o, H4, W4, 0);
-    convf(c, "convDb", c->fdb, c->gda_o, H4, W4, c->draw, H4, W4, 0);
+    if (c->skip_da3_now) {      // sparse descriptor head of SFD2_PREC_F16X3 (sfd2_extract): convDa.3 and convDb run on the sampled corners only
+        const size_t nin = (size_t)H4 * W4 * 256;
+        HIPCHECK(c->x3_da0_planes.ensure(nin * 2 * sizeof(half_t)));
+        ProfScope ps(c, "convDa.0 planes", "x3_split_planes", 0.0, 12.0 * nin);
+        launch_x3_split_planes(st, c->gda0_o.as<float>(), nin, c->x3_da0_planes.p, c->x3_da0_planes.as<half_t>() + nin);
+    } else {
+        convf(c, "convDa.3", c->fda3, c->gda0_o, H4, W4, c->gda_o, H4, W4, 0);
+        convf(c, "convDb", c->fdb, c->gda_o, H4, W4, c->draw, H4, W4, 0);
+    }
     if (c->has_sta) {
         ProfScope ps(c, "ConvSta", "convsta_f32_kernel", 2.0 * P4 * 3 * 256, P4 * (1024 + 12));
         launch_convsta_f32(st, x->as<float>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
@@ -1368,7 +1377,10 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     // Not with compensated head branches (option "comp_heads": convDa.0's output then has a corr plane this kernel does not read).
     const bool comp_heads_now = c->precision == SFD2_PREC_F16C && c->opt_comp_heads && c->opt_comp_rb;
     const bool sparse_da3 = sparse_desc && c->opt_sparse_da3 && !comp_heads_now && !c->opt_branches;
-    c->skip_da3_now = sparse_da3 ? 1 : 0;
+    // SFD2_PREC_F16X3: the same two steps in that mode's arithmetic (planes of convDa.0's output, three MFMA passes, fp32 results)
+    const bool sparse_x3 = c->precision == SFD2_PREC_F16X3 && c->opt_sparse_desc && c->opt_sparse_da3 && c->opt_x3_pp && desc && top_k > 0 &&
+                           (size_t)16 * sel_bound <= (size_t)c->H4 * c->W4;
+    c->skip_da3_now = (sparse_da3 || sparse_x3) ? 1 : 0;
     const int net_rc = run_network(c, img_dev, in_mode);
     c->skip_head_now = 0;
     c->skip_db_now = 0;
@@ -1410,7 +1422,29 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
             HIPCHECK(c->kdesc.ensure((size_t)sel_cap * 128 * sizeof(float)));
             desc_dst = c->kdesc.as<float>();
         }
-        if (sparse_da3) {
+        if (sparse_x3) {
+            const size_t nin = (size_t)c->H4 * c->W4 * 256;
+            const int rows32 = (sel_cap * 4 + 31) / 32;           // the compact pixels as a [rows32][32] image for the generic 1x1 kernel
+            HIPCHECK(c->da3_sparse.ensure((size_t)rows32 * 32 * 256 * sizeof(float)));
+            HIPCHECK(c->db_sparse.ensure((size_t)rows32 * 32 * 128 * sizeof(float)));
+            ConvW &L3 = c->fda3;
+            if (!L3.wx3p.p) {
+                const size_t nfl = (size_t)9 * L3.cout_pad * L3.cin;
+                HIPCHECK(L3.wx3p.ensure(nfl * 2 * sizeof(half_t)));
+                launch_x3_split_planes(c->stream, L3.w.as<float>(), nfl, L3.wx3p.p, L3.wx3p.as<half_t>() + nfl);
+            }
+            {
+                ProfScope ps(c, "convDa.3", "sparse_da3_kernel<x3>", 2.0 * 4 * sel_cap * 256.0 * 256.0 * 9, (double)sel_cap * (16 * 1024 + 4 * 1024));
+                launch_sparse_da3_x3(c->stream, c->x3_da0_planes.as<half_t>(), c->x3_da0_planes.as<half_t>() + nin, c->H4, c->W4, H, W,
+                                     L3.wx3p.as<half_t>(), L3.cout_pad, L3.scale.as<float>(), L3.shift.as<float>(), 0, c->kpts_cur,
+                                     c->counters.as<unsigned int>() + 1, sel_cap, c->da3_sparse.as<float>(), c->zero_page.as<half_t>());
+            }
+            // convDb (1x1) on the compact [sel_cap x 4] "image" with the mode's generic kernel, then the sampler on its compact output
+            convf(c, "convDb", c->fdb, c->da3_sparse, rows32, 32, c->db_sparse, rows32, 32, 0);
+            ProfScope ps(c, "sample_desc", "sample_desc_kernel", 0.0, (double)sel_cap * 128 * 4 * 5);
+            launch_sample_desc(c->stream, c->db_sparse.as<float>(), c->H4, c->W4, H, W, c->kpts_cur, c->counters.as<unsigned int>() + 1,
+                               sel_cap, desc_dst, 1);
+        } else if (sparse_da3) {
             HIPCHECK(c->da3_sparse.ensure((size_t)sel_cap * 4 * 256 * sizeof(half_t)));
             {
                 ProfScope ps(c, "convDa.3", "sparse_da3_kernel", 2.0 * 4 * sel_cap * 256.0 * 256.0 * 9, (double)sel_cap * (16 * 512 + 4 * 512) + 2.0 * 256 * 256 * 9);

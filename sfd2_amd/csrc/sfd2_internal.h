@@ -210,6 +210,9 @@ void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c,
 void launch_sparse_da3(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, int CoutP,
                        const float *scale, const float *shift, int relu, const float *kpts, const unsigned int *count, int n_max,
                        half_t *out, const half_t *zero_page);
+void launch_sparse_da3_x3(hipStream_t st, const half_t *fmap_hi, const half_t *fmap_lo, int hc, int wc, int nh, int nw, const half_t *wpk,
+                          int CoutP, const float *scale, const float *shift, int relu, const float *kpts, const unsigned int *count,
+                          int n_max, float *out, const half_t *zero_page);
 // rb23_c_kernel.hip: ResBlock.conv2 + conv3 + residual in one kernel (SFD2_PREC_F16C, option "rb_inner" = 2: t1 plain fp16 in, t2 in LDS)
 void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t *w2h, const half_t *w2l, const float *sc2,
                    const float *sh2, const half_t *w3h, const half_t *w3l, const float *sc3, const float *sh3,
@@ -349,7 +352,7 @@ void launch_keys_to_kpts(hipStream_t st, const unsigned long long *sorted_keys, 
 // bilinear sampling of desc_raw [hc][wc][128] fp32 NHWC at kpts + per-tap and final L2 normalisation
 void launch_sample_desc(hipStream_t st, const float *desc_nhwc, int hc, int wc, int nh, int nw,
                         const float *kpts_xy, const unsigned int *count /*device, may be null*/, int n_max,
-                        float *out);
+                        float *out, int compact = 0);
 // sparse descriptor head (extract path): gather the key points' bilinear corner pixels, convDb on them, sample -- one kernel
 void launch_pb_heads_heat(hipStream_t st, const half_t *fmap, int hc8, int wc8, const half_t *wpk, int CoutP, const float *scale,
                           const float *shift, const float *sta, int hc, int wc, int H, int W, float *heat,

@@ -35,14 +35,18 @@ __device__ __forceinline__ void sd_corner(float kx, float ky, float half_w, floa
     y0 = (int)floorf(iy);
 }
 
-__global__ __launch_bounds__(SD_NT, 3)
-void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][wc][256]*/, int hc, int wc, float half_w, float half_h,
+// X3 (SFD2_PREC_F16X3): fmap / fmap_lo = convDa.0's output as hi / lo' planes, wpk = [hi chunks][lo' chunks], three MFMAs per K
+// slice into two accumulators (hi x hi; hi x lo' + lo' x hi, weighted 2^-11), fp32 output [n_max][4][256]
+template <bool X3>
+__global__ __launch_bounds__(SD_NT, X3 ? 2 : 3)
+void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][wc][256]*/, const half_t *__restrict__ fmap_lo, int hc, int wc,
+                       float half_w, float half_h,
                        const half_t *__restrict__ wpk /*[8 chunks of 32][9 taps][CoutP][32]*/, int CoutP,
                        const float *__restrict__ scale, const float *__restrict__ shift, int relu,
                        const float *__restrict__ kpts, const unsigned int *__restrict__ count, int n_max,
-                       half_t *__restrict__ out /*[n_max][4][256]*/, const half_t *__restrict__ zero_page)
+                       void *__restrict__ outv /*[n_max][4][256] fp16 (X3: fp32)*/, const half_t *__restrict__ zero_page)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char X[SD_XB];
+    __shared__ __attribute__((aligned(16))) unsigned char X[(X3 ? 2 : 1) * SD_XB];
     __shared__ int geo[2 * SD_KP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,11 +66,11 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
     }
     __syncthreads();
 
-    f32x16_t acc[2];
+    f32x16_t acc[2], acl[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; acl[t][r] = 0.0f; }
 
     // B fragments: lane -> pixel p = lrow of tile t: key point t * 8 + (p >> 2), corner p & 3 (row = corner >> 1, column = corner & 1)
     int recb[2];
@@ -87,17 +91,23 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
             const bool ok = iy >= 0 && iy < hc && ix >= 0 && ix < wc;
             const half_t *src = ok ? fmap + ((size_t)iy * wc + ix) * 256 + c * 64 + part * 8 : zero_page + slot * 8;
             __builtin_amdgcn_global_load_lds((sd_gbl_t *)src, (sd_lds_t *)(X + j * 1024), 16, 0, 0);
+            if (X3) {
+                const half_t *srl = ok ? fmap_lo + ((size_t)iy * wc + ix) * 256 + c * 64 + part * 8 : zero_page + slot * 8;
+                __builtin_amdgcn_global_load_lds((sd_gbl_t *)srl, (sd_lds_t *)(X + SD_XB + j * 1024), 16, 0, 0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
-            h8_t a[4];
+            h8_t a[4], al[4];
 #pragma unroll
-            for (int k16 = 0; k16 < 4; ++k16)
-                a[k16] = *reinterpret_cast<const h8_t *>(wpk + ((size_t)((c * 2 + (k16 >> 1)) * 9 + tap) * CoutP + n0 + lrow) * 32 +
-                                                         (k16 & 1) * 16 + lhi * 8);
+            for (int k16 = 0; k16 < 4; ++k16) {
+                const size_t ao = ((size_t)((c * 2 + (k16 >> 1)) * 9 + tap) * CoutP + n0 + lrow) * 32 + (k16 & 1) * 16 + lhi * 8;
+                a[k16] = *reinterpret_cast<const h8_t *>(wpk + ao);
+                if (X3) al[k16] = *reinterpret_cast<const h8_t *>(wpk + (size_t)8 * 9 * CoutP * 32 + ao);   // the lo' plane of the filters
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int rec = recb[t] + ky * 4 + kx;
@@ -105,6 +115,11 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
                 for (int k16 = 0; k16 < 4; ++k16) {
                     const h8_t b = *reinterpret_cast<const h8_t *>(X + rec * 128 + (((k16 * 2 + lhi) ^ (rec & 7)) << 4));
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k16], b, acc[t], 0, 0, 0);
+                    if (X3) {
+                        const h8_t bl = *reinterpret_cast<const h8_t *>(X + SD_XB + rec * 128 + (((k16 * 2 + lhi) ^ (rec & 7)) << 4));
+                        acl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[k16], b, acl[t], 0, 0, 0);
+                        acl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k16], bl, acl[t], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -115,16 +130,24 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
     for (int t = 0; t < 2; ++t) {
         const int kp = k0 + t * 8 + (lrow >> 2);
         if (kp >= n) continue;
-        half_t *o = out + ((size_t)kp * 4 + (lrow & 3)) * 256 + n0 + 4 * lhi;
+        const size_t oo = ((size_t)kp * 4 + (lrow & 3)) * 256 + n0 + 4 * lhi;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 sc = *reinterpret_cast<const float4 *>(scale + n0 + 8 * q + 4 * lhi);
             const float4 sh = *reinterpret_cast<const float4 *>(shift + n0 + 8 * q + 4 * lhi);
-            float v0 = acc[t][4 * q + 0] * sc.x + sh.x, v1 = acc[t][4 * q + 1] * sc.y + sh.y;
-            float v2 = acc[t][4 * q + 2] * sc.z + sh.z, v3 = acc[t][4 * q + 3] * sc.w + sh.w;
+            float a0 = acc[t][4 * q + 0], a1 = acc[t][4 * q + 1], a2 = acc[t][4 * q + 2], a3 = acc[t][4 * q + 3];
+            if (X3) {   // (conv_igemm_x3_kernel's combination of the two accumulators)
+                a0 += acl[t][4 * q + 0] * (1.0f / 2048.0f); a1 += acl[t][4 * q + 1] * (1.0f / 2048.0f);
+                a2 += acl[t][4 * q + 2] * (1.0f / 2048.0f); a3 += acl[t][4 * q + 3] * (1.0f / 2048.0f);
+            }
+            float v0 = a0 * sc.x + sh.x, v1 = a1 * sc.y + sh.y, v2 = a2 * sc.z + sh.z, v3 = a3 * sc.w + sh.w;
             if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
-            h4_t hv = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
-            *reinterpret_cast<h4_t *>(o + 8 * q) = hv;
+            if (X3) {
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(outv) + oo + 8 * q) = make_float4(v0, v1, v2, v3);
+            } else {
+                h4_t hv = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+                *reinterpret_cast<h4_t *>(reinterpret_cast<half_t *>(outv) + oo + 8 * q) = hv;
+            }
         }
     }
 }
@@ -134,6 +157,16 @@ void launch_sparse_da3(hipStream_t st, const half_t *fmap, int hc, int wc, int n
                        half_t *out, const half_t *zero_page)
 {
     if (n_max <= 0) return;
-    hipLaunchKernelGGL(sparse_da3_kernel, dim3((n_max + SD_KP - 1) / SD_KP, 2), dim3(SD_NT), 0, st, fmap, hc, wc, (float)nw / 2.0f,
+    hipLaunchKernelGGL(sparse_da3_kernel<false>, dim3((n_max + SD_KP - 1) / SD_KP, 2), dim3(SD_NT), 0, st, fmap, nullptr, hc, wc, (float)nw / 2.0f,
                        (float)nh / 2.0f, wpk, CoutP, scale, shift, relu, kpts, count, n_max, out, zero_page);
+}
+
+// SFD2_PREC_F16X3: planes in, [hi][lo'] filters, fp32 out
+void launch_sparse_da3_x3(hipStream_t st, const half_t *fmap_hi, const half_t *fmap_lo, int hc, int wc, int nh, int nw, const half_t *wpk,
+                          int CoutP, const float *scale, const float *shift, int relu, const float *kpts, const unsigned int *count,
+                          int n_max, float *out, const half_t *zero_page)
+{
+    if (n_max <= 0) return;
+    hipLaunchKernelGGL(sparse_da3_kernel<true>, dim3((n_max + SD_KP - 1) / SD_KP, 2), dim3(SD_NT), 0, st, fmap_hi, fmap_lo, hc, wc,
+                       (float)nw / 2.0f, (float)nh / 2.0f, wpk, CoutP, scale, shift, relu, kpts, count, n_max, out, zero_page);
 }
