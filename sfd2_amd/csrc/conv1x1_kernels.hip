@@ -367,6 +367,155 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
 #undef WAIT_GROUP_C
 }
 
+// ---------------------------------------------------------------------------------------------
+// SFD2_PREC_F16X3 for the same layers: the input as hi / lo' planes (x3_split's arithmetic: hi = fp16(x), lo' = fp16((x - hi) * 2^11)),
+// filters as fp16 + lo' fragments in the fragment order above, three MFMAs per K slice into two accumulators (hi x hi;
+// hi x lo' + lo' x hi, weighted 2^-11 -- conv_igemm_x3_kernel's combination), fp32 residual and fp32 output [P][256]; OUT_PLANES
+// additionally writes the output as planes for the layer that reads it next.  The streaming structure is the compensated
+// kernel's with both planes staged: a group = 16 KB hi + 16 KB lo'.
+template <bool HAS_RES, bool OUT_PLANES>
+__global__ __launch_bounds__(NT1, 2)
+void conv1x1_c256_x3_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in_lo, int npix,
+                            const half_t *__restrict__ w, const half_t *__restrict__ wl,
+                            const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                            const float *__restrict__ res, float *__restrict__ out, half_t *__restrict__ out_hi, half_t *__restrict__ out_lo,
+                            int groups_per_block, const half_t *__restrict__ zero_page)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Xs = smem;                                              // [NST][hi 32 x 512 B | lo' 32 x 512 B]
+    float *SS = reinterpret_cast<float *>(smem + NST * STAGE_C);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhi = lane >> 5;
+    const int ngroups = (npix + GPXC - 1) / GPXC;
+    const int g0 = blockIdx.x * groups_per_block;
+    int g1 = g0 + groups_per_block;
+    if (g1 > ngroups) g1 = ngroups;
+    if (g0 >= g1) return;
+
+    h8_t ah[16];
+    v8i_t al[8];
+    {
+        const size_t fo = ((size_t)wave * 8 * 64 + lane) * 16;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            ah[2 * c] = *reinterpret_cast<const h8_t *>(w + fo + (size_t)c * 64 * 16);
+            ah[2 * c + 1] = *reinterpret_cast<const h8_t *>(w + fo + (size_t)c * 64 * 16 + 8);
+            al[c] = sfd2_cat8(*reinterpret_cast<const h8_t *>(wl + fo + (size_t)c * 64 * 16), *reinterpret_cast<const h8_t *>(wl + fo + (size_t)c * 64 * 16 + 8));
+        }
+    }
+    for (int t = tid; t < 256; t += NT1) { SS[t] = scale[t]; SS[256 + t] = shift[t]; }
+
+#define ISSUE_GX(g_)                                                                                       \
+    {                                                                                                      \
+        unsigned char *st = Xs + ((g_) & (NST - 1)) * STAGE_C;                                             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
+            const int ch = wave * 2 + i;                                                                   \
+            const int p = ch * 2 + lhi;                                                                    \
+            const long long gp = (long long)(g_)*GPXC + p;                                                 \
+            const size_t so = (size_t)gp * 256 + ((lrow ^ (p & 31)) << 3);                                 \
+            const half_t *s0 = gp < npix ? in + so : zero_page + (lrow << 3);                              \
+            const half_t *s1 = gp < npix ? in_lo + so : zero_page + (lrow << 3);                           \
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)s0, (lds_void_t *)(st + ch * 1024), 16, 0, 0);  \
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)s1, (lds_void_t *)(st + GPXC * 512 + ch * 1024), 16, 0, 0); \
+        }                                                                                                  \
+    }
+    // per group and wave: 4 copies, 4 residual loads (HAS_RES), 4 fp32 stores (+ 8 plane stores)
+#define WAIT_GROUP_X()                                                                                     \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 + (OUT_PLANES ? 12 : 4) + (HAS_RES ? 4 : 0)) : "memory")
+
+    ISSUE_GX(g0)
+    if (g0 + 1 < g1) { ISSUE_GX(g0 + 1) }
+    if (g0 + 2 < g1) { ISSUE_GX(g0 + 2) }
+    SFD2_BARRIER_DRAIN();
+
+    for (int g = g0; g < g1; ++g) {
+        if (g != g0) {
+            if (g + 2 < g1) WAIT_GROUP_X(); else SFD2_BARRIER_DRAIN();
+        }
+        const unsigned char *st = Xs + (g & (NST - 1)) * STAGE_C;
+        const int p = lrow;
+        const long long gp = (long long)g * GPXC + p;
+        const bool inb = gp < npix;
+        const size_t obase = (size_t)(inb ? gp : 0) * 256 + wave * 32 + 4 * lhi;
+
+        float4 rr[4];
+        if (HAS_RES) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rr[q] = *reinterpret_cast<const float4 *>(res + obase + 8 * q);   // (pixels past the end: pixel 0's)
+            asm volatile("" ::: "memory");       // keep the residual loads ahead of the copies below in program order
+        }
+        if (g + 3 < g1) { ISSUE_GX(g + 3) }
+
+        f32x16_t acc, acl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acl[r] = 0.0f; }
+        const unsigned char *xp = st + p * 512;
+        const int sw = p & 31;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const h8_t b = *reinterpret_cast<const h8_t *>(xp + (((kk * 2 + lhi) ^ sw) << 4));
+            const h8_t bl = *reinterpret_cast<const h8_t *>(xp + GPXC * 512 + (((kk * 2 + lhi) ^ sw) << 4));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], b, acc, 0, 0, 0);
+            acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bl, acl, 0, 0, 0);
+            acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(sfd2_half8(al[kk >> 1], kk & 1), b, acl, 0, 0, 0);
+        }
+        const int cl = wave * 32 + 4 * lhi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 sc = sfd2_lds_f4(SS + cl + 8 * q);
+            const float4 sh = sfd2_lds_f4(SS + 256 + cl + 8 * q);
+            float v0 = (acc[4 * q + 0] + acl[4 * q + 0] * (1.0f / 2048.0f)) * sc.x + sh.x;
+            float v1 = (acc[4 * q + 1] + acl[4 * q + 1] * (1.0f / 2048.0f)) * sc.y + sh.y;
+            float v2 = (acc[4 * q + 2] + acl[4 * q + 2] * (1.0f / 2048.0f)) * sc.z + sh.z;
+            float v3 = (acc[4 * q + 3] + acl[4 * q + 3] * (1.0f / 2048.0f)) * sc.w + sh.w;
+            if (HAS_RES) { v0 += rr[q].x; v1 += rr[q].y; v2 += rr[q].z; v3 += rr[q].w; }
+            if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
+            if (inb) *reinterpret_cast<float4 *>(out + obase + 8 * q) = make_float4(v0, v1, v2, v3);
+            if (OUT_PLANES) {
+                h4_t hv = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+                h4_t lv = {(half_t)((v0 - (float)hv[0]) * 2048.0f), (half_t)((v1 - (float)hv[1]) * 2048.0f),
+                           (half_t)((v2 - (float)hv[2]) * 2048.0f), (half_t)((v3 - (float)hv[3]) * 2048.0f)};
+                if (inb) {
+                    *reinterpret_cast<h4_t *>(out_hi + obase + 8 * q) = hv;
+                    *reinterpret_cast<h4_t *>(out_lo + obase + 8 * q) = lv;
+                }
+            }
+        }
+    }
+#undef ISSUE_GX
+#undef WAIT_GROUP_X
+}
+
+// in / in_lo: input planes; w / wl: fp16 filters and their lo' parts in fragment order; res (fp32, may be null); out fp32; out_hi /
+// out_lo (may be null): the output as planes too
+void launch_conv1x1_c256_x3(hipStream_t st, const half_t *in, const half_t *in_lo, int npix, const half_t *w, const half_t *wl,
+                            const float *scale, const float *shift, int relu, const float *res, float *out, half_t *out_hi,
+                            half_t *out_lo, const half_t *zero_page)
+{
+    static bool attr_done = false;
+    static int slots = 256;
+    const size_t lds = (size_t)NST * STAGE_C + 512 * sizeof(float);
+    if (!attr_done) {
+#define C256X_ATTR(R_, P_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_c256_x3_kernel<R_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        C256X_ATTR(false, false) C256X_ATTR(true, false) C256X_ATTR(false, true) C256X_ATTR(true, true)
+#undef C256X_ATTR
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            slots = cus;
+        attr_done = true;
+    }
+    const int ngroups = (npix + GPXC - 1) / GPXC;
+    if (ngroups == 0) return;
+    const int gpb = (ngroups + sfd2_slots(slots) - 1) / sfd2_slots(slots);
+    const int grid = (ngroups + gpb - 1) / gpb;
+#define C256X_GO(R_, P_) hipLaunchKernelGGL((conv1x1_c256_x3_kernel<R_, P_>), dim3(grid), dim3(NT1), lds, st, in, in_lo, npix, w, wl, scale, shift, relu, res, out, out_hi, out_lo, gpb, zero_page)
+    if (res) { if (out_hi) C256X_GO(true, true); else C256X_GO(true, false); }
+    else { if (out_hi) C256X_GO(false, true); else C256X_GO(false, false); }
+#undef C256X_GO
+}
+
 void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c, int npix, const half_t *w_frag,
                            const half_t *wc_frag, const float *scale, const float *shift, int relu, const half_t *res,
                            const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte)

@@ -91,6 +91,9 @@ struct sfd2_ctx {
     int fuse_det = 0;                  // sfd2_set_option "fuse_det"
     int use_graphs = 0;                // sfd2_set_option "graphs"
     int alias_now = 0;                 // set per call
+    int x3_fast_rb_now = 0;            // set per call: f16x3 ResBlocks on the streaming three-pass 1x1 kernel (not on the parity entry point:
+                                       // the grouped conv's output then exists as planes only)
+    DevBuf x3_rb_planes[2];            // a ResBlock's input / the grouped conv's output as hi / lo' planes
     int opt_fuse_post = 1;             // sfd2_set_option "fuse_post": heads -> heat map -> NMS in one kernel on the extract path
     int skip_head_now = 0;             // set per call: run_network leaves the detector soft-max to the fused NMS kernel
     int opt_sparse_desc = 1;           // sfd2_set_option "sparse_desc": extract path runs convDb on the sampled corner pixels only
@@ -239,7 +242,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     graphs_release(c);
-    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->da3_sparse, &c->x3_planes, &c->x3_da0_planes, &c->db_sparse, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
+    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->da3_sparse, &c->x3_planes, &c->x3_da0_planes, &c->db_sparse, &c->x3_rb_planes[0], &c->x3_rb_planes[1], &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
                       &c->rt1[0], &c->rt1[1], &c->rt1[2], &c->rt2[0], &c->rt2[1], &c->rt2[2], &c->ro[0], &c->ro[1],
                       &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
                       &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->bnd, &c->sel, &c->sorted, &c->counters,
@@ -682,6 +685,7 @@ static void set_path(sfd2_ctx *c, bool parity_entry)
     const bool f16 = c->precision == SFD2_PREC_F16 || c->precision == SFD2_PREC_F16C;
     c->fuse_now = f16 && (parity_entry ? c->fuse_det : c->fuse);
     c->alias_now = c->fuse_now && !parity_entry && c->opt_alias;
+    c->x3_fast_rb_now = c->precision == SFD2_PREC_F16X3 && !parity_entry && c->opt_x3_pp;
 }
 
 // Buffers are allocated for the path that is about to run only: the throughput path needs the 3-slot
@@ -938,7 +942,45 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
     static const char *nm1[3] = {"conv4.0.conv1", "conv4.1.conv1", "conv4.2.conv1"};
     static const char *nm2[3] = {"conv4.0.conv2", "conv4.1.conv2", "conv4.2.conv2"};
     static const char *nm3[3] = {"conv4.0.conv3", "conv4.1.conv3", "conv4.2.conv3"};
-    for (int b = 0; b < 3; ++b) {
+    const bool fast_rb = c->x3_fast_rb_now && c->rb1[0].wfh.p && c->rb1[0].wfl.p;
+    if (fast_rb) {
+        // ResBlocks of SFD2_PREC_F16X3 on the throughput path: the block's input as hi / lo' planes (split once in front of the
+        // first block; conv3 writes its fp32 output AND its planes), conv1 and conv3 on the streaming three-pass 1x1 kernel (filters
+        // = the fp16 set's fragment-ordered hi / lo' arrays: the same split of the same fp32 weights), the grouped conv writes
+        // planes.  conv1 132 -> ~60 us, conv3 168 -> ~90 us per block at 1600x1200.
+        const size_t nin = (size_t)H4 * W4 * 256;
+        HIPCHECK(c->x3_rb_planes[0].ensure(nin * 2 * sizeof(half_t)));
+        HIPCHECK(c->x3_rb_planes[1].ensure(nin * 2 * sizeof(half_t)));
+        half_t *xh = c->x3_rb_planes[0].as<half_t>(), *xl = xh + nin, *th = c->x3_rb_planes[1].as<half_t>(), *tl = th + nin;
+        {
+            ProfScope ps(c, "conv3b planes", "x3_split_planes", 0.0, 12.0 * nin);
+            launch_x3_split_planes(st, x->as<float>(), nin, xh, xl);
+        }
+        for (int b = 0; b < 3; ++b) {
+            {
+                ProfScope ps(c, nm1[b], "conv1x1_c256<x3>", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 8);
+                launch_conv1x1_c256_x3(st, xh, xl, H4 * W4, c->rb1[b].wfh.as<half_t>(), c->rb1[b].wfl.as<half_t>(), c->frb1[b].scale.as<float>(),
+                                       c->frb1[b].shift.as<float>(), 1, nullptr, c->grt1[b].as<float>(), nullptr, nullptr, c->zero_page.as<half_t>());
+            }
+            {
+                if (!c->frb2[b].wx3.p) {
+                    HIPCHECK(c->frb2[b].wx3.ensure((size_t)16 * 5 * 64 * 16 * sizeof(half_t)));
+                    launch_gconv_x3_pack(st, c->frb2[b].w.as<float>(), c->frb2[b].wx3.p);
+                }
+                ProfScope ps(c, nm2[b], "gconv_x3_kernel<planes out>", 2.0 * P4 * 256 * 72, P4 * 256 * 8);
+                launch_gconv_x3(st, c->grt1[b].as<float>(), H4, W4, c->frb2[b].wx3.p, c->frb2[b].scale.as<float>(),
+                                c->frb2[b].shift.as<float>(), nullptr, th, tl);
+            }
+            {
+                ProfScope ps(c, nm3[b], "conv1x1_c256<x3>+res", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * (b < 2 ? 16 : 12));
+                launch_conv1x1_c256_x3(st, th, tl, H4 * W4, c->rb3[b].wfh.as<half_t>(), c->rb3[b].wfl.as<half_t>(), c->frb3[b].scale.as<float>(),
+                                       c->frb3[b].shift.as<float>(), 1, x->as<float>(), c->gro[b].as<float>(), b < 2 ? xh : nullptr,
+                                       b < 2 ? xl : nullptr, c->zero_page.as<half_t>());
+            }
+            x = &c->gro[b];
+        }
+    }
+    for (int b = 0; b < (fast_rb ? 0 : 3); ++b) {
         convf(c, nm1[b], c->frb1[b], *x, H4, W4, c->grt1[b], H4, W4, 1);
         {
             if (c->precision == SFD2_PREC_F16X3) {

@@ -217,6 +217,10 @@ void launch_sparse_da3_x3(hipStream_t st, const half_t *fmap_hi, const half_t *f
 void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t *w2h, const half_t *w2l, const float *sc2,
                    const float *sh2, const half_t *w3h, const half_t *w3l, const float *sc3, const float *sh3,
                    const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page);
+// conv1x1_kernels.hip: SFD2_PREC_F16X3 streaming 1x1 (256 -> 256): planes in, fp32 (+ planes) out, fp32 residual
+void launch_conv1x1_c256_x3(hipStream_t st, const half_t *in, const half_t *in_lo, int npix, const half_t *w, const half_t *wl,
+                            const float *scale, const float *shift, int relu, const float *res, float *out, half_t *out_hi,
+                            half_t *out_lo, const half_t *zero_page);
 void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *wpk /*hi, lo fragments*/,
                      const float *scale, const float *shift, half_t *out, half_t *out_c);
 void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk /*fp16 fragments*/,
@@ -237,7 +241,7 @@ void launch_conv3x3_pp_x3(hipStream_t st, const half_t *in, const half_t *in_lo,
                           const float *scale, const float *shift, int CoutP, int relu, half_t *out_hi, half_t *out_lo, float *out_f32,
                           int Ho, int Wo, const half_t *zero_page);
 void launch_gconv_x3_pack(hipStream_t st, const float *w /*[256][8][3][3]*/, void *out /*16 * 5 * 64 * 16 halves*/);
-void launch_gconv_x3(hipStream_t st, const float *in, int H, int W, const void *wpk, const float *scale, const float *shift, float *out);
+void launch_gconv_x3(hipStream_t st, const float *in, int H, int W, const void *wpk, const float *scale, const float *shift, float *out, half_t *out_hi = nullptr, half_t *out_lo = nullptr);
 void launch_conv_igemm_x3(hipStream_t st, const float *in, int H, int W, int Cin, const float *wpk,
                            const float *scale, const float *shift, int Cout_pad, int ks, int stride, int relu,
                            const float *residual, float *out, int Ho, int Wo);
