@@ -94,6 +94,10 @@ struct sfd2_ctx {
     int x3_fast_rb_now = 0;            // set per call: f16x3 ResBlocks on the streaming three-pass 1x1 kernel (not on the parity entry point:
                                        // the grouped conv's output then exists as planes only)
     DevBuf x3_rb_planes[2];            // a ResBlock's input / the grouped conv's output as hi / lo' planes
+    const void *x3_pre_src = nullptr;  // set by a producer that wrote its output as planes too: the fp32 tensor they belong to ...
+    const half_t *x3_pre_hi = nullptr, *x3_pre_lo = nullptr;   // ... and the planes (consumed by the next convf on that tensor)
+    int x3_planes_out_now = 0;         // set around a convf call: the 3x3 layer writes hi / lo' planes INTO x3_chain instead of fp32
+    DevBuf x3_chain;                   // planes handed from conv3a to conv3b (throughput path of f16x3)
     int opt_fuse_post = 1;             // sfd2_set_option "fuse_post": heads -> heat map -> NMS in one kernel on the extract path
     int skip_head_now = 0;             // set per call: run_network leaves the detector soft-max to the fused NMS kernel
     int opt_sparse_desc = 1;           // sfd2_set_option "sparse_desc": extract path runs convDb on the sampled corner pixels only
@@ -242,7 +246,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     graphs_release(c);
-    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->da3_sparse, &c->x3_planes, &c->x3_da0_planes, &c->db_sparse, &c->x3_rb_planes[0], &c->x3_rb_planes[1], &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
+    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->da3_sparse, &c->x3_planes, &c->x3_da0_planes, &c->db_sparse, &c->x3_rb_planes[0], &c->x3_rb_planes[1], &c->x3_chain, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
                       &c->rt1[0], &c->rt1[1], &c->rt1[2], &c->rt2[0], &c->rt2[1], &c->rt2[2], &c->ro[0], &c->ro[1],
                       &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
                       &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->bnd, &c->sel, &c->sorted, &c->counters,
@@ -900,12 +904,26 @@ static void convf(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &i
             if (Lm.wx3p.ensure(nfl * 2 * sizeof(half_t)) != hipSuccess) { fail("out of device memory (f16x3 filter planes)"); return; }
             launch_x3_split_planes(c->stream, L.w.as<float>(), nfl, Lm.wx3p.p, Lm.wx3p.as<half_t>() + nfl);
         }
-        if (c->x3_planes.ensure(nin * 2 * sizeof(half_t)) != hipSuccess) { fail("out of device memory (f16x3 activation planes)"); return; }
-        ProfScope ps(c, name, "x3_split_planes + conv3x3_pp<x3>", 2.0 * (double)Ho * Wo * L.cout * L.cin * 9, 12.0 * nin + 4.0 * (double)Ho * Wo * L.cout_pad);
-        launch_x3_split_planes(c->stream, in.as<float>(), nin, c->x3_planes.p, c->x3_planes.as<half_t>() + nin);
-        launch_conv3x3_pp_x3(c->stream, c->x3_planes.as<half_t>(), c->x3_planes.as<half_t>() + nin, H, W, L.cin, L.wx3p.as<half_t>(),
-                             L.scale.as<float>(), L.shift.as<float>(), L.cout_pad, relu, nullptr, nullptr, out.as<float>(), Ho, Wo,
-                             c->zero_page.as<half_t>());
+        const half_t *ph = nullptr, *pl = nullptr;
+        const bool pre = c->x3_pre_src == in.p && c->x3_pre_hi;     // the producer left the planes behind: no split
+        if (pre) { ph = c->x3_pre_hi; pl = c->x3_pre_lo; c->x3_pre_src = nullptr; }
+        else {
+            if (c->x3_planes.ensure(nin * 2 * sizeof(half_t)) != hipSuccess) { fail("out of device memory (f16x3 activation planes)"); return; }
+            ph = c->x3_planes.as<half_t>(); pl = ph + nin;
+        }
+        const size_t nout = (size_t)Ho * Wo * L.cout_pad;
+        half_t *oh = nullptr, *ol = nullptr;
+        if (c->x3_planes_out_now) {      // planes out (the only reader is the next 3x3 layer / the sparse descriptor head)
+            DevBuf &dst = c->x3_planes_out_now == 2 ? c->x3_da0_planes : c->x3_chain;
+            if (dst.ensure(nout * 2 * sizeof(half_t)) != hipSuccess) { fail("out of device memory (f16x3 activation planes)"); return; }
+            oh = dst.as<half_t>(); ol = oh + nout;
+            c->x3_pre_src = out.p; c->x3_pre_hi = oh; c->x3_pre_lo = ol;
+        }
+        ProfScope ps(c, name, pre ? (oh ? "conv3x3_pp<x3, planes out>" : "conv3x3_pp<x3>") : (oh ? "x3_split_planes + conv3x3_pp<x3, planes out>" : "x3_split_planes + conv3x3_pp<x3>"),
+                     2.0 * (double)Ho * Wo * L.cout * L.cin * 9, (pre ? 4.0 : 12.0) * nin + 4.0 * nout);
+        if (!pre) launch_x3_split_planes(c->stream, in.as<float>(), nin, const_cast<half_t *>(ph), const_cast<half_t *>(pl));
+        launch_conv3x3_pp_x3(c->stream, ph, pl, H, W, L.cin, L.wx3p.as<half_t>(), L.scale.as<float>(), L.shift.as<float>(), L.cout_pad, relu,
+                             oh, ol, oh ? nullptr : out.as<float>(), Ho, Wo, c->zero_page.as<half_t>());
         return;
     }
     if (x3 && !L.wx3.p) {      // split the packed filters once: the kernel then stages them without arithmetic
@@ -936,8 +954,12 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
     convf(c, "conv1b", c->f1b, c->g1a, H, W, c->g1b, H2, W2, 1);
     convf(c, "conv2a", c->f2a, c->g1b, H2, W2, c->g2a, H2, W2, 1);
     convf(c, "conv2b", c->f2b, c->g2a, H2, W2, c->g2b, H4, W4, 1);
+    // (throughput path: conv3a's only reader is conv3b, convDa.0's the sparse descriptor head -- they write planes, no fp32)
+    c->x3_planes_out_now = c->x3_fast_rb_now ? 1 : 0;
     convf(c, "conv3a", c->f3a, c->g2b, H4, W4, c->g3a, H4, W4, 1);
+    c->x3_planes_out_now = 0;
     convf(c, "conv3b", c->f3b, c->g3a, H4, W4, c->g3b, H4, W4, 1);
+    c->x3_pre_src = nullptr;
     const DevBuf *x = &c->g3b;
     static const char *nm1[3] = {"conv4.0.conv1", "conv4.1.conv1", "conv4.2.conv1"};
     static const char *nm2[3] = {"conv4.0.conv2", "conv4.1.conv2", "conv4.2.conv2"};
@@ -972,13 +994,13 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
                                 c->frb2[b].shift.as<float>(), nullptr, th, tl);
             }
             {
-                ProfScope ps(c, nm3[b], "conv1x1_c256<x3>+res", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * (b < 2 ? 16 : 12));
+                ProfScope ps(c, nm3[b], "conv1x1_c256<x3>+res", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 16);
                 launch_conv1x1_c256_x3(st, th, tl, H4 * W4, c->rb3[b].wfh.as<half_t>(), c->rb3[b].wfl.as<half_t>(), c->frb3[b].scale.as<float>(),
-                                       c->frb3[b].shift.as<float>(), 1, x->as<float>(), c->gro[b].as<float>(), b < 2 ? xh : nullptr,
-                                       b < 2 ? xl : nullptr, c->zero_page.as<half_t>());
+                                       c->frb3[b].shift.as<float>(), 1, x->as<float>(), c->gro[b].as<float>(), xh, xl, c->zero_page.as<half_t>());
             }
             x = &c->gro[b];
         }
+        c->x3_pre_src = x->p; c->x3_pre_hi = xh; c->x3_pre_lo = xl;     // the backbone output's planes: convDa.0 takes them as they are
     }
     for (int b = 0; b < (fast_rb ? 0 : 3); ++b) {
         convf(c, nm1[b], c->frb1[b], *x, H4, W4, c->grt1[b], H4, W4, 1);
@@ -1003,12 +1025,19 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
     convf(c, "convPa.0", c->fpa0, *x, H4, W4, c->gpa0_o, H8, W8, 1);
     convf(c, "convPa.3", c->fpa3, c->gpa0_o, H8, W8, c->gpa_o, H8, W8, 0);
     convf(c, "convPb", c->fpb, c->gpa_o, H8, W8, c->logits, H8, W8, 0);
+    // (convPa.0 above is the generic kernel: it did not consume the backbone output's planes)
+    const bool da0_planes = c->skip_da3_now && c->x3_fast_rb_now;
+    c->x3_planes_out_now = da0_planes ? 2 : 0;
     convf(c, "convDa.0", c->fda0, *x, H4, W4, c->gda0_o, H4, W4, 1);
+    c->x3_planes_out_now = 0;
+    c->x3_pre_src = nullptr;
     if (c->skip_da3_now) {      // sparse descriptor head of SFD2_PREC_F16X3 (sfd2_extract): convDa.3 and convDb run on the sampled corners only
         const size_t nin = (size_t)H4 * W4 * 256;
-        HIPCHECK(c->x3_da0_planes.ensure(nin * 2 * sizeof(half_t)));
-        ProfScope ps(c, "convDa.0 planes", "x3_split_planes", 0.0, 12.0 * nin);
-        launch_x3_split_planes(st, c->gda0_o.as<float>(), nin, c->x3_da0_planes.p, c->x3_da0_planes.as<half_t>() + nin);
+        if (!da0_planes) {
+            HIPCHECK(c->x3_da0_planes.ensure(nin * 2 * sizeof(half_t)));
+            ProfScope ps(c, "convDa.0 planes", "x3_split_planes", 0.0, 12.0 * nin);
+            launch_x3_split_planes(st, c->gda0_o.as<float>(), nin, c->x3_da0_planes.p, c->x3_da0_planes.as<half_t>() + nin);
+        }
     } else {
         convf(c, "convDa.3", c->fda3, c->gda0_o, H4, W4, c->gda_o, H4, W4, 0);
         convf(c, "convDb", c->fdb, c->gda_o, H4, W4, c->draw, H4, W4, 0);
