@@ -60,6 +60,24 @@ __device__ unsigned long long g_stemc_trace[2][16][12];
 #define SC_STAMP(k_)
 #endif
 
+// X3 epilogue of four consecutive channels: y = relu(a * scale + shift) as hi = fp16(y) and lo' = fp16((y - hi) * 2^11)
+// (x3_split's arithmetic, conv_f32_kernels.hip)
+__device__ __forceinline__ void sc_x3_epi4(float a0, float a1, float a2, float a3, float4 sc, float4 sh, uint2 &hv, uint2 &lv)
+{
+    const float v0 = fmaxf(a0 * sc.x + sh.x, 0.0f), v1 = fmaxf(a1 * sc.y + sh.y, 0.0f);
+    const float v2 = fmaxf(a2 * sc.z + sh.z, 0.0f), v3 = fmaxf(a3 * sc.w + sh.w, 0.0f);
+    const h4_t h = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+    const h4_t l = {(half_t)((v0 - (float)h[0]) * 2048.0f), (half_t)((v1 - (float)h[1]) * 2048.0f),
+                    (half_t)((v2 - (float)h[2]) * 2048.0f), (half_t)((v3 - (float)h[3]) * 2048.0f)};
+    __builtin_memcpy(&hv, &h, 8);
+    __builtin_memcpy(&lv, &l, 8);
+}
+
+// X3 (SFD2_PREC_F16X3): the same kernel with conv1a's output and conv1b's filters / output as hi / lo' fp16 pairs instead of hi / corr
+// units: X1c holds lo', w2's second half the filters' lo' fragments, phase 2 runs hi x hi over the wave's units, scales the partial
+// sums by 2^11 (exactly) and adds the cross terms hi x lo' + lo' x hi to the same accumulators (2^-11 goes into phase 4), the
+// output planes are hi / lo'.
+template <bool X3>
 __global__ __launch_bounds__(SC_NT, 2)
 void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normalise,
                          const half_t *__restrict__ w1 /*[2 hi/lo][2][3][64][8] conv1a A fragments*/,
@@ -274,7 +292,8 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     uint2 hv, cv;
-                    sfd2_epi4<false>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], s1[q], h1[q], s1[q], 0.0f, hv, cv);
+                    if (X3) sc_x3_epi4(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], s1[q], h1[q], hv, cv);
+                    else sfd2_epi4<false>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], s1[q], h1[q], s1[q], 0.0f, hv, cv);
                     if (!all_inside && !inside) { hv = make_uint2(0u, 0u); cv = make_uint2(0u, 0u); }
                     {
                         const int o = xo + (((cth * 4 + q) << 4) ^ xsw);
@@ -314,10 +333,43 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                     const int o0 = ro + (((ih * 4 + lhi) ^ bsw) << 4), o1 = ro + (((ih * 4 + 2 + lhi) ^ bsw) << 4);
                     const h8_t b0 = *reinterpret_cast<const h8_t *>(X1h + o0);
                     const h8_t b1 = *reinterpret_cast<const h8_t *>(X1h + o1);
-                    const v8i_t bc = sfd2_cat8(*reinterpret_cast<const h8_t *>(X1c + o0), *reinterpret_cast<const h8_t *>(X1c + o1));
                     acc2[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[i][0], b0, acc2[r], 0, 0, 0);
                     acc2[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[i][1], b1, acc2[r], 0, 0, 0);
-                    acc2[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wc[i], bc, acc2[r], 0, 0, 0, sa, 0, 0x7f7f7f7f);
+                    if (!X3) {
+                        const v8i_t bc = sfd2_cat8(*reinterpret_cast<const h8_t *>(X1c + o0), *reinterpret_cast<const h8_t *>(X1c + o1));
+                        acc2[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wc[i], bc, acc2[r], 0, 0, 0, sa, 0, 0x7f7f7f7f);
+                    }
+                }
+            }
+        }
+        if (X3) {
+            // the cross terms, at 2^11 times their weight, into the same accumulators
+#pragma unroll
+            for (int r = 0; r < SC_TH; ++r)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[r][e] *= 2048.0f;
+            int l2b = 2 * lrow;
+            asm volatile("" : "+v"(l2b));
+#pragma unroll
+            for (int i = 0; i < SC_NU; ++i) {
+                if (i < nu) {
+                    const int u = u0 + i, tap = u >> 1, ih = u & 1;
+                    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                    for (int r = 0; r < SC_TH; ++r) {
+                        const int q = (2 * r + ky) * SC_RW + l2b + kx;
+                        const int ro = (q ^ ((q >> 4) & 1)) * 128;
+                        const int bsw = (q >> 1) & 7;
+                        const int o0 = ro + (((ih * 4 + lhi) ^ bsw) << 4), o1 = ro + (((ih * 4 + 2 + lhi) ^ bsw) << 4);
+                        const h8_t b0 = *reinterpret_cast<const h8_t *>(X1h + o0);
+                        const h8_t b1 = *reinterpret_cast<const h8_t *>(X1h + o1);
+                        const h8_t l0 = *reinterpret_cast<const h8_t *>(X1c + o0);
+                        const h8_t l1 = *reinterpret_cast<const h8_t *>(X1c + o1);
+                        acc2[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sfd2_half8(wc[i], 0), b0, acc2[r], 0, 0, 0);
+                        acc2[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sfd2_half8(wc[i], 1), b1, acc2[r], 0, 0, 0);
+                        acc2[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[i][0], l0, acc2[r], 0, 0, 0);
+                        acc2[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[i][1], l1, acc2[r], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -379,7 +431,9 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                 const int c0 = cth * 32 + 8 * q + 4 * lhi;
                 const float4 s = sfd2_lds_f4(SS + 128 + c0);
                 const float4 h = sfd2_lds_f4(SS + 192 + c0);
-                sfd2_epi4<false>(tot[4 * q + 0], tot[4 * q + 1], tot[4 * q + 2], tot[4 * q + 3], s, h, s, 0.0f, pk[j], ck[j]);
+                if (X3) sc_x3_epi4(tot[4 * q + 0] * (1.0f / 2048.0f), tot[4 * q + 1] * (1.0f / 2048.0f), tot[4 * q + 2] * (1.0f / 2048.0f),
+                                   tot[4 * q + 3] * (1.0f / 2048.0f), s, h, pk[j], ck[j]);
+                else sfd2_epi4<false>(tot[4 * q + 0], tot[4 * q + 1], tot[4 * q + 2], tot[4 * q + 3], s, h, s, 0.0f, pk[j], ck[j]);
             }
             const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
             const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
@@ -404,6 +458,7 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
 #undef SC_STORE_IMG
 }
 
+// sbyte < 0: the X3 instantiation (SFD2_PREC_F16X3): w2's second halves are the filters' lo' fragments, out / out_c the hi / lo' planes
 void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *w1, const float *sc1,
                          const float *sh1, const void *w2, const float *sc2, const float *sh2, half_t *out, half_t *out_c,
                          int H2, int W2, int sbyte)
@@ -411,7 +466,8 @@ void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int nor
     static bool attr_done = false;
     static int slots = 256;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stem_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stem_c_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stem_c_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
@@ -421,9 +477,13 @@ void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int nor
     const int tiles_x = (W2 + SC_TW - 1) / SC_TW, tiles_y = (H2 + SC_TH - 1) / SC_TH;
     const int n_tiles = tiles_x * tiles_y;
     const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
-    hipLaunchKernelGGL(fused_stem_c_kernel, dim3(grid), dim3(SC_NT), SC_LDS, st, img, H, W, normalise, w1, sc1, sh1,
-                       reinterpret_cast<const unsigned char *>(w2), sc2, sh2, out, out_c, H2, W2, tiles_x, n_tiles,
-                       (sbyte & 255) * 0x01010101);
+    if (sbyte < 0)
+        hipLaunchKernelGGL(fused_stem_c_kernel<true>, dim3(grid), dim3(SC_NT), SC_LDS, st, img, H, W, normalise, w1, sc1, sh1,
+                           reinterpret_cast<const unsigned char *>(w2), sc2, sh2, out, out_c, H2, W2, tiles_x, n_tiles, 0);
+    else
+        hipLaunchKernelGGL(fused_stem_c_kernel<false>, dim3(grid), dim3(SC_NT), SC_LDS, st, img, H, W, normalise, w1, sc1, sh1,
+                           reinterpret_cast<const unsigned char *>(w2), sc2, sh2, out, out_c, H2, W2, tiles_x, n_tiles,
+                           (sbyte & 255) * 0x01010101);
 #ifdef SFD2_STEMC_TRACE
     {
         static int dumps = 0;

@@ -134,6 +134,7 @@ struct sfd2_ctx {
     ConvW c1a, c1b, c2a, c2b, c3a, c3b, rb1[3], rb2[3], rb3[3], pa0, pa3, da0, da3, pb, db;
     DevBuf sta_w, sta_b, zero_page, w1b_fused;   // w1b_fused: conv1b filters as [9][64][64] for the fused stem
     DevBuf w1b_stem_c;                             // the same as register fragments (hi K slices + corr) for the compensated fused stem
+    DevBuf w1b_stem_x3;                            // ... with the lo' fragments (fp16 of (w - fp16(w)) * 2^11) in place of the corr fragment: f16x3
     int fuse = 1;                                  // fused kernels on the extract path (SFD2_NO_FUSE=1 disables)
     int fuse_now = 0;                              // set per call: sfd2_det keeps every intermediate readable
     // strict fp32 mode
@@ -246,7 +247,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     graphs_release(c);
-    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->da3_sparse, &c->x3_planes, &c->x3_da0_planes, &c->db_sparse, &c->x3_rb_planes[0], &c->x3_rb_planes[1], &c->x3_chain, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
+    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->w1b_stem_x3, &c->da3_sparse, &c->x3_planes, &c->x3_da0_planes, &c->db_sparse, &c->x3_rb_planes[0], &c->x3_rb_planes[1], &c->x3_chain, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
                       &c->rt1[0], &c->rt1[1], &c->rt1[2], &c->rt2[0], &c->rt2[1], &c->rt2[2], &c->ro[0], &c->ro[1],
                       &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
                       &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->bnd, &c->sel, &c->sorted, &c->counters,
@@ -646,6 +647,19 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
                             pk[base + 16 + kk * 8 + j] = (unsigned short)(f32_to_e4m3(std::ldexp(v, b0)) | (f32_to_e4m3(std::ldexp(v - (float)h, b0 + 11)) << 8));
                         }
         if (upload(c->w1b_stem_c, pk.data(), pk.size() * 2, c->stream)) return -1;
+        for (int cth = 0; cth < 2; ++cth)          // the same fragments with the lo' parts as fp16 (SFD2_PREC_F16X3)
+            for (int u = 0; u < 18; ++u)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int kk = 0; kk < 2; ++kk)
+                        for (int j = 0; j < 8; ++j) {
+                            const int oc = cth * 32 + (lane & 31), ic = (u & 1) * 32 + kk * 16 + (lane >> 5) * 8 + j, tap = u >> 1;
+                            const float v = w->d[((size_t)oc * 64 + ic) * 9 + tap];
+                            const half_t l = (half_t)((v - (float)(half_t)v) * 2048.0f);
+                            unsigned short lb;
+                            std::memcpy(&lb, &l, 2);
+                            pk[((size_t)(cth * 18 + u) * 64 + lane) * 32 + 16 + kk * 8 + j] = lb;
+                        }
+        if (upload(c->w1b_stem_x3, pk.data(), pk.size() * 2, c->stream)) return -1;
     }
     if (pack_igemm(c, m, c->c2a, "conv2a.0", "conv2a.1", 64, 128, 3, 1)) return -1;
     if (pack_igemm(c, m, c->c2b, "conv2b.0", "bn2b.0", 128, 128, 3, 2)) return -1;
@@ -946,12 +960,24 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
     hipStream_t st = c->stream;
     const int H = c->H, W = c->W, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
     const double P1 = (double)H * W, P4 = (double)H4 * W4, P8 = (double)H8 * W8;
+    if (c->x3_fast_rb_now && c->w1b_stem_x3.p && c->c1a.wc.p) {
+        // throughput path of SFD2_PREC_F16X3: the fused stem in three-pass arithmetic (conv1a's image and filters as hi + lo fp16 as
+        // in the compensated mode, conv1b on hi / lo' planes of conv1a's tile in LDS), its output as planes for conv2a
+        const size_t nout = (size_t)H2 * W2 * 64;
+        HIPCHECK(c->x3_chain.ensure(std::max(nout, (size_t)H4 * W4 * 256) * 2 * sizeof(half_t)));
+        ProfScope ps(c, "conv1a+conv1b", "fused_stem_c_kernel<x3>", 2.0 * P1 * 64 * 27 + 2.0 * (double)H2 * W2 * 64 * 576, P1 * 12 + (double)H2 * W2 * 256);
+        launch_fused_stem_c(st, img_dev, H, W, normalise, c->c1a.wc.as<half_t>(), c->f1a.scale.as<float>(), c->f1a.shift.as<float>(),
+                            c->w1b_stem_x3.p, c->f1b.scale.as<float>(), c->f1b.shift.as<float>(), c->x3_chain.as<half_t>(),
+                            c->x3_chain.as<half_t>() + nout, H2, W2, -1);
+        c->x3_pre_src = c->g1b.p; c->x3_pre_hi = c->x3_chain.as<half_t>(); c->x3_pre_lo = c->x3_chain.as<half_t>() + nout;
+    } else {
     {
         ProfScope ps(c, "conv1a", "conv1a_f32_kernel", 2.0 * P1 * 64 * 27, P1 * (12 + 256));
         launch_conv1a_f32(st, img_dev, H, W, normalise, c->f1a.w.as<float>(), c->f1a.scale.as<float>(),
                           c->f1a.shift.as<float>(), c->g1a.as<float>());
     }
     convf(c, "conv1b", c->f1b, c->g1a, H, W, c->g1b, H2, W2, 1);
+    }
     convf(c, "conv2a", c->f2a, c->g1b, H2, W2, c->g2a, H2, W2, 1);
     convf(c, "conv2b", c->f2b, c->g2a, H2, W2, c->g2b, H4, W4, 1);
     // (throughput path: conv3a's only reader is conv3b, convDa.0's the sparse descriptor head -- they write planes, no fp32)
