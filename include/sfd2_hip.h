@@ -131,6 +131,11 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *               conv's output, 2: conv1's output too, 0: both compensated); the block's input / output / skip path and all
  *               filters stay compensated.  These layers are bound by HBM bytes: 1.82 / 1.75 / 1.67 ms per 1600x1200 extract
  *               for 0 / 1 / 2, descriptors <= 3.5e-4 / 3.8e-4 / 4.9e-4 (tests assert 7e-4 for 1 and 2, 1e-3 everywhere).
+ *   "x3_pp"     1 (default) / 0: SFD2_PREC_F16X3 on its throughput kernels -- 3x3 stride-1 layers on conv3x3_pp over pre-split hi / lo'
+ *               planes, and on sfd2_extract (not sfd2_det) the fused three-pass stem, the streaming three-pass 1x1 kernel in the
+ *               ResBlocks and the sparse descriptor head; 0 = the generic three-pass kernel everywhere (same tolerances, 1.6x slower).
+ *   "cu_limit"  0 (default) / n: persistent kernels launch at most n blocks (experiment: with two streams, two kernels side by side
+ *               on half the chip each measure the same throughput as taking turns on all of it).  Process-wide.
  *   "sparse_da3" 1 (default) / 0: on the extract path (with "sparse_desc"), convDa.3 runs on the 4 x K bilinear corner pixels of the
  *               selected key points only instead of the whole 1/4-resolution map (-77 us per 1600x1200 / top-4096 extract;
  *               descriptors within 4e-5 of the dense path's: another fp32 summation order).  0 = dense.

@@ -960,6 +960,8 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
     hipStream_t st = c->stream;
     const int H = c->H, W = c->W, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
     const double P1 = (double)H * W, P4 = (double)H4 * W4, P8 = (double)H8 * W8;
+    c->x3_pre_src = nullptr;           // (no planes of an earlier pass are left over)
+    c->x3_planes_out_now = 0;
     if (c->x3_fast_rb_now && c->w1b_stem_x3.p && c->c1a.wc.p) {
         // throughput path of SFD2_PREC_F16X3: the fused stem in three-pass arithmetic (conv1a's image and filters as hi + lo fp16 as
         // in the compensated mode, conv1b on hi / lo' planes of conv1a's tile in LDS), its output as planes for conv2a

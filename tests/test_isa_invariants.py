@@ -84,7 +84,12 @@ def test_conv3x3_pp_loop_has_only_its_own_drains(asm):
     assert ks
     for name, k in ks.items():
         span = _mfma_span(k["body"])
-        if not name.split("EEv")[0].endswith(("ELi0", "ELi2")):         # COMP & 1: a second chunk loop on the fp8 MFMA
+        comp = int(re.search(r"ELi(\d+)EEv", name).group(1))
+        if comp & 4:                                                      # f16x3 on planes: the fp16 chunk body twice (second copy: the cross terms)
+            assert _count(span, r"v_mfma_f32_32x32x16_f16") == 288 and _count(span, r"v_mfma_scale") == 0, name
+            assert _count(span, r"\bscratch_") == 0, name
+            continue
+        if comp & 1:                                                      # COMP & 1: a second chunk loop on the fp8 MFMA
             assert _count(span, r"v_mfma_f32_32x32x16_f16") == 144 and _count(span, r"v_mfma_scale_f32_32x32x64_f8f6f4") == 72
             # every unit's eight scaled MFMAs sit in their own MFMA section (between the unit's two barriers): instruction
             # selection once sank all 72 below the chunk's last barrier, with the fragments of nine units live

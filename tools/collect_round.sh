@@ -39,5 +39,7 @@ rocprofv3 --pmc WRITE_SIZE -d $out/pmc2 -o x --output-format csv -- $S > /dev/nu
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $out/pmc3 -o x --output-format csv -- $S > /dev/null 2> $out/pmc3.err
 python $R/tools/pmc_summary.py $out/pmc1 $out/pmc2 $out/pmc3 > $out/pmc_summary.txt 2> $out/pmc_summary.err
 python $R/tools/pmc_to_json.py $tag $out/pmc_summary.txt > $out/pmc_traffic.json 2>> $out/pmc_summary.err
+bash $R/tools/collect_strict.sh $tag
+cd /tmp
 rm -rf $out/prof/*/*.db $out/prof/*.db $out/pmc1 $out/pmc2 $out/pmc3   # the databases / raw CSVs are large; the summaries are what gets committed
 ls $out

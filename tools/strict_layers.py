@@ -5,7 +5,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from sfd2_amd import _lib, synth
 from sfd2_amd.model import ResSegNetV2
 
