@@ -77,7 +77,9 @@ __device__ __forceinline__ h4_t cvt4c(float a, float b, float c, float d)
 // being equally long everywhere), not because of the wait the compiler puts in front of the epilogue's first LDS read (it orders
 // LDS accesses behind pending direct-to-LDS copies it cannot prove disjoint, here the next tile's first copies): with the copies
 // issued by inline asm -- no such wait -- and the next tile's scale / shift stored before them, conv2a 147.6 -> 152.9 us,
-// conv3a 119.3 -> 121.0, conv3b and convDa unchanged.  Not kept.
+// conv3a 119.3 -> 121.0, conv3b and convDa unchanged.  Not kept.  Non-temporal epilogue stores (so that the burst does not evict the
+// patches and filters from the L2): conv2a 150 -> 299 us, conv3a 123 -> 196, conv3b 216 -> 278 -- the write-back L2 is what absorbs
+// the burst.
 // -DSFD2_PP_TRACE: wall-clock stamps (s_memrealtime, 100 MHz) of every block (entry, exit) and cycle stamps of block 3's waves 0
 // and 4 around the sections of its tiles, printed by the launcher for the compensated instantiations
 #ifdef SFD2_PP_TRACE
