@@ -158,6 +158,8 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
         // wave at 4 waves per SIMD (+12 %), 128-candidate stages (+23 %, spills), one wave per SIMD (+48 %); late round 2:
         // two wave groups one barrier apart as in conv3x3_pp (512 queries per block, MFMA section / epilogue section per tile,
         // three candidate stages in flight): bit-identical, 269 -> 322-341 us
+        // round 3: the eight candidate-fragment LDS offsets hoisted into registers (the compiler already folds them into
+        // ds_read immediates): 268.1/275.2/268.2 -> 267.8/262.9/269.8 us, within noise, not kept
         for (int s = 0; s < nst; ++s) {
             const int buf = s & 1;
             if (s + 1 < nst) { ISSUE_B(s + 1, buf ^ 1) }
