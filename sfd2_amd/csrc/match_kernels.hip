@@ -370,12 +370,12 @@ void match_mutual_reduce_kernel(const MatchJob2 *__restrict__ jobs, const MatchF
             if (k > best) { best = k; bs = sidx; }
         }
         const unsigned int bits = __float_as_uint(best);
-        // id bits: 3:0 = 15 - register, 4 = 1 - half-wave, (64-query strips only) 5 = 1 - query tile
-        const int t = strip == 64 ? 1 - (int)((bits >> 5) & 1u) : 0, lh = 1 - (int)((bits >> 4) & 1u), r = 15 - (int)(bits & 15u);
+        // id bits: 3:0 = 15 - register, 4 = 1 - half-wave, 5 = 1 - query tile, 7:6 = 3 - wave (256-query strips: one block)
+        const int w = 3 - (int)((bits >> 6) & 3u), t = 1 - (int)((bits >> 5) & 1u), lh = 1 - (int)((bits >> 4) & 1u), r = 15 - (int)(bits & 15u);
         const bool any = best > MQ_NEG;
-        f.red_r[i] = any ? __uint_as_float(bits & 0xFFFFFFC0u) : -INFINITY;
+        f.red_r[i] = any ? __uint_as_float(bits & 0xFFFFFF00u) : -INFINITY;
         f.red_r[(size_t)n + i] = -INFINITY;
-        reinterpret_cast<int *>(f.red_r)[2 * (size_t)n + i] = any ? bs * strip + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh : 0;
+        reinterpret_cast<int *>(f.red_r)[2 * (size_t)n + i] = any ? bs * strip + w * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh : 0;
     }
 }
 

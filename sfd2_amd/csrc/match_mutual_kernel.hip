@@ -21,10 +21,12 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 //       candidate TILE id packed into the 7 low mantissa bits (127 - tile: the lower tile wins among equal values).  The
 //       32-lane reduction happens once per sweep, through an LDS transposition, not per tile.
 //   reverse (best query per candidate): a 16 -> 1 in-lane maximum with the register id packed into 4 bits, the two query
-//       tiles and the two half-waves merged with two more id bits, one 128-byte store per tile: a per-strip partial
-//       [n0 / 64][n1] that match_mutual_reduce folds.
-// ~8 VALU instructions per MFMA instead of a second GEMM.  Packing perturbs a similarity by <= 2^-16 relative, far below
-// the fp16-operand error (1.5e-4); ties between values equal after truncation go to the lower index.
+//       tiles and the two half-waves merged with two more id bits, and the block's four waves (two more) folded in a
+//       per-block LDS table with ds_max_f32; the table leaves the CU once per sweep as a per-strip partial
+//       [n0 / 256][n1] that match_mutual_reduce folds (13 MB per 50 x 4096^2 instead of 52 MB of per-wave partials).
+// ~8 VALU instructions per MFMA instead of a second GEMM.  Packing perturbs a similarity by <= 2^-15 relative (8 id bits,
+// reverse; 2^-16 forward), below the fp16-operand error (1.5e-4); ties between values equal after truncation go to the
+// lower index.
 #define MQ_NEG (-0x1p100f)    // "no value": finite with an all-zero mantissa, so or-ing id bits can only make it MORE negative
 #define MQ_TILE_BITS 7
 #define MQ_MAX_CHUNK (32 << MQ_TILE_BITS)   // candidates per split: the tile id must fit MQ_TILE_BITS
@@ -32,7 +34,8 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 __global__ __launch_bounds__(NT, 2)
 void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qblocks, const half_t *__restrict__ zero_page)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][TA2][256 B]; at the end [4][64][32] floats
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][TA2][256 B] (at the end [4][64][32] floats), then
+                                                                           // the reverse table: MQ_MAX_CHUNK floats
     // XCD-aware work order.  Blocks are dealt round-robin to the 8 XCDs (each with its own L2); with the natural order the
     // query strips that share one candidate chunk (x fastest) land on all eight of them and the chunk is fetched into eight
     // L2s: 424 MB of HBM-side reads per 50 x 4096^2 against 52 MB of database sets (profiles/r02_match_pmc.txt).  Here every
@@ -82,12 +85,16 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
     f32x16_t zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
-    // reverse id bits 5:4 = (1 - t, 1 - lhi) above the 4 register bits: the larger code wins the max, so the lower
-    // (t, lhi, r) wins among values equal after truncation
-    const unsigned int cb[2] = {0x20u | ((1u - (unsigned)lhi) << 4), (1u - (unsigned)lhi) << 4};
-    // this wave's row of the reverse partials as a buffer resource covering candidates [0, ja1)
-    const __amdgpu_buffer_rsrc_t rk_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        job.rkeys + (size_t)(bx * 4 + wave) * n1, 0, ja1 * 4, 0x00020000);
+    // reverse id bits 7:4 = (3 - wave, 1 - t, 1 - lhi) above the 4 register bits: the larger code wins the max, so the lower
+    // (wave, t, lhi, r) wins among values equal after truncation
+    const unsigned int wb = (3u - (unsigned)wave) << 6;
+    const unsigned int cb[2] = {wb | 0x20u | ((1u - (unsigned)lhi) << 4), wb | ((1u - (unsigned)lhi) << 4)};
+    // the block's reverse table: one packed maximum per candidate of this split
+    float *rtab = reinterpret_cast<float *>(smem + 2 * TA2 * 256);
+    for (int i = tid; i < ja1 - ja0; i += NT) rtab[i] = MQ_NEG;          // (published by the barrier behind the first stage's copies)
+    // (issued by inline asm: for a compiler-visible LDS atomic hipcc first drains the next stage's direct-to-LDS copies,
+    // s_waitcnt vmcnt(0), which it cannot prove disjoint from the table)
+    const unsigned rt_lane = (unsigned)(size_t)(const lds_void_t *)rtab + (unsigned)lcol * 4u;
     // the mask lives in a VGPR so that (x & keep) | code is ONE v_and_or_b32 (VOP3 on gfx950 takes no literal, and the
     // tile code is already the one scalar operand)
     unsigned int keep = ~((1u << MQ_TILE_BITS) - 1u);
@@ -118,9 +125,9 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
         }                                                                                                \
     }
     // epilogue of a finished tile: forward running maxima (tile id packed), reverse per-candidate maximum (row id
-    // packed), the two query tiles and the two half-waves merged, one 128-byte store.  Bounds-checked buffer store:
-    // padding columns fall outside the descriptor and are dropped by the hardware, the upper half-wave repeats the
-    // lower one's store -- no exec-mask branch.
+    // packed), the two query tiles and the two half-waves merged, one ds_max_f32 into the block's table (the upper
+    // half-wave repeats the lower one's: idempotent, no exec-mask branch; padding columns hold MQ_NEG and are not
+    // written out).
 #define MQ_TILE_EPI(C0_, C1_, TILE_)                                                                     \
     {                                                                                                    \
         const unsigned int code_ = (unsigned)((1 << MQ_TILE_BITS) - 1 - (TILE_));                        \
@@ -131,12 +138,12 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
             m0_ = fmaxf(m0_, __uint_as_float((__float_as_uint(C0_[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r))); \
             m1_ = fmaxf(m1_, __uint_as_float((__float_as_uint(C1_[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r))); \
         }                                                                                                \
-        const float k0_ = __uint_as_float((__float_as_uint(m0_) & 0xFFFFFFCFu) | cb[0]);                 \
-        const float k1_ = __uint_as_float((__float_as_uint(m1_) & 0xFFFFFFCFu) | cb[1]);                 \
+        const float k0_ = __uint_as_float((__float_as_uint(m0_) & 0xFFFFFF0Fu) | cb[0]);                 \
+        const float k1_ = __uint_as_float((__float_as_uint(m1_) & 0xFFFFFF0Fu) | cb[1]);                 \
         const unsigned int kb_ = __float_as_uint(fmaxf(k0_, k1_));                                       \
         const auto sw2_ = __builtin_amdgcn_permlane32_swap(kb_, kb_, false, false);                      \
         const float kk_ = fmaxf(__uint_as_float(sw2_[0]), __uint_as_float(sw2_[1]));                     \
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(kk_), rk_rsrc, (ja0 + (TILE_)*32 + lcol) * 4, 0, 0); \
+        asm volatile("ds_max_f32 %0, %1" ::"v"(rt_lane + (unsigned)(TILE_)*128u), "v"(kk_) : "memory");          \
     }
 
     if (ja0 < ja1) {
@@ -177,6 +184,9 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
         }
 #undef ISSUE_B
         __syncthreads();
+        // the block's reverse partial: row bx of [n0 / 256][n1]
+        float *rk = job.rkeys + (size_t)bx * n1 + ja0;
+        for (int i = tid; i < ja1 - ja0; i += NT) rk[i] = rtab[i];
     }
 #undef MQ_TILE_MFMA
 #undef MQ_TILE_MASK
@@ -212,12 +222,12 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
 
 
 
-int match_mutual_strip(void) { return 64; }   // queries per reverse-partial strip (match_mutual_reduce decodes accordingly)
+int match_mutual_strip(void) { return 256; }   // queries per reverse-partial strip (match_mutual_reduce decodes accordingly)
 
 void launch_match_mutual_gemm(hipStream_t st, const MatchJob2 *jobs_dev, int npairs, int max_n0, int splits, const half_t *zero_page)
 {
     static bool attr = false;
-    const size_t lds = (size_t)2 * TA2 * 256;
+    const size_t lds = (size_t)2 * TA2 * 256 + (size_t)MQ_MAX_CHUNK * sizeof(float);
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_mutual_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
