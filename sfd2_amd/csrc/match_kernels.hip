@@ -329,12 +329,13 @@ void match_top2_v2_kernel(const MatchJob *__restrict__ jobs, int splits, const h
 
 // ---------------------------------------------------------------- single-GEMM mutual NN: match_mutual_kernel.hip
 #define MQ_NEG (-0x1p100f)
-void launch_match_mutual_gemm(hipStream_t st, const MatchJob2 *jobs_dev, int npairs, int max_n0, int splits, const half_t *zero_page);
+void launch_match_mutual_gemm(hipStream_t st, const MatchJob2 *jobs_dev, int npairs, int max_n0, int splits, int fwd_ids);
 int match_mutual_strip(void);
 
-// merges the partials: forward [splits][n0] (value, index), reverse [ceil(n0 / strip)][n1] packed (value | query id bits)
+// merges the partials: forward [splits][n0] (value, index -- fwd_ids = 0: value only, the index is left at -1 for
+// match_mutual_claim_kernel), reverse [ceil(n0 / strip)][n1] packed (value | query id bits)
 __global__ __launch_bounds__(NT)
-void match_mutual_reduce_kernel(const MatchJob2 *__restrict__ jobs, const MatchFinal *__restrict__ fins, int splits, int strip)
+void match_mutual_reduce_kernel(const MatchJob2 *__restrict__ jobs, const MatchFinal *__restrict__ fins, int splits, int strip, int fwd_ids)
 {
     const MatchJob2 job = jobs[blockIdx.y];
     const MatchFinal f = fins[blockIdx.y];
@@ -347,8 +348,9 @@ void match_mutual_reduce_kernel(const MatchJob2 *__restrict__ jobs, const MatchF
     if (dir == 0) {
         for (int s = 0; s < splits; ++s) {
             const float c1 = job.part_v1[(size_t)s * n + i];
-            if (c1 > b1) { b1 = c1; bi = job.part_i1[(size_t)s * n + i]; }
+            if (c1 > b1) { b1 = c1; if (fwd_ids) bi = job.part_i1[(size_t)s * n + i]; }
         }
+        if (!fwd_ids) bi = -1;
         f.red_f[i] = b1;
         f.red_f[(size_t)n + i] = -INFINITY;
         reinterpret_cast<int *>(f.red_f)[2 * (size_t)n + i] = bi;
@@ -379,14 +381,34 @@ void match_mutual_reduce_kernel(const MatchJob2 *__restrict__ jobs, const MatchF
     }
 }
 
+// Mutual modes without forward ids: (i, j) is a match iff sim[i][j] is the maximum of column j -- i = the reverse direction's
+// query id for j -- AND of row i: the row maximum F[i] (raw accumulator value) equals the column maximum R[j] (the same
+// accumulator value with its 8 low mantissa bits replaced by id bits).  The forward index of query i becomes the LOWEST
+// such j (unsigned atomicMin over an array initialised to 0xFFFFFFFF = -1: torch's argmax takes the first maximum,
+// nearest_neighbor.py:8 / it_loc/matcher.py:124); queries nobody claims keep -1 and match_decide_kernel leaves them unmatched.
+__global__ __launch_bounds__(NT)
+void match_mutual_claim_kernel(const MatchFinal *__restrict__ fins)
+{
+    const MatchFinal f = fins[blockIdx.y];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= f.n1) return;
+    const float r = f.red_r[j];
+    if (!(r > -INFINITY)) return;
+    const int i = reinterpret_cast<const int *>(f.red_r)[2 * (size_t)f.n1 + j];
+    if ((__float_as_uint(f.red_f[i]) & 0xFFFFFF00u) == __float_as_uint(r))
+        atomicMin(reinterpret_cast<unsigned int *>(f.red_f) + 2 * (size_t)f.n0 + i, (unsigned int)j);
+}
+
 void launch_match_mutual(hipStream_t st, const MatchJob2 *jobs_dev, const MatchFinal *fins_dev, int npairs, int max_n0,
-                         int max_n1, int splits, const half_t *zero_page)
+                         int max_n1, int splits, int fwd_ids)
 {
     if (npairs <= 0 || max_n0 <= 0) return;
-    launch_match_mutual_gemm(st, jobs_dev, npairs, max_n0, splits, zero_page);
+    launch_match_mutual_gemm(st, jobs_dev, npairs, max_n0, splits, fwd_ids);
     const int max_n = max_n0 > max_n1 ? max_n0 : max_n1;
     hipLaunchKernelGGL(match_mutual_reduce_kernel, dim3((max_n + NT - 1) / NT, npairs, 2), dim3(NT), 0, st, jobs_dev, fins_dev, splits,
-                       match_mutual_strip());
+                       match_mutual_strip(), fwd_ids);
+    if (!fwd_ids && max_n1 > 0)
+        hipLaunchKernelGGL(match_mutual_claim_kernel, dim3((max_n1 + NT - 1) / NT, npairs), dim3(NT), 0, st, fins_dev);
 }
 
 void launch_match_top2(hipStream_t st, const MatchJob *jobs_dev, int njobs, int max_nb, int splits, int use_lo,
@@ -477,7 +499,10 @@ void match_decide_kernel(const MatchFinal *__restrict__ fins, int flavour, int m
     const int j = reinterpret_cast<const int *>(f.red_f)[2 * (size_t)f.n0 + i];
     long long m = -1;
     float score = 0.0f;
-    if (f.n1 > 0) {
+    if (f.n1 > 0 && j < 0) {
+        // single-GEMM mutual modes (match_mutual_claim_kernel): no candidate has this query as its best one
+        score = flavour == 0 ? (hloc_pass(s1, s2, ratio, dist) ? (s1 + 1.0f) / 2.0f : 0.0f) : s1;
+    } else if (f.n1 > 0) {
         const float t1 = f.red_r[j], t2 = f.red_r[(size_t)f.n1 + j];
         const int back = reinterpret_cast<const int *>(f.red_r)[2 * (size_t)f.n1 + j];
         if (flavour == 0) {  // hloc NearestNeighbor

@@ -31,8 +31,14 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 #define MQ_TILE_BITS 7
 #define MQ_MAX_CHUNK (32 << MQ_TILE_BITS)   // candidates per split: the tile id must fit MQ_TILE_BITS
 
+// FWD_IDS: the forward direction keeps the candidate (tile) id of its maximum -- the modes without a mutual check need
+// matches0 for EVERY query.  With the mutual check a pair (i, j) is kept iff sim[i][j] is the maximum of row i AND of
+// column j: the reverse direction's packed query id names i for every j, and the row maximum's VALUE decides
+// (match_mutual_claim_kernel) -- the forward maxima are then plain v_max3_f32 over the raw accumulators, 0.5 instead of 1.5
+// VALU per value.
+template <bool FWD_IDS>
 __global__ __launch_bounds__(NT, 2)
-void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qblocks, const half_t *__restrict__ zero_page)
+void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qblocks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][TA2][256 B] (at the end [4][64][32] floats), then
                                                                            // the reverse table: MQ_MAX_CHUNK floats
@@ -100,41 +106,31 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
     unsigned int keep = ~((1u << MQ_TILE_BITS) - 1u);
     asm volatile("" : "+v"(keep));
 
-    // MFMAs of one 32-candidate tile (LDS rows SUB_ * 32 .. + 31 of buffer BUF_) against the wave's 64 queries
-#define MQ_TILE_MFMA(N0_, N1_, BUF_, SUB_)                                                               \
-    {                                                                                                    \
-        const int row_ = (SUB_)*32 + lcol;                                                               \
-        const unsigned char *brow_ = smem + ((BUF_)*TA2 + row_) * 256;                                   \
-        const int sw_ = row_ & 15;                                                                       \
-        _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                               \
-            const h8_t b_ = *reinterpret_cast<const h8_t *>(brow_ + (((ks * 2 + lhi) ^ sw_) << 4));     \
-            N0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[0][ks], b_, ks == 0 ? zero16 : N0_, 0, 0, 0); \
-            N1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[1][ks], b_, ks == 0 ? zero16 : N1_, 0, 0, 0); \
-        }                                                                                                \
-    }
-    // edge tiles only (wave-uniform, rare): padding candidate columns (zero-page rows) and padding query rows must never
+    // candidate fragments of one 32-candidate tile: LDS row SUB_ * 32 + lcol of buffer BUF_ (both constants: immediates)
+    const unsigned char *brow = smem + lcol * 256;
+    const int bsw = lcol & 15;
+#define MQ_BFRAG(BUF_, SUB_, KS_) \
+    (*reinterpret_cast<const h8_t *>(brow + ((BUF_)*TA2 + (SUB_)*32) * 256 + ((((KS_)*2 + lhi) ^ bsw) << 4)))
+    // edge tiles only (wave-uniform, rare): padding candidate columns (zero rows) and padding query rows must never
     // be a maximum.  The empty asm keeps the block a branch: if-converted it costs 64 selects on every tile.
 #define MQ_TILE_MASK(C0_, C1_, TILE_)                                                                    \
     if (ja0 + (TILE_)*32 + 32 > ja1 || partial_q) {                                                      \
-        asm volatile("" ::: "memory");                                                                   \
+        int qlim_ = n0 - q0 - 4 * lhi;      /* opaque: the 32 row comparisons stay in here (hoisted they hold 64 SGPRs) */ \
+        asm volatile("" : "+v"(qlim_)::"memory");                                                        \
         const bool pad_col_ = ja0 + (TILE_)*32 + lcol >= ja1;                                            \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
-            const int qr_ = q0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;                                       \
-            if (pad_col_ || qr_ >= n0) C0_[r] = MQ_NEG;                                                  \
-            if (pad_col_ || qr_ + 32 >= n0) C1_[r] = MQ_NEG;                                             \
+            const int qr_ = (r & 3) + 8 * (r >> 2);                                                      \
+            if (pad_col_ || qr_ >= qlim_) C0_[r] = MQ_NEG;                                               \
+            if (pad_col_ || qr_ + 32 >= qlim_) C1_[r] = MQ_NEG;                                          \
         }                                                                                                \
     }
-    // epilogue of a finished tile: forward running maxima (tile id packed), reverse per-candidate maximum (row id
-    // packed), the two query tiles and the two half-waves merged, one ds_max_f32 into the block's table (the upper
-    // half-wave repeats the lower one's: idempotent, no exec-mask branch; padding columns hold MQ_NEG and are not
-    // written out).
-#define MQ_TILE_EPI(C0_, C1_, TILE_)                                                                     \
+    // reverse direction of a finished tile: per-candidate maximum over the lane's 16 + 16 query rows (row id packed), the
+    // two query tiles and the two half-waves merged, one ds_max_f32 into the block's table (the upper half-wave repeats
+    // the lower one's: idempotent, no exec-mask branch; padding columns hold MQ_NEG and are not written out).
+#define MQ_TILE_REV(C0_, C1_, TILE_)                                                                     \
     {                                                                                                    \
-        const unsigned int code_ = (unsigned)((1 << MQ_TILE_BITS) - 1 - (TILE_));                        \
         float m0_ = MQ_NEG, m1_ = MQ_NEG;                                                                \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
-            rm[0][r] = fmaxf(rm[0][r], __uint_as_float((__float_as_uint(C0_[r]) & keep) | code_));      \
-            rm[1][r] = fmaxf(rm[1][r], __uint_as_float((__float_as_uint(C1_[r]) & keep) | code_));      \
             m0_ = fmaxf(m0_, __uint_as_float((__float_as_uint(C0_[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r))); \
             m1_ = fmaxf(m1_, __uint_as_float((__float_as_uint(C1_[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r))); \
         }                                                                                                \
@@ -145,42 +141,82 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
         const float kk_ = fmaxf(__uint_as_float(sw2_[0]), __uint_as_float(sw2_[1]));                     \
         asm volatile("ds_max_f32 %0, %1" ::"v"(rt_lane + (unsigned)(TILE_)*128u), "v"(kk_) : "memory");          \
     }
+    // one stage = 64 candidates = two tiles: four accumulator chains (the matrix pipe measured 1.11 PFLOP/s with four
+    // independent chains per wave against 0.90 with two: tools/probe/mfma_valu.hip), then both tiles' epilogue.  Forward:
+    // FWD_IDS: element-wise running maxima with the tile id packed into the 7 low mantissa bits, else of the raw values --
+    // either way ONE v_max3_f32 per query row takes both tiles.
+#define MQ_STAGE(S_, BUF_)                                                                               \
+    {                                                                                                    \
+        f32x16_t a0_, a1_, b0_, b1_;                                                                     \
+        h8_t fa_ = MQ_BFRAG(BUF_, 0, 0), fb_ = MQ_BFRAG(BUF_, 1, 0), na_ = fa_, nb_ = fb_;               \
+        _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                               \
+            /* the fragments of K step ks + 1 are requested in front of the MFMAs of step ks */         \
+            if (ks + 1 < 8) { na_ = MQ_BFRAG(BUF_, 0, ks + 1); nb_ = MQ_BFRAG(BUF_, 1, ks + 1); }        \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            a0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[0][ks], fa_, ks == 0 ? zero16 : a0_, 0, 0, 0); \
+            a1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[1][ks], fa_, ks == 0 ? zero16 : a1_, 0, 0, 0); \
+            b0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[0][ks], fb_, ks == 0 ? zero16 : b0_, 0, 0, 0); \
+            b1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[1][ks], fb_, ks == 0 ? zero16 : b1_, 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            fa_ = na_; fb_ = nb_;                                                                        \
+        }                                                                                                \
+        const int ta_ = (S_)*2, tb_ = (S_)*2 + 1;                                                        \
+        MQ_TILE_MASK(a0_, a1_, ta_)                                                                      \
+        MQ_TILE_MASK(b0_, b1_, tb_)                                                                      \
+        if (FWD_IDS) {                                                                                   \
+            const unsigned int ca_ = (unsigned)((1 << MQ_TILE_BITS) - 1 - ta_), cb_ = ca_ - 1u;          \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+                rm[0][r] = fmaxf(fmaxf(rm[0][r], __uint_as_float((__float_as_uint(a0_[r]) & keep) | ca_)), \
+                                 __uint_as_float((__float_as_uint(b0_[r]) & keep) | cb_));               \
+                rm[1][r] = fmaxf(fmaxf(rm[1][r], __uint_as_float((__float_as_uint(a1_[r]) & keep) | ca_)), \
+                                 __uint_as_float((__float_as_uint(b1_[r]) & keep) | cb_));               \
+            }                                                                                            \
+        } else {                                                                                         \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+                rm[0][r] = fmaxf(fmaxf(rm[0][r], a0_[r]), b0_[r]);                                       \
+                rm[1][r] = fmaxf(fmaxf(rm[1][r], a1_[r]), b1_[r]);                                       \
+            }                                                                                            \
+        }                                                                                                \
+        MQ_TILE_REV(a0_, a1_, ta_)                                                                       \
+        MQ_TILE_REV(b0_, b1_, tb_)                                                                       \
+    }
 
     if (ja0 < ja1) {
         const int nst = (ja1 - ja0 + TA2 - 1) / TA2;
-        const int srow = lane >> 4;
-#define ISSUE_B(stage_, buf_)                                                                            \
+        // staging copies: buffer_load ... lds, 16 B per lane; the per-lane byte offset of (row, 16-byte slot) advances by one
+        // stage per stage, rows beyond ja1 fall outside the descriptor and read zeros (no zero page, no selects)
+        const __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(job.d_hi), 0, ja1 * (KD * 2), 0x00020000);
+        int voff[TA2 / 16];
+#pragma unroll
+        for (int c = 0; c < TA2 / 16; ++c) {
+            const int row = (wave * (TA2 / 16) + c) * 4 + (lane >> 4);
+            voff[c] = (ja0 + row) * (KD * 2) + (((lane & 15) ^ (row & 15)) << 4);
+        }
+#define ISSUE_B(buf_)                                                                                    \
     _Pragma("unroll") for (int c = 0; c < TA2 / 16; ++c) {                                               \
-        const int row = (wave * (TA2 / 16) + c) * 4 + srow;                                              \
-        const int slot = (lane & 15) ^ (row & 15);                                                       \
-        const int ja = ja0 + (stage_)*TA2 + row;                                                         \
-        const half_t *src = ja < ja1 ? job.d_hi + (size_t)ja * KD + slot * 8 : zero_page + (lane & 3) * 8; \
-        __builtin_amdgcn_global_load_lds((gbl_void_t *)src,                                              \
-                                         (lds_void_t *)(smem + (buf_)*TA2 * 256 + (wave * (TA2 / 16) + c) * 1024), 16, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rsrc, (lds_void_t *)(smem + (buf_)*TA2 * 256 + (wave * (TA2 / 16) + c) * 1024), \
+                                                 16, voff[c], 0, 0, 0);                                  \
+        voff[c] += TA2 * (KD * 2);                                                                       \
     }
-        ISSUE_B(0, 0)
+        ISSUE_B(0)
         SFD2_BARRIER_DRAIN();
-        // tile by tile.  Measured alternatives (profiles/r02_match_pmc.txt): the MFMAs of tile k + 1 software-pipelined
+        // stage by stage, two per loop trip so that the buffer index is a constant (fragment addresses = per-lane base +
+        // immediate).  Measured alternatives (profiles/r02_match_pmc.txt): the MFMAs of tile k + 1 software-pipelined
         // with the epilogue of tile k (+2 %, register pressure), the same pinned with sched_barrier (+3 %), 32 queries per
         // wave at 4 waves per SIMD (+12 %), 128-candidate stages (+23 %, spills), one wave per SIMD (+48 %); late round 2:
         // two wave groups one barrier apart as in conv3x3_pp (512 queries per block, MFMA section / epilogue section per tile,
         // three candidate stages in flight): bit-identical, 269 -> 322-341 us
         // round 3: the eight candidate-fragment LDS offsets hoisted into registers (the compiler already folds them into
         // ds_read immediates): 268.1/275.2/268.2 -> 267.8/262.9/269.8 us, within noise, not kept
-        for (int s = 0; s < nst; ++s) {
-            const int buf = s & 1;
-            if (s + 1 < nst) { ISSUE_B(s + 1, buf ^ 1) }
-            if (wave_active) {
-#pragma unroll
-                for (int sub = 0; sub < TA2 / 32; ++sub) {
-                    f32x16_t c0 = zero16, c1 = zero16;
-                    const int tile = s * (TA2 / 32) + sub;
-                    MQ_TILE_MFMA(c0, c1, buf, sub)
-                    MQ_TILE_MASK(c0, c1, tile)
-                    MQ_TILE_EPI(c0, c1, tile)
-                }
-            }
+        for (int s = 0; s < nst; s += 2) {
+            if (s + 1 < nst) { ISSUE_B(1) }
+            if (wave_active) MQ_STAGE(s, 0)
             SFD2_BARRIER_DRAIN();
+            if (s + 1 < nst) {
+                if (s + 2 < nst) { ISSUE_B(0) }
+                if (wave_active) MQ_STAGE(s + 1, 1)
+                SFD2_BARRIER_DRAIN();
+            }
         }
 #undef ISSUE_B
         __syncthreads();
@@ -188,9 +224,10 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
         float *rk = job.rkeys + (size_t)bx * n1 + ja0;
         for (int i = tid; i < ja1 - ja0; i += NT) rk[i] = rtab[i];
     }
-#undef MQ_TILE_MFMA
+#undef MQ_STAGE
+#undef MQ_BFRAG
 #undef MQ_TILE_MASK
-#undef MQ_TILE_EPI
+#undef MQ_TILE_REV
     // ---- forward: reduce the 32 column classes of every query row through LDS (staging buffers are free now)
     float *T = reinterpret_cast<float *>(smem) + wave * (64 * 32);
     if (wave_active) {
@@ -212,28 +249,32 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
             if (v.w > best) { best = v.w; col = c4 * 4 + 3; }
         }
         const unsigned int bits = __float_as_uint(best);
-        const int tile = (1 << MQ_TILE_BITS) - 1 - (int)(bits & ((1u << MQ_TILE_BITS) - 1u));
         const size_t o = (size_t)by * n0 + q0 + lane;
         const bool any = best > MQ_NEG;
-        job.part_v1[o] = any ? __uint_as_float(bits & ~((1u << MQ_TILE_BITS) - 1u)) : -INFINITY;
-        job.part_i1[o] = any ? ja0 + tile * 32 + col : 0;
+        if (FWD_IDS) {
+            const int tile = (1 << MQ_TILE_BITS) - 1 - (int)(bits & ((1u << MQ_TILE_BITS) - 1u));
+            job.part_v1[o] = any ? __uint_as_float(bits & ~((1u << MQ_TILE_BITS) - 1u)) : -INFINITY;
+            job.part_i1[o] = any ? ja0 + tile * 32 + col : 0;
+        } else {
+            job.part_v1[o] = any ? best : -INFINITY;           // the raw row maximum of this split
+        }
     }
 }
 
-
-
 int match_mutual_strip(void) { return 256; }   // queries per reverse-partial strip (match_mutual_reduce decodes accordingly)
 
-void launch_match_mutual_gemm(hipStream_t st, const MatchJob2 *jobs_dev, int npairs, int max_n0, int splits, const half_t *zero_page)
+void launch_match_mutual_gemm(hipStream_t st, const MatchJob2 *jobs_dev, int npairs, int max_n0, int splits, int fwd_ids)
 {
     static bool attr = false;
     const size_t lds = (size_t)2 * TA2 * 256 + (size_t)MQ_MAX_CHUNK * sizeof(float);
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_mutual_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_mutual_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(match_mutual_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const int qblocks = (max_n0 + 255) / 256;
-    hipLaunchKernelGGL(match_mutual_kernel, dim3(qblocks * splits * npairs), dim3(NT), lds, st, jobs_dev, splits, qblocks, zero_page);
+    if (fwd_ids) hipLaunchKernelGGL(match_mutual_kernel<true>, dim3(qblocks * splits * npairs), dim3(NT), lds, st, jobs_dev, splits, qblocks);
+    else hipLaunchKernelGGL(match_mutual_kernel<false>, dim3(qblocks * splits * npairs), dim3(NT), lds, st, jobs_dev, splits, qblocks);
 }
 
 int match_mutual_max_chunk(void) { return MQ_MAX_CHUNK; }

@@ -2179,7 +2179,7 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
             ProfScope ps(c, "match_mutual", "match_mutual_kernel", 2.0 * (double)n0 * (double)tot_n1 * 128.0,
                          2.0 * ((double)k * n0 + (double)tot_n1) * 128.0);
             launch_match_mutual(c->stream, c->m_jobs.as<MatchJob2>(), fins_dev, k, n0, max_n1, splits,
-                                c->zero_page.as<half_t>());
+                                conf->flavour == SFD2_MATCH_HLOC && !conf->do_mutual_check);
         }
         {
             ProfScope ps(c, "match_finalize", "match_decide", 0.0, (double)tot_part * 12);
@@ -2337,7 +2337,7 @@ extern "C" int sfd2_match_segments(sfd2_ctx *c, const void *d0, int n0, const vo
         if (single_gemm) {
             ProfScope ps(c, "match_segments", "match_mutual_kernel", 0.0, 0.0);
             launch_match_mutual(c->stream, c->m_jobs.as<MatchJob2>(), fins_dev, k, max_a, max_b, splits,
-                                c->zero_page.as<half_t>());
+                                conf->flavour == SFD2_MATCH_HLOC && !conf->do_mutual_check);
             launch_match_decide(c->stream, fins_dev, k, max_n, conf->flavour, conf->do_mutual_check,
                                 conf->ratio_threshold, conf->distance_threshold);
         } else {

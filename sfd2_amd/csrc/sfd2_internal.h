@@ -399,8 +399,10 @@ struct MatchJob2 {         // one pair, both directions from one GEMM (top-1 mod
     float *rkeys;          // reverse partials [ceil(n0/strip)][n1]: value with the strip-local query id in the low mantissa bits
 };
 struct MatchFinal;
+// fwd_ids: the forward direction carries candidate ids (needed without the mutual check); 0 = mutual modes, the forward
+// index is derived from the reverse direction (match_mutual_claim_kernel)
 void launch_match_mutual(hipStream_t st, const MatchJob2 *jobs_dev, const MatchFinal *fins_dev, int npairs, int max_n0,
-                         int max_n1, int splits, const half_t *zero_page);
+                         int max_n1, int splits, int fwd_ids);
 int match_mutual_max_chunk(void);
 int match_mutual_strip(void);        // queries per reverse-partial strip of the single-GEMM kernel   // most candidates one split of the single-GEMM kernel may sweep
 void launch_match_decide(hipStream_t st, const MatchFinal *fin_dev, int npairs, int max_n, int flavour, int mutual,
