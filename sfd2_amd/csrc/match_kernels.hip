@@ -356,28 +356,32 @@ void match_mutual_reduce_kernel(const MatchJob2 *__restrict__ jobs, const MatchF
         reinterpret_cast<int *>(f.red_f)[2 * (size_t)n + i] = bi;
     } else {
         const int nstrip = (job.n0 + strip - 1) / strip;
+        // strips compare by VALUE (id bits masked off): among equal values the lower strip = the lower query index wins
         float best = MQ_NEG;
+        unsigned int bkey = __float_as_uint(MQ_NEG);
         int bs = 0;
         int sidx = 0;
-        for (; sidx + 8 <= nstrip; sidx += 8) {            // 8 independent loads in flight per thread (52 MB per 50 pairs)
+        for (; sidx + 8 <= nstrip; sidx += 8) {            // 8 independent loads in flight per thread (13 MB per 50 pairs)
             float k[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) k[u] = job.rkeys[(size_t)(sidx + u) * n + i];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (k[u] > best) { best = k[u]; bs = sidx + u; }   // ascending strips, strict '>': the lower query wins among equals
+            for (int u = 0; u < 8; ++u) {
+                const float v = __uint_as_float(__float_as_uint(k[u]) & 0xFFFFFF00u);
+                if (v > best) { best = v; bkey = __float_as_uint(k[u]); bs = sidx + u; }   // ascending strips, strict '>'
+            }
         }
         for (; sidx < nstrip; ++sidx) {
             const float k = job.rkeys[(size_t)sidx * n + i];
-            if (k > best) { best = k; bs = sidx; }
+            const float v = __uint_as_float(__float_as_uint(k) & 0xFFFFFF00u);
+            if (v > best) { best = v; bkey = __float_as_uint(k); bs = sidx; }
         }
-        const unsigned int bits = __float_as_uint(best);
-        // id bits: 3:0 = 15 - register, 4 = 1 - half-wave, 5 = 1 - query tile, 7:6 = 3 - wave (256-query strips: one block)
-        const int w = 3 - (int)((bits >> 6) & 3u), t = 1 - (int)((bits >> 5) & 1u), lh = 1 - (int)((bits >> 4) & 1u), r = 15 - (int)(bits & 15u);
+        const unsigned int bits = bkey;
+        // id bits = 255 - query index within the block's 256-query strip (match_mutual_kernel.hip)
         const bool any = best > MQ_NEG;
         f.red_r[i] = any ? __uint_as_float(bits & 0xFFFFFF00u) : -INFINITY;
         f.red_r[(size_t)n + i] = -INFINITY;
-        reinterpret_cast<int *>(f.red_r)[2 * (size_t)n + i] = any ? bs * strip + w * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh : 0;
+        reinterpret_cast<int *>(f.red_r)[2 * (size_t)n + i] = any ? bs * strip + 255 - (int)(bits & 255u) : 0;
     }
 }
 

@@ -91,10 +91,11 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
     f32x16_t zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
-    // reverse id bits 7:4 = (3 - wave, 1 - t, 1 - lhi) above the 4 register bits: the larger code wins the max, so the lower
-    // (wave, t, lhi, r) wins among values equal after truncation
+    // reverse id = 255 - (query index within the block's 256): bits 7:6 = 3 - wave, 5 = 1 - t, 4:3 = 3 - (r >> 2), 2 = 1 - lhi,
+    // 1:0 = 3 - (r & 3) (row of a 32 x 32 tile = 8 (r >> 2) + 4 lhi + (r & 3)).  The larger code wins the max, so among values
+    // equal after truncation -- exact ties included: duplicated descriptors -- the LOWER query index wins, as torch's argmax
     const unsigned int wb = (3u - (unsigned)wave) << 6;
-    const unsigned int cb[2] = {wb | 0x20u | ((1u - (unsigned)lhi) << 4), wb | ((1u - (unsigned)lhi) << 4)};
+    const unsigned int cb[2] = {wb | 0x20u | ((1u - (unsigned)lhi) << 2), wb | ((1u - (unsigned)lhi) << 2)};
     // the block's reverse table: one packed maximum per candidate of this split
     float *rtab = reinterpret_cast<float *>(smem + 2 * TA2 * 256);
     for (int i = tid; i < ja1 - ja0; i += NT) rtab[i] = MQ_NEG;          // (published by the barrier behind the first stage's copies)
@@ -131,11 +132,11 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
     {                                                                                                    \
         float m0_ = MQ_NEG, m1_ = MQ_NEG;                                                                \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
-            m0_ = fmaxf(m0_, __uint_as_float((__float_as_uint(C0_[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r))); \
-            m1_ = fmaxf(m1_, __uint_as_float((__float_as_uint(C1_[r]) & 0xFFFFFFF0u) | (unsigned)(15 - r))); \
+            m0_ = fmaxf(m0_, __uint_as_float((__float_as_uint(C0_[r]) & 0xFFFFFFE0u) | (unsigned)(((3 - (r >> 2)) << 3) | (3 - (r & 3))))); \
+            m1_ = fmaxf(m1_, __uint_as_float((__float_as_uint(C1_[r]) & 0xFFFFFFE0u) | (unsigned)(((3 - (r >> 2)) << 3) | (3 - (r & 3))))); \
         }                                                                                                \
-        const float k0_ = __uint_as_float((__float_as_uint(m0_) & 0xFFFFFF0Fu) | cb[0]);                 \
-        const float k1_ = __uint_as_float((__float_as_uint(m1_) & 0xFFFFFF0Fu) | cb[1]);                 \
+        const float k0_ = __uint_as_float((__float_as_uint(m0_) & 0xFFFFFF1Bu) | cb[0]);                 \
+        const float k1_ = __uint_as_float((__float_as_uint(m1_) & 0xFFFFFF1Bu) | cb[1]);                 \
         const unsigned int kb_ = __float_as_uint(fmaxf(k0_, k1_));                                       \
         const auto sw2_ = __builtin_amdgcn_permlane32_swap(kb_, kb_, false, false);                      \
         const float kk_ = fmaxf(__uint_as_float(sw2_[0]), __uint_as_float(sw2_[1]));                     \
