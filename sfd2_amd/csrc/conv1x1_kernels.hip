@@ -370,17 +370,22 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
 // ---------------------------------------------------------------------------------------------
 // SFD2_PREC_F16X3 for the same layers: the input as hi / lo' planes (x3_split's arithmetic: hi = fp16(x), lo' = fp16((x - hi) * 2^11)),
 // filters as fp16 + lo' fragments in the fragment order above, three MFMAs per K slice into two accumulators (hi x hi;
-// hi x lo' + lo' x hi, weighted 2^-11 -- conv_igemm_x3_kernel's combination), fp32 residual and fp32 output [P][256]; OUT_PLANES
-// additionally writes the output as planes for the layer that reads it next.  The streaming structure is the compensated
-// kernel's with both planes staged: a group = 16 KB hi + 16 KB lo'.
-template <bool HAS_RES, bool OUT_PLANES>
+// hi x lo' + lo' x hi, weighted 2^-11 -- conv_igemm_x3_kernel's combination).  RES: 0 none, 1 fp32 residual [P][256], 2 the
+// residual as hi / lo' planes (res_v / res_lo; hi + lo' * 2^-11: 22 significant bits).  OUT_F32: fp32 output
+// [P][256]; OUT_PLANES: the output as planes for the layer that reads it next (may be the residual's own buffers: a lane reads its
+// residual values before it stores to the same addresses).  The streaming structure is the compensated kernel's with both planes
+// staged: a group = 16 KB hi + 16 KB lo'.
+template <int RES, bool OUT_F32, bool OUT_PLANES>
 __global__ __launch_bounds__(NT1, 2)
 void conv1x1_c256_x3_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in_lo, int npix,
                             const half_t *__restrict__ w, const half_t *__restrict__ wl,
                             const float *__restrict__ scale, const float *__restrict__ shift, int relu,
-                            const float *__restrict__ res, float *__restrict__ out, half_t *__restrict__ out_hi, half_t *__restrict__ out_lo,
+                            const void *res_v, const half_t *res_lo, float *__restrict__ out, half_t *out_hi, half_t *out_lo,
                             int groups_per_block, const half_t *__restrict__ zero_page)
 {
+    constexpr bool HAS_RES = RES != 0;
+    const float *res = static_cast<const float *>(res_v);
+    const half_t *res_hi = static_cast<const half_t *>(res_v);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Xs = smem;                                              // [NST][hi 32 x 512 B | lo' 32 x 512 B]
     float *SS = reinterpret_cast<float *>(smem + NST * STAGE_C);
@@ -421,9 +426,9 @@ void conv1x1_c256_x3_kernel(const half_t *__restrict__ in, const half_t *__restr
             __builtin_amdgcn_global_load_lds((gbl_void_t *)s1, (lds_void_t *)(st + GPXC * 512 + ch * 1024), 16, 0, 0); \
         }                                                                                                  \
     }
-    // per group and wave: 4 copies, 4 residual loads (HAS_RES), 4 fp32 stores (+ 8 plane stores)
+    // per group and wave: 4 copies, 4 residual loads (fp32, or 16 B of each plane per channel-run pair), 4 fp32 stores, 4 plane stores
 #define WAIT_GROUP_X()                                                                                     \
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 + (OUT_PLANES ? 12 : 4) + (HAS_RES ? 4 : 0)) : "memory")
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 + (OUT_F32 ? 4 : 0) + (OUT_PLANES ? 4 : 0) + (HAS_RES ? 4 : 0)) : "memory")
 
     ISSUE_GX(g0)
     if (g0 + 1 < g1) { ISSUE_GX(g0 + 1) }
@@ -441,10 +446,20 @@ void conv1x1_c256_x3_kernel(const half_t *__restrict__ in, const half_t *__restr
         const size_t obase = (size_t)(inb ? gp : 0) * 256 + wave * 32 + 4 * lhi;
 
         float4 rr[4];
-        if (HAS_RES) {
+        uint4 rh16[2], rl16[2];     // RES == 2: a lane pair's 8 + 8 channels of a run pair as one 16-byte load each (regrouped below)
+        if (RES == 1) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) rr[q] = *reinterpret_cast<const float4 *>(res + obase + 8 * q);   // (pixels past the end: pixel 0's)
             asm volatile("" ::: "memory");       // keep the residual loads ahead of the copies below in program order
+        }
+        if (RES == 2) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const size_t o16 = (size_t)(inb ? gp : 0) * 256 + wave * 32 + 8 * (2 * m + lhi);
+                rh16[m] = *reinterpret_cast<const uint4 *>(res_hi + o16);
+                rl16[m] = *reinterpret_cast<const uint4 *>(res_lo + o16);
+            }
+            asm volatile("" ::: "memory");
         }
         if (g + 3 < g1) { ISSUE_GX(g + 3) }
 
@@ -462,6 +477,22 @@ void conv1x1_c256_x3_kernel(const half_t *__restrict__ in, const half_t *__restr
             acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(sfd2_half8(al[kk >> 1], kk & 1), b, acl, 0, 0, 0);
         }
         const int cl = wave * 32 + 4 * lhi;
+        h4_t rh[4], rl[4];
+        if (RES == 2) {
+            // lane (lhi = 0) loaded channels 16 m .. + 7 = run 2 m of both half-waves, lane (lhi = 1) run 2 m + 1 of both:
+            // v_permlane32_swap hands each lane its own two runs (the store regrouping below, reversed)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const auto a0 = __builtin_amdgcn_permlane32_swap(rh16[m].x, rh16[m].z, false, false);
+                const auto a1 = __builtin_amdgcn_permlane32_swap(rh16[m].y, rh16[m].w, false, false);
+                const auto b0 = __builtin_amdgcn_permlane32_swap(rl16[m].x, rl16[m].z, false, false);
+                const auto b1 = __builtin_amdgcn_permlane32_swap(rl16[m].y, rl16[m].w, false, false);
+                const uint2 h0 = make_uint2(a0[0], a1[0]), h1 = make_uint2(a0[1], a1[1]), l0 = make_uint2(b0[0], b1[0]), l1 = make_uint2(b0[1], b1[1]);
+                __builtin_memcpy(&rh[2 * m], &h0, 8); __builtin_memcpy(&rh[2 * m + 1], &h1, 8);
+                __builtin_memcpy(&rl[2 * m], &l0, 8); __builtin_memcpy(&rl[2 * m + 1], &l1, 8);
+            }
+        }
+        uint2 ph[4], pl[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 sc = sfd2_lds_f4(SS + cl + 8 * q);
@@ -470,16 +501,33 @@ void conv1x1_c256_x3_kernel(const half_t *__restrict__ in, const half_t *__restr
             float v1 = (acc[4 * q + 1] + acl[4 * q + 1] * (1.0f / 2048.0f)) * sc.y + sh.y;
             float v2 = (acc[4 * q + 2] + acl[4 * q + 2] * (1.0f / 2048.0f)) * sc.z + sh.z;
             float v3 = (acc[4 * q + 3] + acl[4 * q + 3] * (1.0f / 2048.0f)) * sc.w + sh.w;
+            if (RES == 2) {
+                rr[q] = make_float4((float)rh[q][0] + (float)rl[q][0] * (1.0f / 2048.0f), (float)rh[q][1] + (float)rl[q][1] * (1.0f / 2048.0f),
+                                    (float)rh[q][2] + (float)rl[q][2] * (1.0f / 2048.0f), (float)rh[q][3] + (float)rl[q][3] * (1.0f / 2048.0f));
+            }
             if (HAS_RES) { v0 += rr[q].x; v1 += rr[q].y; v2 += rr[q].z; v3 += rr[q].w; }
             if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
-            if (inb) *reinterpret_cast<float4 *>(out + obase + 8 * q) = make_float4(v0, v1, v2, v3);
+            if (OUT_F32 && inb) *reinterpret_cast<float4 *>(out + obase + 8 * q) = make_float4(v0, v1, v2, v3);
             if (OUT_PLANES) {
                 h4_t hv = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
                 h4_t lv = {(half_t)((v0 - (float)hv[0]) * 2048.0f), (half_t)((v1 - (float)hv[1]) * 2048.0f),
                            (half_t)((v2 - (float)hv[2]) * 2048.0f), (half_t)((v3 - (float)hv[3]) * 2048.0f)};
+                __builtin_memcpy(&ph[q], &hv, 8);
+                __builtin_memcpy(&pl[q], &lv, 8);
+            }
+        }
+        if (OUT_PLANES) {
+            // 16-byte plane stores: runs 2 m / 2 m + 1 of the two half-waves regrouped with v_permlane32_swap (conv2_kernels.hip)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const auto t0 = __builtin_amdgcn_permlane32_swap(ph[2 * m].x, ph[2 * m + 1].x, false, false);
+                const auto t1 = __builtin_amdgcn_permlane32_swap(ph[2 * m].y, ph[2 * m + 1].y, false, false);
+                const auto u0 = __builtin_amdgcn_permlane32_swap(pl[2 * m].x, pl[2 * m + 1].x, false, false);
+                const auto u1 = __builtin_amdgcn_permlane32_swap(pl[2 * m].y, pl[2 * m + 1].y, false, false);
+                const size_t o16 = (size_t)(inb ? gp : 0) * 256 + wave * 32 + 8 * (2 * m + lhi);
                 if (inb) {
-                    *reinterpret_cast<h4_t *>(out_hi + obase + 8 * q) = hv;
-                    *reinterpret_cast<h4_t *>(out_lo + obase + 8 * q) = lv;
+                    *reinterpret_cast<uint4 *>(out_hi + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                    *reinterpret_cast<uint4 *>(out_lo + o16) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
                 }
             }
         }
@@ -488,18 +536,18 @@ void conv1x1_c256_x3_kernel(const half_t *__restrict__ in, const half_t *__restr
 #undef WAIT_GROUP_X
 }
 
-// in / in_lo: input planes; w / wl: fp16 filters and their lo' parts in fragment order; res (fp32, may be null); out fp32; out_hi /
-// out_lo (may be null): the output as planes too
+// in / in_lo: input planes; w / wl: fp16 filters and their lo' parts in fragment order; res: null, fp32 [P][256] (res_lo null) or the hi
+// plane with res_lo its lo' plane; out: fp32 [P][256] or null; out_hi / out_lo: the output as planes, or null (one of the two forms)
 void launch_conv1x1_c256_x3(hipStream_t st, const half_t *in, const half_t *in_lo, int npix, const half_t *w, const half_t *wl,
-                            const float *scale, const float *shift, int relu, const float *res, float *out, half_t *out_hi,
+                            const float *scale, const float *shift, int relu, const void *res, const half_t *res_lo, float *out, half_t *out_hi,
                             half_t *out_lo, const half_t *zero_page)
 {
     static bool attr_done = false;
     static int slots = 256;
     const size_t lds = (size_t)NST * STAGE_C + 512 * sizeof(float);
     if (!attr_done) {
-#define C256X_ATTR(R_, P_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_c256_x3_kernel<R_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        C256X_ATTR(false, false) C256X_ATTR(true, false) C256X_ATTR(false, true) C256X_ATTR(true, true)
+#define C256X_ATTR(...) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_c256_x3_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        C256X_ATTR(0, true, false) C256X_ATTR(0, false, true) C256X_ATTR(1, true, false) C256X_ATTR(1, true, true) C256X_ATTR(2, false, true) C256X_ATTR(2, true, true)
 #undef C256X_ATTR
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
@@ -510,9 +558,15 @@ void launch_conv1x1_c256_x3(hipStream_t st, const half_t *in, const half_t *in_l
     if (ngroups == 0) return;
     const int gpb = (ngroups + sfd2_slots(slots) - 1) / sfd2_slots(slots);
     const int grid = (ngroups + gpb - 1) / gpb;
-#define C256X_GO(R_, P_) hipLaunchKernelGGL((conv1x1_c256_x3_kernel<R_, P_>), dim3(grid), dim3(NT1), lds, st, in, in_lo, npix, w, wl, scale, shift, relu, res, out, out_hi, out_lo, gpb, zero_page)
-    if (res) { if (out_hi) C256X_GO(true, true); else C256X_GO(true, false); }
-    else { if (out_hi) C256X_GO(false, true); else C256X_GO(false, false); }
+#define C256X_GO(...) hipLaunchKernelGGL((conv1x1_c256_x3_kernel<__VA_ARGS__>), dim3(grid), dim3(NT1), lds, st, in, in_lo, npix, w, wl, scale, shift, relu, res, res_lo, out, out_hi, out_lo, gpb, zero_page)
+    const int rmode = !res ? 0 : (res_lo ? 2 : 1);
+    if (rmode == 0 && out && !out_hi) C256X_GO(0, true, false);
+    else if (rmode == 0 && !out && out_hi) C256X_GO(0, false, true);
+    else if (rmode == 1 && out && !out_hi) C256X_GO(1, true, false);
+    else if (rmode == 1 && out && out_hi) C256X_GO(1, true, true);
+    else if (rmode == 2 && !out && out_hi) C256X_GO(2, false, true);
+    else if (rmode == 2 && out && out_hi) C256X_GO(2, true, true);
+    else abort();
 #undef C256X_GO
 }
 

@@ -406,7 +406,10 @@ typedef float f32x4c_t __attribute__((ext_vector_type(4)));
 // IN_C = false: plain fp16 input (option "rb_inner" = 2: ResBlock.conv1 wrote only a hi plane) -- no corr records; the filter
 // residuals arrive as fp16 fragments (w - fp16(w)) * 2^11 in wpk's layout (`wck`) for a second fp16 pass into its own
 // accumulators.  OUT_C = false: only the hi plane is written ("rb_inner" >= 1).
-template <bool IN_C, bool OUT_C>
+// X3 (SFD2_PREC_F16X3 on the throughput path; IN_C = OUT_C = true): in_c / out_c are lo' planes (lo' = fp16((x - hi) * 2^11)) and wck
+// the filters' lo' fragments: hi x hi into acc, hi x lo' + lo' x hi into acl, y = acc + acl * 2^-11 -- gconv_x3_kernel's arithmetic on
+// pre-split operands.
+template <bool IN_C, bool OUT_C, bool X3 = false>
 __global__ __launch_bounds__(CNT, 2)   // two blocks (59 KB of LDS each) per CU
 void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in_c, int H, int W,
                     const half_t *__restrict__ wpk /*[16 pairs][5 steps][64 lanes][8] fp16*/,
@@ -458,7 +461,7 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
         for (int s = 0; s < 5; ++s)
             wh[s] = *reinterpret_cast<const h8_t *>(wpk + ((size_t)(pair * 5 + s) * 64 + lane) * 8);
         h8_t wl[5];
-        if (IN_C) {
+        if (IN_C && !X3) {
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const unsigned char *p = wck + ((size_t)(pair * 3 + m) * 64 + lane) * 32;
@@ -485,17 +488,21 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
                 const int q = ((t >> 1) + ky) * GC_PW + (t & 1) * 16 + lcol + kx;
                 const h8_t bh = *reinterpret_cast<const h8_t *>(Xh + q * GCP + wave * 16 + (g & 1) * 8);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bh, acc[t], 0, 0, 0);
-                if (!IN_C) acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], bh, acl[t], 0, 0, 0);
+                if (!IN_C || X3) acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], bh, acl[t], 0, 0, 0);
+                if (X3) {
+                    const h8_t bl = *reinterpret_cast<const h8_t *>(Xc + q * GCP + wave * 16 + (g & 1) * 8);
+                    acl[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bl, acl[t], 0, 0, 0);
+                }
             }
         }
-        if (!IN_C) {
+        if (!IN_C || X3) {
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_fmaf(acl[t][r], 1.0f / 2048.0f, acc[t][r]);
         }
 #pragma unroll
-        for (int m = 0; m < (IN_C ? 3 : 0); ++m) {
+        for (int m = 0; m < (IN_C && !X3 ? 3 : 0); ++m) {
             int tap = 4 * m + g;
             if (tap > 8) tap = 8;
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -518,8 +525,19 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
         for (int t = 0; t < 8; t += 2) {
             uint2 pk[2], ck[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                sfd2_epi4<false>(acc[t + j][0], acc[t + j][1], acc[t + j][2], acc[t + j][3], sc, sh, sc, 0.0f, pk[j], ck[j]);
+            for (int j = 0; j < 2; ++j) {
+                if (X3) {
+                    const float v0 = fmaxf(acc[t + j][0] * sc.x + sh.x, 0.0f), v1 = fmaxf(acc[t + j][1] * sc.y + sh.y, 0.0f);
+                    const float v2 = fmaxf(acc[t + j][2] * sc.z + sh.z, 0.0f), v3 = fmaxf(acc[t + j][3] * sc.w + sh.w, 0.0f);
+                    const h4_t h = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+                    const h4_t l = {(half_t)((v0 - (float)h[0]) * 2048.0f), (half_t)((v1 - (float)h[1]) * 2048.0f),
+                                    (half_t)((v2 - (float)h[2]) * 2048.0f), (half_t)((v3 - (float)h[3]) * 2048.0f)};
+                    __builtin_memcpy(&pk[j], &h, 8);
+                    __builtin_memcpy(&ck[j], &l, 8);
+                } else {
+                    sfd2_epi4<false>(acc[t + j][0], acc[t + j][1], acc[t + j][2], acc[t + j][3], sc, sh, sc, 0.0f, pk[j], ck[j]);
+                }
+            }
             const bool odd = g & 1;
             const uint2 send = odd ? pk[0] : pk[1], sendc = odd ? ck[0] : ck[1];
             uint2 recv, recvc = make_uint2(0, 0);
@@ -540,6 +558,7 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
 }
 
 // row0 / row1: the output rows to produce (the whole image: 0, H); input rows outside [0, H) are the conv's zero padding
+// (sbyte < 0: SFD2_PREC_F16X3 -- in_c / out_c are lo' planes, wck the filters' lo' fragments)
 void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk, const void *wck,
                     const float *scale, const float *shift, half_t *out, half_t *out_c, int sbyte, int row0, int row1)
 {
@@ -548,9 +567,12 @@ void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H,
     if (row1 > H) row1 = H;
     if (row0 >= row1) return;
     const int tiles_x = (W + CTW - 1) / CTW, tiles_y = (row1 - row0 + CTH - 1) / CTH;
-#define GCC_GO(I_, O_) hipLaunchKernelGGL((gconv_c_kernel<I_, O_>), dim3(tiles_x * tiles_y), dim3(CNT), lds, st, in, in_c, H, W, wpk, \
+#define GCC_GO(...) hipLaunchKernelGGL((gconv_c_kernel<__VA_ARGS__>), dim3(tiles_x * tiles_y), dim3(CNT), lds, st, in, in_c, H, W, wpk, \
                        reinterpret_cast<const unsigned char *>(wck), scale, shift, out, out_c, tiles_x, (sbyte & 255) * 0x01010101, row0, row1)
-    if (in_c && out_c) GCC_GO(true, true);
+    if (sbyte < 0) {
+        if (!in_c || !out_c) abort();
+        GCC_GO(true, true, true);
+    } else if (in_c && out_c) GCC_GO(true, true);
     else if (in_c) GCC_GO(true, false);
     else if (!out_c) GCC_GO(false, false);
     else abort();

@@ -93,7 +93,7 @@ struct sfd2_ctx {
     int alias_now = 0;                 // set per call
     int x3_fast_rb_now = 0;            // set per call: f16x3 ResBlocks on the streaming three-pass 1x1 kernel (not on the parity entry point:
                                        // the grouped conv's output then exists as planes only)
-    DevBuf x3_rb_planes[2];            // a ResBlock's input / the grouped conv's output as hi / lo' planes
+    DevBuf x3_rb_planes[3];            // a ResBlock's input, conv1's and the grouped conv's outputs as hi / lo' planes
     const void *x3_pre_src = nullptr;  // set by a producer that wrote its output as planes too: the fp32 tensor they belong to ...
     const half_t *x3_pre_hi = nullptr, *x3_pre_lo = nullptr;   // ... and the planes (consumed by the next convf on that tensor)
     int x3_planes_out_now = 0;         // set around a convf call: the 3x3 layer writes hi / lo' planes INTO x3_chain instead of fp32
@@ -247,7 +247,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     graphs_release(c);
-    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->w1b_stem_x3, &c->da3_sparse, &c->x3_planes, &c->x3_da0_planes, &c->db_sparse, &c->x3_rb_planes[0], &c->x3_rb_planes[1], &c->x3_chain, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
+    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->w1b_stem_x3, &c->da3_sparse, &c->x3_planes, &c->x3_da0_planes, &c->db_sparse, &c->x3_rb_planes[0], &c->x3_rb_planes[1], &c->x3_rb_planes[2], &c->x3_chain, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
                       &c->rt1[0], &c->rt1[1], &c->rt1[2], &c->rt2[0], &c->rt2[1], &c->rt2[2], &c->ro[0], &c->ro[1],
                       &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
                       &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->bnd, &c->sel, &c->sorted, &c->counters,
@@ -992,16 +992,17 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
     static const char *nm1[3] = {"conv4.0.conv1", "conv4.1.conv1", "conv4.2.conv1"};
     static const char *nm2[3] = {"conv4.0.conv2", "conv4.1.conv2", "conv4.2.conv2"};
     static const char *nm3[3] = {"conv4.0.conv3", "conv4.1.conv3", "conv4.2.conv3"};
-    const bool fast_rb = c->x3_fast_rb_now && c->rb1[0].wfh.p && c->rb1[0].wfl.p;
+    const bool fast_rb = c->x3_fast_rb_now && c->rb1[0].wfh.p && c->rb1[0].wfl.p && c->rb2[0].w.p && c->rb2[0].wlk.p;
     if (fast_rb) {
-        // ResBlocks of SFD2_PREC_F16X3 on the throughput path: the block's input as hi / lo' planes (split once in front of the
-        // first block; conv3 writes its fp32 output AND its planes), conv1 and conv3 on the streaming three-pass 1x1 kernel (filters
-        // = the fp16 set's fragment-ordered hi / lo' arrays: the same split of the same fp32 weights), the grouped conv writes
-        // planes.  conv1 132 -> ~60 us, conv3 168 -> ~90 us per block at 1600x1200.
+        // ResBlocks of SFD2_PREC_F16X3 on the throughput path: every tensor of a block lives as hi / lo' planes (the input is split
+        // once in front of the first block).  conv1 and conv3 on the streaming three-pass 1x1 kernel (filters = the fp16 set's
+        // fragment-ordered hi / lo' arrays: the same split of the same fp32 weights), the grouped conv on gconv_c_kernel<X3>
+        // (pre-split operands, direct plane stores); the skip connection is read from the planes (22 significant bits) and only the
+        // last block also writes the fp32 tensor its generic readers (convPa.0, ConvSta) take.
         const size_t nin = (size_t)H4 * W4 * 256;
-        HIPCHECK(c->x3_rb_planes[0].ensure(nin * 2 * sizeof(half_t)));
-        HIPCHECK(c->x3_rb_planes[1].ensure(nin * 2 * sizeof(half_t)));
+        for (int k = 0; k < 3; ++k) HIPCHECK(c->x3_rb_planes[k].ensure(nin * 2 * sizeof(half_t)));
         half_t *xh = c->x3_rb_planes[0].as<half_t>(), *xl = xh + nin, *th = c->x3_rb_planes[1].as<half_t>(), *tl = th + nin;
+        half_t *uh = c->x3_rb_planes[2].as<half_t>(), *ul = uh + nin;
         {
             ProfScope ps(c, "conv3b planes", "x3_split_planes", 0.0, 12.0 * nin);
             launch_x3_split_planes(st, x->as<float>(), nin, xh, xl);
@@ -1010,24 +1011,21 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
             {
                 ProfScope ps(c, nm1[b], "conv1x1_c256<x3>", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 8);
                 launch_conv1x1_c256_x3(st, xh, xl, H4 * W4, c->rb1[b].wfh.as<half_t>(), c->rb1[b].wfl.as<half_t>(), c->frb1[b].scale.as<float>(),
-                                       c->frb1[b].shift.as<float>(), 1, nullptr, c->grt1[b].as<float>(), nullptr, nullptr, c->zero_page.as<half_t>());
+                                       c->frb1[b].shift.as<float>(), 1, nullptr, nullptr, nullptr, th, tl, c->zero_page.as<half_t>());
             }
             {
-                if (!c->frb2[b].wx3.p) {
-                    HIPCHECK(c->frb2[b].wx3.ensure((size_t)16 * 5 * 64 * 16 * sizeof(half_t)));
-                    launch_gconv_x3_pack(st, c->frb2[b].w.as<float>(), c->frb2[b].wx3.p);
-                }
-                ProfScope ps(c, nm2[b], "gconv_x3_kernel<planes out>", 2.0 * P4 * 256 * 72, P4 * 256 * 8);
-                launch_gconv_x3(st, c->grt1[b].as<float>(), H4, W4, c->frb2[b].wx3.p, c->frb2[b].scale.as<float>(),
-                                c->frb2[b].shift.as<float>(), nullptr, th, tl);
+                ProfScope ps(c, nm2[b], "gconv_c_kernel<x3>", 2.0 * P4 * 256 * 72, P4 * 256 * 8);
+                launch_gconv_c(st, th, tl, H4, W4, c->rb2[b].w.as<half_t>(), c->rb2[b].wlk.p, c->frb2[b].scale.as<float>(),
+                               c->frb2[b].shift.as<float>(), uh, ul, -1, 0, H4);
             }
             {
-                ProfScope ps(c, nm3[b], "conv1x1_c256<x3>+res", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 16);
-                launch_conv1x1_c256_x3(st, th, tl, H4 * W4, c->rb3[b].wfh.as<half_t>(), c->rb3[b].wfl.as<half_t>(), c->frb3[b].scale.as<float>(),
-                                       c->frb3[b].shift.as<float>(), 1, x->as<float>(), c->gro[b].as<float>(), xh, xl, c->zero_page.as<half_t>());
+                ProfScope ps(c, nm3[b], "conv1x1_c256<x3>+res", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * (b == 2 ? 16 : 12));
+                launch_conv1x1_c256_x3(st, uh, ul, H4 * W4, c->rb3[b].wfh.as<half_t>(), c->rb3[b].wfl.as<half_t>(), c->frb3[b].scale.as<float>(),
+                                       c->frb3[b].shift.as<float>(), 1, xh, xl, b == 2 ? c->gro[b].as<float>() : nullptr, xh, xl,
+                                       c->zero_page.as<half_t>());
             }
-            x = &c->gro[b];
         }
+        x = &c->gro[2];
         c->x3_pre_src = x->p; c->x3_pre_hi = xh; c->x3_pre_lo = xl;     // the backbone output's planes: convDa.0 takes them as they are
     }
     for (int b = 0; b < (fast_rb ? 0 : 3); ++b) {

@@ -219,7 +219,7 @@ void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t 
                    const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page);
 // conv1x1_kernels.hip: SFD2_PREC_F16X3 streaming 1x1 (256 -> 256): planes in, fp32 (+ planes) out, fp32 residual
 void launch_conv1x1_c256_x3(hipStream_t st, const half_t *in, const half_t *in_lo, int npix, const half_t *w, const half_t *wl,
-                            const float *scale, const float *shift, int relu, const float *res, float *out, half_t *out_hi,
+                            const float *scale, const float *shift, int relu, const void *res, const half_t *res_lo, float *out, half_t *out_hi,
                             half_t *out_lo, const half_t *zero_page);
 void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *wpk /*hi, lo fragments*/,
                      const float *scale, const float *shift, half_t *out, half_t *out_c);
