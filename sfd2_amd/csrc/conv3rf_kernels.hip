@@ -104,6 +104,13 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                        const half_t *__restrict__ in_c = nullptr, half_t *__restrict__ out_c = nullptr, int sa = 0)
 {
     static_assert(COMP == 0 || (!RES && ABL == 0), "compensated instantiations: streamed filters");
+    // COMP bit 2 (X3, SFD2_PREC_F16X3): in / in_c are hi / lo' planes, wpk holds the filters' hi units then their lo' units; a tile's
+    // chunk sequence runs the plain fp16 body three times -- (hi plane, hi filters), the accumulators times 2^11 (exact), (hi plane, lo'
+    // filters), (lo' plane, hi filters) -- and the epilogue folds 2^-11 into the scale.  Output: hi / lo' planes (out / out_c), or with
+    // bit 3 fp32 [P][CoutP] through `out`.  CPB = the compensated-structure bits (0 for X3: it is the plain kernel's pipeline).
+    constexpr bool X3 = (COMP & 4) != 0;
+    constexpr int CPB = X3 ? 0 : COMP;
+    constexpr bool OUTC = (CPB & 2) != 0 || (X3 && !(COMP & 8));
     using G = RfGeom<S>;
     constexpr int NWC = BN / 32, NF = 4 / (8 / NWC);       // channel groups; pixel fragments per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -122,7 +129,8 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     const int n0 = (wave % NWC) * 32;                      // CoutP == BN: one channel tile (launcher)
 
     const int NCP = Cin / RF_CC;                           // chunks per plane
-    const int NCH = ((COMP & 1) ? 2 : 1) * NCP;            // chunks per tile: the hi plane's, then (COMP & 1) the corr plane's
+    const int NCH = ((CPB & 1) ? 2 : X3 ? 3 : 1) * NCP;    // chunks per tile: the hi plane's, then (COMP & 1) the corr plane's / (X3) two more passes
+    const int NU1 = NCP * 9;                               // units of one pass
     const int NU = NCH * 9;
     const int n_my = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this block
     const int TC = n_my * NCH;                             // chunks of this block
@@ -138,7 +146,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         const int tx_ = swz_ % tiles_x, ty_ = swz_ / tiles_x;                                          \
         const int poy0_ = ty_ * RF_TH, pox0_ = tx_ * RF_TW;                                            \
         int lane_ = lane;                                                                              \
-        if (COMP != 0) asm volatile("" : "+v"(lane_));   /* (per-lane piece geometry recomputed per tile, not hoisted into registers) */ \
+        if (CPB != 0) asm volatile("" : "+v"(lane_));   /* (per-lane piece geometry recomputed per tile, not hoisted into registers) */ \
         _Pragma("unroll") for (int i = 0; i < G::PPW; ++i) {                                           \
             int piece = wave + 8 * i;                                                                  \
             if (piece >= G::NPIECE) piece = G::NPIECE - 1;                                             \
@@ -159,9 +167,11 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #define RF_ISSUE_X1(chunk_, buf_, i_)                                                                  \
     do {                                                                                               \
         const int pc_ = (wave + 8 * (i_) < G::NPIECE) ? wave + 8 * (i_) : G::NPIECE - 1;               \
-        const bool cp_ = (COMP & 1) && (chunk_) >= NCP;                                                \
+        const bool cp_ = X3 ? (chunk_) >= 2 * NCP : ((CPB & 1) && (chunk_) >= NCP);                    \
+        const int ck_ = X3 ? ((chunk_) >= 2 * NCP ? (chunk_) - 2 * NCP : ((chunk_) >= NCP ? (chunk_) - NCP : (chunk_))) \
+                           : (chunk_) - (cp_ ? NCP : 0);                                               \
         rf_copy_piece(cp_ ? in_c : in, in_bytes, Xs + (buf_)*G::XBYTES + pc_ * 1024, xoff[i_],         \
-                      ((chunk_) - (cp_ ? NCP : 0)) * RF_CC * (int)sizeof(half_t));                     \
+                      ck_ * RF_CC * (int)sizeof(half_t));                                              \
     } while (0)
 #define RF_ISSUE_X(chunk_, buf_)                                                                       \
     _Pragma("unroll") for (int i_ = 0; i_ < G::PPW; ++i_) RF_ISSUE_X1(chunk_, buf_, i_);
@@ -172,7 +182,8 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     do {                                                                                               \
         int ao_ = aoff;                                                                                \
         asm volatile("" : "+v"(ao_));                                                                  \
-        const half_t *ap_ = wpk + (size_t)(u_)*CoutP * RF_CC + ao_;                                    \
+        const int uu_ = (X3 && (u_) >= 2 * NU1) ? (u_) - 2 * NU1 : (u_);   /* third pass: the hi filters again */ \
+        const half_t *ap_ = wpk + (size_t)uu_ * CoutP * RF_CC + ao_;                                   \
         dst_[0] = *reinterpret_cast<const h8_t *>(ap_);                                                \
         dst_[1] = *reinterpret_cast<const h8_t *>(ap_ + 16);                                           \
     } while (0)
@@ -219,18 +230,19 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
     constexpr int NFA = RES ? 18 : 9;
-    h8_t fa[NFA][2], fb[3][COMP ? 1 : NF];                // (COMP: the filter ring stays in K-slice halves -- 4-register pieces
-    v8i_t fb8[2][COMP ? NF : 1];                          //  allocate where 8-register tuples spill -- and is joined per fp8 unit)
+    h8_t fa[NFA][2], fb[3][CPB ? 1 : NF];                // (COMP: the filter ring stays in K-slice halves -- 4-register pieces
+    v8i_t fb8[2][CPB ? NF : 1];                          //  allocate where 8-register tuples spill -- and is joined per fp8 unit)
 
     // scale / shift of this wave's 32 channels stay in registers (one channel tile: the same for every tile); RES has no
     // registers to spare and re-reads them per tile
     float4 sc[4], sh[4];
-    constexpr bool SS_RELOAD = RES || COMP != 0;   // (the compensated forms neither: two chunk bodies)
+    constexpr bool SS_RELOAD = RES || CPB != 0;   // (the compensated forms neither: two chunk bodies)
     if (!SS_RELOAD) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             sc[q] = *reinterpret_cast<const float4 *>(scale + n0 + 4 * lhi + 8 * q);
             sh[q] = *reinterpret_cast<const float4 *>(shift + n0 + 4 * lhi + 8 * q);
+            if (X3) { sc[q].x *= 1.0f / 2048.0f; sc[q].y *= 1.0f / 2048.0f; sc[q].z *= 1.0f / 2048.0f; sc[q].w *= 1.0f / 2048.0f; }
         }
     }
     const float lo = relu ? 0.0f : -__builtin_huge_valf();   // branch-free ReLU (this file is compiled with -fno-honor-nans)
@@ -242,7 +254,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     for (int u = 0; u < NFA; ++u) RF_LOAD_A(u, fa[u]);
     // (waiting for the first patch only and letting the rest land behind counted waits was measured: no gain)
     SFD2_BARRIER_DRAIN();
-    if constexpr (COMP != 0) {
+    if constexpr (CPB != 0) {
         RF_READ_B8(Xs, 0, fb8[0]);
     } else {
         RF_READ_B(Xs, 0, 0, fb[0]);
@@ -256,7 +268,13 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         constexpr int CC = decltype(cc_tag)::value;
         // a corr-plane chunk (COMP & 1)?  A wave-uniform RUNTIME flag: two instantiations of this body (one per chunk type) cost
         // 70 more registers than one (each copy keeps its own hoisted state across the shared rings) and spill in the unit loop
-        const bool F8 = (COMP & 1) && c >= NCP;
+        const bool F8 = (CPB & 1) && c >= NCP;
+        if (X3 && c == NCP) {                               // the hi x hi sums are complete: the cross terms carry 2^-11
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[f][r] *= 2048.0f;
+        }
         const int bn = bc == 2 ? 0 : bc + 1, bnn = bn == 2 ? 0 : bn + 1;
         const unsigned char *xs = Xs + bc * G::XBYTES;
         const unsigned char *xn = Xs + bn * G::XBYTES;
@@ -266,7 +284,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         // the in-flight counts stay what the waits assume).
         const int Cx = C + 2 < TC ? C + 2 : TC - 1;
         const int seq_x = Cx / NCH, cx = Cx - seq_x * NCH;
-        if constexpr (COMP == 0) {   // (the compensated forms have two chunk bodies: their caller does this once)
+        if constexpr (CPB == 0) {   // (the compensated forms have two chunk bodies: their caller does this once)
             if (seq_x != xoff_seq) RF_SETUP_X(seq_x)
         }
 #pragma unroll
@@ -283,7 +301,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                 else asm volatile("s_waitcnt vmcnt(33) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (COMP != 0) {
+            if constexpr (CPB != 0) {
                 // the pixel fragments of unit t + 1 (of the next chunk's first unit at t = 8: its patch has landed, see above)
                 if (t + 1 < 9) RF_READ_B8(xs, t + 1, fb8[(t + 1) & 1]);
                 else RF_READ_B8(xn, 0, fb8[1]);
@@ -333,7 +351,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (COMP != 0) {
+        if constexpr (CPB != 0) {
             // nine units per chunk: the next chunk's first fragments were read into slot 1; its units index from slot 0
 #pragma unroll
             for (int f = 0; f < NF; ++f) fb8[0][f] = fb8[1][f];
@@ -366,9 +384,24 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int q = 2 * m + j;
-                    if constexpr ((COMP & 2) != 0) {
+                    if constexpr ((CPB & 2) != 0) {
                         sfd2_epi4<false>(acc[f][4 * q + 0], acc[f][4 * q + 1], acc[f][4 * q + 2], acc[f][4 * q + 3], sc[q], sh[q], sc[q],
                                          relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j]);
+                    } else if constexpr (X3) {
+                        float v0 = acc[f][4 * q + 0] * sc[q].x + sh[q].x;
+                        float v1 = acc[f][4 * q + 1] * sc[q].y + sh[q].y;
+                        float v2 = acc[f][4 * q + 2] * sc[q].z + sh[q].z;
+                        float v3 = acc[f][4 * q + 3] * sc[q].w + sh[q].w;
+                        v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
+                        if constexpr ((COMP & 8) != 0) {
+                            if (inb) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(out) + pix * CoutP + n0 + 4 * lhi + 8 * q) = make_float4(v0, v1, v2, v3);
+                        } else {
+                            const h4_t hv = cvt4r(v0, v1, v2, v3);
+                            const h4_t lv = cvt4r((v0 - (float)hv[0]) * 2048.0f, (v1 - (float)hv[1]) * 2048.0f, (v2 - (float)hv[2]) * 2048.0f,
+                                                  (v3 - (float)hv[3]) * 2048.0f);
+                            __builtin_memcpy(&pk[j], &hv, 8);
+                            __builtin_memcpy(&ck[j], &lv, 8);
+                        }
                     } else {
                         float v0 = acc[f][4 * q + 0] * sc[q].x + sh[q].x;
                         float v1 = acc[f][4 * q + 1] * sc[q].y + sh[q].y;
@@ -379,7 +412,8 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                         __builtin_memcpy(&pk[j], &hv, 8);
                     }
                 }
-                if constexpr ((COMP & 2) != 0) {
+                if constexpr (X3 && (COMP & 8) != 0) continue;      // fp32 rows went out above
+                if constexpr (OUTC) {
                     const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
                     const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
                     if (inb) *reinterpret_cast<uint4 *>(out_c + o16) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
@@ -425,7 +459,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             chunk(std::integral_constant<int, 1>{});
             epilogue();
         }
-    } else if constexpr ((COMP & 1) != 0) {
+    } else if constexpr ((CPB & 1) != 0) {
         while (C < TC) {
             {
                 const int Cx = C + 2 < TC ? C + 2 : TC - 1;
@@ -487,6 +521,25 @@ bool launch_conv3x3_rf_c(hipStream_t st, const half_t *in, const half_t *in_c, i
         return true;
     }
     return false;
+}
+
+// SFD2_PREC_F16X3 on this kernel (256-channel tiles): in_hi / in_lo planes, wpl = the filters as hi units then lo' units (the fp32 set's
+// packing split by x3_split_planes), output as planes (out_hi / out_lo) or as fp32 [P][CoutP] (out_f32).  false = no instantiation.
+bool launch_conv3x3_rf_x3(hipStream_t st, const half_t *in_hi, const half_t *in_lo, int H, int W, int Cin, const half_t *wpl,
+                          const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out_hi, half_t *out_lo,
+                          float *out_f32, int Ho, int Wo, const half_t *zero_page)
+{
+    if (CoutP != RF_BN || Cin % 64 != 0 || (stride != 1 && stride != 2)) return false;
+    if ((long long)(Ho * stride + 2) * (Wo * stride + 2) * Cin * (long long)sizeof(half_t) >= (1ll << 31)) return false;
+    if (out_f32) {
+        half_t *o = reinterpret_cast<half_t *>(out_f32);
+        if (stride == 2) launch_rf_t<2, RF_BN, 0, false, 12>(st, in_hi, H, W, Cin, wpl, scale, shift, CoutP, relu, o, Ho, Wo, zero_page, in_lo, nullptr, 0);
+        else launch_rf_t<1, RF_BN, 0, false, 12>(st, in_hi, H, W, Cin, wpl, scale, shift, CoutP, relu, o, Ho, Wo, zero_page, in_lo, nullptr, 0);
+    } else {
+        if (stride == 2) launch_rf_t<2, RF_BN, 0, false, 4>(st, in_hi, H, W, Cin, wpl, scale, shift, CoutP, relu, out_hi, Ho, Wo, zero_page, in_lo, out_lo, 0);
+        else launch_rf_t<1, RF_BN, 0, false, 4>(st, in_hi, H, W, Cin, wpl, scale, shift, CoutP, relu, out_hi, Ho, Wo, zero_page, in_lo, out_lo, 0);
+    }
+    return true;
 }
 
 // does conv3x3_rf serve this layer?  Shape AND output size decide (the filter packing is the 32-channel-chunk one that

@@ -906,12 +906,15 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &i
 static void convf(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &in, int H, int W, const DevBuf &out,
                   int Ho, int Wo, int relu, const float *res = nullptr)
 {
-    char kn[48];
+    char kn[64];
     const bool x3 = c->precision == SFD2_PREC_F16X3;
-    if (x3 && c->opt_x3_pp && !res && L.ks == 3 && L.stride == 1 && L.cout_pad % 128 == 0 && L.cin % 64 == 0) {
-        // The 3x3 stride-1 layers (half of this mode's time) on the throughput kernel: the input is split ONCE into hi / lo'
-        // planes (the generic kernel splits every staged piece, per tile and chunk), conv3x3_pp stages the planes by direct
-        // copies and runs its fp16 K loop three times (hi x hi, hi x lo', lo' x hi) into one accumulator; fp32 output.
+    const bool fast3 = x3 && c->opt_x3_pp && !res && L.ks == 3 && L.cin % 64 == 0;
+    // small outputs and stride 2 (convPa.0 / convPa.3 at 1600x1200; every 256-channel layer of a 640x480 image): conv3x3_rf, as in f16
+    const bool use_rf = fast3 && L.cout_pad == 256 && conv3x3_rf_serves(3, L.stride, L.cout_pad, L.cin, Ho, Wo);
+    if (use_rf || (fast3 && L.stride == 1 && L.cout_pad % 128 == 0)) {
+        // The 3x3 layers (half of this mode's time) on the throughput kernels: the input is split ONCE into hi / lo'
+        // planes (the generic kernel splits every staged piece, per tile and chunk), conv3x3_pp / conv3x3_rf stage the planes by direct
+        // copies and run their fp16 K loop three times (hi x hi, hi x lo', lo' x hi) into one accumulator; fp32 or planes out.
         ConvW &Lm = const_cast<ConvW &>(L);
         const size_t nfl = (size_t)L.ks * L.ks * L.cout_pad * L.cin, nin = (size_t)H * W * L.cin;
         if (!L.wx3p.p) {
@@ -933,9 +936,13 @@ static void convf(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &i
             oh = dst.as<half_t>(); ol = oh + nout;
             c->x3_pre_src = out.p; c->x3_pre_hi = oh; c->x3_pre_lo = ol;
         }
-        ProfScope ps(c, name, pre ? (oh ? "conv3x3_pp<x3, planes out>" : "conv3x3_pp<x3>") : (oh ? "x3_split_planes + conv3x3_pp<x3, planes out>" : "x3_split_planes + conv3x3_pp<x3>"),
-                     2.0 * (double)Ho * Wo * L.cout * L.cin * 9, (pre ? 4.0 : 12.0) * nin + 4.0 * nout);
+        snprintf(kn, sizeof(kn), "%sconv3x3_%s<x3%s>", pre ? "" : "x3_split_planes + ", use_rf ? "rf" : "pp", oh ? ", planes out" : "");
+        ProfScope ps(c, name, kn, 2.0 * (double)Ho * Wo * L.cout * L.cin * 9, (pre ? 4.0 : 12.0) * nin + 4.0 * nout);
         if (!pre) launch_x3_split_planes(c->stream, in.as<float>(), nin, const_cast<half_t *>(ph), const_cast<half_t *>(pl));
+        if (use_rf && launch_conv3x3_rf_x3(c->stream, ph, pl, H, W, L.cin, L.wx3p.as<half_t>(), L.scale.as<float>(), L.shift.as<float>(), L.cout_pad,
+                                           L.stride, relu, oh, ol, oh ? nullptr : out.as<float>(), Ho, Wo, c->zero_page.as<half_t>()))
+            return;
+        if (L.stride != 1) { fail("conv3x3_rf<x3>: no instantiation for this layer"); return; }
         launch_conv3x3_pp_x3(c->stream, ph, pl, H, W, L.cin, L.wx3p.as<half_t>(), L.scale.as<float>(), L.shift.as<float>(), L.cout_pad, relu,
                              oh, ol, oh ? nullptr : out.as<float>(), Ho, Wo, c->zero_page.as<half_t>());
         return;
@@ -1048,10 +1055,15 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
         convf(c, nm3[b], c->frb3[b], c->grt2[b], H4, W4, c->gro[b], H4, W4, 1, x->as<float>());
         x = &c->gro[b];
     }
+    // (throughput path: convPa.0 reads the backbone output's planes and leaves its own output as planes for convPa.3)
+    const void *bb_src = c->x3_pre_src;
+    const half_t *bb_hi = c->x3_pre_hi, *bb_lo = c->x3_pre_lo;
+    c->x3_planes_out_now = c->x3_fast_rb_now ? 1 : 0;
     convf(c, "convPa.0", c->fpa0, *x, H4, W4, c->gpa0_o, H8, W8, 1);
+    c->x3_planes_out_now = 0;
     convf(c, "convPa.3", c->fpa3, c->gpa0_o, H8, W8, c->gpa_o, H8, W8, 0);
     convf(c, "convPb", c->fpb, c->gpa_o, H8, W8, c->logits, H8, W8, 0);
-    // (convPa.0 above is the generic kernel: it did not consume the backbone output's planes)
+    c->x3_pre_src = bb_src; c->x3_pre_hi = bb_hi; c->x3_pre_lo = bb_lo;      // convDa.0 takes the same planes
     const bool da0_planes = c->skip_da3_now && c->x3_fast_rb_now;
     c->x3_planes_out_now = da0_planes ? 2 : 0;
     convf(c, "convDa.0", c->fda0, *x, H4, W4, c->gda0_o, H4, W4, 1);

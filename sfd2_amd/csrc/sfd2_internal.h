@@ -164,6 +164,9 @@ void launch_fused_stem(hipStream_t st, const float *img, int H, int W, int norma
 // conv3_kernels.hip: the 3x3 stride-1 layers with >= 256 output channels
 bool conv3x3_pp_serves(int ks, int stride, int CoutP, int Cin);
 // conv3rf_kernels.hip: the same layers (and their stride-2 siblings) when the output is small
+bool launch_conv3x3_rf_x3(hipStream_t st, const half_t *in_hi, const half_t *in_lo, int H, int W, int Cin, const half_t *wpl,
+                          const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out_hi, half_t *out_lo,
+                          float *out_f32, int Ho, int Wo, const half_t *zero_page);
 bool conv3x3_rf_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo);
 void launch_conv_igemm(hipStream_t st, const half_t *in, int H, int W, int Cin,
                        const half_t *wpk, const float *scale, const float *shift, int Cout_pad,
