@@ -529,8 +529,14 @@ bool launch_conv3x3_rf_x3(hipStream_t st, const half_t *in_hi, const half_t *in_
                           const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out_hi, half_t *out_lo,
                           float *out_f32, int Ho, int Wo, const half_t *zero_page)
 {
-    if (CoutP != RF_BN || Cin % 64 != 0 || (stride != 1 && stride != 2)) return false;
+    if (Cin % 64 != 0 || (stride != 1 && stride != 2)) return false;
     if ((long long)(Ho * stride + 2) * (Wo * stride + 2) * Cin * (long long)sizeof(half_t) >= (1ll << 31)) return false;
+    if (CoutP == 128 && stride == 2) {      // conv2b
+        if (out_f32) launch_rf_t<2, 128, 0, false, 12>(st, in_hi, H, W, Cin, wpl, scale, shift, CoutP, relu, reinterpret_cast<half_t *>(out_f32), Ho, Wo, zero_page, in_lo, nullptr, 0);
+        else launch_rf_t<2, 128, 0, false, 4>(st, in_hi, H, W, Cin, wpl, scale, shift, CoutP, relu, out_hi, Ho, Wo, zero_page, in_lo, out_lo, 0);
+        return true;
+    }
+    if (CoutP != RF_BN) return false;
     if (out_f32) {
         half_t *o = reinterpret_cast<half_t *>(out_f32);
         if (stride == 2) launch_rf_t<2, RF_BN, 0, false, 12>(st, in_hi, H, W, Cin, wpl, scale, shift, CoutP, relu, o, Ho, Wo, zero_page, in_lo, nullptr, 0);

@@ -93,6 +93,7 @@ struct sfd2_ctx {
     int alias_now = 0;                 // set per call
     int x3_fast_rb_now = 0;            // set per call: f16x3 ResBlocks on the streaming three-pass 1x1 kernel (not on the parity entry point:
                                        // the grouped conv's output then exists as planes only)
+    DevBuf x3_chain2;                  // second buffer of the plane chain (a layer never writes the planes it reads)
     DevBuf x3_rb_planes[3];            // a ResBlock's input, conv1's and the grouped conv's outputs as hi / lo' planes
     const void *x3_pre_src = nullptr;  // set by a producer that wrote its output as planes too: the fp32 tensor they belong to ...
     const half_t *x3_pre_hi = nullptr, *x3_pre_lo = nullptr;   // ... and the planes (consumed by the next convf on that tensor)
@@ -247,7 +248,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     graphs_release(c);
-    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->w1b_stem_x3, &c->da3_sparse, &c->x3_planes, &c->x3_da0_planes, &c->db_sparse, &c->x3_rb_planes[0], &c->x3_rb_planes[1], &c->x3_rb_planes[2], &c->x3_chain, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
+    DevBuf *bufs[] = {&c->sta_w, &c->sta_b, &c->zero_page, &c->w1b_stem_x3, &c->da3_sparse, &c->x3_planes, &c->x3_da0_planes, &c->db_sparse, &c->x3_rb_planes[0], &c->x3_rb_planes[1], &c->x3_rb_planes[2], &c->x3_chain2, &c->x3_chain, &c->w1b_fused, &c->img, &c->a1a, &c->a1b, &c->a2a, &c->a2b, &c->a3a, &c->a3b,
                       &c->rt1[0], &c->rt1[1], &c->rt1[2], &c->rt2[0], &c->rt2[1], &c->rt2[2], &c->ro[0], &c->ro[1],
                       &c->ro[2], &c->pa0_o, &c->pa_o, &c->da0_o, &c->da_o, &c->logits, &c->draw, &c->sta, &c->score,
                       &c->heat, &c->stab, &c->desc_nchw, &c->tmp_f32, &c->cand, &c->bnd, &c->sel, &c->sorted, &c->counters,
@@ -903,15 +904,23 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &i
                        out.as<half_t>(), out_comp ? corr_of(out, (size_t)Ho * Wo, L.cout_pad) : nullptr, Ho, Wo, L.sbyte);
 }
 
+// which throughput kernel takes a layer of SFD2_PREC_F16X3 from hi / lo' planes: 0 none (generic, fp32 in / out), 1 conv3x3_pp, 2 conv3x3_rf
+// (small outputs and stride 2: conv2b, convPa.0 / convPa.3 at 1600x1200, every 256-channel layer of a 640x480 image -- as in f16)
+static int x3_fast_kind(const sfd2_ctx *c, const ConvW &L, bool has_res, int Ho, int Wo)
+{
+    if (c->precision != SFD2_PREC_F16X3 || !c->opt_x3_pp || has_res || L.ks != 3 || L.cin % 64 != 0) return 0;
+    if ((L.cout_pad == 256 || (L.cout_pad == 128 && L.stride == 2)) && conv3x3_rf_serves(3, L.stride, L.cout_pad, L.cin, Ho, Wo)) return 2;
+    return (L.stride == 1 && L.cout_pad % 128 == 0) ? 1 : 0;
+}
+
 static void convf(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &in, int H, int W, const DevBuf &out,
                   int Ho, int Wo, int relu, const float *res = nullptr)
 {
     char kn[64];
     const bool x3 = c->precision == SFD2_PREC_F16X3;
-    const bool fast3 = x3 && c->opt_x3_pp && !res && L.ks == 3 && L.cin % 64 == 0;
-    // small outputs and stride 2 (convPa.0 / convPa.3 at 1600x1200; every 256-channel layer of a 640x480 image): conv3x3_rf, as in f16
-    const bool use_rf = fast3 && L.cout_pad == 256 && conv3x3_rf_serves(3, L.stride, L.cout_pad, L.cin, Ho, Wo);
-    if (use_rf || (fast3 && L.stride == 1 && L.cout_pad % 128 == 0)) {
+    const int kind = x3_fast_kind(c, L, res != nullptr, Ho, Wo);
+    const bool use_rf = kind == 2;
+    if (kind != 0) {
         // The 3x3 layers (half of this mode's time) on the throughput kernels: the input is split ONCE into hi / lo'
         // planes (the generic kernel splits every staged piece, per tile and chunk), conv3x3_pp / conv3x3_rf stage the planes by direct
         // copies and run their fp16 K loop three times (hi x hi, hi x lo', lo' x hi) into one accumulator; fp32 or planes out.
@@ -930,8 +939,9 @@ static void convf(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &i
         }
         const size_t nout = (size_t)Ho * Wo * L.cout_pad;
         half_t *oh = nullptr, *ol = nullptr;
-        if (c->x3_planes_out_now) {      // planes out (the only reader is the next 3x3 layer / the sparse descriptor head)
-            DevBuf &dst = c->x3_planes_out_now == 2 ? c->x3_da0_planes : c->x3_chain;
+        if (c->x3_planes_out_now) {      // planes out (the only reader is the next 3x3 layer / the ResBlocks / the sparse descriptor head)
+            DevBuf &dst = c->x3_planes_out_now == 2 ? c->x3_da0_planes : c->x3_planes_out_now == 3 ? c->x3_rb_planes[0]
+                          : (ph == c->x3_chain.as<half_t>() ? c->x3_chain2 : c->x3_chain);
             if (dst.ensure(nout * 2 * sizeof(half_t)) != hipSuccess) { fail("out of device memory (f16x3 activation planes)"); return; }
             oh = dst.as<half_t>(); ol = oh + nout;
             c->x3_pre_src = out.p; c->x3_pre_hi = oh; c->x3_pre_lo = ol;
@@ -987,19 +997,26 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
     }
     convf(c, "conv1b", c->f1b, c->g1a, H, W, c->g1b, H2, W2, 1);
     }
+    // (throughput path: a layer whose only reader takes planes writes planes and no fp32 tensor: conv2a -> conv2b -> conv3a -> conv3b ->
+    // ResBlocks, convDa.0 -> the sparse descriptor head)
+    const bool fast_rb = c->x3_fast_rb_now && c->rb1[0].wfh.p && c->rb1[0].wfl.p && c->rb2[0].w.p && c->rb2[0].wlk.p;
+    const bool k2b = c->x3_fast_rb_now && x3_fast_kind(c, c->f2b, false, H4, W4) != 0, k3a = c->x3_fast_rb_now && x3_fast_kind(c, c->f3a, false, H4, W4) != 0;
+    const bool k3b = c->x3_fast_rb_now && x3_fast_kind(c, c->f3b, false, H4, W4) != 0;
+    c->x3_planes_out_now = k2b ? 1 : 0;
     convf(c, "conv2a", c->f2a, c->g1b, H2, W2, c->g2a, H2, W2, 1);
+    c->x3_planes_out_now = k3a ? 1 : 0;
     convf(c, "conv2b", c->f2b, c->g2a, H2, W2, c->g2b, H4, W4, 1);
-    // (throughput path: conv3a's only reader is conv3b, convDa.0's the sparse descriptor head -- they write planes, no fp32)
-    c->x3_planes_out_now = c->x3_fast_rb_now ? 1 : 0;
+    c->x3_planes_out_now = k3b ? 1 : 0;
     convf(c, "conv3a", c->f3a, c->g2b, H4, W4, c->g3a, H4, W4, 1);
-    c->x3_planes_out_now = 0;
+    c->x3_planes_out_now = (fast_rb && k3b) ? 3 : 0;
     convf(c, "conv3b", c->f3b, c->g3a, H4, W4, c->g3b, H4, W4, 1);
+    c->x3_planes_out_now = 0;
+    const bool rb_in_planes = c->x3_pre_src == c->g3b.p;      // conv3b left the ResBlocks' input planes in x3_rb_planes[0]
     c->x3_pre_src = nullptr;
     const DevBuf *x = &c->g3b;
     static const char *nm1[3] = {"conv4.0.conv1", "conv4.1.conv1", "conv4.2.conv1"};
     static const char *nm2[3] = {"conv4.0.conv2", "conv4.1.conv2", "conv4.2.conv2"};
     static const char *nm3[3] = {"conv4.0.conv3", "conv4.1.conv3", "conv4.2.conv3"};
-    const bool fast_rb = c->x3_fast_rb_now && c->rb1[0].wfh.p && c->rb1[0].wfl.p && c->rb2[0].w.p && c->rb2[0].wlk.p;
     if (fast_rb) {
         // ResBlocks of SFD2_PREC_F16X3 on the throughput path: every tensor of a block lives as hi / lo' planes (the input is split
         // once in front of the first block).  conv1 and conv3 on the streaming three-pass 1x1 kernel (filters = the fp16 set's
@@ -1010,7 +1027,7 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
         for (int k = 0; k < 3; ++k) HIPCHECK(c->x3_rb_planes[k].ensure(nin * 2 * sizeof(half_t)));
         half_t *xh = c->x3_rb_planes[0].as<half_t>(), *xl = xh + nin, *th = c->x3_rb_planes[1].as<half_t>(), *tl = th + nin;
         half_t *uh = c->x3_rb_planes[2].as<half_t>(), *ul = uh + nin;
-        {
+        if (!rb_in_planes) {
             ProfScope ps(c, "conv3b planes", "x3_split_planes", 0.0, 12.0 * nin);
             launch_x3_split_planes(st, x->as<float>(), nin, xh, xl);
         }
