@@ -455,6 +455,12 @@ def main():
                                 "the fp8 correction MFMAs (one 32x32x64 per two 32x32x16), i.e. 2x the matrix time of the plain fp16 layer at "
                                 "nominal rates: 'frac_of_issued_peak' = frac * 2")
                 roof["frac_of_issued_peak"] = round(2 * achieved / PEAK_TFLOPS_F16, 4)
+            # what this part sustains on fp16 MFMAs alone (tools/probe/mfma_valu.hip, profiles/r03k_mfma_valu_probe.txt: two waves per
+            # SIMD, four or eight accumulator chains each, random operands; the shader clock reads 1.7-1.8 GHz under that load) --
+            # context for `frac`, which stays against the nominal peak
+            roof["sustained_mfma_probe"] = {"value": 1110.0, "unit": "TFLOP/s", "source": "profiles/r03k_mfma_valu_probe.txt (modes 6, 9)",
+                                            "frac_of_probe": round((2 if "comp" in dom_name else 1) * achieved / 1110.0, 4),
+                                            "note": "issued-FLOP rate of this kernel / MFMA-only probe rate on the same part (not re-measured in this run)"}
             if single is not None:
                 roof["measured_in"] = ("single-stream timed leg of this run (same K steps and bracketing, one stream per GPU, eager "
                                        "launches: see 'single_stream').  The headline region replays one hipGraph per image on "
