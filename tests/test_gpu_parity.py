@@ -379,7 +379,7 @@ def test_matchers_vs_reference_golden(golden_dir, tag):
             np.testing.assert_allclose(p["matching_scores0"], gs, atol=tol_s)
 
 
-@pytest.mark.parametrize("n0,n1", [(4096, 4096), (1000, 37), (33, 1025), (1, 3), (5, 1), (128, 128)])
+@pytest.mark.parametrize("n0,n1", [(4096, 4096), (1000, 37), (33, 1025), (1, 3), (5, 1), (128, 128), (300, 9001), (700, 33)])
 def test_matcher_vs_oracle_sizes(n0, n1):
     d0 = synth.make_descriptors(n0, seed=n0 + 7)
     d1 = synth.make_descriptors(n1, seed=n1 + 8)
