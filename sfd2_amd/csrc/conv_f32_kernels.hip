@@ -565,7 +565,7 @@ void launch_gconv_x3_pack(hipStream_t st, const float *w, void *out)
 
 __global__ __launch_bounds__(NT)
 void gconv_x3_kernel(const float *__restrict__ in, int H, int W, const half_t *__restrict__ wpk,
-                     const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out, int tiles_x, half_t *__restrict__ out_hi, half_t *__restrict__ out_lo /* non-null: the output as hi / lo' planes INSTEAD of fp32 */)
+                     const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out, int tiles_x)
 {
     constexpr int NPIX = GX_PH * GX_PW;
     __shared__ __attribute__((aligned(16))) half_t Xh[NPIX * GX_P];
@@ -642,14 +642,7 @@ void gconv_x3_kernel(const float *__restrict__ in, int H, int W, const half_t *_
                 const float4 v = make_float4(fmaxf((accm[t][0] + accl[t][0] * inv) * sc.x + sh.x, 0.0f), fmaxf((accm[t][1] + accl[t][1] * inv) * sc.y + sh.y, 0.0f),
                                              fmaxf((accm[t][2] + accl[t][2] * inv) * sc.z + sh.z, 0.0f), fmaxf((accm[t][3] + accl[t][3] * inv) * sc.w + sh.w, 0.0f));
                 const size_t o = ((size_t)oy * W + ox) * 256 + c0;
-                if (out_hi) {
-                    h4_t hi, lo;
-                    x3_split(v, hi, lo);
-                    *reinterpret_cast<h4_t *>(out_hi + o) = hi;
-                    *reinterpret_cast<h4_t *>(out_lo + o) = lo;
-                } else {
-                    *reinterpret_cast<float4 *>(out + o) = v;
-                }
+                *reinterpret_cast<float4 *>(out + o) = v;
             }
         }
     }
@@ -657,11 +650,11 @@ void gconv_x3_kernel(const float *__restrict__ in, int H, int W, const half_t *_
 }
 
 void launch_gconv_x3(hipStream_t st, const float *in, int H, int W, const void *wpk, const float *scale, const float *shift,
-                     float *out, half_t *out_hi, half_t *out_lo)
+                     float *out)
 {
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     hipLaunchKernelGGL(gconv_x3_kernel, dim3(tiles_x * tiles_y), dim3(NT), 0, st, in, H, W, reinterpret_cast<const half_t *>(wpk),
-                       scale, shift, out, tiles_x, out_hi, out_lo);
+                       scale, shift, out, tiles_x);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -77,7 +77,6 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lrow = lane & 31, lhi = lane >> 5;            // phase C
     const int g = lane >> 4, lcol = lane & 15;              // phase G
     const int pw = wave & 3, rh = wave >> 2;
 

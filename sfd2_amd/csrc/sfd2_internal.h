@@ -244,7 +244,7 @@ void launch_conv3x3_pp_x3(hipStream_t st, const half_t *in, const half_t *in_lo,
                           const float *scale, const float *shift, int CoutP, int relu, half_t *out_hi, half_t *out_lo, float *out_f32,
                           int Ho, int Wo, const half_t *zero_page);
 void launch_gconv_x3_pack(hipStream_t st, const float *w /*[256][8][3][3]*/, void *out /*16 * 5 * 64 * 16 halves*/);
-void launch_gconv_x3(hipStream_t st, const float *in, int H, int W, const void *wpk, const float *scale, const float *shift, float *out, half_t *out_hi = nullptr, half_t *out_lo = nullptr);
+void launch_gconv_x3(hipStream_t st, const float *in, int H, int W, const void *wpk, const float *scale, const float *shift, float *out);
 void launch_conv_igemm_x3(hipStream_t st, const float *in, int H, int W, int Cin, const float *wpk,
                            const float *scale, const float *shift, int Cout_pad, int ks, int stride, int relu,
                            const float *residual, float *out, int Ho, int Wo);
