@@ -14,7 +14,8 @@ from sfd2_amd import _lib, synth
 from sfd2_amd.model import ResSegNetV2
 
 H, W, K, N = 1200, 1600, 4096, 40
-m = ResSegNetV2(outdim=128, require_stability=True, precision="f16").eval()
+PREC = sys.argv[1] if len(sys.argv) > 1 else "f16c"      # python tools/pcie_inclusive_bench.py [f16c | f16 | f16x3]
+m = ResSegNetV2(outdim=128, require_stability=True, precision=PREC).eval()
 m.load_state_dict(synth.make_state_dict(0))
 m.cuda(0)
 ctx = m.context
