@@ -17,16 +17,17 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // two.  Orientation here: QUERIES are the MFMA rows (A operand, a wave keeps its 64 queries in registers), CANDIDATES
 // the columns (B operand, streamed through LDS).  In the 32x32 C layout a lane owns 16 query rows of ONE candidate
 // column, so per 32 x 32 sub-tile:
-//   forward (best candidate per query): 16 element-wise running maxima per lane, kept across the whole sweep, with the
+//   forward (best candidate per query): 16 element-wise running maxima per lane, kept across the whole sweep -- of the raw
+//       accumulators in the mutual modes (the index comes from the reverse direction, see FWD_IDS below), else with the
 //       candidate TILE id packed into the 7 low mantissa bits (127 - tile: the lower tile wins among equal values).  The
 //       32-lane reduction happens once per sweep, through an LDS transposition, not per tile.
-//   reverse (best query per candidate): a 16 -> 1 in-lane maximum with the register id packed into 4 bits, the two query
+//   reverse (best query per candidate): a 16 -> 1 in-lane maximum with the row id packed into 5 bits, the two query
 //       tiles and the two half-waves merged with two more id bits, and the block's four waves (two more) folded in a
 //       per-block LDS table with ds_max_f32; the table leaves the CU once per sweep as a per-strip partial
 //       [n0 / 256][n1] that match_mutual_reduce folds (13 MB per 50 x 4096^2 instead of 52 MB of per-wave partials).
-// ~8 VALU instructions per MFMA instead of a second GEMM.  Packing perturbs a similarity by <= 2^-15 relative (8 id bits,
-// reverse; 2^-16 forward), below the fp16-operand error (1.5e-4); ties between values equal after truncation go to the
-// lower index.
+// 5.6 VALU instructions per MFMA in the mutual modes (7.5 with forward ids) instead of a second GEMM.  Packing perturbs a
+// similarity by <= 2^-15 relative (8 id bits, reverse; 2^-16 forward), below the fp16-operand error (1.5e-4); values equal
+// after truncation -- exact ties included -- go to the lower index, as torch's argmax.
 #define MQ_NEG (-0x1p100f)    // "no value": finite with an all-zero mantissa, so or-ing id bits can only make it MORE negative
 #define MQ_TILE_BITS 7
 #define MQ_MAX_CHUNK (32 << MQ_TILE_BITS)   // candidates per split: the tile id must fit MQ_TILE_BITS
