@@ -147,6 +147,18 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         }                                                                                              \
     }
     int tile = blockIdx.x;
+#ifdef SFD2_PP_CU_STAGGER
+    // experiment builds: some CUs start late so that the tiles' epilogue write bursts of the short-K layer (conv2a) are not in phase
+    // chip-wide.  SFD2_PP_CU_STAGGER = delay in 10 ns units, SFD2_PP_CU_STAGGER_WHO: 0 = the blocks with one tile less, 1 = every other
+    // group of eight blocks.  Measured (tools/ab_libs.py, ms per extract, three rounds): as is 1.668 / 1.683 / 1.680; 19 us on the
+    // blocks with one tile less 1.687 / 1.685 / 1.685; 19 us on every other group 1.672 / 1.679 / 1.688; 10 us on every other group
+    // 1.719 / 1.725 / 1.718 -- phase diversity between CUs buys nothing here, not enabled
+    if (Cin == 64) {
+        const int rem_ = n_tiles % (int)gridDim.x;
+        const bool late_ = SFD2_PP_CU_STAGGER_WHO ? ((blockIdx.x >> 3) & 1) : (rem_ != 0 && (int)blockIdx.x >= rem_);
+        if (late_) { const unsigned long long t0_ = wall_clock64(); while (wall_clock64() - t0_ < SFD2_PP_CU_STAGGER) __builtin_amdgcn_s_sleep(32); }
+    }
+#endif
     PP_WALL(0)
     PP_SETUP(tile)
     const int NCH = Cin / PP_CC;                           // chunks per plane
