@@ -94,6 +94,8 @@ __device__ __forceinline__ void rf_copy_piece(const half_t *base, int nbytes, un
 // pixel fragment instead of two fp16 MFMAs; bit 1 = the output's corr plane is written.  In these instantiations the filter
 // ring and the pixel-fragment ring hold 8-dword tuples (both K slices of a unit adjacent: the fp8 MFMA's operand; the fp16
 // MFMAs take the two halves), the pixel ring is two units deep and is prefetched one unit ahead.
+// (A second accumulator set for conv2b's two-fragment waves -- four independent MFMA chains per wave instead of two, 254
+// registers -- measured 141.2 against 141.0 us: the layer is bound by its filter stream, not by the chains; not kept.)
 template <int S, int BN = RF_BN, int ABL = 0, bool RES = false, int COMP = 0>
 __global__ __launch_bounds__(512, 2)
 void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
