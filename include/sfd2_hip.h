@@ -134,6 +134,9 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *   "x3_pp"     1 (default) / 0: SFD2_PREC_F16X3 on its throughput kernels -- 3x3 stride-1 layers on conv3x3_pp over pre-split hi / lo'
  *               planes, and on sfd2_extract (not sfd2_det) the fused three-pass stem, the streaming three-pass 1x1 kernel in the
  *               ResBlocks and the sparse descriptor head; 0 = the generic three-pass kernel everywhere (same tolerances, 1.6x slower).
+ *   "fp6_filters" 0 (default) / 1: SFD2_PREC_F16C, conv2a / conv3a / conv3b: the correction filters as e2m3 (fp6) with one power-of-two
+ *               scale per output channel instead of e4m3 (fp8 x fp6 scaled MFMA).  Same tolerance (descriptors <= 5.2e-4 measured),
+ *               no measurable speed difference on MI355X: an experiment switch.
  *   "cu_limit"  0 (default) / n: persistent kernels launch at most n blocks (experiment: with two streams, two kernels side by side
  *               on half the chip each measure the same throughput as taking turns on all of it).  Process-wide.
  *   "sparse_da3" 1 (default) / 0: on the extract path (with "sparse_desc"), convDa.3 runs on the 4 x K bilinear corner pixels of the

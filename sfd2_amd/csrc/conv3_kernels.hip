@@ -71,7 +71,9 @@ __device__ __forceinline__ h4_t cvt4c(float a, float b, float c, float d)
 // COMP (SFD2_PREC_F16C, sfd2_internal.h): bit 0 = the input has a corr plane (in_c) and wpk holds 2 * Cin / 32 chunks --
 // the chunk loop simply runs on through the corr plane's chunks, whose units go to ONE v_mfma_scale_f32_32x32x64_f8f6f4 per
 // (channel tile, pixel tile) instead of two fp16 MFMAs (same LDS records, same fragment reads); bit 1 = the corr plane of
-// the output is written (out_c).
+// the output is written (out_c); bit 4 = the corr FILTER rows are fp6 (e2m3) strings with one E8M0 scale byte per output channel
+// (behind the shifts: shift[CoutP + channel] holds the byte replicated into an int; sfd2_api.hip pack_igemm): the same fragment reads (the strings sit in the 16-byte slots the lane halves read), the MFMA
+// runs fp8 x fp6 -- 32 ns per instruction and SIMD instead of 37-41 (profiles/r03k_mfma_f8f6f4_probe.txt).
 // Measured with the trace below (conv2a compensated, 64 -> 128 channels: K loop 45k cycles, epilogue 15-22k, wait at the next
 // tile's top 2-9k): the epilogue is long because every CU writes its 256 KB tile at the same time (64 MB per round, the K loops
 // being equally long everywhere), not because of the wait the compiler puts in front of the epilogue's first LDS read (it orders
@@ -102,6 +104,8 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                        const half_t *__restrict__ zero_page,
                        const half_t *__restrict__ in_c = nullptr, half_t *__restrict__ out_c = nullptr, int sa = 0)
 {
+    constexpr bool F6 = (COMP & 16) != 0;
+    constexpr int SSN = F6 ? 3 : 2;                        // arrays per tile parity in SSb: scale, shift (, the fp6 filters' scale bytes)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Xs = smem;                              // [2][PP_XBYTES]
     unsigned char *Fs = smem + 2 * PP_XBYTES;              // [2][PP_FBYTES]
@@ -189,7 +193,10 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
     for (int i = 0; i < PP_XPW; ++i) PP_ISSUE_X1(0, 0, i);
     PP_ISSUE_F(0, 0)
-    for (int t = tid; t < PP_BN; t += 512) { SSb[t] = scale[n0 + t]; SSb[PP_BN + t] = shift[n0 + t]; }
+    for (int t = tid; t < PP_BN; t += 512) {
+        SSb[t] = scale[n0 + t]; SSb[PP_BN + t] = shift[n0 + t];
+        if (F6) SSb[2 * PP_BN + t] = shift[CoutP + n0 + t];      // (the scale bytes follow the shifts: launcher)
+    }
 
     const int lrow = lane & 31, lhi = lane >> 5;
     int a_off[2], a_sw[2];
@@ -202,7 +209,8 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     const int qb = wrow * PP_PW + lrow;
 
     for (int it = 0;; ++it) {
-    float *SS = SSb + (it & 1) * 2 * PP_BN;
+    float *SS = SSb + (it & 1) * SSN * PP_BN;
+    int sa6v[2] = {0, 0};                                  // F6: this lane's filter rows' scale bytes (published by the barriers of the K loop)
     f32x16_t acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -301,7 +309,8 @@ _Pragma("unroll") \
                 for (int ct = 0; ct < 2; ++ct) \
 _Pragma("unroll") \
                     for (int pr = 0; pr < 4; ++pr) \
-                        acc[ct][pr] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fac[ct], frc[pr + u3], acc[ct][pr], 0, 0, 0, sa, 0, 0x7f7f7f7f); \
+                        acc[ct][pr] = F6 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fac[ct], frc[pr + u3], acc[ct][pr], 2, 0, 0, sa6v[ct], 0, 0x7f7f7f7f) \
+                                         : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fac[ct], frc[pr + u3], acc[ct][pr], 0, 0, 0, sa, 0, 0x7f7f7f7f); \
                 /* the scaled MFMA is a pure node to instruction selection, which otherwise sinks all 72 of a chunk below its last \
                    barrier (every fragment of nine units live at once); an empty asm on the accumulators keeps each unit's in its section */ \
 _Pragma("unroll") \
@@ -327,8 +336,13 @@ _Pragma("unroll") \
         } \
     /* end of PP_CHUNK_BODY */
     for (int c = 0; c < NCH; ++c) { PP_CHUNK_BODY(0) }
-    if (COMP & 1)
+    if (COMP & 1) {
+        if (F6) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) sa6v[ct] = __float_as_int(SS[2 * PP_BN + wch + ct * 32 + lrow]);
+        }
         for (int c = NCH; c < NCT; ++c) { PP_CHUNK_BODY(1) }
+    }
     if (COMP & 4) {
         // X3 (SFD2_PREC_F16X3 on pre-split planes): y = sum hi * w_hi + 2^-11 (sum hi * w_lo' + sum lo' * w_hi), the low parts
         // being stored scaled by 2^11 -- ONE accumulator: the first pass's sums are scaled up (exactly) before the cross terms
@@ -352,8 +366,11 @@ _Pragma("unroll") \
 #pragma unroll
         for (int i = 0; i < PP_XPW; ++i) PP_ISSUE_X1(0, 0, i);
         PP_ISSUE_F(0, 0)
-        float *SSn = SSb + ((it + 1) & 1) * 2 * PP_BN;
-        for (int t = tid; t < PP_BN; t += 512) { SSn[t] = scale[n0 + t]; SSn[PP_BN + t] = shift[n0 + t]; }
+        float *SSn = SSb + ((it + 1) & 1) * SSN * PP_BN;
+        for (int t = tid; t < PP_BN; t += 512) {
+            SSn[t] = scale[n0 + t]; SSn[PP_BN + t] = shift[n0 + t];
+            if (F6) SSn[2 * PP_BN + t] = shift[CoutP + n0 + t];
+        }
     }
 
     const float lo = relu ? 0.0f : -__builtin_huge_valf();   // ReLU without a branch (this file is compiled with -fno-honor-nans:
@@ -434,7 +451,7 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
                         const float *scale, const float *shift, int CoutP, int relu, half_t *out,
                         int Ho, int Wo, const half_t *zero_page, const half_t *in_c = nullptr, half_t *out_c = nullptr, int sa = 0)
 {
-    constexpr size_t lds = (size_t)2 * PP_XBYTES + (size_t)2 * PP_FBYTES + 4 * PP_BN * sizeof(float);
+    constexpr size_t lds = (size_t)2 * PP_XBYTES + (size_t)2 * PP_FBYTES + ((COMP & 16) ? 6 : 4) * PP_BN * sizeof(float);
     static bool attr_done = false;
     auto kern = conv3x3_pp_kernel<STAGGER, PRIO, ABL, SFD2_PP_KXM, COMP>;
     if (!attr_done) {
@@ -476,10 +493,12 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
 // compensated instantiations (SFD2_PREC_F16C): wpk = the layer's wc array, sbyte its scale byte
 void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int relu, half_t *out, half_t *out_c,
-                         int Ho, int Wo, const half_t *zero_page, int sbyte)
+                         int Ho, int Wo, const half_t *zero_page, int sbyte, const float *shift_sa6)
 {
     const int sa = (sbyte & 255) * 0x01010101;
-    if (in_c && out_c) launch_pp_t<1, 1, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
+    // shift_sa6 != null: wpk's corr rows are fp6 strings and shift_sa6 = [shift[CoutP] | the rows' scale bytes as ints [CoutP]]
+    if (in_c && out_c && shift_sa6) launch_pp_t<1, 1, 0, 19>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
+    else if (in_c && out_c) launch_pp_t<1, 1, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
     else if (in_c) launch_pp_t<1, 1, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
     else launch_pp_t<1, 1, 0, 2>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
 }

@@ -66,6 +66,8 @@ struct ConvW {                 // one folded + packed layer
     DevBuf wc;                 // SFD2_PREC_F16C: [2 * cin / 32][taps][cout_pad][32] units -- the fp16 filters in 32-wide chunks, then the
                                // corr units (fp8 of w * 2^b0, fp8 of (w - fp16(w)) * 2^(b0 + 11)); conv1a / grouped conv: hi then lo fragments
     int sbyte = 127;           // E8M0 scale byte of the layer's corr MFMAs: 127 - 9 - b0
+    DevBuf wc6;                // conv3x3_pp layers: wc with the corr filter rows as fp6 (e2m3) strings, and ...
+    DevBuf sa6;                // ... [shift[cout_pad] | per-output-channel E8M0 scale bytes, replicated into the four bytes of an int, [cout_pad]]
     size_t w_floats = 0;       // floats in w (fp32 layers)
 };
 
@@ -106,6 +108,10 @@ struct sfd2_ctx {
     int skip_da3_now = 0;              // set per call: run_network leaves convDa.3 to the sparse descriptor path (sparse_da3_kernel)
     const half_t *da0_cur = nullptr;   // convDa.0 output of the last fp16 network pass
     DevBuf da3_sparse;                 // [sel_cap][4][256] fp16: convDa.3 on the sampled corner pixels
+    int opt_fp6_filters = 0;           // sfd2_set_option "fp6_filters": conv3x3_pp<comp> takes its corr filters as block-scaled fp6 (fp8 x fp6 MFMA).
+                                       // Measured: conv3b 212.0 -> 212.1 us, extract 1.5188 -> 1.5165 ms, descriptors <=5.2e-4 (<=4.9e-4 without): the
+                                       // mixed-format MFMA's shorter issue time in the probe does not show in the layer; off by default, kept as the
+                                       // packing / layout groundwork for fp6 on both sides
     int opt_x3_pp = 1;                 // sfd2_set_option "x3_pp": SFD2_PREC_F16X3 runs its 3x3 stride-1 layers on conv3x3_pp (pre-split planes, three passes)
     DevBuf x3_planes;                  // the input of such a layer as hi / lo' planes
     DevBuf x3_da0_planes;              // convDa.0's output as planes (sparse descriptor head of f16x3)
@@ -264,7 +270,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
                    &c->da0, &c->da3, &c->pb, &c->db, &c->f1a, &c->f1b, &c->f2a, &c->f2b, &c->f3a, &c->f3b, &c->frb1[0],
                    &c->frb1[1], &c->frb1[2], &c->frb2[0], &c->frb2[1], &c->frb2[2], &c->frb3[0], &c->frb3[1], &c->frb3[2],
                    &c->fpa0, &c->fpa3, &c->fda0, &c->fda3, &c->fpb, &c->fdb};
-    for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); w->wrm.release(); w->wgc.release(); w->wx3.release(); w->wx3p.release(); }
+    for (ConvW *w : ws) { w->w.release(); w->scale.release(); w->shift.release(); w->wrm.release(); w->wgc.release(); w->wx3.release(); w->wx3p.release(); w->wc6.release(); w->sa6.release(); }
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
     for (int i = 0; i < 2; ++i) {
@@ -351,6 +357,27 @@ static unsigned char f32_to_e4m3(float f)
     return sign | (unsigned char)((be << 3) | (mant - 8));
 }
 
+// e2m3 (fp6: sign, 2 exponent bits with bias 1, 3 mantissa bits; subnormal step 0.125, largest value 7.5), round to nearest even,
+// saturating.  The operand format of v_mfma_scale_f32_32x32x64_f8f6f4 with cbsz / blgp = 2 (codes checked on the part:
+// tools/probe/mfma_fp6_layout.hip).
+static unsigned char f32_to_e2m3(float v)
+{
+    const unsigned char sign = std::signbit(v) ? 0x20 : 0;
+    const float a = std::fabs(v);
+    if (!(a == a) || a >= 7.75f) return sign | 31;
+    if (a < 1.0f) {
+        const int m = (int)std::nearbyint(a * 8.0f);           // 0 .. 8 (8 = the smallest normal)
+        return sign | (unsigned char)m;
+    }
+    int e;
+    (void)std::frexp(a, &e);
+    int ex = e - 1;                                            // a in [2^ex, 2^(ex+1)), ex = 0 .. 2
+    int mant = (int)std::nearbyint(std::ldexp(a, 3 - ex)) - 8; // 0 .. 8
+    if (mant == 8) { mant = 0; ++ex; }
+    if (ex > 2) return sign | 31;
+    return sign | (unsigned char)(((ex + 1) << 3) | mant);
+}
+
 // scale exponent b0 of a layer's corr filters: the largest power of two with max|w| * 2^b0 <= 448
 static int corr_b0(const float *w, size_t n)
 {
@@ -412,6 +439,50 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
                         pc[plane + o] = (unsigned short)(w8 | (l8 << 8));   // pairs with the pixel unit (residual byte, value byte)
                     }
         if (upload(L.wc, pc.data(), pc.size() * 2, c->stream)) return -1;
+        if (ks == 3 && stride == 1 && cout_pad % 128 == 0 && cin % 64 == 0) {
+            // conv3x3_pp<comp>: the corr filter rows as fp6.  A row (64 B = the filters of one pixel record's 64 unit bytes j: j even ->
+            // w of channel j / 2, pairing with the residual byte; j odd -> (w - fp16(w)) * 2^11, pairing with the value byte) becomes
+            // two 24-byte strings of 32 six-bit codes, string h = bytes j = 32 h .. 32 h + 31, stored where lane half h of the kernel's
+            // fragment read finds them: its first 16 bytes in the row's 16-byte slot h, the other 8 in slot 2 + h (the rest is padding).
+            // One power-of-two scale per OUTPUT CHANNEL (all taps, all input channels): 2^ec >= max|w| / 7.5; its E8M0 byte goes to
+            // the MFMA's A-side scale operand lane by lane.  fp8 x fp6 issues in 32 ns where fp8 x fp8 takes 37-41
+            // (profiles/r03k_mfma_f8f6f4_probe.txt); descriptors on the CPU twin 4.1e-4 against 4.0e-4 (profiles/r03k_error_budget_fp6.txt).
+            std::vector<unsigned short> p6(2 * plane, 0);
+            std::memcpy(p6.data(), pc.data(), plane * 2);
+            std::vector<int> sa(2 * (size_t)cout_pad, 0x7f7f7f7f);      // [shift | scale bytes]
+            std::memcpy(sa.data(), sh.data(), (size_t)cout_pad * sizeof(float));
+            std::vector<int> ec(cout_pad, 0);
+            for (int oc = 0; oc < cout; ++oc) {
+                float mx = 0.0f;
+                for (size_t i = 0; i < (size_t)cin * T; ++i) mx = std::max(mx, std::fabs(w->d[(size_t)oc * cin * T + i]));
+                int e = (mx > 0.0f && std::isfinite(mx)) ? (int)std::ceil(std::log2(mx / 7.5f)) : 0;
+                while (std::ldexp(mx, -e) > 7.5f) ++e;
+                e = std::max(-40, std::min(40, e));
+                ec[oc] = e;
+                sa[cout_pad + oc] = ((127 - SFD2_C_XL_SHIFT + e) & 255) * 0x01010101;
+            }
+            for (int ch = 0; ch < nch32; ++ch)
+                for (int t = 0; t < T; ++t)
+                    for (int oc = 0; oc < cout; ++oc) {
+                        unsigned char *row = reinterpret_cast<unsigned char *>(p6.data() + plane) + ((((size_t)ch * T + t) * cout_pad + oc) * 32) * 2;
+                        for (int h = 0; h < 2; ++h) {
+                            unsigned char str[24] = {0};
+                            for (int p6i = 0; p6i < 32; ++p6i) {
+                                const int j = 32 * h + p6i, k = j >> 1;
+                                const float v = w->d[(((size_t)oc * cin + ch * 32 + k) * ks + t / ks) * ks + t % ks];
+                                const float x = (j & 1) ? std::ldexp(v - (float)(half_t)v, 11 - ec[oc]) : std::ldexp(v, -ec[oc]);
+                                const unsigned int code = f32_to_e2m3(x);
+                                const int bit = 6 * p6i;
+                                str[bit >> 3] |= (unsigned char)(code << (bit & 7));
+                                if ((bit & 7) > 2) str[(bit >> 3) + 1] |= (unsigned char)(code >> (8 - (bit & 7)));
+                            }
+                            std::memcpy(row + 16 * h, str, 16);
+                            std::memcpy(row + 32 + 16 * h, str + 16, 8);
+                        }
+                    }
+            if (upload(L.wc6, p6.data(), p6.size() * 2, c->stream)) return -1;
+            if (upload(L.sa6, sa.data(), sa.size() * sizeof(int), c->stream)) return -1;
+        }
         if (ks == 1 && stride == 1 && cin == 256 && cout == 256) {
             std::vector<half_t> fh((size_t)256 * 256), fl(fh.size());
             std::vector<unsigned short> fc(fh.size());
@@ -868,8 +939,10 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevBuf &i
     // conv3x3_pp's tile is 128 channels wide: in its compensated form it also takes conv2a (64 -> 128 channels, four chunks)
     if (!res && !c->opt_generic_c && L.ks == 3 && L.stride == 1 && L.cout_pad % 128 == 0 && L.cin % 64 == 0) {
         ProfScope ps(c, name, "conv3x3_pp<comp>", flops, bytes);
-        launch_conv3x3_pp_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, L.wc.as<half_t>(), L.scale.as<float>(),
-                            L.shift.as<float>(), L.cout_pad, relu, out.as<half_t>(), out_c, Ho, Wo, c->zero_page.as<half_t>(), L.sbyte);
+        const bool f6 = c->opt_fp6_filters && in_c && out_c && L.wc6.p && L.sa6.p;      // corr filters as fp6 (option "fp6_filters")
+        launch_conv3x3_pp_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, f6 ? L.wc6.as<half_t>() : L.wc.as<half_t>(), L.scale.as<float>(),
+                            L.shift.as<float>(), L.cout_pad, relu, out.as<half_t>(), out_c, Ho, Wo, c->zero_page.as<half_t>(), L.sbyte,
+                            f6 ? L.sa6.as<float>() : nullptr);
         return;
     }
     if (!c->opt_generic_c && !c->opt_no_rf_c && in_c && out_c && !res && L.ks == 3 && L.stride == 2 && L.cout_pad == 128) {   // conv2b
@@ -2567,6 +2640,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "sparse_da3") c->opt_sparse_da3 = value ? 1 : 0;
     else if (k == "cu_limit") g_sfd2_cu_limit = value < 0 ? 0 : value;
     else if (k == "x3_pp") c->opt_x3_pp = value ? 1 : 0;
+    else if (k == "fp6_filters") c->opt_fp6_filters = value ? 1 : 0;
     else if (k == "fuse_pb") c->opt_fuse_pb = value ? 1 : 0;
     else if (k == "generic_c") c->opt_generic_c = value ? 1 : 0;
     else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;

@@ -194,7 +194,7 @@ void launch_convc_igemm(hipStream_t st, const half_t *in, const half_t *in_c, in
 // the tuned kernels' compensated instantiations (same wpk / planes / sbyte as launch_convc_igemm; null plane = plain fp16)
 void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int relu, half_t *out, half_t *out_c,
-                         int Ho, int Wo, const half_t *zero_page, int sbyte);
+                         int Ho, int Wo, const half_t *zero_page, int sbyte, const float *shift_sa6 = nullptr /* non-null: wpk's corr rows are fp6; [shift | scale bytes] */);
 bool launch_conv3x3_rf_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out, half_t *out_c,
                          int Ho, int Wo, const half_t *zero_page, int sbyte);

@@ -343,6 +343,25 @@ def test_f16c_compensated_heads_det_vs_oracle(model_c_heads, synth_sd):
     _record(f"f16c comp_heads=1 det 130x100: dense desc {dd:.2e}")
 
 
+@pytest.mark.parametrize("h,w,seed,topk", [(100, 130, 22, -1), (480, 640, 0, 1024), (1200, 1600, 31, 4096)])
+def test_f16c_fp6_filters_extract_vs_oracle(synth_sd, h, w, seed, topk):
+    """Option fp6_filters = 1: the correction filters of conv2a / conv3a / conv3b as e2m3 with one power-of-two scale per output
+    channel (fp8 x fp6 scaled MFMA; operand layout pinned by tools/probe/mfma_fp6_layout.hip).  Same tolerance as the default."""
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    from sfd2_amd.model import ResSegNetV2
+    m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
+    m.load_state_dict(synth_sd)
+    m.cuda(0)
+    m.context.set_option("fp6_filters", 1)
+    img = synth.make_image(h, w, seed)
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk)
+    got = extract_resnet_return(m, torch.from_numpy(img)[None].cuda(), conf_th=0.001, topK=topk, scales=[1.0])
+    iou, dd, shift, same, n = _compare(got, want, 0.985)
+    assert dd <= 7e-4, dd
+    _record(f"f16c fp6_filters=1 extract {w}x{h} top{topk}: IoU {iou:.4f}, desc {dd:.2e}, same rank {same}/{n}, max rank shift {shift}")
+
+
 @pytest.fixture(scope="module", params=[0, 1])
 def model_c_inner(request, synth_sd):
     """f16c with option rb_inner off its default (2: the tensors inside the ResBlocks, t1 and t2, stored as plain fp16):
