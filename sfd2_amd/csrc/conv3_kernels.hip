@@ -62,6 +62,12 @@ __device__ __forceinline__ h4_t cvt4c(float a, float b, float c, float d)
 }
 
 // STAGGER = 0 builds the same loop without the one-barrier offset (A/B switch for the schedule itself)
+// experiment builds (timing only, wrong results): -DSFD2_PP_NO_CORR_MFMA drops the scaled MFMAs of the corr chunks, everything else stays
+#ifdef SFD2_PP_NO_CORR_MFMA
+#define PP_NO_CORR_MFMA 1
+#else
+#define PP_NO_CORR_MFMA 0
+#endif
 #ifndef SFD2_PP_KXM
 #define SFD2_PP_KXM 1
 #endif
@@ -309,6 +315,7 @@ _Pragma("unroll") \
                 for (int ct = 0; ct < 2; ++ct) \
 _Pragma("unroll") \
                     for (int pr = 0; pr < 4; ++pr) \
+                        if (!PP_NO_CORR_MFMA) \
                         acc[ct][pr] = F6 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fac[ct], frc[pr + u3], acc[ct][pr], 2, 0, 0, sa6v[ct], 0, 0x7f7f7f7f) \
                                          : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fac[ct], frc[pr + u3], acc[ct][pr], 0, 0, 0, sa, 0, 0x7f7f7f7f); \
                 /* the scaled MFMA is a pure node to instruction selection, which otherwise sinks all 72 of a chunk below its last \
