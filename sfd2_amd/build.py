@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfd2hip.so")
-SOURCES = ["conv_kernels.hip", "conv2_kernels.hip", "conv3_kernels.hip", "conv3rf_kernels.hip", "conv1x1_kernels.hip", "resblock_kernel.hip", "conv_f32_kernels.hip", "convc_kernels.hip", "rb23_c_kernel.hip", "sparse_da3_kernel.hip", "fused_stem_kernel.hip", "fused_stem_c_kernel.hip", "post_kernels.hip", "nms4_kernels.hip", "match_kernels.hip", "match_mutual_kernel.hip", "sfd2_api.hip"]
+SOURCES = ["conv_kernels.hip", "conv2_kernels.hip", "conv3_kernels.hip", "conv3rf_kernels.hip", "conv1x1_kernels.hip", "resblock_kernel.hip", "conv_f32_kernels.hip", "convc_kernels.hip", "rb23_c_kernel.hip", "sparse_da3_kernel.hip", "fused_stem_kernel.hip", "fused_stem_c_kernel.hip", "post_kernels.hip", "nms4_kernels.hip", "match_kernels.hip", "match_mutual_kernel.hip", "api_core.hip", "api_weights.hip", "api_network.hip", "api_extract.hip", "api_match.hip", "api_graph.hip"]
 # per-source extra flags (see the header comment of each file)
 # -fno-honor-nans: without it hipcc puts a NaN-canonicalising v_max_f32 x, x in front of every fmaxf operand it cannot
 # prove quiet (the ReLUs of the epilogues: two VALU per value instead of one).  Finite inputs give identical results.
@@ -32,7 +32,7 @@ def needs_build():
     """True when libsfd2hip.so is missing or older than any of its sources."""
     if not os.path.exists(LIB):
         return True
-    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "sfd2_internal.h"),
+    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "sfd2_internal.h"), os.path.join(CSRC, "sfd2_ctx.h"),
                                                       os.path.join(HERE, "..", "include", "sfd2_hip.h")]
     return any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs)
 
@@ -42,7 +42,7 @@ def build_lib(force=False, verbose=False, out=None, extra_flags=()):
     side directory so the product objects are not disturbed."""
     hipcc = _hipcc()
     objs = []
-    deps = [os.path.join(CSRC, "sfd2_internal.h"), os.path.join(HERE, "..", "include", "sfd2_hip.h")]
+    deps = [os.path.join(CSRC, "sfd2_internal.h"), os.path.join(CSRC, "sfd2_ctx.h"), os.path.join(HERE, "..", "include", "sfd2_hip.h")]
     procs = []
     lib = out or LIB
     odir = CSRC

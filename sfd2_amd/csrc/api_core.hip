@@ -1,0 +1,176 @@
+// libsfd2hip: context life cycle, options, profiling and timings of the C-ABI declared in include/sfd2_hip.h.
+#include "sfd2_ctx.h"
+
+static thread_local std::string g_err;
+int sfd2_fail(const std::string &m)
+{
+    g_err = m;
+    return -1;
+}
+
+std::atomic<unsigned long long> g_alloc_gen{0};
+
+int g_sfd2_cu_limit = 0;       // sfd2_set_option "cu_limit" (sfd2_internal.h)
+
+// ------------------------------------------------------------------------------------------ basics
+extern "C" int sfd2_version(void) { return 100; }
+extern "C" const char *sfd2_last_error(void) { return g_err.c_str(); }
+
+extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
+{
+    if (!out) return fail("sfd2_ctx_create: out is null");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail("sfd2_ctx_create: no HIP device available (libsfd2hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail("sfd2_ctx_create: bad device index");
+    HIPCHECK(hipSetDevice(device));
+    sfd2_ctx *c = new sfd2_ctx();
+    c->device = device;
+    HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) HIPCHECK(hipEventCreate(&c->ev[i]));
+    HIPCHECK(hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming));
+    HIPCHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHECK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    c->cur_stream = c->stream;
+    for (int i = 0; i < 2; ++i) {
+        HIPCHECK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&c->ev_img_free[i], hipEventDisableTiming));
+    }
+    c->fuse = sfd2_env("SFD2_NO_FUSE") ? 0 : 1;
+    HIPCHECK(c->zero_page.ensure(1024));
+    HIPCHECK(hipMemset(c->zero_page.p, 0, 1024));
+    *out = c;
+    return 0;
+}
+
+extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    graphs_release(c);
+    for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+        if (c->ev_img_free[i]) (void)hipEventDestroy(c->ev_img_free[i]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    if (c->pin_jobs) (void)hipHostFree(c->pin_jobs);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;      // every DevBuf / ConvW member frees its own allocation (sfd2_ctx.h)
+}
+
+extern "C" void *sfd2_get_stream(sfd2_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int sfd2_set_precision(sfd2_ctx *c, int mode)
+{
+    if (!c) return fail("sfd2_set_precision: null ctx");
+    if (mode != SFD2_PREC_F16 && mode != SFD2_PREC_F32 && mode != SFD2_PREC_F16X3 && mode != SFD2_PREC_F16C)
+        return fail("sfd2_set_precision: unknown mode");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (mode != c->precision) graphs_release(c);   // a captured unit holds the kernels of the precision it was captured in
+    c->precision = mode;
+    return 0;
+}
+
+extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
+{
+    if (!c || !key) return fail("sfd2_set_option: null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    const std::string k(key);
+    graphs_release(c);   // every option below decides which kernels a captured unit contains
+    if (k == "fuse") c->fuse = value ? 1 : 0;
+    else if (k == "fuse_det") c->fuse_det = value ? 1 : 0;
+    else if (k == "alias") c->opt_alias = value ? 1 : 0;
+    else if (k == "graphs") c->use_graphs = value ? 1 : 0;
+    else if (k == "branches") c->opt_branches = value ? 1 : 0;
+    else if (k == "fuse_post") c->opt_fuse_post = value ? 1 : 0;
+    else if (k == "sparse_desc") c->opt_sparse_desc = value ? 1 : 0;
+    else if (k == "sparse_da3") c->opt_sparse_da3 = value ? 1 : 0;
+    else if (k == "cu_limit") g_sfd2_cu_limit = value < 0 ? 0 : value;
+    else if (k == "x3_pp") c->opt_x3_pp = value ? 1 : 0;
+    else if (k == "fp6_filters") c->opt_fp6_filters = value ? 1 : 0;
+    else if (k == "fuse_pb") c->opt_fuse_pb = value ? 1 : 0;
+    else if (k == "generic_c") c->opt_generic_c = value ? 1 : 0;
+    else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;
+    else if (k == "no_rf_c") c->opt_no_rf_c = value ? 1 : 0;
+    else if (k == "comp_heads") c->opt_comp_heads = value ? 1 : 0;
+    else if (k == "fuse_rb23") c->opt_fuse_rb23 = value ? 1 : 0;
+    else if (k == "rb_inner") c->opt_rb_inner = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else return fail("sfd2_set_option: unknown key '" + k + "'");
+    return 0;
+}
+
+extern "C" int sfd2_sync(sfd2_ctx *c)
+{
+    if (!c) return fail("sfd2_sync: null ctx");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int sfd2_set_profiling(sfd2_ctx *c, int max_steps)
+{
+    if (!c) return fail("sfd2_set_profiling: null ctx");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (max_steps < 0 || max_steps > 4096) return fail("sfd2_set_profiling: max_steps out of range");
+    const size_t need = (size_t)max_steps * PROF_SLOTS * 2;
+    while (c->prof_ev.size() < need) {
+        hipEvent_t e;
+        HIPCHECK(hipEventCreate(&e));
+        c->prof_ev.push_back(e);
+    }
+    c->prof_max_steps = max_steps;
+    c->prof_step = 0;
+    c->prof_slot = 0;
+    c->prof_used.assign(max_steps, 0);
+    c->prof_row.assign((size_t)max_steps * PROF_SLOTS, 0);
+    c->prof_tab.clear();
+    return 0;
+}
+
+extern "C" int sfd2_set_profile_filter(sfd2_ctx *c, const char *substr)
+{
+    if (!c) return fail("sfd2_set_profile_filter: null ctx");
+    c->prof_filter = substr ? substr : "";
+    return 0;
+}
+
+extern "C" int sfd2_get_layer_timings(sfd2_ctx *c, sfd2_layer_timing *out, int cap, int *n)
+{
+    if (!c || !n) return fail("sfd2_get_layer_timings: null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    for (int st = 0; st < c->prof_step; ++st)
+        for (int sl = 0; sl < c->prof_used[st]; ++sl) {
+            float ms = 0.0f;
+            const size_t e = ((size_t)st * PROF_SLOTS + sl) * 2;
+            const int row = c->prof_row[(size_t)st * PROF_SLOTS + sl];
+            if (hipEventElapsedTime(&ms, c->prof_ev[e], c->prof_ev[e + 1]) == hipSuccess) {
+                c->prof_tab[row].ms_total += ms;
+                c->prof_tab[row].launches += 1;
+            }
+        }
+    c->prof_step = 0;  // events consumed; the table keeps accumulating until sfd2_set_profiling resets it
+    *n = (int)c->prof_tab.size();
+    if (out)
+        for (int i = 0; i < *n && i < cap; ++i) out[i] = c->prof_tab[i];
+    return 0;
+}
+
+extern "C" int sfd2_get_timings(sfd2_ctx *c, sfd2_timings *out)
+{
+    if (!c || !out) return fail("sfd2_get_timings: null argument");
+    *out = c->tim;
+    return 0;
+}

@@ -203,7 +203,7 @@ void launch_conv1x1_c256(hipStream_t st, const half_t *in, int npix, const half_
 // finishing between 55 and 70 us for identical work (mean 64), so handing groups out dynamically (an atomic claim counter,
 // claims five ahead through an LDS ring) was tried: the blocks then finish within 2 us of each other, but LATER (mean 73) --
 // with one counter or with eight -- and the launch is slower (conv1 47 -> 66 us, conv3 78 -> 84): not kept.
-// IN_C = false: the input is a plain fp16 tensor (ResBlock-internal tensors under option "rb_inner", sfd2_api.hip): no corr
+// IN_C = false: the input is a plain fp16 tensor (ResBlock-internal tensors under option "rb_inner", api_network.hip): no corr
 // plane to stage, and the filter residuals arrive as fp16 (w - fp16(w)) * 2^11 (`wc` = [256][256] halves) for a second fp16
 // pass into its own accumulator.  OUT_C = false: only the hi plane is written.
 template <bool HAS_RES, bool IN_C, bool OUT_C>

@@ -78,7 +78,7 @@ __device__ __forceinline__ h4_t cvt4c(float a, float b, float c, float d)
 // the chunk loop simply runs on through the corr plane's chunks, whose units go to ONE v_mfma_scale_f32_32x32x64_f8f6f4 per
 // (channel tile, pixel tile) instead of two fp16 MFMAs (same LDS records, same fragment reads); bit 1 = the corr plane of
 // the output is written (out_c); bit 4 = the corr FILTER rows are fp6 (e2m3) strings with one E8M0 scale byte per output channel
-// (behind the shifts: shift[CoutP + channel] holds the byte replicated into an int; sfd2_api.hip pack_igemm): the same fragment reads (the strings sit in the 16-byte slots the lane halves read), the MFMA
+// (behind the shifts: shift[CoutP + channel] holds the byte replicated into an int; api_weights.hip pack_igemm): the same fragment reads (the strings sit in the 16-byte slots the lane halves read), the MFMA
 // runs fp8 x fp6 -- 32 ns per instruction and SIMD instead of 37-41 (profiles/r03k_mfma_f8f6f4_probe.txt).
 // Measured with the trace below (conv2a compensated, 64 -> 128 channels: K loop 45k cycles, epilogue 15-22k, wait at the next
 // tile's top 2-9k): the epilogue is long because every CU writes its 256 KB tile at the same time (64 MB per round, the K loops

@@ -58,13 +58,37 @@ def _filter_bank(rs, cout, cin, k, gain):
     return (w * std).astype(np.float32)
 
 
-def make_state_dict(seed=0):
-    """Returns {name: np.ndarray} with the reference ResSegNetV2 state_dict layout."""
+def make_state_dict(seed=0, family=None, gain_log2=0, gain_on="all"):
+    """Returns {name: np.ndarray} with the reference ResSegNetV2 state_dict layout.
+
+    family=None is the well-conditioned draw every golden vector was made with (bytes fixed).  The other families are
+    for the conditioning sweep of the reduced-precision modes (tests/test_gpu_f16c_conditioning.py): weights a TRAINED
+    checkpoint may have and the benign draw does not --
+      "student"     heavy-tailed filters (Student-t, 3 degrees of freedom, unit variance), zero-sum as the default
+      "calibrated"  the default draw with every BatchNorm's running statistics replaced by the statistics its input
+                    actually has on a calibration image (what training leaves behind)
+      "biased"      filters that do NOT sum to zero over the input channels (mean 0.3 sigma) + calibrated statistics
+      "dead"        calibrated, and 5 % of the output channels of every BatchNorm'd layer have filters 2^-5 .. 2^-9 of
+                    the others (running_var 2^-10 .. 2^-18 of theirs: the folded scale is x 32 .. x 512)
+      "smallvar"    the default draw with running_var = 1e-3 on 5 % of the channels (those channels come out x 30)
+    gain_log2 = k multiplies the activation tensors named by gain_on ("all" backbone tensors, or one of "conv1a",
+    "conv1b", "conv2a", "conv2b", "conv3a", "trunk", "t1", "t2") by 2^k and their consumers' filters by 2^-k: the
+    network's function is unchanged (powers of two: exactly, up to the BatchNorm eps), only the scale of what is stored
+    between the layers moves.  This is what probes the fixed scalings of the compensated mode."""
     rs = np.random.RandomState(seed)
+    fam = family or "gauss"
+    if fam not in ("gauss", "student", "calibrated", "biased", "dead", "smallvar"):
+        raise ValueError(f"unknown weight family {family!r}")
     sd = {}
     for name, cout, cin, k, has_bias, bn in _LAYERS:
         gain = _HEAD_GAIN.get(name, 1.0)
-        sd[name + ".weight"] = _filter_bank(rs, cout, cin, k, gain)
+        if fam == "student":
+            sd[name + ".weight"] = _filter_bank_t(rs, cout, cin, k, gain)
+        elif fam == "biased":
+            w = _filter_bank(rs, cout, cin, k, gain)
+            sd[name + ".weight"] = (w + 0.3 * w.std()).astype(np.float32) if cin >= 8 and name not in _HEAD_GAIN else w
+        else:
+            sd[name + ".weight"] = _filter_bank(rs, cout, cin, k, gain)
         if has_bias:
             sd[name + ".bias"] = (0.1 * rs.standard_normal(cout)).astype(np.float32)
         if bn is not None:
@@ -75,7 +99,135 @@ def make_state_dict(seed=0):
             if kind == "affine":
                 sd[bname + ".weight"] = (1.0 + 0.1 * rs.standard_normal(cout)).astype(np.float32)
                 sd[bname + ".bias"] = (0.1 * rs.standard_normal(cout)).astype(np.float32)
+    if fam == "dead":
+        for name, cout, cin, k, has_bias, bn in _LAYERS:
+            if bn is None:
+                continue
+            idx = rs.choice(cout, max(1, cout // 20), replace=False)
+            sh = rs.randint(5, 10, size=idx.size)
+            sd[name + ".weight"][idx] *= np.exp2(-sh).astype(np.float32)[:, None, None, None]
+            if has_bias:
+                sd[name + ".bias"][idx] *= np.exp2(-sh).astype(np.float32)
+    if fam in ("calibrated", "biased", "dead"):
+        _calibrate_bn(sd, make_image(64, 96, 900 + seed))
+    if fam == "smallvar":
+        for name, cout, cin, k, has_bias, bn in _LAYERS:
+            if bn is not None:
+                idx = rs.choice(cout, max(1, cout // 20), replace=False)
+                sd[bn[0] + ".running_var"][idx] = np.float32(1e-3)
+    if gain_log2:
+        _apply_gain(sd, int(gain_log2), gain_on)
     return sd
+
+
+def _filter_bank_t(rs, cout, cin, k, gain):
+    """_filter_bank with Student-t (3 degrees of freedom) entries scaled to unit variance: a few entries per filter
+    are 5-20 sigma."""
+    fan_in = cin * k * k
+    std = gain * np.sqrt(2.0 / fan_in) / np.sqrt(3.0)
+    if cin >= 8:
+        half = rs.standard_t(3, size=(cout, cin // 2, k, k))
+        w = np.concatenate([half, -np.roll(half, 1, axis=1)], axis=1)
+    else:
+        w = rs.standard_t(3, size=(cout, cin, k, k))
+    return (w * std).astype(np.float32)
+
+
+def _np_conv(x, w, stride, groups):
+    """x [C,H,W], w [Cout,Cin/groups,k,k], zero padding k // 2 (float64 einsum over an im2col view; small maps only)."""
+    cout, cg, k, _ = w.shape
+    c, h, wd = x.shape
+    p = k // 2
+    xp = np.pad(x, ((0, 0), (p, p), (p, p)))
+    ho, wo = (h + 2 * p - k) // stride + 1, (wd + 2 * p - k) // stride + 1
+    cols = np.empty((c, k, k, ho, wo), dtype=np.float64)
+    for dy in range(k):
+        for dx in range(k):
+            cols[:, dy, dx] = xp[:, dy:dy + stride * ho:stride, dx:dx + stride * wo:stride]
+    og = cout // groups
+    out = np.empty((cout, ho, wo), dtype=np.float64)
+    for g in range(groups):
+        out[g * og:(g + 1) * og] = np.einsum("oikl,iklhw->ohw", w[g * og:(g + 1) * og].astype(np.float64), cols[g * cg:(g + 1) * cg])
+    return out
+
+
+def _calibrate_bn(sd, img):
+    """Replaces every BatchNorm's running_mean / running_var by the mean / variance its input has on `img` [3,h,w] in [0,1]
+    (propagated layer by layer through the network with the statistics already replaced), floor 1e-8 on the variance."""
+    mean = np.array([0.485, 0.456, 0.406]).reshape(3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225]).reshape(3, 1, 1)
+
+    def layer(x, conv, bn, stride=1, groups=1, relu=True, res=None):
+        y = _np_conv(x, sd[conv + ".weight"], stride, groups)
+        if conv + ".bias" in sd:
+            y = y + sd[conv + ".bias"].astype(np.float64).reshape(-1, 1, 1)
+        if bn is not None:
+            m, v = y.mean(axis=(1, 2)), np.maximum(y.var(axis=(1, 2)), 1e-8)
+            sd[bn + ".running_mean"] = m.astype(np.float32)
+            sd[bn + ".running_var"] = v.astype(np.float32)
+            y = (y - m.reshape(-1, 1, 1)) / np.sqrt(v.reshape(-1, 1, 1) + 1e-5)
+            if bn + ".weight" in sd:
+                y = y * sd[bn + ".weight"].astype(np.float64).reshape(-1, 1, 1) + sd[bn + ".bias"].astype(np.float64).reshape(-1, 1, 1)
+        if res is not None:
+            y = y + res
+        return np.maximum(y, 0.0) if relu else y
+
+    o = layer((img.astype(np.float64) - mean) / std, "conv1a.0", "conv1a.1")
+    o = layer(o, "conv1b.0", "bn1b.0", stride=2)
+    o = layer(o, "conv2a.0", "conv2a.1")
+    o = layer(o, "conv2b.0", "bn2b.0", stride=2)
+    o = layer(o, "conv3a.0", "conv3a.1")
+    o = layer(o, "conv3b.0", "bn3b.0")
+    for b in range(3):
+        q = f"conv4.{b}."
+        t = layer(o, q + "conv1", q + "bn1")
+        t = layer(t, q + "conv2", q + "bn2", groups=32)
+        o = layer(t, q + "conv3", q + "bn3", res=o)
+    layer(o, "convPa.0", "convPa.1", stride=2)
+    layer(o, "convDa.0", "convDa.1")
+
+
+# producers / consumers of the backbone's stored tensors (gain family)
+def _apply_gain(sd, k, on):
+    g, gi = np.float32(2.0 ** k), np.float32(2.0 ** -k)
+
+    def plain(conv, bn):       # BatchNorm(affine=False): y = (conv(x) + b - mean) / sqrt(var + eps)  ->  g y
+        sd[conv + ".weight"] = sd[conv + ".weight"] * g
+        sd[conv + ".bias"] = sd[conv + ".bias"] * g
+        sd[bn + ".running_mean"] = sd[bn + ".running_mean"] * g
+        v = sd[bn + ".running_var"].astype(np.float64)
+        sd[bn + ".running_var"] = v.astype(np.float32)   # (unchanged: numerator scaled instead)
+
+    def affine(bn):            # gamma, beta
+        sd[bn + ".weight"] = sd[bn + ".weight"] * g
+        sd[bn + ".bias"] = sd[bn + ".bias"] * g
+
+    def consumer(conv):        # every input channel / g
+        sd[conv + ".weight"] = sd[conv + ".weight"] * gi
+
+    chain = [("conv1a", "conv1a.0", "conv1a.1", ["conv1b.0"]), ("conv1b", "conv1b.0", "bn1b.0", ["conv2a.0"]),
+             ("conv2a", "conv2a.0", "conv2a.1", ["conv2b.0"]), ("conv2b", "conv2b.0", "bn2b.0", ["conv3a.0"]),
+             ("conv3a", "conv3a.0", "conv3a.1", ["conv3b.0"])]
+    for name, conv, bn, cons in chain:
+        if on in ("all", name):
+            plain(conv, bn)
+            for c in cons:
+                consumer(c)
+    if on in ("all", "trunk"):   # conv3b's output and every ResBlock's output share the skip path: one scale
+        plain("conv3b.0", "bn3b.0")
+        for b in range(3):
+            affine(f"conv4.{b}.bn3")
+            consumer(f"conv4.{b}.conv1")
+        for c in ("convPa.0", "convDa.0", "ConvSta"):
+            if c + ".weight" in sd:
+                consumer(c)
+    for b in range(3):
+        if on in ("all", "t1"):
+            affine(f"conv4.{b}.bn1")
+            consumer(f"conv4.{b}.conv2")
+        if on in ("all", "t2"):
+            affine(f"conv4.{b}.bn2")
+            consumer(f"conv4.{b}.conv3")
 
 
 def make_image(h, w, seed=0):
