@@ -99,8 +99,10 @@ int sfd2_load_weights(sfd2_ctx *ctx, const sfd2_tensor *tensors, int n);
  * carrying a second 2-byte plane per activation and per filter that holds the fp16 rounding residual and the value at
  * fp8 precision; every backbone layer adds the two first-order error terms with ONE block-scaled fp8 MFMA per 32
  * channels (1.65x the matrix time of the fp16 layer).  Operands then carry ~15 significant bits: descriptors within
- * 1e-3 of the fp32 reference (measured <= 3e-4), which is the tolerance BASELINE.json's north_star states.  The head
- * branches stay plain fp16 (they contribute 2.4e-4 on their own).  Option "comp_heads" extends it to convPa / convDa. */
+ * 1e-3 of the fp32 reference (measured <= 5e-4), which is the tolerance BASELINE.json's north_star states.  The head
+ * branches stay plain fp16 (they contribute 2.4e-4 on their own).  Option "comp_heads" extends it to convPa / convDa.
+ * RANGE: the compensated tensors saturate at +-1792 in stored units and lose their correction bits below ~0.03 (the fp32
+ * reference has neither limit): see "Range management" below for what keeps real checkpoints inside and reports it. */
 #define SFD2_PREC_F16 0
 #define SFD2_PREC_F32 1
 #define SFD2_PREC_F16X3 2
@@ -137,8 +139,12 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *   "fp6_filters" 0 (default) / 1: SFD2_PREC_F16C, conv2a / conv3a / conv3b: the correction filters as e2m3 (fp6) with one power-of-two
  *               scale per output channel instead of e4m3 (fp8 x fp6 scaled MFMA).  Same tolerance (descriptors <= 5.2e-4 measured),
  *               no measurable speed difference on MI355X: an experiment switch.
- *   "cu_limit"  0 (default) / n: persistent kernels launch at most n blocks (experiment: with two streams, two kernels side by side
- *               on half the chip each measure the same throughput as taking turns on all of it).  Process-wide.
+ *   "cu_limit"  0 (default) / n: persistent kernels of THIS context launch at most n blocks (experiment: with two streams, two kernels
+ *               side by side on half the chip each measure the same throughput as taking turns on all of it).
+ *   "auto_range" 1 (default) / 0: sfd2_load_weights calibrates the activation exponents on a built-in probe image (see
+ *               sfd2_calibrate_range below); 0 = all exponents zero until the caller calibrates.
+ *   "range_fallback" 1 (default) / 0: a synchronous sfd2_extract in SFD2_PREC_F16C that saturated a tensor is re-run in
+ *               SFD2_PREC_F16X3 before it returns.
  *   "sparse_da3" 1 (default) / 0: on the extract path (with "sparse_desc"), convDa.3 runs on the 4 x K bilinear corner pixels of the
  *               selected key points only instead of the whole 1/4-resolution map (-77 us per 1600x1200 / top-4096 extract;
  *               descriptors within 4e-5 of the dense path's: another fp32 summation order).  0 = dense.
@@ -146,6 +152,8 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *               stays in LDS); 0 = two launches.  Bit-identical.
  *   "comp_heads" 0 (default) / 1: SFD2_PREC_F16C compensates the four 3x3 layers of the two head branches as well
  *               (descriptors ~1.5e-4 instead of ~3e-4, key points closer to the reference's list; ~0.25 ms more per image).
+ *   "comp_det"  0 (default) / 1: SFD2_PREC_F16C compensates the detector branch's two 3x3 layers (convPa.0, convPa.3) only: the score goes
+ *               through exp(), so its error is what moves key points; the descriptor branch stays plain (and keeps its sparse head).
  *   "no_rf_c"   0 (default) / 1: conv2b of SFD2_PREC_F16C on conv_igemm2<comp> instead of conv3x3_rf<comp> (A/B switch).
  *   "generic_c" 0 (default) / 1: SFD2_PREC_F16C layers all run on the generic compensated kernel (the reference
  *               implementation of that arithmetic) instead of the tuned kernels' compensated instantiations; the two
@@ -288,6 +296,47 @@ int sfd2_extract_match(sfd2_ctx *ctx, const void *img_dev, int H, int W, float c
                        const sfd2_match_conf *conf, int64_t *matches0, float *scores0);
 
 int sfd2_get_timings(sfd2_ctx *ctx, sfd2_timings *out);
+
+/* ---- Range management of the fp16 family (SFD2_PREC_F16 / SFD2_PREC_F16C).  The reference computes in fp32 and has nothing
+ * of the kind (nets/sfd2.py:313-326); this is what keeps a reduced-precision path honest on a checkpoint nobody has seen.
+ *
+ * The compensated mode stores every backbone tensor as fp16 + two e4m3 bytes with FIXED scalings (value / 4, fp16 residual
+ * * 512) and saturates it at 1792 (so that neither byte can overflow e4m3's 448).  That suits tensors whose largest
+ * entry lies between ~0.2 and ~500 (descriptors within 5e-4 of the fp32 reference there; 1.1e-3 at 0.03; garbage above
+ * 1792: tools/conditioning_sweep.py).  Three mechanisms keep it there and make leaving it visible:
+ *   1. sfd2_load_weights normalises every filter per output channel by a power of two (the factor goes into the folded
+ *      BatchNorm scale: exact), so no channel's filter sits in fp16's subnormals or below the e4m3 units' range.
+ *   2. Activation exponents: the stored tensor of group g is 2^e[g] times the network's tensor, the factors folded into
+ *      the layers' scale / shift constants (exact: powers of two commute with ReLU and with fp32 rounding).
+ *      sfd2_calibrate_range measures every group's largest |x| on an image (one pass in SFD2_PREC_F32) and sets e[g] so
+ *      that it lands at 16; sfd2_load_weights does that on a built-in probe image (option "auto_range", default 1).
+ *   3. Range status: every kernel that writes a tensor of the compensated mode records the largest value it WOULD have
+ *      stored, before the saturation.  sfd2_get_range_status reports them; a synchronous sfd2_extract that saturated a
+ *      tensor is re-run in SFD2_PREC_F16X3 before it returns (option "range_fallback", default 1) and counted.
+ *      Asynchronous calls (SFD2_FLAG_ASYNC, sfd2_extract_match) cannot look at the counters: the caller polls
+ *      sfd2_get_range_status at its own synchronisation points. */
+#define SFD2_RANGE_TENSORS 17
+#define SFD2_RANGE_GROUPS 14
+typedef struct {
+    int32_t n_tensors;                        /* SFD2_RANGE_TENSORS                                                      */
+    float max_stored[SFD2_RANGE_TENSORS];     /* largest value in front of the saturation, as stored (x 2^exponent), since
+                                                 the last reset; 0 = the tensor was not produced by a recording kernel   */
+    float max_value[SFD2_RANGE_TENSORS];      /* the same in the network's own units                                      */
+    int32_t exponent[SFD2_RANGE_TENSORS];     /* the tensor's activation exponent                                         */
+    uint32_t saturated;                       /* bit i: tensor i reached 1792 (values were clamped: results are wrong)    */
+    uint32_t low;                             /* bit i: tensor i never exceeded 2^-5 (the corr units have lost their bits:
+                                                 plain-fp16 accuracy, ~2e-3 on descriptors)                               */
+    int32_t fallbacks;                        /* synchronous extracts re-run in SFD2_PREC_F16X3 since the context exists  */
+} sfd2_range_status;
+int sfd2_get_range_status(sfd2_ctx *ctx, sfd2_range_status *out, int reset);
+/* "conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4.b.t1", "conv4.b.t2", "conv4.b" (b = 0..2), "convPa.0", "convDa.0" */
+const char *sfd2_range_tensor_name(int i);
+/* img: [3][H][W] fp32 as for sfd2_det (flags: SFD2_FLAG_IMG_NORMALISED).  Replaces the exponents; captured graphs are dropped. */
+int sfd2_calibrate_range(sfd2_ctx *ctx, const float *img, int img_on_device, int H, int W, int flags);
+/* exps / maxima [SFD2_RANGE_GROUPS]: conv1a, conv1b, conv2a, conv2b, conv3a, trunk (conv3b's and the ResBlocks' outputs share the
+ * skip path), t1 of block 0..2, t2 of block 0..2, convPa.0, convDa.0.  maxima = what the last calibration measured. */
+int sfd2_get_act_exponents(sfd2_ctx *ctx, int32_t *exps, float *maxima, int cap, int *n);
+int sfd2_set_act_exponents(sfd2_ctx *ctx, const int32_t *exps, int n /* SFD2_RANGE_GROUPS, or 0 = all zero */);
 
 /* Blocks until every kernel queued on the context's stream has finished. */
 int sfd2_sync(sfd2_ctx *ctx);

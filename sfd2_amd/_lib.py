@@ -58,6 +58,15 @@ class LayerTiming(ctypes.Structure):
                 ("bytes", ctypes.c_double), ("ms_total", ctypes.c_double), ("launches", ctypes.c_int32)]
 
 
+RANGE_TENSORS, RANGE_GROUPS = 17, 14
+
+
+class RangeStatus(ctypes.Structure):
+    _fields_ = [("n_tensors", ctypes.c_int32), ("max_stored", ctypes.c_float * RANGE_TENSORS),
+                ("max_value", ctypes.c_float * RANGE_TENSORS), ("exponent", ctypes.c_int32 * RANGE_TENSORS),
+                ("saturated", ctypes.c_uint32), ("low", ctypes.c_uint32), ("fallbacks", ctypes.c_int32)]
+
+
 # every symbol include/sfd2_hip.h declares (tests/test_abi.py checks the two lists agree)
 EXPORTS = [
     "sfd2_version", "sfd2_last_error", "sfd2_ctx_create", "sfd2_ctx_destroy", "sfd2_get_stream",
@@ -66,6 +75,7 @@ EXPORTS = [
     "sfd2_match", "sfd2_match_batch", "sfd2_get_timings", "sfd2_sync", "sfd2_set_profiling",
     "sfd2_get_layer_timings", "sfd2_set_precision", "sfd2_extract_spp", "sfd2_nms_fast",
     "sfd2_set_profile_filter", "sfd2_extract_multiscale", "sfd2_set_option", "sfd2_extract_match", "sfd2_preprocess", "sfd2_extract_spp_levels", "sfd2_match_segments",
+    "sfd2_get_range_status", "sfd2_range_tensor_name", "sfd2_calibrate_range", "sfd2_get_act_exponents", "sfd2_set_act_exponents",
 ]
 
 _lib = None
@@ -133,6 +143,12 @@ def load():
     lib.sfd2_set_profiling.argtypes = [vp, ci]
     lib.sfd2_set_profile_filter.argtypes = [vp, ctypes.c_char_p]
     lib.sfd2_get_layer_timings.argtypes = [vp, ctypes.POINTER(LayerTiming), ci, pi]
+    lib.sfd2_get_range_status.argtypes = [vp, ctypes.POINTER(RangeStatus), ci]
+    lib.sfd2_range_tensor_name.argtypes = [ci]
+    lib.sfd2_range_tensor_name.restype = ctypes.c_char_p
+    lib.sfd2_calibrate_range.argtypes = [vp, vp, ci, ci, ci, ci]
+    lib.sfd2_get_act_exponents.argtypes = [vp, vp, vp, ci, pi]
+    lib.sfd2_set_act_exponents.argtypes = [vp, vp, ci]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the .so lacks a declared symbol
     _lib = lib
@@ -229,6 +245,41 @@ class Context:
         return [{"name": arr[i].name.decode(), "kernel": arr[i].kernel.decode(), "flops": arr[i].flops,
                  "bytes": arr[i].bytes, "ms_total": arr[i].ms_total, "launches": arr[i].launches}
                 for i in range(min(n.value, 64))]
+
+    def range_status(self, reset=False):
+        """Largest value every stored tensor of the compensated mode reached since the last reset (include/sfd2_hip.h,
+        sfd2_range_status): {'tensors': {name: {'max_stored', 'max_value', 'exponent'}}, 'saturated': [names], 'low': [names],
+        'fallbacks': n}."""
+        rs = RangeStatus()
+        check(self.lib.sfd2_get_range_status(self.h, ctypes.byref(rs), 1 if reset else 0))
+        names = [self.lib.sfd2_range_tensor_name(i).decode() for i in range(rs.n_tensors)]
+        return {"tensors": {n: {"max_stored": rs.max_stored[i], "max_value": rs.max_value[i], "exponent": rs.exponent[i]}
+                            for i, n in enumerate(names)},
+                "saturated": [n for i, n in enumerate(names) if rs.saturated >> i & 1],
+                "low": [n for i, n in enumerate(names) if rs.low >> i & 1], "fallbacks": rs.fallbacks}
+
+    def calibrate_range(self, img, normalised=False):
+        """img: [3,H,W] float32 (numpy: host; torch cuda tensor: device).  Sets the activation exponents of the fp16 family from
+        this image's fp32 activations (sfd2_calibrate_range)."""
+        on_dev = 0 if isinstance(img, np.ndarray) else 1
+        if isinstance(img, np.ndarray):
+            img = np.ascontiguousarray(img, dtype=np.float32)
+        check(self.lib.sfd2_calibrate_range(self.h, ptr(img), on_dev, int(img.shape[-2]), int(img.shape[-1]),
+                                            FLAG_IMG_NORMALISED if normalised else 0))
+
+    def act_exponents(self):
+        e = np.zeros(RANGE_GROUPS, dtype=np.int32)
+        m = np.zeros(RANGE_GROUPS, dtype=np.float32)
+        n = ctypes.c_int(0)
+        check(self.lib.sfd2_get_act_exponents(self.h, e.ctypes.data, m.ctypes.data, RANGE_GROUPS, ctypes.byref(n)))
+        return e, m
+
+    def set_act_exponents(self, exps=None):
+        if exps is None:
+            check(self.lib.sfd2_set_act_exponents(self.h, None, 0))
+        else:
+            e = np.ascontiguousarray(exps, dtype=np.int32)
+            check(self.lib.sfd2_set_act_exponents(self.h, e.ctypes.data, int(e.size)))
 
     def debug_activation(self, name):
         c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfd2hip.so")
-SOURCES = ["conv_kernels.hip", "conv2_kernels.hip", "conv3_kernels.hip", "conv3rf_kernels.hip", "conv1x1_kernels.hip", "resblock_kernel.hip", "conv_f32_kernels.hip", "convc_kernels.hip", "rb23_c_kernel.hip", "sparse_da3_kernel.hip", "fused_stem_kernel.hip", "fused_stem_c_kernel.hip", "post_kernels.hip", "nms4_kernels.hip", "match_kernels.hip", "match_mutual_kernel.hip", "api_core.hip", "api_weights.hip", "api_network.hip", "api_extract.hip", "api_match.hip", "api_graph.hip"]
+SOURCES = ["conv_kernels.hip", "conv2_kernels.hip", "conv3_kernels.hip", "conv3rf_kernels.hip", "conv1x1_kernels.hip", "resblock_kernel.hip", "conv_f32_kernels.hip", "convc_kernels.hip", "rb23_c_kernel.hip", "sparse_da3_kernel.hip", "fused_stem_kernel.hip", "fused_stem_c_kernel.hip", "post_kernels.hip", "util_kernels.hip", "nms4_kernels.hip", "match_kernels.hip", "match_mutual_kernel.hip", "api_core.hip", "api_weights.hip", "api_network.hip", "api_extract.hip", "api_match.hip", "api_graph.hip"]
 # per-source extra flags (see the header comment of each file)
 # -fno-honor-nans: without it hipcc puts a NaN-canonicalising v_max_f32 x, x in front of every fmaxf operand it cannot
 # prove quiet (the ReLUs of the epilogues: two VALU per value instead of one).  Finite inputs give identical results.

@@ -10,7 +10,7 @@ int sfd2_fail(const std::string &m)
 
 std::atomic<unsigned long long> g_alloc_gen{0};
 
-int g_sfd2_cu_limit = 0;       // sfd2_set_option "cu_limit" (sfd2_internal.h)
+thread_local int g_sfd2_cu_limit = 0;       // set per network pass from the context's option "cu_limit" (sfd2_internal.h)
 
 // ------------------------------------------------------------------------------------------ basics
 extern "C" int sfd2_version(void) { return 100; }
@@ -39,8 +39,12 @@ extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
         HIPCHECK(hipEventCreateWithFlags(&c->ev_img_free[i], hipEventDisableTiming));
     }
     c->fuse = sfd2_env("SFD2_NO_FUSE") ? 0 : 1;
-    HIPCHECK(c->zero_page.ensure(1024));
-    HIPCHECK(hipMemset(c->zero_page.p, 0, 1024));
+    // the zero page, and behind it the range-status words (conv3x3_pp reaches them through the zero-page pointer it holds anyway)
+    HIPCHECK(c->zero_page.ensure(SFD2_ZERO_PAGE_BYTES + (size_t)SFD2_RS_COUNT * SFD2_RANGE_SUB * sizeof(unsigned int)));
+    HIPCHECK(hipMemset(c->zero_page.p, 0, c->zero_page.cap));
+    c->range_stat.p = c->zero_page.as<char>() + SFD2_ZERO_PAGE_BYTES;
+    static_assert(SFD2_RS_COUNT == SFD2_RANGE_TENSORS && AE_COUNT == SFD2_RANGE_GROUPS, "include/sfd2_hip.h and the internal tables agree");
+
     *out = c;
     return 0;
 }
@@ -96,7 +100,9 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "fuse_post") c->opt_fuse_post = value ? 1 : 0;
     else if (k == "sparse_desc") c->opt_sparse_desc = value ? 1 : 0;
     else if (k == "sparse_da3") c->opt_sparse_da3 = value ? 1 : 0;
-    else if (k == "cu_limit") g_sfd2_cu_limit = value < 0 ? 0 : value;
+    else if (k == "cu_limit") c->opt_cu_limit = value < 0 ? 0 : value;
+    else if (k == "auto_range") c->opt_auto_range = value ? 1 : 0;
+    else if (k == "range_fallback") c->opt_range_fallback = value ? 1 : 0;
     else if (k == "x3_pp") c->opt_x3_pp = value ? 1 : 0;
     else if (k == "fp6_filters") c->opt_fp6_filters = value ? 1 : 0;
     else if (k == "fuse_pb") c->opt_fuse_pb = value ? 1 : 0;
@@ -104,6 +110,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;
     else if (k == "no_rf_c") c->opt_no_rf_c = value ? 1 : 0;
     else if (k == "comp_heads") c->opt_comp_heads = value ? 1 : 0;
+    else if (k == "comp_det") c->opt_comp_det = value ? 1 : 0;
     else if (k == "fuse_rb23") c->opt_fuse_rb23 = value ? 1 : 0;
     else if (k == "rb_inner") c->opt_rb_inner = value < 0 ? 0 : (value > 2 ? 2 : value);
     else return fail("sfd2_set_option: unknown key '" + k + "'");
@@ -173,4 +180,67 @@ extern "C" int sfd2_get_timings(sfd2_ctx *c, sfd2_timings *out)
     if (!c || !out) return fail("sfd2_get_timings: null argument");
     *out = c->tim;
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------ range status (include/sfd2_hip.h)
+static const int kRsGroup[SFD2_RS_COUNT] = {AE_CONV1A, AE_CONV1B, AE_CONV2A, AE_CONV2B, AE_CONV3A, AE_TRUNK, AE_T1_0, AE_T1_1, AE_T1_2,
+                                            AE_T2_0, AE_T2_1, AE_T2_2, AE_TRUNK, AE_TRUNK, AE_TRUNK, AE_PA0, AE_DA0};
+extern "C" const char *sfd2_range_tensor_name(int i)
+{
+    static const char *names[SFD2_RS_COUNT] = {"conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4.0.t1", "conv4.1.t1", "conv4.2.t1",
+                                               "conv4.0.t2", "conv4.1.t2", "conv4.2.t2", "conv4.0", "conv4.1", "conv4.2", "convPa.0", "convDa.0"};
+    return (i >= 0 && i < SFD2_RS_COUNT) ? names[i] : "";
+}
+
+int read_range_status(sfd2_ctx *c, sfd2_range_status *out, int reset)
+{
+    unsigned int raw[SFD2_RS_COUNT * SFD2_RANGE_SUB];
+    HIPCHECK(hipMemcpyAsync(raw, c->range_stat.p, sizeof(raw), hipMemcpyDeviceToHost, c->stream));
+    if (reset) HIPCHECK(hipMemsetAsync(c->range_stat.p, 0, sizeof(raw), c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    std::memset(out, 0, sizeof(*out));
+    out->n_tensors = SFD2_RS_COUNT;
+    for (int t = 0; t < SFD2_RS_COUNT; ++t) {
+        unsigned int m = 0;
+        for (int s = 0; s < SFD2_RANGE_SUB; ++s) m = std::max(m, raw[t * SFD2_RANGE_SUB + s]);
+        float f;
+        std::memcpy(&f, &m, 4);
+        f = std::max(f, c->range_hist[t]);
+        if (reset) c->range_hist[t] = 0.0f;
+        const int e = c->act_exp[kRsGroup[t]];
+        out->max_stored[t] = f;
+        out->max_value[t] = std::ldexp(f, -e);
+        out->exponent[t] = e;
+        if (f >= SFD2_C_SAT) out->saturated |= 1u << t;
+        if (f > 0.0f && f < 0.03125f) out->low |= 1u << t;
+    }
+    out->fallbacks = c->range_fallbacks;
+    return 0;
+}
+
+extern "C" int sfd2_get_range_status(sfd2_ctx *c, sfd2_range_status *out, int reset)
+{
+    if (!c || !out) return fail("sfd2_get_range_status: null argument");
+    HIPCHECK(hipSetDevice(c->device));
+    return read_range_status(c, out, reset);
+}
+
+int range_wants_fallback(sfd2_ctx *c)
+{
+    if (c->precision != SFD2_PREC_F16C || !c->opt_range_fallback || c->in_fallback) return 0;
+    unsigned int raw[SFD2_RS_COUNT * SFD2_RANGE_SUB];
+    HIPCHECK(hipMemcpyAsync(raw, c->range_stat.p, sizeof(raw), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    bool sat = false;
+    float mx[SFD2_RS_COUNT];
+    for (int t = 0; t < SFD2_RS_COUNT; ++t) {
+        unsigned int m = 0;
+        for (int s = 0; s < SFD2_RANGE_SUB; ++s) m = std::max(m, raw[t * SFD2_RANGE_SUB + s]);
+        std::memcpy(&mx[t], &m, 4);
+        sat = sat || mx[t] >= SFD2_C_SAT;
+    }
+    if (!sat) return 0;
+    for (int t = 0; t < SFD2_RS_COUNT; ++t) c->range_hist[t] = std::max(c->range_hist[t], mx[t]);   // the report keeps what happened
+    HIPCHECK(hipMemsetAsync(c->range_stat.p, 0, sizeof(raw), c->stream));                          // the next image starts clean
+    return 1;
 }

@@ -260,6 +260,14 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     }
     int n = 0;
     if (read_counts(c, cap_out, &n)) return -1;
+    {   // SFD2_PREC_F16C: a tensor reached the saturation of the compensated format -> this image again in the strict arithmetic
+        const int fb = range_wants_fallback(c);
+        if (fb < 0) return -1;
+        if (fb) {
+            FallbackScope scope(c);
+            return sfd2_extract(c, img, img_on_device, H, W, conf_th, top_k, flags, kpts_xy, scores, desc, out_on_device, cap_out, n_out);
+        }
+    }
     if (!direct && copy_out(c, kpts_xy, c->kpts.p, (size_t)n * 2 * sizeof(float), out_on_device)) return -1;
     if (!direct && copy_out(c, scores, c->kscores.p, (size_t)n * sizeof(float), out_on_device)) return -1;
     if (desc && desc_dst != desc && copy_out(c, desc, desc_dst, (size_t)n * 128 * sizeof(float), out_on_device)) return -1;
@@ -386,6 +394,15 @@ extern "C" int sfd2_extract_multiscale(sfd2_ctx *c, const void *img, int img_on_
     for (int l = 0; l < n_scales; ++l)
         if (c->ms_cand_seen[l] > (unsigned int)c->ms_cand_cap[l])
             return fail("candidate buffer overflow at pyramid level " + std::to_string(l));
+    {
+        const int fb = range_wants_fallback(c);
+        if (fb < 0) return -1;
+        if (fb) {
+            FallbackScope scope(c);
+            return sfd2_extract_multiscale(c, img, img_on_device, H, W, scales, n_scales, conf_th, top_k, flags, kpts_xy, scores, desc,
+                                           out_on_device, cap_out, n_out);
+        }
+    }
     const int64_t n = n_max > 0 ? (int64_t)n_dev : 0;
     if (!out_on_device) {
         if (copy_out(c, kpts_xy, kp_dst, (size_t)n * 2 * sizeof(float), 0)) return -1;
@@ -474,6 +491,14 @@ extern "C" int sfd2_extract_spp(sfd2_ctx *c, const float *x, int x_on_device, in
     prof_step_end(c);
     int n = 0;
     if (read_counts(c, cap_out, &n)) return -1;
+    {
+        const int fb = range_wants_fallback(c);
+        if (fb < 0) return -1;
+        if (fb) {
+            FallbackScope scope(c);
+            return sfd2_extract_spp(c, x, x_on_device, H, W, conf_th, flags, kpts_xy, scores, desc, cap_out, n_out, heat_out, desc_full_out);
+        }
+    }
     if (copy_out(c, kpts_xy, c->kpts.p, (size_t)n * 2 * sizeof(float), 0)) return -1;
     if (copy_out(c, scores, c->kscores.p, (size_t)n * sizeof(float), 0)) return -1;
     if (desc && n > 0) {
@@ -555,6 +580,14 @@ extern "C" int sfd2_extract_spp_levels(sfd2_ctx *c, const float *x, int x_on_dev
     lvl[0].release();
     lvl[1].release();
     if (rc == 0 && hipGetLastError() != hipSuccess) rc = fail("sfd2_extract_spp_levels: kernel launch failed");
+    if (rc == 0) {
+        const int fb = range_wants_fallback(c);
+        if (fb < 0) return -1;
+        if (fb) {
+            FallbackScope scope(c);
+            return sfd2_extract_spp_levels(c, x, x_on_device, H, W, n_levels, nh, nw, emit, conf_th, flags, kpts_xy, scores, desc, cap_out, level_count);
+        }
+    }
     return rc;
 }
 
@@ -667,6 +700,7 @@ extern "C" int sfd2_debug_activation(sfd2_ctx *c, const char *name, float *out, 
         if (a.f32) launch_nhwc_f_to_nchw_f(c->stream, reinterpret_cast<const float *>(a.p), np, a.pitch, a.c, c->tmp_f32.as<float>());
         else if (a.pc) launch_nhwc_hc_to_nchw_f(c->stream, reinterpret_cast<const half_t *>(a.p), reinterpret_cast<const half_t *>(a.pc), np, a.pitch, a.c, c->tmp_f32.as<float>());
         else launch_nhwc_h_to_nchw_f(c->stream, reinterpret_cast<const half_t *>(a.p), np, a.pitch, a.c, c->tmp_f32.as<float>());
+        if (a.exp2) launch_scale_inplace(c->stream, c->tmp_f32.as<float>(), n, std::ldexp(1.0f, -a.exp2));
         if (copy_out(c, out, c->tmp_f32.p, n * sizeof(float), 0)) return -1;
     }
     HIPCHECK(hipStreamSynchronize(c->stream));

@@ -67,6 +67,15 @@ int ensure_workspace(sfd2_ctx *c, int H, int W)
         // backbone activations of SFD2_PREC_F16C: the corr plane follows the hi plane
         if (comp && !is_f32 && std::strncmp(nm, "convP", 5) != 0 && std::strncmp(nm, "convD", 5) != 0)
             ai.pc = reinterpret_cast<const half_t *>(ptr) + (size_t)pitch * h * w;
+        if (!is_f32) {      // the fp16 family stores its tensors times 2^act_exp (sfd2_ctx.h): sfd2_debug_activation divides it out
+            static const struct { const char *name; int group; } gmap[] = {
+                {"conv1a", AE_CONV1A}, {"bn1b", AE_CONV1B}, {"conv2a", AE_CONV2A}, {"bn2b", AE_CONV2B}, {"conv3a", AE_CONV3A},
+                {"bn3b", AE_TRUNK}, {"conv4.0", AE_TRUNK}, {"conv4.1", AE_TRUNK}, {"conv4.2", AE_TRUNK},
+                {"conv4.0.bn1", AE_T1_0}, {"conv4.1.bn1", AE_T1_1}, {"conv4.2.bn1", AE_T1_2},
+                {"conv4.0.bn2", AE_T2_0}, {"conv4.1.bn2", AE_T2_1}, {"conv4.2.bn2", AE_T2_2}, {"convPa.0", AE_PA0}, {"convDa.0", AE_DA0}};
+            for (const auto &g : gmap)
+                if (std::strcmp(nm, g.name) == 0) ai.exp2 = c->act_exp[g.group];
+        }
         c->acts[nm] = ai;
     };
     static const char *n1[3] = {"conv4.0.bn1", "conv4.1.bn1", "conv4.2.bn1"};
@@ -158,10 +167,16 @@ static void conv(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &in
 
 // SFD2_PREC_F16C: one compensated layer.  A compensated tensor = hi plane followed by its corr plane; in_comp / out_comp
 // say which of the two tensors have one (a plain-fp16 consumer just reads the hi plane).
+// the range-status slot of a stored tensor of the compensated mode (sfd2_internal.h), null when nothing is recorded
+static unsigned int *range_slot(sfd2_ctx *c, int id)
+{
+    return (id >= 0 && c->range_stat.p) ? c->range_stat.as<unsigned int>() + id * SFD2_RANGE_SUB : nullptr;
+}
 static half_t *corr_of(const DevPtr &b, size_t px, int pitch) { return b.as<half_t>() + px * (size_t)pitch; }
 static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &in, int H, int W, const DevPtr &out,
-                  int Ho, int Wo, int relu, bool in_comp, bool out_comp, const DevPtr *res = nullptr)
+                  int Ho, int Wo, int relu, bool in_comp, bool out_comp, const DevPtr *res = nullptr, int rs_id = -1 /* SFD2_RS_*: the output's range-status slot */)
 {
+    unsigned int *rs = range_slot(c, rs_id);
     char kn[48];
     snprintf(kn, sizeof(kn), "convc_igemm<%d,%d>", L.ks, L.stride);
     const double px = (double)Ho * Wo;
@@ -176,14 +191,14 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &i
         const bool f6 = c->opt_fp6_filters && in_c && out_c && L.wc6.p && L.sa6.p;      // corr filters as fp6 (option "fp6_filters")
         launch_conv3x3_pp_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, f6 ? L.wc6.as<half_t>() : L.wc.as<half_t>(), L.scale.as<float>(),
                             L.shift.as<float>(), L.cout_pad, relu, out.as<half_t>(), out_c, Ho, Wo, c->zero_page.as<half_t>(), L.sbyte,
-                            f6 ? L.sa6.as<float>() : nullptr);
+                            f6 ? L.sa6.as<float>() : nullptr, rs);
         return;
     }
     if (!c->opt_generic_c && !c->opt_no_rf_c && in_c && out_c && !res && L.ks == 3 && L.stride == 2 && L.cout_pad == 128) {   // conv2b
         ProfScope ps(c, name, "conv3x3_rf<2,comp>", flops, bytes);
         if (!launch_conv3x3_rf_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, L.wc.as<half_t>(), L.scale.as<float>(),
                                 L.shift.as<float>(), L.cout_pad, L.stride, relu, out.as<half_t>(), out_c, Ho, Wo,
-                                c->zero_page.as<half_t>(), L.sbyte))
+                                c->zero_page.as<half_t>(), L.sbyte, rs))
             ps.cancel();     // no instantiation for this geometry: the next candidate takes the layer (and the profile row)
         else
             return;
@@ -194,7 +209,7 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &i
         launch_conv1x1_c256_c(c->cur_stream, in.as<half_t>(), in_c, Ho * Wo, L.wfh.as<half_t>(), L.wfc.as<half_t>(), L.scale.as<float>(),
                               L.shift.as<float>(), relu, res ? res->as<half_t>() : nullptr,
                               res ? corr_of(*res, (size_t)Ho * Wo, L.cout_pad) : nullptr, out.as<half_t>(), out_c,
-                              c->zero_page.as<half_t>(), L.sbyte);
+                              c->zero_page.as<half_t>(), L.sbyte, rs);
         return;
     }
     if (!c->opt_generic_c && in_c && out_c && L.cout_pad % 128 == 0 && ((L.ks == 1 && L.stride == 1) || (L.ks == 3 && L.stride == 2 && !res))) {
@@ -203,7 +218,7 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &i
         if (!launch_conv_igemm2_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, L.wc.as<half_t>(), L.scale.as<float>(),
                                  L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu, res ? res->as<half_t>() : nullptr,
                                  res ? corr_of(*res, (size_t)Ho * Wo, L.cout_pad) : nullptr, out.as<half_t>(), out_c, Ho, Wo,
-                                 c->zero_page.as<half_t>(), L.sbyte))
+                                 c->zero_page.as<half_t>(), L.sbyte, rs))
             ps.cancel();
         else
             return;
@@ -213,7 +228,7 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &i
     launch_convc_igemm(c->cur_stream, in.as<half_t>(), in_comp ? corr_of(in, (size_t)H * W, L.cin) : nullptr, H, W, L.cin,
                        L.wc.as<half_t>(), L.scale.as<float>(), L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu,
                        res ? res->as<half_t>() : nullptr, res ? corr_of(*res, (size_t)Ho * Wo, L.cout_pad) : nullptr,
-                       out.as<half_t>(), out_comp ? corr_of(out, (size_t)Ho * Wo, L.cout_pad) : nullptr, Ho, Wo, L.sbyte);
+                       out.as<half_t>(), out_comp ? corr_of(out, (size_t)Ho * Wo, L.cout_pad) : nullptr, Ho, Wo, L.sbyte, rs);
 }
 
 // which throughput kernel takes a layer of SFD2_PREC_F16X3 from hi / lo' planes: 0 none (generic, fp32 in / out), 1 conv3x3_pp, 2 conv3x3_rf
@@ -426,6 +441,7 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
 int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
 {
     c->cur_stream = c->stream;
+    g_sfd2_cu_limit = c->opt_cu_limit;
     if (c->precision == SFD2_PREC_F32 || c->precision == SFD2_PREC_F16X3) return run_network_f32(c, img_dev, normalise);
     const bool comp = c->precision == SFD2_PREC_F16C;
     hipStream_t st = c->stream;
@@ -509,19 +525,19 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                          P1 * 12 + (double)H2 * W2 * 256);
             launch_fused_stem_c(st, img_dev, H, W, normalise, c->c1a.wc.as<half_t>(), c->c1a.scale.as<float>(),
                                 c->c1a.shift.as<float>(), c->w1b_stem_c.p, c->c1b.scale.as<float>(), c->c1b.shift.as<float>(),
-                                a1b.as<half_t>(), corr_of(a1b, (size_t)H2 * W2, 64), H2, W2, c->c1b.sbyte);
+                                a1b.as<half_t>(), corr_of(a1b, (size_t)H2 * W2, 64), H2, W2, c->c1b.sbyte, c->range_stat.as<unsigned int>());
         } else {
             {
                 ProfScope ps(c, "conv1a", "conv1a_c_kernel", 2.0 * P1 * 64 * 27, P1 * (12 + 256));
                 launch_conv1a_c(st, img_dev, H, W, normalise, c->c1a.wc.as<half_t>(), c->c1a.scale.as<float>(),
-                                c->c1a.shift.as<float>(), c->a1a.as<half_t>(), corr_of(c->a1a, (size_t)H * W, 64));
+                                c->c1a.shift.as<float>(), c->a1a.as<half_t>(), corr_of(c->a1a, (size_t)H * W, 64), range_slot(c, SFD2_RS_CONV1A));
             }
-            convc(c, "conv1b", c->c1b, c->a1a, H, W, a1b, H2, W2, 1, true, true);
+            convc(c, "conv1b", c->c1b, c->a1a, H, W, a1b, H2, W2, 1, true, true, nullptr, SFD2_RS_CONV1B);
         }
-        convc(c, "conv2a", c->c2a, a1b, H2, W2, a2a, H2, W2, 1, true, true);
-        convc(c, "conv2b", c->c2b, a2a, H2, W2, a2b, H4, W4, 1, true, true);
-        convc(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1, true, true);
-        convc(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1, true, true);
+        convc(c, "conv2a", c->c2a, a1b, H2, W2, a2a, H2, W2, 1, true, true, nullptr, SFD2_RS_CONV2A);
+        convc(c, "conv2b", c->c2b, a2a, H2, W2, a2b, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV2B);
+        convc(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV3A);
+        convc(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV3B);
         for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
             if (!c->opt_comp_rb) { rb_f16(b); continue; }   // option "comp_rb" = 0: this block in plain fp16 on the hi planes
             DevPtr &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];
@@ -542,28 +558,30 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                     ProfScope ps(c, nm1[b], "conv1x1_c256<comp,plain out>", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 6);
                     launch_conv1x1_c256_c(st, x->as<half_t>(), corr_of(*x, PP, 256), (int)PP, L1.wfh.as<half_t>(), L1.wfc.as<half_t>(),
                                           L1.scale.as<float>(), L1.shift.as<float>(), 1, nullptr, nullptr, t1.as<half_t>(), nullptr,
-                                          c->zero_page.as<half_t>(), L1.sbyte);
+                                          c->zero_page.as<half_t>(), L1.sbyte, range_slot(c, SFD2_RS_T1_0 + b));
                 } else {
-                    convc(c, nm1[b], L1, *x, H4, W4, t1, H4, W4, 1, true, true);
+                    convc(c, nm1[b], L1, *x, H4, W4, t1, H4, W4, 1, true, true, nullptr, SFD2_RS_T1_0 + b);
                 }
                 if (t1p && c->opt_fuse_rb23) {
                     ProfScope ps(c, nm3[b], "rb23_c_kernel", 2.0 * P4 * 256 * 72 + 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 10);
                     launch_rb23_c(st, t1.as<half_t>(), H4, W4, L2.w.as<half_t>(), L2.wlk.as<half_t>(), L2.scale.as<float>(), L2.shift.as<float>(),
                                   L3.wfh.as<half_t>(), L3.wfl.as<half_t>(), L3.scale.as<float>(), L3.shift.as<float>(), x->as<half_t>(),
-                                  corr_of(*x, PP, 256), ob.as<half_t>(), corr_of(ob, PP, 256), c->zero_page.as<half_t>());
+                                  corr_of(*x, PP, 256), ob.as<half_t>(), corr_of(ob, PP, 256), c->zero_page.as<half_t>(),
+                                  range_slot(c, SFD2_RS_T2_0 + b), range_slot(c, SFD2_RS_OUT_0 + b));
                     x = &ob;
                     continue;
                 }
                 {
                     ProfScope ps(c, nm2[b], t1p ? "gconv_c_kernel<plain>" : "gconv_c_kernel<plain out>", 2.0 * P4 * 256 * 72, P4 * 256 * (t1p ? 4 : 6));
                     launch_gconv_c(st, t1.as<half_t>(), t1p ? nullptr : corr_of(t1, PP, 256), H4, W4, L2.w.as<half_t>(),
-                                   t1p ? L2.wlk.p : L2.wc.p, L2.scale.as<float>(), L2.shift.as<float>(), t2.as<half_t>(), nullptr, L2.sbyte, 0, H4);
+                                   t1p ? L2.wlk.p : L2.wc.p, L2.scale.as<float>(), L2.shift.as<float>(), t2.as<half_t>(), nullptr, L2.sbyte, 0, H4,
+                                   range_slot(c, SFD2_RS_T2_0 + b));
                 }
                 {
                     ProfScope ps(c, nm3[b], "conv1x1_c256<comp,plain in>+res", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 10);
                     launch_conv1x1_c256_c(st, t2.as<half_t>(), nullptr, (int)PP, L3.wfh.as<half_t>(), L3.wfl.as<half_t>(), L3.scale.as<float>(),
                                           L3.shift.as<float>(), 1, x->as<half_t>(), corr_of(*x, PP, 256), ob.as<half_t>(), corr_of(ob, PP, 256),
-                                          c->zero_page.as<half_t>(), L3.sbyte);
+                                          c->zero_page.as<half_t>(), L3.sbyte, range_slot(c, SFD2_RS_OUT_0 + b));
                 }
             } else {
                 {
@@ -571,14 +589,14 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                     if (i1 != c->acts.end() && i1->second.p == t1.p) i1->second.pc = corr_of(t1, (size_t)H4 * W4, 256);
                     if (i2 != c->acts.end() && i2->second.p == t2.p) { i2->second.pc = corr_of(t2, (size_t)H4 * W4, 256); i2->second.absent = false; }
                 }
-                convc(c, nm1[b], c->rb1[b], *x, H4, W4, t1, H4, W4, 1, true, true);
+                convc(c, nm1[b], c->rb1[b], *x, H4, W4, t1, H4, W4, 1, true, true, nullptr, SFD2_RS_T1_0 + b);
                 {
                     ProfScope ps(c, nm2[b], "gconv_c_kernel", 2.0 * P4 * 256 * 72, P4 * 256 * 8);
                     launch_gconv_c(st, t1.as<half_t>(), corr_of(t1, (size_t)H4 * W4, 256), H4, W4, c->rb2[b].w.as<half_t>(),
                                    c->rb2[b].wc.p, c->rb2[b].scale.as<float>(), c->rb2[b].shift.as<float>(), t2.as<half_t>(),
-                                   corr_of(t2, (size_t)H4 * W4, 256), c->rb2[b].sbyte, 0, H4);
+                                   corr_of(t2, (size_t)H4 * W4, 256), c->rb2[b].sbyte, 0, H4, range_slot(c, SFD2_RS_T2_0 + b));
                 }
-                convc(c, nm3[b], c->rb3[b], t2, H4, W4, ob, H4, W4, 1, true, true, x);
+                convc(c, nm3[b], c->rb3[b], t2, H4, W4, ob, H4, W4, 1, true, true, x, SFD2_RS_OUT_0 + b);
             }
             x = &ob;
         }
@@ -612,7 +630,7 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     const bool sta_early = alias && c->skip_pb_now;
     if (c->has_sta && sta_early) {
         ProfScope ps(c, "ConvSta", "convsta_kernel", 2.0 * P4 * 3 * 256, P4 * (512 + 12));
-        launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
+        launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w16.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
     }
     const bool fork = c->opt_branches != 0;
     if (fork) {
@@ -622,9 +640,11 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     }
     // option "comp_heads": the four 3x3 layers of the head branches compensated as well (their inputs then need corr planes: the
     // backbone output has one when the ResBlocks are compensated); convPb / convDb / ConvSta read hi planes either way
+    // option "comp_det": the detector branch only (convPa.0, convPa.3) -- its score goes through exp(), which is what moves key points
     const bool ch = comp && c->opt_comp_heads && c->opt_comp_rb;
-    if (ch) {
-        convc(c, "convPa.0", c->pa0, *x, H4, W4, pa0_o, H8, W8, 1, true, true);
+    const bool chp = ch || (comp && c->opt_comp_det && c->opt_comp_rb);
+    if (chp) {
+        convc(c, "convPa.0", c->pa0, *x, H4, W4, pa0_o, H8, W8, 1, true, true, nullptr, SFD2_RS_PA0);
         convc(c, "convPa.3", c->pa3, pa0_o, H8, W8, pa_o, H8, W8, 0, true, false);
     } else {
         conv(c, "convPa.0", c->pa0, *x, H4, W4, pa0_o, H8, W8, 1);
@@ -641,7 +661,7 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         c->cur_stream = st;
     }
     if (ch) {
-        convc(c, "convDa.0", c->da0, *x, H4, W4, da0_o, H4, W4, 1, true, true);
+        convc(c, "convDa.0", c->da0, *x, H4, W4, da0_o, H4, W4, 1, true, true, nullptr, SFD2_RS_DA0);
         convc(c, "convDa.3", c->da3, da0_o, H4, W4, da_o, H4, W4, 0, true, false);
     } else {
         conv(c, "convDa.0", c->da0, *x, H4, W4, da0_o, H4, W4, 1);
@@ -652,7 +672,7 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     if (!c->skip_db_now) conv(c, "convDb", c->db, da_o, H4, W4, c->draw, H4, W4, 0, nullptr, 1);
     if (c->has_sta && !sta_early) {
         ProfScope ps(c, "ConvSta", "convsta_kernel", 2.0 * P4 * 3 * 256, P4 * (512 + 12));
-        launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
+        launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w16.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
     }
     if (fork) HIPCHECK(hipStreamWaitEvent(st, c->ev_join, 0));
     HIPCHECK(hipGetLastError());

@@ -2,7 +2,12 @@
 #include "sfd2_ctx.h"
 
 // ------------------------------------------------------------------------------------------ weights
-struct TView { const float *d; std::vector<int64_t> shape; size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; } };
+struct TView {
+    const float *d;
+    std::vector<int64_t> shape;
+    std::vector<int> ec;       // conv filters after normalise_filters: d holds w[oc] * 2^-ec[oc]; fold_scale_shift puts 2^ec[oc] into the scale
+    size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
+};
 typedef std::map<std::string, TView> TMap;
 
 static const TView *find_t(const TMap &m, const std::string &k)
@@ -19,6 +24,22 @@ static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st)
     return 0;
 }
 
+static float ec_factor(const TMap &m, const std::string &conv, int c)
+{
+    const TView *w = find_t(m, conv + ".weight");
+    return (w && (size_t)c < w->ec.size()) ? std::ldexp(1.0f, w->ec[c]) : 1.0f;
+}
+
+// the folded epilogue constants of a layer: host copies stay with the layer (the activation exponents of the fp16 family are
+// applied to them later: apply_act_exponents)
+static int set_scale_shift(sfd2_ctx *c, ConvW &L, const std::vector<float> &sc, const std::vector<float> &sh)
+{
+    L.h_scale = sc;
+    L.h_shift = sh;
+    if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
+    return upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream);
+}
+
 // y = scale * conv_nobias(x) + shift  with conv bias and BatchNorm(eval, eps 1e-5) folded:
 //   BN(affine=False): (x + b - mean) / sqrt(var + eps)                         nets/sfd2.py:58-65
 //   BN(affine):       gamma * (x + b - mean) / sqrt(var + eps) + beta           nets/sfd2.py:286-296, :25-55
@@ -30,7 +51,7 @@ static int fold_scale_shift(const TMap &m, const std::string &conv, const std::s
     const TView *bias = find_t(m, conv + ".bias");
     if (bias && (int)bias->numel() != cout) return fail("bad bias shape for " + conv);
     if (bn.empty()) {
-        for (int c = 0; c < cout; ++c) shift[c] = bias ? bias->d[c] : 0.0f;
+        for (int c = 0; c < cout; ++c) { scale[c] = ec_factor(m, conv, c); shift[c] = bias ? bias->d[c] : 0.0f; }
         return 0;
     }
     const TView *mean = find_t(m, bn + ".running_mean"), *var = find_t(m, bn + ".running_var");
@@ -41,10 +62,38 @@ static int fold_scale_shift(const TMap &m, const std::string &conv, const std::s
         const float inv = 1.0f / std::sqrt(var->d[c] + 1e-5f);
         const float a = gamma ? gamma->d[c] * inv : inv;
         const float b = bias ? bias->d[c] : 0.0f;
-        scale[c] = a;
+        scale[c] = a * ec_factor(m, conv, c);      // (a power of two: exact)
         shift[c] = (beta ? beta->d[c] : 0.0f) + (b - mean->d[c]) * a;
     }
     return 0;
+}
+
+// Per-output-channel power-of-two normalisation of a conv layer's filters: w'[oc] = w[oc] * 2^-ec[oc] with max|w'[oc]| in [1, 2),
+// and 2^ec[oc] goes into the folded scale.  Exact in every mode (products and fp32 sums scale by the same power of two, the
+// epilogue's acc * scale is the same number), so a well-conditioned checkpoint gives the same bits as without it.  What it buys:
+// a TRAINED checkpoint has no reason to keep its filters in fp16's comfortable range -- weight decay under a BatchNorm shrinks a
+// channel's filter freely (running_var follows), and below 6e-5 the fp16 parts go subnormal, the e4m3 correction units of a
+// channel 2^-9 of the layer's largest vanish altogether.  After the normalisation every channel uses the full range of both.
+static void normalise_filters(TMap &m, const std::string &conv, std::vector<std::vector<float>> &owned)
+{
+    auto it = m.find(conv + ".weight");
+    if (it == m.end() || it->second.shape.size() != 4) return;
+    TView &w = it->second;
+    const size_t cout = (size_t)w.shape[0], per = w.numel() / std::max<size_t>(cout, 1);
+    owned.emplace_back(w.d, w.d + w.numel());
+    std::vector<float> &o = owned.back();
+    w.ec.assign(cout, 0);
+    for (size_t oc = 0; oc < cout; ++oc) {
+        float mx = 0.0f;
+        for (size_t i = 0; i < per; ++i) mx = std::max(mx, std::fabs(o[oc * per + i]));
+        if (!(mx > 0.0f) || !std::isfinite(mx)) continue;
+        int e = 0;
+        (void)std::frexp(mx, &e);                 // mx = f * 2^e, f in [0.5, 1)  ->  mx * 2^-(e - 1) in [1, 2)
+        e = std::max(-100, std::min(100, e - 1));
+        w.ec[oc] = e;
+        for (size_t i = 0; i < per; ++i) o[oc * per + i] = std::ldexp(o[oc * per + i], -e);
+    }
+    w.d = o.data();
 }
 
 // OCP fp8 e4m3fn, round to nearest even, saturating at +-448 (the filters' corr units of SFD2_PREC_F16C)
@@ -122,8 +171,7 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
     std::vector<float> sc, sh;
     if (fold_scale_shift(m, conv, bn, cout, cout_pad, sc, sh)) return -1;
     if (upload(L.w, pk.data(), pk.size() * sizeof(half_t), c->stream)) return -1;
-    if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
-    if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+    if (set_scale_shift(c, L, sc, sh)) return -1;
     if (ks == 1 && stride == 1 && cin == 256 && cout == 256) {
         std::vector<half_t> rm((size_t)256 * 256);
         for (size_t i = 0; i < rm.size(); ++i) rm[i] = (half_t)w->d[i];
@@ -192,6 +240,7 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
                         }
                     }
             if (upload(L.wc6, p6.data(), p6.size() * 2, c->stream)) return -1;
+            L.h_sa6 = sa;
             if (upload(L.sa6, sa.data(), sa.size() * sizeof(int), c->stream)) return -1;
         }
         if (ks == 1 && stride == 1 && cin == 256 && cout == 256) {
@@ -239,8 +288,7 @@ static int pack_conv1a(sfd2_ctx *c, const TMap &m)
     std::vector<float> sc, sh;
     if (fold_scale_shift(m, "conv1a.0", "conv1a.1", 64, 64, sc, sh)) return -1;
     if (upload(L.w, pk.data(), pk.size() * sizeof(half_t), c->stream)) return -1;
-    if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
-    if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+    if (set_scale_shift(c, L, sc, sh)) return -1;
     {   // SFD2_PREC_F16C: the same fragments (hi) followed by fp16(w - hi) (lo)
         std::vector<half_t> pc(2 * pk.size(), (half_t)0.0f);
         for (int ct = 0; ct < 2; ++ct)
@@ -286,8 +334,7 @@ static int pack_gconv(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
     std::vector<float> sc, sh;
     if (fold_scale_shift(m, conv, bn, 256, 256, sc, sh)) return -1;
     if (upload(L.w, pk.data(), pk.size() * sizeof(half_t), c->stream)) return -1;
-    if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
-    if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+    if (set_scale_shift(c, L, sc, sh)) return -1;
     std::vector<half_t> cp((size_t)256 * 9 * 8);
     for (int oc = 0; oc < 256; ++oc)
         for (int tap = 0; tap < 9; ++tap)
@@ -337,8 +384,7 @@ static int pack_igemm_f32(sfd2_ctx *c, const TMap &m, ConvW &L, const std::strin
     std::vector<float> sc, sh;
     if (fold_scale_shift(m, conv, bn, cout, cout_pad, sc, sh)) return -1;
     if (upload(L.w, pk.data(), pk.size() * sizeof(float), c->stream)) return -1;
-    if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
-    if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+    if (set_scale_shift(c, L, sc, sh)) return -1;
     return 0;
 }
 
@@ -351,8 +397,7 @@ static int pack_raw_f32(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string 
     std::vector<float> sc, sh;
     if (fold_scale_shift(m, conv, bn, cout, cout, sc, sh)) return -1;
     if (upload(L.w, w->d, numel * sizeof(float), c->stream)) return -1;
-    if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
-    if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+    if (set_scale_shift(c, L, sc, sh)) return -1;
     return 0;
 }
 
@@ -379,6 +424,8 @@ static int pack_all_f32(sfd2_ctx *c, const TMap &m)
     return 0;
 }
 
+static int calibrate_on_probe(sfd2_ctx *c);
+
 extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
 {
     if (!c || !tensors) return fail("sfd2_load_weights: null argument");
@@ -399,6 +446,15 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
         v.d = tensors[i].data;
         for (int d = 0; d < tensors[i].ndim && d < 4; ++d) v.shape.push_back(tensors[i].shape[d]);
         m[tensors[i].name] = v;
+    }
+    std::vector<std::vector<float>> owned;     // the normalised filter copies m points into from here on
+    owned.reserve(32);
+    {
+        static const char *convs[] = {"conv1a.0", "conv1b.0", "conv2a.0", "conv2b.0", "conv3a.0", "conv3b.0", "convPa.0", "convPa.3",
+                                      "convDa.0", "convDa.3", "convPb", "convDb"};
+        for (const char *n : convs) normalise_filters(m, n, owned);
+        for (int b = 0; b < 3; ++b)
+            for (int i = 1; i <= 3; ++i) normalise_filters(m, "conv4." + std::to_string(b) + ".conv" + std::to_string(i), owned);
     }
     if (pack_conv1a(c, m)) return -1;
     if (pack_igemm(c, m, c->c1b, "conv1b.0", "bn1b.0", 64, 64, 3, 2)) return -1;
@@ -468,11 +524,146 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
     if (sw || sb) {
         if (!sw || !sb) return fail("missing tensor: ConvSta.{weight,bias} (only one of the two is present)");
         if (sw->numel() != 3 * 256 || sb->numel() != 3) return fail("bad shape for ConvSta");
+        c->h_sta_w.assign(sw->d, sw->d + 3 * 256);
         if (upload(c->sta_w, sw->d, 3 * 256 * sizeof(float), c->stream)) return -1;
         if (upload(c->sta_b, sb->d, 3 * sizeof(float), c->stream)) return -1;
         c->has_sta = true;
     }
     if (pack_all_f32(c, m)) return -1;
+    for (int g = 0; g < AE_COUNT; ++g) { c->act_exp[g] = 0; c->act_max[g] = 0.0f; }
     c->weights_loaded = true;
+    if (apply_act_exponents(c)) { c->weights_loaded = false; return -1; }
+    if (c->opt_auto_range && calibrate_on_probe(c)) { c->weights_loaded = false; return -1; }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------ activation exponents
+int apply_act_exponents(sfd2_ctx *c)
+{
+    struct Row { ConvW *L; int e_in, e_out; };
+    const int *e = c->act_exp;
+    std::vector<Row> rows = {
+        {&c->c1a, -1, AE_CONV1A}, {&c->c1b, AE_CONV1A, AE_CONV1B}, {&c->c2a, AE_CONV1B, AE_CONV2A}, {&c->c2b, AE_CONV2A, AE_CONV2B},
+        {&c->c3a, AE_CONV2B, AE_CONV3A}, {&c->c3b, AE_CONV3A, AE_TRUNK}, {&c->pa0, AE_TRUNK, AE_PA0}, {&c->pa3, AE_PA0, -1},
+        {&c->da0, AE_TRUNK, AE_DA0}, {&c->da3, AE_DA0, -1}};
+    for (int b = 0; b < 3; ++b) {
+        rows.push_back({&c->rb1[b], AE_TRUNK, AE_T1_0 + b});
+        rows.push_back({&c->rb2[b], AE_T1_0 + b, AE_T2_0 + b});
+        rows.push_back({&c->rb3[b], AE_T2_0 + b, AE_TRUNK});
+    }
+    std::vector<float> sc, sh;
+    for (const Row &r : rows) {
+        ConvW &L = *r.L;
+        if (L.h_scale.empty()) continue;
+        const int ei = r.e_in >= 0 ? e[r.e_in] : 0, eo = r.e_out >= 0 ? e[r.e_out] : 0;
+        sc = L.h_scale; sh = L.h_shift;
+        for (float &v : sc) v = std::ldexp(v, eo - ei);
+        for (float &v : sh) v = std::ldexp(v, eo);
+        if (upload(L.scale, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
+        if (upload(L.shift, sh.data(), sh.size() * sizeof(float), c->stream)) return -1;
+        if (!L.h_sa6.empty() && L.sa6.p) {          // conv3x3_pp's fp6 form keeps its own copy of the shifts
+            std::vector<int> sa = L.h_sa6;
+            std::memcpy(sa.data(), sh.data(), std::min(sh.size(), sa.size() / 2) * sizeof(float));
+            if (upload(L.sa6, sa.data(), sa.size() * sizeof(int), c->stream)) return -1;
+        }
+    }
+    if (c->has_sta && !c->h_sta_w.empty()) {        // ConvSta reads the backbone output with fp32 filters of its own
+        std::vector<float> w = c->h_sta_w;
+        for (float &v : w) v = std::ldexp(v, -e[AE_TRUNK]);
+        if (upload(c->sta_w16, w.data(), w.size() * sizeof(float), c->stream)) return -1;
+    }
+    graphs_release(c);      // (captured units hold nothing of this by value, but a unit captured mid-way must not survive a change of scale)
+    return 0;
+}
+
+// Range calibration.  The image goes through the network ONCE in SFD2_PREC_F32 on the parity entry point (every activation in its
+// own fp32 buffer, at the network's own scale), the largest |x| of every stored tensor is reduced on the device, and each group's
+// exponent becomes the power of two that brings that maximum to SFD2_RANGE_TARGET.  One pass: the fp32 tensors do not depend on
+// the exponents.  The CPU study of the compensated mode (tools/conditioning_sweep.py) has descriptors within
+// 5e-4 for tensor maxima from 0.2 to 500, 1.1e-3 at 0.03 and a cliff above 1792: 16 sits 2^7 below the cliff and 2^9 above the floor.
+#define SFD2_RANGE_TARGET 16.0f
+static int calibrate_impl(sfd2_ctx *c, const float *img, int on_device, int H, int W, int flags)
+{
+    if (!c->weights_loaded) return fail("sfd2_calibrate_range: weights not loaded");
+    HIPCHECK(hipSetDevice(c->device));
+    const int prec = c->precision;
+    c->precision = SFD2_PREC_F32;
+    const int rc = sfd2_det(c, img, on_device, H, W, flags, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
+    c->precision = prec;
+    if (rc) return -1;
+    HIPCHECK(c->range_scratch.ensure(AE_COUNT * sizeof(unsigned int)));
+    HIPCHECK(hipMemsetAsync(c->range_scratch.p, 0, AE_COUNT * sizeof(unsigned int), c->stream));
+    static const struct { const char *name; int group; } tens[] = {
+        {"conv1a", AE_CONV1A}, {"bn1b", AE_CONV1B}, {"conv2a", AE_CONV2A}, {"bn2b", AE_CONV2B}, {"conv3a", AE_CONV3A},
+        {"bn3b", AE_TRUNK}, {"conv4.0", AE_TRUNK}, {"conv4.1", AE_TRUNK}, {"conv4.2", AE_TRUNK},
+        {"conv4.0.bn1", AE_T1_0}, {"conv4.1.bn1", AE_T1_1}, {"conv4.2.bn1", AE_T1_2},
+        {"conv4.0.bn2", AE_T2_0}, {"conv4.1.bn2", AE_T2_1}, {"conv4.2.bn2", AE_T2_2}, {"convPa.0", AE_PA0}, {"convDa.0", AE_DA0}};
+    for (const auto &t : tens) {
+        auto it = c->acts.find(t.name);
+        if (it == c->acts.end() || !it->second.f32 || it->second.planar || it->second.pitch != it->second.c)
+            return fail(std::string("sfd2_calibrate_range: activation not available: ") + t.name);
+        launch_absmax_f32(c->stream, reinterpret_cast<const float *>(it->second.p), (size_t)it->second.c * it->second.h * it->second.w,
+                          c->range_scratch.as<unsigned int>() + t.group);
+    }
+    HIPCHECK(hipGetLastError());
+    float mx[AE_COUNT];
+    HIPCHECK(hipMemcpyAsync(mx, c->range_scratch.p, sizeof(mx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    for (int g = 0; g < AE_COUNT; ++g) {
+        c->act_max[g] = mx[g];
+        int e = 0;
+        if (mx[g] > 0.0f && std::isfinite(mx[g])) e = (int)std::lround(std::log2(SFD2_RANGE_TARGET / mx[g]));
+        c->act_exp[g] = std::max(-60, std::min(60, e));
+    }
+    return apply_act_exponents(c);
+}
+
+extern "C" int sfd2_calibrate_range(sfd2_ctx *c, const float *img, int img_on_device, int H, int W, int flags)
+{
+    if (!c || !img) return fail("sfd2_calibrate_range: null argument");
+    return calibrate_impl(c, img, img_on_device, H, W, flags);
+}
+
+extern "C" int sfd2_get_act_exponents(sfd2_ctx *c, int32_t *exps, float *maxima, int cap, int *n)
+{
+    if (!c || !n) return fail("sfd2_get_act_exponents: null argument");
+    *n = AE_COUNT;
+    for (int g = 0; g < AE_COUNT && g < cap; ++g) {
+        if (exps) exps[g] = c->act_exp[g];
+        if (maxima) maxima[g] = c->act_max[g];
+    }
+    return 0;
+}
+
+extern "C" int sfd2_set_act_exponents(sfd2_ctx *c, const int32_t *exps, int n)
+{
+    if (!c || (n > 0 && !exps)) return fail("sfd2_set_act_exponents: null argument");
+    if (!c->weights_loaded) return fail("sfd2_set_act_exponents: weights not loaded");
+    if (n != 0 && n != AE_COUNT) return fail("sfd2_set_act_exponents: expected " + std::to_string((int)AE_COUNT) + " exponents (or 0 to clear)");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    for (int g = 0; g < AE_COUNT; ++g) {
+        const int e = n ? exps[g] : 0;
+        if (e < -60 || e > 60) return fail("sfd2_set_act_exponents: exponent out of range");
+        c->act_exp[g] = e;
+    }
+    return apply_act_exponents(c);
+}
+
+// The built-in probe: 192 x 256, half white noise and half a blocky low-frequency field (like the synthetic images of the tests), from
+// a fixed xorshift stream -- what sfd2_load_weights calibrates on when nothing better has been shown to the context yet.  A network
+// with BatchNorm after every conv keeps its activations at the same order of magnitude on any image; the envelope is 2^12 wide.
+static int calibrate_on_probe(sfd2_ctx *c)
+{
+    const int H = 192, W = 256;
+    std::vector<float> img((size_t)3 * H * W);
+    unsigned int s = 0x9E3779B9u;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return (float)(s >> 8) * (1.0f / 16777216.0f); };
+    std::vector<float> coarse((size_t)3 * (H / 16) * (W / 16));
+    for (float &v : coarse) v = rnd();
+    for (int ch = 0; ch < 3; ++ch)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x)
+                img[((size_t)ch * H + y) * W + x] = 0.5f * rnd() + 0.5f * coarse[((size_t)ch * (H / 16) + y / 16) * (W / 16) + x / 16];
+    return calibrate_impl(c, img.data(), 0, H, W, 0);
 }

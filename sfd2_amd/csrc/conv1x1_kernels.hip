@@ -217,7 +217,7 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
                            const float *__restrict__ scale, const float *__restrict__ shift, int relu,
                            const half_t *__restrict__ res, const half_t *__restrict__ res_c,
                            half_t *__restrict__ out, half_t *__restrict__ out_c, int groups_per_block,
-                           const half_t *__restrict__ zero_page, int sa)
+                           const half_t *__restrict__ zero_page, int sa, unsigned int *__restrict__ range /* the output tensor's range-status slot */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Xs = smem;                                              // [NST][hi 32 x 512 B | corr 32 x 512 B]
@@ -270,6 +270,7 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
     if (g0 + 2 < g1) { ISSUE_GC(g0 + 2) }
     SFD2_BARRIER_DRAIN();
 
+    float mx = 0.0f;     // range status: the largest output value in front of the saturation
     for (int g = g0; g < g1; ++g) {
         if (g != g0) {
             if (g + 2 < g1) WAIT_GROUP_C(); else SFD2_BARRIER_DRAIN();
@@ -351,7 +352,7 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
                     ad = make_float4((float)r[0] + sfd2_corr_lo(rcp[j].x, 0), (float)r[1] + sfd2_corr_lo(rcp[j].x, 1),
                                      (float)r[2] + sfd2_corr_lo(rcp[j].y, 0), (float)r[3] + sfd2_corr_lo(rcp[j].y, 1));
                 }
-                sfd2_epi4<HAS_RES>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], sc, sh, ad, relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j]);
+                sfd2_epi4<HAS_RES>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], sc, sh, ad, relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j], mx, inb);
             }
             const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
             const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
@@ -363,6 +364,7 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
             }
         }
     }
+    sfd2_range_commit(range, sfd2_wave_max_bits(mx));
 #undef ISSUE_GC
 #undef WAIT_GROUP_C
 }
@@ -572,7 +574,7 @@ void launch_conv1x1_c256_x3(hipStream_t st, const half_t *in, const half_t *in_l
 
 void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c, int npix, const half_t *w_frag,
                            const half_t *wc_frag, const float *scale, const float *shift, int relu, const half_t *res,
-                           const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte)
+                           const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte, unsigned int *range)
 // in_c == null: plain fp16 input, wc_frag = the fp16 filter residuals * 2^11; out_c == null: only the hi plane is written
 {
     static bool attr_done = false;
@@ -593,7 +595,7 @@ void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c,
     const int gpb = (ngroups + sfd2_slots(slots) - 1) / sfd2_slots(slots);
     const int grid = (ngroups + gpb - 1) / gpb;
     const int sa = (sbyte & 255) * 0x01010101;
-#define C256C_GO(R_, I_, O_) hipLaunchKernelGGL((conv1x1_c256_c_kernel<R_, I_, O_>), dim3(grid), dim3(NT1), lds, st, in, in_c, npix, w_frag, wc_frag, scale, shift, relu, res, res_c, out, out_c, gpb, zero_page, sa)
+#define C256C_GO(R_, I_, O_) hipLaunchKernelGGL((conv1x1_c256_c_kernel<R_, I_, O_>), dim3(grid), dim3(NT1), lds, st, in, in_c, npix, w_frag, wc_frag, scale, shift, relu, res, res_c, out, out_c, gpb, zero_page, sa, range)
     if (in_c && out_c) { if (res) C256C_GO(true, true, true); else C256C_GO(false, true, true); }
     else if (in_c && !res) C256C_GO(false, true, false);           // ResBlock.conv1 writing a plain t1
     else if (!in_c && out_c && res) C256C_GO(true, false, true);   // ResBlock.conv3 reading a plain t2

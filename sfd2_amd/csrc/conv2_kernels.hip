@@ -47,7 +47,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                         const half_t *__restrict__ res, void *__restrict__ outv,
                         int Ho, int Wo, int tiles_x, const half_t *__restrict__ zero_page,
                         const half_t *__restrict__ in_c = nullptr, const half_t *__restrict__ res_c = nullptr,
-                        half_t *__restrict__ out_c = nullptr, int sa = 0)
+                        half_t *__restrict__ out_c = nullptr, int sa = 0, unsigned int *__restrict__ range = nullptr /* range-status slot of a compensated output */)
 {
     static_assert(COMP == 0 || (CC == 32 && TPS == 1 && WBUF == 2 && XBUF != 3 && !OUT_F32 && ABL == 0), "compensated instantiations: 32-wide chunks, plain pipeline");
     constexpr int T = KS * KS;
@@ -300,6 +300,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     // run.  For the fp16 output a v_permlane32_swap per dword regroups two quads so that lanes 0-31
     // own the full 16 bytes of quad 2m and lanes 32-63 those of quad 2m+1: half as many stores (and
     // residual loads), each 16 bytes wide.
+    float mx = 0.0f;
 #pragma unroll
     for (int pr = 0; pr < PX_T; ++pr) {
         const int oy = oy0 + wrow + pr, ox = ox0 + lrow;
@@ -363,7 +364,7 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                                                  (float)r[2] + sfd2_corr_lo(rcq[j].y, 0), (float)r[3] + sfd2_corr_lo(rcq[j].y, 1));
                             }
                             sfd2_epi4<HAS_RES>(acc[ct][pr][4 * q + 0], acc[ct][pr][4 * q + 1], acc[ct][pr][4 * q + 2], acc[ct][pr][4 * q + 3], sc, sh, ad,
-                                               relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j]);
+                                               relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j], mx, inb);
                             continue;
                         }
                         float v0 = acc[ct][pr][4 * q + 0] * sc.x + sh.x;
@@ -402,13 +403,14 @@ void conv_igemm2_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             }
         }
     }
+    if (COMP & 2) sfd2_range_commit(range, sfd2_wave_max_bits(mx));
 }
 
 template <int KS, int STRIDE, int BN, int CC, bool OUT_F32, bool HAS_RES, int NW = 8, int ROWS = 0, int XBUF = 2, int ABL = 0, int WBUF = 2, int TPS = 1, int COMP = 0>
 static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                             const float *scale, const float *shift, int CoutP, int relu, const half_t *res,
                             void *out, int Ho, int Wo, const half_t *zero_page, const half_t *in_c = nullptr,
-                            const half_t *res_c = nullptr, half_t *out_c = nullptr, int sa = 0)
+                            const half_t *res_c = nullptr, half_t *out_c = nullptr, int sa = 0, unsigned int *range = nullptr)
 {
     constexpr int THT = ROWS ? ROWS : ((STRIDE == 1) ? TH2 : 4);
     constexpr int PH = (THT - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
@@ -425,7 +427,7 @@ static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int 
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + THT - 1) / THT;
     const int grid = tiles_x * tiles_y * (CoutP / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, res, out,
-                       Ho, Wo, tiles_x, zero_page, in_c, res_c, out_c, sa);
+                       Ho, Wo, tiles_x, zero_page, in_c, res_c, out_c, sa, range);
 }
 
 // compensated instantiations (SFD2_PREC_F16C; in and out compensated): 1x1 256 -> 256 (+ residual) of the ResBlocks and the
@@ -433,18 +435,18 @@ static void launch_igemm2_t(hipStream_t st, const half_t *in, int H, int W, int 
 bool launch_conv_igemm2_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                           const float *scale, const float *shift, int CoutP, int ks, int stride, int relu,
                           const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, int Ho, int Wo,
-                          const half_t *zero_page, int sbyte)
+                          const half_t *zero_page, int sbyte, unsigned int *range)
 {
     const int sa = (sbyte & 255) * 0x01010101;
     if (!in_c || !out_c) return false;
     if (ks == 1 && stride == 1 && CoutP % 128 == 0) {   // 128-channel tiles: the 256-channel tile's compensated epilogue spills
-        if (res) launch_igemm2_t<1, 1, 128, 32, false, true, 8, 0, 2, 0, 2, 1, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, res, out, Ho, Wo, zero_page, in_c, res_c, out_c, sa);
-        else launch_igemm2_t<1, 1, 128, 32, false, false, 8, 0, 2, 0, 2, 1, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page, in_c, nullptr, out_c, sa);
+        if (res) launch_igemm2_t<1, 1, 128, 32, false, true, 8, 0, 2, 0, 2, 1, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, res, out, Ho, Wo, zero_page, in_c, res_c, out_c, sa, range);
+        else launch_igemm2_t<1, 1, 128, 32, false, false, 8, 0, 2, 0, 2, 1, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page, in_c, nullptr, out_c, sa, range);
         return true;
     }
     if (ks == 3 && stride == 2 && !res && CoutP % 128 == 0) {
-        if (CoutP % 256 == 0) launch_igemm2_t<3, 2, 256, 32, false, false, 8, 0, 1, 0, 2, 1, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page, in_c, nullptr, out_c, sa);
-        else launch_igemm2_t<3, 2, 128, 32, false, false, 8, 0, 1, 0, 2, 1, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page, in_c, nullptr, out_c, sa);
+        if (CoutP % 256 == 0) launch_igemm2_t<3, 2, 256, 32, false, false, 8, 0, 1, 0, 2, 1, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page, in_c, nullptr, out_c, sa, range);
+        else launch_igemm2_t<3, 2, 128, 32, false, false, 8, 0, 1, 0, 2, 1, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, nullptr, out, Ho, Wo, zero_page, in_c, nullptr, out_c, sa, range);
         return true;
     }
     return false;

@@ -108,7 +108,8 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                        const float *__restrict__ shift, int CoutP, int relu,
                        half_t *__restrict__ out, int Ho, int Wo, int tiles_x, int n_tiles,
                        const half_t *__restrict__ zero_page,
-                       const half_t *__restrict__ in_c = nullptr, half_t *__restrict__ out_c = nullptr, int sa = 0)
+                       const half_t *__restrict__ in_c = nullptr, half_t *__restrict__ out_c = nullptr, int sa = 0,
+                       unsigned int *__restrict__ range = nullptr /* the output tensor's range-status slot (compensated output) */)
 {
     constexpr bool F6 = (COMP & 16) != 0;
     constexpr int SSN = F6 ? 3 : 2;                        // arrays per tile parity in SSb: scale, shift (, the fp6 filters' scale bytes)
@@ -157,6 +158,8 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         }                                                                                              \
     }
     int tile = blockIdx.x;
+    constexpr bool RANGE = (COMP & 2) && !(COMP & 4);      // compensated output: keep the largest value in front of the saturation
+    unsigned int smax = 0;                                 // (wave-uniform: a scalar register across the tiles)
 #ifdef SFD2_PP_CU_STAGGER
     // experiment builds: some CUs start late so that the tiles' epilogue write bursts of the short-K layer (conv2a) are not in phase
     // chip-wide.  SFD2_PP_CU_STAGGER = delay in 10 ns units, SFD2_PP_CU_STAGGER_WHO: 0 = the blocks with one tile less, 1 = every other
@@ -384,6 +387,7 @@ _Pragma("unroll") \
                                                               // no canonicalising v_max in front of each fmaxf)
     // epilogue: y = acc * scale + shift (ReLU), regrouped with v_permlane32_swap into 16-byte stores
     // (see conv2_kernels.hip)
+    float mx = 0.0f;
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {
         const int oy = eoy0 + wrow + pr, ox = eox0 + lrow;
@@ -417,7 +421,7 @@ _Pragma("unroll") \
                         }
                     } else if (COMP & 2) {
                         sfd2_epi4<false>(acc[ct][pr][4 * q + 0], acc[ct][pr][4 * q + 1], acc[ct][pr][4 * q + 2], acc[ct][pr][4 * q + 3], sc, sh,
-                                         sc, relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j]);
+                                         sc, relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j], mx, inb);
                     } else {
                         float v0 = acc[ct][pr][4 * q + 0] * sc.x + sh.x;
                         float v1 = acc[ct][pr][4 * q + 1] * sc.y + sh.y;
@@ -440,10 +444,12 @@ _Pragma("unroll") \
             }
         }
     }
+    if (RANGE) { const unsigned int wb = sfd2_wave_max_bits(mx); smax = wb > smax ? wb : smax; }
     PP_CYC(3)
     if (!has_next) break;
     tile = next;
     }
+    if (RANGE) sfd2_range_commit(range, smax);
 #ifdef SFD2_PP_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_WALL(1)
@@ -456,7 +462,8 @@ _Pragma("unroll") \
 template <int STAGGER, int PRIO, int ABL = 0, int COMP = 0>
 static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                         const float *scale, const float *shift, int CoutP, int relu, half_t *out,
-                        int Ho, int Wo, const half_t *zero_page, const half_t *in_c = nullptr, half_t *out_c = nullptr, int sa = 0)
+                        int Ho, int Wo, const half_t *zero_page, const half_t *in_c = nullptr, half_t *out_c = nullptr, int sa = 0,
+                        unsigned int *range = nullptr)
 {
     constexpr size_t lds = (size_t)2 * PP_XBYTES + (size_t)2 * PP_FBYTES + ((COMP & 16) ? 6 : 4) * PP_BN * sizeof(float);
     static bool attr_done = false;
@@ -475,7 +482,7 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
     const int n_tiles = tiles_x * tiles_y * (CoutP / PP_BN);
     const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out,
-                       Ho, Wo, tiles_x, n_tiles, zero_page, in_c, out_c, sa);
+                       Ho, Wo, tiles_x, n_tiles, zero_page, in_c, out_c, sa, range);
 #ifdef SFD2_PP_TRACE
     {
         static int dumps = 0;
@@ -500,14 +507,14 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
 // compensated instantiations (SFD2_PREC_F16C): wpk = the layer's wc array, sbyte its scale byte
 void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int relu, half_t *out, half_t *out_c,
-                         int Ho, int Wo, const half_t *zero_page, int sbyte, const float *shift_sa6)
+                         int Ho, int Wo, const half_t *zero_page, int sbyte, const float *shift_sa6, unsigned int *range)
 {
     const int sa = (sbyte & 255) * 0x01010101;
     // shift_sa6 != null: wpk's corr rows are fp6 strings and shift_sa6 = [shift[CoutP] | the rows' scale bytes as ints [CoutP]]
-    if (in_c && out_c && shift_sa6) launch_pp_t<1, 1, 0, 19>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
-    else if (in_c && out_c) launch_pp_t<1, 1, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
+    if (in_c && out_c && shift_sa6) launch_pp_t<1, 1, 0, 19>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
+    else if (in_c && out_c) launch_pp_t<1, 1, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
     else if (in_c) launch_pp_t<1, 1, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
-    else launch_pp_t<1, 1, 0, 2>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
+    else launch_pp_t<1, 1, 0, 2>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
 }
 
 // SFD2_PREC_F16X3 on pre-split planes (hi = fp16(x), lo' = fp16((x - hi) * 2^11), x3_split's arithmetic): in / in_lo = the input's

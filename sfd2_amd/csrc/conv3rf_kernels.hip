@@ -103,7 +103,8 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                        const float *__restrict__ shift, int CoutP, int relu,
                        half_t *__restrict__ out, int Ho, int Wo, int tiles_x, int n_tiles,
                        const half_t *__restrict__ zero_page,
-                       const half_t *__restrict__ in_c = nullptr, half_t *__restrict__ out_c = nullptr, int sa = 0)
+                       const half_t *__restrict__ in_c = nullptr, half_t *__restrict__ out_c = nullptr, int sa = 0,
+                       unsigned int *__restrict__ range = nullptr /* the output tensor's range-status slot (compensated output) */)
 {
     static_assert(COMP == 0 || (!RES && ABL == 0), "compensated instantiations: streamed filters");
     // COMP bit 2 (X3, SFD2_PREC_F16X3): in / in_c are hi / lo' planes, wpk holds the filters' hi units then their lo' units; a tile's
@@ -363,7 +364,9 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     };
     // a tile's epilogue: y = acc * scale + shift (ReLU), regrouped with v_permlane32_swap into 16-byte stores
     // (conv2_kernels.hip); the next tile's first operands are already in registers / in flight
+    unsigned int smax = 0;         // range status: the largest value in front of the saturation, wave-uniform across the tiles
     auto epilogue = [&]() {
+        float mx = 0.0f;
         if (SS_RELOAD) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -388,7 +391,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                     const int q = 2 * m + j;
                     if constexpr ((CPB & 2) != 0) {
                         sfd2_epi4<false>(acc[f][4 * q + 0], acc[f][4 * q + 1], acc[f][4 * q + 2], acc[f][4 * q + 3], sc[q], sh[q], sc[q],
-                                         relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j]);
+                                         relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j], mx, inb);
                     } else if constexpr (X3) {
                         float v0 = acc[f][4 * q + 0] * sc[q].x + sh[q].x;
                         float v1 = acc[f][4 * q + 1] * sc[q].y + sh[q].y;
@@ -452,6 +455,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                     *reinterpret_cast<uint4 *>(out + ((size_t)oy * Wo + ox) * CoutP + slot * 8) = v16;
             }
         }
+        if constexpr ((CPB & 2) != 0) { const unsigned int wb = sfd2_wave_max_bits(mx); smax = wb > smax ? wb : smax; }
         c = 0;
         ++seq;
     };
@@ -477,6 +481,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             if (++c == NCH) epilogue();
         }
     }
+    if constexpr ((CPB & 2) != 0) sfd2_range_commit(range, smax);
 #undef RF_ISSUE_X
 #undef RF_ISSUE_X1
 #undef RF_LOAD_A
@@ -489,7 +494,8 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 template <int S, int BN = RF_BN, int ABL = 0, bool RES = false, int COMP = 0>
 static void launch_rf_t(hipStream_t st, const half_t *in, int H, int W, int Cin, const half_t *wpk,
                         const float *scale, const float *shift, int CoutP, int relu, half_t *out,
-                        int Ho, int Wo, const half_t *zero_page, const half_t *in_c = nullptr, half_t *out_c = nullptr, int sa = 0)
+                        int Ho, int Wo, const half_t *zero_page, const half_t *in_c = nullptr, half_t *out_c = nullptr, int sa = 0,
+                        unsigned int *range = nullptr)
 {
     constexpr size_t lds = (size_t)3 * RfGeom<S>::XBYTES;
     static bool attr_done = false;
@@ -506,20 +512,20 @@ static void launch_rf_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
     const int n_tiles = tiles_x * tiles_y;                 // CoutP == BN: one channel tile
     const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out,
-                       Ho, Wo, tiles_x, n_tiles, zero_page, in_c, out_c, sa);
+                       Ho, Wo, tiles_x, n_tiles, zero_page, in_c, out_c, sa, range);
 }
 
 // compensated instantiations (SFD2_PREC_F16C): the stride-2 layer with 128 output channels (conv2b).  wpk = the layer's wc
 // array (32-wide chunks, hi then corr), sbyte its scale byte.  false = no instantiation for this shape.
 bool launch_conv3x3_rf_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out, half_t *out_c,
-                         int Ho, int Wo, const half_t *zero_page, int sbyte)
+                         int Ho, int Wo, const half_t *zero_page, int sbyte, unsigned int *range)
 {
     if (!in_c || !out_c || Cin % 64 != 0) return false;
     if ((long long)(Ho * stride + 2) * (Wo * stride + 2) * Cin * (long long)sizeof(half_t) >= (1ll << 31)) return false;
     const int sa = (sbyte & 255) * 0x01010101;
     if (CoutP == 128 && stride == 2) {
-        launch_rf_t<2, 128, 0, false, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
+        launch_rf_t<2, 128, 0, false, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
         return true;
     }
     return false;

@@ -37,8 +37,10 @@ void convc_igemm_kernel(const half_t *__restrict__ in, const half_t *__restrict_
                         const half_t *__restrict__ wpk, const float *__restrict__ scale,
                         const float *__restrict__ shift, int CoutP, int relu,
                         const half_t *__restrict__ res, const half_t *__restrict__ res_c,
-                        half_t *__restrict__ out, half_t *__restrict__ out_c, int Ho, int Wo, int tiles_x, int sa)
+                        half_t *__restrict__ out, half_t *__restrict__ out_c, int Ho, int Wo, int tiles_x, int sa,
+                        unsigned int *__restrict__ range /* the output tensor's range-status slot, or null */)
 {
+    float mx = 0.0f;
     constexpr int T = KS * KS;
     constexpr int PAD = KS / 2;
     constexpr int PH = (CTH - 1) * STRIDE + KS;
@@ -207,6 +209,8 @@ void convc_igemm_kernel(const half_t *__restrict__ in, const half_t *__restrict_
                             v2 += sfd2_corr_lo(rc.y, 0); v3 += sfd2_corr_lo(rc.y, 1);
                         }
                     }
+                    mx = sfd2_max3(mx, v0, v1);
+                    mx = sfd2_max3(mx, v2, v3);
                     {   // ReLU and the saturation of compensated tensors at +-SFD2_C_SAT in one (as sfd2_epi4 in the tuned kernels)
                         const float lo = relu ? 0.0f : -SFD2_C_SAT;
                         v0 = __builtin_amdgcn_fmed3f(v0, lo, SFD2_C_SAT); v1 = __builtin_amdgcn_fmed3f(v1, lo, SFD2_C_SAT);
@@ -220,12 +224,13 @@ void convc_igemm_kernel(const half_t *__restrict__ in, const half_t *__restrict_
             }
         }
     }
+    sfd2_range_commit(range, sfd2_wave_max_bits(mx));
 }
 
 template <int KS, int STRIDE, int BN, bool HAS_RES, bool CIN_C, bool COUT_C>
 static void launch_convc_t(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                            const float *scale, const float *shift, int CoutP, int relu, const half_t *res, const half_t *res_c,
-                           half_t *out, half_t *out_c, int Ho, int Wo, int sa)
+                           half_t *out, half_t *out_c, int Ho, int Wo, int sa, unsigned int *range)
 {
     constexpr int PH = (CTH - 1) * STRIDE + KS, PW = (CTW - 1) * STRIDE + KS;
     constexpr size_t lds = (size_t)(2 * PH * PW + 2 * BN) * CPIXP * sizeof(half_t) + (size_t)2 * BN * sizeof(float);
@@ -238,22 +243,22 @@ static void launch_convc_t(hipStream_t st, const half_t *in, const half_t *in_c,
     const int tiles_x = (Wo + CTW - 1) / CTW, tiles_y = (Ho + CTH - 1) / CTH;
     const int grid = tiles_x * tiles_y * (CoutP / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(CNT), lds, st, in, in_c, H, W, Cin, wpk, scale, shift, CoutP, relu, res, res_c,
-                       out, out_c, Ho, Wo, tiles_x, sa);
+                       out, out_c, Ho, Wo, tiles_x, sa, range);
 }
 
 // Generic compensated layer.  wpk: [2 * Cin / 32][ks * ks][CoutP][32] units when in_c != null (fp16 chunks, then corr
 // chunks), the first half only otherwise; sbyte: 127 - 9 - b0 of the layer.
 void launch_convc_igemm(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                         const float *scale, const float *shift, int CoutP, int ks, int stride, int relu,
-                        const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, int Ho, int Wo, int sbyte)
+                        const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, int Ho, int Wo, int sbyte, unsigned int *range)
 {
     const int sa = (sbyte & 255) * 0x01010101;
     const int bn = (CoutP % 128 == 0) ? 128 : 64;   // 256-channel tiles spill here (two accumulator-heavy paths in one body)
 #define CC_GO(KS_, ST_, BN_, RES_)                                                                                       \
     do {                                                                                                                \
-        if (in_c && out_c) launch_convc_t<KS_, ST_, BN_, RES_, true, true>(st, in, in_c, H, W, Cin, wpk, scale, shift, CoutP, relu, res, res_c, out, out_c, Ho, Wo, sa); \
-        else if (in_c) launch_convc_t<KS_, ST_, BN_, RES_, true, false>(st, in, in_c, H, W, Cin, wpk, scale, shift, CoutP, relu, res, res_c, out, out_c, Ho, Wo, sa);   \
-        else launch_convc_t<KS_, ST_, BN_, RES_, false, true>(st, in, in_c, H, W, Cin, wpk, scale, shift, CoutP, relu, res, res_c, out, out_c, Ho, Wo, sa);             \
+        if (in_c && out_c) launch_convc_t<KS_, ST_, BN_, RES_, true, true>(st, in, in_c, H, W, Cin, wpk, scale, shift, CoutP, relu, res, res_c, out, out_c, Ho, Wo, sa, range); \
+        else if (in_c) launch_convc_t<KS_, ST_, BN_, RES_, true, false>(st, in, in_c, H, W, Cin, wpk, scale, shift, CoutP, relu, res, res_c, out, out_c, Ho, Wo, sa, range);   \
+        else launch_convc_t<KS_, ST_, BN_, RES_, false, true>(st, in, in_c, H, W, Cin, wpk, scale, shift, CoutP, relu, res, res_c, out, out_c, Ho, Wo, sa, range);             \
     } while (0)
 #define CC_BN(KS_, ST_, RES_)                                                                                            \
     do {                                                                                                                \
@@ -278,8 +283,10 @@ void launch_convc_igemm(hipStream_t st, const half_t *in, const half_t *in_c, in
 __global__ __launch_bounds__(CNT)
 void conv1a_c_kernel(const float *__restrict__ img, int H, int W, int normalise,
                      const half_t *__restrict__ wpk /*[2 hi/lo][2][3][64][8]*/, const float *__restrict__ scale,
-                     const float *__restrict__ shift, half_t *__restrict__ out, half_t *__restrict__ out_c, int tiles_x)
+                     const float *__restrict__ shift, half_t *__restrict__ out, half_t *__restrict__ out_c, int tiles_x,
+                     unsigned int *__restrict__ range)
 {
+    float mx = 0.0f;
     __shared__ __attribute__((aligned(16))) half_t Xh[C1C_PH * C1C_PW * 4];
     __shared__ __attribute__((aligned(16))) half_t Xl[C1C_PH * C1C_PW * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -371,10 +378,12 @@ void conv1a_c_kernel(const float *__restrict__ img, int H, int W, int normalise,
                     const int c0 = ct * 32 + 8 * q + 4 * lg;
                     const float4 sc = *reinterpret_cast<const float4 *>(scale + c0);
                     const float4 sh = *reinterpret_cast<const float4 *>(shift + c0);
-                    const float v0 = __builtin_amdgcn_fmed3f(acc[ct][pr][4 * q + 0] * sc.x + sh.x, 0.0f, SFD2_C_SAT);
-                    const float v1 = __builtin_amdgcn_fmed3f(acc[ct][pr][4 * q + 1] * sc.y + sh.y, 0.0f, SFD2_C_SAT);
-                    const float v2 = __builtin_amdgcn_fmed3f(acc[ct][pr][4 * q + 2] * sc.z + sh.z, 0.0f, SFD2_C_SAT);
-                    const float v3 = __builtin_amdgcn_fmed3f(acc[ct][pr][4 * q + 3] * sc.w + sh.w, 0.0f, SFD2_C_SAT);
+                    const float y0 = acc[ct][pr][4 * q + 0] * sc.x + sh.x, y1 = acc[ct][pr][4 * q + 1] * sc.y + sh.y;
+                    const float y2 = acc[ct][pr][4 * q + 2] * sc.z + sh.z, y3 = acc[ct][pr][4 * q + 3] * sc.w + sh.w;
+                    mx = sfd2_max3(mx, y0, y1);
+                    mx = sfd2_max3(mx, y2, y3);
+                    const float v0 = __builtin_amdgcn_fmed3f(y0, 0.0f, SFD2_C_SAT), v1 = __builtin_amdgcn_fmed3f(y1, 0.0f, SFD2_C_SAT);
+                    const float v2 = __builtin_amdgcn_fmed3f(y2, 0.0f, SFD2_C_SAT), v3 = __builtin_amdgcn_fmed3f(y3, 0.0f, SFD2_C_SAT);
                     uint2 hv, cv;
                     sfd2_split4(v0, v1, v2, v3, hv, cv);
                     *reinterpret_cast<uint2 *>(out + pix * 64 + c0) = hv;
@@ -382,14 +391,15 @@ void conv1a_c_kernel(const float *__restrict__ img, int H, int W, int normalise,
                 }
         }
     }
+    sfd2_range_commit(range, sfd2_wave_max_bits(mx));
 }
 
 void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *wpk, const float *scale,
-                     const float *shift, half_t *out, half_t *out_c)
+                     const float *shift, half_t *out, half_t *out_c, unsigned int *range)
 {
     const int tiles_x = (W + CTW - 1) / CTW, tiles_y = (H + C1C_TH - 1) / C1C_TH;
     hipLaunchKernelGGL(conv1a_c_kernel, dim3(tiles_x * tiles_y), dim3(CNT), 0, st, img, H, W, normalise, wpk, scale, shift,
-                       out, out_c, tiles_x);
+                       out, out_c, tiles_x, range);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -415,8 +425,10 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
                     const half_t *__restrict__ wpk /*[16 pairs][5 steps][64 lanes][8] fp16*/,
                     const unsigned char *__restrict__ wck /*[16 pairs][3 steps][64 lanes][32 B] corr units*/,
                     const float *__restrict__ scale, const float *__restrict__ shift, half_t *__restrict__ out,
-                    half_t *__restrict__ out_c, int tiles_x, int sa, int row0, int row1 /* output rows [row0, row1) of the image */)
+                    half_t *__restrict__ out_c, int tiles_x, int sa, int row0, int row1 /* output rows [row0, row1) of the image */,
+                    unsigned int *__restrict__ range)
 {
+    float mx = 0.0f;
     constexpr int NPIX = GC_PH * GC_PW;
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     half_t *Xh = reinterpret_cast<half_t *>(gsm);      // [NPIX][GCP]
@@ -535,7 +547,8 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
                     __builtin_memcpy(&pk[j], &h, 8);
                     __builtin_memcpy(&ck[j], &l, 8);
                 } else {
-                    sfd2_epi4<false>(acc[t + j][0], acc[t + j][1], acc[t + j][2], acc[t + j][3], sc, sh, sc, 0.0f, pk[j], ck[j]);
+                    sfd2_epi4<false>(acc[t + j][0], acc[t + j][1], acc[t + j][2], acc[t + j][3], sc, sh, sc, 0.0f, pk[j], ck[j], mx,
+                                     oy0 + ((t + j) >> 1) < row1 && ox0 + ((t + j) & 1) * 16 + lcol < W);
                 }
             }
             const bool odd = g & 1;
@@ -554,13 +567,14 @@ void gconv_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in
             }
         }
     }
+    if (!X3) sfd2_range_commit(range, sfd2_wave_max_bits(mx));
 #undef GC_FETCH
 }
 
 // row0 / row1: the output rows to produce (the whole image: 0, H); input rows outside [0, H) are the conv's zero padding
 // (sbyte < 0: SFD2_PREC_F16X3 -- in_c / out_c are lo' planes, wck the filters' lo' fragments)
 void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk, const void *wck,
-                    const float *scale, const float *shift, half_t *out, half_t *out_c, int sbyte, int row0, int row1)
+                    const float *scale, const float *shift, half_t *out, half_t *out_c, int sbyte, int row0, int row1, unsigned int *range)
 {
     // in_c == null: plain input, wck = fp16 residual fragments; out_c == null: hi plane only
     const size_t lds = (size_t)(in_c ? 2 : 1) * GC_PH * GC_PW * GCP * sizeof(half_t);
@@ -568,7 +582,7 @@ void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H,
     if (row0 >= row1) return;
     const int tiles_x = (W + CTW - 1) / CTW, tiles_y = (row1 - row0 + CTH - 1) / CTH;
 #define GCC_GO(...) hipLaunchKernelGGL((gconv_c_kernel<__VA_ARGS__>), dim3(tiles_x * tiles_y), dim3(CNT), lds, st, in, in_c, H, W, wpk, \
-                       reinterpret_cast<const unsigned char *>(wck), scale, shift, out, out_c, tiles_x, (sbyte & 255) * 0x01010101, row0, row1)
+                       reinterpret_cast<const unsigned char *>(wck), scale, shift, out, out_c, tiles_x, (sbyte & 255) * 0x01010101, row0, row1, range)
     if (sbyte < 0) {
         if (!in_c || !out_c) abort();
         GCC_GO(true, true, true);

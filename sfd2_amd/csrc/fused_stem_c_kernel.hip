@@ -85,8 +85,9 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                          const unsigned char *__restrict__ w2 /*[2 cth][18 units][64 lanes][64 B]: hi K slices 0, 1, then the corr fragment*/,
                          const float *__restrict__ sc2, const float *__restrict__ sh2,
                          half_t *__restrict__ out, half_t *__restrict__ out_c /*[H2][W2][64] each*/, int H2, int W2,
-                         int tiles_x, int n_tiles, int sa)
+                         int tiles_x, int n_tiles, int sa, unsigned int *__restrict__ range /* base of the context's range-status words, or null */)
 {
+    unsigned int smax1 = 0, smax2 = 0;     // range status of conv1a's (LDS-resident) and conv1b's output: wave-uniform across the tiles
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *X1h = smem;                                   // [SC_RP][128 B], 16-B slots swizzled with (rec >> 1) & 7, records pair-swapped
     unsigned char *X1c = smem + SC_X1;                           // the corr plane, same addressing
@@ -227,6 +228,7 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
         const int oy0 = ty * SC_TH, ox0 = tx * SC_TW;
         const int ry0 = 2 * oy0 - 1, rx0 = 2 * ox0 - 1;
 
+        float mx1 = 0.0f, mx2 = 0.0f;
         // ---- phase 1: conv1a -> X1h / X1c
         // conv1a's scale / shift of this wave's channels: read once per tile (they must not be live across phase 2)
         float4 s1[4], h1[4];
@@ -293,7 +295,7 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                 for (int q = 0; q < 4; ++q) {
                     uint2 hv, cv;
                     if (X3) sc_x3_epi4(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], s1[q], h1[q], hv, cv);
-                    else sfd2_epi4<false>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], s1[q], h1[q], s1[q], 0.0f, hv, cv);
+                    else sfd2_epi4<false>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], s1[q], h1[q], s1[q], 0.0f, hv, cv, mx1, all_inside || inside);
                     if (!all_inside && !inside) { hv = make_uint2(0u, 0u); cv = make_uint2(0u, 0u); }
                     {
                         const int o = xo + (((cth * 4 + q) << 4) ^ xsw);
@@ -306,6 +308,7 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
             __builtin_amdgcn_sched_barrier(0);   // (experiment: units not interleaved)
 #endif
         }
+        if (!X3) { const unsigned int wb = sfd2_wave_max_bits(mx1); smax1 = wb > smax1 ? wb : smax1; }
         const int next = tile + (int)gridDim.x, next2 = next + (int)gridDim.x;
         const bool has_next = next < n_tiles;
         SC_STAMP(1)
@@ -433,7 +436,7 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                 const float4 h = sfd2_lds_f4(SS + 192 + c0);
                 if (X3) sc_x3_epi4(tot[4 * q + 0] * (1.0f / 2048.0f), tot[4 * q + 1] * (1.0f / 2048.0f), tot[4 * q + 2] * (1.0f / 2048.0f),
                                    tot[4 * q + 3] * (1.0f / 2048.0f), s, h, pk[j], ck[j]);
-                else sfd2_epi4<false>(tot[4 * q + 0], tot[4 * q + 1], tot[4 * q + 2], tot[4 * q + 3], s, h, s, 0.0f, pk[j], ck[j]);
+                else sfd2_epi4<false>(tot[4 * q + 0], tot[4 * q + 1], tot[4 * q + 2], tot[4 * q + 3], s, h, s, 0.0f, pk[j], ck[j], mx2, inb);
             }
             const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
             const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
@@ -445,6 +448,7 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                 *reinterpret_cast<uint4 *>(out_c + o) = make_uint4(u0s[0], u1s[0], u0s[1], u1s[1]);
             }
         }
+        if (!X3) { const unsigned int wb = sfd2_wave_max_bits(mx2); smax2 = wb > smax2 ? wb : smax2; }
         SC_STAMP(9)
         if (!has_next) break;
         if (next2 < n_tiles) SC_FETCH_IMG(next2)
@@ -452,6 +456,10 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
         SC_LDS_BARRIER();                     // IM complete; every wave is done with the partials (phase 1 writes X1 again)
         SC_STAMP(11)
         tile = next;
+    }
+    if (!X3 && range != nullptr) {
+        sfd2_range_commit(range + SFD2_RS_CONV1A * SFD2_RANGE_SUB, smax1);
+        sfd2_range_commit(range + SFD2_RS_CONV1B * SFD2_RANGE_SUB, smax2);
     }
 #undef SC_LOAD_A1
 #undef SC_FETCH_IMG
@@ -461,7 +469,7 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
 // sbyte < 0: the X3 instantiation (SFD2_PREC_F16X3): w2's second halves are the filters' lo' fragments, out / out_c the hi / lo' planes
 void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *w1, const float *sc1,
                          const float *sh1, const void *w2, const float *sc2, const float *sh2, half_t *out, half_t *out_c,
-                         int H2, int W2, int sbyte)
+                         int H2, int W2, int sbyte, unsigned int *range)
 {
     static bool attr_done = false;
     static int slots = 256;
@@ -479,11 +487,11 @@ void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int nor
     const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
     if (sbyte < 0)
         hipLaunchKernelGGL(fused_stem_c_kernel<true>, dim3(grid), dim3(SC_NT), SC_LDS, st, img, H, W, normalise, w1, sc1, sh1,
-                           reinterpret_cast<const unsigned char *>(w2), sc2, sh2, out, out_c, H2, W2, tiles_x, n_tiles, 0);
+                           reinterpret_cast<const unsigned char *>(w2), sc2, sh2, out, out_c, H2, W2, tiles_x, n_tiles, 0, nullptr);
     else
         hipLaunchKernelGGL(fused_stem_c_kernel<false>, dim3(grid), dim3(SC_NT), SC_LDS, st, img, H, W, normalise, w1, sc1, sh1,
                            reinterpret_cast<const unsigned char *>(w2), sc2, sh2, out, out_c, H2, W2, tiles_x, n_tiles,
-                           (sbyte & 255) * 0x01010101);
+                           (sbyte & 255) * 0x01010101, range);
 #ifdef SFD2_STEMC_TRACE
     {
         static int dumps = 0;

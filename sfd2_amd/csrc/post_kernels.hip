@@ -854,44 +854,6 @@ void launch_desc_normalise_nchw(hipStream_t st, const float *in, int npix, float
     hipLaunchKernelGGL(desc_normalise_nchw_kernel, dim3((npix + 63) / 64), dim3(NT), 0, st, in, npix, out);
 }
 
-// ---------------------------------------------------------------- layout helpers (parity / debug paths)
-__global__ void nhwc_h_to_nchw_f_kernel(const half_t *__restrict__ in, int npix, int pitch, int c, float *__restrict__ out)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)npix * c) return;
-    const int ch = (int)(i / npix), p = (int)(i % npix);
-    out[i] = (float)in[(size_t)p * pitch + ch];
-}
-__global__ void nhwc_f_to_nchw_f_kernel(const float *__restrict__ in, int npix, int pitch, int c, float *__restrict__ out)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)npix * c) return;
-    const int ch = (int)(i / npix), p = (int)(i % npix);
-    out[i] = in[(size_t)p * pitch + ch];
-}
-__global__ void nchw_f_to_nhwc_f_kernel(const float *__restrict__ in, int npix, int c, float *__restrict__ out)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)npix * c) return;
-    const int p = (int)(i / c), ch = (int)(i % c);
-    out[i] = in[(size_t)ch * npix + p];
-}
-void launch_nhwc_h_to_nchw_f(hipStream_t st, const half_t *in, int npix, int pitch, int c, float *out)
-{
-    const size_t n = (size_t)npix * c;
-    hipLaunchKernelGGL(nhwc_h_to_nchw_f_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, in, npix, pitch, c, out);
-}
-void launch_nhwc_f_to_nchw_f(hipStream_t st, const float *in, int npix, int pitch, int c, float *out)
-{
-    const size_t n = (size_t)npix * c;
-    hipLaunchKernelGGL(nhwc_f_to_nchw_f_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, in, npix, pitch, c, out);
-}
-void launch_nchw_f_to_nhwc_f(hipStream_t st, const float *in, int npix, int c, float *out)
-{
-    const size_t n = (size_t)npix * c;
-    hipLaunchKernelGGL(nchw_f_to_nhwc_f_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, in, npix, c, out);
-}
-
 // ---------------------------------------------------------------- scale pyramid (nets/extractor.py:118-124,211-236)
 // level image = F.interpolate(norm_RGB(img), (nh, nw), bilinear, align_corners=False): normalise the four taps with
 // norm_RGB's IEEE sub + div, blend with the pinned torch rounding sequence (lin_coef / bilerp above).
@@ -1035,85 +997,4 @@ void launch_ms_merge(hipStream_t st, int n_levels, const int *offsets, const uns
     if (n_max <= 0) return;
     hipLaunchKernelGGL(ms_gather_kernel, dim3((n_max + 3) / 4), dim3(NT), 0, st, lv, level_count, order, kp_stage, sc_stage,
                        de_stage, n_max, kp_out, sc_out, de_out, ms_counters);
-}
-
-// ---------------------------------------------------------------- decoder-side ingest (extract_localization.py:158-186)
-// ImageDataset.__getitem__: image.astype(float32) -> cv2.resize(..., INTER_CUBIC) when max(w, h) > resize_max ->
-// HWC to CHW -> / 255.  OpenCV's float32 cubic resize, restated from its published algorithm (imgproc resize.cpp,
-// resizeGeneric_ with HResizeCubic / VResizeCubic): separable, horizontal pass first, Keys kernel with A = -0.75,
-// source coordinate (d + 0.5) * (src / dst) - 0.5 evaluated in double and rounded to float, taps sx-1 .. sx+2 with
-// replicated borders, no clamping of the overshoot.  Products and sums in the order the scalar code writes them, with
-// contraction forbidden (__fmul_rn / __fadd_rn) so the oracle's numpy restatement is reproduced bit for bit.
-// HIP's __fmul_rn / __fadd_rn are header inlines compiled under the default contract mode, so they still fuse; the
-// arithmetic below is therefore written with plain operators lexically under `fp contract(off)`.
-__device__ __forceinline__ void cubic_coeffs(float x, float *c)
-{
-#pragma clang fp contract(off)
-    const float A = -0.75f;
-    const float x1 = x + 1.0f;
-    c[0] = ((A * x1 - 5.0f * A) * x1 + 8.0f * A) * x1 - 4.0f * A;
-    c[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
-    const float y = 1.0f - x;
-    c[2] = ((A + 2.0f) * y - (A + 3.0f)) * y * y + 1.0f;
-    c[3] = 1.0f - c[0] - c[1] - c[2];
-}
-
-__global__ __launch_bounds__(NT)
-void ingest_u8_kernel(const unsigned char *__restrict__ src, int H, int W, int bgr, int nh, int nw, double scale_x,
-                      double scale_y, float *__restrict__ out /*[3][nh][nw]*/)
-{
-#pragma clang fp contract(off)
-    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
-    const int oy = blockIdx.y;
-    if (ox >= nw) return;
-    const size_t plane = (size_t)nh * nw;
-    if (nh == H && nw == W) {   // no resize: astype(float32) / 255.
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float v = (float)src[((size_t)oy * W + ox) * 3 + (bgr ? 2 - c : c)];
-            out[c * plane + (size_t)oy * nw + ox] = __fdiv_rn(v, 255.0f);
-        }
-        return;
-    }
-    const double dx = (ox + 0.5) * scale_x, dy = (oy + 0.5) * scale_y;
-    float fx = (float)(dx - 0.5);
-    float fy = (float)(dy - 0.5);
-    const int sx = (int)floorf(fx), sy = (int)floorf(fy);
-    fx = fx - (float)sx;
-    fy = fy - (float)sy;
-    float a[4], b[4];
-    cubic_coeffs(fx, a);
-    cubic_coeffs(fy, b);
-    int xs[4], ys[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        xs[k] = min(max(sx - 1 + k, 0), W - 1);
-        ys[k] = min(max(sy - 1 + k, 0), H - 1);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int cs = bgr ? 2 - c : c;
-        float rows[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const unsigned char *row = src + (size_t)ys[r] * W * 3 + cs;
-            float acc = (float)row[xs[0] * 3] * a[0];
-            acc = acc + (float)row[xs[1] * 3] * a[1];
-            acc = acc + (float)row[xs[2] * 3] * a[2];
-            acc = acc + (float)row[xs[3] * 3] * a[3];
-            rows[r] = acc;
-        }
-        float v = rows[0] * b[0];
-        v = v + rows[1] * b[1];
-        v = v + rows[2] * b[2];
-        v = v + rows[3] * b[3];
-        out[c * plane + (size_t)oy * nw + ox] = __fdiv_rn(v, 255.0f);
-    }
-}
-
-void launch_ingest_u8(hipStream_t st, const unsigned char *src, int H, int W, int bgr, int nh, int nw, float *out)
-{
-    // cv2.resize: inv_scale = dsize / ssize (double), scale = 1. / inv_scale
-    const double scale_x = 1.0 / ((double)nw / (double)W), scale_y = 1.0 / ((double)nh / (double)H);
-    hipLaunchKernelGGL(ingest_u8_kernel, dim3((nw + NT - 1) / NT, nh), dim3(NT), 0, st, src, H, W, bgr, nh, nw, scale_x, scale_y, out);
 }

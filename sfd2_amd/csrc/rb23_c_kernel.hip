@@ -66,8 +66,10 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                    const half_t *__restrict__ w3h /*fragment order [8 waves][8][64 lanes][16]*/, const half_t *__restrict__ w3l,
                    const float *__restrict__ sc3, const float *__restrict__ sh3,
                    const half_t *__restrict__ res, const half_t *__restrict__ res_c,
-                   half_t *__restrict__ out, half_t *__restrict__ out_c, int tiles_x, int n_tiles)
+                   half_t *__restrict__ out, half_t *__restrict__ out_c, int tiles_x, int n_tiles,
+                   unsigned int *__restrict__ range_t2, unsigned int *__restrict__ range_out /* range-status slots of t2 (LDS-resident) and of the block's output, or null */)
 {
+    unsigned int smax_t2 = 0, smax_out = 0;                 // wave-uniform across the tiles
     // Three separate LDS objects, not slices of one array: the compiler orders every LDS store behind all pending direct-to-LDS
     // copies it cannot prove disjoint from it (`s_waitcnt vmcnt(0)` in front of the first T2 store of every chunk: the copies
     // just issued had to land before the epilogue went on -- no prefetch at all)
@@ -189,6 +191,7 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
             const int swz = r23_xcd_swizzle(next, n_tiles);
             noy0 = (swz / tiles_x) * R23_TH; nox0 = (swz % tiles_x) * R23_TW;
         }
+        // (range status: reduced per chunk / per row into the scalars -- a vector register carried through the chunk loop spills here)
         // ------------------------------------------------ phase G: grouped 3x3 -> T2
 #pragma unroll 1
         for (int chunk = 0; chunk < 4; ++chunk) {
@@ -239,18 +242,22 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
             const float4 sh = sfd2_lds_f4(SS + 256 + c0);
             const unsigned t2c = (unsigned)(size_t)(const r23_lds_t *)T2 + t2b;
             const int slc = t2s ^ (chunk * 8);
+            unsigned int mx_t2 = 0;       // (packed fp16 maxima of the stored words: sfd2_track_h4)
+            float mx_none = 0.0f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_fmaf(acl[t][r], 1.0f / 2048.0f, acc[t][r]);
                 uint2 hv, cv;
-                sfd2_epi4<false>(acc[t][0], acc[t][1], acc[t][2], acc[t][3], sc, sh, sc, 0.0f, hv, cv);
+                sfd2_epi4<false, false>(acc[t][0], acc[t][1], acc[t][2], acc[t][3], sc, sh, sc, 0.0f, hv, cv, mx_none);
+                sfd2_track_h4(hv, mx_t2);
                 // (stored by hand: in front of a compiler-visible LDS store behind pending direct-to-LDS copies the compiler puts
                 //  `s_waitcnt vmcnt(0)` -- it did here for one of the four stores although T2 is an object of its own -- i.e. the
                 //  chunk's epilogue waited for the copies issued a moment before it: one memory round trip per chunk)
                 const unsigned t2a = t2c + ((slc ^ ((t & 1) * 16)) << 4) + ((t >> 1) * 32 + (t & 1) * 16) * 512;
                 asm volatile("ds_write_b64 %0, %1" ::"v"(t2a), "v"(hv) : "memory");
             }
+            { const unsigned int wb = sfd2_wave_max_bits(sfd2_h2_max(mx_t2)); smax_t2 = wb > smax_t2 ? wb : smax_t2; }
             ring = ring == 2 ? 0 : ring + 1;
         }
         // ------------------------------------------------ phase C: 1x1 + residual over the tile's four rows
@@ -286,6 +293,8 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
             const int oy = oy0 + r4, ox = ox0 + lrow;
             const size_t obase = (size_t)(oy * W + ox) * 256 + wave * 32;
             f32x16_t acc, acl;
+            unsigned int mx_out = 0;
+            float mx_none = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acl[r] = 0.0f; }
             int sw = lrow;
@@ -331,7 +340,8 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                     __builtin_memcpy(&rr, &rp[m][j], 8);
                     const float4 ad = make_float4((float)rr[0] + sfd2_corr_lo(rcp[m][j].x, 0), (float)rr[1] + sfd2_corr_lo(rcp[m][j].x, 1),
                                                   (float)rr[2] + sfd2_corr_lo(rcp[m][j].y, 0), (float)rr[3] + sfd2_corr_lo(rcp[m][j].y, 1));
-                    sfd2_epi4<true>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], sc, sh, ad, 0.0f, pk[j], ck[j]);
+                    sfd2_epi4<true, false>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], sc, sh, ad, 0.0f, pk[j], ck[j], mx_none);
+                    sfd2_track_h4(pk[j], mx_out);
                 }
                 const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                 const auto t1v = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
@@ -340,6 +350,7 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                 *reinterpret_cast<uint4 *>(out + obase + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1v[0], t0[1], t1v[1]);
                 *reinterpret_cast<uint4 *>(out_c + obase + 8 * (2 * m + lhi)) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
             }
+            { const unsigned int wb = sfd2_wave_max_bits(sfd2_h2_max(mx_out)); smax_out = wb > smax_out ? wb : smax_out; }
         };
         // four copies of the row's code: a loop would carry the residual registers around its back edge through copies, and the
         // compiler waits for the loads in front of those
@@ -354,6 +365,8 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
         tile = next; oy0 = noy0; ox0 = nox0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (copies of chunks nobody will read)
+    sfd2_range_commit(range_t2, smax_t2);
+    sfd2_range_commit(range_out, smax_out);
     R23_WALL(1)
 #undef R23_COPIES
 #undef R23_SETUP
@@ -362,7 +375,8 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
 // t1: ResBlock.conv1's output, plain fp16 [H][W][256]; res / res_c: the block's input (hi + corr planes); out / out_c: its output
 void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t *w2h, const half_t *w2l, const float *sc2,
                    const float *sh2, const half_t *w3h, const half_t *w3l, const float *sc3, const float *sh3,
-                   const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page)
+                   const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page,
+                   unsigned int *range_t2, unsigned int *range_out)
 {
     constexpr size_t lds = 0;                               // (static LDS: 150 KB)
     static bool attr_done = false;
@@ -378,7 +392,7 @@ void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t 
     if (n_tiles == 0) return;
     const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
     hipLaunchKernelGGL(rb23_c_kernel, dim3(grid), dim3(R23_NT), lds, st, t1, H, W, w2h, w2l, sc2, sh2, w3h, w3l, sc3, sh3, res, res_c,
-                       out, out_c, tiles_x, n_tiles);
+                       out, out_c, tiles_x, n_tiles, range_t2, range_out);
     (void)zero_page;
 #ifdef SFD2_RB23_TRACE
     {

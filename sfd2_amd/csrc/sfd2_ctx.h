@@ -84,9 +84,19 @@ struct ConvW {                 // one folded + packed layer
     DevBuf wc6;                // conv3x3_pp layers: wc with the corr filter rows as fp6 (e2m3) strings, and ...
     DevBuf sa6;                // ... [shift[cout_pad] | per-output-channel E8M0 scale bytes, replicated into the four bytes of an int, [cout_pad]]
     size_t w_floats = 0;       // floats in w (fp32 layers)
+    std::vector<float> h_scale, h_shift;   // host copies of the folded constants as loaded (before the activation exponents)
+    std::vector<int> h_sa6;                // host copy of sa6
 };
 
-struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; const void *pc = nullptr; /* corr plane (f16c) */ bool absent = false; /* stays on chip on the path taken */ };
+// Activation exponents of the fp16 family (SFD2_PREC_F16 / F16C): the stored tensor of group g is 2^act_exp[g] times the network's
+// tensor.  ReLU commutes with a positive factor and the factor is a power of two, so folding 2^(e_out - e_in) into a layer's scale
+// and 2^e_out into its shift changes nothing but where the tensor sits in the number formats: exact in fp32, and it is what keeps
+// the compensated mode's fixed-point-like corr units (e4m3 of x / 4 and of the fp16 residual * 512, tensors saturating at 1792)
+// in their sweet spot whatever scale the checkpoint's activations have.  Set by sfd2_calibrate_range (api_weights.hip).
+enum { AE_CONV1A, AE_CONV1B, AE_CONV2A, AE_CONV2B, AE_CONV3A, AE_TRUNK /* conv3b's and every ResBlock's output: one skip path */,
+       AE_T1_0, AE_T1_1, AE_T1_2, AE_T2_0, AE_T2_1, AE_T2_2, AE_PA0, AE_DA0, AE_COUNT };
+
+struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; const void *pc = nullptr; /* corr plane (f16c) */ int exp2 = 0; /* stored = value * 2^exp2 (activation exponents of the fp16 family) */ bool absent = false; /* stays on chip on the path taken */ };
 
 struct sfd2_ctx {
     int device = 0;
@@ -105,6 +115,15 @@ struct sfd2_ctx {
     bool counters_clean = false;       // the kernel in front of the selection cleared the counters (pb_heads_heat_kernel)
     bool has_sta = false;              // ConvSta present in the loaded state_dict (absent for require_stability=False models)
     int opt_alias = 1;                 // sfd2_set_option "alias"
+    int act_exp[AE_COUNT] = {};        // activation exponents of the fp16 family (above)
+    float act_max[AE_COUNT] = {};      // what the calibration measured (largest |x| of the group's tensors on the calibration image)
+    int opt_range_fallback = 1;        // sfd2_set_option "range_fallback": a synchronous f16c extract that saturated a tensor is re-run in f16x3
+    int range_fallbacks = 0;           // how often that happened
+    int in_fallback = 0;               // set around the re-run
+    float range_hist[SFD2_RS_COUNT] = {};   // maxima (stored units) folded away from the device words by a fallback's reset
+    int opt_auto_range = 1;            // sfd2_set_option "auto_range": sfd2_load_weights calibrates the exponents on a built-in probe image
+    std::vector<float> h_sta_w;        // ConvSta filters as loaded (the uploaded copy carries 2^-act_exp[AE_TRUNK])
+    int opt_cu_limit = 0;              // sfd2_set_option "cu_limit": persistent kernels of THIS context launch at most so many blocks
     int fuse_det = 0;                  // sfd2_set_option "fuse_det"
     int use_graphs = 0;                // sfd2_set_option "graphs"
     int alias_now = 0;                 // set per call
@@ -142,6 +161,7 @@ struct sfd2_ctx {
                                        // (second fp16 pass with their residuals).  Measured at 1600x1200: 1.82 / 1.75 / 1.67 ms per
                                        // extract for 0 / 1 / 2, descriptors <= 3.5e-4 / 3.8e-4 / 4.9e-4 over the BASELINE geometries.
     int opt_fuse_rb23 = 1;             // sfd2_set_option "fuse_rb23": with rb_inner = 2, ResBlock.conv2 + conv3 + residual in one kernel (t2 stays in LDS)
+    int opt_comp_det = 0;              // sfd2_set_option "comp_det": SFD2_PREC_F16C compensates the detector branch's 3x3 layers (convPa.0, convPa.3) only
     int opt_comp_heads = 0;            // sfd2_set_option "comp_heads": SFD2_PREC_F16C compensates the 3x3 layers of the two head branches too
     int opt_no_rf_c = 0;               // sfd2_set_option "no_rf_c": conv2b on conv_igemm2<comp> instead of conv3x3_rf<comp> (A/B switch)
     int opt_generic_c = 0;             // sfd2_set_option "generic_c": SFD2_PREC_F16C layers on the generic reference kernel (tests)
@@ -154,6 +174,9 @@ struct sfd2_ctx {
     unsigned long long graph_clock = 0;
     // weights
     ConvW c1a, c1b, c2a, c2b, c3a, c3b, rb1[3], rb2[3], rb3[3], pa0, pa3, da0, da3, pb, db;
+    DevBuf sta_w16;                                // ConvSta filters times 2^-act_exp[AE_TRUNK]: what the fp16 family launches with
+    DevPtr range_stat;                             // (a view: the words live behind the zero page) SFD2_RS_COUNT x SFD2_RANGE_SUB words: running maxima of the compensated mode's stored tensors (sticky until read with reset)
+    DevBuf range_scratch;                          // AE_COUNT words: absolute maxima of a calibration pass
     DevBuf sta_w, sta_b, zero_page, w1b_fused;   // w1b_fused: conv1b filters as [9][64][64] for the fused stem
     DevBuf w1b_stem_c;                             // the same as register fragments (hi K slices + corr) for the compensated fused stem
     DevBuf w1b_stem_x3;                            // ... with the lo' fragments (fp16 of (w - fp16(w)) * 2^11) in place of the corr fragment: f16x3
@@ -235,6 +258,18 @@ static inline void prof_step_end(sfd2_ctx *c)
     }
 }
 
+// api_weights.hip
+int apply_act_exponents(sfd2_ctx *c);                   // re-uploads the fp16 family's scale / shift arrays with c->act_exp folded in
+// api_core.hip
+int read_range_status(sfd2_ctx *c, sfd2_range_status *out, int reset);
+// after a synchronous extraction in SFD2_PREC_F16C: 1 = a compensated tensor saturated and the call is to be repeated in SFD2_PREC_F16X3
+// (the device words are folded into the context's history and cleared), 0 = fine / not applicable, -1 = error
+int range_wants_fallback(sfd2_ctx *c);
+struct FallbackScope {      // the repeat: strict arithmetic, no recursion
+    sfd2_ctx *c; int prec;
+    explicit FallbackScope(sfd2_ctx *c_) : c(c_), prec(c_->precision) { c->precision = SFD2_PREC_F16X3; c->in_fallback = 1; c->range_fallbacks++; }
+    ~FallbackScope() { c->precision = prec; c->in_fallback = 0; }
+};
 // api_network.hip
 void set_path(sfd2_ctx *c, bool parity_entry);          // which kernels / buffers the next network pass uses; call before ensure_workspace
 int ensure_workspace(sfd2_ctx *c, int H, int W);

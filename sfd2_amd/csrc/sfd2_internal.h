@@ -13,9 +13,11 @@ static inline const char *sfd2_env(const char *name) { return getenv(name); }
 static inline const char *sfd2_env(const char *) { return nullptr; }
 #endif
 
-// Option "cu_limit" (process-wide): the persistent kernels launch at most this many blocks (0 = one per CU).  With two streams per
+// Option "cu_limit" (per context): the persistent kernels launch at most this many blocks (0 = one per CU).  With two streams per
 // GPU and half the CUs each, two DIFFERENT kernels (of two images) run side by side instead of taking turns on the whole chip.
-extern int g_sfd2_cu_limit;
+// The launchers read a thread-local that every network pass sets from ITS context (run_network, api_network.hip): launches are
+// made on the caller's thread, so two contexts never see each other's limit.
+extern thread_local int g_sfd2_cu_limit;
 static inline int sfd2_slots(int cus) { return (g_sfd2_cu_limit > 0 && g_sfd2_cu_limit < cus) ? g_sfd2_cu_limit : cus; }
 
 // Block barrier that must make other waves' LDS-DMA copies (global_load_lds) visible: the drain of the vector-memory
@@ -124,13 +126,81 @@ __device__ __forceinline__ unsigned sfd2_corr2v(f32x2_t v, h2_t h)
     d = __builtin_amdgcn_cvt_pk_fp8_f32(l[1], x[1], d, true);
     return (unsigned)d;
 }
-template <bool ADD>
+// ---- range status: the largest value every compensated layer WOULD have stored, before the saturation.
+// A lane folds its values into `mx` in the epilogue (one v_max3_f32 per two values); sfd2_wave_max_bits reduces the wave with
+// six DPP steps and hands back a wave-uniform word (post-ReLU values are >= 0, so the bit patterns order like the floats) that a
+// kernel keeps in a SCALAR register across its tiles -- no vector register lives through the K loops for it -- and every wave
+// commits once, when it exits, into one of SFD2_RANGE_SUB sub-slots of the tensor's slot (blocks spread over them so that
+// 2 048 waves do not queue on one address).  sfd2_get_range_status folds the sub-slots on the host.
+#define SFD2_RANGE_SUB 16
+#define SFD2_ZERO_PAGE_BYTES 1024       // the context's zero page; the range-status words follow it in the same allocation
+enum { SFD2_RS_CONV1A, SFD2_RS_CONV1B, SFD2_RS_CONV2A, SFD2_RS_CONV2B, SFD2_RS_CONV3A, SFD2_RS_CONV3B, SFD2_RS_T1_0, SFD2_RS_T1_1, SFD2_RS_T1_2,
+       SFD2_RS_T2_0, SFD2_RS_T2_1, SFD2_RS_T2_2, SFD2_RS_OUT_0, SFD2_RS_OUT_1, SFD2_RS_OUT_2, SFD2_RS_PA0, SFD2_RS_DA0, SFD2_RS_COUNT };
+__device__ __forceinline__ float sfd2_max3(float m, float a, float b) { return __builtin_fmaxf(__builtin_fmaxf(m, a), b); }
+__device__ __forceinline__ unsigned int sfd2_wave_max_bits(float mx)
+{
+#ifdef SFD2_NO_RANGE      // timing experiment (tools/ab_libs.py): what the recording costs
+    return 0u;
+#endif
+    int v = __float_as_int(__builtin_fmaxf(mx, 0.0f));
+#define SFD2_DPP_MAX(ctrl_, rmask_) { const int o_ = __builtin_amdgcn_update_dpp(0, v, ctrl_, rmask_, 0xf, false); v = o_ > v ? o_ : v; }
+    SFD2_DPP_MAX(0x111, 0xf)      // row_shr:1   (lanes without a source keep `old` = 0: the identity here)
+    SFD2_DPP_MAX(0x112, 0xf)      // row_shr:2
+    SFD2_DPP_MAX(0x114, 0xf)      // row_shr:4
+    SFD2_DPP_MAX(0x118, 0xf)      // row_shr:8   -> lane 15 of every row holds the row's maximum
+    SFD2_DPP_MAX(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
+    SFD2_DPP_MAX(0x143, 0xc)      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+#undef SFD2_DPP_MAX
+    return (unsigned int)__builtin_amdgcn_readlane(v, 63);
+}
+// One commit per wave, at its exit.  The word is READ first and the atomic issued only when this wave has something larger to say:
+// the words are sticky (running maxima until the host resets them), so from the second image on nearly no wave writes.  That matters:
+// device-scope atomics of 2 048 waves on a handful of addresses are resolved one after the other at the memory side -- measured
+// +10 .. +17 us at the tail of every recording kernel when each wave simply issued its atomic (profiles/r04_range_cost.txt).
+// (The read may come from this XCD's L2 and be stale, i.e. too small: then the atomic is issued needlessly, never wrongly skipped
+// for a value that is not already recorded -- a larger recorded value only ever makes the skip right.)
+__device__ __forceinline__ void sfd2_range_commit(unsigned int *slot /* the tensor's SFD2_RANGE_SUB words, or null */, unsigned int wave_bits)
+{
+    if (slot == nullptr || wave_bits == 0u) return;      // (wave-uniform)
+    unsigned int *w = slot + (blockIdx.x & (SFD2_RANGE_SUB - 1));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned int cur = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave_bits > cur) atomicMax(w, wave_bits);
+    }
+}
+
+// the same record taken from the STORED fp16 values (after the saturation: it reads 1792 when values were clamped, which is all
+// the status needs): for kernels with no vector register to spare in their epilogue -- the operands are the packed words that
+// are about to be stored, one v_pk_max_f16 per two values
+__device__ __forceinline__ void sfd2_track_h4(uint2 hv, unsigned int &mxh)
+{
+    h2_t a, b, m;
+    __builtin_memcpy(&a, &hv.x, 4);
+    __builtin_memcpy(&b, &hv.y, 4);
+    __builtin_memcpy(&m, &mxh, 4);
+    m = __builtin_elementwise_max(__builtin_elementwise_max(m, a), b);
+    __builtin_memcpy(&mxh, &m, 4);
+}
+__device__ __forceinline__ float sfd2_h2_max(unsigned int mxh)
+{
+    h2_t m;
+    __builtin_memcpy(&m, &mxh, 4);
+    return __builtin_fmaxf((float)m[0], (float)m[1]);
+}
+
+template <bool ADD, bool TRACK = true>
 __device__ __forceinline__ void sfd2_epi4(float a0, float a1, float a2, float a3, float4 sc, float4 sh, float4 add, float lo,
-                                          uint2 &hv, uint2 &cv)
+                                          uint2 &hv, uint2 &cv, float &mx, bool counted = true /* false: a lane past the image's edge */)
 {
     f32x2_t v01 = f32x2_t{a0, a1} * f32x2_t{sc.x, sc.y} + f32x2_t{sh.x, sh.y};
     f32x2_t v23 = f32x2_t{a2, a3} * f32x2_t{sc.z, sc.w} + f32x2_t{sh.z, sh.w};
     if (ADD) { v01 += f32x2_t{add.x, add.y}; v23 += f32x2_t{add.z, add.w}; }
+#ifndef SFD2_NO_RANGE
+    if (TRACK) {
+        const float m = sfd2_max3(sfd2_max3(mx, v01[0], v01[1]), v23[0], v23[1]);
+        mx = counted ? m : mx;
+    }
+#endif
     v01[0] = __builtin_amdgcn_fmed3f(v01[0], lo, SFD2_C_SAT); v01[1] = __builtin_amdgcn_fmed3f(v01[1], lo, SFD2_C_SAT);
     v23[0] = __builtin_amdgcn_fmed3f(v23[0], lo, SFD2_C_SAT); v23[1] = __builtin_amdgcn_fmed3f(v23[1], lo, SFD2_C_SAT);
     const h2_t h01 = {(half_t)v01[0], (half_t)v01[1]}, h23 = {(half_t)v23[0], (half_t)v23[1]};
@@ -190,25 +260,26 @@ void launch_convsta(hipStream_t st, const half_t *in, int npix, const float *w /
 //   in_c / res_c / out_c: corr planes (null = that tensor is plain fp16);  sbyte: the layer's E8M0 scale byte
 void launch_convc_igemm(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                         const float *scale, const float *shift, int Cout_pad, int ks, int stride, int relu,
-                        const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, int Ho, int Wo, int sbyte);
+                        const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, int Ho, int Wo, int sbyte, unsigned int *range = nullptr);
 // the tuned kernels' compensated instantiations (same wpk / planes / sbyte as launch_convc_igemm; null plane = plain fp16)
 void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int relu, half_t *out, half_t *out_c,
-                         int Ho, int Wo, const half_t *zero_page, int sbyte, const float *shift_sa6 = nullptr /* non-null: wpk's corr rows are fp6; [shift | scale bytes] */);
+                         int Ho, int Wo, const half_t *zero_page, int sbyte, const float *shift_sa6 = nullptr /* non-null: wpk's corr rows are fp6; [shift | scale bytes] */,
+                         unsigned int *range = nullptr /* the output tensor's range-status slot (SFD2_RANGE_SUB words), here and below */);
 bool launch_conv3x3_rf_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out, half_t *out_c,
-                         int Ho, int Wo, const half_t *zero_page, int sbyte);
+                         int Ho, int Wo, const half_t *zero_page, int sbyte, unsigned int *range = nullptr);
 bool launch_conv_igemm2_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                           const float *scale, const float *shift, int CoutP, int ks, int stride, int relu,
                           const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, int Ho, int Wo,
-                          const half_t *zero_page, int sbyte);
+                          const half_t *zero_page, int sbyte, unsigned int *range = nullptr);
 // compensated fused stem (fused_stem_c_kernel.hip): w1 = conv1a hi, lo fragments; w2 = conv1b register fragments
 void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *w1, const float *sc1,
                          const float *sh1, const void *w2, const float *sc2, const float *sh2, half_t *out, half_t *out_c,
-                         int H2, int W2, int sbyte);
+                         int H2, int W2, int sbyte, unsigned int *range_base = nullptr /* the context's range-status words (conv1a's and conv1b's slots) */);
 void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c, int npix, const half_t *w_frag,
                            const half_t *wc_frag, const float *scale, const float *shift, int relu, const half_t *res,
-                           const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte);
+                           const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte, unsigned int *range = nullptr);
 // sparse_da3_kernel.hip: convDa.3 on the four bilinear corner pixels of every selected key point only -> out [n_max][4][256] fp16
 void launch_sparse_da3(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, int CoutP,
                        const float *scale, const float *shift, int relu, const float *kpts, const unsigned int *count, int n_max,
@@ -219,16 +290,17 @@ void launch_sparse_da3_x3(hipStream_t st, const half_t *fmap_hi, const half_t *f
 // rb23_c_kernel.hip: ResBlock.conv2 + conv3 + residual in one kernel (SFD2_PREC_F16C, option "rb_inner" = 2: t1 plain fp16 in, t2 in LDS)
 void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t *w2h, const half_t *w2l, const float *sc2,
                    const float *sh2, const half_t *w3h, const half_t *w3l, const float *sc3, const float *sh3,
-                   const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page);
+                   const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page,
+                   unsigned int *range_t2 = nullptr, unsigned int *range_out = nullptr);
 // conv1x1_kernels.hip: SFD2_PREC_F16X3 streaming 1x1 (256 -> 256): planes in, fp32 (+ planes) out, fp32 residual
 void launch_conv1x1_c256_x3(hipStream_t st, const half_t *in, const half_t *in_lo, int npix, const half_t *w, const half_t *wl,
                             const float *scale, const float *shift, int relu, const void *res, const half_t *res_lo, float *out, half_t *out_hi,
                             half_t *out_lo, const half_t *zero_page);
 void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *wpk /*hi, lo fragments*/,
-                     const float *scale, const float *shift, half_t *out, half_t *out_c);
+                     const float *scale, const float *shift, half_t *out, half_t *out_c, unsigned int *range = nullptr);
 void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk /*fp16 fragments*/,
                     const void *wck /*corr fragments*/, const float *scale, const float *shift, half_t *out, half_t *out_c, int sbyte,
-                    int row0, int row1 /*output rows [row0, row1)*/);
+                    int row0, int row1 /*output rows [row0, row1)*/, unsigned int *range = nullptr);
 void launch_nhwc_hc_to_nchw_f(hipStream_t st, const half_t *in, const half_t *in_c, int npix, int pitch, int c, float *out);
 
 // ---- strict fp32 mode (conv_f32_kernels.hip): fp32 NHWC activations, f32-input MFMA
@@ -373,6 +445,10 @@ void launch_desc_normalise_nchw(hipStream_t st, const float *desc_nhwc, int npix
 void launch_nhwc_h_to_nchw_f(hipStream_t st, const half_t *in, int npix, int c_pitch, int c, float *out);
 void launch_nhwc_f_to_nchw_f(hipStream_t st, const float *in, int npix, int c_pitch, int c, float *out);
 void launch_nchw_f_to_nhwc_f(hipStream_t st, const float *in, int npix, int c, float *out);
+
+void launch_scale_inplace(hipStream_t st, float *p, size_t n, float mul);
+// *out = max(*out, max |in[i]|), as the bit pattern of the non-negative float
+void launch_absmax_f32(hipStream_t st, const float *in, size_t n, unsigned int *out);
 
 // decoder-side ingest: uint8 HWC (RGB or BGR) -> float32 CHW in [0,1] at nh x nw (cv2 INTER_CUBIC when the size changes)
 void launch_ingest_u8(hipStream_t st, const unsigned char *src, int H, int W, int bgr, int nh, int nw, float *out);

@@ -37,7 +37,11 @@ class ResSegNetV2:
         'f16c' = compensated fp16: the throughput mode's kernels with a second 2-byte plane per backbone activation and
         filter (fp16 rounding residual + the value, both at fp8 precision) and one block-scaled fp8 MFMA per 32 channels
         that adds the two first-order error terms -- descriptors within 1e-3 of the fp32 reference (north_star's
-        tolerance; measured <= 3e-4), key-point set IoU >= 0.99 (tests/test_gpu_f16c.py)."""
+        tolerance; measured <= 5e-4), key-point set IoU >= 0.99 (tests/test_gpu_f16c.py).  Its tensors have a RANGE
+        the fp32 reference does not have (stored values saturate at 1792, the correction bytes fade below ~0.03):
+        load_state_dict() places every tensor inside it from a built-in probe image, calibrate_range(img) does the same
+        from one of yours, range_status() reports what the kernels actually saw, and a synchronous extraction that
+        saturates is re-run in 'f16x3' before it returns (include/sfd2_hip.h "Range management")."""
         if precision not in ("f16", "f32", "f16x3", "f16c"):
             raise ValueError("precision must be 'f16', 'f32', 'f16x3' or 'f16c'")
         self.precision = precision
@@ -97,6 +101,27 @@ class ResSegNetV2:
     @property
     def context(self):
         return self._ensure_ctx()
+
+    # -- range management of the reduced-precision modes (extension; include/sfd2_hip.h "Range management")
+    def calibrate_range(self, img, normalised=False):
+        """img: [3,H,W] or [1,3,H,W] float32 in [0,1] (normalised=True: after norm_RGB)."""
+        if self._sd is None:
+            raise RuntimeError("load_state_dict() first")
+        if _is_torch(img):
+            img = img.detach().to(torch.float32).contiguous()
+            img = img[0] if img.dim() == 4 else img
+            if not img.is_cuda:
+                img = img.numpy()
+            else:
+                torch.cuda.current_stream(img.device).synchronize()
+        else:
+            img = np.asarray(img, dtype=np.float32)
+            img = img[0] if img.ndim == 4 else img
+        self._ensure_ctx().calibrate_range(img, normalised)
+        return self
+
+    def range_status(self, reset=False):
+        return self._ensure_ctx().range_status(reset)
 
     # -- the operator (nets/sfd2.py:313-354)
     def det(self, x):

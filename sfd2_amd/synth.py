@@ -70,7 +70,8 @@ def make_state_dict(seed=0, family=None, gain_log2=0, gain_on="all"):
       "biased"      filters that do NOT sum to zero over the input channels (mean 0.3 sigma) + calibrated statistics
       "dead"        calibrated, and 5 % of the output channels of every BatchNorm'd layer have filters 2^-5 .. 2^-9 of
                     the others (running_var 2^-10 .. 2^-18 of theirs: the folded scale is x 32 .. x 512)
-      "smallvar"    the default draw with running_var = 1e-3 on 5 % of the channels (those channels come out x 30)
+      "smallvar"    calibrated, except that on 5 % of the channels of the backbone's BatchNorms running_var is 1e-3 of the
+                    input's variance (those channels come out x 31.6; the layers behind them are calibrated on that)
     gain_log2 = k multiplies the activation tensors named by gain_on ("all" backbone tensors, or one of "conv1a",
     "conv1b", "conv2a", "conv2b", "conv3a", "trunk", "t1", "t2") by 2^k and their consumers' filters by 2^-k: the
     network's function is unchanged (powers of two: exactly, up to the BatchNorm eps), only the scale of what is stored
@@ -108,13 +109,14 @@ def make_state_dict(seed=0, family=None, gain_log2=0, gain_on="all"):
             sd[name + ".weight"][idx] *= np.exp2(-sh).astype(np.float32)[:, None, None, None]
             if has_bias:
                 sd[name + ".bias"][idx] *= np.exp2(-sh).astype(np.float32)
-    if fam in ("calibrated", "biased", "dead"):
-        _calibrate_bn(sd, make_image(64, 96, 900 + seed))
+    fixed_var = None
     if fam == "smallvar":
-        for name, cout, cin, k, has_bias, bn in _LAYERS:
-            if bn is not None:
-                idx = rs.choice(cout, max(1, cout // 20), replace=False)
-                sd[bn[0] + ".running_var"][idx] = np.float32(1e-3)
+        # (layers that a calibrated BatchNorm follows: the stem, conv2a .. conv3b, and conv1 / conv2 of the ResBlocks -- not the skip path's
+        #  bn3 nor the head branches, where x 30 would compound into the logits)
+        fixed_var = {bn[0]: rs.choice(cout, max(1, cout // 20), replace=False) for name, cout, cin, k, has_bias, bn in _LAYERS
+                     if bn is not None and not bn[0].endswith("bn3") and not name.startswith("convP") and not name.startswith("convD")}
+    if fam in ("calibrated", "biased", "dead", "smallvar"):
+        _calibrate_bn(sd, make_image(64, 96, 900 + seed), fixed_var)
     if gain_log2:
         _apply_gain(sd, int(gain_log2), gain_on)
     return sd
@@ -151,9 +153,10 @@ def _np_conv(x, w, stride, groups):
     return out
 
 
-def _calibrate_bn(sd, img):
+def _calibrate_bn(sd, img, fixed_var=None):
     """Replaces every BatchNorm's running_mean / running_var by the mean / variance its input has on `img` [3,h,w] in [0,1]
-    (propagated layer by layer through the network with the statistics already replaced), floor 1e-8 on the variance."""
+    (propagated layer by layer through the network with the statistics already replaced), floor 1e-8 on the variance.
+    fixed_var: {bn name: channel indices} whose running_var is 1e-3 of the measured variance instead."""
     mean = np.array([0.485, 0.456, 0.406]).reshape(3, 1, 1)
     std = np.array([0.229, 0.224, 0.225]).reshape(3, 1, 1)
 
@@ -163,6 +166,8 @@ def _calibrate_bn(sd, img):
             y = y + sd[conv + ".bias"].astype(np.float64).reshape(-1, 1, 1)
         if bn is not None:
             m, v = y.mean(axis=(1, 2)), np.maximum(y.var(axis=(1, 2)), 1e-8)
+            if fixed_var is not None and bn in fixed_var:
+                v[fixed_var[bn]] *= 1e-3
             sd[bn + ".running_mean"] = m.astype(np.float32)
             sd[bn + ".running_var"] = v.astype(np.float32)
             y = (y - m.reshape(-1, 1, 1)) / np.sqrt(v.reshape(-1, 1, 1) + 1e-5)
@@ -194,9 +199,7 @@ def _apply_gain(sd, k, on):
     def plain(conv, bn):       # BatchNorm(affine=False): y = (conv(x) + b - mean) / sqrt(var + eps)  ->  g y
         sd[conv + ".weight"] = sd[conv + ".weight"] * g
         sd[conv + ".bias"] = sd[conv + ".bias"] * g
-        sd[bn + ".running_mean"] = sd[bn + ".running_mean"] * g
-        v = sd[bn + ".running_var"].astype(np.float64)
-        sd[bn + ".running_var"] = v.astype(np.float32)   # (unchanged: numerator scaled instead)
+        sd[bn + ".running_mean"] = sd[bn + ".running_mean"] * g      # (running_var unchanged: the numerator carries the factor)
 
     def affine(bn):            # gamma, beta
         sd[bn + ".weight"] = sd[bn + ".weight"] * g

@@ -474,3 +474,35 @@ def test_sparse_da3_equals_dense_path_and_oracle(synth_sd, prec, tol, h, w, seed
     assert do <= tol, do
     np.testing.assert_allclose(np.linalg.norm(outs[1]["descriptors"], axis=1), 1.0, atol=1e-5)
     _record(f"{prec} sparse_da3 {w}x{h} top{topk}: vs dense path {dd:.2e}, vs oracle {do:.2e} ({len(common)} common key points)")
+
+
+def test_f16c_detector_branch_compensation_table(synth_sd):
+    """Which head layers to compensate: the detector score goes through exp(), so the detector branch's fp16
+    roundings are what moves key points.  Records score error / key-point agreement for {default, comp_det, comp_heads}; asserts
+    that comp_det buys what it is for (a smaller score error than the default, key points no worse)."""
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    from sfd2_amd.model import ResSegNetV2
+    x = orc.norm_rgb(synth.make_image(100, 130, 12))
+    o_score, _, _ = orc.det(synth_sd, x, {})
+    img = synth.make_image(1200, 1600, 31)
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=4096)
+    rows = {}
+    for name, opts in (("default", {}), ("comp_det", {"comp_det": 1}), ("comp_heads", {"comp_heads": 1})):
+        m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
+        m.load_state_dict(synth_sd)
+        m.cuda(0)
+        for k, v in opts.items():
+            m.context.set_option(k, v)
+        score, _, _ = m.det(x[None])
+        rel = float((np.abs(score[0, 0] - o_score) / (o_score + 1e-4 / SCORE_TOL)).max())
+        got = extract_resnet_return(m, torch.from_numpy(img)[None].cuda(), conf_th=0.001, topK=4096, scales=[1.0])
+        iou, dd, shift, same, n = _compare(got, want, 0.985)
+        rows[name] = (rel, iou, same, n, dd)
+        _record(f"f16c head compensation [{name}]: score rel {rel:.2e}, 1600x1200 IoU {iou:.4f}, same rank {same}/{n}, max rank shift {shift}, desc {dd:.2e}")
+    # Measured (profiles/r04_f16c_parity_measured.txt) and predicted by the CPU twin (profiles/r04_detector_budget.txt): the score error
+    # (1.2-1.3e-2 relative) is the BACKBONE's f16c-level error carried through the detector branch into logits of magnitude ~18 and
+    # through exp() -- compensating convPa.0 / convPa.3, even with convPb in three passes, moves it by a quarter at most.  The option is
+    # therefore off by default; what is asserted is that it does no harm.
+    assert rows["comp_det"][0] <= 1.5 * rows["default"][0] and rows["comp_heads"][0] <= 1.5 * rows["default"][0], rows
+    assert rows["comp_det"][1] >= rows["default"][1] - 2e-3, rows

@@ -72,7 +72,9 @@ def test_no_spills_and_two_waves_per_simd(asm, src):
         # (its compensated instantiations, COMP & 1, have two chunk loops and park a few more between them; the generic
         # compensated kernel and the compensated fused stem keep their tile geometry that way too)
         pp_comp = "conv3x3_pp_kernel" in name and not name.split("EEv")[0].endswith(("ELi0", "ELi2"))
-        lim = 32 if pp_comp else ((8 if name.split("EEv")[0].endswith("ELi0") else 16) if "conv3x3_pp_kernel" in name else (48 if ("convc_igemm" in name or "fused_stem_c" in name or "gconv_c" in name or "rb23_c" in name) else 0))
+        # (round 4: the range-status pointer and the running maximum are two more tile-loop scalars: 29 -> 33 parked, all outside the K loops --
+        #  the assertion below; same-box A/B against a -DSFD2_NO_RANGE build in profiles/r04_range_cost.txt)
+        lim = 36 if pp_comp else ((8 if name.split("EEv")[0].endswith("ELi0") else 20) if "conv3x3_pp_kernel" in name else (48 if ("convc_igemm" in name or "fused_stem_c" in name or "gconv_c" in name or "rb23_c" in name) else 0))
         assert meta["sgpr_spill_count"] <= lim, (name, meta)
         if "convc_igemm" in name or "fused_stem_c" in name or "gconv_c" in name or "conv1a_c" in name or "rb23_c" in name:
             continue
