@@ -499,12 +499,15 @@ def main():
                                 "the fp8 correction MFMAs (one 32x32x64 per two 32x32x16), i.e. 2x the matrix time of the plain fp16 layer at "
                                 "nominal rates: 'frac_of_issued_peak' = frac * 2")
                 roof["frac_of_issued_peak"] = round(2 * achieved / PEAK_TFLOPS_F16, 4)
-            # what this part sustains on fp16 MFMAs alone (tools/probe/mfma_valu.hip, profiles/r03k_mfma_valu_probe.txt: two waves per
-            # SIMD, four or eight accumulator chains each, random operands; the shader clock reads 1.7-1.8 GHz under that load) --
-            # context for `frac`, which stays against the nominal peak
-            roof["sustained_mfma_probe"] = {"value": 1110.0, "unit": "TFLOP/s", "source": "profiles/r03k_mfma_valu_probe.txt (modes 6, 9)",
-                                            "frac_of_probe": round((2 if "comp" in dom_name else 1) * achieved / 1110.0, 4),
-                                            "note": "issued-FLOP rate of this kernel / MFMA-only probe rate on the same part (not re-measured in this run)"}
+            # what this part sustains on v_mfma_f32_32x32x16_f16 alone (tools/probe/mfma_peak.hip, profiles/r04_mfma_probe.txt): one MFMA per 32.2-32.9
+            # cycles and SIMD in every configuration; the clock the part holds depends on the operands' switching activity -- 2.39 GHz on zeros
+            # (2.49 PFLOP/s), 1.73 GHz on post-ReLU-like activations (1.77), 1.65 GHz on uniform +-0.5 (1.68).  A POWER ceiling, not an issue limit:
+            # context for `frac`, which stays against the nominal peak.  (Round 3 quoted 1.11 PFLOP/s from an issue-limited probe: retracted.)
+            issued = (2 if "comp" in dom_name else 1) * achieved
+            roof["mfma_only_probe"] = {"zeros": 2490.0, "relu_like": 1765.0, "uniform": 1680.0, "unit": "TFLOP/s",
+                                       "source": "profiles/r04_mfma_probe.txt (not re-measured in this run)",
+                                       "issued_frac_of_relu_like": round(issued / 1765.0, 4),
+                                       "note": "issued-FLOP rate of this kernel (fp8 correction MFMAs counted at fp16-equivalent time) / the MFMA-only rate on relu-like data"}
             if single is not None:
                 roof["measured_in"] = ("single-stream timed leg of this run (same K steps and bracketing, one stream per GPU, eager "
                                        "launches: see 'single_stream').  The headline region replays one hipGraph per image on "

@@ -163,7 +163,7 @@ def test_f16c_reload_weights_and_mode_switch(synth_sd):
 def test_f16c_tuned_kernels_vs_generic_kernel(synth_sd, h, w, seed):
     """The tuned kernels' compensated forms (fused stem, conv3x3_pp, conv_igemm2; option 'fuse_det' routes sfd2_det through
     the fused stem) against the generic compensated kernel (option 'generic_c'), the reference implementation of the
-    arithmetic: same operands, same products, fp32 summation order differs -- every backbone activation within 5e-5 of
+    arithmetic: same operands, same products, fp32 summation order differs -- every backbone activation within 7e-5 of
     max|layer|."""
     from sfd2_amd.model import ResSegNetV2
     x = orc.norm_rgb(synth.make_image(h, w, seed))
@@ -183,7 +183,9 @@ def test_f16c_tuned_kernels_vs_generic_kernel(synth_sd, h, w, seed):
         a, b = outs[0][0][n], outs[1][0][n]
         err = np.abs(a - b).max() / np.abs(a).max()
         worst = max(worst, err)
-        assert err <= 5e-5, (n, err)
+        # (one step of a compensated tensor's corr byte is 2^-15 = 3e-5 of its binade: a flipped step after the last ResBlock reads 5.6e-5 of
+        #  max once the activation exponents place the maximum at 16-32 instead of 4-8)
+        assert err <= 7e-5, (n, err)
     dd = np.abs(outs[0][1] - outs[1][1]).max()
     assert dd <= 5e-4, dd      # (the heads are plain fp16: a one-ulp flip of a backbone hi value is fp16-level noise behind them)
     _record(f"f16c tuned vs generic {h}x{w}: worst activation diff {worst:.2e} of max, dense desc diff {dd:.2e}")

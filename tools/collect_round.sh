@@ -7,10 +7,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd $R
-rm -f gpurun_out/f16c_parity_measured.txt gpurun_out/strict_parity_measured.txt
+rm -f gpurun_out/f16c_parity_measured.txt gpurun_out/strict_parity_measured.txt gpurun_out/f16c_conditioning_measured.txt
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/pytest_gpu.txt
 cp gpurun_out/f16c_parity_measured.txt $out/f16c_parity_measured.txt 2>/dev/null
 cp gpurun_out/strict_parity_measured.txt $out/strict_parity_measured.txt 2>/dev/null
+cp gpurun_out/f16c_conditioning_measured.txt $out/f16c_conditioning_measured.txt 2>/dev/null
+[ -x build/probe/mfma_peak ] && { ./build/probe/mfma_peak > $out/mfma_peak.txt 2>&1; ./build/probe/mfma_peak mixed > $out/mfma_mixed.txt 2>&1; }
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.txt 2>&1
 python tools/determinism_check.py 1500 f16c > $out/determinism.txt 2>&1
 python tools/determinism_check.py 500 f16 >> $out/determinism.txt 2>&1

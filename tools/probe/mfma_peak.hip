@@ -61,6 +61,80 @@ __global__ __launch_bounds__(256) void peak(float *out, int iters, int data, uns
     if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
 
+// Second question: how much VALU work rides along for free?  VALU independent v_max3_f32 / v_and_or_b32 (four register chains, no
+// dependence on the accumulators) behind every MFMA, W waves per SIMD, four chains in VGPRs, relu-like operands.
+#define VOP(x0_, x1_, x2_, x3_) asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_and_or_b32 %1, %1, %4, %3" : "+v"(x0_), "+v"(x1_), "+v"(x2_), "+v"(x3_) : "v"(keep))
+template <int NV /* VALU instructions per MFMA, even */>
+__global__ __launch_bounds__(256) void mixed(float *out, int iters, unsigned long long *clk)
+{
+    extern __shared__ unsigned char pad[];
+    f32x16 c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int r = 0; r < 16; ++r) c[q][r] = 0.f;
+    h8 a[4], b[4];
+    unsigned x = (threadIdx.x + 256u * blockIdx.x) * 2654435761u + 12345u;
+    for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 8; ++i) {
+            x = x * 1664525u + 1013904223u;
+            const float u = (float)(x >> 16) / 65536.f, v = (float)(x & 0xffff) / 65536.f;
+            a[k][i] = (_Float16)((x & 0x100) ? 0.f : 4.f * u);
+            b[k][i] = (_Float16)(v - 0.5f);
+        }
+    float v0 = (float)x, v1 = v0 + 1.f, v2 = v0 + 2.f, v3 = v0 + 3.f, v4 = v0 + 4.f, v5 = v0 + 5.f, v6 = v0 + 6.f, v7 = v0 + 7.f;
+    unsigned keep = 0xffffff80u;
+    asm volatile("" : "+v"(keep));
+    if (threadIdx.x == 9999) pad[0] = 1;
+    const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            MF_V(c[m % 4], a[m & 3], b[(m >> 2) & 3]);
+#pragma unroll
+            for (int j = 0; j < NV / 2; ++j) {
+                if (j & 1) VOP(v4, v5, v6, v7); else VOP(v0, v1, v2, v3);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    float s = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int r = 0; r < 16; ++r) s += c[q][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
+}
+
+template <int NV>
+static void run_mixed(int W, int cus, float *out, unsigned long long *clk)
+{
+    const size_t lds = (size_t)(160 * 1024 / W) - 1024;
+    auto k = mixed<NV>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int iters = 30000 / W;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    unsigned long long h[2] = {0, 0};
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k, dim3(cus * W), dim3(256), lds, 0, out, iters, clk);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < best) { best = ms; (void)hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost); }
+    }
+    const double mf_simd = (double)iters * 16.0 * W;
+    const double ns = best * 1e6 / mf_simd;
+    const double mhz = (double)h[0] / ((double)h[1] * 10.0) * 1000.0;
+    printf("mixed    W=%d  %2d VALU per MFMA: %6.2f ns/MFMA/SIMD  %5.1f cyc/MFMA/SIMD  shader clock %4.0f MHz  %5.3f PFLOP/s   (VALU alone would take %d x 4 = %d cyc)\n", W, NV, ns,
+           ns * mhz * 1e-3, mhz, (double)cus * 4.0 * mf_simd * 32768.0 / (best * 1e-3) / 1e15, NV, NV * 4);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+}
+
 template <int CHAINS, bool AGPR>
 static void run(int W, int data, int cus, float *out, unsigned long long *clk, const char *dname)
 {
@@ -103,6 +177,13 @@ int main(int argc, char **argv)
     (void)hipMalloc(&clk, 16);
     const char *names[3] = {"zeros", "relu", "uniform"};
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+    if (argc > 1 && !strcmp(argv[1], "mixed")) {
+        for (int W = 1; W <= 2; ++W) {
+            run_mixed<0>(W, cus, out, clk); run_mixed<2>(W, cus, out, clk); run_mixed<4>(W, cus, out, clk); run_mixed<6>(W, cus, out, clk);
+            run_mixed<8>(W, cus, out, clk); run_mixed<10>(W, cus, out, clk); run_mixed<12>(W, cus, out, clk); run_mixed<16>(W, cus, out, clk);
+        }
+        return 0;
+    }
     for (int data = 0; data < 3; ++data) {
         for (int W = 1; W <= 4; W *= 2) {
             if (quick && W != 2) continue;
