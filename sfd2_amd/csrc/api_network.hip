@@ -116,6 +116,14 @@ int ensure_workspace(sfd2_ctx *c, int H, int W)
         reg("convPa", c->gpa_o.p, 1, 0, 256, 256, c->H8, c->W8);
         reg("convDa.0", c->gda0_o.p, 1, 0, 256, 256, c->H4, c->W4);
         reg("convDa", c->gda_o.p, 1, 0, 256, 256, c->H4, c->W4);
+        if (c->x3_fast_rb_now) {
+            // throughput path of SFD2_PREC_F16X3 (sfd2_extract): from the stem to convDa.0 the tensors exist as hi / lo' planes only; the fp32
+            // buffers are written for the last ResBlock's output and convPa.3's.  sfd2_debug_activation must say so instead of handing
+            // back what an earlier sfd2_det left in them
+            for (auto &kv : c->acts)
+                if (kv.first != "conv4.2" && kv.first != "convPa" && kv.first != "convPb" && kv.first != "convDb" && kv.first != "ConvSta")
+                    kv.second.absent = true;
+        }
         return 0;
     }
     if (!layers) return 0;   // throughput path: intermediates live in aliased arena slots and are not readable

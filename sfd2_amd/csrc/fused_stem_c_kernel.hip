@@ -421,6 +421,11 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
 
         SC_STAMP(7)
         if (has_next) SC_STORE_IMG()          // the next tile's patch (requested a tile ago) -> IM, in front of the output stores
+#ifndef SFD2_STEMC_FETCH_LATE
+        // ... and the patch of the tile after next is requested HERE, in front of this tile's output stores: issued behind them (as until round 4)
+        // the request sat 1.3-4.3k cycles in the vector-memory queue (profiles/r04e_stemc_trace.txt, column "fetch issue")
+        if (has_next && next2 < n_tiles) SC_FETCH_IMG(next2)
+#endif
         SC_STAMP(8)
         const int oy = oy0 + kg, ox = ox0 + lrow;
         const bool inb = oy < H2 && ox < W2;
@@ -451,7 +456,9 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
         if (!X3) { const unsigned int wb = sfd2_wave_max_bits(mx2); smax2 = wb > smax2 ? wb : smax2; }
         SC_STAMP(9)
         if (!has_next) break;
+#ifdef SFD2_STEMC_FETCH_LATE
         if (next2 < n_tiles) SC_FETCH_IMG(next2)
+#endif
         SC_STAMP(10)
         SC_LDS_BARRIER();                     // IM complete; every wave is done with the partials (phase 1 writes X1 again)
         SC_STAMP(11)

@@ -435,6 +435,46 @@ def test_matcher_exact_ties_take_the_first_index(name):
     assert ((dq == -1).mean() > 0.9) if conf["do_mutual_check"] else ((dq == dup_q).mean() > 0.9)
 
 
+def test_matcher_near_ties_are_bounded():
+    """Near ties: the mutual modes carry an 8-bit query id in the low mantissa bits of the column maxima, so two
+    similarities closer than 2^-15 relative compare equal and the lower index wins -- torch compares all 24 bits.  Where the two
+    differ, the pair this library reports is a mutual nearest neighbour UP TO that truncation: never a pair whose similarity is
+    more than 2^-14 (relative) below the row's and the column's true maximum.  Descriptors are fp16-representable, so the only
+    differences left are summation order (1e-7) and the truncation."""
+    rs = np.random.RandomState(77)
+    n0, n1 = 1500, 1800
+    d0 = synth.make_descriptors(n0, seed=51).astype(np.float16).astype(np.float32)
+    d1 = synth.make_descriptors(n1, seed=52).astype(np.float16).astype(np.float32)
+    d1[:600] = d0[rs.permutation(n0)[:600]]                      # partners
+    base = rs.permutation(600)[:300]
+    dup = 600 + np.arange(300)
+    d1[dup] = d1[base]                                           # near-duplicates of partners: one element one fp16 step away
+    k = rs.randint(0, 128, size=300)
+    step = np.spacing(np.abs(d1[dup, k]).astype(np.float16)).astype(np.float32)
+    d1[dup, k] += np.where(rs.rand(300) < 0.5, step, -step)
+    conf = HLOC_CONFS["NNM"]
+    want = orc.hloc_nearest_neighbor(d0, d1, **conf)["matches0"]
+    got, _ = _hloc(d0, d1, conf, "f16")
+    sim = d0.astype(np.float64) @ d1.astype(np.float64).T
+    rmax, cmax = sim.max(axis=1), sim.max(axis=0)
+    diff = np.nonzero(got != want)[0]
+    assert len(diff) <= 0.15 * n0, len(diff)      # (300 planted near-duplicates: each can flip a row either way)
+    tol = 2.0 ** -14
+    for i in diff:
+        if got[i] >= 0:       # a reported pair must be mutual up to the truncation
+            j = got[i]
+            assert sim[i, j] >= rmax[i] - tol * abs(rmax[i]) and sim[i, j] >= cmax[j] - tol * abs(cmax[j]), (i, j)
+        if want[i] >= 0:      # a dropped pair must have lost against a near-equal
+            j = want[i]
+            assert got[i] >= 0 or np.sort(sim[:, j])[-2] >= cmax[j] - tol * abs(cmax[j]) or np.sort(sim[i])[-2] >= rmax[i] - tol * abs(rmax[i]), (i, j)
+    # rows without a near-tie are identical
+    r2 = np.sort(sim, axis=1)[:, -2]
+    clear = (rmax - r2) > 1e-3
+    cl_c = (cmax - np.sort(sim, axis=0)[-2]) > 1e-3
+    rows = np.nonzero(clear & ((want < 0) | cl_c[np.maximum(want, 0)]))[0]
+    assert (got[rows] == want[rows]).mean() > 0.995
+
+
 def test_matcher_batch_equals_single_and_handles_empty():
     from sfd2_amd.matcher import Matcher, confs as mconfs
     mt = Matcher(mconfs["NNM"])

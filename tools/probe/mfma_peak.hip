@@ -135,6 +135,81 @@ static void run_mixed(int W, int cus, float *out, unsigned long long *clk)
     (void)hipEventDestroy(e1);
 }
 
+// Third question: the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64: 131 072 FLOP per instruction) by operand format -- what the
+// compensated mode's correction MFMAs cost.  cbsz / blgp: 0 = fp8 e4m3, 2 = fp6 e2m3, 4 = fp4 e2m1.  Four chains, random operand bits.
+// (inline asm: through the builtin hipcc moved every accumulator through AGPRs and back once per iteration)
+template <int N> struct VecI { typedef int type __attribute__((ext_vector_type(N))); };
+template <int F> struct FmtRegs { static constexpr int n = F == 0 ? 8 : (F == 2 ? 6 : 4); };
+#define SC_STR2(x) #x
+#define SC_STR(x) SC_STR2(x)
+template <int FA, int FB>
+__global__ __launch_bounds__(256) void scaled(float *out, int iters, unsigned long long *clk)
+{
+    extern __shared__ unsigned char pad[];
+    typedef typename VecI<FmtRegs<FA>::n>::type va_t;
+    typedef typename VecI<FmtRegs<FB>::n>::type vb_t;
+    f32x16 c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int r = 0; r < 16; ++r) c[q][r] = 0.f;
+    va_t A[4];
+    vb_t B[4];
+    unsigned x = (threadIdx.x + 256u * blockIdx.x) * 2654435761u + 777u;
+    for (int k = 0; k < 4; ++k) {
+        for (int i = 0; i < FmtRegs<FA>::n; ++i) { x = x * 1664525u + 1013904223u; A[k][i] = (int)(x & 0x37373737u); }   // (exponent fields kept small: finite in every format)
+        for (int i = 0; i < FmtRegs<FB>::n; ++i) { x = x * 1664525u + 1013904223u; B[k][i] = (int)(x & 0x37373737u); }
+    }
+    int sc = 0x7f7f7f7f;
+    asm volatile("" : "+v"(sc));
+    if (threadIdx.x == 9999) pad[0] = 1;
+    const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (FA == 0 && FB == 0) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c[m % 4]) : "v"(A[m & 3]), "v"(B[(m >> 2) & 3]), "v"(sc));
+            if (FA == 0 && FB == 2) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] blgp:2" : "+v"(c[m % 4]) : "v"(A[m & 3]), "v"(B[(m >> 2) & 3]), "v"(sc));
+            if (FA == 2 && FB == 2) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:2 blgp:2" : "+v"(c[m % 4]) : "v"(A[m & 3]), "v"(B[(m >> 2) & 3]), "v"(sc));
+            if (FA == 4 && FB == 4) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+v"(c[m % 4]) : "v"(A[m & 3]), "v"(B[(m >> 2) & 3]), "v"(sc));
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int r = 0; r < 16; ++r) s += c[q][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
+}
+template <int FA, int FB>
+static void run_scaled(int W, int cus, float *out, unsigned long long *clk, const char *name)
+{
+    const size_t lds = (size_t)(160 * 1024 / W) - 1024;
+    auto k = scaled<FA, FB>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int iters = 30000 / W;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    unsigned long long h[2] = {0, 0};
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k, dim3(cus * W), dim3(256), lds, 0, out, iters, clk);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < best) { best = ms; (void)hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost); }
+    }
+    const double mf_simd = (double)iters * 16.0 * W;
+    const double ns = best * 1e6 / mf_simd;
+    const double mhz = (double)h[0] / ((double)h[1] * 10.0) * 1000.0;
+    printf("scaled   W=%d %-11s: %6.2f ns/MFMA/SIMD  %5.1f cyc/MFMA/SIMD  shader clock %4.0f MHz  %5.3f PFLOP/s (K = 64)\n", W, name, ns, ns * mhz * 1e-3, mhz,
+           (double)cus * 4.0 * mf_simd * 131072.0 / (best * 1e-3) / 1e15);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+}
+
 template <int CHAINS, bool AGPR>
 static void run(int W, int data, int cus, float *out, unsigned long long *clk, const char *dname)
 {
@@ -177,6 +252,13 @@ int main(int argc, char **argv)
     (void)hipMalloc(&clk, 16);
     const char *names[3] = {"zeros", "relu", "uniform"};
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+    if (argc > 1 && !strcmp(argv[1], "scaled")) {
+        for (int W = 1; W <= 2; ++W) {
+            run_scaled<0, 0>(W, cus, out, clk, "fp8 x fp8"); run_scaled<0, 2>(W, cus, out, clk, "fp8 x fp6"); run_scaled<2, 2>(W, cus, out, clk, "fp6 x fp6");
+            run_scaled<4, 4>(W, cus, out, clk, "fp4 x fp4");
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "mixed")) {
         for (int W = 1; W <= 2; ++W) {
             run_mixed<0>(W, cus, out, clk); run_mixed<2>(W, cus, out, clk); run_mixed<4>(W, cus, out, clk); run_mixed<6>(W, cus, out, clk);
