@@ -106,7 +106,8 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                        const half_t *__restrict__ in_c = nullptr, half_t *__restrict__ out_c = nullptr, int sa = 0,
                        unsigned int *__restrict__ range = nullptr /* the output tensor's range-status slot (compensated output) */)
 {
-    static_assert(COMP == 0 || (!RES && ABL == 0), "compensated instantiations: streamed filters");
+    static_assert(COMP == 0 || !RES, "compensated instantiations: streamed filters");
+    // (ABL with COMP = 3: experiment builds only, SFD2_RFC_ABL -- 1 no filter loads, 2 no fragment reads, 4 no patch copies, 8 no stores, 16 no MFMAs)
     // COMP bit 2 (X3, SFD2_PREC_F16X3): in / in_c are hi / lo' planes, wpk holds the filters' hi units then their lo' units; a tile's
     // chunk sequence runs the plain fp16 body three times -- (hi plane, hi filters), the accumulators times 2^11 (exact), (hi plane, lo'
     // filters), (lo' plane, hi filters) -- and the epilogue folds 2^-11 into the scale.  Output: hi / lo' planes (out / out_c), or with
@@ -264,6 +265,8 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         RF_READ_B(Xs, 0, 1, fb[1]);
     }
 
+    int sb1 = 0x7f7f7f7f;                                  // the B side's scale bytes (2^0), in a register for the asm form
+    asm volatile("" : "+v"(sb1));
     int bc = 0;                                            // C % 3: three patch buffers
     int c = 0, seq = 0, C = 0;                             // chunk within the tile, tile of this block, chunk of this block
     // one chunk; CC = the chunk's index within the tile as a constant (RES), or -1 (runtime c)
@@ -272,6 +275,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         // a corr-plane chunk (COMP & 1)?  A wave-uniform RUNTIME flag: two instantiations of this body (one per chunk type) cost
         // 70 more registers than one (each copy keeps its own hoisted state across the shared rings) and spill in the unit loop
         const bool F8 = (CPB & 1) && c >= NCP;
+        const int f8s = __builtin_amdgcn_readfirstlane(F8 ? 1 : 0);   // (a scalar register for the branch inside sfd2_mfma_unit2)
         if (X3 && c == NCP) {                               // the hi x hi sums are complete: the cross terms carry 2^-11
 #pragma unroll
             for (int f = 0; f < NF; ++f)
@@ -306,31 +310,24 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             }
             if constexpr (CPB != 0) {
                 // the pixel fragments of unit t + 1 (of the next chunk's first unit at t = 8: its patch has landed, see above)
-                if (t + 1 < 9) RF_READ_B8(xs, t + 1, fb8[(t + 1) & 1]);
-                else RF_READ_B8(xn, 0, fb8[1]);
+                if (!(ABL & 2)) {
+                    if (t + 1 < 9) RF_READ_B8(xs, t + 1, fb8[(t + 1) & 1]);
+                    else RF_READ_B8(xn, 0, fb8[1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                if (F8) {
-                    // the ring holds K-slice halves (4-register values); the fp8 operand is joined HERE: left to itself hipcc keeps a second,
-                    // tuple-shaped copy of the whole ring alive across the chunk (72 more registers, spills in the unit loop)
+                if (!(ABL & 16)) {
+                    // both chunk types are ONE statement to hipcc (a scalar branch inside the asm picks four fp16 or two fp8 MFMAs): with an
+                    // if / else around builtins it copied every accumulator back to its home registers where the paths meet -- 160 v_mov_b64 per
+                    // chunk, as much VALU time as the chunk's MFMAs (profiles/r04_conv2b_ablations.txt)
+                    static_assert(NF == 2, "sfd2_mfma_unit2: two pixel fragments per wave");
                     h8_t x0 = fa[t][0], x1 = fa[t][1];
                     asm volatile("" : "+v"(x0), "+v"(x1));
-                    const v8i_t a8 = sfd2_cat8(x0, x1);
-#pragma unroll
-                    for (int f = 0; f < NF; ++f)
-                        acc[f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, fb8[t & 1][f], acc[f], 0, 0, 0, sa, 0, 0x7f7f7f7f);
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(acc[f]));   // (pure nodes to instruction selection: keep them here)
-                } else {
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                        for (int f = 0; f < NF; ++f)
-                            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][kk], sfd2_half8(fb8[t & 1][f], kk), acc[f], 0, 0, 0);
+                    sfd2_mfma_unit2(acc[0], acc[1], x0, x1, sfd2_cat8(x0, x1), fb8[t & 1][0], fb8[t & 1][1], sa, sb1, f8s);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 int ua = c * 9 + t + 9;
                 if (ua >= NU) ua -= NU;
-                RF_LOAD_A(ua, fa[t]);
+                if (!(ABL & 1)) RF_LOAD_A(ua, fa[t]);
                 __builtin_amdgcn_sched_barrier(0);
                 continue;
             }
@@ -367,6 +364,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     unsigned int smax = 0;         // range status: the largest value in front of the saturation, wave-uniform across the tiles
     auto epilogue = [&]() {
         float mx = 0.0f;
+        if constexpr ((CPB & 1) != 0) sfd2_mfma_settle();   // the tile's last MFMAs were issued by inline asm
         if (SS_RELOAD) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -525,6 +523,16 @@ bool launch_conv3x3_rf_c(hipStream_t st, const half_t *in, const half_t *in_c, i
     if ((long long)(Ho * stride + 2) * (Wo * stride + 2) * Cin * (long long)sizeof(half_t) >= (1ll << 31)) return false;
     const int sa = (sbyte & 255) * 0x01010101;
     if (CoutP == 128 && stride == 2) {
+#ifdef SFD2_EXPERIMENTS
+        if (const char *ab = sfd2_env("SFD2_RFC_ABL")) {
+            switch (atoi(ab)) {
+#define RFC_ABL_CASE(a_) case a_: launch_rf_t<2, 128, a_, false, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range); return true;
+                RFC_ABL_CASE(1) RFC_ABL_CASE(2) RFC_ABL_CASE(4) RFC_ABL_CASE(8) RFC_ABL_CASE(16) RFC_ABL_CASE(5) RFC_ABL_CASE(7) RFC_ABL_CASE(23)
+#undef RFC_ABL_CASE
+            default: break;
+            }
+        }
+#endif
         launch_rf_t<2, 128, 0, false, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
         return true;
     }

@@ -87,6 +87,37 @@ __device__ __forceinline__ f32x16_t sfd2_mfma_corr(h8_t a0, h8_t a1, h8_t b0, h8
 {
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(sfd2_cat8(a0, a1), sfd2_cat8(b0, b1), acc, 0, 0, 0, sa, 0, 0x7f7f7f7f);
 }
+// The same instruction with the accumulator TIED (destination = C operand), by inline asm.  To instruction selection the scaled MFMA's
+// destination is a fresh value: in straight-line code the accumulators then ping-pong between two register sets for free, but where two
+// control-flow paths (an fp16 unit / an fp8 unit behind a wave-uniform flag) meet, hipcc copies every accumulator back to its home
+// registers -- conv3x3_rf<2, 128, comp> carried 160 v_mov_b64 per chunk, as much VALU time as its MFMAs (profiles/r04_conv2b_ablations.txt).
+// The asm is opaque to hipcc's hazard recogniser: a VALU read of the accumulators must be preceded by sfd2_mfma_settle().
+__device__ __forceinline__ void sfd2_mfma_corr_tied(f32x16_t &acc, v8i_t a, v8i_t b, int sa, int sb)
+{
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
+// One unit (tap x 32 channels) of a kernel whose chunk type is a wave-uniform RUNTIME flag, for two pixel fragments: four fp16 MFMAs (both K
+// slices of both fragments) or two scaled fp8 MFMAs, chosen by a scalar branch INSIDE the asm, so that to hipcc both chunk types are the same
+// straight-line statement with tied accumulators.  b0 / b1: the fragments' 8-dword tuples (their halves are the fp16 operands), a8 = (a0, a1).
+__device__ __forceinline__ void sfd2_mfma_unit2(f32x16_t &c0, f32x16_t &c1, h8_t a0, h8_t a1, v8i_t a8, v8i_t b0, v8i_t b1, int sa, int sb, int f8)
+{
+    const h8_t b00 = sfd2_half8(b0, 0), b01 = sfd2_half8(b0, 1), b10 = sfd2_half8(b1, 0), b11 = sfd2_half8(b1, 1);
+    asm volatile("s_cmp_lg_u32 %11, 0\n\t"
+                 "s_cbranch_scc1 .Lsfd2_u8_%=\n\t"
+                 "v_mfma_f32_32x32x16_f16 %0, %2, %5, %0\n\t"
+                 "v_mfma_f32_32x32x16_f16 %1, %2, %7, %1\n\t"
+                 "v_mfma_f32_32x32x16_f16 %0, %3, %6, %0\n\t"
+                 "v_mfma_f32_32x32x16_f16 %1, %3, %8, %1\n\t"
+                 "s_branch .Lsfd2_ue_%=\n"
+                 ".Lsfd2_u8_%=:\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %4, %12, %0, %9, %10 op_sel_hi:[0,0,0]\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %1, %4, %13, %1, %9, %10 op_sel_hi:[0,0,0]\n"
+                 ".Lsfd2_ue_%=:"
+                 : "+v"(c0), "+v"(c1)
+                 : "v"(a0), "v"(a1), "v"(a8), "v"(b00), "v"(b01), "v"(b10), "v"(b11), "v"(sa), "v"(sb), "s"(f8), "v"(b0), "v"(b1)
+                 : "scc");
+}
+__device__ __forceinline__ void sfd2_mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }   // 32 wait states >= any XDL write -> VALU read distance
 // corr units of two channels (values v0, v1 with fp16 parts h0, h1) as one dword: bytes (lo8_0, x8_0, lo8_1, x8_1).
 // v_cvt_pk_fp8_f32 returns NaN above 464, hence the clamps (x saturates at 1792, its residual then too).
 __device__ __forceinline__ unsigned sfd2_corr2(float v0, half_t h0, float v1, half_t h1)
