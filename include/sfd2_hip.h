@@ -139,6 +139,13 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *   "fp6_filters" 0 (default) / 1: SFD2_PREC_F16C, conv2a / conv3a / conv3b: the correction filters as e2m3 (fp6) with one power-of-two
  *               scale per output channel instead of e4m3 (fp8 x fp6 scaled MFMA).  Same tolerance (descriptors <= 5.2e-4 measured),
  *               no measurable speed difference on MI355X: an experiment switch.
+ *   "fp6_acts"  1 (default) / 0: SFD2_PREC_F16C, the correction records of the three tensors whose only reader is conv3x3_pp<comp>
+ *               (conv1b's, conv2b's and conv3a's output) as block-scaled fp6: per pixel and 16 channels 32 e2m3 codes (residual * 2^11 and
+ *               value of every channel) and one E8M0 exponent, written by the producers' epilogues (v_cvt_scalef32_2xpk16_fp6_f32); conv2a /
+ *               conv3a / conv3b then correct with ONE fp6 x fp6 scaled MFMA per unit (33.5 cycles; 66 with fp8 on either side).
+ *               -37 us per 1600x1200 extract (profiles/r04n_ab_fp6_acts.txt); descriptor rms error +1 .. 2.4 % of the fp8 records'
+ *               (profiles/r04n_fp6_record_formats.txt), same 1e-3 tolerance asserted.  Decided per tensor: a producer that is not the
+ *               tuned kernel ("fuse" 0, "no_rf_c", "generic_c") keeps its records fp8.  0 = fp8 records everywhere.
  *   "cu_limit"  0 (default) / n: persistent kernels of THIS context launch at most n blocks (experiment: with two streams, two kernels
  *               side by side on half the chip each measure the same throughput as taking turns on all of it).
  *   "auto_range" 1 (default) / 0: sfd2_load_weights calibrates the activation exponents on a built-in probe image (see

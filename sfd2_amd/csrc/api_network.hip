@@ -182,7 +182,8 @@ static unsigned int *range_slot(sfd2_ctx *c, int id)
 }
 static half_t *corr_of(const DevPtr &b, size_t px, int pitch) { return b.as<half_t>() + px * (size_t)pitch; }
 static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &in, int H, int W, const DevPtr &out,
-                  int Ho, int Wo, int relu, bool in_comp, bool out_comp, const DevPtr *res = nullptr, int rs_id = -1 /* SFD2_RS_*: the output's range-status slot */)
+                  int Ho, int Wo, int relu, bool in_comp, bool out_comp, const DevPtr *res = nullptr, int rs_id = -1 /* SFD2_RS_*: the output's range-status slot */,
+                  int fmt6 = 0 /* option "fp6_acts": bit 0 = the input's corr records are fp6 half-records, bit 1 = the output's are to be */)
 {
     unsigned int *rs = range_slot(c, rs_id);
     char kn[48];
@@ -196,17 +197,30 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &i
     // conv3x3_pp's tile is 128 channels wide: in its compensated form it also takes conv2a (64 -> 128 channels, four chunks)
     if (!res && !c->opt_generic_c && L.ks == 3 && L.stride == 1 && L.cout_pad % 128 == 0 && L.cin % 64 == 0) {
         ProfScope ps(c, name, "conv3x3_pp<comp>", flops, bytes);
+        if (fmt6 && in_c && out_c && relu && L.wc66.p && L.sa66.p && L.wc6.p && L.sa6.p) {
+            // fp6 pixel records on either side: the filter strings in the input records' format (fp6 x fp6 when the input's are fp6)
+            const bool i6 = (fmt6 & 1) != 0;
+            launch_conv3x3_pp_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, i6 ? L.wc66.as<half_t>() : L.wc6.as<half_t>(), L.scale.as<float>(),
+                                L.shift.as<float>(), L.cout_pad, relu, out.as<half_t>(), out_c, Ho, Wo, c->zero_page.as<half_t>(), L.sbyte,
+                                i6 ? L.sa66.as<float>() : L.sa6.as<float>(), rs, fmt6);
+            return;
+        }
+        if (fmt6) { fprintf(stderr, "sfd2: %s: fp6 records requested from a layer without fp6 filter strings\n", name); abort(); }
         const bool f6 = c->opt_fp6_filters && in_c && out_c && L.wc6.p && L.sa6.p;      // corr filters as fp6 (option "fp6_filters")
         launch_conv3x3_pp_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, f6 ? L.wc6.as<half_t>() : L.wc.as<half_t>(), L.scale.as<float>(),
                             L.shift.as<float>(), L.cout_pad, relu, out.as<half_t>(), out_c, Ho, Wo, c->zero_page.as<half_t>(), L.sbyte,
                             f6 ? L.sa6.as<float>() : nullptr, rs);
         return;
     }
+    if ((fmt6 & 1) || ((fmt6 & 2) && !(!c->opt_generic_c && !c->opt_no_rf_c && conv3x3_rf_c_serves(L.ks, L.stride, L.cout_pad, L.cin, Ho, Wo) && relu))) {
+        fprintf(stderr, "sfd2: %s: fp6 records on a path that cannot read / write them\n", name);     // (run_network decides per tensor: cannot happen)
+        abort();
+    }
     if (!c->opt_generic_c && !c->opt_no_rf_c && in_c && out_c && !res && L.ks == 3 && L.stride == 2 && L.cout_pad == 128) {   // conv2b
         ProfScope ps(c, name, "conv3x3_rf<2,comp>", flops, bytes);
         if (!launch_conv3x3_rf_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, L.wc.as<half_t>(), L.scale.as<float>(),
                                 L.shift.as<float>(), L.cout_pad, L.stride, relu, out.as<half_t>(), out_c, Ho, Wo,
-                                c->zero_page.as<half_t>(), L.sbyte, rs))
+                                c->zero_page.as<half_t>(), L.sbyte, rs, fmt6 & 2))
             ps.cancel();     // no instantiation for this geometry: the next candidate takes the layer (and the profile row)
         else
             return;
@@ -528,12 +542,28 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     };
     if (comp) {
         // SFD2_PREC_F16C backbone: every activation carries a corr plane, every layer adds the fp8 correction terms
+        // Option "fp6_acts": three tensors have conv3x3_pp<comp> as their only reader -- conv1b's output (-> conv2a), conv2b's (-> conv3a) and
+        // conv3a's (-> conv3b).  Their corr records leave the producer as block-scaled fp6 half-records, and the consumer's correction is one
+        // fp6 x fp6 scaled MFMA per unit: 33.5 cycles where a unit with fp8 on either side takes 66 (profiles/r04_mfma_probe.txt).  Decided
+        // per tensor: the producer must be the kernel that can write them.
+        const bool use6 = c->opt_fp6_acts && !c->opt_generic_c && c->c2a.wc66.p && c->c3a.wc66.p && c->c3b.wc66.p;
+        const bool s6 = use6 && c->fuse_now;                                                                   // a1b (the fused stem writes it)
+        const bool b6 = use6 && !c->opt_no_rf_c && conv3x3_rf_c_serves(3, 2, c->c2b.cout_pad, c->c2b.cin, H4, W4);   // a2b (conv3x3_rf<2,comp>)
+        const bool a6 = use6;                                                                                   // a3a (conv3x3_pp<comp>)
+        {
+            static const char *t6[3] = {"bn1b", "bn2b", "conv3a"};
+            const bool f6[3] = {s6, b6, a6};
+            for (int i = 0; i < 3; ++i) {
+                auto it = c->acts.find(t6[i]);
+                if (it != c->acts.end()) it->second.fmt6 = f6[i];
+            }
+        }
         if (c->fuse_now && !c->opt_generic_c) {
             ProfScope ps(c, "conv1a+conv1b", "fused_stem_c_kernel", 2.0 * P1 * 64 * 27 + 2.0 * (double)H2 * W2 * 64 * 576,
                          P1 * 12 + (double)H2 * W2 * 256);
             launch_fused_stem_c(st, img_dev, H, W, normalise, c->c1a.wc.as<half_t>(), c->c1a.scale.as<float>(),
                                 c->c1a.shift.as<float>(), c->w1b_stem_c.p, c->c1b.scale.as<float>(), c->c1b.shift.as<float>(),
-                                a1b.as<half_t>(), corr_of(a1b, (size_t)H2 * W2, 64), H2, W2, c->c1b.sbyte, c->range_stat.as<unsigned int>());
+                                a1b.as<half_t>(), corr_of(a1b, (size_t)H2 * W2, 64), H2, W2, c->c1b.sbyte, c->range_stat.as<unsigned int>(), s6 ? 2 : 0);
         } else {
             {
                 ProfScope ps(c, "conv1a", "conv1a_c_kernel", 2.0 * P1 * 64 * 27, P1 * (12 + 256));
@@ -542,10 +572,10 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
             }
             convc(c, "conv1b", c->c1b, c->a1a, H, W, a1b, H2, W2, 1, true, true, nullptr, SFD2_RS_CONV1B);
         }
-        convc(c, "conv2a", c->c2a, a1b, H2, W2, a2a, H2, W2, 1, true, true, nullptr, SFD2_RS_CONV2A);
-        convc(c, "conv2b", c->c2b, a2a, H2, W2, a2b, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV2B);
-        convc(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV3A);
-        convc(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV3B);
+        convc(c, "conv2a", c->c2a, a1b, H2, W2, a2a, H2, W2, 1, true, true, nullptr, SFD2_RS_CONV2A, s6 ? 1 : 0);
+        convc(c, "conv2b", c->c2b, a2a, H2, W2, a2b, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV2B, b6 ? 2 : 0);
+        convc(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV3A, (b6 ? 1 : 0) | (a6 ? 2 : 0));
+        convc(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV3B, a6 ? 1 : 0);
         for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
             if (!c->opt_comp_rb) { rb_f16(b); continue; }   // option "comp_rb" = 0: this block in plain fp16 on the hi planes
             DevPtr &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];

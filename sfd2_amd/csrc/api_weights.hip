@@ -206,11 +206,17 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
             // One power-of-two scale per OUTPUT CHANNEL (all taps, all input channels): 2^ec >= max|w| / 7.5; its E8M0 byte goes to
             // the MFMA's A-side scale operand lane by lane.  fp8 x fp6 issues in 32 ns where fp8 x fp8 takes 37-41
             // (profiles/r03k_mfma_f8f6f4_probe.txt); descriptors on the CPU twin 4.1e-4 against 4.0e-4 (profiles/r03k_error_budget_fp6.txt).
+            //
+            // pix6 (option "fp6_acts"): the pixel records are fp6 half-records too (sfd2_epi16_fp6): position p of string h = code 2 j + (p & 1),
+            // j = p / 2 <-> channel 8 (j / 4) + 4 h + (j % 4) of the chunk; p even pairs with the pixel's residual code (lo' = (x - hi) * 2^11 over
+            // the pixel block's scale), p odd with its value code, so the filter side carries w, then lo'_w = (w - fp16(w)) * 2^11, and 2^-11 moves
+            // into the scale byte: 2^(ec - 11).
+            std::vector<int> ec(cout_pad, 0);
+            for (int pix6 = 0; pix6 < 2; ++pix6) {
             std::vector<unsigned short> p6(2 * plane, 0);
             std::memcpy(p6.data(), pc.data(), plane * 2);
             std::vector<int> sa(2 * (size_t)cout_pad, 0x7f7f7f7f);      // [shift | scale bytes]
             std::memcpy(sa.data(), sh.data(), (size_t)cout_pad * sizeof(float));
-            std::vector<int> ec(cout_pad, 0);
             for (int oc = 0; oc < cout; ++oc) {
                 float mx = 0.0f;
                 for (size_t i = 0; i < (size_t)cin * T; ++i) mx = std::max(mx, std::fabs(w->d[(size_t)oc * cin * T + i]));
@@ -218,7 +224,7 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
                 while (std::ldexp(mx, -e) > 7.5f) ++e;
                 e = std::max(-40, std::min(40, e));
                 ec[oc] = e;
-                sa[cout_pad + oc] = ((127 - SFD2_C_XL_SHIFT + e) & 255) * 0x01010101;
+                sa[cout_pad + oc] = ((127 - (pix6 ? 11 : SFD2_C_XL_SHIFT) + e) & 255) * 0x01010101;
             }
             for (int ch = 0; ch < nch32; ++ch)
                 for (int t = 0; t < T; ++t)
@@ -227,7 +233,8 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
                         for (int h = 0; h < 2; ++h) {
                             unsigned char str[24] = {0};
                             for (int p6i = 0; p6i < 32; ++p6i) {
-                                const int j = 32 * h + p6i, k = j >> 1;
+                                const int j = 32 * h + p6i, jj = p6i >> 1;
+                                const int k = pix6 ? 8 * (jj >> 2) + 4 * h + (jj & 3) : j >> 1;
                                 const float v = w->d[(((size_t)oc * cin + ch * 32 + k) * ks + t / ks) * ks + t % ks];
                                 const float x = (j & 1) ? std::ldexp(v - (float)(half_t)v, 11 - ec[oc]) : std::ldexp(v, -ec[oc]);
                                 const unsigned int code = f32_to_e2m3(x);
@@ -239,9 +246,10 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
                             std::memcpy(row + 32 + 16 * h, str + 16, 8);
                         }
                     }
-            if (upload(L.wc6, p6.data(), p6.size() * 2, c->stream)) return -1;
-            L.h_sa6 = sa;
-            if (upload(L.sa6, sa.data(), sa.size() * sizeof(int), c->stream)) return -1;
+            if (upload(pix6 ? L.wc66 : L.wc6, p6.data(), p6.size() * 2, c->stream)) return -1;
+            (pix6 ? L.h_sa66 : L.h_sa6) = sa;
+            if (upload(pix6 ? L.sa66 : L.sa6, sa.data(), sa.size() * sizeof(int), c->stream)) return -1;
+            }
         }
         if (ks == 1 && stride == 1 && cin == 256 && cout == 256) {
             std::vector<half_t> fh((size_t)256 * 256), fl(fh.size());
@@ -565,6 +573,11 @@ int apply_act_exponents(sfd2_ctx *c)
             std::vector<int> sa = L.h_sa6;
             std::memcpy(sa.data(), sh.data(), std::min(sh.size(), sa.size() / 2) * sizeof(float));
             if (upload(L.sa6, sa.data(), sa.size() * sizeof(int), c->stream)) return -1;
+        }
+        if (!L.h_sa66.empty() && L.sa66.p) {
+            std::vector<int> sa = L.h_sa66;
+            std::memcpy(sa.data(), sh.data(), std::min(sh.size(), sa.size() / 2) * sizeof(float));
+            if (upload(L.sa66, sa.data(), sa.size() * sizeof(int), c->stream)) return -1;
         }
     }
     if (c->has_sta && !c->h_sta_w.empty()) {        // ConvSta reads the backbone output with fp32 filters of its own

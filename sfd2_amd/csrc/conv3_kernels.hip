@@ -112,6 +112,9 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                        unsigned int *__restrict__ range = nullptr /* the output tensor's range-status slot (compensated output) */)
 {
     constexpr bool F6 = (COMP & 16) != 0;
+    constexpr bool B6 = (COMP & 32) != 0;                  // the INPUT's corr records are fp6 half-records (sfd2_internal.h; with F6: fp6 x fp6, 33.5 cycles per scaled MFMA)
+    constexpr bool O6 = (COMP & 64) != 0;                  // the OUTPUT's corr records are written as fp6 half-records
+    static_assert(!B6 || F6, "fp6 pixel operands come with fp6 filter strings");
     constexpr int SSN = F6 ? 3 : 2;                        // arrays per tile parity in SSb: scale, shift (, the fp6 filters' scale bytes)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Xs = smem;                              // [2][PP_XBYTES]
@@ -319,7 +322,8 @@ _Pragma("unroll") \
 _Pragma("unroll") \
                     for (int pr = 0; pr < 4; ++pr) \
                         if (!PP_NO_CORR_MFMA) \
-                        acc[ct][pr] = F6 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fac[ct], frc[pr + u3], acc[ct][pr], 2, 0, 0, sa6v[ct], 0, 0x7f7f7f7f) \
+                        acc[ct][pr] = B6 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fac[ct], frc[pr + u3], acc[ct][pr], 2, SFD2_PIX6_BLGP, 0, sa6v[ct], 0, frc[pr + u3][6]) \
+                                    : F6 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fac[ct], frc[pr + u3], acc[ct][pr], 2, 0, 0, sa6v[ct], 0, 0x7f7f7f7f) \
                                          : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fac[ct], frc[pr + u3], acc[ct][pr], 0, 0, 0, sa, 0, 0x7f7f7f7f); \
                 /* the scaled MFMA is a pure node to instruction selection, which otherwise sinks all 72 of a chunk below its last \
                    barrier (every fragment of nine units live at once); an empty asm on the accumulators keeps each unit's in its section */ \
@@ -396,6 +400,30 @@ _Pragma("unroll") \
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const int cl = wch + ct * 32 + 4 * lhi;
+            if constexpr (O6) {
+                // fp6 corr records (sfd2_epi16_fp6): this lane's 16 channels of the (pixel, 32-channel chunk) are one half-record
+                float4 sc4[4], sh4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    sc4[q] = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
+                    sh4[q] = *reinterpret_cast<const float4 *>(SS + PP_BN + cl + 8 * q);
+                }
+                uint2 hv4[4];
+                uint4 r0, r1;
+                sfd2_epi16_fp6(acc[ct][pr], sc4, sh4, (relu & 1) ? 0.0f : -SFD2_C_SAT, hv4, r0, r1, mx, inb);
+                const size_t ob = pix * CoutP + en0 + wch + ct * 32;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const auto t0 = __builtin_amdgcn_permlane32_swap(hv4[2 * m].x, hv4[2 * m + 1].x, false, false);
+                    const auto t1 = __builtin_amdgcn_permlane32_swap(hv4[2 * m].y, hv4[2 * m + 1].y, false, false);
+                    if (inb) *reinterpret_cast<uint4 *>(out + ob + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                }
+                if (inb) {
+                    *reinterpret_cast<uint4 *>(out_c + ob + 8 * lhi) = r0;            // slot lhi
+                    *reinterpret_cast<uint4 *>(out_c + ob + 16 + 8 * lhi) = r1;       // slot 2 + lhi
+                }
+                continue;
+            }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const size_t o16 = pix * CoutP + en0 + wch + ct * 32 + 8 * (2 * m + lhi);
@@ -507,10 +535,17 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
 // compensated instantiations (SFD2_PREC_F16C): wpk = the layer's wc array, sbyte its scale byte
 void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int relu, half_t *out, half_t *out_c,
-                         int Ho, int Wo, const half_t *zero_page, int sbyte, const float *shift_sa6, unsigned int *range)
+                         int Ho, int Wo, const half_t *zero_page, int sbyte, const float *shift_sa6, unsigned int *range, int fmt6)
 {
     const int sa = (sbyte & 255) * 0x01010101;
     // shift_sa6 != null: wpk's corr rows are fp6 strings and shift_sa6 = [shift[CoutP] | the rows' scale bytes as ints [CoutP]]
+    if (in_c && out_c && shift_sa6 && fmt6 != 0) {      // fp6 corr records: bit 0 of fmt6 = the input's, bit 1 = the output's (filters: the (w, lo'_w) strings)
+        if ((fmt6 & 3) == 3) launch_pp_t<1, 1, 0, 3 | 16 | 32 | 64>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
+        else if (fmt6 & 1) launch_pp_t<1, 1, 0, 3 | 16 | 32>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
+        else launch_pp_t<1, 1, 0, 3 | 16 | 64>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
+        return;
+    }
+    if (in_c && out_c && (fmt6 & 2)) { launch_pp_t<1, 1, 0, 3 | 64>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range); return; }
     if (in_c && out_c && shift_sa6) launch_pp_t<1, 1, 0, 19>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
     else if (in_c && out_c) launch_pp_t<1, 1, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
     else if (in_c) launch_pp_t<1, 1, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);

@@ -113,7 +113,7 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     // filters), (lo' plane, hi filters) -- and the epilogue folds 2^-11 into the scale.  Output: hi / lo' planes (out / out_c), or with
     // bit 3 fp32 [P][CoutP] through `out`.  CPB = the compensated-structure bits (0 for X3: it is the plain kernel's pipeline).
     constexpr bool X3 = (COMP & 4) != 0;
-    constexpr int CPB = X3 ? 0 : COMP;
+    constexpr int CPB = X3 ? 0 : (COMP & 3);               // (bit 6, with CPB: the output's corr records as fp6 half-records)
     constexpr bool OUTC = (CPB & 2) != 0 || (X3 && !(COMP & 8));
     using G = RfGeom<S>;
     constexpr int NWC = BN / 32, NF = 4 / (8 / NWC);       // channel groups; pixel fragments per wave
@@ -380,6 +380,26 @@ void conv3x3_rf_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
             const int oy = oy0 + 2 * (f0 + f) + ly, ox = ox0 + lx;
             const bool inb = oy < Ho && ox < Wo;
             const size_t pix = (size_t)(inb ? oy : 0) * Wo + (inb ? ox : 0);
+            if constexpr ((COMP & 64) != 0) {
+                // fp6 corr records (sfd2_epi16_fp6, sfd2_internal.h): the fragment's 16 channels of this lane are one half-record of its pixel
+                uint2 hv4[4];
+                uint4 r0, r1;
+                sfd2_epi16_fp6(acc[f], sc, sh, relu ? 0.0f : -SFD2_C_SAT, hv4, r0, r1, mx, inb);
+                const size_t ob = pix * CoutP + n0;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const auto t0 = __builtin_amdgcn_permlane32_swap(hv4[2 * m].x, hv4[2 * m + 1].x, false, false);
+                    const auto t1 = __builtin_amdgcn_permlane32_swap(hv4[2 * m].y, hv4[2 * m + 1].y, false, false);
+                    if (inb) *reinterpret_cast<uint4 *>(out + ob + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                }
+                if (inb) {
+                    *reinterpret_cast<uint4 *>(out_c + ob + 8 * lhi) = r0;
+                    *reinterpret_cast<uint4 *>(out_c + ob + 16 + 8 * lhi) = r1;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+                continue;
+            }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const size_t o16 = pix * CoutP + n0 + 8 * (2 * m + lhi);
@@ -515,9 +535,15 @@ static void launch_rf_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
 
 // compensated instantiations (SFD2_PREC_F16C): the stride-2 layer with 128 output channels (conv2b).  wpk = the layer's wc
 // array (32-wide chunks, hi then corr), sbyte its scale byte.  false = no instantiation for this shape.
+// the geometries launch_conv3x3_rf_c takes (a caller that wants fp6 output records has to know beforehand)
+bool conv3x3_rf_c_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo)
+{
+    if (ks != 3 || Cin % 64 != 0 || !(CoutP == 128 && stride == 2)) return false;
+    return (long long)(Ho * stride + 2) * (Wo * stride + 2) * Cin * (long long)sizeof(half_t) < (1ll << 31);
+}
 bool launch_conv3x3_rf_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out, half_t *out_c,
-                         int Ho, int Wo, const half_t *zero_page, int sbyte, unsigned int *range)
+                         int Ho, int Wo, const half_t *zero_page, int sbyte, unsigned int *range, int fmt6)
 {
     if (!in_c || !out_c || Cin % 64 != 0) return false;
     if ((long long)(Ho * stride + 2) * (Wo * stride + 2) * Cin * (long long)sizeof(half_t) >= (1ll << 31)) return false;
@@ -533,7 +559,8 @@ bool launch_conv3x3_rf_c(hipStream_t st, const half_t *in, const half_t *in_c, i
             }
         }
 #endif
-        launch_rf_t<2, 128, 0, false, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
+        if (fmt6 & 2) launch_rf_t<2, 128, 0, false, 3 | 64>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
+        else launch_rf_t<2, 128, 0, false, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
         return true;
     }
     return false;

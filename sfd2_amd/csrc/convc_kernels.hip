@@ -594,18 +594,40 @@ void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H,
 }
 
 // hi + corr planes -> NCHW fp32 (sfd2_debug_activation): hi + the residual the corr unit carries
+// fmt6: the corr plane holds fp6 half-records (sfd2_epi16_fp6): per 32-channel chunk 64 bytes, half-record h in the 16-byte slots h and 2 + h --
+// 32 six-bit codes (2 j = residual * 2^11, 2 j + 1 = value; j = 4 q + r <-> channel 8 q + 4 h + r), then the block's E8M0 scale byte
 __global__ void nhwc_hc_to_nchw_f_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in_c, int npix, int pitch, int c,
-                                         float *__restrict__ out)
+                                         float *__restrict__ out, int fmt6)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)npix * c) return;
     const int ch = (int)(i / npix), p = (int)(i % npix);
     const size_t o = (size_t)p * pitch + ch;
+    if (fmt6) {
+        const int cl = ch & 31, q = cl >> 3, h = (cl >> 2) & 1, r = cl & 3, j = 4 * q + r;
+        const unsigned char *rec = reinterpret_cast<const unsigned char *>(in_c) + ((size_t)p * pitch + (ch & ~31)) * 2;
+        const int bit = 12 * j;                                   // code 2 j of the 192-bit string: bytes 0..15 in slot h, 16..23 in slot 2 + h
+        auto byte_at = [&](int b) -> unsigned { return b < 16 ? rec[16 * h + b] : rec[32 + 16 * h + (b - 16)]; };
+        const unsigned w16 = byte_at(bit >> 3) | (byte_at((bit >> 3) + 1) << 8);
+        const unsigned code = (w16 >> (bit & 7)) & 63u;
+        const unsigned e8 = rec[32 + 16 * h + 8];
+        const int ex = (int)((code >> 3) & 3u), mant = (int)(code & 7u);
+#if SFD2_PIX6_BF6
+        const int ex3 = (int)((code >> 2) & 7u), m2 = (int)(code & 3u);
+        float v = ex3 ? (float)(4 + m2) * 0.25f * __builtin_ldexpf(1.0f, ex3 - 3) : (float)m2 * 0.0625f;
+        (void)ex; (void)mant;
+#else
+        float v = ex ? (float)(8 + mant) * 0.125f * (float)(1 << (ex - 1)) : (float)mant * 0.125f;
+#endif
+        if (code & 32u) v = -v;
+        out[i] = (float)in[o] + v * __builtin_ldexpf(1.0f, (int)e8 - 127 - 11);
+        return;
+    }
     const unsigned short u = reinterpret_cast<const unsigned short *>(in_c)[o];
     out[i] = (float)in[o] + sfd2_corr_lo((unsigned)u, 0);
 }
-void launch_nhwc_hc_to_nchw_f(hipStream_t st, const half_t *in, const half_t *in_c, int npix, int pitch, int c, float *out)
+void launch_nhwc_hc_to_nchw_f(hipStream_t st, const half_t *in, const half_t *in_c, int npix, int pitch, int c, float *out, int fmt6)
 {
     const size_t n = (size_t)npix * c;
-    hipLaunchKernelGGL(nhwc_hc_to_nchw_f_kernel, dim3((unsigned)((n + CNT - 1) / CNT)), dim3(CNT), 0, st, in, in_c, npix, pitch, c, out);
+    hipLaunchKernelGGL(nhwc_hc_to_nchw_f_kernel, dim3((unsigned)((n + CNT - 1) / CNT)), dim3(CNT), 0, st, in, in_c, npix, pitch, c, out, fmt6);
 }

@@ -77,7 +77,8 @@ __device__ __forceinline__ void sc_x3_epi4(float a0, float a1, float a2, float a
 // units: X1c holds lo', w2's second half the filters' lo' fragments, phase 2 runs hi x hi over the wave's units, scales the partial
 // sums by 2^11 (exactly) and adds the cross terms hi x lo' + lo' x hi to the same accumulators (2^-11 goes into phase 4), the
 // output planes are hi / lo'.
-template <bool X3>
+// O6: conv1b's corr records leave as fp6 half-records (sfd2_epi16_fp6) for a consumer that reads them with the fp6 x fp6 scaled MFMA.
+template <bool X3, bool O6 = false>
 __global__ __launch_bounds__(SC_NT, 2)
 void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normalise,
                          const half_t *__restrict__ w1 /*[2 hi/lo][2][3][64][8] conv1a A fragments*/,
@@ -430,6 +431,27 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
         const int oy = oy0 + kg, ox = ox0 + lrow;
         const bool inb = oy < H2 && ox < W2;
         const size_t ob = ((size_t)(inb ? oy : 0) * W2 + (inb ? ox : 0)) * 64;
+        if constexpr (O6 && !X3) {
+            float4 s4[4], h4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s4[q] = sfd2_lds_f4(SS + 128 + cth * 32 + 8 * q + 4 * lhi);
+                h4[q] = sfd2_lds_f4(SS + 192 + cth * 32 + 8 * q + 4 * lhi);
+            }
+            uint2 hv4[4];
+            uint4 r0, r1;
+            sfd2_epi16_fp6(tot, s4, h4, 0.0f, hv4, r0, r1, mx2, inb);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const auto t0 = __builtin_amdgcn_permlane32_swap(hv4[2 * m].x, hv4[2 * m + 1].x, false, false);
+                const auto t1 = __builtin_amdgcn_permlane32_swap(hv4[2 * m].y, hv4[2 * m + 1].y, false, false);
+                if (inb) *reinterpret_cast<uint4 *>(out + ob + cth * 32 + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+            }
+            if (inb) {
+                *reinterpret_cast<uint4 *>(out_c + ob + cth * 32 + 8 * lhi) = r0;
+                *reinterpret_cast<uint4 *>(out_c + ob + cth * 32 + 16 + 8 * lhi) = r1;
+            }
+        } else
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             uint2 pk[2], ck[2];
@@ -476,13 +498,14 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
 // sbyte < 0: the X3 instantiation (SFD2_PREC_F16X3): w2's second halves are the filters' lo' fragments, out / out_c the hi / lo' planes
 void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *w1, const float *sc1,
                          const float *sh1, const void *w2, const float *sc2, const float *sh2, half_t *out, half_t *out_c,
-                         int H2, int W2, int sbyte, unsigned int *range)
+                         int H2, int W2, int sbyte, unsigned int *range, int fmt6)
 {
     static bool attr_done = false;
     static int slots = 256;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stem_c_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stem_c_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stem_c_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
@@ -495,6 +518,10 @@ void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int nor
     if (sbyte < 0)
         hipLaunchKernelGGL(fused_stem_c_kernel<true>, dim3(grid), dim3(SC_NT), SC_LDS, st, img, H, W, normalise, w1, sc1, sh1,
                            reinterpret_cast<const unsigned char *>(w2), sc2, sh2, out, out_c, H2, W2, tiles_x, n_tiles, 0, nullptr);
+    else if (fmt6 & 2)
+        hipLaunchKernelGGL((fused_stem_c_kernel<false, true>), dim3(grid), dim3(SC_NT), SC_LDS, st, img, H, W, normalise, w1, sc1, sh1,
+                           reinterpret_cast<const unsigned char *>(w2), sc2, sh2, out, out_c, H2, W2, tiles_x, n_tiles,
+                           (sbyte & 255) * 0x01010101, range);
     else
         hipLaunchKernelGGL(fused_stem_c_kernel<false>, dim3(grid), dim3(SC_NT), SC_LDS, st, img, H, W, normalise, w1, sc1, sh1,
                            reinterpret_cast<const unsigned char *>(w2), sc2, sh2, out, out_c, H2, W2, tiles_x, n_tiles,

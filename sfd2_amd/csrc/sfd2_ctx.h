@@ -86,6 +86,8 @@ struct ConvW {                 // one folded + packed layer
     size_t w_floats = 0;       // floats in w (fp32 layers)
     std::vector<float> h_scale, h_shift;   // host copies of the folded constants as loaded (before the activation exponents)
     std::vector<int> h_sa6;                // host copy of sa6
+    DevBuf wc66, sa66;                     // the same two arrays for fp6 PIXEL records (option "fp6_acts"): the strings in the half-records' channel
+    std::vector<int> h_sa66;               // order (sfd2_epi16_fp6), the scale bytes 2^(ec - 11)
 };
 
 // Activation exponents of the fp16 family (SFD2_PREC_F16 / F16C): the stored tensor of group g is 2^act_exp[g] times the network's
@@ -96,7 +98,7 @@ struct ConvW {                 // one folded + packed layer
 enum { AE_CONV1A, AE_CONV1B, AE_CONV2A, AE_CONV2B, AE_CONV3A, AE_TRUNK /* conv3b's and every ResBlock's output: one skip path */,
        AE_T1_0, AE_T1_1, AE_T1_2, AE_T2_0, AE_T2_1, AE_T2_2, AE_PA0, AE_DA0, AE_COUNT };
 
-struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; const void *pc = nullptr; /* corr plane (f16c) */ int exp2 = 0; /* stored = value * 2^exp2 (activation exponents of the fp16 family) */ bool absent = false; /* stays on chip on the path taken */ };
+struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; const void *pc = nullptr; /* corr plane (f16c) */ int exp2 = 0; /* stored = value * 2^exp2 (activation exponents of the fp16 family) */ bool absent = false; /* stays on chip on the path taken */ bool fmt6 = false; /* pc holds fp6 half-records (option "fp6_acts") */ };
 
 struct sfd2_ctx {
     int device = 0;
@@ -142,6 +144,8 @@ struct sfd2_ctx {
     int skip_da3_now = 0;              // set per call: run_network leaves convDa.3 to the sparse descriptor path (sparse_da3_kernel)
     const half_t *da0_cur = nullptr;   // convDa.0 output of the last fp16 network pass
     DevBuf da3_sparse;                 // [sel_cap][4][256] fp16: convDa.3 on the sampled corner pixels
+    int opt_fp6_acts = 1;              // sfd2_set_option "fp6_acts": the corr records of the three tensors only conv3x3_pp<comp> reads (conv1b's, conv2b's,
+                                       // conv3a's output) as block-scaled fp6 half-records, their consumers' corr MFMAs fp6 x fp6 (33.5 cycles instead of 66)
     int opt_fp6_filters = 0;           // sfd2_set_option "fp6_filters": conv3x3_pp<comp> takes its corr filters as block-scaled fp6 (fp8 x fp6 MFMA).
                                        // Measured: conv3b 212.0 -> 212.1 us, extract 1.5188 -> 1.5165 ms, descriptors <=5.2e-4 (<=4.9e-4 without): the
                                        // mixed-format MFMA's shorter issue time in the probe does not show in the layer; off by default, kept as the

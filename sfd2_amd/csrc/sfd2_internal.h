@@ -240,6 +240,64 @@ __device__ __forceinline__ void sfd2_epi4(float a0, float a1, float a2, float a3
     cv.x = sfd2_corr2v(v01, h01);
     cv.y = sfd2_corr2v(v23, h23);
 }
+// ---- corr records in fp6 (round 4; option "fp6_acts": the tensors whose only readers are conv3x3_pp layers).  The scaled MFMA takes 66
+// cycles with fp8 operands on either side and 33.5 with e2m3 on both (profiles/r04_mfma_probe.txt), so the correction operands of those
+// layers are block-scaled e2m3: per pixel and lane half a HALF-RECORD of 32 bytes = 32 six-bit codes (24 B) + one E8M0 scale byte (replicated
+// into a dword) + 4 B padding, occupying the 16-byte slots {lhi, 2 + lhi} of the pixel's 64-byte record -- exactly the two slots the
+// consumer's lane half reads today, so staging and fragment reads do not change; the fragment's dwords 0..5 are the operand, dword 6 the
+// scale.  Codes (v_cvt_scalef32_2xpk16_fp6_f32, probed in tools/probe/cvt_fp6.hip: code 2 j = src0[j], code 2 j + 1 = src1[j], round to
+// nearest even, saturating at 7.5, value / scale): 2 j = lo'_j = (x_j - fp16(x_j)) * 2^11, 2 j + 1 = x_j, for the lane's 16 channels j = 4 q + r
+// <-> channel 8 q + 4 lhi + r of the chunk (the MFMA C layout of the producer).  |lo'| <= x, so ONE scale 2^E >= max x / 7.5 serves both;
+// the filters' strings carry (w, lo'_w) in the same positions and 2^-11 in their scale byte.  No fixed shifts: every block has its exponent.
+// SFD2_PIX6_BF6 = 1: the PIXEL codes are bf6 (e3m2: largest value 28, subnormal step 2^-4) instead of fp6 (e2m3: 7.5, 2^-3): one mantissa
+// bit less on the block's largest values, three binades more under the block's maximum before a residual falls into the subnormal step.
+#ifndef SFD2_PIX6_BF6
+#define SFD2_PIX6_BF6 0
+#endif
+#define SFD2_PIX6_BLGP (SFD2_PIX6_BF6 ? 3 : 2)
+typedef float f32x16v_t __attribute__((ext_vector_type(16)));
+typedef int v6i_t __attribute__((ext_vector_type(6)));
+template <bool TRACK = true>
+__device__ __forceinline__ void sfd2_epi16_fp6(const f32x16_t &acc, const float4 (&sc)[4], const float4 (&sh)[4], float lo, uint2 (&hv)[4], uint4 &rec0, uint4 &rec1,
+                                               float &mx, bool counted = true)
+{
+    f32x16v_t v, l;
+    float m = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x2_t v01 = f32x2_t{acc[4 * q], acc[4 * q + 1]} * f32x2_t{sc[q].x, sc[q].y} + f32x2_t{sh[q].x, sh[q].y};
+        f32x2_t v23 = f32x2_t{acc[4 * q + 2], acc[4 * q + 3]} * f32x2_t{sc[q].z, sc[q].w} + f32x2_t{sh[q].z, sh[q].w};
+        m = sfd2_max3(sfd2_max3(m, v01[0], v01[1]), v23[0], v23[1]);
+        v01[0] = __builtin_amdgcn_fmed3f(v01[0], lo, SFD2_C_SAT); v01[1] = __builtin_amdgcn_fmed3f(v01[1], lo, SFD2_C_SAT);
+        v23[0] = __builtin_amdgcn_fmed3f(v23[0], lo, SFD2_C_SAT); v23[1] = __builtin_amdgcn_fmed3f(v23[1], lo, SFD2_C_SAT);
+        const h2_t h01 = {(half_t)v01[0], (half_t)v01[1]}, h23 = {(half_t)v23[0], (half_t)v23[1]};
+        __builtin_memcpy(&hv[q].x, &h01, 4);
+        __builtin_memcpy(&hv[q].y, &h23, 4);
+        const f32x2_t l01 = (v01 - f32x2_t{(float)h01[0], (float)h01[1]}) * 2048.0f, l23 = (v23 - f32x2_t{(float)h23[0], (float)h23[1]}) * 2048.0f;
+        v[4 * q] = v01[0]; v[4 * q + 1] = v01[1]; v[4 * q + 2] = v23[0]; v[4 * q + 3] = v23[1];
+        l[4 * q] = l01[0]; l[4 * q + 1] = l01[1]; l[4 * q + 2] = l23[0]; l[4 * q + 3] = l23[1];
+    }
+#ifndef SFD2_NO_RANGE
+    if (TRACK) mx = counted ? __builtin_fmaxf(mx, m) : mx;
+#endif
+    const unsigned int mb = __float_as_uint(__builtin_fminf(__builtin_fmaxf(m, 0.0f), SFD2_C_SAT));
+    v6i_t d;
+#if SFD2_PIX6_BF6
+    // the block's exponent: the smallest E with max / 2^E <= 28 (max = f * 2^k, f in [0.5, 1): E = k - 5, one more when f > 0.875)
+    int e8 = (int)(mb >> 23) - 4 + ((mb & 0x7fffffu) > 0x600000u ? 1 : 0);
+    e8 = e8 < 1 ? 1 : e8;
+    const float scale = __uint_as_float((unsigned int)e8 << 23);
+    asm volatile("v_cvt_scalef32_2xpk16_bf6_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(l), "v"(v), "v"(scale));
+#else
+    // the block's exponent: the smallest E with max / 2^E <= 7.5 (max = f * 2^k, f in [0.5, 1): E = k - 3, one more when f > 0.9375)
+    int e8 = (int)(mb >> 23) - 2 + ((mb & 0x7fffffu) > 0x700000u ? 1 : 0);
+    e8 = e8 < 1 ? 1 : e8;
+    const float scale = __uint_as_float((unsigned int)e8 << 23);
+    asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(l), "v"(v), "v"(scale));
+#endif
+    rec0 = make_uint4((unsigned)d[0], (unsigned)d[1], (unsigned)d[2], (unsigned)d[3]);
+    rec1 = make_uint4((unsigned)d[4], (unsigned)d[5], (unsigned)e8 * 0x01010101u, 0u);
+}
 // the residual (x - hi) two corr units of a dword carry, as floats
 __device__ __forceinline__ float sfd2_corr_lo(unsigned d, int ch /*0 or 1*/)
 {
@@ -296,10 +354,12 @@ void launch_convc_igemm(hipStream_t st, const half_t *in, const half_t *in_c, in
 void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int relu, half_t *out, half_t *out_c,
                          int Ho, int Wo, const half_t *zero_page, int sbyte, const float *shift_sa6 = nullptr /* non-null: wpk's corr rows are fp6; [shift | scale bytes] */,
-                         unsigned int *range = nullptr /* the output tensor's range-status slot (SFD2_RANGE_SUB words), here and below */);
+                         unsigned int *range = nullptr /* the output tensor's range-status slot (SFD2_RANGE_SUB words), here and below */,
+                         int fmt6 = 0 /* bit 0: in_c holds fp6 half-records (then wpk / shift_sa6 are the fp6 x fp6 arrays), bit 1: out_c is written as fp6 half-records */);
+bool conv3x3_rf_c_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo);
 bool launch_conv3x3_rf_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out, half_t *out_c,
-                         int Ho, int Wo, const half_t *zero_page, int sbyte, unsigned int *range = nullptr);
+                         int Ho, int Wo, const half_t *zero_page, int sbyte, unsigned int *range = nullptr, int fmt6 = 0 /* bit 1: out_c as fp6 half-records */);
 bool launch_conv_igemm2_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                           const float *scale, const float *shift, int CoutP, int ks, int stride, int relu,
                           const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, int Ho, int Wo,
@@ -307,7 +367,8 @@ bool launch_conv_igemm2_c(hipStream_t st, const half_t *in, const half_t *in_c, 
 // compensated fused stem (fused_stem_c_kernel.hip): w1 = conv1a hi, lo fragments; w2 = conv1b register fragments
 void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *w1, const float *sc1,
                          const float *sh1, const void *w2, const float *sc2, const float *sh2, half_t *out, half_t *out_c,
-                         int H2, int W2, int sbyte, unsigned int *range_base = nullptr /* the context's range-status words (conv1a's and conv1b's slots) */);
+                         int H2, int W2, int sbyte, unsigned int *range_base = nullptr /* the context's range-status words (conv1a's and conv1b's slots) */,
+                         int fmt6 = 0 /* bit 1: out_c as fp6 half-records */);
 void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c, int npix, const half_t *w_frag,
                            const half_t *wc_frag, const float *scale, const float *shift, int relu, const half_t *res,
                            const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte, unsigned int *range = nullptr);
@@ -332,7 +393,7 @@ void launch_conv1a_c(hipStream_t st, const float *img, int H, int W, int normali
 void launch_gconv_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, const half_t *wpk /*fp16 fragments*/,
                     const void *wck /*corr fragments*/, const float *scale, const float *shift, half_t *out, half_t *out_c, int sbyte,
                     int row0, int row1 /*output rows [row0, row1)*/, unsigned int *range = nullptr);
-void launch_nhwc_hc_to_nchw_f(hipStream_t st, const half_t *in, const half_t *in_c, int npix, int pitch, int c, float *out);
+void launch_nhwc_hc_to_nchw_f(hipStream_t st, const half_t *in, const half_t *in_c, int npix, int pitch, int c, float *out, int fmt6 = 0 /* in_c: fp6 half-records */);
 
 // ---- strict fp32 mode (conv_f32_kernels.hip): fp32 NHWC activations, f32-input MFMA
 //   wpk [Cin/32][ks*ks][Cout_pad][32] fp32

@@ -50,6 +50,11 @@ ROWS = [
     ({"generic_c": 1, "rb_inner": 0, "fuse": 0}, ("f16c",), False),
     ({"no_rf_c": 1}, ("f16c",), False),
     ({"range_fallback": 0}, ("f16c",), True),
+    ({"fp6_acts": 1}, ("f16c",), False),
+    ({"fp6_acts": 1, "fuse": 0}, ("f16c",), False),
+    ({"fp6_acts": 1, "no_rf_c": 1}, ("f16c",), False),
+    ({"fp6_acts": 1, "generic_c": 1}, ("f16c",), False),
+    ({"fp6_acts": 1, "fp6_filters": 1, "comp_heads": 1}, ("f16c",), False),
 ]
 
 

@@ -112,11 +112,11 @@ def test_conv3x3_pp_loop_has_only_its_own_drains(asm):
 
 def test_conv3x3_rf_loop_keeps_counted_waits(asm):
     ks = {n: k for n, k in asm("conv3rf_kernels.hip").items() if "conv3x3_rf_kernel" in n}
-    assert len(ks) == 11                     # stride 1, stride 2, stride 2 with 128-channel blocks, conv2a's resident filters, conv2b compensated,
+    assert len(ks) == 12                     # stride 1, stride 2, stride 2 with 128-channel blocks, conv2a's resident filters, conv2b compensated (fp8 / fp6 records out),
                                              # f16x3 (COMP = 4 planes out / 12 fp32 out) at stride 1, 2 and 2 with 128-channel blocks: the plain pipeline run three times
     for name, k in ks.items():
         span = _mfma_span(k["body"])
-        if name.split("EEv")[0].endswith("ELi3"):                        # COMP = 3: one chunk body, fp16 and fp8 MFMAs behind a wave-uniform flag
+        if name.split("EEv")[0].endswith(("ELi3", "ELi67")):             # COMP = 3 (| 64: fp6 output records): one chunk body, fp16 and fp8 MFMAs behind a wave-uniform flag
             assert _count(span, r"v_mfma_f32_32x32x16_f16") == 36 and _count(span, r"v_mfma_scale_f32_32x32x64_f8f6f4") == 18
             assert _count(span, r"s_waitcnt.*vmcnt\(0\)") == 0, name    # the counted waits survive (no spill reload, no drain)
             assert _count(span, r"\bscratch_") == 0, name

@@ -21,6 +21,8 @@ from sfd2_amd import synth
 from sfd2_amd.model import ResSegNetV2
 m = ResSegNetV2(outdim=128, require_stability=True, precision=os.environ.get("SFD2_AB_PREC", "f16c")).eval(); m.load_state_dict(synth.make_state_dict(0)); m.cuda(0)
 ctx = m.context; lib = ctx.lib
+for kv in filter(None, os.environ.get("SFD2_AB_OPTS", "").split("+")):      # e.g. default@SFD2_AB_OPTS=fp6_acts=1+fp6_filters=1
+    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 H, W, K = 1200, 1600, 4096
 imgs = [torch.from_numpy(synth.make_image(H, W, 100 + i)).cuda() for i in range(4)]
 kp = torch.empty((K, 2), device="cuda"); sc = torch.empty((K,), device="cuda"); de = torch.empty((K, 128), device="cuda"); n = ctypes.c_int()
