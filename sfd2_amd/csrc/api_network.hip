@@ -547,7 +547,7 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         // fp6 x fp6 scaled MFMA per unit: 33.5 cycles where a unit with fp8 on either side takes 66 (profiles/r04_mfma_probe.txt).  Decided
         // per tensor: the producer must be the kernel that can write them.
         const bool use6 = c->opt_fp6_acts && !c->opt_generic_c && c->c2a.wc66.p && c->c3a.wc66.p && c->c3b.wc66.p;
-        const bool s6 = use6 && c->fuse_now;                                                                   // a1b (the fused stem writes it)
+        const bool s6 = use6 && c->fuse_now && c->w1b_stem_c6.p;                                                                   // a1b (the fused stem writes it)
         const bool b6 = use6 && !c->opt_no_rf_c && conv3x3_rf_c_serves(3, 2, c->c2b.cout_pad, c->c2b.cin, H4, W4);   // a2b (conv3x3_rf<2,comp>)
         const bool a6 = use6;                                                                                   // a3a (conv3x3_pp<comp>)
         {
@@ -562,7 +562,7 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
             ProfScope ps(c, "conv1a+conv1b", "fused_stem_c_kernel", 2.0 * P1 * 64 * 27 + 2.0 * (double)H2 * W2 * 64 * 576,
                          P1 * 12 + (double)H2 * W2 * 256);
             launch_fused_stem_c(st, img_dev, H, W, normalise, c->c1a.wc.as<half_t>(), c->c1a.scale.as<float>(),
-                                c->c1a.shift.as<float>(), c->w1b_stem_c.p, c->c1b.scale.as<float>(), c->c1b.shift.as<float>(),
+                                c->c1a.shift.as<float>(), s6 ? c->w1b_stem_c6.p : c->w1b_stem_c.p, c->c1b.scale.as<float>(), c->c1b.shift.as<float>(),
                                 a1b.as<half_t>(), corr_of(a1b, (size_t)H2 * W2, 64), H2, W2, c->c1b.sbyte, c->range_stat.as<unsigned int>(), s6 ? 2 : 0);
         } else {
             {

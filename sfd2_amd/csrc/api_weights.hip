@@ -494,6 +494,36 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
                             pk[base + 16 + kk * 8 + j] = (unsigned short)(f32_to_e4m3(std::ldexp(v, b0)) | (f32_to_e4m3(std::ldexp(v - (float)h, b0 + 11)) << 8));
                         }
         if (upload(c->w1b_stem_c, pk.data(), pk.size() * 2, c->stream)) return -1;
+        {   // option "fp6_acts": the corr fragment (bytes 32 .. 63 of a lane's 64) = 32 e2m3 codes in the order of the fp6 half-records the
+            // kernel's phase 1 writes (position p: j = p / 2 <-> input channel 8 (j / 4) + 4 (lane / 32) + j % 4 of the unit's 32; p even: w,
+            // p odd: (w - fp16(w)) * 2^11), 24 bytes, then in dword 6 the output channel's E8M0 scale byte 2^(ec - 11), ec: max|w| / 2^ec <= 7.5
+            std::vector<unsigned short> p6 = pk;
+            for (int cth = 0; cth < 2; ++cth)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int oc = cth * 32 + (lane & 31), h = lane >> 5;
+                    float mx = 0.0f;
+                    for (int i = 0; i < 64 * 9; ++i) mx = std::max(mx, std::fabs(w->d[(size_t)oc * 576 + i]));
+                    int ec = (mx > 0.0f && std::isfinite(mx)) ? (int)std::ceil(std::log2(mx / 7.5f)) : 0;
+                    while (std::ldexp(mx, -ec) > 7.5f) ++ec;
+                    ec = std::max(-40, std::min(40, ec));
+                    for (int u = 0; u < 18; ++u) {
+                        unsigned char str[32] = {0};
+                        for (int p = 0; p < 32; ++p) {
+                            const int j = p >> 1, ic = (u & 1) * 32 + 8 * (j >> 2) + 4 * h + (j & 3), tap = u >> 1;
+                            const float v = w->d[((size_t)oc * 64 + ic) * 9 + tap];
+                            const float x = (p & 1) ? std::ldexp(v - (float)(half_t)v, 11 - ec) : std::ldexp(v, -ec);
+                            const unsigned int code = f32_to_e2m3(x);
+                            const int bit = 6 * p;
+                            str[bit >> 3] |= (unsigned char)(code << (bit & 7));
+                            if ((bit & 7) > 2) str[(bit >> 3) + 1] |= (unsigned char)(code >> (8 - (bit & 7)));
+                        }
+                        const unsigned int sb = ((unsigned int)(127 - 11 + ec) & 255u) * 0x01010101u;
+                        std::memcpy(str + 24, &sb, 4);
+                        std::memcpy(reinterpret_cast<unsigned char *>(p6.data()) + (((size_t)(cth * 18 + u) * 64 + lane) * 32 + 16) * 2, str, 32);
+                    }
+                }
+            if (upload(c->w1b_stem_c6, p6.data(), p6.size() * 2, c->stream)) return -1;
+        }
         for (int cth = 0; cth < 2; ++cth)          // the same fragments with the lo' parts as fp16 (SFD2_PREC_F16X3)
             for (int u = 0; u < 18; ++u)
                 for (int lane = 0; lane < 64; ++lane)

@@ -77,7 +77,10 @@ __device__ __forceinline__ void sc_x3_epi4(float a0, float a1, float a2, float a
 // units: X1c holds lo', w2's second half the filters' lo' fragments, phase 2 runs hi x hi over the wave's units, scales the partial
 // sums by 2^11 (exactly) and adds the cross terms hi x lo' + lo' x hi to the same accumulators (2^-11 goes into phase 4), the
 // output planes are hi / lo'.
-// O6: conv1b's corr records leave as fp6 half-records (sfd2_epi16_fp6) for a consumer that reads them with the fp6 x fp6 scaled MFMA.
+// O6: conv1b's corr records leave as fp6 half-records (sfd2_epi16_fp6) for a consumer that reads them with the fp6 x fp6 scaled MFMA --
+// and conv1a's (LDS-resident) records are fp6 half-records too: phase 1 converts a lane's 16 channels with one
+// v_cvt_scalef32_2xpk16_fp6_f32 instead of sixteen fp8 conversions, phase 2's correction is the 33.5-cycle fp6 x fp6 MFMA; w2's corr
+// fragments are then fp6 strings in the half-records' channel order with the row's E8M0 scale byte in dword 6 (api_weights.hip).
 template <bool X3, bool O6 = false>
 __global__ __launch_bounds__(SC_NT, 2)
 void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normalise,
@@ -292,6 +295,21 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                 const bool all_inside = __builtin_amdgcn_ballot_w64(!inside) == 0;
                 int xo = p1_x[i] & 0xFFFFF, xsw = (p1_x[i] >> 20) << 4;
                 asm volatile("" : "+v"(xo), "+v"(xsw));
+                if constexpr (O6 && !X3) {
+                    uint2 hv4[4];
+                    uint4 r0, r1;
+                    sfd2_epi16_fp6(acc, s1, h1, 0.0f, hv4, r0, r1, mx1, all_inside || inside);
+                    if (!all_inside && !inside) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) hv4[q] = make_uint2(0u, 0u);
+                        r0 = make_uint4(0u, 0u, 0u, 0u); r1 = r0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2 *>(X1h + xo + (((cth * 4 + q) << 4) ^ xsw)) = hv4[q];
+                    const int xb = xo & ~8;             // the record's base: half-record lhi = the chunk's 16-byte slots lhi and 2 + lhi
+                    *reinterpret_cast<uint4 *>(X1c + xb + (((cth * 4 + lhi) << 4) ^ xsw)) = r0;
+                    *reinterpret_cast<uint4 *>(X1c + xb + (((cth * 4 + 2 + lhi) << 4) ^ xsw)) = r1;
+                } else
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     uint2 hv, cv;
@@ -341,7 +359,8 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                     acc2[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[i][1], b1, acc2[r], 0, 0, 0);
                     if (!X3) {
                         const v8i_t bc = sfd2_cat8(*reinterpret_cast<const h8_t *>(X1c + o0), *reinterpret_cast<const h8_t *>(X1c + o1));
-                        acc2[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wc[i], bc, acc2[r], 0, 0, 0, sa, 0, 0x7f7f7f7f);
+                        if constexpr (O6) acc2[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wc[i], bc, acc2[r], 2, SFD2_PIX6_BLGP, 0, wc[i][6], 0, bc[6]);
+                        else acc2[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wc[i], bc, acc2[r], 0, 0, 0, sa, 0, 0x7f7f7f7f);
                     }
                 }
             }
@@ -498,7 +517,7 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
 // sbyte < 0: the X3 instantiation (SFD2_PREC_F16X3): w2's second halves are the filters' lo' fragments, out / out_c the hi / lo' planes
 void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int normalise, const half_t *w1, const float *sc1,
                          const float *sh1, const void *w2, const float *sc2, const float *sh2, half_t *out, half_t *out_c,
-                         int H2, int W2, int sbyte, unsigned int *range, int fmt6)
+                         int H2, int W2, int sbyte, unsigned int *range, int fmt6 /* bit 1: fp6 records inside and out; w2 = the fp6 fragment array */)
 {
     static bool attr_done = false;
     static int slots = 256;

@@ -182,6 +182,7 @@ struct sfd2_ctx {
     DevPtr range_stat;                             // (a view: the words live behind the zero page) SFD2_RS_COUNT x SFD2_RANGE_SUB words: running maxima of the compensated mode's stored tensors (sticky until read with reset)
     DevBuf range_scratch;                          // AE_COUNT words: absolute maxima of a calibration pass
     DevBuf sta_w, sta_b, zero_page, w1b_fused;   // w1b_fused: conv1b filters as [9][64][64] for the fused stem
+    DevBuf w1b_stem_c6;                            // ... with the corr fragments as fp6 strings + scale byte (option "fp6_acts")
     DevBuf w1b_stem_c;                             // the same as register fragments (hi K slices + corr) for the compensated fused stem
     DevBuf w1b_stem_x3;                            // ... with the lo' fragments (fp16 of (w - fp16(w)) * 2^11) in place of the corr fragment: f16x3
     int fuse = 1;                                  // fused kernels on the extract path (SFD2_NO_FUSE=1 disables)
