@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--lib", default=None, help="kernel A/B runs: another build of libsfd2hip.so (sfd2_amd/build.py build_lib(out=...))")
     ap.add_argument("--precision", default="f16c", choices=["f16c", "f16"], help="mode of the headline legs (default f16c: the "
                     "tolerance-conformant throughput mode; f16 = the 3e-3 approximation, for kernel A/Bs of that path)")
+    ap.add_argument("--fp6-acts", type=int, default=1, help="f16c option fp6_acts (0: fp8 correction records everywhere, the round-3 arithmetic)")
     ap.add_argument("--comp-det", type=int, default=0, help="f16c option comp_det (1: the detector branch's 3x3 layers compensated)")
     ap.add_argument("--comp-heads", type=int, default=0, help="f16c option comp_heads (1: the head branches' 3x3 layers compensated as well)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="sfd2_set_option on every context (A/B switches, e.g. fuse_rb23=0)")
@@ -254,6 +255,8 @@ def main():
                 self.ctx.set_option("comp_heads", 1)
             if args.precision == "f16c" and args.comp_det:
                 self.ctx.set_option("comp_det", 1)
+            if args.precision == "f16c" and not args.fp6_acts:
+                self.ctx.set_option("fp6_acts", 0)
             if args.branches:
                 self.ctx.set_option("branches", 1)
             for kv in args.opt:
@@ -492,22 +495,25 @@ def main():
                     "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 5), "launches": dom["launches"],
                     "traffic": pmc_traffic(dom_name),
                     "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this command; not re-measured in this run)"}
+            # matrix time of a compensated 32-channel unit relative to the plain one's two v_mfma_f32_32x32x16_f16 (2 x 32 cycles), measured
+            # (profiles/r04_mfma_probe.txt): + one v_mfma_scale_f32_32x32x64_f8f6f4 of 66 cycles with fp8 operands, 33.5 with fp6 on both sides
+            # (option fp6_acts, the default for this family's three layers)
+            corr_factor = 1.0
             if "comp" in dom_name:
-                # a compensated layer issues, per algorithmic FLOP, one fp16 MFMA FLOP and two fp8 MFMA FLOPs (K = 64 bytes per 32
-                # channels) at twice the fp16 rate: 2x the fp16 layer's matrix time at nominal rates
-                roof["note"] = ("achieved / frac count ALGORITHMIC FLOPs (2 * MAC of the layer) against the fp16 peak; the kernel also issues "
-                                "the fp8 correction MFMAs (one 32x32x64 per two 32x32x16), i.e. 2x the matrix time of the plain fp16 layer at "
-                                "nominal rates: 'frac_of_issued_peak' = frac * 2")
-                roof["frac_of_issued_peak"] = round(2 * achieved / PEAK_TFLOPS_F16, 4)
+                corr_factor = (64.0 + (33.5 if args.fp6_acts else 66.0)) / 64.0
+                roof["note"] = ("achieved / frac count ALGORITHMIC FLOPs (2 * MAC of the layer) against the fp16 peak; the kernel also issues one "
+                                "correction MFMA (32x32x64, " + ("fp6 x fp6: 33.5" if args.fp6_acts else "fp8: 66") + " cycles) per two 32x32x16 (2 x 32 cycles), "
+                                f"i.e. {corr_factor:.2f}x the matrix time of the plain fp16 layer: 'frac_of_issued_peak' = frac * {corr_factor:.2f}")
+                roof["frac_of_issued_peak"] = round(corr_factor * achieved / PEAK_TFLOPS_F16, 4)
             # what this part sustains on v_mfma_f32_32x32x16_f16 alone (tools/probe/mfma_peak.hip, profiles/r04_mfma_probe.txt): one MFMA per 32.2-32.9
             # cycles and SIMD in every configuration; the clock the part holds depends on the operands' switching activity -- 2.39 GHz on zeros
             # (2.49 PFLOP/s), 1.73 GHz on post-ReLU-like activations (1.77), 1.65 GHz on uniform +-0.5 (1.68).  A POWER ceiling, not an issue limit:
             # context for `frac`, which stays against the nominal peak.  (Round 3 quoted 1.11 PFLOP/s from an issue-limited probe: retracted.)
-            issued = (2 if "comp" in dom_name else 1) * achieved
+            issued = corr_factor * achieved
             roof["mfma_only_probe"] = {"zeros": 2490.0, "relu_like": 1765.0, "uniform": 1680.0, "unit": "TFLOP/s",
                                        "source": "profiles/r04_mfma_probe.txt (not re-measured in this run)",
                                        "issued_frac_of_relu_like": round(issued / 1765.0, 4),
-                                       "note": "issued-FLOP rate of this kernel (fp8 correction MFMAs counted at fp16-equivalent time) / the MFMA-only rate on relu-like data"}
+                                       "note": "issued-FLOP rate of this kernel (correction MFMAs counted at fp16-equivalent time) / the MFMA-only rate on relu-like data"}
             if single is not None:
                 roof["measured_in"] = ("single-stream timed leg of this run (same K steps and bracketing, one stream per GPU, eager "
                                        "launches: see 'single_stream').  The headline region replays one hipGraph per image on "
