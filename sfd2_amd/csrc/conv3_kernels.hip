@@ -545,6 +545,10 @@ void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, i
         else if ((fmt6 & 1) && sfd2_env("SFD2_PPC_ABL"))    // timing ablation (wrong results): conv3b's instantiation without its staging copies
             launch_pp_t<1, 1, 1, 3 | 16 | 32>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
 #endif
+#ifdef SFD2_EXPERIMENTS
+        else if ((fmt6 & 1) && sfd2_env("SFD2_PPC_ABL"))    // timing ablation (wrong results): conv3b's instantiation without its staging copies
+            launch_pp_t<1, 1, 1, 3 | 16 | 32>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
+#endif
         else if (fmt6 & 1) launch_pp_t<1, 1, 0, 3 | 16 | 32>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
         else launch_pp_t<1, 1, 0, 3 | 16 | 64>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
         return;
