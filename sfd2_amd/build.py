@@ -5,13 +5,13 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfd2hip.so")
-SOURCES = ["conv_kernels.hip", "conv2_kernels.hip", "conv3_kernels.hip", "conv3rf_kernels.hip", "conv1x1_kernels.hip", "resblock_kernel.hip", "conv_f32_kernels.hip", "convc_kernels.hip", "rb23_c_kernel.hip", "sparse_da3_kernel.hip", "fused_stem_kernel.hip", "fused_stem_c_kernel.hip", "post_kernels.hip", "util_kernels.hip", "nms4_kernels.hip", "match_kernels.hip", "match_mutual_kernel.hip", "api_core.hip", "api_weights.hip", "api_network.hip", "api_extract.hip", "api_match.hip", "api_graph.hip"]
+SOURCES = ["conv_kernels.hip", "conv2_kernels.hip", "conv3_kernels.hip", "conv3rf_kernels.hip", "conv2b_s2d_kernel.hip", "conv1x1_kernels.hip", "resblock_kernel.hip", "conv_f32_kernels.hip", "convc_kernels.hip", "rb23_c_kernel.hip", "sparse_da3_kernel.hip", "fused_stem_kernel.hip", "fused_stem_c_kernel.hip", "post_kernels.hip", "util_kernels.hip", "nms4_kernels.hip", "match_kernels.hip", "match_mutual_kernel.hip", "api_core.hip", "api_weights.hip", "api_network.hip", "api_extract.hip", "api_match.hip", "api_graph.hip"]
 # per-source extra flags (see the header comment of each file)
 # -fno-honor-nans: without it hipcc puts a NaN-canonicalising v_max_f32 x, x in front of every fmaxf operand it cannot
 # prove quiet (the ReLUs of the epilogues: two VALU per value instead of one).  Finite inputs give identical results.
 _NN = ["-fno-honor-nans"]
 SRC_FLAGS = {"match_mutual_kernel.hip": _NN, "conv3_kernels.hip": _NN, "conv3rf_kernels.hip": _NN, "resblock_kernel.hip": _NN, "conv2_kernels.hip": _NN,
-             "fused_stem_kernel.hip": _NN, "conv_kernels.hip": _NN, "conv1x1_kernels.hip": _NN, "nms4_kernels.hip": _NN, "convc_kernels.hip": _NN, "fused_stem_c_kernel.hip": _NN, "rb23_c_kernel.hip": _NN, "sparse_da3_kernel.hip": _NN}
+             "fused_stem_kernel.hip": _NN, "conv_kernels.hip": _NN, "conv1x1_kernels.hip": _NN, "nms4_kernels.hip": _NN, "convc_kernels.hip": _NN, "fused_stem_c_kernel.hip": _NN, "rb23_c_kernel.hip": _NN, "sparse_da3_kernel.hip": _NN, "conv2b_s2d_kernel.hip": _NN}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("SFD2_EXTRA_FLAGS", "").split()
 

@@ -202,7 +202,7 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &i
             const bool i6 = (fmt6 & 1) != 0;
             launch_conv3x3_pp_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, i6 ? L.wc66.as<half_t>() : L.wc6.as<half_t>(), L.scale.as<float>(),
                                 L.shift.as<float>(), L.cout_pad, relu, out.as<half_t>(), out_c, Ho, Wo, c->zero_page.as<half_t>(), L.sbyte,
-                                i6 ? L.sa66.as<float>() : L.sa6.as<float>(), rs, fmt6);
+                                i6 ? L.sa66.as<float>() : L.sa6.as<float>(), rs, fmt6);      // (bit 2: the output stored space-to-depth, with fp6 input records only)
             return;
         }
         if (fmt6) { fprintf(stderr, "sfd2: %s: fp6 records requested from a layer without fp6 filter strings\n", name); abort(); }
@@ -550,6 +550,10 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         const bool s6 = use6 && c->fuse_now && c->w1b_stem_c6.p;                                                                   // a1b (the fused stem writes it)
         const bool b6 = use6 && !c->opt_no_rf_c && conv3x3_rf_c_serves(3, 2, c->c2b.cout_pad, c->c2b.cin, H4, W4);   // a2b (conv3x3_rf<2,comp>)
         const bool a6 = use6;                                                                                   // a3a (conv3x3_pp<comp>)
+        // Option "s2d" (throughput path only: the tensor is not readable by sfd2_debug_activation in that layout): conv2a stores its output as
+        // four parity planes at quarter resolution, conv2b reads them as a stride-1 layer (conv2b_s2d_kernel.hip)
+        const bool d2 = c->opt_s2d && alias && s6 && !c->opt_no_rf_c && conv2b_s2d_serves(H2, W2, c->c2b.cin, c->c2b.cout_pad) &&
+                        H4 * 2 == H2 && W4 * 2 == W2;
         {
             static const char *t6[3] = {"bn1b", "bn2b", "conv3a"};
             const bool f6[3] = {s6, b6, a6};
@@ -572,7 +576,13 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
             }
             convc(c, "conv1b", c->c1b, c->a1a, H, W, a1b, H2, W2, 1, true, true, nullptr, SFD2_RS_CONV1B);
         }
-        convc(c, "conv2a", c->c2a, a1b, H2, W2, a2a, H2, W2, 1, true, true, nullptr, SFD2_RS_CONV2A, s6 ? 1 : 0);
+        convc(c, "conv2a", c->c2a, a1b, H2, W2, a2a, H2, W2, 1, true, true, nullptr, SFD2_RS_CONV2A, (s6 ? 1 : 0) | (d2 ? 4 : 0));
+        if (d2) {
+            const ConvW &L = c->c2b;
+            ProfScope ps(c, "conv2b", "conv2b_s2d_kernel", 2.0 * P4 * L.cout * L.cin * 9, 4.0 * ((double)H2 * W2 * L.cin + (double)L.cout * L.cin * 9) + P4 * L.cout_pad * 4.0);
+            launch_conv2b_s2d(st, a2a.as<half_t>(), corr_of(a2a, (size_t)H2 * W2, L.cin), H4, W4, L.wc.as<half_t>(), L.scale.as<float>(), L.shift.as<float>(), 1,
+                              a2b.as<half_t>(), corr_of(a2b, (size_t)H4 * W4, L.cout_pad), c->zero_page.as<half_t>(), L.sbyte, range_slot(c, SFD2_RS_CONV2B), b6 ? 2 : 0);
+        } else
         convc(c, "conv2b", c->c2b, a2a, H2, W2, a2b, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV2B, b6 ? 2 : 0);
         convc(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV3A, (b6 ? 1 : 0) | (a6 ? 2 : 0));
         convc(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV3B, a6 ? 1 : 0);

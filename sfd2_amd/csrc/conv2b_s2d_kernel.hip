@@ -1,0 +1,317 @@
+// conv2b (3x3, stride 2, 128 -> 128 channels, nets/sfd2.py:271) of the compensated mode as a STRIDE-1 layer over conv2a's output stored
+// space-to-depth.
+//
+// The stride-2 patch (17 x 33 input records per 8 x 16 outputs) is what forces conv3x3_rf<2,comp>'s 128-pixel tile, and with it 1.18 MB of
+// filter fragments loaded per tile and CU: the layer is bound by that stream (profiles/r04_conv2b_ablations.txt).  Here conv2a writes its
+// output as four parity planes [H/4][W/4][(y & 1) * 2 + (x & 1)][128] (conv3x3_pp<comp>, COMP bit 7: a different store address, nothing
+// else), and an output pixel (Y, X) reads, for the original tap (ky, kx), plane (par(ky), par(kx)) at (Y + d(ky), X + d(kx)) with
+// par = (1, 0, 1), d = (-1, 0, 0): a stride-1 layer whose nine taps are spread over the four planes (4 + 2 + 2 + 1).  So the tile is
+// conv3x3_pp's -- 16 x 32 output pixels x 128 channels, filters through the LDS once per 512 pixels, the 18 x 34 patch of ONE plane's 32-channel
+// chunk at a time -- and the K loop is a list of 32 steps per tile: (hi | corr) x 4 chunks x 4 planes, each with the plane's 1, 2 or 4 taps.
+//
+// A step's operands (patch 39 KB + its taps' filter rows, 8 KB each) are copied into LDS (global_load ... lds) while the previous step
+// computes; one workgroup barrier per step.  Same LDS record layout / swizzle, fragment reads, MFMA orientation and epilogue as
+// conv3_kernels.hip; the filter array is the layer's generic one (api_weights.hip pack_igemm: [hi chunks | corr chunks][tap][oc][32]).
+// Per tile 1.8 MB of copies against 75 k cycles of MFMA issue: the kernel is bound by the copies, at a quarter of the bytes per pixel the
+// register-filter kernel asks of the L2.
+#include "sfd2_internal.h"
+#include <type_traits>
+#include <stdlib.h>
+
+#define S2_TW 32
+#define S2_TH 16
+#define S2_BN 128
+#define S2_PW (S2_TW + 2)
+#define S2_PH (S2_TH + 2)
+#define S2_NPIX (S2_PH * S2_PW)                 // 612 patch records of 64 B
+#define S2_XCH ((S2_NPIX + 15) / 16)            // 39 pieces of 1 KB
+#define S2_XPW 5                                // pieces per wave (the tail repeats the last piece)
+#define S2_XBYTES (S2_XCH * 1024)
+#define S2_FBYTES (4 * S2_BN * 64)              // up to four taps x 128 filters x 64 B = 32 KB
+
+typedef __attribute__((address_space(3))) void lds_void5_t;
+typedef const __attribute__((address_space(1))) void gbl_void5_t;
+
+// O6: the output's corr records as fp6 half-records (sfd2_epi16_fp6) for conv3a's fp6 x fp6 correction
+// ABL (experiment builds, timing only): 1 = no copies inside the step loops, 2 = no fragment reads / MFMAs
+template <bool O6, int ABL = 0>
+__global__ __launch_bounds__(512, 2)
+void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4][128] */, const half_t *__restrict__ in_c /* its corr units */,
+                       int H4, int W4, const half_t *__restrict__ wpk /* [8 chunks][9][128][32] */, const float *__restrict__ scale,
+                       const float *__restrict__ shift, int relu, half_t *__restrict__ out, half_t *__restrict__ out_c, int tiles_x, int n_tiles,
+                       const half_t *__restrict__ zero_page, int sa, unsigned int *__restrict__ range)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Xs = smem;                              // [2][S2_XBYTES]
+    unsigned char *Fs = smem + 2 * S2_XBYTES;              // [2][S2_FBYTES]
+    float *SS = reinterpret_cast<float *>(Fs + 2 * S2_FBYTES);   // scale[128], shift[128]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wch = (wave & 1) * 64;                       // 2 channel tiles
+    const int wrow = (wave >> 1) * 4;                      // 4 image rows = 4 pixel tiles
+    const int lrow = lane & 31, lhi = lane >> 5;
+    constexpr int CIN = 512, CO = 128;
+
+    for (int t = tid; t < S2_BN; t += 512) { SS[t] = scale[t]; SS[S2_BN + t] = shift[t]; }
+
+    int a_off[2], a_sw[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int r = wch + ct * 32 + lrow;
+        a_off[ct] = r * 64;
+        a_sw[ct] = (r >> 2) & 3;
+    }
+    const int qb = wrow * S2_PW + lrow;
+    // filter pieces: wave w moves rows 16 w .. 16 w + 15 of every tap's 128 x 64 B matrix
+    const int frow = wave * 16 + (lane >> 2);
+    const int fsrc = frow * 32 + (((lane & 3) ^ ((frow >> 2) & 3)) * 8);      // halfs within a tap's matrix
+
+    int oy0 = 0, ox0 = 0;
+    int xoff[S2_XPW];
+#define S2_SETUP(tile_)                                                                                \
+    {                                                                                                  \
+        const int tx_ = (tile_) % tiles_x, ty_ = (tile_) / tiles_x;                                    \
+        oy0 = ty_ * S2_TH; ox0 = tx_ * S2_TW;                                                          \
+        _Pragma("unroll") for (int i = 0; i < S2_XPW; ++i) {                                           \
+            int piece = wave + 8 * i;                                                                  \
+            if (piece >= S2_XCH) piece = S2_XCH - 1;                                                   \
+            const int q = piece * 16 + (lane >> 2);                                                    \
+            const int slot = (lane & 3) ^ ((q >> 2) & 3);                                              \
+            int off = -1;                                                                              \
+            if (q < S2_NPIX) {                                                                         \
+                const int py = q / S2_PW, px = q - py * S2_PW;                                         \
+                const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;                                        \
+                if (iy >= 0 && iy < H4 && ix >= 0 && ix < W4) off = (iy * W4 + ix) * CIN + slot * 8;   \
+            }                                                                                          \
+            xoff[i] = off;                                                                             \
+        }                                                                                              \
+    }
+    // step s of a tile: corr = s >> 4, chunk k = (s >> 2) & 3, plane order (1,1), (1,0), (0,1), (0,0) = memory planes 3, 2, 1, 0
+#define S2_ISSUE(step_, buf_)                                                                          \
+    {                                                                                                  \
+        const int cr_ = (step_) >> 4, k_ = ((step_) >> 2) & 3, pl_ = 3 - ((step_) & 3);                 \
+        const half_t *xp_ = (cr_ ? in_c : in) + pl_ * 128 + k_ * 32;                                   \
+        _Pragma("unroll") for (int i = 0; i < S2_XPW; ++i) {                                           \
+            const int pc_ = (wave + 8 * i < S2_XCH) ? wave + 8 * i : S2_XCH - 1;                       \
+            const half_t *src_ = xoff[i] >= 0 ? xp_ + (size_t)xoff[i] : zero_page + (lane & 3) * 8;    \
+            __builtin_amdgcn_global_load_lds((gbl_void5_t *)src_, (lds_void5_t *)(Xs + (buf_)*S2_XBYTES + pc_ * 1024), 16, 0, 0); \
+        }                                                                                              \
+        const int py_ = pl_ >> 1, px_ = pl_ & 1;                                                       \
+        const half_t *fp_ = wpk + (size_t)((cr_ * 4 + k_) * 9) * CO * 32 + fsrc;                       \
+        int j_ = 0;                                                                                    \
+        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                               \
+            _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                           \
+                if ((ky != 1) == (py_ != 0) && (kx != 1) == (px_ != 0)) {                              \
+                    __builtin_amdgcn_global_load_lds((gbl_void5_t *)(fp_ + (size_t)(ky * 3 + kx) * CO * 32),  \
+                                                     (lds_void5_t *)(Fs + (buf_)*S2_FBYTES + j_ * (S2_BN * 64) + wave * 1024), 16, 0, 0); \
+                    ++j_;                                                                              \
+                }                                                                                      \
+    }
+
+    int tile = blockIdx.x;
+    S2_SETUP(tile)
+    S2_ISSUE(0, 0)
+    unsigned int smax = 0;
+
+    for (;;) {
+        f32x16_t acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < n_tiles;
+        const int eoy0 = oy0, eox0 = ox0;
+
+        // one step: the NKY x NKX taps of one plane's chunk (runtime loop: 1, 2 or 4 trips); tap j = iy * NKX + ix reads the patch shifted by
+        // (iy + (NKY == 1), ix + (NKX == 1)) records.  Two bodies (fp16 / corr), each in its own step loop: one body with the type as a runtime
+        // flag, or the eight (type, shape) combinations as separate inlined bodies, spill
+#define S2_STEP_PROLOGUE(s_)                                                                           \
+            SFD2_BARRIER_DRAIN();                                                                      \
+            const int buf = (s_) & 1;                                                                   \
+            if (ABL & 1) {                                                                             \
+            } else if ((s_) + 1 < 32) { S2_ISSUE((s_) + 1, buf ^ 1) }                                   \
+            else if (has_next) {                                                                       \
+                S2_SETUP(next)                                                                         \
+                S2_ISSUE(0, buf ^ 1)   /* (32 steps: the next tile's step 0 lands in buffer 0 again) */ \
+            }                                                                                          \
+            const int ty = (s_) & 3;   /* plane (1,1), (1,0), (0,1), (0,0) */                          \
+            const int nky = ty < 2 ? 2 : 1, nkx = (ty & 1) ? 1 : 2;                                     \
+            const unsigned char *xs = Xs + buf * S2_XBYTES;                                            \
+            const unsigned char *fs = Fs + buf * S2_FBYTES;
+#pragma unroll 1
+        for (int s = 0; s < 16; ++s) {
+            // this step's operands have landed (every wave waits for its own pieces, then the block), and every wave is done reading the
+            // other buffers (step s - 1): the next step's copies go there
+            S2_STEP_PROLOGUE(s)
+#pragma unroll 1
+            for (int j = 0; j < ((ABL & 2) ? 0 : nky * nkx); ++j) {
+                const int iy = nkx == 2 ? (j >> 1) : j, ix = nkx == 2 ? (j & 1) : 0;
+                const int ro = iy + (nky == 1 ? 1 : 0), co = ix + (nkx == 1 ? 1 : 0);
+                const unsigned char *ft = fs + j * (S2_BN * 64);
+                const int qv = qb + ro * S2_PW + co;
+                h8_t fa[2][2], fb[2][4];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        fa[kk][ct] = *reinterpret_cast<const h8_t *>(ft + a_off[ct] + (((kk * 2 + lhi) ^ a_sw[ct]) << 4));
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const int q = qv + pr * S2_PW;
+                    const int sw = (q >> 2) & 3;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        fb[kk][pr] = *reinterpret_cast<const h8_t *>(xs + q * 64 + (((kk * 2 + lhi) ^ sw) << 4));
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int pr = 0; pr < 4; ++pr)
+                            acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][ct], fb[kk][pr], acc[ct][pr], 0, 0, 0);
+            }
+        }
+#pragma unroll 1
+        for (int s = 16; s < 32; ++s) {
+            S2_STEP_PROLOGUE(s)
+#pragma unroll 1
+            for (int j = 0; j < ((ABL & 2) ? 0 : nky * nkx); ++j) {
+                const int iy = nkx == 2 ? (j >> 1) : j, ix = nkx == 2 ? (j & 1) : 0;
+                const int ro = iy + (nky == 1 ? 1 : 0), co = ix + (nkx == 1 ? 1 : 0);
+                const unsigned char *ft = fs + j * (S2_BN * 64);
+                const int qv = qb + ro * S2_PW + co;
+                v8i_t fac[2], frc[4];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    fac[ct] = sfd2_cat8(*reinterpret_cast<const h8_t *>(ft + a_off[ct] + (((0 * 2 + lhi) ^ a_sw[ct]) << 4)),
+                                        *reinterpret_cast<const h8_t *>(ft + a_off[ct] + (((1 * 2 + lhi) ^ a_sw[ct]) << 4)));
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const int q = qv + pr * S2_PW;
+                    const int sw = (q >> 2) & 3;
+                    frc[pr] = sfd2_cat8(*reinterpret_cast<const h8_t *>(xs + q * 64 + (((0 * 2 + lhi) ^ sw) << 4)),
+                                        *reinterpret_cast<const h8_t *>(xs + q * 64 + (((1 * 2 + lhi) ^ sw) << 4)));
+                }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr)
+                        acc[ct][pr] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fac[ct], frc[pr], acc[ct][pr], 0, 0, 0, sa, 0, 0x7f7f7f7f);
+                // (the scaled MFMA's destination is untied: pin the accumulators so that none is copied at the loop edge)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) asm volatile("" : "+v"(acc[ct][pr]));
+            }
+        }
+#undef S2_STEP_PROLOGUE
+
+        // epilogue (conv3_kernels.hip): y = acc * scale + shift, ReLU, hi plane + corr records, 16-byte stores
+        float mx = 0.0f;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            const int oy = eoy0 + wrow + pr, ox = eox0 + lrow;
+            const bool inb = oy < H4 && ox < W4;
+            const size_t pix = (size_t)(inb ? oy : 0) * W4 + (inb ? ox : 0);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int cl = wch + ct * 32 + 4 * lhi;
+                const size_t ob = pix * CO + wch + ct * 32;
+                if constexpr (O6) {
+                    float4 sc4[4], sh4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sc4[q] = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
+                        sh4[q] = *reinterpret_cast<const float4 *>(SS + S2_BN + cl + 8 * q);
+                    }
+                    uint2 hv4[4];
+                    uint4 r0, r1;
+                    sfd2_epi16_fp6(acc[ct][pr], sc4, sh4, relu ? 0.0f : -SFD2_C_SAT, hv4, r0, r1, mx, inb);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const auto t0 = __builtin_amdgcn_permlane32_swap(hv4[2 * m].x, hv4[2 * m + 1].x, false, false);
+                        const auto t1 = __builtin_amdgcn_permlane32_swap(hv4[2 * m].y, hv4[2 * m + 1].y, false, false);
+                        if (inb) *reinterpret_cast<uint4 *>(out + ob + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                    }
+                    if (inb) {
+                        *reinterpret_cast<uint4 *>(out_c + ob + 8 * lhi) = r0;
+                        *reinterpret_cast<uint4 *>(out_c + ob + 16 + 8 * lhi) = r1;
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        uint2 pk[2], ck[2];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int q = 2 * m + j;
+                            const float4 sc = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
+                            const float4 sh = *reinterpret_cast<const float4 *>(SS + S2_BN + cl + 8 * q);
+                            sfd2_epi4<false>(acc[ct][pr][4 * q + 0], acc[ct][pr][4 * q + 1], acc[ct][pr][4 * q + 2], acc[ct][pr][4 * q + 3], sc, sh,
+                                             sc, relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j], mx, inb);
+                        }
+                        const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                        const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                        const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
+                        const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
+                        if (inb) {
+                            *reinterpret_cast<uint4 *>(out + ob + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                            *reinterpret_cast<uint4 *>(out_c + ob + 8 * (2 * m + lhi)) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
+                        }
+                    }
+                }
+            }
+        }
+        { const unsigned int wb = sfd2_wave_max_bits(mx); smax = wb > smax ? wb : smax; }
+        if (!has_next) break;
+        tile = next;
+    }
+    if (range != nullptr) sfd2_range_commit(range, smax);
+#undef S2_SETUP
+#undef S2_ISSUE
+}
+
+// does the s2d form serve this geometry?  (conv2a's output H2 x W2 must split into whole 2 x 2 cells)
+bool conv2b_s2d_serves(int H2, int W2, int Cin, int CoutP) { return (H2 % 2) == 0 && (W2 % 2) == 0 && Cin == 128 && CoutP == 128 && H2 >= 2 && W2 >= 2; }
+
+void launch_conv2b_s2d(hipStream_t st, const half_t *in, const half_t *in_c, int H4, int W4, const half_t *wpk, const float *scale,
+                       const float *shift, int relu, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte, unsigned int *range, int fmt6)
+{
+    constexpr size_t lds = (size_t)2 * S2_XBYTES + (size_t)2 * S2_FBYTES + 2 * S2_BN * sizeof(float);
+    static bool attr_done = false;
+    static int slots = 256;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv2b_s2d_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv2b_s2d_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            slots = cus;
+        attr_done = true;
+    }
+    const int tiles_x = (W4 + S2_TW - 1) / S2_TW, tiles_y = (H4 + S2_TH - 1) / S2_TH;
+    const int n_tiles = tiles_x * tiles_y;
+    const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
+    const int sa = (sbyte & 255) * 0x01010101;
+#ifdef SFD2_EXPERIMENTS
+    if (const char *ab = sfd2_env("SFD2_S2D_ABL")) {
+        const int a = atoi(ab);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv2b_s2d_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv2b_s2d_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv2b_s2d_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (a == 1) hipLaunchKernelGGL((conv2b_s2d_kernel<true, 1>), dim3(grid), dim3(512), lds, st, in, in_c, H4, W4, wpk, scale, shift, relu, out, out_c, tiles_x, n_tiles, zero_page, sa, range);
+        if (a == 2) hipLaunchKernelGGL((conv2b_s2d_kernel<true, 2>), dim3(grid), dim3(512), lds, st, in, in_c, H4, W4, wpk, scale, shift, relu, out, out_c, tiles_x, n_tiles, zero_page, sa, range);
+        if (a == 3) hipLaunchKernelGGL((conv2b_s2d_kernel<true, 3>), dim3(grid), dim3(512), lds, st, in, in_c, H4, W4, wpk, scale, shift, relu, out, out_c, tiles_x, n_tiles, zero_page, sa, range);
+        if (a >= 1 && a <= 3) return;
+    }
+#endif
+    if (fmt6 & 2)
+        hipLaunchKernelGGL(conv2b_s2d_kernel<true>, dim3(grid), dim3(512), lds, st, in, in_c, H4, W4, wpk, scale, shift, relu, out, out_c, tiles_x,
+                           n_tiles, zero_page, sa, range);
+    else
+        hipLaunchKernelGGL(conv2b_s2d_kernel<false>, dim3(grid), dim3(512), lds, st, in, in_c, H4, W4, wpk, scale, shift, relu, out, out_c, tiles_x,
+                           n_tiles, zero_page, sa, range);
+}

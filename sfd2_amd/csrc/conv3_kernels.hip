@@ -114,6 +114,7 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     constexpr bool F6 = (COMP & 16) != 0;
     constexpr bool B6 = (COMP & 32) != 0;                  // the INPUT's corr records are fp6 half-records (sfd2_internal.h; with F6: fp6 x fp6, 33.5 cycles per scaled MFMA)
     constexpr bool O6 = (COMP & 64) != 0;                  // the OUTPUT's corr records are written as fp6 half-records
+    constexpr bool S2D = (COMP & 128) != 0;                // the OUTPUT is stored space-to-depth: [Ho / 2][Wo / 2][(y & 1) * 2 + (x & 1)][CoutP] (conv2b_s2d_kernel.hip; Ho, Wo even)
     static_assert(!B6 || F6, "fp6 pixel operands come with fp6 filter strings");
     constexpr int SSN = F6 ? 3 : 2;                        // arrays per tile parity in SSb: scale, shift (, the fp6 filters' scale bytes)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -396,7 +397,8 @@ _Pragma("unroll") \
     for (int pr = 0; pr < 4; ++pr) {
         const int oy = eoy0 + wrow + pr, ox = eox0 + lrow;
         const bool inb = oy < Ho && ox < Wo;
-        const size_t pix = (size_t)(inb ? oy : 0) * Wo + (inb ? ox : 0);
+        const size_t pix = S2D ? ((size_t)((inb ? oy : 0) >> 1) * (Wo >> 1) + ((inb ? ox : 0) >> 1)) * 4 + (((inb ? oy : 0) & 1) * 2 + ((inb ? ox : 0) & 1))
+                               : (size_t)(inb ? oy : 0) * Wo + (inb ? ox : 0);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const int cl = wch + ct * 32 + 4 * lhi;
@@ -549,6 +551,7 @@ void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, i
         else if ((fmt6 & 1) && sfd2_env("SFD2_PPC_ABL"))    // timing ablation (wrong results): conv3b's instantiation without its staging copies
             launch_pp_t<1, 1, 1, 3 | 16 | 32>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
 #endif
+        else if ((fmt6 & 5) == 5) launch_pp_t<1, 1, 0, 3 | 16 | 32 | 128>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
         else if (fmt6 & 1) launch_pp_t<1, 1, 0, 3 | 16 | 32>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
         else launch_pp_t<1, 1, 0, 3 | 16 | 64>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
         return;

@@ -355,8 +355,12 @@ void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, i
                          const float *scale, const float *shift, int CoutP, int relu, half_t *out, half_t *out_c,
                          int Ho, int Wo, const half_t *zero_page, int sbyte, const float *shift_sa6 = nullptr /* non-null: wpk's corr rows are fp6; [shift | scale bytes] */,
                          unsigned int *range = nullptr /* the output tensor's range-status slot (SFD2_RANGE_SUB words), here and below */,
-                         int fmt6 = 0 /* bit 0: in_c holds fp6 half-records (then wpk / shift_sa6 are the fp6 x fp6 arrays), bit 1: out_c is written as fp6 half-records */);
+                         int fmt6 = 0 /* bit 0: in_c holds fp6 half-records (then wpk / shift_sa6 are the fp6 x fp6 arrays), bit 1: out_c is written as fp6 half-records, bit 2 (with bit 0, without bit 1): the output is stored space-to-depth for conv2b_s2d_kernel */);
 bool conv3x3_rf_c_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo);
+// conv2b_s2d_kernel.hip: conv2b over conv2a's output stored space-to-depth (launch_conv3x3_pp_c with bit 2 of fmt6 writes that layout)
+bool conv2b_s2d_serves(int H2, int W2, int Cin, int CoutP);
+void launch_conv2b_s2d(hipStream_t st, const half_t *in_s2d, const half_t *in_c_s2d, int H4, int W4, const half_t *wpk, const float *scale,
+                       const float *shift, int relu, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte, unsigned int *range, int fmt6 /* bit 1: out_c as fp6 half-records */);
 bool launch_conv3x3_rf_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out, half_t *out_c,
                          int Ho, int Wo, const half_t *zero_page, int sbyte, unsigned int *range = nullptr, int fmt6 = 0 /* bit 1: out_c as fp6 half-records */);
