@@ -146,6 +146,11 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *               -37 us per 1600x1200 extract (profiles/r04n_ab_fp6_acts.txt); descriptor rms error +1 .. 2.4 % of the fp8 records'
  *               (profiles/r04n_fp6_record_formats.txt), same 1e-3 tolerance asserted.  Decided per tensor: a producer that is not the
  *               tuned kernel ("fuse" 0, "no_rf_c", "generic_c") keeps its records fp8.  0 = fp8 records everywhere.
+ *   "s2d"       1 (default) / 0: SFD2_PREC_F16C on the throughput path (sfd2_extract / sfd2_extract_match; image sides multiples of 4, fp6_acts on):
+ *               conv2a stores its output space-to-depth (four parity planes at quarter resolution) and conv2b runs as a stride-1 layer over
+ *               it (conv2b_s2d_kernel.hip: filters through the LDS once per 512 pixels; conv3x3_rf<2,comp> loads 1.18 MB of filter fragments per
+ *               128).  conv2b 147 -> 98 us at 1600x1200; same products, another fp32 summation order (descriptors within 5e-4 of the strided
+ *               kernel's, both <= 1e-3 against the reference).  sfd2_det keeps the strided kernel (its tensors stay readable).
  *   "cu_limit"  0 (default) / n: persistent kernels of THIS context launch at most n blocks (experiment: with two streams, two kernels
  *               side by side on half the chip each measure the same throughput as taking turns on all of it).
  *   "auto_range" 1 (default) / 0: sfd2_load_weights calibrates the activation exponents on a built-in probe image (see

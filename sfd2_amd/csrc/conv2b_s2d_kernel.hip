@@ -9,11 +9,14 @@
 // conv3x3_pp's -- 16 x 32 output pixels x 128 channels, filters through the LDS once per 512 pixels, the 18 x 34 patch of ONE plane's 32-channel
 // chunk at a time -- and the K loop is a list of 32 steps per tile: (hi | corr) x 4 chunks x 4 planes, each with the plane's 1, 2 or 4 taps.
 //
-// A step's operands (patch 39 KB + its taps' filter rows, 8 KB each) are copied into LDS (global_load ... lds) while the previous step
-// computes; one workgroup barrier per step.  Same LDS record layout / swizzle, fragment reads, MFMA orientation and epilogue as
-// conv3_kernels.hip; the filter array is the layer's generic one (api_weights.hip pack_igemm: [hi chunks | corr chunks][tap][oc][32]).
-// Per tile 1.8 MB of copies against 75 k cycles of MFMA issue: the kernel is bound by the copies, at a quarter of the bytes per pixel the
-// register-filter kernel asks of the L2.
+// Pipeline.  Per (hi | corr, chunk) group five steps: plane (1,1) with its taps of filter row 0, the same patch with those of row 2, planes
+// (1,0), (0,1) (two taps each), (0,0) (one) -- 40 steps per tile, at most two taps (16 KB of filters) each.  Patches live in a ring of THREE
+// buffers and are requested two patches ahead, filters in two buffers one step ahead: with two patch buffers every step waited for an HBM
+// round trip that had a single step (~1.5 us of MFMAs) to hide behind -- 105 us, of which the copies alone were 80 (ablations below).  Copies
+// are `buffer_load ... lds` (complete in issue order: a step waits for its own operands by COUNT and leaves the newer patch in flight; lanes
+// outside the image get an offset beyond the buffer and read zeros).  One workgroup barrier per step.  Same LDS record layout / swizzle,
+// fragment reads, MFMA orientation and epilogue as conv3_kernels.hip; the filter array is the layer's generic one (api_weights.hip pack_igemm:
+// [hi chunks | corr chunks][tap][oc][32]).
 #include "sfd2_internal.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -21,13 +24,13 @@
 #define S2_TW 32
 #define S2_TH 16
 #define S2_BN 128
-#define S2_PW (S2_TW + 2)
-#define S2_PH (S2_TH + 2)
-#define S2_NPIX (S2_PH * S2_PW)                 // 612 patch records of 64 B
-#define S2_XCH ((S2_NPIX + 15) / 16)            // 39 pieces of 1 KB
-#define S2_XPW 5                                // pieces per wave (the tail repeats the last piece)
+#define S2_PW (S2_TW + 1)                       // the taps reach one record up / left only: 17 x 33 patch records
+#define S2_PH (S2_TH + 1)
+#define S2_NPIX (S2_PH * S2_PW)                 // 561 patch records of 64 B
+#define S2_XCH ((S2_NPIX + 15) / 16)            // 36 pieces of 1 KB
+#define S2_XPW 5                                // pieces per wave: waves 0 .. 3 move five, waves 4 .. 7 four
 #define S2_XBYTES (S2_XCH * 1024)
-#define S2_FBYTES (4 * S2_BN * 64)              // up to four taps x 128 filters x 64 B = 32 KB
+#define S2_FBYTES (2 * S2_BN * 64)              // two taps x 128 filters x 64 B = 16 KB
 
 typedef __attribute__((address_space(3))) void lds_void5_t;
 typedef const __attribute__((address_space(1))) void gbl_void5_t;
@@ -42,8 +45,8 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
                        const half_t *__restrict__ zero_page, int sa, unsigned int *__restrict__ range)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *Xs = smem;                              // [2][S2_XBYTES]
-    unsigned char *Fs = smem + 2 * S2_XBYTES;              // [2][S2_FBYTES]
+    unsigned char *Xs = smem;                              // [3][S2_XBYTES]
+    unsigned char *Fs = smem + 3 * S2_XBYTES;              // [2][S2_FBYTES]
     float *SS = reinterpret_cast<float *>(Fs + 2 * S2_FBYTES);   // scale[128], shift[128]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -74,45 +77,53 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
         const int tx_ = (tile_) % tiles_x, ty_ = (tile_) / tiles_x;                                    \
         oy0 = ty_ * S2_TH; ox0 = tx_ * S2_TW;                                                          \
         _Pragma("unroll") for (int i = 0; i < S2_XPW; ++i) {                                           \
-            int piece = wave + 8 * i;                                                                  \
-            if (piece >= S2_XCH) piece = S2_XCH - 1;                                                   \
+            const int piece = wave + 8 * i;      /* (i = 4: waves 0 .. 3 only, see S2_ISSUE_X) */      \
             const int q = piece * 16 + (lane >> 2);                                                    \
             const int slot = (lane & 3) ^ ((q >> 2) & 3);                                              \
-            int off = -1;                                                                              \
+            int off = (int)0x80000000;   /* beyond the buffer: zeros */                                \
             if (q < S2_NPIX) {                                                                         \
                 const int py = q / S2_PW, px = q - py * S2_PW;                                         \
                 const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;                                        \
-                if (iy >= 0 && iy < H4 && ix >= 0 && ix < W4) off = (iy * W4 + ix) * CIN + slot * 8;   \
+                if (iy >= 0 && iy < H4 && ix >= 0 && ix < W4) off = ((iy * W4 + ix) * CIN + slot * 8) * (int)sizeof(half_t); \
             }                                                                                          \
             xoff[i] = off;                                                                             \
         }                                                                                              \
     }
-    // step s of a tile: corr = s >> 4, chunk k = (s >> 2) & 3, plane order (1,1), (1,0), (0,1), (0,0) = memory planes 3, 2, 1, 0
-#define S2_ISSUE(step_, buf_)                                                                          \
+    const int t_bytes = (int)((size_t)H4 * W4 * CIN * sizeof(half_t));
+    const auto rs_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(in), 0, t_bytes, 0x00020000);
+    const auto rs_co = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(in_c), 0, t_bytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(wpk), 0, 8 * 9 * CO * 32 * (int)sizeof(half_t), 0x00020000);
+    // patch x of a tile (x = 0 .. 31): group g = x >> 2 (corr = g >> 2, chunk = g & 3), memory plane 3 - (x & 3); FIVE copies per wave
+#define S2_ISSUE_X(x_, xb_)                                                                            \
     {                                                                                                  \
-        const int cr_ = (step_) >> 4, k_ = ((step_) >> 2) & 3, pl_ = 3 - ((step_) & 3);                 \
-        const half_t *xp_ = (cr_ ? in_c : in) + pl_ * 128 + k_ * 32;                                   \
+        const int g_ = (x_) >> 2, pl_ = 3 - ((x_) & 3);                                                \
+        const int so_ = (pl_ * 128 + (g_ & 3) * 32) * (int)sizeof(half_t);                              \
         _Pragma("unroll") for (int i = 0; i < S2_XPW; ++i) {                                           \
-            const int pc_ = (wave + 8 * i < S2_XCH) ? wave + 8 * i : S2_XCH - 1;                       \
-            const half_t *src_ = xoff[i] >= 0 ? xp_ + (size_t)xoff[i] : zero_page + (lane & 3) * 8;    \
-            __builtin_amdgcn_global_load_lds((gbl_void5_t *)src_, (lds_void5_t *)(Xs + (buf_)*S2_XBYTES + pc_ * 1024), 16, 0, 0); \
+            const int pc_ = wave + 8 * i;                                                              \
+            if (pc_ >= S2_XCH) continue;         /* wave-uniform */                                    \
+            if ((g_ >> 2) != 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_co, (lds_void5_t *)(Xs + (xb_)*S2_XBYTES + pc_ * 1024), 16, xoff[i], so_, 0, 0); \
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_hi, (lds_void5_t *)(Xs + (xb_)*S2_XBYTES + pc_ * 1024), 16, xoff[i], so_, 0, 0); \
         }                                                                                              \
-        const int py_ = pl_ >> 1, px_ = pl_ & 1;                                                       \
-        const half_t *fp_ = wpk + (size_t)((cr_ * 4 + k_) * 9) * CO * 32 + fsrc;                       \
-        int j_ = 0;                                                                                    \
-        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                               \
-            _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                           \
-                if ((ky != 1) == (py_ != 0) && (kx != 1) == (px_ != 0)) {                              \
-                    __builtin_amdgcn_global_load_lds((gbl_void5_t *)(fp_ + (size_t)(ky * 3 + kx) * CO * 32),  \
-                                                     (lds_void5_t *)(Fs + (buf_)*S2_FBYTES + j_ * (S2_BN * 64) + wave * 1024), 16, 0, 0); \
-                    ++j_;                                                                              \
-                }                                                                                      \
+    }
+    // filters of step f (f = 0 .. 39): group f / 5, e = f % 5 -> original taps (0, 2), (6, 8), (1, 7), (3, 5), (4); ONE copy per wave and tap
+#define S2_ISSUE_F(f_, fb_)                                                                            \
+    {                                                                                                  \
+        const int g_ = (f_) / 5, e_ = (f_) - g_ * 5;                                                   \
+        const int t0_ = e_ == 0 ? 0 : e_ == 1 ? 6 : e_ == 2 ? 1 : e_ == 3 ? 3 : 4;                      \
+        const int t1_ = e_ == 0 ? 2 : e_ == 1 ? 8 : e_ == 2 ? 7 : 5;                                   \
+        const int sb_ = g_ * 9 * CO * 32 * (int)sizeof(half_t);                                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void5_t *)(Fs + (fb_)*S2_FBYTES + wave * 1024), 16, fsrc * 2, sb_ + t0_ * CO * 32 * 2, 0, 0); \
+        if (e_ != 4)                                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void5_t *)(Fs + (fb_)*S2_FBYTES + S2_BN * 64 + wave * 1024), 16, fsrc * 2, sb_ + t1_ * CO * 32 * 2, 0, 0); \
     }
 
     int tile = blockIdx.x;
     S2_SETUP(tile)
-    S2_ISSUE(0, 0)
+    S2_ISSUE_X(0, 0)
+    S2_ISSUE_X(1, 1)
+    S2_ISSUE_F(0, 0)
     unsigned int smax = 0;
+    int xb = 0;                                            // ring buffer of the patch at hand (patch x + 1 in xb + 1, x + 2 goes to xb + 2)
 
     for (;;) {
         f32x16_t acc[2][4];
@@ -125,34 +136,48 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
         const int next = tile + (int)gridDim.x;
         const bool has_next = next < n_tiles;
         const int eoy0 = oy0, eox0 = ox0;
+        bool lax = false;                                  // the previous step requested a patch BEHIND this step's filters: those copies (five or four per wave) may stay in flight
 
-        // one step: the NKY x NKX taps of one plane's chunk (runtime loop: 1, 2 or 4 trips); tap j = iy * NKX + ix reads the patch shifted by
-        // (iy + (NKY == 1), ix + (NKX == 1)) records.  Two bodies (fp16 / corr), each in its own step loop: one body with the type as a runtime
-        // flag, or the eight (type, shape) combinations as separate inlined bodies, spill
-#define S2_STEP_PROLOGUE(s_)                                                                           \
-            SFD2_BARRIER_DRAIN();                                                                      \
-            const int buf = (s_) & 1;                                                                   \
-            if (ABL & 1) {                                                                             \
-            } else if ((s_) + 1 < 32) { S2_ISSUE((s_) + 1, buf ^ 1) }                                   \
-            else if (has_next) {                                                                       \
-                S2_SETUP(next)                                                                         \
-                S2_ISSUE(0, buf ^ 1)   /* (32 steps: the next tile's step 0 lands in buffer 0 again) */ \
+        // Start of step f: this step's filters (requested a step ago, in front of that step's patch request) and patch (two patches ago) have
+        // landed -- every wave waits for its own copies, then the block; every wave is also done reading what the copies issued below
+        // overwrite (the other filter buffer: step f - 1; the third patch buffer: the previous patch).  Then the requests: filters of step
+        // f + 1 FIRST, then (first step of a patch) the patch after next.
+#define S2_STEP_PROLOGUE(f_)                                                                           \
+            if (lax && wave < 4) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+            else if (lax) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");     \
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");              \
+            const int g = (f_) / 5, e = (f_) - g * 5;                                                   \
+            const int fbuf = (f_) & 1;                                                                  \
+            lax = false;                                                                               \
+            if (!(ABL & 1)) {                                                                          \
+                if ((f_) + 1 < 40) { S2_ISSUE_F((f_) + 1, fbuf ^ 1) }                                   \
+                else if (has_next) { S2_ISSUE_F(0, fbuf ^ 1) }                                          \
+                if (e != 1) {   /* first step of patch x = 4 g + (e ? e - 1 : 0) */                     \
+                    const int x2 = 4 * g + (e ? e - 1 : 0) + 2;                                         \
+                    const int b2 = xb >= 1 ? xb - 1 : 2;   /* (xb + 2) % 3 */                           \
+                    if (x2 < 32) { S2_ISSUE_X(x2, b2) lax = true; }                                     \
+                    else if (has_next) {                                                               \
+                        if (x2 == 32) { S2_SETUP(next) }                                               \
+                        S2_ISSUE_X(x2 - 32, b2)                                                        \
+                        lax = true;                                                                    \
+                    }                                                                                  \
+                }                                                                                      \
             }                                                                                          \
-            const int ty = (s_) & 3;   /* plane (1,1), (1,0), (0,1), (0,0) */                          \
-            const int nky = ty < 2 ? 2 : 1, nkx = (ty & 1) ? 1 : 2;                                     \
-            const unsigned char *xs = Xs + buf * S2_XBYTES;                                            \
-            const unsigned char *fs = Fs + buf * S2_FBYTES;
+            const int ntap = e == 4 ? 1 : 2;                                                            \
+            /* tap j of the step: patch shift (rows, columns) */                                        \
+            const int ro0 = (e == 0 || e == 2) ? 0 : 1, co0 = (e == 2 || e == 4) ? 1 : 0;               \
+            const int ro1 = e == 0 ? 0 : 1, co1 = 1;                                                    \
+            const unsigned char *xs = Xs + xb * S2_XBYTES;                                             \
+            const unsigned char *fs = Fs + fbuf * S2_FBYTES;
+#define S2_STEP_EPILOGUE()                                                                             \
+            if (e != 0) xb = xb == 2 ? 0 : xb + 1;         /* (step 0 of a group shares its patch with step 1) */
 #pragma unroll 1
-        for (int s = 0; s < 16; ++s) {
-            // this step's operands have landed (every wave waits for its own pieces, then the block), and every wave is done reading the
-            // other buffers (step s - 1): the next step's copies go there
-            S2_STEP_PROLOGUE(s)
+        for (int f = 0; f < 20; ++f) {
+            S2_STEP_PROLOGUE(f)
 #pragma unroll 1
-            for (int j = 0; j < ((ABL & 2) ? 0 : nky * nkx); ++j) {
-                const int iy = nkx == 2 ? (j >> 1) : j, ix = nkx == 2 ? (j & 1) : 0;
-                const int ro = iy + (nky == 1 ? 1 : 0), co = ix + (nkx == 1 ? 1 : 0);
+            for (int j = 0; j < ((ABL & 2) ? 0 : ntap); ++j) {
                 const unsigned char *ft = fs + j * (S2_BN * 64);
-                const int qv = qb + ro * S2_PW + co;
+                const int qv = qb + (j ? ro1 : ro0) * S2_PW + (j ? co1 : co0);
                 h8_t fa[2][2], fb[2][4];
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
@@ -175,16 +200,15 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
                         for (int pr = 0; pr < 4; ++pr)
                             acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][ct], fb[kk][pr], acc[ct][pr], 0, 0, 0);
             }
+            S2_STEP_EPILOGUE()
         }
 #pragma unroll 1
-        for (int s = 16; s < 32; ++s) {
-            S2_STEP_PROLOGUE(s)
+        for (int f = 20; f < 40; ++f) {
+            S2_STEP_PROLOGUE(f)
 #pragma unroll 1
-            for (int j = 0; j < ((ABL & 2) ? 0 : nky * nkx); ++j) {
-                const int iy = nkx == 2 ? (j >> 1) : j, ix = nkx == 2 ? (j & 1) : 0;
-                const int ro = iy + (nky == 1 ? 1 : 0), co = ix + (nkx == 1 ? 1 : 0);
+            for (int j = 0; j < ((ABL & 2) ? 0 : ntap); ++j) {
                 const unsigned char *ft = fs + j * (S2_BN * 64);
-                const int qv = qb + ro * S2_PW + co;
+                const int qv = qb + (j ? ro1 : ro0) * S2_PW + (j ? co1 : co0);
                 v8i_t fac[2], frc[4];
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
@@ -208,8 +232,11 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
 #pragma unroll
                     for (int pr = 0; pr < 4; ++pr) asm volatile("" : "+v"(acc[ct][pr]));
             }
+            S2_STEP_EPILOGUE()
         }
 #undef S2_STEP_PROLOGUE
+#undef S2_STEP_EPILOGUE
+        // (the epilogue's stores are younger than every copy in flight: the next tile's first wait is a full one)
 
         // epilogue (conv3_kernels.hip): y = acc * scale + shift, ReLU, hi plane + corr records, 16-byte stores
         float mx = 0.0f;
@@ -272,16 +299,21 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
     }
     if (range != nullptr) sfd2_range_commit(range, smax);
 #undef S2_SETUP
-#undef S2_ISSUE
+#undef S2_ISSUE_X
+#undef S2_ISSUE_F
 }
 
 // does the s2d form serve this geometry?  (conv2a's output H2 x W2 must split into whole 2 x 2 cells)
-bool conv2b_s2d_serves(int H2, int W2, int Cin, int CoutP) { return (H2 % 2) == 0 && (W2 % 2) == 0 && Cin == 128 && CoutP == 128 && H2 >= 2 && W2 >= 2; }
+bool conv2b_s2d_serves(int H2, int W2, int Cin, int CoutP)
+{
+    return (H2 % 2) == 0 && (W2 % 2) == 0 && Cin == 128 && CoutP == 128 && H2 >= 2 && W2 >= 2 &&
+           (long long)H2 * W2 * 128 * (long long)sizeof(half_t) < (1ll << 31);      // (buffer offsets are 32-bit)
+}
 
 void launch_conv2b_s2d(hipStream_t st, const half_t *in, const half_t *in_c, int H4, int W4, const half_t *wpk, const float *scale,
                        const float *shift, int relu, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte, unsigned int *range, int fmt6)
 {
-    constexpr size_t lds = (size_t)2 * S2_XBYTES + (size_t)2 * S2_FBYTES + 2 * S2_BN * sizeof(float);
+    constexpr size_t lds = (size_t)3 * S2_XBYTES + (size_t)2 * S2_FBYTES + 2 * S2_BN * sizeof(float);
     static bool attr_done = false;
     static int slots = 256;
     if (!attr_done) {

@@ -447,6 +447,38 @@ def test_f16c_fp6_acts_per_tensor_fallbacks(synth_sd):
         _record(f"f16c fp6_acts=1 {opts} extract 130x100: IoU {iou:.4f}, desc {dd:.2e}")
 
 
+@pytest.mark.parametrize("h,w,seed,topk", [(96, 128, 21, 200), (480, 640, 0, 1024), (1200, 1600, 31, 4096), (1600, 1200, 64, 4096), (1024, 1024, 61, 4096),
+                                           (100, 132, 22, -1), (36, 40, 3, -1), (1028, 772, 7, 2000)])
+def test_f16c_conv2b_space_to_depth_vs_oracle_and_strided_kernel(synth_sd, h, w, seed, topk):
+    """Option s2d (default on; throughput path, image sides multiples of 4): conv2a stores its output as four parity planes at quarter
+    resolution and conv2b runs as a stride-1 layer over them (conv2b_s2d_kernel.hip) -- the same products as conv3x3_rf<2,comp>, another
+    fp32 summation order: both inside the tolerance against the oracle, and within 5e-4 of each other on the common key points (the bound of
+    test_f16c_tuned_kernels_vs_generic_kernel: a flipped fp16 rounding of a backbone value is fp16-level noise behind the plain fp16 heads)."""
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    from sfd2_amd.model import ResSegNetV2
+    img = synth.make_image(h, w, seed)
+    want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk)
+    outs = []
+    for s2d in (1, 0):
+        m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
+        m.load_state_dict(synth_sd)
+        m.cuda(0)
+        m.context.set_option("s2d", s2d)
+        got = extract_resnet_return(m, torch.from_numpy(img)[None].cuda(), conf_th=0.001, topK=topk, scales=[1.0])
+        iou, dd, shift, same, n = _compare(got, want, 0.985 if topk > 0 else 0.97)      # (every point above the threshold: a few sit on it)
+        outs.append(got)
+        st = m.range_status()
+        assert not st["saturated"] and st["fallbacks"] == 0, st
+        _record(f"f16c s2d={s2d} extract {w}x{h} top{topk}: IoU {iou:.4f}, desc {dd:.2e}, same rank {same}/{n}")
+    a, b = _kp_index(outs[0]["keypoints"]), _kp_index(outs[1]["keypoints"])
+    common = sorted(set(a) & set(b))
+    assert len(common) >= 0.98 * min(len(a), len(b))
+    d = np.abs(outs[0]["descriptors"][[a[k] for k in common]] - outs[1]["descriptors"][[b[k] for k in common]]).max()
+    assert d <= 5e-4, d
+    _record(f"f16c s2d on vs off {w}x{h}: {len(common)} common key points, descriptors within {d:.2e}")
+
+
 @pytest.fixture(scope="module", params=[0, 1])
 def model_c_inner(request, synth_sd):
     """f16c with option rb_inner off its default (2: the tensors inside the ResBlocks, t1 and t2, stored as plain fp16):

@@ -23,7 +23,8 @@ F16S = ("f16c", "f16")
 ROWS = [
     ({}, ALL, False),
     ({"fuse": 0}, F16S, False),
-    ({"alias": 0}, F16S, True),
+    ({"alias": 0}, ("f16",), True),
+    ({"alias": 0}, ("f16c",), False),    # (private buffers are the readable layout: conv2b on the strided kernel, not the space-to-depth one)
     ({"fuse_post": 0}, ALL, True),
     ({"fuse_pb": 0}, F16S, False),
     ({"sparse_desc": 0}, F16S, False),
@@ -55,6 +56,9 @@ ROWS = [
     ({"fp6_acts": 1, "no_rf_c": 1}, ("f16c",), False),
     ({"fp6_acts": 1, "generic_c": 1}, ("f16c",), False),
     ({"fp6_acts": 1, "fp6_filters": 1, "comp_heads": 1}, ("f16c",), False),
+    ({"s2d": 0}, ("f16c",), False),
+    ({"s2d": 1, "fp6_acts": 0}, ("f16c",), False),       # (the s2d store exists for the fp6-input form of conv2a only: falls back)
+    ({"s2d": 1, "no_rf_c": 1}, ("f16c",), False),
 ]
 
 
