@@ -205,7 +205,7 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &i
                                 i6 ? L.sa66.as<float>() : L.sa6.as<float>(), rs, fmt6);      // (bit 2: the output stored space-to-depth, with fp6 input records only)
             return;
         }
-        if (fmt6) { fprintf(stderr, "sfd2: %s: fp6 records requested from a layer without fp6 filter strings\n", name); abort(); }
+        if (fmt6) { c->net_error = 1; (void)fail(std::string(name) + ": fp6 records requested from a layer without fp6 filter strings"); return; }
         const bool f6 = c->opt_fp6_filters && in_c && out_c && L.wc6.p && L.sa6.p;      // corr filters as fp6 (option "fp6_filters")
         launch_conv3x3_pp_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, f6 ? L.wc6.as<half_t>() : L.wc.as<half_t>(), L.scale.as<float>(),
                             L.shift.as<float>(), L.cout_pad, relu, out.as<half_t>(), out_c, Ho, Wo, c->zero_page.as<half_t>(), L.sbyte,
@@ -213,8 +213,10 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &i
         return;
     }
     if ((fmt6 & 1) || ((fmt6 & 2) && !(!c->opt_generic_c && !c->opt_no_rf_c && conv3x3_rf_c_serves(L.ks, L.stride, L.cout_pad, L.cin, Ho, Wo) && relu))) {
-        fprintf(stderr, "sfd2: %s: fp6 records on a path that cannot read / write them\n", name);     // (run_network decides per tensor: cannot happen)
-        abort();
+        // (run_network decides the format per tensor from the same predicates: reaching this is a bug, reported as an error of the call)
+        c->net_error = 1;
+        (void)fail(std::string(name) + ": fp6 records on a path that cannot read / write them");
+        return;
     }
     if (!c->opt_generic_c && !c->opt_no_rf_c && in_c && out_c && !res && L.ks == 3 && L.stride == 2 && L.cout_pad == 128) {   // conv2b
         ProfScope ps(c, name, "conv3x3_rf<2,comp>", flops, bytes);
@@ -724,5 +726,6 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     }
     if (fork) HIPCHECK(hipStreamWaitEvent(st, c->ev_join, 0));
     HIPCHECK(hipGetLastError());
+    if (c->net_error) { c->net_error = 0; return -1; }      // (a layer helper recorded an error: sfd2_last_error has its text)
     return 0;
 }

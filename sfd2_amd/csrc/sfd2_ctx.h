@@ -146,6 +146,7 @@ struct sfd2_ctx {
     DevBuf da3_sparse;                 // [sel_cap][4][256] fp16: convDa.3 on the sampled corner pixels
     int opt_fp6_acts = 1;              // sfd2_set_option "fp6_acts": the corr records of the three tensors only conv3x3_pp<comp> reads (conv1b's, conv2b's,
                                        // conv3a's output) as block-scaled fp6 half-records, their consumers' corr MFMAs fp6 x fp6 (33.5 cycles instead of 66)
+    int net_error = 0;                 // set by a layer helper of run_network that cannot return an error itself; run_network returns -1 and clears it
     int opt_s2d = 1;                   // sfd2_set_option "s2d": on the throughput path conv2a stores its output space-to-depth and conv2b runs as a stride-1 layer
                                        // over it (conv2b_s2d_kernel.hip) instead of conv3x3_rf<2,comp>
     int opt_fp6_filters = 0;           // sfd2_set_option "fp6_filters": conv3x3_pp<comp> takes its corr filters as block-scaled fp6 (fp8 x fp6 MFMA).
