@@ -147,10 +147,19 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
     // independent chains per wave against 0.90 with two: tools/probe/mfma_valu.hip), then both tiles' epilogue.  Forward:
     // FWD_IDS: element-wise running maxima with the tile id packed into the 7 low mantissa bits, else of the raw values --
     // either way ONE v_max3_f32 per query row takes both tiles.
+// A wave raises its priority for the MFMA burst of a stage: two waves of a SIMD that start their bursts together otherwise share the matrix
+// pipe AND then the vector ALU (MFMA time + VALU time per stage pair, as measured); with the priority the first one through keeps the pipe,
+// the other follows, and from then on one wave's epilogue runs under the other's burst.  (-DSFD2_MQ_NO_PRIO: without)
+#ifdef SFD2_MQ_NO_PRIO
+#define MQ_PRIO(p_)
+#else
+#define MQ_PRIO(p_) __builtin_amdgcn_s_setprio(p_);
+#endif
 #define MQ_STAGE(S_, BUF_)                                                                               \
     {                                                                                                    \
         f32x16_t a0_, a1_, b0_, b1_;                                                                     \
         h8_t fa_ = MQ_BFRAG(BUF_, 0, 0), fb_ = MQ_BFRAG(BUF_, 1, 0), na_ = fa_, nb_ = fb_;               \
+        MQ_PRIO(1)                                                                                       \
         _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                               \
             /* the fragments of K step ks + 1 are requested in front of the MFMAs of step ks */         \
             if (ks + 1 < 8) { na_ = MQ_BFRAG(BUF_, 0, ks + 1); nb_ = MQ_BFRAG(BUF_, 1, ks + 1); }        \
@@ -162,6 +171,7 @@ void match_mutual_kernel(const MatchJob2 *__restrict__ jobs, int splits, int qbl
             __builtin_amdgcn_sched_barrier(0);                                                           \
             fa_ = na_; fb_ = nb_;                                                                        \
         }                                                                                                \
+        MQ_PRIO(0)                                                                                       \
         const int ta_ = (S_)*2, tb_ = (S_)*2 + 1;                                                        \
         MQ_TILE_MASK(a0_, a1_, ta_)                                                                      \
         MQ_TILE_MASK(b0_, b1_, tb_)                                                                      \
