@@ -93,11 +93,15 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
     const auto rs_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(in), 0, t_bytes, 0x00020000);
     const auto rs_co = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(in_c), 0, t_bytes, 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(wpk), 0, 8 * 9 * CO * 32 * (int)sizeof(half_t), 0x00020000);
-    // patch x of a tile (x = 0 .. 31): group g = x >> 2 (corr = g >> 2, chunk = g & 3), memory plane 3 - (x & 3); FIVE copies per wave
+    // Order within a tile: (hi | corr) x plane (1,1), (1,0), (0,1), (0,0) x chunk 0 .. 3 -- the CHUNK innermost: a pixel's 64-byte records of
+    // chunks 2 j and 2 j + 1 are the two halves of one 128-byte line, and consecutive patches find the second half in the L2 the first one
+    // brought it into (with the chunk outermost the halves were five steps = 6 MB of patches per XCD apart: the PMC passes counted 1.65 x
+    // the tensor's bytes).
+    // patch x of a tile (x = 0 .. 31): corr = x >> 4, memory plane 3 - ((x >> 2) & 3), chunk x & 3; five (waves 4 .. 7: four) copies per wave
 #define S2_ISSUE_X(x_, xb_)                                                                            \
     {                                                                                                  \
-        const int g_ = (x_) >> 2, pl_ = 3 - ((x_) & 3);                                                \
-        const int so_ = (pl_ * 128 + (g_ & 3) * 32) * (int)sizeof(half_t);                              \
+        const int g_ = ((x_) >> 4) << 2, pl_ = 3 - (((x_) >> 2) & 3);     /* (g_ >> 2 = corr) */         \
+        const int so_ = (pl_ * 128 + ((x_) & 3) * 32) * (int)sizeof(half_t);                            \
         _Pragma("unroll") for (int i = 0; i < S2_XPW; ++i) {                                           \
             const int pc_ = wave + 8 * i;                                                              \
             if (pc_ >= S2_XCH) continue;         /* wave-uniform */                                    \
@@ -105,10 +109,16 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_hi, (lds_void5_t *)(Xs + (xb_)*S2_XBYTES + pc_ * 1024), 16, xoff[i], so_, 0, 0); \
         }                                                                                              \
     }
-    // filters of step f (f = 0 .. 39): group f / 5, e = f % 5 -> original taps (0, 2), (6, 8), (1, 7), (3, 5), (4); ONE copy per wave and tap
+    // step f (f = 0 .. 39): corr = f / 20, r = f % 20; r < 8: plane (1,1), chunk r >> 1, e = r & 1 (filter row 0 / 2); else plane index
+    // (r - 8) >> 2, chunk (r - 8) & 3, e = 2 + plane index.  e -> original taps (0, 2), (6, 8), (1, 7), (3, 5), (4); ONE copy per wave and tap
+#define S2_STEP_MAP(f_, cr_, e_, k_)                                                                   \
+        const int cr_ = (f_) >= 20 ? 1 : 0, r__##e_ = (f_) - cr_ * 20;                                  \
+        const int e_ = r__##e_ < 8 ? (r__##e_ & 1) : 2 + ((r__##e_ - 8) >> 2);                          \
+        const int k_ = r__##e_ < 8 ? (r__##e_ >> 1) : ((r__##e_ - 8) & 3);
 #define S2_ISSUE_F(f_, fb_)                                                                            \
     {                                                                                                  \
-        const int g_ = (f_) / 5, e_ = (f_) - g_ * 5;                                                   \
+        S2_STEP_MAP(f_, c_, e_, kk_)                                                                   \
+        const int g_ = c_ * 4 + kk_;                                                                   \
         const int t0_ = e_ == 0 ? 0 : e_ == 1 ? 6 : e_ == 2 ? 1 : e_ == 3 ? 3 : 4;                      \
         const int t1_ = e_ == 0 ? 2 : e_ == 1 ? 8 : e_ == 2 ? 7 : 5;                                   \
         const int sb_ = g_ * 9 * CO * 32 * (int)sizeof(half_t);                                        \
@@ -146,14 +156,14 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
             if (lax && wave < 4) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
             else if (lax) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");     \
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");              \
-            const int g = (f_) / 5, e = (f_) - g * 5;                                                   \
+            S2_STEP_MAP(f_, cr, e, kc)                                                                  \
             const int fbuf = (f_) & 1;                                                                  \
             lax = false;                                                                               \
             if (!(ABL & 1)) {                                                                          \
                 if ((f_) + 1 < 40) { S2_ISSUE_F((f_) + 1, fbuf ^ 1) }                                   \
                 else if (has_next) { S2_ISSUE_F(0, fbuf ^ 1) }                                          \
-                if (e != 1) {   /* first step of patch x = 4 g + (e ? e - 1 : 0) */                     \
-                    const int x2 = 4 * g + (e ? e - 1 : 0) + 2;                                         \
+                if (e != 1) {   /* first step of patch x = 16 corr + 4 plane index + chunk */           \
+                    const int x2 = 16 * cr + (e >= 2 ? 4 * (e - 1) : 0) + kc + 2;                       \
                     const int b2 = xb >= 1 ? xb - 1 : 2;   /* (xb + 2) % 3 */                           \
                     if (x2 < 32) { S2_ISSUE_X(x2, b2) lax = true; }                                     \
                     else if (has_next) {                                                               \
@@ -301,6 +311,7 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
 #undef S2_SETUP
 #undef S2_ISSUE_X
 #undef S2_ISSUE_F
+#undef S2_STEP_MAP
 }
 
 // does the s2d form serve this geometry?  (conv2a's output H2 x W2 must split into whole 2 x 2 cells)
