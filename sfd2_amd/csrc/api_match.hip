@@ -87,7 +87,9 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     if (single_gemm) {
         // one GEMM per pair instead of two: twice the blocks per job for the same tail behaviour
         const int qblocks = (n0 + 255) / 256;
-        splits = (768 * 6 + k * qblocks - 1) / (k * qblocks);
+        // (512 resident blocks: two per CU at this kernel's 200 registers.  Measured for 50 x 4096^2, us: 3 splits 209.0, 4 207.9, 5 210.1,
+        //  6 214.9, 8 220.2 -- six items per slot)
+        splits = (512 * 6 + k * qblocks - 1) / (k * qblocks);
         splits = std::max(1, std::min(splits, 8));
         splits = std::min(splits, std::max(1, (std::max(1, max_n1) + 31) / 32));
         if (const char *e = sfd2_env("SFD2_MATCH_SPLITS")) splits = std::max(1, std::min(16, atoi(e)));
