@@ -146,6 +146,11 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *               -37 us per 1600x1200 extract (profiles/r04n_ab_fp6_acts.txt); descriptor rms error +1 .. 2.4 % of the fp8 records'
  *               (profiles/r04n_fp6_record_formats.txt), same 1e-3 tolerance asserted.  Decided per tensor: a producer that is not the
  *               tuned kernel ("fuse" 0, "no_rf_c", "generic_c") keeps its records fp8.  0 = fp8 records everywhere.
+ *   "trunk_r1"  1 (default) / 0: SFD2_PREC_F16C (with "rb_inner" 2, "fuse_rb23", "fp6_acts"): conv3b's output and the ResBlocks' outputs carry ONE
+ *               correction byte per channel -- the residual e4m3((x - fp16(x)) * 2^9) -- instead of the (residual, value) unit: 3 bytes per channel
+ *               through the HBM-bound ResBlock kernels instead of 4.  The skip path never used the value byte; ResBlock.conv1 rebuilds it from
+ *               the hi plane in registers (v_cvt_scalef32_pk_fp8_f16).  conv2 + conv3 + residual 92 -> 83 us per block, extract 1.468 -> 1.431 ms
+ *               at 1600x1200; the rebuilt byte is e4m3(fp16(x) / 4) where the stored one was e4m3(x / 4): second-order, same tolerances.
  *   "s2d"       1 (default) / 0: SFD2_PREC_F16C on the throughput path (sfd2_extract / sfd2_extract_match; image sides multiples of 4, fp6_acts on):
  *               conv2a stores its output space-to-depth (four parity planes at quarter resolution) and conv2b runs as a stride-1 layer over
  *               it (conv2b_s2d_kernel.hip: filters through the LDS once per 512 pixels; conv3x3_rf<2,comp> loads 1.18 MB of filter fragments per

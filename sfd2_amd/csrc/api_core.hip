@@ -107,6 +107,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "fp6_filters") c->opt_fp6_filters = value ? 1 : 0;
     else if (k == "fp6_acts") c->opt_fp6_acts = value ? 1 : 0;
     else if (k == "s2d") c->opt_s2d = value ? 1 : 0;
+    else if (k == "trunk_r1") c->opt_trunk_r1 = value ? 1 : 0;
     else if (k == "fuse_pb") c->opt_fuse_pb = value ? 1 : 0;
     else if (k == "generic_c") c->opt_generic_c = value ? 1 : 0;
     else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;

@@ -698,7 +698,7 @@ extern "C" int sfd2_debug_activation(sfd2_ctx *c, const char *name, float *out, 
     } else {
         HIPCHECK(c->tmp_f32.ensure(n * sizeof(float)));
         if (a.f32) launch_nhwc_f_to_nchw_f(c->stream, reinterpret_cast<const float *>(a.p), np, a.pitch, a.c, c->tmp_f32.as<float>());
-        else if (a.pc) launch_nhwc_hc_to_nchw_f(c->stream, reinterpret_cast<const half_t *>(a.p), reinterpret_cast<const half_t *>(a.pc), np, a.pitch, a.c, c->tmp_f32.as<float>(), a.fmt6 ? 1 : 0);
+        else if (a.pc) launch_nhwc_hc_to_nchw_f(c->stream, reinterpret_cast<const half_t *>(a.p), reinterpret_cast<const half_t *>(a.pc), np, a.pitch, a.c, c->tmp_f32.as<float>(), a.r1 ? 2 : (a.fmt6 ? 1 : 0));
         else launch_nhwc_h_to_nchw_f(c->stream, reinterpret_cast<const half_t *>(a.p), np, a.pitch, a.c, c->tmp_f32.as<float>());
         if (a.exp2) launch_scale_inplace(c->stream, c->tmp_f32.as<float>(), n, std::ldexp(1.0f, -a.exp2));
         if (copy_out(c, out, c->tmp_f32.p, n * sizeof(float), 0)) return -1;

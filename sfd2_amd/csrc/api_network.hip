@@ -587,7 +587,18 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         } else
         convc(c, "conv2b", c->c2b, a2a, H2, W2, a2b, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV2B, b6 ? 2 : 0);
         convc(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV3A, (b6 ? 1 : 0) | (a6 ? 2 : 0));
-        convc(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV3B, a6 ? 1 : 0);
+        // Option "trunk_r1": the three tensors the ResBlocks read as block input (conv3b's output, the outputs of blocks 0 and 1) with the residual
+        // byte only -- their readers are conv1x1_c256_c<.., 2, ..> (value bytes rebuilt from the hi plane) and rb23_c_kernel's skip path
+        const bool tr1 = c->opt_trunk_r1 && a6 && !c->opt_generic_c && c->opt_comp_rb && c->opt_rb_inner >= 2 && c->opt_fuse_rb23 &&
+                         c->rb1[0].wfl.p && c->rb3[0].wfl.p && c->rb2[0].wlk.p && c->rb1[0].wfr.p;
+        {
+            static const char *tr[3] = {"bn3b", "conv4.0", "conv4.1"};
+            for (int i = 0; i < 3; ++i) {
+                auto it = c->acts.find(tr[i]);
+                if (it != c->acts.end()) it->second.r1 = tr1;
+            }
+        }
+        convc(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV3B, (a6 ? 1 : 0) | (tr1 ? 8 : 0));
         for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
             if (!c->opt_comp_rb) { rb_f16(b); continue; }   // option "comp_rb" = 0: this block in plain fp16 on the hi planes
             DevPtr &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];
@@ -605,19 +616,23 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                     if (i2 != c->acts.end() && i2->second.p == t2.p) { i2->second.pc = nullptr; i2->second.absent = t1p && c->opt_fuse_rb23; }
                 }
                 if (t1p) {
-                    ProfScope ps(c, nm1[b], "conv1x1_c256<comp,plain out>", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 6);
-                    launch_conv1x1_c256_c(st, x->as<half_t>(), corr_of(*x, PP, 256), (int)PP, L1.wfh.as<half_t>(), L1.wfc.as<half_t>(),
+                    ProfScope ps(c, nm1[b], "conv1x1_c256<comp,plain out>", 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * (tr1 ? 5 : 6));
+                    launch_conv1x1_c256_c(st, x->as<half_t>(), corr_of(*x, PP, 256), (int)PP, L1.wfh.as<half_t>(), tr1 ? L1.wfr.as<half_t>() : L1.wfc.as<half_t>(),
                                           L1.scale.as<float>(), L1.shift.as<float>(), 1, nullptr, nullptr, t1.as<half_t>(), nullptr,
-                                          c->zero_page.as<half_t>(), L1.sbyte, range_slot(c, SFD2_RS_T1_0 + b));
+                                          c->zero_page.as<half_t>(), L1.sbyte, range_slot(c, SFD2_RS_T1_0 + b), tr1 ? 1 : 0);
                 } else {
                     convc(c, nm1[b], L1, *x, H4, W4, t1, H4, W4, 1, true, true, nullptr, SFD2_RS_T1_0 + b);
                 }
                 if (t1p && c->opt_fuse_rb23) {
-                    ProfScope ps(c, nm3[b], "rb23_c_kernel", 2.0 * P4 * 256 * 72 + 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * 10);
+                    // (the last block's output keeps its units when a compensated head layer will read them)
+                    const bool out_r1 = b < 2 || !(c->opt_comp_heads || c->opt_comp_det);
+                    const int r1f = tr1 ? (1 | (out_r1 ? 2 : 0)) : 0;
+                    if (b == 2) { auto it = c->acts.find("conv4.2"); if (it != c->acts.end()) it->second.r1 = tr1 && out_r1; }
+                    ProfScope ps(c, nm3[b], "rb23_c_kernel", 2.0 * P4 * 256 * 72 + 2.0 * P4 * 256.0 * 256.0, P4 * 256.0 * (10 - (r1f & 1) - ((r1f >> 1) & 1)));
                     launch_rb23_c(st, t1.as<half_t>(), H4, W4, L2.w.as<half_t>(), L2.wlk.as<half_t>(), L2.scale.as<float>(), L2.shift.as<float>(),
                                   L3.wfh.as<half_t>(), L3.wfl.as<half_t>(), L3.scale.as<float>(), L3.shift.as<float>(), x->as<half_t>(),
                                   corr_of(*x, PP, 256), ob.as<half_t>(), corr_of(ob, PP, 256), c->zero_page.as<half_t>(),
-                                  range_slot(c, SFD2_RS_T2_0 + b), range_slot(c, SFD2_RS_OUT_0 + b));
+                                  range_slot(c, SFD2_RS_T2_0 + b), range_slot(c, SFD2_RS_OUT_0 + b), r1f);
                     x = &ob;
                     continue;
                 }

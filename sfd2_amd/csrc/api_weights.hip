@@ -254,6 +254,7 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
         if (ks == 1 && stride == 1 && cin == 256 && cout == 256) {
             std::vector<half_t> fh((size_t)256 * 256), fl(fh.size());
             std::vector<unsigned short> fc(fh.size());
+            std::vector<unsigned char> fr(fh.size() * 2);      // `wfr`: the corr units of a lane as [16 x w8][16 x lo_w8] (conv1x1_c256_c<.., 2, ..>)
             for (int wv = 0; wv < 8; ++wv)
                 for (int cc = 0; cc < 8; ++cc)
                     for (int l = 0; l < 64; ++l)
@@ -264,10 +265,13 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
                             fh[o] = (half_t)v;
                             fl[o] = (half_t)((v - (float)(half_t)v) * 2048.0f);
                             fc[o] = (unsigned short)(f32_to_e4m3(std::ldexp(v, b0)) | (f32_to_e4m3(std::ldexp(v - (float)(half_t)v, b0 + 11)) << 8));
+                            fr[(o - e) * 2 + e] = f32_to_e4m3(std::ldexp(v, b0));
+                            fr[(o - e) * 2 + 16 + e] = f32_to_e4m3(std::ldexp(v - (float)(half_t)v, b0 + 11));
                         }
             if (upload(L.wfh, fh.data(), fh.size() * 2, c->stream)) return -1;
             if (upload(L.wfl, fl.data(), fl.size() * 2, c->stream)) return -1;
             if (upload(L.wfc, fc.data(), fc.size() * 2, c->stream)) return -1;
+            if (upload(L.wfr, fr.data(), fr.size(), c->stream)) return -1;
         }
     }
     return 0;

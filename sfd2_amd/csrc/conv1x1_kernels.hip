@@ -206,7 +206,14 @@ void launch_conv1x1_c256(hipStream_t st, const half_t *in, int npix, const half_
 // IN_C = false: the input is a plain fp16 tensor (ResBlock-internal tensors under option "rb_inner", api_network.hip): no corr
 // plane to stage, and the filter residuals arrive as fp16 (w - fp16(w)) * 2^11 (`wc` = [256][256] halves) for a second fp16
 // pass into its own accumulator.  OUT_C = false: only the hi plane is written.
-template <bool HAS_RES, bool IN_C, bool OUT_C>
+// IN_C = 2 (option "trunk_r1"): the input's corr plane holds ONE byte per channel, the residual e4m3((x - hi) * 2^9), 256 bytes per pixel.
+// The value byte of a unit is rebuilt from the hi plane in registers -- a lane's fp16 fragments of K steps 2 c and 2 c + 1 ARE the 16
+// channels whose units its corr fragment of chunk c holds: v_cvt_scalef32_pk_fp8_f16 (two values per instruction) and a byte permute per
+// two channels -- so filters, MFMAs and results' structure are those of IN_C = 1, with 24 KB staged per group instead of 32.
+#ifndef SFD2_R1_VSCALE
+#define SFD2_R1_VSCALE 4.0f
+#endif
+template <bool HAS_RES, int IN_C, bool OUT_C>
 __global__ __launch_bounds__(NT1, 2)
 void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in_c, int npix,
                            const half_t *__restrict__ w /*fp16 filters*/, const half_t *__restrict__ wc /*corr units, or fp16 residuals*/,
@@ -220,7 +227,7 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
                            const half_t *__restrict__ zero_page, int sa, unsigned int *__restrict__ range /* the output tensor's range-status slot */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *Xs = smem;                                              // [NST][hi 32 x 512 B | corr 32 x 512 B]
+    unsigned char *Xs = smem;                                              // [NST][hi 32 x 512 B | corr 32 x 512 B (IN_C = 2: 32 x 256 B)]
     float *SS = reinterpret_cast<float *>(smem + NST * STAGE_C);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -256,14 +263,21 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
             const size_t so = (size_t)gp * 256 + ((lrow ^ (p & 31)) << 3);                                 \
             const half_t *s0 = gp < npix ? in + so : zero_page + (lrow << 3);                              \
             __builtin_amdgcn_global_load_lds((gbl_void_t *)s0, (lds_void_t *)(st + ch * 1024), 16, 0, 0);  \
-            if (IN_C) {                                                                                    \
+            if (IN_C == 1) {                                                                               \
                 const half_t *s1 = gp < npix ? in_c + so : zero_page + (lrow << 3);                        \
                 __builtin_amdgcn_global_load_lds((gbl_void_t *)s1, (lds_void_t *)(st + GPXC * 512 + ch * 1024), 16, 0, 0); \
             }                                                                                              \
         }                                                                                                  \
+        if (IN_C == 2) {   /* residual bytes: 256 B per pixel, ONE one-KB chunk (4 pixels) per wave, 16-byte slots XOR (pixel & 15) */ \
+            const int p = wave * 4 + (lane >> 4);                                                          \
+            const long long gp = (long long)(g_)*GPXC + p;                                                 \
+            const unsigned char *s1 = gp < npix ? reinterpret_cast<const unsigned char *>(in_c) + (size_t)gp * 256 + (((lane & 15) ^ (p & 15)) << 4) \
+                                                : reinterpret_cast<const unsigned char *>(zero_page) + ((lane & 15) << 4); \
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)s1, (lds_void_t *)(st + GPXC * 512 + wave * 1024), 16, 0, 0); \
+        }                                                                                                  \
     }
 #define WAIT_GROUP_C()                                                                                     \
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((IN_C ? 4 : 2) + (OUT_C ? 4 : 2) + (HAS_RES ? 4 : 0)) : "memory")
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((IN_C == 1 ? 4 : IN_C == 2 ? 3 : 2) + (OUT_C ? 4 : 2) + (HAS_RES ? 4 : 0)) : "memory")
 
     ISSUE_GC(g0)
     if (g0 + 1 < g1) { ISSUE_GC(g0 + 1) }
@@ -306,13 +320,52 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acl[r] = 0.0f;
         }
+        if (IN_C == 2) {
+            const unsigned char *xr = st + GPXC * 512 + p * 256 + 8 * lhi;
+            const int sr = p & 15;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const h8_t b0 = *reinterpret_cast<const h8_t *>(xp + (((c * 4 + lhi) ^ sw) << 4));
+                const h8_t b1 = *reinterpret_cast<const h8_t *>(xp + (((c * 4 + 2 + lhi) ^ sw) << 4));
+                // (read as halves like the fragments: behind a differently typed LDS read the compiler drains the ring's copies in flight, vmcnt(0))
+                const h4_t r0h = *reinterpret_cast<const h4_t *>(xr + (((2 * c) ^ sr) << 4)), r1h = *reinterpret_cast<const h4_t *>(xr + (((2 * c + 1) ^ sr) << 4));
+                uint2 r0, r1;
+                __builtin_memcpy(&r0, &r0h, 8);
+                __builtin_memcpy(&r1, &r1h, 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[2 * c], b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[2 * c + 1], b1, acc, 0, 0, 0);
+                // units (residual byte, e4m3(hi / 4)) of this lane's 16 channels
+                typedef short s2v_t __attribute__((ext_vector_type(2)));
+                v8i_t bu;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const h8_t bb = h ? b1 : b0;
+                    const uint2 rr = h ? r1 : r0;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {   // channels 4 q .. 4 q + 3 of the fragment
+                        s2v_t v = {0, 0};
+                        v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(v, h2_t{bb[4 * q], bb[4 * q + 1]}, SFD2_R1_VSCALE, false);
+                        v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(v, h2_t{bb[4 * q + 2], bb[4 * q + 3]}, SFD2_R1_VSCALE, true);
+                        unsigned int vb;
+                        __builtin_memcpy(&vb, &v, 4);
+                        // K order of this form's fragments (filters packed to match, api_weights.hip `wfr`): the lane's 16 residual bytes, then
+                        // its 16 value bytes -- no byte interleave
+                        bu[2 * h + q] = (int)(q ? rr.y : rr.x);
+                        bu[4 + 2 * h + q] = (int)vb;
+                    }
+                }
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ac[c], bu, acc, 0, 0, 0, sa, 0, 0x7f7f7f7f);
+            }
+            asm volatile("" : "+v"(acc));
+        } else
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const h8_t b = *reinterpret_cast<const h8_t *>(xp + (((kk * 2 + lhi) ^ sw) << 4));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], b, acc, 0, 0, 0);
             if (!IN_C) acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(sfd2_half8(ac[kk >> 1], kk & 1), b, acl, 0, 0, 0);
         }
-        if (IN_C) {
+        if (IN_C == 2) {
+        } else if (IN_C) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const v8i_t b = sfd2_cat8(*reinterpret_cast<const h8_t *>(xp + GPXC * 512 + (((c * 4 + lhi) ^ sw) << 4)),
@@ -574,15 +627,16 @@ void launch_conv1x1_c256_x3(hipStream_t st, const half_t *in, const half_t *in_l
 
 void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c, int npix, const half_t *w_frag,
                            const half_t *wc_frag, const float *scale, const float *shift, int relu, const half_t *res,
-                           const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte, unsigned int *range)
-// in_c == null: plain fp16 input, wc_frag = the fp16 filter residuals * 2^11; out_c == null: only the hi plane is written
+                           const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte, unsigned int *range, int in_r1)
+// in_c == null: plain fp16 input, wc_frag = the fp16 filter residuals * 2^11; out_c == null: only the hi plane is written;
+// in_r1: in_c holds residual bytes only (256 B per pixel)
 {
     static bool attr_done = false;
     static int slots = 256;
     const size_t lds = (size_t)NST * STAGE_C + 512 * sizeof(float);
     if (!attr_done) {
 #define C256C_ATTR(R_, I_, O_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_c256_c_kernel<R_, I_, O_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        C256C_ATTR(true, true, true) C256C_ATTR(false, true, true) C256C_ATTR(false, true, false) C256C_ATTR(true, false, true)
+        C256C_ATTR(true, 1, true) C256C_ATTR(false, 1, true) C256C_ATTR(false, 1, false) C256C_ATTR(true, 0, true) C256C_ATTR(false, 2, false)
 #undef C256C_ATTR
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
@@ -596,9 +650,10 @@ void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c,
     const int grid = (ngroups + gpb - 1) / gpb;
     const int sa = (sbyte & 255) * 0x01010101;
 #define C256C_GO(R_, I_, O_) hipLaunchKernelGGL((conv1x1_c256_c_kernel<R_, I_, O_>), dim3(grid), dim3(NT1), lds, st, in, in_c, npix, w_frag, wc_frag, scale, shift, relu, res, res_c, out, out_c, gpb, zero_page, sa, range)
-    if (in_c && out_c) { if (res) C256C_GO(true, true, true); else C256C_GO(false, true, true); }
-    else if (in_c && !res) C256C_GO(false, true, false);           // ResBlock.conv1 writing a plain t1
-    else if (!in_c && out_c && res) C256C_GO(true, false, true);   // ResBlock.conv3 reading a plain t2
+    if (in_r1) { if (in_c && !out_c && !res) C256C_GO(false, 2, false); else abort(); }   // ResBlock.conv1 over a residual-only input
+    else if (in_c && out_c) { if (res) C256C_GO(true, 1, true); else C256C_GO(false, 1, true); }
+    else if (in_c && !res) C256C_GO(false, 1, false);           // ResBlock.conv1 writing a plain t1
+    else if (!in_c && out_c && res) C256C_GO(true, 0, true);   // ResBlock.conv3 reading a plain t2
     else abort();                                                   // no other combination is dispatched
 #undef C256C_GO
 }

@@ -114,6 +114,7 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     constexpr bool F6 = (COMP & 16) != 0;
     constexpr bool B6 = (COMP & 32) != 0;                  // the INPUT's corr records are fp6 half-records (sfd2_internal.h; with F6: fp6 x fp6, 33.5 cycles per scaled MFMA)
     constexpr bool O6 = (COMP & 64) != 0;                  // the OUTPUT's corr records are written as fp6 half-records
+    constexpr bool OR1 = (COMP & 256) != 0;                // the OUTPUT's corr plane holds the residual byte only, CoutP bytes per pixel (option "trunk_r1": conv3b -> ResBlock 0)
     constexpr bool S2D = (COMP & 128) != 0;                // the OUTPUT is stored space-to-depth: [Ho / 2][Wo / 2][(y & 1) * 2 + (x & 1)][CoutP] (conv2b_s2d_kernel.hip; Ho, Wo even)
     static_assert(!B6 || F6, "fp6 pixel operands come with fp6 filter strings");
     constexpr int SSN = F6 ? 3 : 2;                        // arrays per tile parity in SSb: scale, shift (, the fp6 filters' scale bytes)
@@ -449,6 +450,9 @@ _Pragma("unroll") \
                             __builtin_memcpy(&pk[j], &hv, 8);
                             __builtin_memcpy(&ck[j], &lv, 8);
                         }
+                    } else if (OR1) {
+                        sfd2_epi4_r1<false>(acc[ct][pr][4 * q + 0], acc[ct][pr][4 * q + 1], acc[ct][pr][4 * q + 2], acc[ct][pr][4 * q + 3], sc, sh,
+                                            sc, relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j].x, mx, inb);
                     } else if (COMP & 2) {
                         sfd2_epi4<false>(acc[ct][pr][4 * q + 0], acc[ct][pr][4 * q + 1], acc[ct][pr][4 * q + 2], acc[ct][pr][4 * q + 3], sc, sh,
                                          sc, relu ? 0.0f : -SFD2_C_SAT, pk[j], ck[j], mx, inb);
@@ -466,7 +470,10 @@ _Pragma("unroll") \
                 const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                 const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
                 if (inb && (!(ABL & 4) || t0[0] == 0x12345678u)) *reinterpret_cast<uint4 *>(out + o16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
-                if (COMP & 2) {
+                if (OR1) {          // eight residual bytes: this lane's channels 8 (2 m + lhi) .. + 7
+                    const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
+                    if (inb) *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned char *>(out_c) + o16) = make_uint2(u0[0], u0[1]);
+                } else if (COMP & 2) {
                     const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
                     const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
                     if (inb) *reinterpret_cast<uint4 *>(out_c + o16) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
@@ -551,6 +558,7 @@ void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, i
         else if ((fmt6 & 1) && sfd2_env("SFD2_PPC_ABL"))    // timing ablation (wrong results): conv3b's instantiation without its staging copies
             launch_pp_t<1, 1, 1, 3 | 16 | 32>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
 #endif
+        else if ((fmt6 & 9) == 9) launch_pp_t<1, 1, 0, 3 | 16 | 32 | 256>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
         else if ((fmt6 & 5) == 5) launch_pp_t<1, 1, 0, 3 | 16 | 32 | 128>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
         else if (fmt6 & 1) launch_pp_t<1, 1, 0, 3 | 16 | 32>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
         else launch_pp_t<1, 1, 0, 3 | 16 | 64>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);

@@ -603,6 +603,11 @@ __global__ void nhwc_hc_to_nchw_f_kernel(const half_t *__restrict__ in, const ha
     if (i >= (size_t)npix * c) return;
     const int ch = (int)(i / npix), p = (int)(i % npix);
     const size_t o = (size_t)p * pitch + ch;
+    if (fmt6 == 2) {      // one residual byte per channel, c bytes per pixel (option "trunk_r1")
+        const unsigned char rb = reinterpret_cast<const unsigned char *>(in_c)[(size_t)p * pitch + ch];
+        out[i] = (float)in[o] + __builtin_amdgcn_cvt_f32_fp8((int)rb, 0) * (1.0f / (float)(1 << SFD2_C_XL_SHIFT));
+        return;
+    }
     if (fmt6) {
         const int cl = ch & 31, q = cl >> 3, h = (cl >> 2) & 1, r = cl & 3, j = 4 * q + r;
         const unsigned char *rec = reinterpret_cast<const unsigned char *>(in_c) + ((size_t)p * pitch + (ch & ~31)) * 2;

@@ -12,6 +12,7 @@
 // Persistent, one block per CU; the same operations in the same order as the two kernels it replaces: results are identical
 // bit for bit (tests/test_gpu_f16c.py).
 #include "sfd2_internal.h"
+#include <type_traits>
 
 #define R23_NT 512
 #define R23_TH 4
@@ -59,6 +60,11 @@ __device__ unsigned long long g_r23_wall[1024][2];
 // around chunk 3's copies, rows 2 / 3 during the epilogues of rows 0 / 1, into the registers those have just emptied), the next
 // tile's first filter fragments before the last row's stores; those four stores are all that is still in flight at the top of
 // the next tile.
+// RES_R1 / OUT_R1 (round 4, option "trunk_r1"): the block's input / output carries ONE correction byte per channel -- the residual
+// e4m3((x - hi) * 2^9), 256 bytes per pixel at the start of the corr plane -- instead of the (residual, value) unit: the tensors between the
+// ResBlocks are read by conv1x1_c256_c<.., 2, ..> (which takes the value term from the hi plane) and by this kernel's skip path (which never
+// used the value byte), and these kernels are bound by bytes: 3 instead of 4 per channel.
+template <bool RES_R1, bool OUT_R1>
 __global__ __launch_bounds__(R23_NT, 2)
 void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                    const half_t *__restrict__ w2h /*[16 pairs][5 steps][64 lanes][8]*/, const half_t *__restrict__ w2l /*residuals * 2^11, same layout*/,
@@ -172,7 +178,9 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
     int ring = 0;                                           // buffer of the chunk at hand; the copies go to (ring + 2) % 3
     bool drain = true;                                      // top of the first tile / behind a tile with rows below the image: full wait
 
-    uint4 rqa[2], rca[2], rqb[2], rcb[2];   // residuals of two rows in flight (even / odd rows)
+    using rc_t = typename std::conditional<RES_R1, uint2, uint4>::type;
+    uint4 rqa[2], rqb[2];                   // residuals of two rows in flight (even / odd rows)
+    rc_t rca[2], rcb[2];
 #define R23_RES(r4_, rq_, rc_)                                                                                      \
         {                                                                                                 \
             /* (rows / columns past the image repeat its last row / column: same values, same addresses, no predicate) */ \
@@ -180,7 +188,8 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
             const size_t ob_ = (size_t)(oy_ * W + ox_) * 256 + wave * 32;                                 \
             _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                               \
                 rq_[m] = *reinterpret_cast<const uint4 *>(res + ob_ + 8 * (2 * m + lhi));                  \
-                rc_[m] = *reinterpret_cast<const uint4 *>(res_c + ob_ + 8 * (2 * m + lhi));                \
+                if constexpr (RES_R1) rc_[m] = *reinterpret_cast<const rc_t *>(reinterpret_cast<const unsigned char *>(res_c) + ob_ + 8 * (2 * m + lhi)); \
+                else rc_[m] = *reinterpret_cast<const rc_t *>(res_c + ob_ + 8 * (2 * m + lhi));            \
             }                                                                                             \
         }
     for (;;) {
@@ -283,7 +292,7 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
         R23_CYC(5)
         // one row of phase C; LAST: behind it comes the next tile (its first filter fragments are requested here, on EVERY path, so
         // that the registers are free through the rows before), otherwise the next row's residual
-        auto row = [&](const int r4u, uint4 (&rq)[2], uint4 (&rc)[2]) __attribute__((always_inline)) {
+        auto row = [&](const int r4u, uint4 (&rq)[2], rc_t (&rc)[2]) __attribute__((always_inline)) {
             const bool last = r4u == 3;
             const int r4 = oy0 + r4u < H ? r4u : H - 1 - oy0;     // rows past the image repeat its last row (same values to the same place)
             int ln = lane;
@@ -315,9 +324,14 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                 const auto s0 = __builtin_amdgcn_permlane32_swap(rq[m].x, rq[m].z, false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(rq[m].y, rq[m].w, false, false);
                 rp[m][0] = make_uint2(s0[0], s1[0]); rp[m][1] = make_uint2(s0[1], s1[1]);
-                const auto c0 = __builtin_amdgcn_permlane32_swap(rc[m].x, rc[m].z, false, false);
-                const auto c1 = __builtin_amdgcn_permlane32_swap(rc[m].y, rc[m].w, false, false);
-                rcp[m][0] = make_uint2(c0[0], c1[0]); rcp[m][1] = make_uint2(c0[1], c1[1]);
+                if constexpr (RES_R1) {      // 8 residual bytes per lane: after the swap, dword j = the bytes of this lane's channels 8 (2 m + j) + 4 lhi ..
+                    const auto c0 = __builtin_amdgcn_permlane32_swap(rc[m].x, rc[m].y, false, false);
+                    rcp[m][0] = make_uint2(c0[0], 0u); rcp[m][1] = make_uint2(c0[1], 0u);
+                } else {
+                    const auto c0 = __builtin_amdgcn_permlane32_swap(rc[m].x, rc[m].z, false, false);
+                    const auto c1 = __builtin_amdgcn_permlane32_swap(rc[m].y, rc[m].w, false, false);
+                    rcp[m][0] = make_uint2(c0[0], c1[0]); rcp[m][1] = make_uint2(c0[1], c1[1]);
+                }
             }
             if (r4u < 2) { R23_RES(r4u + 2, rq, rc) }       // two rows ahead, into the registers this row's residual has just left
             else if (last) {
@@ -338,17 +352,28 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                     const float4 sh = sfd2_lds_f4(SS + 768 + cl + 8 * q);
                     h4_t rr;
                     __builtin_memcpy(&rr, &rp[m][j], 8);
-                    const float4 ad = make_float4((float)rr[0] + sfd2_corr_lo(rcp[m][j].x, 0), (float)rr[1] + sfd2_corr_lo(rcp[m][j].x, 1),
-                                                  (float)rr[2] + sfd2_corr_lo(rcp[m][j].y, 0), (float)rr[3] + sfd2_corr_lo(rcp[m][j].y, 1));
-                    sfd2_epi4<true, false>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], sc, sh, ad, 0.0f, pk[j], ck[j], mx_none);
+                    constexpr float ks = 1.0f / (float)(1 << SFD2_C_XL_SHIFT);
+                    const float4 ad = RES_R1 ? make_float4((float)rr[0] + __builtin_amdgcn_cvt_f32_fp8((int)rcp[m][j].x, 0) * ks,
+                                                           (float)rr[1] + __builtin_amdgcn_cvt_f32_fp8((int)rcp[m][j].x, 1) * ks,
+                                                           (float)rr[2] + __builtin_amdgcn_cvt_f32_fp8((int)rcp[m][j].x, 2) * ks,
+                                                           (float)rr[3] + __builtin_amdgcn_cvt_f32_fp8((int)rcp[m][j].x, 3) * ks)
+                                             : make_float4((float)rr[0] + sfd2_corr_lo(rcp[m][j].x, 0), (float)rr[1] + sfd2_corr_lo(rcp[m][j].x, 1),
+                                                           (float)rr[2] + sfd2_corr_lo(rcp[m][j].y, 0), (float)rr[3] + sfd2_corr_lo(rcp[m][j].y, 1));
+                    if constexpr (OUT_R1) sfd2_epi4_r1<true, false>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], sc, sh, ad, 0.0f, pk[j], ck[j].x, mx_none);
+                    else sfd2_epi4<true, false>(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], sc, sh, ad, 0.0f, pk[j], ck[j], mx_none);
                     sfd2_track_h4(pk[j], mx_out);
                 }
                 const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                 const auto t1v = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
-                const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
-                const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
                 *reinterpret_cast<uint4 *>(out + obase + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1v[0], t0[1], t1v[1]);
-                *reinterpret_cast<uint4 *>(out_c + obase + 8 * (2 * m + lhi)) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
+                if constexpr (OUT_R1) {      // (ck[j].x = the four residual bytes of the lane's channel quad j)
+                    const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned char *>(out_c) + obase + 8 * (2 * m + lhi)) = make_uint2(u0[0], u0[1]);
+                } else {
+                    const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
+                    const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
+                    *reinterpret_cast<uint4 *>(out_c + obase + 8 * (2 * m + lhi)) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
+                }
             }
             { const unsigned int wb = sfd2_wave_max_bits(sfd2_h2_max(mx_out)); smax_out = wb > smax_out ? wb : smax_out; }
         };
@@ -376,7 +401,7 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
 void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t *w2h, const half_t *w2l, const float *sc2,
                    const float *sh2, const half_t *w3h, const half_t *w3l, const float *sc3, const float *sh3,
                    const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page,
-                   unsigned int *range_t2, unsigned int *range_out)
+                   unsigned int *range_t2, unsigned int *range_out, int r1 /* bit 0: res_c is residual-only, bit 1: out_c is written residual-only */)
 {
     constexpr size_t lds = 0;                               // (static LDS: 150 KB)
     static bool attr_done = false;
@@ -391,8 +416,11 @@ void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t 
     const int n_tiles = tiles_x * tiles_y;
     if (n_tiles == 0) return;
     const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
-    hipLaunchKernelGGL(rb23_c_kernel, dim3(grid), dim3(R23_NT), lds, st, t1, H, W, w2h, w2l, sc2, sh2, w3h, w3l, sc3, sh3, res, res_c,
-                       out, out_c, tiles_x, n_tiles, range_t2, range_out);
+#define R23_GO(a_, b_) hipLaunchKernelGGL((rb23_c_kernel<a_, b_>), dim3(grid), dim3(R23_NT), lds, st, t1, H, W, w2h, w2l, sc2, sh2, w3h, w3l, sc3, sh3, res, res_c, \
+                                          out, out_c, tiles_x, n_tiles, range_t2, range_out)
+    // (units in, residual bytes out is not instantiated: it spills 261 registers; the caller converts conv3b's output as well)
+    if ((r1 & 3) == 3) R23_GO(true, true); else if (r1 & 1) R23_GO(true, false); else if (r1 & 2) abort(); else R23_GO(false, false);
+#undef R23_GO
     (void)zero_page;
 #ifdef SFD2_RB23_TRACE
     {

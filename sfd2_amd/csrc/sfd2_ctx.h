@@ -81,6 +81,7 @@ struct ConvW {                 // one folded + packed layer
     DevBuf wc;                 // SFD2_PREC_F16C: [2 * cin / 32][taps][cout_pad][32] units -- the fp16 filters in 32-wide chunks, then the
                                // corr units (fp8 of w * 2^b0, fp8 of (w - fp16(w)) * 2^(b0 + 11)); conv1a / grouped conv: hi then lo fragments
     int sbyte = 127;           // E8M0 scale byte of the layer's corr MFMAs: 127 - 9 - b0
+    DevBuf wfr;                // the 1x1 layers' corr units in the order of the residual-only input form (option "trunk_r1")
     DevBuf wc6;                // conv3x3_pp layers: wc with the corr filter rows as fp6 (e2m3) strings, and ...
     DevBuf sa6;                // ... [shift[cout_pad] | per-output-channel E8M0 scale bytes, replicated into the four bytes of an int, [cout_pad]]
     size_t w_floats = 0;       // floats in w (fp32 layers)
@@ -98,7 +99,7 @@ struct ConvW {                 // one folded + packed layer
 enum { AE_CONV1A, AE_CONV1B, AE_CONV2A, AE_CONV2B, AE_CONV3A, AE_TRUNK /* conv3b's and every ResBlock's output: one skip path */,
        AE_T1_0, AE_T1_1, AE_T1_2, AE_T2_0, AE_T2_1, AE_T2_2, AE_PA0, AE_DA0, AE_COUNT };
 
-struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; const void *pc = nullptr; /* corr plane (f16c) */ int exp2 = 0; /* stored = value * 2^exp2 (activation exponents of the fp16 family) */ bool absent = false; /* stays on chip on the path taken */ bool fmt6 = false; /* pc holds fp6 half-records (option "fp6_acts") */ };
+struct ActInfo { const void *p; int f32; int planar; int c, pitch, h, w; const void *pc = nullptr; /* corr plane (f16c) */ int exp2 = 0; /* stored = value * 2^exp2 (activation exponents of the fp16 family) */ bool absent = false; /* stays on chip on the path taken */ bool fmt6 = false; /* pc holds fp6 half-records (option "fp6_acts") */ bool r1 = false; /* pc holds one residual byte per channel, c bytes per pixel (option "trunk_r1") */ };
 
 struct sfd2_ctx {
     int device = 0;
@@ -147,6 +148,8 @@ struct sfd2_ctx {
     int opt_fp6_acts = 1;              // sfd2_set_option "fp6_acts": the corr records of the three tensors only conv3x3_pp<comp> reads (conv1b's, conv2b's,
                                        // conv3a's output) as block-scaled fp6 half-records, their consumers' corr MFMAs fp6 x fp6 (33.5 cycles instead of 66)
     int net_error = 0;                 // set by a layer helper of run_network that cannot return an error itself; run_network returns -1 and clears it
+    int opt_trunk_r1 = 1;              // sfd2_set_option "trunk_r1": conv3b's output and the outputs of ResBlocks 0 and 1 carry ONE correction byte per channel (the
+                                       // residual) instead of the (residual, value) unit: 3 bytes per channel through the HBM-bound ResBlock kernels instead of 4
     int opt_s2d = 1;                   // sfd2_set_option "s2d": on the throughput path conv2a stores its output space-to-depth and conv2b runs as a stride-1 layer
                                        // over it (conv2b_s2d_kernel.hip) instead of conv3x3_rf<2,comp>
     int opt_fp6_filters = 0;           // sfd2_set_option "fp6_filters": conv3x3_pp<comp> takes its corr filters as block-scaled fp6 (fp8 x fp6 MFMA).

@@ -240,6 +240,31 @@ __device__ __forceinline__ void sfd2_epi4(float a0, float a1, float a2, float a3
     cv.x = sfd2_corr2v(v01, h01);
     cv.y = sfd2_corr2v(v23, h23);
 }
+// ... the same with ONE correction byte per channel (the residual; option "trunk_r1": rb23_c_kernel.hip): rv = the four residual bytes
+template <bool ADD, bool TRACK = true>
+__device__ __forceinline__ void sfd2_epi4_r1(float a0, float a1, float a2, float a3, float4 sc, float4 sh, float4 add, float lo,
+                                             uint2 &hv, unsigned int &rv, float &mx, bool counted = true)
+{
+    f32x2_t v01 = f32x2_t{a0, a1} * f32x2_t{sc.x, sc.y} + f32x2_t{sh.x, sh.y};
+    f32x2_t v23 = f32x2_t{a2, a3} * f32x2_t{sc.z, sc.w} + f32x2_t{sh.z, sh.w};
+    if (ADD) { v01 += f32x2_t{add.x, add.y}; v23 += f32x2_t{add.z, add.w}; }
+#ifndef SFD2_NO_RANGE
+    if (TRACK) {
+        const float m = sfd2_max3(sfd2_max3(mx, v01[0], v01[1]), v23[0], v23[1]);
+        mx = counted ? m : mx;
+    }
+#endif
+    v01[0] = __builtin_amdgcn_fmed3f(v01[0], lo, SFD2_C_SAT); v01[1] = __builtin_amdgcn_fmed3f(v01[1], lo, SFD2_C_SAT);
+    v23[0] = __builtin_amdgcn_fmed3f(v23[0], lo, SFD2_C_SAT); v23[1] = __builtin_amdgcn_fmed3f(v23[1], lo, SFD2_C_SAT);
+    const h2_t h01 = {(half_t)v01[0], (half_t)v01[1]}, h23 = {(half_t)v23[0], (half_t)v23[1]};
+    __builtin_memcpy(&hv.x, &h01, 4);
+    __builtin_memcpy(&hv.y, &h23, 4);
+    const f32x2_t l01 = (v01 - f32x2_t{(float)h01[0], (float)h01[1]}) * (float)(1 << SFD2_C_XL_SHIFT);
+    const f32x2_t l23 = (v23 - f32x2_t{(float)h23[0], (float)h23[1]}) * (float)(1 << SFD2_C_XL_SHIFT);
+    int d = __builtin_amdgcn_cvt_pk_fp8_f32(l01[0], l01[1], 0, false);
+    d = __builtin_amdgcn_cvt_pk_fp8_f32(l23[0], l23[1], d, true);
+    rv = (unsigned int)d;
+}
 // ---- corr records in fp6 (round 4; option "fp6_acts": the tensors whose only readers are conv3x3_pp layers).  The scaled MFMA takes 66
 // cycles with fp8 operands on either side and 33.5 with e2m3 on both (profiles/r04_mfma_probe.txt), so the correction operands of those
 // layers are block-scaled e2m3: per pixel and lane half a HALF-RECORD of 32 bytes = 32 six-bit codes (24 B) + one E8M0 scale byte (replicated
@@ -355,7 +380,7 @@ void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, i
                          const float *scale, const float *shift, int CoutP, int relu, half_t *out, half_t *out_c,
                          int Ho, int Wo, const half_t *zero_page, int sbyte, const float *shift_sa6 = nullptr /* non-null: wpk's corr rows are fp6; [shift | scale bytes] */,
                          unsigned int *range = nullptr /* the output tensor's range-status slot (SFD2_RANGE_SUB words), here and below */,
-                         int fmt6 = 0 /* bit 0: in_c holds fp6 half-records (then wpk / shift_sa6 are the fp6 x fp6 arrays), bit 1: out_c is written as fp6 half-records, bit 2 (with bit 0, without bit 1): the output is stored space-to-depth for conv2b_s2d_kernel */);
+                         int fmt6 = 0 /* bit 0: in_c holds fp6 half-records (then wpk / shift_sa6 are the fp6 x fp6 arrays), bit 1: out_c is written as fp6 half-records, bit 2 (with bit 0, without bit 1): the output is stored space-to-depth for conv2b_s2d_kernel, bit 3 (with bit 0, without bits 1 / 2): out_c holds the residual byte only (CoutP bytes per pixel) */);
 bool conv3x3_rf_c_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo);
 // conv2b_s2d_kernel.hip: conv2b over conv2a's output stored space-to-depth (launch_conv3x3_pp_c with bit 2 of fmt6 writes that layout)
 bool conv2b_s2d_serves(int H2, int W2, int Cin, int CoutP);
@@ -375,7 +400,8 @@ void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int nor
                          int fmt6 = 0 /* bit 1: out_c as fp6 half-records */);
 void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c, int npix, const half_t *w_frag,
                            const half_t *wc_frag, const float *scale, const float *shift, int relu, const half_t *res,
-                           const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte, unsigned int *range = nullptr);
+                           const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte, unsigned int *range = nullptr,
+                           int in_r1 = 0 /* in_c = residual bytes only (256 B per pixel): option "trunk_r1" */);
 // sparse_da3_kernel.hip: convDa.3 on the four bilinear corner pixels of every selected key point only -> out [n_max][4][256] fp16
 void launch_sparse_da3(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, int CoutP,
                        const float *scale, const float *shift, int relu, const float *kpts, const unsigned int *count, int n_max,
@@ -387,7 +413,8 @@ void launch_sparse_da3_x3(hipStream_t st, const half_t *fmap_hi, const half_t *f
 void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t *w2h, const half_t *w2l, const float *sc2,
                    const float *sh2, const half_t *w3h, const half_t *w3l, const float *sc3, const float *sh3,
                    const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page,
-                   unsigned int *range_t2 = nullptr, unsigned int *range_out = nullptr);
+                   unsigned int *range_t2 = nullptr, unsigned int *range_out = nullptr,
+                   int r1 = 0 /* residual-only corr bytes (256 B per pixel): bit 0 = res_c, bit 1 = out_c */);
 // conv1x1_kernels.hip: SFD2_PREC_F16X3 streaming 1x1 (256 -> 256): planes in, fp32 (+ planes) out, fp32 residual
 void launch_conv1x1_c256_x3(hipStream_t st, const half_t *in, const half_t *in_lo, int npix, const half_t *w, const half_t *wl,
                             const float *scale, const float *shift, int relu, const void *res, const half_t *res_lo, float *out, half_t *out_hi,

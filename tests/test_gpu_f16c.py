@@ -479,6 +479,36 @@ def test_f16c_conv2b_space_to_depth_vs_oracle_and_strided_kernel(synth_sd, h, w,
     _record(f"f16c s2d on vs off {w}x{h}: {len(common)} common key points, descriptors within {d:.2e}")
 
 
+@pytest.mark.parametrize("h,w,seed", [(64, 96, 11), (100, 130, 12), (200, 264, 14)])
+def test_f16c_trunk_residual_only_tensors(synth_sd, h, w, seed):
+    """Option trunk_r1 (default on): conv3b's output and the ResBlocks' outputs carry one correction byte per channel (the residual) instead
+    of the (residual, value) unit; conv1x1_c256_c rebuilds the value byte from the hi plane.  Every tensor of the trunk -- the three-byte
+    ones decoded by sfd2_debug_activation -- within the mode's tolerance of the oracle.  Against the four-byte form: conv3b's output identical
+    (same hi plane, same residual bytes); behind it the rebuilt value byte is e4m3(hi / 4) where the stored one was e4m3(y / 4), which moves a
+    sum by ~1e-6 and flips a few fp16 roundings of the plain tensor t1 -- one fp16 ulp at the top binade is 4.9e-4 of max."""
+    from sfd2_amd.model import ResSegNetV2
+    x = orc.norm_rgb(synth.make_image(h, w, seed))
+    taps = {}
+    orc.det(synth_sd, x, taps)
+    names = ["bn3b", "conv4.0.bn1", "conv4.0", "conv4.1", "conv4.2"]      # (the oracle taps the first block's inner tensors)
+    outs = []
+    for r1 in (1, 0):
+        m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
+        m.load_state_dict(synth_sd)
+        m.cuda(0)
+        m.context.set_option("trunk_r1", r1)
+        m.det(x[None])
+        got = {n: m.context.debug_activation(n) for n in names}
+        for n in names:
+            err = np.abs(got[n] - taps[n]).max() / np.abs(taps[n]).max()
+            assert err <= ACT_TOL, (r1, n, err)
+        outs.append(got)
+    worst = max(np.abs(outs[0][n] - outs[1][n]).max() / np.abs(outs[1][n]).max() for n in names)
+    assert np.array_equal(outs[0]["bn3b"], outs[1]["bn3b"])
+    assert worst <= 6e-4, worst
+    _record(f"f16c trunk_r1 on vs off {h}x{w}: trunk activations within {worst:.2e} of max")
+
+
 @pytest.fixture(scope="module", params=[0, 1])
 def model_c_inner(request, synth_sd):
     """f16c with option rb_inner off its default (2: the tensors inside the ResBlocks, t1 and t2, stored as plain fp16):
@@ -538,6 +568,7 @@ def test_f16c_fused_conv2_conv3_bit_identical(synth_sd, h, w, topk):
         m.load_state_dict(synth_sd)
         m.cuda(0)
         m.context.set_option("fuse_rb23", fuse)
+        m.context.set_option("trunk_r1", 0)      # (the same tensor format on both sides: the residual-only trunk tensors need the fused kernel)
         o = extract_resnet_return(m, img[None], conf_th=0.001, topK=topk, scales=[1.0])
         m.det(x[None])
         o["acts"] = [m.context.debug_activation(f"conv4.{b}") for b in range(3)]

@@ -40,7 +40,7 @@ ROWS = [
     ({"rb_inner": 0}, ("f16c",), False),
     ({"rb_inner": 1}, ("f16c",), False),
     ({"rb_inner": 1, "fuse_rb23": 0}, ("f16c",), False),
-    ({"fuse_rb23": 0}, ("f16c",), True),
+    ({"fuse_rb23": 0}, ("f16c",), False),     # (bit-identical to the fused kernel at the same tensor format: test_f16c_fused_conv2_conv3_bit_identical)
     ({"comp_heads": 1}, ("f16c",), False),
     ({"comp_det": 1}, ("f16c",), False),
     ({"comp_heads": 1, "fp6_filters": 1}, ("f16c",), False),
@@ -56,6 +56,10 @@ ROWS = [
     ({"fp6_acts": 1, "no_rf_c": 1}, ("f16c",), False),
     ({"fp6_acts": 1, "generic_c": 1}, ("f16c",), False),
     ({"fp6_acts": 1, "fp6_filters": 1, "comp_heads": 1}, ("f16c",), False),
+    ({"trunk_r1": 0}, ("f16c",), False),
+    ({"trunk_r1": 1, "comp_heads": 1}, ("f16c",), False),     # (the last block's output keeps its units for the compensated heads)
+    ({"trunk_r1": 1, "fp6_acts": 0}, ("f16c",), False),       # (falls back: conv3b's residual-only store exists for its fp6-input form)
+    ({"trunk_r1": 1, "fuse_rb23": 0}, ("f16c",), False),
     ({"s2d": 0}, ("f16c",), False),
     ({"s2d": 1, "fp6_acts": 0}, ("f16c",), False),       # (the s2d store exists for the fp6-input form of conv2a only: falls back)
     ({"s2d": 1, "no_rf_c": 1}, ("f16c",), False),

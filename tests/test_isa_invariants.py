@@ -148,7 +148,7 @@ def test_resblock_row_loop_drains(asm):
 
 def test_conv1x1_ring_not_drained_in_epilogue(asm):
     ks = {n: k for n, k in asm("conv1x1_kernels.hip").items() if "conv1x1_c256_kernel" in n or "conv1x1_c256_c_kernel" in n}
-    assert len(ks) == 6       # fp16: +-residual; compensated: +-residual, plain output (conv1), plain input + residual (conv3)
+    assert len(ks) == 7       # fp16: +-residual; compensated: +-residual, plain output (conv1; unit or residual-only input), plain input + residual (conv3)
     for name, k in ks.items():
         span = _mfma_span(k["body"])
         # the residual variants wait for their residual loads, the youngest operations in flight
