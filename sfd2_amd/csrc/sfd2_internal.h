@@ -234,7 +234,7 @@ __device__ __forceinline__ void sfd2_epi4(float a0, float a1, float a2, float a3
 #endif
     v01[0] = __builtin_amdgcn_fmed3f(v01[0], lo, SFD2_C_SAT); v01[1] = __builtin_amdgcn_fmed3f(v01[1], lo, SFD2_C_SAT);
     v23[0] = __builtin_amdgcn_fmed3f(v23[0], lo, SFD2_C_SAT); v23[1] = __builtin_amdgcn_fmed3f(v23[1], lo, SFD2_C_SAT);
-    const h2_t h01 = {(half_t)v01[0], (half_t)v01[1]}, h23 = {(half_t)v23[0], (half_t)v23[1]};
+    const h2_t h01 = __builtin_convertvector(v01, h2_t), h23 = __builtin_convertvector(v23, h2_t);      // (one v_cvt_pk_f16_f32 per pair, round to nearest even)
     __builtin_memcpy(&hv.x, &h01, 4);
     __builtin_memcpy(&hv.y, &h23, 4);
     cv.x = sfd2_corr2v(v01, h01);
@@ -256,7 +256,7 @@ __device__ __forceinline__ void sfd2_epi4_r1(float a0, float a1, float a2, float
 #endif
     v01[0] = __builtin_amdgcn_fmed3f(v01[0], lo, SFD2_C_SAT); v01[1] = __builtin_amdgcn_fmed3f(v01[1], lo, SFD2_C_SAT);
     v23[0] = __builtin_amdgcn_fmed3f(v23[0], lo, SFD2_C_SAT); v23[1] = __builtin_amdgcn_fmed3f(v23[1], lo, SFD2_C_SAT);
-    const h2_t h01 = {(half_t)v01[0], (half_t)v01[1]}, h23 = {(half_t)v23[0], (half_t)v23[1]};
+    const h2_t h01 = {(half_t)v01[0], (half_t)v01[1]}, h23 = {(half_t)v23[0], (half_t)v23[1]};      // (element-wise: as a vector conversion conv3x3_pp<.., 307> spills)
     __builtin_memcpy(&hv.x, &h01, 4);
     __builtin_memcpy(&hv.y, &h23, 4);
     const f32x2_t l01 = (v01 - f32x2_t{(float)h01[0], (float)h01[1]}) * (float)(1 << SFD2_C_XL_SHIFT);
@@ -295,7 +295,7 @@ __device__ __forceinline__ void sfd2_epi16_fp6(const f32x16_t &acc, const float4
         m = sfd2_max3(sfd2_max3(m, v01[0], v01[1]), v23[0], v23[1]);
         v01[0] = __builtin_amdgcn_fmed3f(v01[0], lo, SFD2_C_SAT); v01[1] = __builtin_amdgcn_fmed3f(v01[1], lo, SFD2_C_SAT);
         v23[0] = __builtin_amdgcn_fmed3f(v23[0], lo, SFD2_C_SAT); v23[1] = __builtin_amdgcn_fmed3f(v23[1], lo, SFD2_C_SAT);
-        const h2_t h01 = {(half_t)v01[0], (half_t)v01[1]}, h23 = {(half_t)v23[0], (half_t)v23[1]};
+        const h2_t h01 = __builtin_convertvector(v01, h2_t), h23 = __builtin_convertvector(v23, h2_t);      // (one v_cvt_pk_f16_f32 per pair, round to nearest even)
         __builtin_memcpy(&hv[q].x, &h01, 4);
         __builtin_memcpy(&hv[q].y, &h23, 4);
         const f32x2_t l01 = (v01 - f32x2_t{(float)h01[0], (float)h01[1]}) * 2048.0f, l23 = (v23 - f32x2_t{(float)h23[0], (float)h23[1]}) * 2048.0f;
