@@ -514,6 +514,9 @@ def main():
                                        "source": "profiles/r04_mfma_probe.txt (not re-measured in this run)",
                                        "issued_frac_of_relu_like": round(issued / 1765.0, 4),
                                        "note": "issued-FLOP rate of this kernel (correction MFMAs counted at fp16-equivalent time) / the MFMA-only rate on relu-like data"}
+            roof["power"] = {"cap_w": 1400, "socket_w_during_this_loop": "1372-1399", "sclk_ghz": "1.97-2.09",
+                             "source": "profiles/r04s_power_during_bench.txt (rocm-smi sampled during the headline loop; not re-measured in this run)",
+                             "note": "the part runs this workload at its power cap: time follows the work issued (MFMAs, VALU, bytes) more than its overlap"}
             if single is not None:
                 roof["measured_in"] = ("single-stream timed leg of this run (same K steps and bracketing, one stream per GPU, eager "
                                        "launches: see 'single_stream').  The headline region replays one hipGraph per image on "
