@@ -590,7 +590,7 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         // Option "trunk_r1": the three tensors the ResBlocks read as block input (conv3b's output, the outputs of blocks 0 and 1) with the residual
         // byte only -- their readers are conv1x1_c256_c<.., 2, ..> (value bytes rebuilt from the hi plane) and rb23_c_kernel's skip path
         const bool tr1 = c->opt_trunk_r1 && a6 && !c->opt_generic_c && c->opt_comp_rb && c->opt_rb_inner >= 2 && c->opt_fuse_rb23 &&
-                         c->rb1[0].wfl.p && c->rb3[0].wfl.p && c->rb2[0].wlk.p && c->rb1[0].wfr.p;
+                         c->rb1[0].wfl.p && c->rb3[0].wfl.p && c->rb2[0].wlk.p && c->rb1[0].wfr.p && c->rb3[0].wf8l.p;
         {
             static const char *tr[3] = {"bn3b", "conv4.0", "conv4.1"};
             for (int i = 0; i < 3; ++i) {
@@ -632,7 +632,7 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                     launch_rb23_c(st, t1.as<half_t>(), H4, W4, L2.w.as<half_t>(), L2.wlk.as<half_t>(), L2.scale.as<float>(), L2.shift.as<float>(),
                                   L3.wfh.as<half_t>(), L3.wfl.as<half_t>(), L3.scale.as<float>(), L3.shift.as<float>(), x->as<half_t>(),
                                   corr_of(*x, PP, 256), ob.as<half_t>(), corr_of(ob, PP, 256), c->zero_page.as<half_t>(),
-                                  range_slot(c, SFD2_RS_T2_0 + b), range_slot(c, SFD2_RS_OUT_0 + b), r1f);
+                                  range_slot(c, SFD2_RS_T2_0 + b), range_slot(c, SFD2_RS_OUT_0 + b), r1f, L3.wf8l.as<half_t>(), L3.sbyte);
                     x = &ob;
                     continue;
                 }

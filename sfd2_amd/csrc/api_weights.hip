@@ -272,6 +272,19 @@ static int pack_igemm(sfd2_ctx *c, const TMap &m, ConvW &L, const std::string &c
             if (upload(L.wfl, fl.data(), fl.size() * 2, c->stream)) return -1;
             if (upload(L.wfc, fc.data(), fc.size() * 2, c->stream)) return -1;
             if (upload(L.wfr, fr.data(), fr.size(), c->stream)) return -1;
+            {   // `wf8l`: the filter residuals as e4m3((w - fp16(w)) * 2^(b0 + 11)) in rb23_c_kernel's K order for its scaled MFMAs over t2's value
+                // bytes: [8 waves][4 j][64 lanes][32 B], byte n of a lane = channel 16 (4 j + n / 8) + 8 (lane / 32) + n % 8 of row wave * 32 + lane % 32
+                std::vector<unsigned char> f8((size_t)8 * 4 * 64 * 32);
+                for (int wv = 0; wv < 8; ++wv)
+                    for (int j = 0; j < 4; ++j)
+                        for (int l = 0; l < 64; ++l)
+                            for (int n = 0; n < 32; ++n) {
+                                const int row = wv * 32 + (l & 31), col = 16 * (4 * j + (n >> 3)) + 8 * (l >> 5) + (n & 7);
+                                const float v = w->d[(size_t)row * 256 + col];
+                                f8[(((size_t)wv * 4 + j) * 64 + l) * 32 + n] = f32_to_e4m3(std::ldexp(v - (float)(half_t)v, b0 + 11));
+                            }
+                if (upload(L.wf8l, f8.data(), f8.size(), c->stream)) return -1;
+            }
         }
     }
     return 0;

@@ -15,6 +15,9 @@
 #include <type_traits>
 
 #define R23_NT 512
+#ifndef R23_RES_AT
+#define R23_RES_AT 3        // the chunk at whose top an L8 instantiation requests row 0's residual
+#endif
 #define R23_TH 4
 #define R23_TW 32
 #define R23_PH 6
@@ -73,8 +76,13 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                    const float *__restrict__ sc3, const float *__restrict__ sh3,
                    const half_t *__restrict__ res, const half_t *__restrict__ res_c,
                    half_t *__restrict__ out, half_t *__restrict__ out_c, int tiles_x, int n_tiles,
-                   unsigned int *__restrict__ range_t2, unsigned int *__restrict__ range_out /* range-status slots of t2 (LDS-resident) and of the block's output, or null */)
+                   unsigned int *__restrict__ range_t2, unsigned int *__restrict__ range_out /* range-status slots of t2 (LDS-resident) and of the block's output, or null */,
+                   int sa3 /* RES_R1: conv3's corr scale byte x 0x01010101; then w3l = its filter residuals as e4m3, [8 waves][4][64 lanes][32 B] */)
 {
+    // RES_R1 instantiations (the default path): conv3's term x * lo_w runs on the scaled MFMA -- t2's value bytes e4m3(t2 / 4), rebuilt from the
+    // lane's fp16 fragments of four K steps (sixteen v_cvt_scalef32_pk_fp8_f16), against the filter residuals as e4m3 -- instead of a second
+    // fp16 pass: 4 x 66 cycles instead of 16 x 32 per row, 32 resident registers instead of 64 and no second accumulator.
+    constexpr bool L8 = RES_R1;
     unsigned int smax_t2 = 0, smax_out = 0;                 // wave-uniform across the tiles
     // Three separate LDS objects, not slices of one array: the compiler orders every LDS store behind all pending direct-to-LDS
     // copies it cannot prove disjoint from it (`s_waitcnt vmcnt(0)` in front of the first T2 store of every chunk: the copies
@@ -90,8 +98,20 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
 
     // conv3's filters: resident
     h8_t ah[16];
-    v8i_t al[8];
-    {
+    v8i_t al[L8 ? 4 : 8];
+    if constexpr (L8) {
+        const size_t fo = ((size_t)wave * 8 * 64 + lane) * 16;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            ah[2 * c] = *reinterpret_cast<const h8_t *>(w3h + fo + (size_t)c * 64 * 16);
+            ah[2 * c + 1] = *reinterpret_cast<const h8_t *>(w3h + fo + (size_t)c * 64 * 16 + 8);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const half_t *p8 = w3l + ((size_t)(wave * 4 + c) * 64 + lane) * 16;
+            al[c] = sfd2_cat8(*reinterpret_cast<const h8_t *>(p8), *reinterpret_cast<const h8_t *>(p8 + 8));
+        }
+    } else {
         const size_t fo = ((size_t)wave * 8 * 64 + lane) * 16;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -168,7 +188,7 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
     // (conv3's filters are waited for HERE: a load still pending at the head of the tile loop makes the compiler drain the
     //  memory queue in front of the chunk loop of every tile)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(ah[2 * c]), "+v"(ah[2 * c + 1]), "+v"(al[c]));
+    for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(ah[2 * c]), "+v"(ah[2 * c + 1]), "+v"(al[L8 ? c & 3 : c]));
     R23_SETUP(oy0, ox0)
     R23_COPIES(0, 0)
     R23_COPIES(1, 1)
@@ -218,6 +238,17 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
             R23_WTIE();
             R23_CYC(chunk)
             drain = false;
+            if (L8 && chunk == R23_RES_AT) {
+                // (L8 instantiations have the registers for it) row 0's residual is requested HERE, ahead of phase C: requested behind chunk 3 its
+                // HBM round trip sat in front of row 0 (profiles/r04s_rb23_trace.txt, column "residual + copies + barrier": 4-6 k of a 43 k-cycle
+                // tile).  Nothing else is issued between here and the chunk's counted wait that this would be counted into: the wait at the top of
+                // the next chunk allows four newer operations -- the residual's four loads are older than those copies.
+                int ln0 = lane;
+                asm volatile("" : "+v"(ln0));
+                const int lrow = ln0 & 31, lhi = ln0 >> 5;
+                R23_RES(0, rqa, rca)
+                // (row 1's residual here as well, or row 0's a chunk earlier: 71.6 / 70.0 / 74.1 us per block -> 75.0 / 72.3 / 73.8 and 74.0 / 72.7 / 77.0)
+            }
             const unsigned char *Xb = XP + ring * R23_XB;
             const int pair = chunk * 4 + pw;
             r23_f4 acc[4], acl[4];
@@ -275,7 +306,8 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
             int ln0 = lane;
             asm volatile("" : "+v"(ln0));                   // (recomputed: a lane-derived value carried through the chunk loop is a spill)
             const int lrow = ln0 & 31, lhi = ln0 >> 5;
-            R23_RES(0, rqa, rca)                            // row 0's residual IN FRONT of chunk 3's copies (below), row 1's behind them
+            if (!L8) { R23_RES(0, rqa, rca) }               // row 0's residual IN FRONT of chunk 3's copies (below), row 1's behind them
+            else { (void)lrow; (void)lhi; }
         }
 
         {
@@ -309,14 +341,40 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
             int sw = lrow;
             asm volatile("" : "+v"(sw));   // (the 16 fragment addresses: per row, not hoisted)
             const unsigned char *xp = T2 + (r4 * 32 + sw) * 512;
+            if constexpr (L8) {
+                typedef short s2v_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v8i_t vb;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int kk = 4 * j + i;
+                        const h8_t b = *reinterpret_cast<const h8_t *>(xp + (((kk * 2 + lhi) ^ sw) << 4));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], b, acc, 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            s2v_t v = {0, 0};
+                            v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(v, h2_t{b[4 * q], b[4 * q + 1]}, 4.0f, false);
+                            v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(v, h2_t{b[4 * q + 2], b[4 * q + 3]}, 4.0f, true);
+                            int d;
+                            __builtin_memcpy(&d, &v, 4);
+                            vb[2 * i + q] = d;
+                        }
+                    }
+                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al[j], vb, acc, 0, 0, 0, sa3, 0, 0x7f7f7f7f);
+                }
+                asm volatile("" : "+v"(acc));
+            } else
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
                 const h8_t b = *reinterpret_cast<const h8_t *>(xp + (((kk * 2 + lhi) ^ sw) << 4));
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], b, acc, 0, 0, 0);
                 acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(sfd2_half8(al[kk >> 1], kk & 1), b, acl, 0, 0, 0);
             }
+            if constexpr (!L8) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(acl[r], 1.0f / 2048.0f, acc[r]);
+                for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(acl[r], 1.0f / 2048.0f, acc[r]);
+            }
 
             uint2 rp[2][2], rcp[2][2];
 #pragma unroll
@@ -401,7 +459,8 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
 void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t *w2h, const half_t *w2l, const float *sc2,
                    const float *sh2, const half_t *w3h, const half_t *w3l, const float *sc3, const float *sh3,
                    const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page,
-                   unsigned int *range_t2, unsigned int *range_out, int r1 /* bit 0: res_c is residual-only, bit 1: out_c is written residual-only */)
+                   unsigned int *range_t2, unsigned int *range_out, int r1 /* bit 0: res_c is residual-only, bit 1: out_c is written residual-only */,
+                   const half_t *w3l8, int sbyte3 /* r1 & 1: conv3's filter residuals as e4m3 ([8][4][64][32 B]) and its corr scale byte */)
 {
     constexpr size_t lds = 0;                               // (static LDS: 150 KB)
     static bool attr_done = false;
@@ -416,8 +475,10 @@ void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t 
     const int n_tiles = tiles_x * tiles_y;
     if (n_tiles == 0) return;
     const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
-#define R23_GO(a_, b_) hipLaunchKernelGGL((rb23_c_kernel<a_, b_>), dim3(grid), dim3(R23_NT), lds, st, t1, H, W, w2h, w2l, sc2, sh2, w3h, w3l, sc3, sh3, res, res_c, \
-                                          out, out_c, tiles_x, n_tiles, range_t2, range_out)
+    const int sa3 = (sbyte3 & 255) * 0x01010101;
+    if ((r1 & 1) && !w3l8) abort();
+#define R23_GO(a_, b_) hipLaunchKernelGGL((rb23_c_kernel<a_, b_>), dim3(grid), dim3(R23_NT), lds, st, t1, H, W, w2h, w2l, sc2, sh2, w3h, (a_) ? w3l8 : w3l, sc3, sh3, res, res_c, \
+                                          out, out_c, tiles_x, n_tiles, range_t2, range_out, sa3)
     // (units in, residual bytes out is not instantiated: it spills 261 registers; the caller converts conv3b's output as well)
     if ((r1 & 3) == 3) R23_GO(true, true); else if (r1 & 1) R23_GO(true, false); else if (r1 & 2) abort(); else R23_GO(false, false);
 #undef R23_GO

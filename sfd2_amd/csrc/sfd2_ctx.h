@@ -81,6 +81,7 @@ struct ConvW {                 // one folded + packed layer
     DevBuf wc;                 // SFD2_PREC_F16C: [2 * cin / 32][taps][cout_pad][32] units -- the fp16 filters in 32-wide chunks, then the
                                // corr units (fp8 of w * 2^b0, fp8 of (w - fp16(w)) * 2^(b0 + 11)); conv1a / grouped conv: hi then lo fragments
     int sbyte = 127;           // E8M0 scale byte of the layer's corr MFMAs: 127 - 9 - b0
+    DevBuf wf8l;               // the 1x1 layers' filter residuals as e4m3 in rb23_c_kernel's K order (option "trunk_r1": conv3's x * lo_w term on the scaled MFMA)
     DevBuf wfr;                // the 1x1 layers' corr units in the order of the residual-only input form (option "trunk_r1")
     DevBuf wc6;                // conv3x3_pp layers: wc with the corr filter rows as fp6 (e2m3) strings, and ...
     DevBuf sa6;                // ... [shift[cout_pad] | per-output-channel E8M0 scale bytes, replicated into the four bytes of an int, [cout_pad]]

@@ -414,7 +414,8 @@ void launch_rb23_c(hipStream_t st, const half_t *t1, int H, int W, const half_t 
                    const float *sh2, const half_t *w3h, const half_t *w3l, const float *sc3, const float *sh3,
                    const half_t *res, const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page,
                    unsigned int *range_t2 = nullptr, unsigned int *range_out = nullptr,
-                   int r1 = 0 /* residual-only corr bytes (256 B per pixel): bit 0 = res_c, bit 1 = out_c */);
+                   int r1 = 0 /* residual-only corr bytes (256 B per pixel): bit 0 = res_c, bit 1 = out_c */,
+                   const half_t *w3l8 = nullptr, int sbyte3 = 0 /* with r1 & 1: conv3's filter residuals as e4m3 in the kernel's K order, its corr scale byte */);
 // conv1x1_kernels.hip: SFD2_PREC_F16X3 streaming 1x1 (256 -> 256): planes in, fp32 (+ planes) out, fp32 residual
 void launch_conv1x1_c256_x3(hipStream_t st, const half_t *in, const half_t *in_lo, int npix, const half_t *w, const half_t *wl,
                             const float *scale, const float *shift, int relu, const void *res, const half_t *res_lo, float *out, half_t *out_hi,
