@@ -73,12 +73,12 @@ void conv1x1_c256_kernel(const half_t *__restrict__ in, int npix, const half_t *
         }                                                                                                  \
     }
     // Counted wait: loads retire in order, so group g's copies have landed once no more than N vector-memory
-    // operations are outstanding, N = the fewest loads that can have been issued after them when iteration g
-    // starts: the copies of g+1 and g+2 (8), plus -- with a residual, whose loads are issued BEFORE the iteration's
-    // copies so that waiting for them never drains a prefetch -- one iteration's residual loads (4).  Stores are
-    // not relied upon (they may retire early); a smaller N only waits longer.
+    // operations are outstanding, N = the LOADS that can still be in flight behind them when iteration g starts: the
+    // copies of g+1 and g+2 (8).  Nothing else is counted on: an iteration's residual loads were consumed by its own
+    // epilogue, and stores may retire early -- with them (or with the residual loads, as until round 4: 12) in N, a
+    // wave whose stores had drained could pass with group g's copies still pending.  A smaller N only waits longer.
 #define WAIT_GROUP()                                                                                       \
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(HAS_RES ? 12 : 8) : "memory")
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
     ISSUE_G(g0)
     if (g0 + 1 < g1) { ISSUE_G(g0 + 1) }
@@ -277,7 +277,8 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
         }                                                                                                  \
     }
 #define WAIT_GROUP_C()                                                                                     \
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((IN_C == 1 ? 4 : IN_C == 2 ? 3 : 2) + (OUT_C ? 4 : 2) + (HAS_RES ? 4 : 0)) : "memory")
+    /* (N = the copies of the two younger groups, loads only: see WAIT_GROUP) */                          \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (IN_C == 1 ? 4 : IN_C == 2 ? 3 : 2)) : "memory")
 
     ISSUE_GC(g0)
     if (g0 + 1 < g1) { ISSUE_GC(g0 + 1) }
@@ -483,7 +484,8 @@ void conv1x1_c256_x3_kernel(const half_t *__restrict__ in, const half_t *__restr
     }
     // per group and wave: 4 copies, 4 residual loads (fp32, or 16 B of each plane per channel-run pair), 4 fp32 stores, 4 plane stores
 #define WAIT_GROUP_X()                                                                                     \
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 + (OUT_F32 ? 4 : 0) + (OUT_PLANES ? 4 : 0) + (HAS_RES ? 4 : 0)) : "memory")
+    /* (N = the copies of the two younger groups, loads only: see WAIT_GROUP) */                          \
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
     ISSUE_GX(g0)
     if (g0 + 1 < g1) { ISSUE_GX(g0 + 1) }
