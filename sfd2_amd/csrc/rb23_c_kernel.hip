@@ -196,7 +196,7 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
     (void)tcount;
     R23_WALL(0)
     int ring = 0;                                           // buffer of the chunk at hand; the copies go to (ring + 2) % 3
-    bool drain = true;                                      // top of the first tile / behind a tile with rows below the image: full wait
+    bool drain = true;                                      // top of a tile: full wait; the chunks behind it wait by count
 
     using rc_t = typename std::conditional<RES_R1, uint2, uint4>::type;
     uint4 rqa[2], rqb[2];                   // residuals of two rows in flight (even / odd rows)
@@ -446,6 +446,10 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
 #undef R23_RES
         if (!has_next) break;
         tile = next; oy0 = noy0; ox0 = nox0;
+        // a full wait at every tile's top.  Until round 4 this was vmcnt(4) = "the last row's four stores are all that is in flight", which leans on
+        // stores retiring in order with the filter-fragment loads issued just before them; the full wait measures the same (77.0 / 76.8 / 78.0 ->
+        // 77.4 / 76.4 / 78.7 us per block) and leans on nothing
+        drain = true;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (copies of chunks nobody will read)
     sfd2_range_commit(range_t2, smax_t2);
