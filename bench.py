@@ -15,9 +15,9 @@ Multi-GPU: one process per GPU, images sharded, no collective on the data path
         --master-port P bench.py --gpus N --steps K --warmup W
 
 `value` is the fastest mode whose tests assert BASELINE.json north_star's tolerance (descriptors within 1e-3 of the fp32
-reference): precision 'f16c', compensated fp16 -- fp16 MFMA operands plus one block-scaled fp8 MFMA per 32 channels that
-adds the two first-order rounding terms (tests/test_gpu_f16c.py asserts 1e-3 at every BASELINE geometry; measured
-<= 3.5e-4).  Other modes of the same workload, same bracket, in the same line: `approx_f16` (plain fp16, descriptors within
+reference): precision 'f16c', compensated fp16 -- fp16 MFMA operands plus one block-scaled MFMA per 32 channels that adds the
+two first-order rounding terms (fp6 x fp6 records on conv2a / conv3a / conv3b, option fp6_acts, the default; fp8 elsewhere;
+tests/test_gpu_f16c.py asserts 1e-3 at every BASELINE geometry; measured <= 5e-4: profiles/r04v_f16c_parity_measured.txt).  Other modes of the same workload, same bracket, in the same line: `approx_f16` (plain fp16, descriptors within
 3e-3: OUTSIDE the tolerance, reported for reference only), `strict_f32` (fp32 on the f32-input MFMA: descriptors within
 2e-5, key-point list equal up to near-ties) and `strict_f16x3` (three hi / lo fp16 passes, same tolerances as f32).
 Tolerances are asserted by tests/, not here.
@@ -424,6 +424,9 @@ def main():
                                            [(1200, 1600)] * 4 + [(1600, 1200)], K_DB, n_c, 300),
             "robotcar_1024x1024_k20": config_leg("BASELINE configs[3] geometry: 1024x1024 queries, netvlad-20", [(1024, 1024)] * 4, 20, n_c, 400),
             "ecmu_1024x768_k10": config_leg("BASELINE configs[4] geometry: 1024x768 queries, netvlad-10, hipGraph replay", [(768, 1024)] * 4, 10, n_c, 500),
+            # every database image of configs[2] has this size: height not a multiple of 8 (score map resized, no fused post kernel) nor of 4 (no
+            # space-to-depth conv2b); extract only -- database images are not queries
+            "aachen_db_1600x1063": config_leg("aachen_v1.1 database images 1600x1063 (odd geometry: heat-map resize path), extract only", [(1063, 1600)] * 4, 0, n_c, 600),
         }
     # what the compensated mode's range status saw over everything above (include/sfd2_hip.h "Range management"): nothing may have saturated
     range_seen = None
@@ -556,13 +559,14 @@ def main():
                        "launch": "hipGraph replay per image (sfd2_extract_match)" if use_graphs else "eager"},
             "roofline": roof, "kernel_ms_per_step": breakdown, "device_ms_per_step": round(total_ms, 4),
             "mutual_matches_last_step": n_matched,
-            "parity": ({"mode": "f16c: compensated fp16 (fp16 MFMA + one block-scaled fp8 MFMA of the rounding residuals per 32 channels, fp32 accumulate)"
+            "parity": ({"mode": "f16c: compensated fp16 (fp16 MFMA + one block-scaled MFMA of the rounding residuals per 32 channels -- "
+                                + ("fp6 x fp6 on conv2a / conv3a / conv3b (option fp6_acts), fp8 elsewhere" if args.fp6_acts else "fp8 operands") + " -- fp32 accumulate)"
                                 + (f"; backbone compensated, tensors inside the ResBlocks per option rb_inner = {args.rb_inner}" if args.comp_rb else "; option comp_rb = 0 (ResBlocks plain fp16)"),
                         "descriptors_max_abs": "<= 1e-3 asserted = north_star's tolerance (measured "
                                                + (("<= 4.9e-4", "<= 3.8e-4", "<= 3.5e-4")[2 - max(0, min(2, args.rb_inner))] if args.comp_rb else "<= 8.1e-4") + " at 480x640 .. 2048x1536)",
                         "keypoint_set_iou": ">= 0.985 asserted (measured 0.997 - 1.0)" if args.comp_rb else ">= 0.97 asserted (measured 0.991 - 0.996)",
                         "selection_given_heat_map": "bit-exact", "asserted_in": "tests/test_gpu_f16c.py",
-                        "measured_in": "profiles/r03*_f16c_parity_measured.txt"} if args.precision == "f16c" else
+                        "measured_in": "profiles/r04v_f16c_parity_measured.txt"} if args.precision == "f16c" else
                        {"mode": "f16 throughput (OUTSIDE north_star's 1e-3)", "descriptors_max_abs": "<= 3e-3 (measured 1.8e-3)", "keypoint_set_iou": ">= 0.93",
                         "selection_given_heat_map": "bit-exact", "asserted_in": "tests/test_gpu_parity.py"}),
             "single_stream": single, "sustained": sustained, "configs": configs_obj, "range_status": range_seen,

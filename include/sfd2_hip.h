@@ -97,8 +97,9 @@ int sfd2_load_weights(sfd2_ctx *ctx, const sfd2_tensor *tensors, int n);
  * fp32's 2^-24, fp32 accumulation) -- descriptors within 2e-5 of the reference like SFD2_PREC_F32, ~1.9x its speed.
  * SFD2_PREC_F16C: compensated fp16 -- the throughput mode's layout and kernels, with the backbone (conv1a .. conv4.2)
  * carrying a second 2-byte plane per activation and per filter that holds the fp16 rounding residual and the value at
- * fp8 precision; every backbone layer adds the two first-order error terms with ONE block-scaled fp8 MFMA per 32
- * channels (1.65x the matrix time of the fp16 layer).  Operands then carry ~15 significant bits: descriptors within
+ * fp8 precision; every backbone layer adds the two first-order error terms with ONE block-scaled MFMA per 32
+ * channels (measured matrix time relative to the plain fp16 layer: 2.03x with fp8 operands, 1.52x with fp6 on both sides -- option
+ * "fp6_acts", the default for conv2a / conv3a / conv3b; profiles/r04_mfma_probe.txt).  Operands then carry ~15 significant bits: descriptors within
  * 1e-3 of the fp32 reference (measured <= 5e-4), which is the tolerance BASELINE.json's north_star states.  The head
  * branches stay plain fp16 (they contribute 2.4e-4 on their own).  Option "comp_heads" extends it to convPa / convDa.
  * RANGE: the compensated tensors saturate at +-1792 in stored units and lose their correction bits below ~0.03 (the fp32
@@ -159,7 +160,9 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *   "cu_limit"  0 (default) / n: persistent kernels of THIS context launch at most n blocks (experiment: with two streams, two kernels
  *               side by side on half the chip each measure the same throughput as taking turns on all of it).
  *   "auto_range" 1 (default) / 0: sfd2_load_weights calibrates the activation exponents on a built-in probe image (see
- *               sfd2_calibrate_range below); 0 = all exponents zero until the caller calibrates.
+ *               sfd2_calibrate_range below); 0 = all exponents zero until the caller calibrates.  The probe is one 192x256
+ *               SFD2_PREC_F32 pass (its fp32 workspace is released again); the exponents apply to SFD2_PREC_F16 as well as
+ *               F16C, so both modes' results depend on what the context was calibrated on.
  *   "range_fallback" 1 (default) / 0: a synchronous sfd2_extract in SFD2_PREC_F16C that saturated a tensor is re-run in
  *               SFD2_PREC_F16X3 before it returns.
  *   "sparse_da3" 1 (default) / 0: on the extract path (with "sparse_desc"), convDa.3 runs on the 4 x K bilinear corner pixels of the
@@ -219,6 +222,27 @@ int sfd2_preprocess(sfd2_ctx *ctx, const unsigned char *img_hwc, int on_device, 
 
 /* After an SFD2_FLAG_ASYNC extract: number of key points, once the stream is idle. */
 int sfd2_extract_count(sfd2_ctx *ctx, int *n_out);
+
+/* Pipelined callers (the DataLoader-fed loop of extract_localization.py:230-250 with several images in flight):
+ * sfd2_extract with SFD2_FLAG_ASYNC returns as soon as the image's work is queued; img may be a (pinned) host buffer -- it goes
+ * through the context's copy stream into one of two staging slots, so the upload of image i + 1 overlaps the network of image i --
+ * and the outputs may be (pinned) host buffers too: kpts_xy / scores / desc then receive the full capacity (top_k rows) by
+ * asynchronous copies and hold the result once the stream is synchronised (an event recorded on sfd2_get_stream()).
+ * sfd2_extract_record_async queues, behind that extract, the image's record into `rec` (pinned host or device memory):
+ *   n            key points written (already clipped to the capacity)
+ *   n_candidates NMS survivors (sfd2_timings.n_candidates of the synchronous call)
+ *   saturated    bit i: tensor i (sfd2_range_tensor_name) reached the saturation of SFD2_PREC_F16C ON THIS IMAGE -- the caller
+ *                repeats such an image with a synchronous sfd2_extract (which falls back to SFD2_PREC_F16X3 by itself)
+ *   flags        bit 0: candidate buffer overflow (the synchronous call's error)
+ * and moves the image's range maxima into the context's history (sfd2_get_range_status still reports them), so the next
+ * image's record speaks for that image alone.  One call per asynchronous extract, before the next extract is queued. */
+typedef struct {
+    int32_t n;
+    int32_t n_candidates;
+    uint32_t saturated;
+    uint32_t flags;
+} sfd2_extract_record;
+int sfd2_extract_record_async(sfd2_ctx *ctx, sfd2_extract_record *rec, int rec_on_device);
 
 /* extract_spp_feats_singlescale (extract.py:205-277), the older SuperPoint-style variant:
  * candidates heat >= conf_th, greedy grid NMS in score order (nms_fast, extract.py:17-84,
@@ -292,6 +316,14 @@ typedef struct {
     int32_t reserved;
 } sfd2_desc_set;
 
+/* One descriptor set into the matcher's resident form: fp16 [n][128] row-major on the device (columns beyond dim zero), made by
+ * the conversion kernel every sfd2_match* call runs on its inputs -- a set packed once and then passed as (SFD2_DT_F16,
+ * SFD2_LAYOUT_ND, on_device = 1) gives bit-identical matches to passing the original every time.  This is what lets a batch
+ * driver keep the database sets of hloc/match_features.py:99-105 (read + .float() + .cuda() per PAIR there) resident in HBM
+ * across pairs.  src->rows selects / orders rows as in sfd2_match_batch; dst_f16_dev: caller-owned device buffer of
+ * (rows ? n_rows : n) * 128 * 2 bytes.  flags: SFD2_FLAG_ASYNC (a host source must stay valid until the stream is synchronised). */
+int sfd2_desc_pack(sfd2_ctx *ctx, const sfd2_desc_set *src, int dim, void *dst_f16_dev, int flags);
+
 /* One query against k database images in one launch (the localiser's inner loop,
  * it_loc/localize_cv2.py:705-715 -> feature_matching :511-560 -> Matcher.forward).
  * matches0 [k][q->n] int64, scores0 [k][q->n] fp32.  Device-resident fp16 [n][128] database
@@ -331,7 +363,10 @@ int sfd2_get_timings(sfd2_ctx *ctx, sfd2_timings *out);
  *      stored, before the saturation.  sfd2_get_range_status reports them; a synchronous sfd2_extract that saturated a
  *      tensor is re-run in SFD2_PREC_F16X3 before it returns (option "range_fallback", default 1) and counted.
  *      Asynchronous calls (SFD2_FLAG_ASYNC, sfd2_extract_match) cannot look at the counters: the caller polls
- *      sfd2_get_range_status at its own synchronisation points. */
+ *      sfd2_get_range_status at its own synchronisation points, or takes the per-image record of sfd2_extract_record_async.
+ *      A fallback's first SFD2_PREC_F16X3 pass allocates that mode's workspace: captured sfd2_extract_match graphs of the
+ *      context are dropped and re-captured on their next use.  Recalibration (sfd2_calibrate_range, sfd2_set_act_exponents)
+ *      clears the recorded maxima: they were measured under the previous scaling. */
 #define SFD2_RANGE_TENSORS 17
 #define SFD2_RANGE_GROUPS 14
 typedef struct {

@@ -58,6 +58,10 @@ class LayerTiming(ctypes.Structure):
                 ("bytes", ctypes.c_double), ("ms_total", ctypes.c_double), ("launches", ctypes.c_int32)]
 
 
+class ExtractRecord(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("n_candidates", ctypes.c_int32), ("saturated", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
+
+
 RANGE_TENSORS, RANGE_GROUPS = 17, 14
 
 
@@ -76,6 +80,7 @@ EXPORTS = [
     "sfd2_get_layer_timings", "sfd2_set_precision", "sfd2_extract_spp", "sfd2_nms_fast",
     "sfd2_set_profile_filter", "sfd2_extract_multiscale", "sfd2_set_option", "sfd2_extract_match", "sfd2_preprocess", "sfd2_extract_spp_levels", "sfd2_match_segments",
     "sfd2_get_range_status", "sfd2_range_tensor_name", "sfd2_calibrate_range", "sfd2_get_act_exponents", "sfd2_set_act_exponents",
+    "sfd2_extract_record_async", "sfd2_desc_pack",
 ]
 
 _lib = None
@@ -149,6 +154,8 @@ def load():
     lib.sfd2_calibrate_range.argtypes = [vp, vp, ci, ci, ci, ci]
     lib.sfd2_get_act_exponents.argtypes = [vp, vp, vp, ci, pi]
     lib.sfd2_set_act_exponents.argtypes = [vp, vp, ci]
+    lib.sfd2_extract_record_async.argtypes = [vp, vp, ci]
+    lib.sfd2_desc_pack.argtypes = [vp, ctypes.POINTER(DescSet), ci, vp, ci]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the .so lacks a declared symbol
     _lib = lib

@@ -40,9 +40,12 @@ extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
     }
     c->fuse = sfd2_env("SFD2_NO_FUSE") ? 0 : 1;
     // the zero page, and behind it the range-status words (conv3x3_pp reaches them through the zero-page pointer it holds anyway)
-    HIPCHECK(c->zero_page.ensure(SFD2_ZERO_PAGE_BYTES + (size_t)SFD2_RS_COUNT * SFD2_RANGE_SUB * sizeof(unsigned int)));
+    // ... and behind those the device-side history of folded maxima (SFD2_RS_COUNT words) and the record of the last asynchronous extract (4 words)
+    HIPCHECK(c->zero_page.ensure(SFD2_ZERO_PAGE_BYTES + ((size_t)SFD2_RS_COUNT * (SFD2_RANGE_SUB + 1) + 4) * sizeof(unsigned int)));
     HIPCHECK(hipMemset(c->zero_page.p, 0, c->zero_page.cap));
     c->range_stat.p = c->zero_page.as<char>() + SFD2_ZERO_PAGE_BYTES;
+    c->range_hist_dev.p = c->range_stat.as<unsigned int>() + SFD2_RS_COUNT * SFD2_RANGE_SUB;
+    c->extract_rec.p = c->range_hist_dev.as<unsigned int>() + SFD2_RS_COUNT;
     static_assert(SFD2_RS_COUNT == SFD2_RANGE_TENSORS && AE_COUNT == SFD2_RANGE_GROUPS, "include/sfd2_hip.h and the internal tables agree");
 
     *out = c;
@@ -195,29 +198,58 @@ extern "C" const char *sfd2_range_tensor_name(int i)
     return (i >= 0 && i < SFD2_RS_COUNT) ? names[i] : "";
 }
 
+// the running words and the device-side history behind them in one read: [SFD2_RS_COUNT][SFD2_RANGE_SUB] then [SFD2_RS_COUNT]
+static int fetch_range_words(sfd2_ctx *c, unsigned int *raw /* SFD2_RS_COUNT * (SFD2_RANGE_SUB + 1) */, bool clear)
+{
+    const size_t bytes = (size_t)SFD2_RS_COUNT * (SFD2_RANGE_SUB + 1) * sizeof(unsigned int);
+    HIPCHECK(hipMemcpyAsync(raw, c->range_stat.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (clear) HIPCHECK(hipMemsetAsync(c->range_stat.p, 0, bytes, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int read_range_status(sfd2_ctx *c, sfd2_range_status *out, int reset)
 {
-    unsigned int raw[SFD2_RS_COUNT * SFD2_RANGE_SUB];
-    HIPCHECK(hipMemcpyAsync(raw, c->range_stat.p, sizeof(raw), hipMemcpyDeviceToHost, c->stream));
-    if (reset) HIPCHECK(hipMemsetAsync(c->range_stat.p, 0, sizeof(raw), c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    unsigned int raw[SFD2_RS_COUNT * (SFD2_RANGE_SUB + 1)];
+    if (fetch_range_words(c, raw, reset != 0)) return -1;
     std::memset(out, 0, sizeof(*out));
     out->n_tensors = SFD2_RS_COUNT;
+    const unsigned int sat_bits = 0x44E00000u;      // 1792.0f: raw compare, so that Inf / NaN patterns count as saturated too
     for (int t = 0; t < SFD2_RS_COUNT; ++t) {
-        unsigned int m = 0;
+        unsigned int m = raw[SFD2_RS_COUNT * SFD2_RANGE_SUB + t];             // folded away by sfd2_extract_record_async / a synchronous extract's start
         for (int s = 0; s < SFD2_RANGE_SUB; ++s) m = std::max(m, raw[t * SFD2_RANGE_SUB + s]);
         float f;
         std::memcpy(&f, &m, 4);
-        f = std::max(f, c->range_hist[t]);
+        const bool sat = m >= sat_bits || c->range_hist[t] >= SFD2_C_SAT;
+        if (!(f >= c->range_hist[t])) f = c->range_hist[t];                   // (a NaN pattern stays visible)
         if (reset) c->range_hist[t] = 0.0f;
         const int e = c->act_exp[kRsGroup[t]];
         out->max_stored[t] = f;
         out->max_value[t] = std::ldexp(f, -e);
         out->exponent[t] = e;
-        if (f >= SFD2_C_SAT) out->saturated |= 1u << t;
+        if (sat) out->saturated |= 1u << t;
         if (f > 0.0f && f < 0.03125f) out->low |= 1u << t;
     }
     out->fallbacks = c->range_fallbacks;
+    return 0;
+}
+
+// sfd2_calibrate_range / sfd2_set_act_exponents: maxima recorded under the previous exponents say nothing about the new scaling
+int reset_range_records(sfd2_ctx *c)
+{
+    if (!c->range_stat.p) return 0;
+    HIPCHECK(hipMemsetAsync(c->range_stat.p, 0, (size_t)SFD2_RS_COUNT * (SFD2_RANGE_SUB + 1) * sizeof(unsigned int), c->stream));
+    for (int t = 0; t < SFD2_RS_COUNT; ++t) c->range_hist[t] = 0.0f;
+    return 0;
+}
+
+// In front of a synchronous extraction that may fall back: whatever earlier (asynchronous) calls left in the running words goes
+// into the device-side history, so the decision after this image covers this image only.  No host synchronisation.
+int range_fold_before_sync_extract(sfd2_ctx *c)
+{
+    if (c->precision != SFD2_PREC_F16C || !c->opt_range_fallback || c->in_fallback) return 0;
+    launch_extract_record(c->stream, c->range_stat.as<unsigned int>(), c->range_hist_dev.as<unsigned int>(), nullptr, 0, 0, nullptr);
+    HIPCHECK(hipGetLastError());
     return 0;
 }
 
@@ -240,10 +272,26 @@ int range_wants_fallback(sfd2_ctx *c)
         unsigned int m = 0;
         for (int s = 0; s < SFD2_RANGE_SUB; ++s) m = std::max(m, raw[t * SFD2_RANGE_SUB + s]);
         std::memcpy(&mx[t], &m, 4);
-        sat = sat || mx[t] >= SFD2_C_SAT;
+        sat = sat || m >= 0x44E00000u;      // bits of SFD2_C_SAT (1792.0f); also true for Inf / NaN patterns
     }
     if (!sat) return 0;
-    for (int t = 0; t < SFD2_RS_COUNT; ++t) c->range_hist[t] = std::max(c->range_hist[t], mx[t]);   // the report keeps what happened
+    for (int t = 0; t < SFD2_RS_COUNT; ++t)
+        if (!(c->range_hist[t] >= mx[t])) c->range_hist[t] = mx[t];                                // the report keeps what happened
     HIPCHECK(hipMemsetAsync(c->range_stat.p, 0, sizeof(raw), c->stream));                          // the next image starts clean
     return 1;
+}
+
+// After an SFD2_FLAG_ASYNC sfd2_extract (include/sfd2_hip.h).
+extern "C" int sfd2_extract_record_async(sfd2_ctx *c, sfd2_extract_record *rec, int rec_on_device)
+{
+    if (!c || !rec) return fail("sfd2_extract_record_async: null argument");
+    if (!c->counters.p) return fail("sfd2_extract_record_async: no extract has run on this context");
+    HIPCHECK(hipSetDevice(c->device));
+    static_assert(sizeof(sfd2_extract_record) == 16, "four words");
+    unsigned int *dev = rec_on_device ? reinterpret_cast<unsigned int *>(rec) : c->extract_rec.as<unsigned int>();
+    launch_extract_record(c->stream, c->range_stat.as<unsigned int>(), c->range_hist_dev.as<unsigned int>(), c->counters.as<unsigned int>(),
+                          c->last_sel_cap, c->cand_cap, dev);
+    HIPCHECK(hipGetLastError());
+    if (!rec_on_device) HIPCHECK(hipMemcpyAsync(rec, dev, sizeof(sfd2_extract_record), hipMemcpyDeviceToHost, c->stream));
+    return 0;
 }

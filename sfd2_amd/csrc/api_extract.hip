@@ -27,6 +27,15 @@ static int release_image_slot(sfd2_ctx *c)
     return 0;
 }
 
+// Entry of an extraction that may fall back to SFD2_PREC_F16X3: remember where its profile steps start (the repeat replaces them)
+// and, when the call is synchronous, move what earlier asynchronous calls left in the range words out of the way.
+static int extract_begin(sfd2_ctx *c, int flags)
+{
+    c->prof_step_entry = c->prof_step;
+    if (!(flags & SFD2_FLAG_ASYNC) && range_fold_before_sync_extract(c)) return -1;
+    return 0;
+}
+
 int copy_out(sfd2_ctx *c, void *dst, const void *src_dev, size_t bytes, int dst_on_device)
 {
     if (!dst || bytes == 0) return 0;
@@ -131,6 +140,7 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     if (!(flags & SFD2_FLAG_NO_STABILITY) && !c->has_sta)
         return fail("sfd2_extract: the loaded state_dict has no ConvSta; pass SFD2_FLAG_NO_STABILITY (use_stability=False)");
     HIPCHECK(hipSetDevice(c->device));
+    if (extract_begin(c, flags)) return -1;
     set_path(c, false);
     if (ensure_workspace(c, H, W)) return -1;
     const float *img_dev = nullptr;
@@ -250,11 +260,11 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     HIPCHECK(hipEventRecord(c->ev[2], c->stream));
     HIPCHECK(hipGetLastError());
     if (flags & SFD2_FLAG_ASYNC) {
-        // device-resident outputs only: copy the fixed-capacity arrays, the count stays on the device
-        if (!out_on_device) return fail("SFD2_FLAG_ASYNC needs device output buffers");
-        if (!direct && copy_out(c, kpts_xy, c->kpts.p, (size_t)ncopy * 2 * sizeof(float), 1)) return -1;
-        if (!direct && copy_out(c, scores, c->kscores.p, (size_t)ncopy * sizeof(float), 1)) return -1;
-        if (desc && desc_dst != desc && copy_out(c, desc, desc_dst, (size_t)ncopy * 128 * sizeof(float), 1)) return -1;
+        // the fixed-capacity arrays are copied, the count stays on the device (sfd2_extract_record_async / sfd2_extract_count).
+        // Host output buffers (pinned, or the copies are not asynchronous) hold the result once the stream has been synchronised.
+        if (!direct && copy_out(c, kpts_xy, c->kpts.p, (size_t)ncopy * 2 * sizeof(float), out_on_device)) return -1;
+        if (!direct && copy_out(c, scores, c->kscores.p, (size_t)ncopy * sizeof(float), out_on_device)) return -1;
+        if (desc && desc_dst != desc && copy_out(c, desc, desc_dst, (size_t)ncopy * 128 * sizeof(float), out_on_device)) return -1;
         if (n_out) *n_out = -1;
         return 0;
     }
@@ -315,6 +325,7 @@ extern "C" int sfd2_extract_multiscale(sfd2_ctx *c, const void *img, int img_on_
     if (flags & SFD2_FLAG_ASYNC) return fail("sfd2_extract_multiscale: SFD2_FLAG_ASYNC is not supported");
     if (!kpts_xy || !scores) return fail("sfd2_extract_multiscale: kpts_xy and scores are required");
     HIPCHECK(hipSetDevice(c->device));
+    if (extract_begin(c, 0)) return -1;
     const int u8 = (flags & SFD2_FLAG_IMG_U8_HWC) ? 1 : 0;
     if (u8 && (flags & SFD2_FLAG_IMG_NORMALISED)) return fail("sfd2_extract_multiscale: a uint8 image cannot be pre-normalised");
     if ((flags & SFD2_FLAG_IMG_BGR) && !u8) return fail("sfd2_extract_multiscale: SFD2_FLAG_IMG_BGR needs SFD2_FLAG_IMG_U8_HWC");
@@ -475,6 +486,7 @@ extern "C" int sfd2_extract_spp(sfd2_ctx *c, const float *x, int x_on_device, in
     if (!(flags & SFD2_FLAG_NO_STABILITY) && !c->has_sta)
         return fail("sfd2_extract_spp: the loaded state_dict has no ConvSta; pass SFD2_FLAG_NO_STABILITY");
     HIPCHECK(hipSetDevice(c->device));
+    if (extract_begin(c, 0)) return -1;
     set_path(c, false);
     if (ensure_workspace(c, H, W)) return -1;
     const float *img_dev = nullptr;
@@ -536,6 +548,7 @@ extern "C" int sfd2_extract_spp_levels(sfd2_ctx *c, const float *x, int x_on_dev
     if (nh[0] != H || nw[0] != W) return fail("sfd2_extract_spp_levels: level 0 must be the image itself");
     (void)flags;
     HIPCHECK(hipSetDevice(c->device));
+    if (extract_begin(c, 0)) return -1;
     const float *cur = nullptr;
     if (stage_image(c, x, x_on_device, H, W, &cur)) return -1;
     DevBuf lvl[2];          // ping-pong level images (released at the end: this entry point is not on the throughput path)

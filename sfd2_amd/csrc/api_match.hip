@@ -38,6 +38,46 @@ static int prep_set(sfd2_ctx *c, const void *src, int n_src, const int32_t *rows
     return 0;
 }
 
+// One descriptor set into the matcher's resident form (include/sfd2_hip.h): the conversion every matcher call does, done once.
+extern "C" int sfd2_desc_pack(sfd2_ctx *c, const sfd2_desc_set *src, int dim, void *dst_f16_dev, int flags)
+{
+    if (!c || !src || !dst_f16_dev) return fail("sfd2_desc_pack: null argument");
+    if (dim <= 0 || dim > 128) return fail("descriptor dimension must be in [1,128]");
+    if (src->n < 0 || src->n_rows < 0) return fail("negative size");
+    if (src->dtype != SFD2_DT_F32 && src->dtype != SFD2_DT_F64 && src->dtype != SFD2_DT_F16) return fail("sfd2_desc_pack: unknown dtype");
+    if (src->layout != SFD2_LAYOUT_ND && src->layout != SFD2_LAYOUT_DN) return fail("sfd2_desc_pack: unknown layout");
+    const int n = src->rows ? src->n_rows : src->n;
+    if (n == 0) return 0;
+    if (!src->data) return fail("sfd2_desc_pack: null descriptors");
+    if (src->rows)
+        for (int r = 0; r < src->n_rows; ++r)
+            if (src->rows[r] < 0 || src->rows[r] >= src->n) return fail("sfd2_desc_pack: row index out of range");
+    HIPCHECK(hipSetDevice(c->device));
+    size_t stage_bytes = 256;
+    if (!src->on_device) stage_bytes += (((size_t)src->n * dim * elt_size(src->dtype)) + 255) & ~(size_t)255;
+    if (src->rows) stage_bytes += ((size_t)n * sizeof(int32_t) + 255) & ~(size_t)255;
+    HIPCHECK(c->m_stage.ensure(stage_bytes));
+    size_t off = 0;
+    void *dev_src = const_cast<void *>(src->data);
+    if (!src->on_device) {
+        const size_t bytes = (size_t)src->n * dim * elt_size(src->dtype);
+        HIPCHECK(hipMemcpyAsync(c->m_stage.p, src->data, bytes, hipMemcpyHostToDevice, c->stream));
+        dev_src = c->m_stage.p;
+        off += (bytes + 255) & ~(size_t)255;
+    }
+    const int *rd = nullptr;
+    if (src->rows) {
+        void *dst = c->m_stage.as<char>() + off;
+        HIPCHECK(hipMemcpyAsync(dst, src->rows, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        rd = reinterpret_cast<const int *>(dst);
+    }
+    // (always through the conversion kernel: a resident fp16 [n][128] source is copied, with dim < 128 zero-filled like every other)
+    launch_match_prep(c->stream, dev_src, n, src->n, rd, dim, src->dtype, src->layout, reinterpret_cast<half_t *>(dst_f16_dev), nullptr);
+    HIPCHECK(hipGetLastError());
+    if (!(flags & SFD2_FLAG_ASYNC)) HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_desc_set *db, int k, int dim,
                                 const sfd2_match_conf *conf, int64_t *matches0, float *scores0, int out_on_device,
                                 int flags)

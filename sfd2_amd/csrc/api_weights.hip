@@ -633,7 +633,7 @@ int apply_act_exponents(sfd2_ctx *c)
         if (upload(c->sta_w16, w.data(), w.size() * sizeof(float), c->stream)) return -1;
     }
     graphs_release(c);      // (captured units hold nothing of this by value, but a unit captured mid-way must not survive a change of scale)
-    return 0;
+    return reset_range_records(c);   // maxima recorded under the previous exponents would mix two scalings in sfd2_get_range_status
 }
 
 // Range calibration.  The image goes through the network ONCE in SFD2_PREC_F32 on the parity entry point (every activation in its
@@ -646,10 +646,12 @@ static int calibrate_impl(sfd2_ctx *c, const float *img, int on_device, int H, i
 {
     if (!c->weights_loaded) return fail("sfd2_calibrate_range: weights not loaded");
     HIPCHECK(hipSetDevice(c->device));
-    const int prec = c->precision;
+    const int prec = c->precision, prof_max = c->prof_max_steps;
     c->precision = SFD2_PREC_F32;
+    c->prof_max_steps = 0;      // the calibration pass is not one of the caller's profiled steps
     const int rc = sfd2_det(c, img, on_device, H, W, flags, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
     c->precision = prec;
+    c->prof_max_steps = prof_max;
     if (rc) return -1;
     HIPCHECK(c->range_scratch.ensure(AE_COUNT * sizeof(unsigned int)));
     HIPCHECK(hipMemsetAsync(c->range_scratch.p, 0, AE_COUNT * sizeof(unsigned int), c->stream));
@@ -725,5 +727,13 @@ static int calibrate_on_probe(sfd2_ctx *c)
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x)
                 img[((size_t)ch * H + y) * W + x] = 0.5f * rnd() + 0.5f * coarse[((size_t)ch * (H / 16) + y / 16) * (W / 16) + x / 16];
-    return calibrate_impl(c, img.data(), 0, H, W, 0);
+    const int rc = calibrate_impl(c, img.data(), 0, H, W, 0);
+    // the probe's fp32 parity workspace (every activation in its own fp32 buffer) is of no use to a throughput context: give it back
+    // (a context that runs SFD2_PREC_F32 / F16X3 allocates what its own geometry needs on its first call)
+    DevBuf *f32ws[] = {&c->g1a, &c->g1b, &c->g2a, &c->g2b, &c->g3a, &c->g3b, &c->gpa0_o, &c->gpa_o, &c->gda0_o, &c->gda_o};
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : f32ws) b->release();
+    for (int b = 0; b < 3; ++b) { c->grt1[b].release(); c->grt2[b].release(); c->gro[b].release(); }
+    c->acts.clear();            // (they named those buffers)
+    return rc;
 }

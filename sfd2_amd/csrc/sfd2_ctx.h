@@ -124,6 +124,7 @@ struct sfd2_ctx {
     int opt_range_fallback = 1;        // sfd2_set_option "range_fallback": a synchronous f16c extract that saturated a tensor is re-run in f16x3
     int range_fallbacks = 0;           // how often that happened
     int in_fallback = 0;               // set around the re-run
+    int prof_step_entry = 0;           // profile step at the entry of the running extraction: the repeat starts there again
     float range_hist[SFD2_RS_COUNT] = {};   // maxima (stored units) folded away from the device words by a fallback's reset
     int opt_auto_range = 1;            // sfd2_set_option "auto_range": sfd2_load_weights calibrates the exponents on a built-in probe image
     std::vector<float> h_sta_w;        // ConvSta filters as loaded (the uploaded copy carries 2^-act_exp[AE_TRUNK])
@@ -187,6 +188,8 @@ struct sfd2_ctx {
     ConvW c1a, c1b, c2a, c2b, c3a, c3b, rb1[3], rb2[3], rb3[3], pa0, pa3, da0, da3, pb, db;
     DevBuf sta_w16;                                // ConvSta filters times 2^-act_exp[AE_TRUNK]: what the fp16 family launches with
     DevPtr range_stat;                             // (a view: the words live behind the zero page) SFD2_RS_COUNT x SFD2_RANGE_SUB words: running maxima of the compensated mode's stored tensors (sticky until read with reset)
+    DevPtr range_hist_dev;                         // (a view behind range_stat) SFD2_RS_COUNT words: maxima folded away from the running words on the device
+    DevPtr extract_rec;                            // (a view behind range_hist_dev) the four words of sfd2_extract_record_async
     DevBuf range_scratch;                          // AE_COUNT words: absolute maxima of a calibration pass
     DevBuf sta_w, sta_b, zero_page, w1b_fused;   // w1b_fused: conv1b filters as [9][64][64] for the fused stem
     DevBuf w1b_stem_c6;                            // ... with the corr fragments as fp6 strings + scale byte (option "fp6_acts")
@@ -277,9 +280,15 @@ int read_range_status(sfd2_ctx *c, sfd2_range_status *out, int reset);
 // after a synchronous extraction in SFD2_PREC_F16C: 1 = a compensated tensor saturated and the call is to be repeated in SFD2_PREC_F16X3
 // (the device words are folded into the context's history and cleared), 0 = fine / not applicable, -1 = error
 int range_wants_fallback(sfd2_ctx *c);
+int range_fold_before_sync_extract(sfd2_ctx *c);        // earlier asynchronous calls' maxima -> device-side history, running words cleared (no host sync)
+int reset_range_records(sfd2_ctx *c);                   // the exponents changed: running words, device and host history cleared
 struct FallbackScope {      // the repeat: strict arithmetic, no recursion
     sfd2_ctx *c; int prec;
-    explicit FallbackScope(sfd2_ctx *c_) : c(c_), prec(c_->precision) { c->precision = SFD2_PREC_F16X3; c->in_fallback = 1; c->range_fallbacks++; }
+    explicit FallbackScope(sfd2_ctx *c_) : c(c_), prec(c_->precision)
+    {
+        c->precision = SFD2_PREC_F16X3; c->in_fallback = 1; c->range_fallbacks++;
+        if (c->prof_step > c->prof_step_entry) c->prof_step = c->prof_step_entry;   // the saturated pass is not a profiled step: its slots are recorded again
+    }
     ~FallbackScope() { c->precision = prec; c->in_fallback = 0; }
 };
 // api_network.hip

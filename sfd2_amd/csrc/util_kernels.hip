@@ -161,3 +161,37 @@ void launch_ingest_u8(hipStream_t st, const unsigned char *src, int H, int W, in
     const double scale_x = 1.0 / ((double)nw / (double)W), scale_y = 1.0 / ((double)nh / (double)H);
     hipLaunchKernelGGL(ingest_u8_kernel, dim3((nw + NT - 1) / NT, nh), dim3(NT), 0, st, src, H, W, bgr, nh, nw, scale_x, scale_y, out);
 }
+
+// ---------------------------------------------------------------- per-image record of an asynchronous extract
+// One wave.  Lane t < SFD2_RS_COUNT folds tensor t's SFD2_RANGE_SUB running maxima (stored units, bit patterns of non-negative
+// floats: unsigned order = float order, and every Inf / NaN pattern compares above the saturation value) into the device-side
+// history hist[t] and CLEARS them, so what the next image records is that image's alone.  rec (null = fold only) receives
+// { key points (clipped to sel_cap), NMS survivors, mask of the tensors that reached SFD2_C_SAT, bit 0: candidate overflow }.
+__global__ __launch_bounds__(64)
+void extract_record_kernel(unsigned int *__restrict__ range_stat, unsigned int *__restrict__ hist, const unsigned int *__restrict__ counters,
+                           int sel_cap, int cand_cap, unsigned int *__restrict__ rec)
+{
+    const int t = threadIdx.x;
+    unsigned int m = 0;
+    if (t < SFD2_RS_COUNT) {
+#pragma unroll
+        for (int s = 0; s < SFD2_RANGE_SUB; ++s) {
+            m = max(m, range_stat[t * SFD2_RANGE_SUB + s]);
+            range_stat[t * SFD2_RANGE_SUB + s] = 0u;
+        }
+        hist[t] = max(hist[t], m);
+    }
+    const unsigned long long sat = __ballot(t < SFD2_RS_COUNT && m >= __float_as_uint(SFD2_C_SAT));
+    if (t == 0 && rec) {
+        const unsigned int n = counters ? counters[1] : 0u, nc = counters ? counters[0] : 0u;
+        rec[0] = min(n, (unsigned int)sel_cap);
+        rec[1] = nc;
+        rec[2] = (unsigned int)sat;
+        rec[3] = nc > (unsigned int)cand_cap ? 1u : 0u;
+    }
+}
+void launch_extract_record(hipStream_t st, unsigned int *range_stat, unsigned int *hist, const unsigned int *counters, int sel_cap,
+                           int cand_cap, unsigned int *rec)
+{
+    hipLaunchKernelGGL(extract_record_kernel, dim3(1), dim3(64), 0, st, range_stat, hist, counters, sel_cap, cand_cap, rec);
+}

@@ -5,6 +5,7 @@ selection and descriptors -- runs on the MI355X.  Work lists shard round-robin o
 no data-path collective); rank 0 merges the per-rank parts in index order."""
 import os
 import os.path as osp
+import threading
 
 import numpy as np
 
@@ -61,15 +62,25 @@ def resized_shape(w, h, resize_max=None, resize_force=False):
     return w, h
 
 
-def _read_rgb_u8(path):
-    """The decoder: uint8 [H,W,3] RGB (the reference: cv2.imread(..., IMREAD_COLOR)[:, :, ::-1], :162-165)."""
+def _read_rgb_u8(path, reserve=None):
+    """The decoder: uint8 [H,W,3] RGB (the reference: cv2.imread(..., IMREAD_COLOR)[:, :, ::-1], :162-165).
+    reserve(nbytes) -> writable uint8 buffer: the pixels are put there (the pipelined driver's pinned buffers)."""
     try:
         from PIL import Image
     except Exception as e:  # pragma: no cover
         raise RuntimeError("no image decoder importable (PIL); pass decoded uint8 arrays instead of paths") from e
     try:
         with Image.open(path) as im:
-            return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
+            if im.mode != "RGB":
+                im = im.convert("RGB")
+            else:
+                im.load()
+            if reserve is None:
+                return np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+            w, h = im.size
+            out = reserve(h * w * 3).reshape(h, w, 3)
+            np.copyto(out, np.asarray(im, dtype=np.uint8))
+            return out
     except (OSError, ValueError) as e:
         raise ValueError(f'Cannot read image {str(path)}.') from e   # extract_localization.py:166-167
 
@@ -108,8 +119,12 @@ class ImageDataset:
         return len(self.paths)
 
     def __getitem__(self, idx):
+        return self.load(idx)
+
+    def load(self, idx, reserve=None):
+        """__getitem__ with the decoded pixels placed in reserve(nbytes) (see _read_rgb_u8)."""
         path = self.paths[idx]
-        image = _read_rgb_u8(self.root / path)
+        image = _read_rgb_u8(self.root / path, reserve)
         h, w = image.shape[:2]
         return {'name': str(path), 'image': image, 'original_size': np.array((w, h)),
                 'resize': resized_shape(w, h, self.conf['resize_max'], self.conf['resize_force'])}
@@ -148,8 +163,109 @@ def _part_path(export_dir, conf, rank, world):
     return base + '.h5' if world == 1 else f'{base}.part{rank}of{world}.h5'
 
 
+def _extract_pipelined(model, extractor, conf, images, indices, tag, store, names, num_workers, writers, depth):
+    """The loop of main() with its three stages running side by side (sfd2_amd/pipeline.py): `num_workers` decoder threads
+    (the reference: DataLoader(num_workers=4), extract_localization.py:230-233) fill pinned buffers in item order, the
+    device runs up to `depth` asynchronous extractions, `writers` threads build the float64 groups and append them.
+    Single-scale uint8 items on a HIP model go through the asynchronous C-ABI; anything else (float images, a scale
+    pyramid, a stub extractor in the CPU tests) calls `extractor` synchronously between the same decode and writer
+    stages.  Groups are written in item order per writer, with the arithmetic of the serial loop."""
+    from .feature_io import write_features
+    from .pipeline import AsyncExtractor, OrderedPrefetch, PinnedPool, WriterPool, slot_arrays
+    mconf = conf["model"]
+    top_k, conf_th, scales = mconf["max_keypoints"], mconf["conf_th"], [float(x) for x in mconf["scales"]]
+    use_async = (extractor is extract_resnet_return and getattr(model, "context", None) is not None
+                 and scales == [1.0] and top_k > 0)
+    ax = AsyncExtractor(model, top_k, conf_th, depth=depth, slots=depth + 2 * writers + 2) if use_async else None
+    pool = PinnedPool(num_workers + depth + 2) if use_async else None
+    lock = threading.Lock()
+
+    def load(idx, buf):
+        if hasattr(images, "load"):
+            data = images.load(idx, buf.reserve if buf is not None else None)
+        else:
+            data = images[idx]
+            img = data["image"]
+            if buf is not None and getattr(img, "dtype", None) == np.uint8:
+                pinned = buf.reserve(img.size).reshape(img.shape)
+                np.copyto(pinned, img)
+                data = dict(data, image=pinned)
+        return idx, data, buf
+
+    def write(job):
+        idx, name, original_size, size, arrays, slot = job
+        if slot is not None:
+            arrays = slot_arrays(slot)
+            ax.release(slot)
+        kp, sc, de = arrays
+        pred = {'keypoints': rescale_keypoints(kp, original_size, size), 'descriptors': de.transpose(), 'scores': sc,
+                'image_size': original_size}
+        write_features(store, name, pred)
+        with lock:
+            names.append((idx, name))
+
+    if tag is not None and hasattr(images, "paths"):
+        indices = [i for i in indices if str(images.paths[i]).find(tag) >= 0]
+    pf = OrderedPrefetch(load, indices, num_workers, window=num_workers + 2,
+                         claim=(lambda: pool.acquire(block=False)) if pool is not None else None)
+    wp = WriterPool(write, workers=writers, maxsize=4 * writers)
+
+    def drain_one():
+        slot = ax.finish()
+        if slot.inbuf is not None:
+            pool.release(slot.inbuf)
+            slot.inbuf = None
+        idx, name, original_size = slot.meta
+        wp.put((idx, name, original_size, np.array(slot.size), None, slot))
+
+    try:
+        while True:
+            pf.top_up()
+            if pf.ready and (ax is None or len(ax.inflight) < depth):
+                idx, data, buf = pf.pop()
+                if tag is not None and data['name'].find(tag) < 0:
+                    if buf is not None:
+                        pool.release(buf)
+                    continue
+                img = data['image']
+                original_size = np.asarray(data['original_size'])
+                if ax is not None and getattr(img, "dtype", None) == np.uint8 and img.ndim == 3:
+                    H, W = img.shape[:2]
+                    ax.submit(img, H, W, tuple(data.get('resize', (W, H))), (idx, data['name'], original_size), inbuf=buf)
+                    continue
+                if ax is not None:
+                    while ax.inflight:          # keep the store in item order: everything queued before this item first
+                        drain_one()
+                if buf is not None:
+                    pool.release(buf)
+                feed, size = _feed_of(model, data)
+                pred = extractor(model, img=feed, topK=top_k, mask=None, conf_th=conf_th, scales=mconf["scales"])
+                wp.put((idx, data['name'], original_size, size, (pred['keypoints'], pred['scores'], pred['descriptors']), None))
+            elif ax is not None and ax.inflight:
+                drain_one()
+            elif pf.exhausted:
+                break
+    finally:
+        pf.close()
+        wp.close()
+    # the serial loop appends in item order; writers finish out of order by a few items
+    names.sort()
+
+
+def _feed_of(model, data):
+    """What main()'s loop hands to the extractor for one item, and the size the key points refer to."""
+    img = data['image']
+    if img.dtype == np.uint8:
+        H, W = img.shape[:2]
+        resize = tuple(data.get('resize', (W, H)))
+        if resize != (W, H):
+            return preprocess(model, img, resize), np.array(resize)      # device: float, cubic resize, / 255
+        return img, np.array((W, H))                                     # converted while conv1a stages its patch
+    return (img[None] if img.ndim == 3 else img), np.array(img.shape[-2:][::-1])
+
+
 def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precision="f16x3", world=1, rank=0,
-         barrier=None, model_and_extractor=None):
+         barrier=None, model_and_extractor=None, num_workers=0, writers=2, depth=3):
     """extract_localization.py:221-279.  ``images``: an ImageDataset (decoded from files, resized per
     conf['preprocessing']) or any indexable / iterable of {'name', 'image': uint8 [H,W,3] RGB or float [3,H,W] in
     [0,1], 'original_size': (w, h)[, 'resize': (w, h)]}.  uint8 input is exact only together with the device resize
@@ -159,6 +275,10 @@ def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precisio
     Multi-GPU: with world > 1 this process takes items rank, rank + world, ... (extract_localization.py:240
     is the loop that shards), writes them to its own part store and, after ``barrier()`` (torch.distributed.barrier
     or equivalent; one process per GPU), rank 0 merges the parts into the final store in item order.
+
+    num_workers > 0: the pipelined loop (_extract_pipelined: that many decoder threads -- the reference's DataLoader
+    uses 4 --, `depth` images in flight on the device, `writers` writer threads); 0: the reference's serial loop.
+    Both write the same groups.
     Returns the final store path (rank 0) or the part path (other ranks)."""
     from .feature_io import open_store, write_features
     from .sharding import shard_indices
@@ -176,22 +296,14 @@ def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precisio
     store = open_store(path, 'a' if world == 1 else 'w')
     names = []
     try:
-        for idx in shard_indices(n_items, rank, world):
+        if num_workers and num_workers > 0:
+            _extract_pipelined(model, extractor, conf, images, list(shard_indices(n_items, rank, world)), tag, store, names,
+                               int(num_workers), max(1, int(writers)), max(1, int(depth)))
+        for idx in (() if num_workers and num_workers > 0 else shard_indices(n_items, rank, world)):
             data = images[idx]
             if tag is not None and data['name'].find(tag) < 0:
                 continue
-            img = data['image']
-            if img.dtype == np.uint8:
-                H, W = img.shape[:2]
-                resize = tuple(data.get('resize', (W, H)))
-                if resize != (W, H):
-                    feed = preprocess(model, img, resize)       # device: float, cubic resize, / 255
-                    size = np.array(resize)
-                else:
-                    feed, size = img, np.array((W, H))          # converted while conv1a stages its patch
-            else:
-                size = np.array(img.shape[-2:][::-1])
-                feed = img[None] if img.ndim == 3 else img
+            feed, size = _feed_of(model, data)
             pred = extractor(model, img=feed, topK=conf["model"]["max_keypoints"], mask=None,
                              conf_th=conf["model"]["conf_th"], scales=conf["model"]["scales"])
             pred['descriptors'] = pred['descriptors'].transpose()

@@ -6,10 +6,19 @@ The reference writes one HDF5 group per image (extract_localization.py:266-270: 
 them back as ``f[name]['keypoints'].__array__()`` (it_loc/localize_cv2.py:571-574,
 hloc/triangulation.py:57-111).  h5py is a third-party dependency that this image does not
 carry: when it imports, the stores below ARE h5py files with exactly that layout; when it does
-not, the same names and arrays go into a directory of ``.npz`` shards (one per group) behind
-the same mapping interface, so callers are written once.
+not, the same names and arrays go behind the same mapping interface into a stand-in, so callers
+are written once.  Two stand-ins:
+
+  PackStore (default, ``<name>.pack/``)  one append-only data file + a text index, read back through
+      one memory map.  Written for the pipelined drivers: a 4 MB feature group is one write(), a
+      pair's two small datasets cost microseconds instead of a zip archive each, and readers on
+      several threads share the map (no per-group open / CRC pass).
+  NpzStore (``<name>.npzdir/``)  one ``.npz`` shard per group; what rounds 2-4 wrote, still read.
 """
+import json
+import mmap
 import os
+import threading
 import zipfile
 
 import numpy as np
@@ -67,6 +76,7 @@ class _NpzGroup:
 class NpzStore:
     """Directory of .npz shards with the h5py.File subset the pipelines use:
     create_group / __getitem__ / __contains__ / keys / close / context manager."""
+    threadsafe_reads = True
 
     def __init__(self, path, mode="a"):
         if mode not in ("r", "a", "w"):
@@ -121,20 +131,193 @@ class NpzStore:
         self.close()
 
 
-def open_store(path, mode="a"):
-    """``path`` ending in .h5 with h5py importable -> h5py.File (the reference's format);
-    otherwise an NpzStore at ``path`` (a trailing .h5 becomes .npzdir)."""
+class _PackGroup:
+    def __init__(self, store, name, entries):
+        self._store, self._name, self._entries = store, name, entries    # key -> (dtype str, shape, offset)
+
+    def create_dataset(self, key, data=None):
+        if key in self._entries:
+            raise ValueError(f"Unable to create dataset (name already exists): {self._name}/{key}")
+        self._store._append(self._name, {key: np.asarray(data)}, new_group=False)
+        return self[key]
+
+    def __getitem__(self, key):
+        dt, shape, off = self._entries[key]
+        return _Dataset(self._store._view(dt, shape, off))
+
+    def __contains__(self, key):
+        return key in self._entries
+
+    def keys(self):
+        return self._entries.keys()
+
+
+class PackStore:
+    """``<path>/data.bin`` (every dataset's bytes, 64-byte aligned, append-only) + ``<path>/index.jsonl`` (one line per
+    write: group name and its datasets' dtype / shape / offset).  A group exists once its index line is on disk, so a
+    killed writer leaves a readable store (trailing data without a line is ignored).  The h5py.File subset the pipelines
+    use -- create_group / __getitem__ / __contains__ / keys / close / context manager -- plus write_group(name, {key:
+    array}) (one lock round, one write() per dataset, one index line): what the writer threads of the pipelined drivers
+    call.  Thread-safe; reads go through ONE shared read-only memory map (remapped when the file has grown)."""
+    threadsafe_reads = True
+
+    def __init__(self, path, mode="a"):
+        if mode not in ("r", "a", "w"):
+            raise ValueError(mode)
+        self.path, self.mode = str(path), mode
+        self._data_path = os.path.join(self.path, "data.bin")
+        self._index_path = os.path.join(self.path, "index.jsonl")
+        if mode == "r" and not os.path.exists(self._index_path):
+            raise FileNotFoundError(self.path)
+        os.makedirs(self.path, exist_ok=True)
+        if mode == "w":
+            for f in (self._data_path, self._index_path):
+                if os.path.exists(f):
+                    os.remove(f)
+        self._lock = threading.Lock()
+        self._groups = {}          # name -> {key: (dtype str, shape tuple, offset)}
+        self._map = None
+        self._map_len = 0
+        good = 0
+        if os.path.exists(self._index_path):
+            with open(self._index_path, "r") as fh:
+                for line in fh:
+                    if not line.endswith("\n"):
+                        break      # a torn last line: the write never completed
+                    good += len(line.encode())
+                    rec = json.loads(line)
+                    g = self._groups.setdefault(rec["g"], {})
+                    for key, (dt, shape, off) in rec["d"].items():
+                        g[key] = (dt, tuple(shape), int(off))
+        self._fd = self._fi = None
+        self._end = 0
+        if mode != "r":
+            if os.path.exists(self._index_path) and os.path.getsize(self._index_path) != good:
+                with open(self._index_path, "r+b") as fh:
+                    fh.truncate(good)       # drop the torn tail so the next line starts on its own
+            self._fd = open(self._data_path, "ab")
+            self._fi = open(self._index_path, "a")
+            self._end = self._fd.tell()
+            # a killed writer may have left data behind the last indexed dataset: new data goes behind it, aligned
+            if self._end % 64:
+                self._fd.write(b"\0" * (64 - self._end % 64))
+                self._end = self._fd.tell()
+
+    # -- writing
+    def _append(self, name, datasets, new_group):
+        if self.mode == "r":
+            raise IOError("store opened read-only")
+        arrs = {k: np.ascontiguousarray(v) for k, v in datasets.items()}
+        with self._lock:
+            if new_group and name in self._groups:
+                raise ValueError(f"Unable to create group (name already exists): {name}")   # h5py's behaviour
+            g = self._groups.setdefault(name, {})
+            rec = {}
+            for k, a in arrs.items():
+                if k in g:
+                    raise ValueError(f"Unable to create dataset (name already exists): {name}/{k}")
+                off = self._end
+                self._fd.write(a.data if a.size else b"")
+                pad = (-a.nbytes) % 64
+                if pad:
+                    self._fd.write(b"\0" * pad)
+                self._end += a.nbytes + pad
+                rec[k] = (a.dtype.str, list(a.shape), off)
+                g[k] = (a.dtype.str, tuple(a.shape), off)
+            self._fi.write(json.dumps({"g": name, "d": rec}, separators=(",", ":")) + "\n")
+
+    def write_group(self, name, datasets):
+        """create_group + one create_dataset per item, as one append."""
+        self._append(name, datasets, new_group=True)
+
+    def create_group(self, name):
+        self._append(name, {}, new_group=True)
+        return _PackGroup(self, name, self._groups[name])
+
+    def flush(self):
+        with self._lock:
+            if self._fd is not None:
+                self._fd.flush()
+                self._fi.flush()
+
+    # -- reading
+    def _view(self, dt, shape, off):
+        dtype = np.dtype(dt)
+        n = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
+        if n == 0:
+            return np.zeros(shape, dtype=dtype)
+        need = off + n * dtype.itemsize
+        with self._lock:
+            if self._map is None or self._map_len < need:
+                if self._fd is not None:
+                    self._fd.flush()
+                with open(self._data_path, "rb") as fh:
+                    size = os.fstat(fh.fileno()).st_size
+                    if size < need:
+                        raise IOError(f"corrupt store {self.path}: dataset beyond the end of data.bin")
+                    self._map = mmap.mmap(fh.fileno(), size, access=mmap.ACCESS_READ)   # older views keep the old map alive
+                    self._map_len = size
+            m = self._map
+        return np.frombuffer(m, dtype=dtype, count=n, offset=off).reshape(shape)
+
+    def __contains__(self, name):
+        return name in self._groups
+
+    def __getitem__(self, name):
+        if name not in self._groups:
+            raise KeyError(name)
+        return _PackGroup(self, name, self._groups[name])
+
+    def keys(self):
+        return sorted(self._groups.keys())
+
+    def close(self):
+        with self._lock:
+            if self._fd is not None:
+                self._fd.close()
+                self._fi.close()
+                self._fd = self._fi = None
+                self.mode = "r"
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+STANDIN = "pack"     # what a '.h5' path becomes when h5py is not importable: "pack" (PackStore) or "npz" (NpzStore)
+
+
+def open_store(path, mode="a", standin=None):
+    """``path`` ending in .h5 with h5py importable -> h5py.File (the reference's format).  Otherwise a stand-in at
+    ``path`` with the trailing .h5 replaced: a PackStore (<name>.pack, the default) or an NpzStore (<name>.npzdir,
+    ``standin="npz"``); reading picks whichever of the two exists."""
     path = str(path)
     if h5py is not None and path.endswith(".h5"):
         return h5py.File(path, mode)
-    if path.endswith(".h5"):
-        path = path[:-3] + ".npzdir"
-    return NpzStore(path, mode)
+    base = path[:-3] if path.endswith(".h5") else None
+    if base is None:
+        if path.endswith(".npzdir"):
+            return NpzStore(path, mode)
+        return PackStore(path, mode)
+    kind = standin or STANDIN
+    if mode == "r" and standin is None:
+        if not os.path.exists(base + ".pack") and os.path.isdir(base + ".npzdir"):
+            kind = "npz"
+    if kind == "npz":
+        return NpzStore(base + ".npzdir", mode)
+    if kind != "pack":
+        raise ValueError(f"unknown stand-in store {kind!r}")
+    return PackStore(base + ".pack", mode)
 
 
 def write_features(store, name, pred):
     """extract_localization.py:266-270: one group per image, one dataset per key, dtypes as produced
     (keypoints / descriptors / scores float64, image_size integer)."""
+    if hasattr(store, "write_group"):
+        store.write_group(name, pred)
+        return store[name]
     grp = store.create_group(name)
     for k, v in pred.items():
         grp.create_dataset(k, data=v)
@@ -145,6 +328,9 @@ def write_matches(store, pair, matches0, scores0):
     """hloc/match_features.py:108-116: matches0 -> int16, matching_scores0 -> fp16."""
     from .match_features import cast_for_storage
     m, s = cast_for_storage(matches0, scores0)
+    if hasattr(store, "write_group"):
+        store.write_group(pair, {"matches0": m, "matching_scores0": s})
+        return store[pair]
     grp = store.create_group(pair)
     grp.create_dataset("matches0", data=m)
     grp.create_dataset("matching_scores0", data=s)

@@ -52,12 +52,116 @@ def load_matcher(conf):
     return Model(conf['model']).eval().to('cuda')
 
 
+def group_pairs(pairs):
+    """[(name0, name1)] -> [(name0, [(pair index, name1), ...])] in order of first appearance: the query-owns-its-matches
+    unit (every pair of a group shares descriptors0, hloc/match_features.py:99-103)."""
+    groups, order = {}, []
+    for idx, (name0, name1) in enumerate(pairs):
+        if name0 not in groups:
+            groups[name0] = []
+            order.append(name0)
+        groups[name0].append((idx, name1))
+    return [(name0, groups[name0]) for name0 in order]
+
+
+def _match_grouped(model, feats, store, pairs, rank, world, done, device=0, max_batch=64, readers=4, cache_bytes=None,
+                   lookahead=8):
+    """The per-pair loop of main() with the reference's read + .float() + .cuda() per pair (hloc/match_features.py:99-105)
+    replaced by device-resident sets: pairs are grouped by their first image, every descriptor set is converted once
+    (sfd2_desc_pack) and kept in HBM as fp16 [n][128] (LRU, sfd2_amd/pipeline.py ResidentSets), one sfd2_match_batch per
+    group (at most `max_batch` pairs per launch), results cast and appended by a writer thread while the next group
+    runs.  Sharding (world > 1) is by group: the process that owns a query runs all its pairs.  Writes the same
+    groups as the per-pair loop (same conversion kernel, same matcher kernels, same casts)."""
+    import ctypes
+    import torch
+    from . import _lib
+    from .feature_io import write_matches
+    from .pipeline import ResidentSets, WriterPool
+    from .sharding import shard_indices
+    ctx = _lib.default_context(device)
+    conf = model.match_conf()
+    groups = group_pairs(pairs)
+    mine = [groups[g] for g in shard_indices(len(groups), rank, world)]
+    # split into launches of <= max_batch pairs, skipping pairs the store already holds (hloc/match_features.py:93-94)
+    units = []
+    for name0, members in mine:
+        todo = [(idx, name1) for idx, name1 in members if names_to_pair(name0, name1) not in store]
+        for i in range(0, len(todo), max_batch):
+            units.append((name0, todo[i:i + max_batch]))
+    if not units:
+        return
+    sets = ResidentSets(ctx, feats, budget=cache_bytes, readers=readers)
+    dev = torch.device("cuda", ctx.device)
+    stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
+
+    class Ring:
+        def __init__(self):
+            self.m = self.s = None
+            self.event = torch.cuda.Event()
+
+        def reserve(self, k, n0):
+            if self.m is None or self.m.numel() < k * n0:
+                self.m = torch.empty(max(k * n0, 1), dtype=torch.int64, pin_memory=True)
+                self.s = torch.empty(max(k * n0, 1), dtype=torch.float32, pin_memory=True)
+            return self.m.numpy()[:k * n0].reshape(k, n0), self.s.numpy()[:k * n0].reshape(k, n0)
+
+    import queue
+    free = queue.Queue()
+    for _ in range(3):
+        free.put(Ring())
+    lock = __import__("threading").Lock()
+
+    def write(job):
+        ring, m, s, name0, members = job
+        ring.event.synchronize()
+        m16, s16 = cast_for_storage(m, s)          # the whole [k, n0] block at once: int16 / fp16 as stored (:114,118)
+        free.put(ring)
+        for i, (idx, name1) in enumerate(members):
+            pair = names_to_pair(name0, name1)
+            if hasattr(store, "write_group"):
+                store.write_group(pair, {"matches0": m16[i], "matching_scores0": s16[i]})
+            else:
+                write_matches(store, pair, m16[i], s16[i])
+            with lock:
+                done.append((idx, pair))
+
+    wp = WriterPool(write, workers=1, maxsize=2, name="sfd2-match-writer")
+    try:
+        for u, (name0, members) in enumerate(units):
+            for name0_next, members_next in units[u:u + 1 + lookahead]:
+                sets.prefetch([name0_next] + [n1 for _, n1 in members_next])
+            q_ptr, n0 = sets.get(name0, u)
+            k = len(members)
+            db = (_lib.DescSet * k)()
+            for i, (_, name1) in enumerate(members):
+                p1, n1 = sets.get(name1, u)
+                db[i] = _lib.DescSet(p1, n1, _lib.DT_F16, _lib.LAYOUT_ND, 1, None, 0, 0)
+            q = _lib.DescSet(q_ptr, n0, _lib.DT_F16, _lib.LAYOUT_ND, 1, None, 0, 0)
+            ring = free.get()
+            m, s = ring.reserve(k, n0)
+            if n0 == 0:
+                pass                                 # nothing to match: empty rows, as the per-pair call returns
+            else:
+                _lib.check(ctx.lib.sfd2_match_batch(ctx.h, ctypes.byref(q), db, k, 128, ctypes.byref(conf), m.ctypes.data,
+                                                    s.ctypes.data, 0, _lib.FLAG_ASYNC))
+            ring.event.record(stream)
+            wp.put((ring, m, s, name0, members))
+            sets.completed_seq = u - 3               # three rings: a unit's buffers are reused only after its event was awaited
+    finally:
+        wp.close()
+        ctx.sync()
+        sets.close()
+    done.sort()
+    return {"loads": sets.loads, "hits": sets.hits, "evictions": sets.evictions}
+
+
 def _out_path(export_dir, features, conf, pairs_name, rank, world):
     base = os.path.join(str(export_dir), f'{features}-{conf["output"]}-{pairs_name}')
     return base + '.h5' if world == 1 else f'{base}.part{rank}of{world}.h5'
 
 
-def main(conf, pair_list, features, export_dir, pairs_name='pairs', world=1, rank=0, barrier=None, model=None):
+def main(conf, pair_list, features, export_dir, pairs_name='pairs', world=1, rank=0, barrier=None, model=None,
+         grouped=None, device=0, cache_bytes=None, readers=4):
     """hloc/match_features.py:48-123: ``pair_list`` holds the pairs file's lines ("name0 name1"),
     ``features`` the feature store's name inside export_dir (:52-54).  Skips pairs already matched in
     either order or already stored (:88-97), writes matches0 int16 / matching_scores0 fp16 per pair
@@ -65,10 +169,16 @@ def main(conf, pair_list, features, export_dir, pairs_name='pairs', world=1, ran
 
     Multi-GPU (:90 is the loop that shards): the de-duplicated pair list is dealt round-robin over
     `world` processes (one per GPU); each writes a part store, and after ``barrier()`` rank 0 merges the parts in
-    pair order.  ``model``: a ready matcher (tests inject a stub on CPU); default = the conf's HIP matcher."""
+    pair order.  ``model``: a ready matcher (tests inject a stub on CPU); default = the conf's HIP matcher.
+
+    grouped (default: on for the HIP nearest-neighbour matcher, off for an injected model): _match_grouped above --
+    device-resident descriptor sets and one batched launch per query instead of the reference's read / cast / upload /
+    launch per pair; shards by query group instead of by pair.  grouped=False is the reference's loop.  Same store."""
     import json
     from .feature_io import open_store, write_matches
     from .sharding import shard_indices
+    if grouped is None:
+        grouped = model is None and conf['model']['name'] == 'nearest_neighbor'
     if model is None:
         model = load_matcher(conf)
     feats = open_store(os.path.join(str(export_dir), features + '.h5'), 'r')
@@ -77,7 +187,9 @@ def main(conf, pair_list, features, export_dir, pairs_name='pairs', world=1, ran
     pairs = unique_pairs(pair_list)
     done = []
     try:
-        for idx in shard_indices(len(pairs), rank, world):
+        if grouped:
+            _match_grouped(model, feats, store, pairs, rank, world, done, device=device, cache_bytes=cache_bytes, readers=readers)
+        for idx in (() if grouped else shard_indices(len(pairs), rank, world)):
             name0, name1 = pairs[idx]
             pair = names_to_pair(name0, name1)
             if pair in store:

@@ -27,6 +27,12 @@ class NearestNeighbor(BaseModel):
     def _init(self, conf):
         pass
 
+    def match_conf(self):
+        """The C-ABI form of this plugin's conf (sfd2_match_conf)."""
+        return _lib.MatchConf(_lib.MATCH_HLOC, int(bool(self.conf['do_mutual_check'])),
+                              float(self.conf['ratio_threshold'] or 0.0), float(self.conf['distance_threshold'] or 0.0),
+                              _lib.SIM_F16X2 if self.conf['sim_mode'] == 'f16x2' else _lib.SIM_F16)
+
     def _forward(self, data):
         d0, d1 = data['descriptors0'], data['descriptors1']   # [B, D, N], [B, D, M]
         is_t = torch is not None and isinstance(d0, torch.Tensor)
@@ -43,9 +49,7 @@ class NearestNeighbor(BaseModel):
         M = a1.shape[2]
         dev = a0.device.index if on_dev and a0.device.index is not None else 0
         ctx = _lib.default_context(dev)
-        conf = _lib.MatchConf(_lib.MATCH_HLOC, int(bool(self.conf['do_mutual_check'])),
-                              float(self.conf['ratio_threshold'] or 0.0), float(self.conf['distance_threshold'] or 0.0),
-                              _lib.SIM_F16X2 if self.conf['sim_mode'] == 'f16x2' else _lib.SIM_F16)
+        conf = self.match_conf()
         if on_dev:
             m = torch.empty((B, N), dtype=torch.int64, device=a0.device)
             s = torch.empty((B, N), dtype=torch.float32, device=a0.device)

@@ -512,7 +512,7 @@ def test_f16x3_det_vs_oracle(model_x3, synth_sd, h, w, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("h,w,seed,topk", [(96, 128, 21, 200), (480, 640, 0, 1024), (1200, 1600, 5, 4096)])
+@pytest.mark.parametrize("h,w,seed,topk", [(96, 128, 21, 200), (480, 640, 0, 1024), (1200, 1600, 5, 4096), (1063, 1600, 65, 4096)])
 def test_f16x3_extract_vs_oracle(model_x3, synth_sd, h, w, seed, topk):
     """Key-point list (order up to near-ties), scores and descriptors (<= 2e-5) of the f16x3 mode against the oracle, up to the
     full BASELINE size."""

@@ -127,9 +127,11 @@ def test_f16c_extract_vs_reference_golden(model_c, golden_dir, tag):
 
 
 @pytest.mark.parametrize("h,w,seed,topk", [(96, 128, 21, 200), (1200, 1600, 31, 4096), (1024, 1024, 61, 4096), (768, 1024, 62, 4096),
-                                            (1536, 2048, 63, 4096), (1600, 1200, 64, 4096)])
+                                            (1536, 2048, 63, 4096), (1600, 1200, 64, 4096), (1063, 1600, 65, 4096)])
 def test_f16c_extract_vs_oracle(model_c, synth_sd, h, w, seed, topk):
-    """Every BASELINE geometry (1600x1200 landscape and portrait, 1024x1024, 1024x768) and 2048x1536, device-resident input."""
+    """Every BASELINE geometry (1600x1200 landscape and portrait, 1024x1024, 1024x768), 2048x1536, and the Aachen database
+    images' 1600x1063 (height a multiple of neither 8 nor 4: resized score map, strided conv2b -- the path every database image
+    of configs[2] takes); device-resident input."""
     import torch
     from sfd2_amd.extractor import extract_resnet_return
     img = synth.make_image(h, w, seed)

@@ -1,0 +1,323 @@
+"""GPU tests of the pipelined host drivers (sfd2_amd/pipeline.py): the decode-pool / asynchronous-extract / writer loop of
+extract_localization.main and the query-grouped, device-resident loop of match_features.main write exactly what the
+reference-shaped serial loops write (dataset by dataset, bit for bit); plus the C-ABI additions they stand on
+(sfd2_extract_record_async, sfd2_desc_pack, SFD2_FLAG_ASYNC with host outputs) and the round-4 ADVICE items on the
+range bookkeeping."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from sfd2_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_ok():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def _model(sd, precision, **opts):
+    if not _gpu_ok():
+        pytest.fail("no MI355X visible: GPU tests cannot run (there is no CPU fallback)")
+    from sfd2_amd.model import ResSegNetV2
+    m = ResSegNetV2(outdim=128, require_stability=True, precision=precision).eval()
+    m.cuda(0)
+    for k, v in opts.items():
+        m.context.set_option(k, v)
+    m.load_state_dict(sd)
+    return m
+
+
+def _stores_equal(a_path, b_path):
+    from sfd2_amd.feature_io import open_store
+    a, b = open_store(a_path, "r"), open_store(b_path, "r")
+    assert list(a.keys()) == list(b.keys()) and len(list(a.keys())) > 0, (list(a.keys()), list(b.keys()))
+    for k in a.keys():
+        assert sorted(a[k].keys()) == sorted(b[k].keys()), k
+        for ds in b[k].keys():
+            x, y = np.asarray(a[k][ds].__array__()), np.asarray(b[k][ds].__array__())
+            assert x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y), (k, ds)
+    return list(a.keys())
+
+
+@pytest.mark.parametrize("precision", ["f16c", "f16x3"])
+def test_pipelined_extract_equals_serial_loop(tmp_path, synth_sd, precision):
+    """files -> feature store: num_workers = 3 (decoder threads, asynchronous extracts, writer threads) against the
+    serial loop, on images of four geometries, two of which go through the device cubic resize (resize_max 160)."""
+    pytest.importorskip("PIL")
+    from PIL import Image
+    from sfd2_amd import extract_localization as el
+    root = tmp_path / "images"
+    (root / "db").mkdir(parents=True)
+    (root / "query").mkdir(parents=True)
+    sizes = [(120, 160), (160, 120), (150, 210), (96, 128), (201, 140), (120, 160), (128, 160), (160, 128), (120, 160), (96, 128), (144, 160)]
+    for i, (h, w) in enumerate(sizes):
+        u8 = (synth.make_image(h, w, 300 + i).transpose(1, 2, 0) * 255).astype(np.uint8)
+        Image.fromarray(u8).save(root / ("db" if i % 3 else "query") / f"im{i:02d}.png")
+    name, conf = next(iter(el.confs.items()))
+    conf = {**conf, "model": {**conf["model"], "max_keypoints": 300}, "preprocessing": {"grayscale": False, "resize_max": 160}}
+    model = _model(synth_sd, precision)
+    ds = el.ImageDataset(root, conf["preprocessing"])
+    assert len(ds) == len(sizes)
+    p_serial = el.main(conf, ds, tmp_path / "serial", model_and_extractor=(model, el.extract_resnet_return), num_workers=0)
+    p_pipe = el.main(conf, ds, tmp_path / "pipe", model_and_extractor=(model, el.extract_resnet_return), num_workers=3, writers=2, depth=3)
+    names = _stores_equal(p_pipe, p_serial)
+    assert len(names) == len(sizes)
+    # tag filter and the two-rank sharding go through the same loop
+    p_tag_s = el.main(conf, ds, tmp_path / "tag_s", model_and_extractor=(model, el.extract_resnet_return), tag="query")
+    p_tag_p = el.main(conf, ds, tmp_path / "tag_p", model_and_extractor=(model, el.extract_resnet_return), tag="query", num_workers=2)
+    assert all(n.startswith("query/") for n in _stores_equal(p_tag_p, p_tag_s))
+    assert model.context.range_status()["fallbacks"] == 0
+
+
+def test_pipelined_extract_in_memory_items_and_float_images(tmp_path, synth_sd):
+    """Items that are not files: uint8 arrays (asynchronous path) mixed with float [3,H,W] images (synchronous call
+    between the same decode and writer stages); item order is kept across the two kinds."""
+    from sfd2_amd import extract_localization as el
+    model = _model(synth_sd, "f16c")
+    items = []
+    for i in range(7):
+        f = synth.make_image(96, 128, 400 + i)
+        if i in (2, 5):
+            items.append({"name": f"m/{i}.png", "image": f, "original_size": (128, 96)})
+        else:
+            items.append({"name": f"m/{i}.png", "image": (f.transpose(1, 2, 0) * 255).astype(np.uint8), "original_size": (256, 192)})
+    name, conf = next(iter(el.confs.items()))
+    conf = {**conf, "model": {**conf["model"], "max_keypoints": 150}}
+    a = el.main(conf, items, tmp_path / "s", model_and_extractor=(model, el.extract_resnet_return))
+    b = el.main(conf, items, tmp_path / "p", model_and_extractor=(model, el.extract_resnet_return), num_workers=2)
+    assert _stores_equal(b, a) == sorted(it["name"] for it in items)
+
+
+def test_pipelined_extract_repeats_saturated_images_in_strict_mode(tmp_path):
+    """SFD2_PREC_F16C, exponents zero, weights x 2^10: every image saturates.  The per-image record reports it, the
+    pipelined loop repeats each such image synchronously (-> SFD2_PREC_F16X3 inside the library), and the store equals
+    the serial loop's (whose synchronous extracts fall back the same way)."""
+    from sfd2_amd import extract_localization as el
+    sd = synth.make_state_dict(0, gain_log2=10)
+    model = _model(sd, "f16c", auto_range=0, range_fallback=1)
+    items = [{"name": f"s/{i}.png", "image": (synth.make_image(96, 128, 500 + i).transpose(1, 2, 0) * 255).astype(np.uint8),
+              "original_size": (128, 96)} for i in range(4)]
+    name, conf = next(iter(el.confs.items()))
+    conf = {**conf, "model": {**conf["model"], "max_keypoints": 100}}
+    a = el.main(conf, items, tmp_path / "s", model_and_extractor=(model, el.extract_resnet_return))
+    n_serial = model.context.range_status(reset=True)["fallbacks"]
+    b = el.main(conf, items, tmp_path / "p", model_and_extractor=(model, el.extract_resnet_return), num_workers=2)
+    st = model.context.range_status()
+    assert n_serial == 4 and st["fallbacks"] == 8, (n_serial, st)
+    _stores_equal(b, a)
+    want = orc.extract_resnet_return(sd, items[0]["image"].transpose(2, 0, 1).astype(np.float32) / 255.0, conf_th=0.001, topK=100)
+    from sfd2_amd.feature_io import open_store
+    kp = open_store(b, "r")["s/0.png"]["keypoints"].__array__()
+    assert len({tuple(p) for p in kp} & {tuple(p) for p in want["keypoints"]}) >= 0.98 * len(want["keypoints"])
+
+
+def test_extract_record_async_and_host_outputs(synth_sd):
+    """SFD2_FLAG_ASYNC with (pinned) host outputs + sfd2_extract_record_async == the synchronous call."""
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    model = _model(synth_sd, "f16c")
+    ctx = model.context
+    K = 256
+    imgs = [(synth.make_image(96, 128, 600 + i).transpose(1, 2, 0) * 255).astype(np.uint8) for i in range(3)]
+    want = [extract_resnet_return(model, im, conf_th=0.001, topK=K) for im in imgs]
+    pins = [torch.from_numpy(im).pin_memory() for im in imgs]
+    outs = []
+    for p in pins:
+        kp = torch.empty((K, 2), dtype=torch.float32, pin_memory=True)
+        sc = torch.empty((K,), dtype=torch.float32, pin_memory=True)
+        de = torch.empty((K, 128), dtype=torch.float32, pin_memory=True)
+        rec = torch.zeros(4, dtype=torch.int32, pin_memory=True)
+        n = ctypes.c_int(0)
+        _lib.check(ctx.lib.sfd2_extract(ctx.h, p.data_ptr(), 0, 96, 128, 0.001, K, _lib.FLAG_ASYNC | _lib.FLAG_IMG_U8_HWC,
+                                        kp.data_ptr(), sc.data_ptr(), de.data_ptr(), 0, K, ctypes.byref(n)))
+        assert n.value == -1
+        _lib.check(ctx.lib.sfd2_extract_record_async(ctx.h, rec.data_ptr(), 0))
+        outs.append((kp, sc, de, rec))
+    ctx.sync()
+    for (kp, sc, de, rec), w in zip(outs, want):
+        n = int(rec[0])
+        assert n == len(w["keypoints"]) and int(rec[1]) >= n and int(rec[2]) == 0 and int(rec[3]) == 0
+        np.testing.assert_array_equal(kp.numpy()[:n].astype(np.float64), w["keypoints"])
+        np.testing.assert_array_equal(sc.numpy()[:n].astype(np.float64), w["scores"])
+        np.testing.assert_array_equal(de.numpy()[:n].astype(np.float64), w["descriptors"])
+    # the records moved the maxima into the history: the status still shows them, nothing is saturated
+    st = ctx.range_status()
+    assert not st["saturated"] and max(v["max_stored"] for v in st["tensors"].values()) > 0.0
+
+
+def test_recalibration_clears_recorded_maxima():
+    """maxima recorded under other exponents say nothing about the new scaling -- sfd2_set_act_exponents /
+    sfd2_calibrate_range clear the running words and both histories."""
+    import torch
+    sd = synth.make_state_dict(0)
+    model = _model(sd, "f16c")
+    ctx = model.context
+    u8 = (synth.make_image(96, 128, 700).transpose(1, 2, 0) * 255).astype(np.uint8)
+    e0, _ = ctx.act_exponents()
+    ctx.set_act_exponents(e0 + 12)                       # everything 4096 x larger as stored: saturates
+    K = 64
+    kp = torch.empty((K, 2), dtype=torch.float32, device="cuda")
+    sc = torch.empty((K,), dtype=torch.float32, device="cuda")
+    de = torch.empty((K, 128), dtype=torch.float32, device="cuda")
+    rec = torch.zeros(4, dtype=torch.int32, pin_memory=True)
+    n = ctypes.c_int(0)
+    p = torch.from_numpy(u8).cuda()
+    for with_record in (False, True):                    # running words only / folded into the device-side history
+        _lib.check(ctx.lib.sfd2_extract(ctx.h, p.data_ptr(), 1, 96, 128, 0.001, K, _lib.FLAG_ASYNC | _lib.FLAG_IMG_U8_HWC,
+                                        kp.data_ptr(), sc.data_ptr(), de.data_ptr(), 1, K, ctypes.byref(n)))
+        if with_record:
+            _lib.check(ctx.lib.sfd2_extract_record_async(ctx.h, rec.data_ptr(), 0))
+        ctx.sync()
+        assert ctx.range_status()["saturated"]
+        if with_record:
+            assert int(rec[2]) != 0
+        ctx.set_act_exponents(e0 + 12)                   # same values: still a new scaling as far as the records go
+        st = ctx.range_status()
+        assert not st["saturated"] and all(v["max_stored"] == 0.0 for v in st["tensors"].values()), st
+    ctx.set_act_exponents(e0)
+
+
+def test_async_leftover_does_not_trigger_fallback(synth_sd):
+    """The leftover case proper: two contexts' worth of state in one -- an asynchronous extract of a huge-gain image saturates,
+    then a synchronous extract of a normal image must return the compensated mode's own result, not the strict repeat."""
+    import torch
+    from sfd2_amd.extractor import extract_resnet_return
+    model = _model(synth_sd, "f16c")
+    ctx = model.context
+    ok = (synth.make_image(96, 128, 710).transpose(1, 2, 0) * 255).astype(np.uint8)
+    ref = extract_resnet_return(model, ok, conf_th=0.001, topK=64)
+    assert ctx.range_status(reset=True)["fallbacks"] == 0
+    # an image far outside the calibrated range: float input x 4000 (the network is linear up to the first ReLU, BatchNorm keeps the gain)
+    hot = (synth.make_image(96, 128, 711) * 4000.0).astype(np.float32)
+    K = 64
+    kp = torch.empty((K, 2), dtype=torch.float32, device="cuda")
+    sc = torch.empty((K,), dtype=torch.float32, device="cuda")
+    de = torch.empty((K, 128), dtype=torch.float32, device="cuda")
+    n = ctypes.c_int(0)
+    p = torch.from_numpy(hot).cuda()
+    _lib.check(ctx.lib.sfd2_extract(ctx.h, p.data_ptr(), 1, 96, 128, 0.001, K, _lib.FLAG_ASYNC, kp.data_ptr(), sc.data_ptr(),
+                                    de.data_ptr(), 1, K, ctypes.byref(n)))
+    ctx.sync()
+    got = extract_resnet_return(model, ok, conf_th=0.001, topK=64)
+    st = ctx.range_status()
+    assert st["fallbacks"] == 0, st                                  # the synchronous call was judged on its own image
+    if not st["saturated"]:
+        pytest.skip("the x 4000 image did not saturate on this checkpoint family: nothing to guard")
+    np.testing.assert_array_equal(got["keypoints"], ref["keypoints"])
+    np.testing.assert_array_equal(got["descriptors"], ref["descriptors"])
+
+
+def _feature_store(path, sets):
+    from sfd2_amd.feature_io import open_store, write_features
+    st = open_store(path, "w")
+    for name, d in sets.items():
+        n = d.shape[0]
+        write_features(st, name, {"keypoints": np.zeros((n, 2)), "descriptors": d.astype(np.float64).transpose(),
+                                  "scores": np.zeros((n,)), "image_size": np.array([640, 480])})
+    st.close()
+
+
+@pytest.mark.parametrize("conf_name", ["NNM", "NNR", "ONN"])
+def test_grouped_match_driver_equals_per_pair_loop(tmp_path, conf_name):
+    """feature store -> match store: query-grouped, device-resident sets, batched launches (with a cache so small that
+    sets are evicted and packed again) against the reference-shaped per-pair loop.  Sets of different sizes, duplicate
+    and reversed pairs, a query that is also a database image."""
+    from sfd2_amd import match_features as mf
+    rs = np.random.RandomState(5)
+    sizes = {"query/q0.jpg": 700, "query/q1.jpg": 1024, "query/q2.jpg": 333, "db/a.jpg": 1024, "db/b.jpg": 512, "db/c.jpg": 37,
+             "db/d.jpg": 900, "db/e.jpg": 1024, "db/f.jpg": 4}
+    base = synth.make_descriptors(1024, seed=9)
+    sets = {}
+    for i, (name, n) in enumerate(sizes.items()):
+        d = base[rs.permutation(1024)[:n]] + 0.05 * rs.standard_normal((n, 128)).astype(np.float32)
+        sets[name] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    feats = "feats-x"
+    _feature_store(str(tmp_path / (feats + ".h5")), sets)
+    dbs = [n for n in sizes if n.startswith("db/")]
+    pairs = [f"{q} {d}" for q in sizes if q.startswith("query/") for d in dbs]
+    pairs += ["db/a.jpg db/b.jpg", "db/b.jpg db/a.jpg", "db/a.jpg db/d.jpg", "query/q0.jpg db/a.jpg", "db/e.jpg query/q1.jpg"]
+    rs.shuffle(pairs)
+    a = mf.main(mf.confs[conf_name], pairs, feats, tmp_path, pairs_name="serial", grouped=False)
+    b = mf.main(mf.confs[conf_name], pairs, feats, tmp_path, pairs_name="grouped", grouped=True, cache_bytes=6 * 1024 * 128 * 2)
+    keys = _stores_equal(b, a)
+    assert len(keys) == len(mf.unique_pairs(pairs))
+    from sfd2_amd.feature_io import open_store
+    g = open_store(b, "r")[mf.names_to_pair("query/q1.jpg", "db/a.jpg")]
+    assert g["matches0"].dtype == np.int16 and g["matching_scores0"].dtype == np.float16 and (g["matches0"].__array__() >= 0).mean() > 0.5
+    # a second run finds every pair stored and does nothing (hloc/match_features.py:93-94)
+    b2 = mf.main(mf.confs[conf_name], pairs, feats, tmp_path, pairs_name="grouped", grouped=True)
+    assert b2 == b and _stores_equal(b2, a) == keys
+
+
+def test_desc_pack_bit_identical_to_inline_conversion():
+    """sfd2_desc_pack is the conversion sfd2_match* runs on its inputs: packed sets (fp16 [n][128], resident) give the
+    same matches and scores as the float64 / float32 originals in either layout, with and without a row selection."""
+    import torch
+    ctx = _lib.default_context(0)
+    rs = np.random.RandomState(3)
+    d0 = synth.make_descriptors(900, seed=1)
+    d1 = synth.make_descriptors(777, seed=2)
+    conf = _lib.MatchConf(_lib.MATCH_HLOC, 1, 0.0, 0.0, _lib.SIM_F16)
+
+    def run(q, db):
+        m = np.empty((q.n,), dtype=np.int64)
+        s = np.empty((q.n,), dtype=np.float32)
+        _lib.check(ctx.lib.sfd2_match_batch(ctx.h, ctypes.byref(q), ctypes.byref(db), 1, 128, ctypes.byref(conf), m.ctypes.data,
+                                            s.ctypes.data, 0, 0))
+        return m, s
+
+    rows = np.sort(rs.permutation(777)[:300]).astype(np.int32)
+    for dtype, code in ((np.float64, _lib.DT_F64), (np.float32, _lib.DT_F32)):
+        for layout in (_lib.LAYOUT_ND, _lib.LAYOUT_DN):
+            a0 = np.ascontiguousarray((d0 if layout == _lib.LAYOUT_ND else d0.T).astype(dtype))
+            a1 = np.ascontiguousarray((d1 if layout == _lib.LAYOUT_ND else d1.T).astype(dtype))
+            for r in (None, rows):
+                q = _lib.DescSet(a0.ctypes.data, 900, code, layout, 0, None, 0, 0)
+                db = _lib.DescSet(a1.ctypes.data, 777, code, layout, 0, None if r is None else r.ctypes.data, 0 if r is None else len(r), 0)
+                want = run(q, db)
+                p0 = torch.empty((900, 128), dtype=torch.float16, device="cuda")
+                p1 = torch.empty((777 if r is None else len(r), 128), dtype=torch.float16, device="cuda")
+                _lib.check(ctx.lib.sfd2_desc_pack(ctx.h, ctypes.byref(q), 128, p0.data_ptr(), 0))
+                _lib.check(ctx.lib.sfd2_desc_pack(ctx.h, ctypes.byref(db), 128, p1.data_ptr(), _lib.FLAG_ASYNC))
+                ctx.sync()
+                got = run(_lib.DescSet(p0.data_ptr(), 900, _lib.DT_F16, _lib.LAYOUT_ND, 1, None, 0, 0),
+                          _lib.DescSet(p1.data_ptr(), p1.shape[0], _lib.DT_F16, _lib.LAYOUT_ND, 1, None, 0, 0))
+                if r is not None:          # packed sets report positions in the packed set; the row-selected call reports the caller's rows
+                    hit = got[0] >= 0
+                    got[0][hit] = r[got[0][hit]]
+                np.testing.assert_array_equal(got[0], want[0])
+                np.testing.assert_array_equal(got[1], want[1])
+    # the packed bytes are fp16(float(x)) row-major
+    np.testing.assert_array_equal(p0.cpu().numpy(), d0.astype(np.float32).astype(np.float16))
+
+
+def test_f16x3_debug_activation_after_throughput_extract(synth_sd):
+    """VERDICT r4 weak #10 / ADVICE r3: after an f16x3 sfd2_extract on its throughput kernels (tensors exist as hi / lo' planes
+    only) sfd2_debug_activation must refuse the tensors that were not written as fp32 -- not hand back what an earlier sfd2_det
+    left in the buffers -- and still serve the ones that were."""
+    from sfd2_amd.extractor import extract_resnet_return
+    model = _model(synth_sd, "f16x3")
+    ctx = model.context
+    img = synth.make_image(96, 128, 800)
+    x = orc.norm_rgb(img)
+    model.det(x[None])                                             # parity entry point: every tensor readable
+    before = ctx.debug_activation("conv3a")
+    assert np.isfinite(before).all() and before.shape == (256, 24, 32)
+    extract_resnet_return(model, synth.make_image(96, 128, 801)[None], conf_th=0.001, topK=100)   # another image, throughput path
+    for name in ("conv1a", "bn1b", "conv2a", "bn2b", "conv3a", "bn3b", "conv4.0", "conv4.1", "conv4.0.bn1", "conv4.2.bn2", "convDa.0", "convDa"):
+        with pytest.raises(RuntimeError, match="not materialised"):
+            ctx.debug_activation(name)
+    taps = {}
+    orc.det(synth_sd, orc.norm_rgb(synth.make_image(96, 128, 801)), taps)
+    got = ctx.debug_activation("conv4.2")
+    assert np.abs(got - taps["conv4.2"]).max() <= 2e-5 * max(1.0, np.abs(taps["conv4.2"]).max())
+    model.det(x[None])                                             # and the parity entry point makes them readable again
+    np.testing.assert_array_equal(ctx.debug_activation("conv3a"), before)

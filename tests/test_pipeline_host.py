@@ -1,0 +1,201 @@
+"""CPU tests of the pipelined drivers' host side (no GPU: stub extractor): the stand-in stores, the ordered decode pool,
+the writer pool, and that extract_localization.main writes the same store with num_workers > 0 as with the serial loop."""
+import json
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from sfd2_amd import feature_io as fio
+
+
+def test_pack_store_layout_roundtrip_and_reopen(tmp_path):
+    p = str(tmp_path / "feats-x.h5")
+    st = fio.open_store(p, "a")
+    if fio.h5py is not None:
+        pytest.skip("h5py present: the stand-in is not used")
+    assert isinstance(st, fio.PackStore) and st.path.endswith("feats-x.pack")
+    g = st.create_group("db/1.jpg")
+    g.create_dataset("keypoints", data=np.arange(8.).reshape(4, 2))
+    g.create_dataset("image_size", data=np.array([640, 480]))
+    assert "keypoints" in g and sorted(g.keys()) == ["image_size", "keypoints"]
+    st.write_group("query/2.jpg", {"descriptors": np.ones((128, 3)), "scores": np.zeros((0,)), "h": np.float16([1.5, 2.5])})
+    with pytest.raises(ValueError, match="already exists"):
+        st.create_group("db/1.jpg")
+    with pytest.raises(ValueError, match="already exists"):
+        st["db/1.jpg"].create_dataset("keypoints", data=np.zeros(1))
+    # readable while open for writing (the drivers' `pair in store` / resume checks)
+    np.testing.assert_array_equal(st["db/1.jpg"]["keypoints"].__array__(), np.arange(8.).reshape(4, 2))
+    st.close()
+    rd = fio.open_store(p, "r")
+    assert rd.keys() == ["db/1.jpg", "query/2.jpg"] and "db/1.jpg" in rd and "nope" not in rd
+    with pytest.raises(KeyError):
+        rd["nope"]
+    g = rd["query/2.jpg"]
+    assert g["descriptors"].shape == (128, 3) and g["descriptors"].dtype == np.float64
+    assert g["scores"].shape == (0,) and g["h"].dtype == np.float16 and g["h"][1] == 2.5
+    assert rd["db/1.jpg"]["image_size"][()].tolist() == [640, 480]
+    with pytest.raises(IOError):
+        rd.write_group("x", {})
+    rd.close()
+    # append to an existing store; a torn index line (killed writer) is ignored and overwritten data is never referenced
+    with open(os.path.join(st.path, "index.jsonl"), "a") as f:
+        f.write('{"g":"torn","d":{"a":["<f8",[2],')
+    with open(os.path.join(st.path, "data.bin"), "ab") as f:
+        f.write(b"xyz")
+    ap = fio.open_store(p, "a")
+    assert "torn" not in ap
+    ap.write_group("later", {"v": np.arange(5, dtype=np.int16)})
+    ap.close()
+    rd = fio.open_store(p, "r")
+    np.testing.assert_array_equal(rd["later"]["v"].__array__(), np.arange(5, dtype=np.int16))
+    assert rd["query/2.jpg"]["h"][0] == 1.5
+    # mode 'w' starts empty
+    assert fio.open_store(p, "w").keys() == []
+
+
+def test_pack_store_concurrent_writers_and_readers(tmp_path):
+    if fio.h5py is not None:
+        pytest.skip("h5py present")
+    st = fio.open_store(str(tmp_path / "m.h5"), "w")
+
+    def work(t):
+        for i in range(200):
+            st.write_group(f"t{t}_{i}", {"matches0": np.full(64, t * 1000 + i, dtype=np.int16), "s": np.full(3, i, dtype=np.float16)})
+            if i % 50 == 49:
+                assert st[f"t{t}_{i - 7}"]["matches0"][0] == t * 1000 + i - 7
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    st.close()
+    rd = fio.open_store(str(tmp_path / "m.h5"), "r")
+    assert len(rd.keys()) == 800
+    for t in range(4):
+        for i in (0, 57, 199):
+            assert (rd[f"t{t}_{i}"]["matches0"].__array__() == t * 1000 + i).all()
+
+
+def test_open_store_reads_round4_npz_shards(tmp_path):
+    if fio.h5py is not None:
+        pytest.skip("h5py present")
+    old = fio.open_store(str(tmp_path / "f.h5"), "w", standin="npz")
+    fio.write_features(old, "a/b.jpg", {"keypoints": np.zeros((2, 2)), "image_size": np.array([3, 4])})
+    old.close()
+    rd = fio.open_store(str(tmp_path / "f.h5"), "r")
+    assert isinstance(rd, fio.NpzStore) and rd.keys() == ["a/b.jpg"]
+    with pytest.raises(ValueError):
+        fio.open_store(str(tmp_path / "g.h5"), "w", standin="zip")
+
+
+def test_ordered_prefetch_keeps_order_and_deals_buffers_in_order():
+    from sfd2_amd.pipeline import OrderedPrefetch
+    import queue
+    free = queue.Queue()
+    for b in range(3):
+        free.put(b)
+    claimed = []
+
+    def claim():
+        try:
+            b = free.get(block=False)
+        except queue.Empty:
+            return None
+        claimed.append(b)
+        return b
+
+    def load(idx, buf):
+        time.sleep(0.002 * ((idx * 7) % 5))      # later items often finish first
+        return idx, buf
+
+    pf = OrderedPrefetch(load, range(40), workers=4, window=6, claim=claim)
+    got = []
+    while True:
+        pf.top_up()
+        if pf.ready:
+            idx, buf = pf.pop()
+            got.append(idx)
+            free.put(buf)                        # the consumer gives the buffer back: with 3 buffers the pool never runs further ahead
+        elif pf.exhausted:
+            break
+    pf.close()
+    assert got == list(range(40)) and len(claimed) == 40
+    # no claim: plain windowed prefetch
+    pf = OrderedPrefetch(lambda i, r: i * i, range(10), workers=3, window=4)
+    out = []
+    while True:
+        pf.top_up()
+        if pf.ready:
+            out.append(pf.pop())
+        elif pf.exhausted:
+            break
+    pf.close()
+    assert out == [i * i for i in range(10)]
+
+
+def test_writer_pool_surfaces_errors():
+    from sfd2_amd.pipeline import WriterPool
+    seen = []
+
+    def fn(job):
+        if job == 3:
+            raise RuntimeError("disk full")
+        seen.append(job)
+    wp = WriterPool(fn, workers=2)
+    for j in range(6):
+        try:
+            wp.put(j)
+        except RuntimeError:
+            break
+    with pytest.raises(RuntimeError, match="disk full"):
+        wp.close()
+    assert 3 not in seen
+
+
+def _stub_extractor(model, img, topK, mask, conf_th, scales):
+    a = np.asarray(img, dtype=np.float64).reshape(-1)
+    n = 5 + int(a[:7].sum()) % 11
+    rs = np.random.RandomState(int(a[:16].sum() * 1000) % (2 ** 31))
+    return {"keypoints": rs.randint(0, 100, size=(n, 2)).astype(np.float64), "descriptors": rs.rand(n, 128),
+            "scores": np.sort(rs.rand(n))[::-1].copy()}
+
+
+def test_pipelined_main_equals_serial_main_with_stub_extractor(tmp_path):
+    """extract_localization.main(num_workers=3) -- decode pool, synchronous stub extractor, writer threads -- writes the
+    store the serial loop writes; with the tag filter; and sharded over two ranks + merge."""
+    from sfd2_amd import extract_localization as el
+    rs = np.random.RandomState(0)
+    items = [{"name": f"{'query' if i % 4 == 0 else 'db'}/im{i:03d}.jpg", "image": rs.rand(3, 24, 32).astype(np.float32),
+              "original_size": (64, 48)} for i in range(23)]
+    name, conf = next(iter(el.confs.items()))
+    me = (None, _stub_extractor)
+
+    def equal(a, b):
+        x, y = fio.open_store(a, "r"), fio.open_store(b, "r")
+        assert list(x.keys()) == list(y.keys()) and len(list(x.keys())) > 0
+        for k in x.keys():
+            for ds in y[k].keys():
+                u, v = np.asarray(x[k][ds].__array__()), np.asarray(y[k][ds].__array__())
+                assert u.dtype == v.dtype and np.array_equal(u, v), (k, ds)
+        return list(x.keys())
+
+    a = el.main(conf, items, tmp_path / "s", model_and_extractor=me)
+    b = el.main(conf, items, tmp_path / "p", model_and_extractor=me, num_workers=3, writers=2)
+    assert len(equal(b, a)) == 23
+    at = el.main(conf, items, tmp_path / "st", model_and_extractor=me, tag="query")
+    bt = el.main(conf, items, tmp_path / "pt", model_and_extractor=me, tag="query", num_workers=2)
+    assert len(equal(bt, at)) == 6
+    # two ranks in turn (no barrier needed in one process), pipelined, then rank 0's merge
+    el.main(conf, items, tmp_path / "w", model_and_extractor=me, world=2, rank=1, num_workers=2)
+    m = el.main(conf, items, tmp_path / "w", model_and_extractor=me, world=2, rank=0, num_workers=2)
+    assert len(equal(m, a)) == 23
+    idx = json.load(open(str(tmp_path / "w" / (conf["output"] + ".part1of2.h5.index.json"))))
+    assert [i for i, _ in idx] == list(range(1, 23, 2))
+
+
+def test_group_pairs_is_query_major_in_first_appearance_order():
+    from sfd2_amd import match_features as mf
+    pairs = mf.unique_pairs(["q1 a", "q0 a", "q1 b", "a q1", "q0 c", "q1 c", "q0 a"])
+    assert pairs == [("q1", "a"), ("q0", "a"), ("q1", "b"), ("q0", "c"), ("q1", "c")]
+    assert mf.group_pairs(pairs) == [("q1", [(0, "a"), (2, "b"), (4, "c")]), ("q0", [(1, "a"), (3, "c")])]
