@@ -71,6 +71,15 @@ __device__ __forceinline__ h4_t cvt4c(float a, float b, float c, float d)
 #ifndef SFD2_PP_KXM
 #define SFD2_PP_KXM 1
 #endif
+// SFD2_PP_RING3 (compensated instantiations, not X3): the K loop takes the chunks INTERLEAVED -- hi chunk of channels 32 k, then the corr
+// chunk of the same channels -- and the filter stages go through a ring of THREE buffers, requested two stages ahead, with counted waits
+// that leave the newest requests in flight.  Why: a hi chunk is bound by its MFMAs (9 units x 16 x 32 cycles, two waves per SIMD: 9.2 k
+// cycles against 6.3 k for its 111 KB of operand copies at ~18 B/clk/CU), a corr chunk by its copies (4.8 k of MFMA against the same
+// 6.3 k).  Run as two blocks of eight the second block waits for its copies throughout; interleaved, with two stages of lookahead,
+// the copies average over both kinds (222 KB per 14 k cycles of MFMA issue).
+#ifndef SFD2_PP_RING3
+#define SFD2_PP_RING3 0
+#endif
 // KXM = 1: the nine taps of a chunk run column by column (stage = one filter COLUMN kx, units ky = 0, 1, 2), so that the
 // pixel fragments of patch row r serve output rows r, r - 1, r - 2 of the same stage from registers: a stage reads six
 // patch rows once (4 + 1 + 1 over its three units) instead of four rows per unit -- 8 fragment reads per unit instead of 12.
@@ -118,10 +127,12 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     constexpr bool S2D = (COMP & 128) != 0;                // the OUTPUT is stored space-to-depth: [Ho / 2][Wo / 2][(y & 1) * 2 + (x & 1)][CoutP] (conv2b_s2d_kernel.hip; Ho, Wo even)
     static_assert(!B6 || F6, "fp6 pixel operands come with fp6 filter strings");
     constexpr int SSN = F6 ? 3 : 2;                        // arrays per tile parity in SSb: scale, shift (, the fp6 filters' scale bytes)
+    constexpr bool RING3 = SFD2_PP_RING3 && (COMP & 1) && !(COMP & 4) && KXM && !ABL;   // interleaved chunks, three filter buffers (above)
+    constexpr int NFB = RING3 ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Xs = smem;                              // [2][PP_XBYTES]
-    unsigned char *Fs = smem + 2 * PP_XBYTES;              // [2][PP_FBYTES]
-    float *SSb = reinterpret_cast<float *>(Fs + 2 * PP_FBYTES);  // [2] x (scale[128], shift[128]): one set per tile parity
+    unsigned char *Fs = smem + 2 * PP_XBYTES;              // [NFB][PP_FBYTES]
+    float *SSb = reinterpret_cast<float *>(Fs + NFB * PP_FBYTES);  // [2] x (scale[128], shift[128]): one set per tile parity
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,7 +164,8 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
                 const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;                                        \
                 if (iy >= 0 && iy < H && ix >= 0 && ix < W) off = (iy * W + ix) * Cin + slot * 8;      \
             }                                                                                          \
-            xoff[i] = off;                                                                             \
+            /* RING3: BYTE offsets for buffer_load ... lds; outside the image = beyond the descriptor's range, which reads zeros */ \
+            xoff[i] = RING3 ? (off >= 0 ? off * 2 : (int)0x80000000) : off;                            \
         }                                                                                              \
         _Pragma("unroll") for (int i = 0; i < PP_FPW; ++i) {                                           \
             const int r = (wave * PP_FPW + i) * 16 + (lane >> 2);   /* row of the stage tile: tap r / 128, filter r % 128 */ \
@@ -163,6 +175,10 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
         }                                                                                              \
     }
     int tile = blockIdx.x;
+    // RING3: the two input planes as buffer descriptors (patch copies by buffer_load ... lds, per-lane byte offsets)
+    const int plane_bytes = (int)((size_t)H * W * Cin * sizeof(half_t));
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(in), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(RING3 ? in_c : in), 0, plane_bytes, 0x00020000);
     constexpr bool RANGE = (COMP & 2) && !(COMP & 4);      // compensated output: keep the largest value in front of the saturation
     unsigned int smax = 0;                                 // (wave-uniform: a scalar register across the tiles)
 #ifdef SFD2_PP_CU_STAGGER
@@ -184,9 +200,19 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #define PP_ISSUE_X1(chunk_, buf_, i_)                                                                  \
     do {                                                                                               \
         const int pc_ = (wave + 8 * (i_) < PP_XCH) ? wave + 8 * (i_) : PP_XCH - 1;                     \
+        if constexpr (RING3) {   /* one 32-bit offset per piece and lane instead of a 64-bit address per piece, lane AND plane */ \
+            if ((chunk_) & 1)                                                                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_c, (lds_void3_t *)(Xs + (buf_)*PP_XBYTES + pc_ * 1024), 16, xoff[i_], ((chunk_) >> 1) * (PP_CC * 2), 0, 0); \
+            else                                                                                       \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lds_void3_t *)(Xs + (buf_)*PP_XBYTES + pc_ * 1024), 16, xoff[i_], ((chunk_) >> 1) * (PP_CC * 2), 0, 0); \
+            break;                                                                                     \
+        }                                                                                              \
         /* X3: chunks [0, 2 NCH) read the hi plane (against the hi, then the lo' filters), [2 NCH, 3 NCH) the lo' plane */ \
-        const int pch_ = (COMP & 4) ? ((chunk_) >= NCH ? (chunk_) - NCH - ((chunk_) >= 2 * NCH ? NCH : 0) : (chunk_)) : (chunk_); \
-        const half_t *pl_ = (COMP & 4) ? ((chunk_) >= 2 * NCH ? in_c : in)                             \
+        /* RING3: chunk 2 k = channels 32 k of the hi plane, 2 k + 1 = the same channels of the corr plane */ \
+        const int pch_ = RING3 ? ((chunk_) >> 1)                                                       \
+                               : (COMP & 4) ? ((chunk_) >= NCH ? (chunk_) - NCH - ((chunk_) >= 2 * NCH ? NCH : 0) : (chunk_)) : (chunk_); \
+        const half_t *pl_ = RING3 ? (((chunk_) & 1) ? in_c : in)                                       \
+                          : (COMP & 4) ? ((chunk_) >= 2 * NCH ? in_c : in)                             \
                                        : (((COMP & 1) && (chunk_) >= NCH) ? in_c - (size_t)NCH * PP_CC : in); \
         const half_t *src_ = xoff[i_] >= 0 ? pl_ + (size_t)xoff[i_] + pch_ * PP_CC : zero_page + (lane & 3) * 8; \
         __builtin_amdgcn_global_load_lds((gbl_void3_t *)src_,                                          \
@@ -195,7 +221,9 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #define PP_ISSUE_F(stage_, buf_)                                                                       \
     _Pragma("unroll") for (int i_ = 0; i_ < PP_FPW; ++i_) {                                            \
         /* X3: the filter array is [hi chunks][lo' chunks]; the K loop's chunk sequence uses hi, lo', hi */ \
-        const int fst_ = (COMP & 4) ? ((stage_) >= 6 * NCH ? (stage_) - 6 * NCH : (stage_)) : (stage_); \
+        /* RING3: the array stays [hi chunks][corr chunks]; K-loop chunk c is array chunk (c & 1) * NCH + (c >> 1) */ \
+        const int fst_ = RING3 ? ((((stage_) / 3) & 1) * NCH + (((stage_) / 3) >> 1)) * 3 + (stage_) % 3 \
+                               : (COMP & 4) ? ((stage_) >= 6 * NCH ? (stage_) - 6 * NCH : (stage_)) : (stage_); \
         const half_t *src_ = wpk + (size_t)(KXM ? (fst_ / 3) * 9 + fst_ % 3 : fst_ * 3) * CoutP * PP_CC + woff[i_]; \
         __builtin_amdgcn_global_load_lds((gbl_void3_t *)src_,                                          \
                                          (lds_void3_t *)(Fs + (buf_)*PP_FBYTES + (wave * PP_FPW + i_) * 1024), 16, 0, 0); \
@@ -207,6 +235,7 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #pragma unroll
     for (int i = 0; i < PP_XPW; ++i) PP_ISSUE_X1(0, 0, i);
     PP_ISSUE_F(0, 0)
+    if (RING3) { PP_ISSUE_F(1, 1) }
     for (int t = tid; t < PP_BN; t += 512) {
         SSb[t] = scale[n0 + t]; SSb[PP_BN + t] = shift[n0 + t];
         if (F6) SSb[2 * PP_BN + t] = shift[CoutP + n0 + t];      // (the scale bytes follow the shifts: launcher)
@@ -237,6 +266,18 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
     PP_CYC(1)
 
+    /* End of a stage (both sections of its last unit): what the NEXT stage reads must have landed -- its filters, and after a chunk's \
+       last stage the next chunk's patch.  Two buffers: everything requested so far (the youngest request is a unit old).  RING3: the \
+       requests younger than that may stay in flight -- per wave and chunk the queue is  X0 F F F X1 | X2 F F F X3 | X4 F F F  (F = the \
+       wave's three pieces of stage st + 2), so behind F(st + 1) sit 5 / 6 / 3 requests at the end of stage 0 / 1 / 2 (stage 2 also needs \
+       X4: only its own F stays out).  The last chunk requests nothing of the kind: full wait. */ \
+#define PP_STAGE_WAIT(sg_, extra_)                                                                     \
+    if (RING3 && more_x) {                                                                             \
+        if ((sg_) == 0) asm volatile("s_waitcnt vmcnt(5) " extra_ ::: "memory");                       \
+        else if ((sg_) == 1) asm volatile("s_waitcnt vmcnt(6) " extra_ ::: "memory");                  \
+        else asm volatile("s_waitcnt vmcnt(3) " extra_ ::: "memory");                                  \
+    } else asm volatile("s_waitcnt vmcnt(0) " extra_ ::: "memory");
+
 #define PP_CHUNK_BODY(F8_)  /* one 32-channel chunk of the K loop; F8_: a corr-plane chunk (fp8 MFMA) */ \
         const unsigned char *xs = Xs + (c & 1) * PP_XBYTES; \
         const bool more_x = c + 1 < NCT; \
@@ -249,7 +290,7 @@ _Pragma("unroll") \
             const int sg = t9 / 3, u3 = t9 % 3; \
             const int ky = KXM ? u3 : sg, kx = KXM ? sg : u3; \
             const int st = c * 3 + sg; \
-            const unsigned char *fs = Fs + (st & 1) * PP_FBYTES + u3 * (PP_BN * 64); \
+            const unsigned char *fs = Fs + (RING3 ? sg : (st & 1)) * PP_FBYTES + u3 * (PP_BN * 64); /* RING3: st % 3 = sg */ \
 /* ---------------- LOAD section */ \
             h8_t fa[2][2], fb[2][4]; \
             if (ABL & 2) { /* timing ablation: no fragment reads */ \
@@ -302,7 +343,7 @@ _Pragma("unroll") \
                 for (int kk = 0; kk < 2; ++kk) \
                     fa[kk][ct] = *reinterpret_cast<const h8_t *>(fs + a_off[ct] + (((kk * 2 + lhi) ^ a_sw[ct]) << 4)); \
             } \
-            if (!(ABL & 1) && u3 == 0 && st + 1 < NST) { PP_ISSUE_F(st + 1, (st + 1) & 1) } \
+            if (!RING3 && !(ABL & 1) && u3 == 0 && st + 1 < NST) { PP_ISSUE_F(st + 1, (st + 1) & 1) } \
             if (!(ABL & 1) && more_x) { \
                 if (t9 == 0) PP_ISSUE_X1(c + 1, (c + 1) & 1, 0); \
                 if (t9 == 1) PP_ISSUE_X1(c + 1, (c + 1) & 1, 1); \
@@ -310,7 +351,10 @@ _Pragma("unroll") \
                 if (t9 == 4) PP_ISSUE_X1(c + 1, (c + 1) & 1, 3); \
                 if (t9 == 6) PP_ISSUE_X1(c + 1, (c + 1) & 1, 4); \
             } \
-            if (u3 == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+            /* RING3: stage st + 2 into the buffer stage st - 1 has just left, BEHIND this unit's patch piece in the wave's queue (the counted \
+               waits below rely on the order  X0 F F F X1 | X2 F F F X3 | X4 F F F  per chunk) */ \
+            if (RING3 && u3 == 0 && st + 2 < NST) { PP_ISSUE_F(st + 2, (sg + 2) % 3) } \
+            if (u3 == 2) { PP_STAGE_WAIT(sg, "lgkmcnt(0)") } \
             __builtin_amdgcn_sched_barrier(0); \
             asm volatile("s_barrier" ::: "memory"); \
             __builtin_amdgcn_sched_barrier(0); \
@@ -345,12 +389,22 @@ _Pragma("unroll") \
             } \
             if (PRIO) __builtin_amdgcn_s_setprio(0); \
             __builtin_amdgcn_sched_barrier(0); \
-            if (u3 == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+            if (u3 == 2) { PP_STAGE_WAIT(sg, "") } \
 /* group 1's last MFMA section has nobody left to hand the pipe to */ \
             if (!(STAGGER && grp == 1 && t9 == 8 && c + 1 == NCT)) asm volatile("s_barrier" ::: "memory"); \
             __builtin_amdgcn_sched_barrier(0); \
         } \
     /* end of PP_CHUNK_BODY */
+    if constexpr (RING3) {
+        if (F6) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) sa6v[ct] = __float_as_int(SS[2 * PP_BN + wch + ct * 32 + lrow]);
+        }
+        for (int cc = 0; cc < NCH; ++cc) {
+            { const int c = 2 * cc; PP_CHUNK_BODY(0) }
+            { const int c = 2 * cc + 1; PP_CHUNK_BODY(1) }
+        }
+    } else {
     for (int c = 0; c < NCH; ++c) { PP_CHUNK_BODY(0) }
     if (COMP & 1) {
         if (F6) {
@@ -358,6 +412,7 @@ _Pragma("unroll") \
             for (int ct = 0; ct < 2; ++ct) sa6v[ct] = __float_as_int(SS[2 * PP_BN + wch + ct * 32 + lrow]);
         }
         for (int c = NCH; c < NCT; ++c) { PP_CHUNK_BODY(1) }
+    }
     }
     if (COMP & 4) {
         // X3 (SFD2_PREC_F16X3 on pre-split planes): y = sum hi * w_hi + 2^-11 (sum hi * w_lo' + sum lo' * w_hi), the low parts
@@ -372,6 +427,7 @@ _Pragma("unroll") \
         for (int c = NCH; c < NCT; ++c) { PP_CHUNK_BODY(0) }
     }
 #undef PP_CHUNK_BODY
+#undef PP_STAGE_WAIT
     PP_CYC(2)
     // the next tile's first copies go out before this tile's epilogue (buffers 0: last read a chunk / a stage ago)
     const int eoy0 = oy0, eox0 = ox0, en0 = n0;
@@ -382,6 +438,7 @@ _Pragma("unroll") \
 #pragma unroll
         for (int i = 0; i < PP_XPW; ++i) PP_ISSUE_X1(0, 0, i);
         PP_ISSUE_F(0, 0)
+        if (RING3) { PP_ISSUE_F(1, 1) }     // (buffers 0 and 1: the last stage sat in buffer 2, stage NST - 2's readers are barriers behind)
         float *SSn = SSb + ((it + 1) & 1) * SSN * PP_BN;
         for (int t = tid; t < PP_BN; t += 512) {
             SSn[t] = scale[n0 + t]; SSn[PP_BN + t] = shift[n0 + t];
@@ -502,7 +559,8 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
                         int Ho, int Wo, const half_t *zero_page, const half_t *in_c = nullptr, half_t *out_c = nullptr, int sa = 0,
                         unsigned int *range = nullptr)
 {
-    constexpr size_t lds = (size_t)2 * PP_XBYTES + (size_t)2 * PP_FBYTES + ((COMP & 16) ? 6 : 4) * PP_BN * sizeof(float);
+    constexpr bool ring3 = SFD2_PP_RING3 && (COMP & 1) && !(COMP & 4) && SFD2_PP_KXM && !ABL;
+    constexpr size_t lds = (size_t)2 * PP_XBYTES + (size_t)(ring3 ? 3 : 2) * PP_FBYTES + ((COMP & 16) ? 6 : 4) * PP_BN * sizeof(float);
     static bool attr_done = false;
     auto kern = conv3x3_pp_kernel<STAGGER, PRIO, ABL, SFD2_PP_KXM, COMP>;
     if (!attr_done) {

@@ -163,7 +163,7 @@ def _part_path(export_dir, conf, rank, world):
     return base + '.h5' if world == 1 else f'{base}.part{rank}of{world}.h5'
 
 
-def _extract_pipelined(model, extractor, conf, images, indices, tag, store, names, num_workers, writers, depth):
+def _extract_pipelined(model, extractor, conf, images, indices, tag, store, names, num_workers, writers, depth, lanes=1):
     """The loop of main() with its three stages running side by side (sfd2_amd/pipeline.py): `num_workers` decoder threads
     (the reference: DataLoader(num_workers=4), extract_localization.py:230-233) fill pinned buffers in item order, the
     device runs up to `depth` asynchronous extractions, `writers` threads build the float64 groups and append them.
@@ -176,7 +176,7 @@ def _extract_pipelined(model, extractor, conf, images, indices, tag, store, name
     top_k, conf_th, scales = mconf["max_keypoints"], mconf["conf_th"], [float(x) for x in mconf["scales"]]
     use_async = (extractor is extract_resnet_return and getattr(model, "context", None) is not None
                  and scales == [1.0] and top_k > 0)
-    ax = AsyncExtractor(model, top_k, conf_th, depth=depth, slots=depth + 2 * writers + 2) if use_async else None
+    ax = AsyncExtractor(model, top_k, conf_th, depth=depth, slots=depth + 2 * writers + 2, lanes=lanes) if use_async else None
     pool = PinnedPool(num_workers + depth + 2) if use_async else None
     lock = threading.Lock()
 
@@ -265,7 +265,7 @@ def _feed_of(model, data):
 
 
 def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precision="f16x3", world=1, rank=0,
-         barrier=None, model_and_extractor=None, num_workers=0, writers=2, depth=3):
+         barrier=None, model_and_extractor=None, num_workers=0, writers=2, depth=3, lanes=1):
     """extract_localization.py:221-279.  ``images``: an ImageDataset (decoded from files, resized per
     conf['preprocessing']) or any indexable / iterable of {'name', 'image': uint8 [H,W,3] RGB or float [3,H,W] in
     [0,1], 'original_size': (w, h)[, 'resize': (w, h)]}.  uint8 input is exact only together with the device resize
@@ -277,7 +277,8 @@ def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precisio
     or equivalent; one process per GPU), rank 0 merges the parts into the final store in item order.
 
     num_workers > 0: the pipelined loop (_extract_pipelined: that many decoder threads -- the reference's DataLoader
-    uses 4 --, `depth` images in flight on the device, `writers` writer threads); 0: the reference's serial loop.
+    uses 4 --, `depth` images in flight on the device over `lanes` contexts (HIP streams), `writers` writer threads); 0:
+    the reference's serial loop.
     Both write the same groups.
     Returns the final store path (rank 0) or the part path (other ranks)."""
     from .feature_io import open_store, write_features
@@ -298,7 +299,7 @@ def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precisio
     try:
         if num_workers and num_workers > 0:
             _extract_pipelined(model, extractor, conf, images, list(shard_indices(n_items, rank, world)), tag, store, names,
-                               int(num_workers), max(1, int(writers)), max(1, int(depth)))
+                               int(num_workers), max(1, int(writers)), max(1, int(depth)), max(1, int(lanes)))
         for idx in (() if num_workers and num_workers > 0 else shard_indices(n_items, rank, world)):
             data = images[idx]
             if tag is not None and data['name'].find(tag) < 0:

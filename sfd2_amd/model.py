@@ -35,7 +35,7 @@ class ResSegNetV2:
         the 3x3 / 1x1 convolutions on the fp16 matrix path in three hi / lo passes (~2^-22 per product, fp32 accumulation):
         the strict mode's tolerances hold (tests/test_gpu_baseline_configs.py::test_f16x3_*), 1.9x its speed.
         'f16c' = compensated fp16: the throughput mode's kernels with a second 2-byte plane per backbone activation and
-        filter (fp16 rounding residual + the value, both at fp8 precision) and one block-scaled fp8 MFMA per 32 channels
+        filter (fp16 rounding residual + the value, both at fp8 / fp6 precision) and one block-scaled MFMA per 32 channels
         that adds the two first-order error terms -- descriptors within 1e-3 of the fp32 reference (north_star's
         tolerance; measured <= 5e-4), key-point set IoU >= 0.99 (tests/test_gpu_f16c.py).  Its tensors have a RANGE
         the fp32 reference does not have (stored values saturate at 1792, the correction bytes fade below ~0.03):
@@ -101,6 +101,21 @@ class ResSegNetV2:
     @property
     def context(self):
         return self._ensure_ctx()
+
+    def replica(self):
+        """A second context with the same weights, precision and activation exponents on the same device: another HIP stream
+        for the pipelined driver (two images in flight fill the units one image's kernels leave idle).
+        Options set on this model's context with set_option are NOT copied."""
+        if self._sd is None:
+            raise RuntimeError("load_state_dict() first")
+        m = ResSegNetV2(outdim=self.outdim, require_feature=self.require_feature, require_stability=self.require_stability,
+                        ms_detector=self.ms_detector, precision=self.precision)
+        m._device = self._device
+        m._sd = self._sd
+        m._ensure_ctx()
+        exps, _ = self._ensure_ctx().act_exponents()
+        m._ctx.set_act_exponents(exps)          # the same scaling of every stored tensor: bit-identical results on either context
+        return m
 
     # -- range management of the reduced-precision modes (extension; include/sfd2_hip.h "Range management")
     def calibrate_range(self, img, normalised=False):

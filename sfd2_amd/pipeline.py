@@ -89,7 +89,12 @@ class AsyncExtractor:
     C-ABI's asynchronous form).  submit() queues one decoded uint8 image; results come back in submission order from
     finish(), as the float32 arrays the synchronous call fills."""
 
-    def __init__(self, model, top_k, conf_th, depth=3, slots=8):
+    def __init__(self, model, top_k, conf_th, depth=3, slots=8, lanes=1):
+        """lanes > 1: that many contexts (model.replica(): own HIP stream, workspace and staging slots) take the images
+        in turn; results do not depend on the lane.  Measured in THIS loop (eager launches, tools/pipeline_bench.py, f16c,
+        16 decoder threads): 547 images/s with one lane, 393 with two -- the +8 % bench.py gets from two streams comes with
+        one hipGraph replay per image; with ~35 eager launches per image from one host thread the second stream only adds
+        submission work.  Default 1."""
         import torch
         if top_k <= 0:
             raise ValueError("the pipelined extractor needs a key-point capacity (max_keypoints > 0)")
@@ -98,30 +103,38 @@ class AsyncExtractor:
         self.top_k, self.conf_th, self.depth = int(top_k), float(conf_th), int(depth)
         self.flags = 0 if getattr(model, "require_stability", True) else _lib.FLAG_NO_STABILITY
         self.device = torch.device("cuda", self.ctx.device)
+        self.models = [model] + [model.replica() for _ in range(max(1, int(lanes)) - 1)]
         with torch.cuda.device(self.device):
             self._free = queue.Queue()
             for _ in range(max(slots, depth + 1)):
                 self._free.put(_Slot(torch, self.top_k))
-            self.stream = torch.cuda.ExternalStream(self.ctx.stream, device=self.device)
-        self._resized = None            # device float32 [3][h][w] of the image being resized (stream ordered: one is enough)
+            self.streams = [torch.cuda.ExternalStream(m.context.stream, device=self.device) for m in self.models]
+        self._resized = [None] * len(self.models)   # device float32 [3][h][w] of the image being resized (stream ordered: one per lane is enough)
+        self._turn = 0
         self.inflight = collections.deque()
         self.repeats = 0                # images re-run synchronously (range fallback)
 
     def submit(self, image_u8, H, W, resize, meta, inbuf=None):
         """image_u8: uint8 [H,W,3] RGB view (pinned for a truly asynchronous upload); resize (w, h) or None."""
+        if not image_u8.flags.c_contiguous:
+            image_u8 = np.ascontiguousarray(image_u8)      # (a transposed view multiplied / cast keeps its operand's layout)
         slot = self._free.get()         # blocks while the writers are behind: back-pressure
-        lib, ctx, torch = self.ctx.lib, self.ctx, self.torch
+        lane = self._turn % len(self.models)
+        self._turn += 1
+        ctx, torch = self.models[lane].context, self.torch
+        lib = ctx.lib
+        slot.lane = lane
         slot.meta, slot.inbuf, slot.sync_result = meta, inbuf, None
         slot.image = image_u8           # kept for a synchronous repeat
         src, on_dev, h, w = image_u8.ctypes.data, 0, H, W
         flags = self.flags | _lib.FLAG_ASYNC
         if resize is not None and tuple(resize) != (W, H):
             w, h = int(resize[0]), int(resize[1])
-            if self._resized is None or self._resized.numel() < 3 * h * w:
-                self.ctx.sync()         # nothing may still read the old buffer when it is replaced
-                self._resized = torch.empty(3 * h * w, dtype=torch.float32, device=self.device)
-            _lib.check(lib.sfd2_preprocess(ctx.h, src, 0, H, W, _lib.FLAG_ASYNC, h, w, self._resized.data_ptr()))
-            src, on_dev = self._resized.data_ptr(), 1
+            if self._resized[lane] is None or self._resized[lane].numel() < 3 * h * w:
+                ctx.sync()              # nothing may still read the old buffer when it is replaced
+                self._resized[lane] = torch.empty(3 * h * w, dtype=torch.float32, device=self.device)
+            _lib.check(lib.sfd2_preprocess(ctx.h, src, 0, H, W, _lib.FLAG_ASYNC, h, w, self._resized[lane].data_ptr()))
+            src, on_dev = self._resized[lane].data_ptr(), 1
         else:
             flags |= _lib.FLAG_IMG_U8_HWC
         slot.size = (w, h)
@@ -130,7 +143,7 @@ class AsyncExtractor:
         _lib.check(lib.sfd2_extract(ctx.h, src, on_dev, h, w, self.conf_th, self.top_k, flags, slot.kp.ctypes.data,
                                     slot.sc.ctypes.data, slot.de.ctypes.data, 0, slot.cap, ctypes.byref(n)))
         _lib.check(lib.sfd2_extract_record_async(ctx.h, slot.rec.ctypes.data, 0))
-        slot.event.record(self.stream)
+        slot.event.record(self.streams[lane])
         self.inflight.append(slot)
 
     def finish(self):
@@ -143,11 +156,11 @@ class AsyncExtractor:
         if saturated:
             # SFD2_PREC_F16C left its range on this image: the synchronous call repeats it in SFD2_PREC_F16X3 by itself
             from .extractor import extract_resnet_return
-            img = slot.image
+            img, model = slot.image, self.models[slot.lane]
             if slot.resize is not None:
                 from .extract_localization import preprocess
-                img = preprocess(self.model, slot.image, slot.resize)
-            slot.sync_result = extract_resnet_return(self.model, img=img, topK=self.top_k, conf_th=self.conf_th)
+                img = preprocess(model, slot.image, slot.resize)
+            slot.sync_result = extract_resnet_return(model, img=img, topK=self.top_k, conf_th=self.conf_th)
             self.repeats += 1
         slot.n = n
         slot.image = None

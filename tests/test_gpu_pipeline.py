@@ -70,6 +70,9 @@ def test_pipelined_extract_equals_serial_loop(tmp_path, synth_sd, precision):
     p_pipe = el.main(conf, ds, tmp_path / "pipe", model_and_extractor=(model, el.extract_resnet_return), num_workers=3, writers=2, depth=3)
     names = _stores_equal(p_pipe, p_serial)
     assert len(names) == len(sizes)
+    # two lanes: a replica context (own stream) takes every other image -- same store
+    p_two = el.main(conf, ds, tmp_path / "two", model_and_extractor=(model, el.extract_resnet_return), num_workers=4, depth=4, lanes=2)
+    _stores_equal(p_two, p_serial)
     # tag filter and the two-rank sharding go through the same loop
     p_tag_s = el.main(conf, ds, tmp_path / "tag_s", model_and_extractor=(model, el.extract_resnet_return), tag="query")
     p_tag_p = el.main(conf, ds, tmp_path / "tag_p", model_and_extractor=(model, el.extract_resnet_return), tag="query", num_workers=2)
@@ -126,7 +129,7 @@ def test_extract_record_async_and_host_outputs(synth_sd):
     model = _model(synth_sd, "f16c")
     ctx = model.context
     K = 256
-    imgs = [(synth.make_image(96, 128, 600 + i).transpose(1, 2, 0) * 255).astype(np.uint8) for i in range(3)]
+    imgs = [np.ascontiguousarray((synth.make_image(96, 128, 600 + i).transpose(1, 2, 0) * 255).astype(np.uint8)) for i in range(3)]   # (C order: the product is laid out like its CHW operand)
     want = [extract_resnet_return(model, im, conf_th=0.001, topK=K) for im in imgs]
     pins = [torch.from_numpy(im).pin_memory() for im in imgs]
     outs = []
@@ -160,7 +163,7 @@ def test_recalibration_clears_recorded_maxima():
     sd = synth.make_state_dict(0)
     model = _model(sd, "f16c")
     ctx = model.context
-    u8 = (synth.make_image(96, 128, 700).transpose(1, 2, 0) * 255).astype(np.uint8)
+    u8 = np.ascontiguousarray((synth.make_image(96, 128, 700).transpose(1, 2, 0) * 255).astype(np.uint8))
     e0, _ = ctx.act_exponents()
     ctx.set_act_exponents(e0 + 12)                       # everything 4096 x larger as stored: saturates
     K = 64
@@ -321,3 +324,41 @@ def test_f16x3_debug_activation_after_throughput_extract(synth_sd):
     assert np.abs(got - taps["conv4.2"]).max() <= 2e-5 * max(1.0, np.abs(taps["conv4.2"]).max())
     model.det(x[None])                                             # and the parity entry point makes them readable again
     np.testing.assert_array_equal(ctx.debug_activation("conv3a"), before)
+
+
+def test_f16_matcher_decides_like_fp64_above_2e4_gap_on_network_descriptors(synth_sd):
+    """SURVEY 8c asks for identical matches where the top-1 / top-2 gap exceeds 1e-4; SFD2_SIM_F16's worst-case
+    bound only promises 1e-3.  On descriptors the NETWORK produces (two views of a scene: true correspondences and near-duplicates)
+    its measured similarity error is ~6e-5 (tools/match_gap_stats.py, profiles/r05c_match_gap_stats.json: 0 of 2 160 rows with a gap in
+    (1e-4, 1e-3] decided differently) -- asserted here with a 2x margin: no arg-max differs where the fp64 gap exceeds 2e-4, and
+    SFD2_SIM_F16X2 meets 1e-5."""
+    from sfd2_amd.extractor import extract_resnet_return
+    model = _model(synth_sd, "f16c")
+    ctx = model.context
+    base = synth.make_image(480, 640, 11)
+    rs = np.random.RandomState(3)
+    views = []
+    for v in range(3):
+        img = np.roll(base, (7 * v, -11 * v), axis=(1, 2))
+        if v:
+            img = np.clip(img * (1.0 + 0.05 * v) + 0.02 * rs.standard_normal(img.shape).astype(np.float32), 0.0, 1.0).astype(np.float32)
+        views.append(extract_resnet_return(model, img[None], conf_th=0.001, topK=2048)["descriptors"].astype(np.float32))
+    n_band = 0
+    for v in (1, 2):
+        for d0, d1 in ((views[0], views[v]), (views[v], views[0])):
+            sim = d0.astype(np.float64) @ d1.astype(np.float64).T
+            order = np.argsort(-sim, axis=1)[:, :2]
+            rows = np.arange(len(sim))
+            gap = sim[rows, order[:, 0]] - sim[rows, order[:, 1]]
+            for mode, min_gap in ((_lib.SIM_F16, 2e-4), (_lib.SIM_F16X2, 1e-5)):
+                conf = _lib.MatchConf(_lib.MATCH_HLOC, 0, 0.0, 0.0, mode)
+                m = np.empty((len(d0),), dtype=np.int64)
+                s = np.empty((len(d0),), dtype=np.float32)
+                a0, a1 = np.ascontiguousarray(d0), np.ascontiguousarray(d1)
+                _lib.check(ctx.lib.sfd2_match(ctx.h, a0.ctypes.data, len(a0), a1.ctypes.data, len(a1), 128, _lib.DT_F32, _lib.LAYOUT_ND, 0,
+                                              ctypes.byref(conf), m.ctypes.data, s.ctypes.data, 0))
+                sel = gap > min_gap
+                assert (m[sel] == order[sel, 0]).all(), (mode, int((m[sel] != order[sel, 0]).sum()))
+                assert np.abs(s - (sim.max(1) + 1.0) / 2.0).max() <= (1e-3 if mode == _lib.SIM_F16 else 1e-5)
+            n_band += int(((gap > 2e-4) & (gap <= 1e-3)).sum())
+    assert n_band > 50      # the band the contract is about is populated on these sets

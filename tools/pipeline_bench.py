@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--writers", type=int, default=3)
     ap.add_argument("--depth", type=int, default=3)
+    ap.add_argument("--lanes", type=int, default=1, help="contexts (HIP streams) the pipelined extract loop alternates over")
     ap.add_argument("--size", default="1600x1200")
     ap.add_argument("--topk", type=int, default=4096)
     ap.add_argument("--precision", default="f16c,f16x3")
@@ -135,7 +136,7 @@ def main():
     scratch = args.scratch or tempfile.mkdtemp(prefix="sfd2_pipe_")
     os.makedirs(scratch, exist_ok=True)
     out = {"workload": f"{args.queries} query + {args.db} db JPEG files {W}x{H} -> top-{args.topk} features -> NNM matches, {args.k} db images per query",
-           "decode_workers": args.workers, "writer_threads": args.writers, "extracts_in_flight": args.depth,
+           "decode_workers": args.workers, "writer_threads": args.writers, "extracts_in_flight": args.depth, "lanes": args.lanes,
            "host_logical_cpus": len(os.sched_getaffinity(0)), "host_cpu_count": os.cpu_count()}
     try:
         t0 = time.perf_counter()
@@ -162,7 +163,7 @@ def main():
             el.extract_resnet_return(model, ds[0]["image"], conf_th=0.001, topK=args.topk)        # workspace, first-use packing
             d_pipe, d_ser = os.path.join(scratch, f"pipe_{prec}"), os.path.join(scratch, f"serial_{prec}")
             t0 = time.perf_counter()
-            p_pipe = el.main(conf, ds, d_pipe, model_and_extractor=me, num_workers=args.workers, writers=args.writers, depth=args.depth)
+            p_pipe = el.main(conf, ds, d_pipe, model_and_extractor=me, num_workers=args.workers, writers=args.writers, depth=args.depth, lanes=args.lanes)
             dt = time.perf_counter() - t0
             t0 = time.perf_counter()
             p_ser = el.main(conf, ds_sub, d_ser, model_and_extractor=me, num_workers=0)
