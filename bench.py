@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--graphs", action="store_true", help="(default since round 2; kept for old command lines) sfd2_extract_match with the per-context hipGraph cache (configs[4]); "
                                                           "per-kernel events are not available then")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-f32 leg")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the files -> feature store -> match store leg (the `pipeline` object: tools/pipeline_bench.py "
+                    "on a reduced workload, N = 1 only)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configs (the 'configs' object)")
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the extra untimed-by-contract sustained leg (0 = off)")
     ap.add_argument("--lib", default=None, help="kernel A/B runs: another build of libsfd2hip.so (sfd2_amd/build.py build_lib(out=...))")
@@ -573,6 +575,21 @@ def main():
             "strict_f32": strict, "strict_f16x3": strict_x3,
             ("approx_f16" if args.precision == "f16c" else "f16c"): approx,
         }
+        if world == 1 and not args.no_pipeline and not args.extract_only and not args.size and args.precision == "f16c":
+            # not `value`: what the reference-shaped DRIVERS reach from JPEG files and stores (host decode, PCIe, float64 stores included)
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("pipeline_bench", os.path.join(ROOT, "tools", "pipeline_bench.py"))
+                pb = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(pb)
+                lanes.clear()                      # the headline contexts' workspaces are not needed any more
+                torch.cuda.empty_cache()
+                out["pipeline"] = pb.run(pb.parse_args(["--queries", "160", "--db", "64", "--k", "50", "--workers", "16", "--precision", "f16c",
+                                                        "--serial-images", "16", "--serial-pairs", "100"]))
+                out["pipeline"]["note"] = ("extract_localization.main(num_workers=16) and match_features.main(grouped=True) on synthetic JPEG files, timed end to end "
+                                           "(tools/pipeline_bench.py; DESIGN.md section 6); never part of `value`")
+            except Exception as e:      # noqa: BLE001 -- the leg is informative: a failure must not cost the line
+                out["pipeline"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out), flush=True)

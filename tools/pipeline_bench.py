@@ -108,7 +108,7 @@ def stores_equal(a_path, b_path, keys=None):
     return len(keys) > 0
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--queries", type=int, default=256)
     ap.add_argument("--db", type=int, default=128)
@@ -124,7 +124,11 @@ def main():
     ap.add_argument("--serial-pairs", type=int, default=200)
     ap.add_argument("--scratch", default=None)
     ap.add_argument("--keep", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def run(args):
+    """The whole measurement; returns the result dict (bench.py's `pipeline` object calls this with a smaller workload)."""
     W, H = (int(v) for v in args.size.split("x"))
 
     import torch
@@ -208,8 +212,8 @@ def main():
     finally:
         if not args.keep:
             shutil.rmtree(scratch, ignore_errors=True)
-    print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    print(json.dumps(run(parse_args())))
