@@ -305,7 +305,7 @@ int convf(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &in, int H
             return 0;
         if (L.stride != 1) { ps.cancel(); return fail("conv3x3_rf<x3>: no instantiation for this layer (x3_fast_kind and the launcher disagree)"); }
         launch_conv3x3_pp_x3(c->stream, ph, pl, H, W, L.cin, L.wx3p.as<half_t>(), L.scale.as<float>(), L.shift.as<float>(), L.cout_pad, relu,
-                             oh, ol, oh ? nullptr : out.as<float>(), Ho, Wo, c->zero_page.as<half_t>());
+                             oh, ol, oh ? nullptr : out.as<float>(), Ho, Wo, c->zero_page.as<half_t>(), (oh && c->x3_s2d_out_now) ? 1 : 0);
         return 0;
     }
     if (x3 && !L.wx3.p) {      // split the packed filters once: the kernel then stages them without arithmetic
@@ -354,10 +354,32 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
     const bool fast_rb = c->x3_fast_rb_now && c->rb1[0].wfh.p && c->rb1[0].wfl.p && c->rb2[0].w.p && c->rb2[0].wlk.p;
     const bool k2b = c->x3_fast_rb_now && x3_fast_kind(c, c->f2b, false, H4, W4) != 0, k3a = c->x3_fast_rb_now && x3_fast_kind(c, c->f3a, false, H4, W4) != 0;
     const bool k3b = c->x3_fast_rb_now && x3_fast_kind(c, c->f3b, false, H4, W4) != 0;
+    // Option "s2d" in this mode too (round 5): conv2a (conv3x3_pp<x3>) stores its planes space-to-depth and conv2b runs as a stride-1 layer over
+    // them (conv2b_s2d_kernel<x3>) instead of on the strided conv3x3_rf<2, x3>; planes out for conv3a
+    const bool s2d_x3 = c->opt_s2d && k2b && k3a && x3_fast_kind(c, c->f2a, false, H2, W2) == 1 && conv2b_s2d_serves(H2, W2, c->f2b.cin, c->f2b.cout_pad) &&
+                        H4 * 2 == H2 && W4 * 2 == W2;
     c->x3_planes_out_now = k2b ? 1 : 0;
+    c->x3_s2d_out_now = s2d_x3 ? 1 : 0;
     if (convf(c, "conv2a", c->f2a, c->g1b, H2, W2, c->g2a, H2, W2, 1)) return -1;
+    c->x3_s2d_out_now = 0;
     c->x3_planes_out_now = k3a ? 1 : 0;
-    if (convf(c, "conv2b", c->f2b, c->g2a, H2, W2, c->g2b, H4, W4, 1)) return -1;
+    if (s2d_x3 && c->x3_pre_src == c->g2a.p && c->x3_pre_hi) {
+        ConvW &L = c->f2b;
+        const size_t nfl = (size_t)9 * L.cout_pad * L.cin, nout = (size_t)H4 * W4 * L.cout_pad;
+        if (!L.wx3p.p) {
+            HIPCHECK(L.wx3p.ensure(nfl * 2 * sizeof(half_t)));
+            launch_x3_split_planes(st, L.w.as<float>(), nfl, L.wx3p.p, L.wx3p.as<half_t>() + nfl);
+        }
+        const half_t *ph = c->x3_pre_hi, *pl = c->x3_pre_lo;
+        DevBuf &dst = (ph == c->x3_chain.as<half_t>()) ? c->x3_chain2 : c->x3_chain;
+        HIPCHECK(dst.ensure(nout * 2 * sizeof(half_t)));
+        half_t *oh = dst.as<half_t>(), *ol = oh + nout;
+        {
+            ProfScope ps(c, "conv2b", "conv2b_s2d_kernel<x3>", 2.0 * (double)H4 * W4 * L.cout * L.cin * 9, 4.0 * (double)H2 * W2 * L.cin + 4.0 * nout);
+            launch_conv2b_s2d_x3(st, ph, pl, H4, W4, L.wx3p.as<half_t>(), L.scale.as<float>(), L.shift.as<float>(), 1, oh, ol, c->zero_page.as<half_t>());
+        }
+        c->x3_pre_src = c->g2b.p; c->x3_pre_hi = oh; c->x3_pre_lo = ol;
+    } else if (convf(c, "conv2b", c->f2b, c->g2a, H2, W2, c->g2b, H4, W4, 1)) return -1;
     c->x3_planes_out_now = k3b ? 1 : 0;
     if (convf(c, "conv3a", c->f3a, c->g2b, H4, W4, c->g3a, H4, W4, 1)) return -1;
     c->x3_planes_out_now = (fast_rb && k3b) ? 3 : 0;

@@ -37,7 +37,11 @@ typedef const __attribute__((address_space(1))) void gbl_void5_t;
 
 // O6: the output's corr records as fp6 half-records (sfd2_epi16_fp6) for conv3a's fp6 x fp6 correction
 // ABL (experiment builds, timing only): 1 = no copies inside the step loops, 2 = no fragment reads / MFMAs
-template <bool O6, int ABL = 0>
+// X3 (SFD2_PREC_F16X3, round 5): in / in_c are the hi / lo' PLANES of conv2a's output (conv3x3_pp<x3, planes out> with the space-to-depth store),
+// wpk the filters as [4 hi chunks | 4 lo' chunks], and the step list runs THREE times over fp16 MFMAs -- hi x hi, then (the accumulators
+// scaled by 2^11, exactly) hi x lo' and lo' x hi, conv3x3_pp<x3>'s arithmetic -- 60 steps and 48 patches per tile; the output leaves as hi / lo'
+// planes [H4][W4][128] for conv3a.  Replaces conv3x3_rf<2, x3> on the strict mode's throughput path (192 us at 1600x1200).
+template <bool O6, int ABL = 0, bool X3 = false>
 __global__ __launch_bounds__(512, 2)
 void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4][128] */, const half_t *__restrict__ in_c /* its corr units */,
                        int H4, int W4, const half_t *__restrict__ wpk /* [8 chunks][9][128][32] */, const float *__restrict__ scale,
@@ -55,6 +59,7 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
     const int wrow = (wave >> 1) * 4;                      // 4 image rows = 4 pixel tiles
     const int lrow = lane & 31, lhi = lane >> 5;
     constexpr int CIN = 512, CO = 128;
+    constexpr int NPASS = X3 ? 3 : 2, NSTEP = 20 * NPASS, NPATCH = 16 * NPASS;
 
     for (int t = tid; t < S2_BN; t += 512) { SS[t] = scale[t]; SS[S2_BN + t] = shift[t]; }
 
@@ -98,9 +103,10 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
     // brought it into (with the chunk outermost the halves were five steps = 6 MB of patches per XCD apart: the PMC passes counted 1.65 x
     // the tensor's bytes).
     // patch x of a tile (x = 0 .. 31): corr = x >> 4, memory plane 3 - ((x >> 2) & 3), chunk x & 3; five (waves 4 .. 7: four) copies per wave
+    // (X3: x = 0 .. 47, pass = x >> 4: the hi plane for passes 0 and 1, the lo' plane for pass 2)
 #define S2_ISSUE_X(x_, xb_)                                                                            \
     {                                                                                                  \
-        const int g_ = ((x_) >> 4) << 2, pl_ = 3 - (((x_) >> 2) & 3);     /* (g_ >> 2 = corr) */         \
+        const int g_ = (X3 ? ((x_) >> 5) : ((x_) >> 4)) << 2, pl_ = 3 - (((x_) >> 2) & 3);     /* (g_ >> 2 = the second input plane) */ \
         const int so_ = (pl_ * 128 + ((x_) & 3) * 32) * (int)sizeof(half_t);                            \
         _Pragma("unroll") for (int i = 0; i < S2_XPW; ++i) {                                           \
             const int pc_ = wave + 8 * i;                                                              \
@@ -112,13 +118,13 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
     // step f (f = 0 .. 39): corr = f / 20, r = f % 20; r < 8: plane (1,1), chunk r >> 1, e = r & 1 (filter row 0 / 2); else plane index
     // (r - 8) >> 2, chunk (r - 8) & 3, e = 2 + plane index.  e -> original taps (0, 2), (6, 8), (1, 7), (3, 5), (4); ONE copy per wave and tap
 #define S2_STEP_MAP(f_, cr_, e_, k_)                                                                   \
-        const int cr_ = (f_) >= 20 ? 1 : 0, r__##e_ = (f_) - cr_ * 20;                                  \
+        const int cr_ = (f_) >= 40 ? 2 : (f_) >= 20 ? 1 : 0, r__##e_ = (f_) - cr_ * 20;   /* the pass */     \
         const int e_ = r__##e_ < 8 ? (r__##e_ & 1) : 2 + ((r__##e_ - 8) >> 2);                          \
         const int k_ = r__##e_ < 8 ? (r__##e_ >> 1) : ((r__##e_ - 8) & 3);
 #define S2_ISSUE_F(f_, fb_)                                                                            \
     {                                                                                                  \
         S2_STEP_MAP(f_, c_, e_, kk_)                                                                   \
-        const int g_ = c_ * 4 + kk_;                                                                   \
+        const int g_ = (X3 ? (c_ == 1 ? 4 : 0) : c_ * 4) + kk_;   /* X3: hi, lo', hi filter chunks */     \
         const int t0_ = e_ == 0 ? 0 : e_ == 1 ? 6 : e_ == 2 ? 1 : e_ == 3 ? 3 : 4;                      \
         const int t1_ = e_ == 0 ? 2 : e_ == 1 ? 8 : e_ == 2 ? 7 : 5;                                   \
         const int sb_ = g_ * 9 * CO * 32 * (int)sizeof(half_t);                                        \
@@ -160,15 +166,15 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
             const int fbuf = (f_) & 1;                                                                  \
             lax = false;                                                                               \
             if (!(ABL & 1)) {                                                                          \
-                if ((f_) + 1 < 40) { S2_ISSUE_F((f_) + 1, fbuf ^ 1) }                                   \
+                if ((f_) + 1 < NSTEP) { S2_ISSUE_F((f_) + 1, fbuf ^ 1) }                                \
                 else if (has_next) { S2_ISSUE_F(0, fbuf ^ 1) }                                          \
                 if (e != 1) {   /* first step of patch x = 16 corr + 4 plane index + chunk */           \
                     const int x2 = 16 * cr + (e >= 2 ? 4 * (e - 1) : 0) + kc + 2;                       \
                     const int b2 = xb >= 1 ? xb - 1 : 2;   /* (xb + 2) % 3 */                           \
-                    if (x2 < 32) { S2_ISSUE_X(x2, b2) lax = true; }                                     \
+                    if (x2 < NPATCH) { S2_ISSUE_X(x2, b2) lax = true; }                                 \
                     else if (has_next) {                                                               \
-                        if (x2 == 32) { S2_SETUP(next) }                                               \
-                        S2_ISSUE_X(x2 - 32, b2)                                                        \
+                        if (x2 == NPATCH) { S2_SETUP(next) }                                           \
+                        S2_ISSUE_X(x2 - NPATCH, b2)                                                    \
                         lax = true;                                                                    \
                     }                                                                                  \
                 }                                                                                      \
@@ -181,37 +187,56 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
             const unsigned char *fs = Fs + fbuf * S2_FBYTES;
 #define S2_STEP_EPILOGUE()                                                                             \
             if (e != 0) xb = xb == 2 ? 0 : xb + 1;         /* (step 0 of a group shares its patch with step 1) */
+#define S2_FP16_TAPS() \
+_Pragma("unroll 1") \
+            for (int j = 0; j < ((ABL & 2) ? 0 : ntap); ++j) { \
+                const unsigned char *ft = fs + j * (S2_BN * 64); \
+                const int qv = qb + (j ? ro1 : ro0) * S2_PW + (j ? co1 : co0); \
+                h8_t fa[2][2], fb[2][4]; \
+_Pragma("unroll") \
+                for (int ct = 0; ct < 2; ++ct) \
+_Pragma("unroll") \
+                    for (int kk = 0; kk < 2; ++kk) \
+                        fa[kk][ct] = *reinterpret_cast<const h8_t *>(ft + a_off[ct] + (((kk * 2 + lhi) ^ a_sw[ct]) << 4)); \
+_Pragma("unroll") \
+                for (int pr = 0; pr < 4; ++pr) { \
+                    const int q = qv + pr * S2_PW; \
+                    const int sw = (q >> 2) & 3; \
+_Pragma("unroll") \
+                    for (int kk = 0; kk < 2; ++kk) \
+                        fb[kk][pr] = *reinterpret_cast<const h8_t *>(xs + q * 64 + (((kk * 2 + lhi) ^ sw) << 4)); \
+                } \
+_Pragma("unroll") \
+                for (int kk = 0; kk < 2; ++kk) \
+_Pragma("unroll") \
+                    for (int ct = 0; ct < 2; ++ct) \
+_Pragma("unroll") \
+                        for (int pr = 0; pr < 4; ++pr) \
+                            acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][ct], fb[kk][pr], acc[ct][pr], 0, 0, 0); \
+            } \
+
 #pragma unroll 1
         for (int f = 0; f < 20; ++f) {
             S2_STEP_PROLOGUE(f)
-#pragma unroll 1
-            for (int j = 0; j < ((ABL & 2) ? 0 : ntap); ++j) {
-                const unsigned char *ft = fs + j * (S2_BN * 64);
-                const int qv = qb + (j ? ro1 : ro0) * S2_PW + (j ? co1 : co0);
-                h8_t fa[2][2], fb[2][4];
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-                        fa[kk][ct] = *reinterpret_cast<const h8_t *>(ft + a_off[ct] + (((kk * 2 + lhi) ^ a_sw[ct]) << 4));
-#pragma unroll
-                for (int pr = 0; pr < 4; ++pr) {
-                    const int q = qv + pr * S2_PW;
-                    const int sw = (q >> 2) & 3;
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-                        fb[kk][pr] = *reinterpret_cast<const h8_t *>(xs + q * 64 + (((kk * 2 + lhi) ^ sw) << 4));
-                }
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                        for (int pr = 0; pr < 4; ++pr)
-                            acc[ct][pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][ct], fb[kk][pr], acc[ct][pr], 0, 0, 0);
-            }
+            S2_FP16_TAPS()
             S2_STEP_EPILOGUE()
         }
+        if constexpr (X3) {
+            // hi x hi is done: scale the sums by 2^11 (exact) so that the cross terms -- whose lo' operands carry that factor -- join the
+            // same accumulators; 2^-11 goes into the epilogue
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] *= 2048.0f;
+#pragma unroll 1
+            for (int f = 20; f < 60; ++f) {
+                S2_STEP_PROLOGUE(f)
+                S2_FP16_TAPS()
+                S2_STEP_EPILOGUE()
+            }
+        } else {
 #pragma unroll 1
         for (int f = 20; f < 40; ++f) {
             S2_STEP_PROLOGUE(f)
@@ -244,8 +269,10 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
             }
             S2_STEP_EPILOGUE()
         }
+        }
 #undef S2_STEP_PROLOGUE
 #undef S2_STEP_EPILOGUE
+#undef S2_FP16_TAPS
         // (the epilogue's stores are younger than every copy in flight: the next tile's first wait is a full one)
 
         // epilogue (conv3_kernels.hip): y = acc * scale + shift, ReLU, hi plane + corr records, 16-byte stores
@@ -259,7 +286,36 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
             for (int ct = 0; ct < 2; ++ct) {
                 const int cl = wch + ct * 32 + 4 * lhi;
                 const size_t ob = pix * CO + wch + ct * 32;
-                if constexpr (O6) {
+                if constexpr (X3) {      // hi / lo' planes (x3_split's arithmetic, as conv3x3_pp<x3, planes out>)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        uint2 pk[2], ck[2];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int q = 2 * m + j;
+                            const float4 sc = *reinterpret_cast<const float4 *>(SS + cl + 8 * q);
+                            const float4 sh = *reinterpret_cast<const float4 *>(SS + S2_BN + cl + 8 * q);
+                            constexpr float k = 1.0f / 2048.0f;
+                            const float lo = relu ? 0.0f : -__builtin_huge_valf();
+                            float v0 = acc[ct][pr][4 * q + 0] * k * sc.x + sh.x, v1 = acc[ct][pr][4 * q + 1] * k * sc.y + sh.y;
+                            float v2 = acc[ct][pr][4 * q + 2] * k * sc.z + sh.z, v3 = acc[ct][pr][4 * q + 3] * k * sc.w + sh.w;
+                            v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
+                            const h4_t hv = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+                            const h4_t lv = {(half_t)((v0 - (float)hv[0]) * 2048.0f), (half_t)((v1 - (float)hv[1]) * 2048.0f),
+                                             (half_t)((v2 - (float)hv[2]) * 2048.0f), (half_t)((v3 - (float)hv[3]) * 2048.0f)};
+                            __builtin_memcpy(&pk[j], &hv, 8);
+                            __builtin_memcpy(&ck[j], &lv, 8);
+                        }
+                        const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                        const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                        const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
+                        const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
+                        if (inb) {
+                            *reinterpret_cast<uint4 *>(out + ob + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                            *reinterpret_cast<uint4 *>(out_c + ob + 8 * (2 * m + lhi)) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
+                        }
+                    }
+                } else if constexpr (O6) {
                     float4 sc4[4], sh4[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -303,11 +359,11 @@ void conv2b_s2d_kernel(const half_t *__restrict__ in /* s2d hi plane [H4][W4][4]
                 }
             }
         }
-        { const unsigned int wb = sfd2_wave_max_bits(mx); smax = wb > smax ? wb : smax; }
+        if (!X3) { const unsigned int wb = sfd2_wave_max_bits(mx); smax = wb > smax ? wb : smax; }
         if (!has_next) break;
         tile = next;
     }
-    if (range != nullptr) sfd2_range_commit(range, smax);
+    if (!X3 && range != nullptr) sfd2_range_commit(range, smax);
 #undef S2_SETUP
 #undef S2_ISSUE_X
 #undef S2_ISSUE_F
@@ -357,4 +413,27 @@ void launch_conv2b_s2d(hipStream_t st, const half_t *in, const half_t *in_c, int
     else
         hipLaunchKernelGGL(conv2b_s2d_kernel<false>, dim3(grid), dim3(512), lds, st, in, in_c, H4, W4, wpk, scale, shift, relu, out, out_c, tiles_x,
                            n_tiles, zero_page, sa, range);
+}
+
+// SFD2_PREC_F16X3: conv2b on hi / lo' planes stored space-to-depth (conv3x3_pp<x3, planes out, s2d>), planes out.  wpk = the layer's f16x3
+// filter planes, [4 hi chunks | 4 lo' chunks][9][128][32] (api_network.hip convf: x3_split_planes of the packed fp32 filters).
+void launch_conv2b_s2d_x3(hipStream_t st, const half_t *in_hi, const half_t *in_lo, int H4, int W4, const half_t *wpk, const float *scale,
+                          const float *shift, int relu, half_t *out_hi, half_t *out_lo, const half_t *zero_page)
+{
+    constexpr size_t lds = (size_t)3 * S2_XBYTES + (size_t)2 * S2_FBYTES + 2 * S2_BN * sizeof(float);
+    static bool attr_done = false;
+    static int slots = 256;
+    auto kern = conv2b_s2d_kernel<false, 0, true>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            slots = cus;
+        attr_done = true;
+    }
+    const int tiles_x = (W4 + S2_TW - 1) / S2_TW, tiles_y = (H4 + S2_TH - 1) / S2_TH;
+    const int n_tiles = tiles_x * tiles_y;
+    const int grid = n_tiles < sfd2_slots(slots) ? n_tiles : sfd2_slots(slots);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, in_hi, in_lo, H4, W4, wpk, scale, shift, relu, out_hi, out_lo, tiles_x, n_tiles,
+                       zero_page, 0, nullptr);
 }

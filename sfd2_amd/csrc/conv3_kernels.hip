@@ -634,8 +634,9 @@ void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, i
 // (out_lo != null) or fp32 [Ho][Wo][CoutP] (out_f32).  Three passes of the fp16 K loop: hi x hi, hi x lo', lo' x hi.
 void launch_conv3x3_pp_x3(hipStream_t st, const half_t *in, const half_t *in_lo, int H, int W, int Cin, const half_t *wpk,
                           const float *scale, const float *shift, int CoutP, int relu, half_t *out_hi, half_t *out_lo, float *out_f32,
-                          int Ho, int Wo, const half_t *zero_page)
+                          int Ho, int Wo, const half_t *zero_page, int s2d)
 {
+    if (s2d && !out_f32) { launch_pp_t<1, 1, 0, 6 | 128>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out_hi, Ho, Wo, zero_page, in_lo, out_lo, 0); return; }
     if (out_f32) launch_pp_t<1, 1, 0, 12>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, reinterpret_cast<half_t *>(out_f32), Ho, Wo, zero_page, in_lo, nullptr, 0);
     else launch_pp_t<1, 1, 0, 6>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out_hi, Ho, Wo, zero_page, in_lo, out_lo, 0);
 }

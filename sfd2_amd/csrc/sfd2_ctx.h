@@ -138,6 +138,7 @@ struct sfd2_ctx {
     DevBuf x3_rb_planes[3];            // a ResBlock's input, conv1's and the grouped conv's outputs as hi / lo' planes
     const void *x3_pre_src = nullptr;  // set by a producer that wrote its output as planes too: the fp32 tensor they belong to ...
     const half_t *x3_pre_hi = nullptr, *x3_pre_lo = nullptr;   // ... and the planes (consumed by the next convf on that tensor)
+    int x3_s2d_out_now = 0;            // set around conv2a's convf call: its planes are stored space-to-depth for conv2b_s2d_kernel<x3> (option "s2d")
     int x3_planes_out_now = 0;         // set around a convf call: the 3x3 layer writes hi / lo' planes INTO x3_chain instead of fp32
     DevBuf x3_chain;                   // planes handed from conv3a to conv3b (throughput path of f16x3)
     int opt_fuse_post = 1;             // sfd2_set_option "fuse_post": heads -> heat map -> NMS in one kernel on the extract path

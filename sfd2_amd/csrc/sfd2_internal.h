@@ -386,6 +386,8 @@ bool conv3x3_rf_c_serves(int ks, int stride, int CoutP, int Cin, int Ho, int Wo)
 bool conv2b_s2d_serves(int H2, int W2, int Cin, int CoutP);
 void launch_conv2b_s2d(hipStream_t st, const half_t *in_s2d, const half_t *in_c_s2d, int H4, int W4, const half_t *wpk, const float *scale,
                        const float *shift, int relu, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte, unsigned int *range, int fmt6 /* bit 1: out_c as fp6 half-records */);
+void launch_conv2b_s2d_x3(hipStream_t st, const half_t *in_hi_s2d, const half_t *in_lo_s2d, int H4, int W4, const half_t *wpk /* [4 hi | 4 lo' chunks][9][128][32] */,
+                          const float *scale, const float *shift, int relu, half_t *out_hi, half_t *out_lo, const half_t *zero_page);
 bool launch_conv3x3_rf_c(hipStream_t st, const half_t *in, const half_t *in_c, int H, int W, int Cin, const half_t *wpk,
                          const float *scale, const float *shift, int CoutP, int stride, int relu, half_t *out, half_t *out_c,
                          int Ho, int Wo, const half_t *zero_page, int sbyte, unsigned int *range = nullptr, int fmt6 = 0 /* bit 1: out_c as fp6 half-records */);
@@ -438,7 +440,7 @@ void launch_x3_split_planes(hipStream_t st, const float *in, size_t n_floats, vo
 // conv3_kernels.hip: SFD2_PREC_F16X3 for the 3x3 stride-1 layers on pre-split planes (three passes of conv3x3_pp's fp16 K loop)
 void launch_conv3x3_pp_x3(hipStream_t st, const half_t *in, const half_t *in_lo, int H, int W, int Cin, const half_t *wpk,
                           const float *scale, const float *shift, int CoutP, int relu, half_t *out_hi, half_t *out_lo, float *out_f32,
-                          int Ho, int Wo, const half_t *zero_page);
+                          int Ho, int Wo, const half_t *zero_page, int s2d = 0 /* planes out stored space-to-depth (conv2b_s2d_kernel<x3>; Ho, Wo even) */);
 void launch_gconv_x3_pack(hipStream_t st, const float *w /*[256][8][3][3]*/, void *out /*16 * 5 * 64 * 16 halves*/);
 void launch_gconv_x3(hipStream_t st, const float *in, int H, int W, const void *wpk, const float *scale, const float *shift, float *out);
 void launch_conv_igemm_x3(hipStream_t st, const float *in, int H, int W, int Cin, const float *wpk,

@@ -663,3 +663,35 @@ def test_f16x3_throughput_kernels_equal_generic_path(synth_sd, h, w, topk):
     np.testing.assert_allclose(a["scores"][ia], b["scores"][ib], rtol=1e-4, atol=1e-7)   # (soft-max of logits that agree to ~1e-6)
     dd = np.abs(a["descriptors"][ia] - b["descriptors"][ib]).max()
     assert dd <= 5e-6, dd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,topk", [(480, 640, 1024), (200, 264, 300), (1200, 1600, 4096)])
+def test_f16x3_s2d_conv2b_equals_strided_kernel(synth_sd, h, w, topk):
+    """Round 5: f16x3's conv2b as a stride-1 layer over conv2a's planes stored space-to-depth (conv2b_s2d_kernel<x3>, option 's2d') against
+    the strided conv3x3_rf<2, x3> (s2d = 0): the same products in another fp32 summation order -- key-point list equal up to a near-tie at the
+    top-K boundary, scores within 1e-4 relative, descriptors within 5e-6; and both within 2e-5 of the oracle (test_f16x3_extract_vs_oracle runs
+    with the default, s2d = 1)."""
+    from sfd2_amd.model import ResSegNetV2
+    from sfd2_amd.extractor import extract_resnet_return
+    img = synth.make_image(h, w, 92)
+    outs, kernels = [], []
+    for s2d in (1, 0):
+        m = ResSegNetV2(outdim=128, require_stability=True, precision="f16x3").eval()
+        m.load_state_dict(synth_sd)
+        m.cuda(0)
+        m.context.set_option("s2d", s2d)
+        m.context.set_profiling(4)
+        outs.append(extract_resnet_return(m, img[None], conf_th=0.001, topK=topk, scales=[1.0]))
+        kernels.append({r["name"]: r["kernel"] for r in m.context.layer_timings()}.get("conv2b", ""))
+    assert "s2d" in kernels[0] and "s2d" not in kernels[1], kernels          # the option selects the kernel it says it selects
+    a, b = outs
+    assert len(a["keypoints"]) == len(b["keypoints"]) > 0
+    ka = {(float(x), float(y)): i for i, (x, y) in enumerate(a["keypoints"])}
+    kb = {(float(x), float(y)): i for i, (x, y) in enumerate(b["keypoints"])}
+    common = sorted(set(ka) & set(kb))
+    assert len(common) >= 0.998 * len(ka), (len(common), len(ka))
+    ia = np.array([ka[k] for k in common]); ib = np.array([kb[k] for k in common])
+    np.testing.assert_allclose(a["scores"][ia], b["scores"][ib], rtol=1e-4, atol=1e-7)
+    dd = np.abs(a["descriptors"][ia] - b["descriptors"][ib]).max()
+    assert dd <= 5e-6, dd
