@@ -362,3 +362,40 @@ def test_f16_matcher_decides_like_fp64_above_2e4_gap_on_network_descriptors(synt
                 assert np.abs(s - (sim.max(1) + 1.0) / 2.0).max() <= (1e-3 if mode == _lib.SIM_F16 else 1e-5)
             n_band += int(((gap > 2e-4) & (gap <= 1e-3)).sum())
     assert n_band > 50      # the band the contract is about is populated on these sets
+
+
+@pytest.mark.parametrize("mode", ["NNM", "NNR"])
+def test_store_matcher_equals_feature_matching_batch(tmp_path, mode):
+    """The localiser's loop against a feature store with resident database sets (sfd2_amd.localize.StoreMatcher) == feature_matching_batch on
+    the arrays read back from the store, with 3D-point masks, the <= 3 early-out, an unmasked image, a tiny cache (evictions) and a query that
+    is itself a set of the store."""
+    from sfd2_amd.feature_io import open_store
+    from sfd2_amd.localize import StoreMatcher, feature_matching_batch
+    from sfd2_amd.matcher import Matcher, confs as mconfs
+    rs = np.random.RandomState(21)
+    base = synth.make_descriptors(1500, seed=31)
+    sets, ids = {}, {}
+    for i, n in enumerate([900, 64, 1500, 10, 700, 333]):
+        d = base[rs.permutation(1500)[:n]] + 0.03 * rs.standard_normal((n, 128)).astype(np.float32)
+        sets[f"db/{i}.jpg"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        ids[f"db/{i}.jpg"] = np.where(rs.random_sample(n) < 0.5, rs.randint(0, 100000, n), -1)
+    ids["db/3.jpg"][:] = -1
+    ids["db/3.jpg"][:3] = 7
+    sets["query/q.jpg"] = base[:800].copy()
+    _feature_store(str(tmp_path / "feats.h5"), sets)
+    feats = open_store(str(tmp_path / "feats.h5"), "r")
+    mt = Matcher(mconfs[mode]).eval().cuda()
+    sm = StoreMatcher(mt, feats, cache_bytes=1500 * 128 * 2)      # less than one query's sets: every call evicts
+    names = [n for n in sets if n.startswith("db/")]
+    q = feats["query/q.jpg"]["descriptors"].__array__().transpose()                  # [N,128] float64, as the localiser reads it
+    dbs = [np.ascontiguousarray(feats[n]["descriptors"].__array__().transpose()) for n in names]
+    for trial, id_list in enumerate(([ids[n] for n in names], [None if i == 2 else ids[n] for i, n in enumerate(names)], None)):
+        want = feature_matching_batch(q, dbs, mt, [None] * len(names) if id_list is None else id_list)
+        got = sm.match(q, names, id_list)
+        got_by_name = sm.match("query/q.jpg", names, id_list)
+        for i in range(len(names)):
+            np.testing.assert_array_equal(got[i], want[i], err_msg=f"{trial} {names[i]}")
+            np.testing.assert_array_equal(got_by_name[i], want[i], err_msg=f"{trial} {names[i]} (query by name)")
+    assert (sm.match(q, names, [ids[n] for n in names])[3] == -1).all()
+    assert sm.sets.evictions > 0 and sm.sets.loads > len(names)
+    sm.close()
