@@ -399,3 +399,22 @@ def test_store_matcher_equals_feature_matching_batch(tmp_path, mode):
     assert (sm.match(q, names, [ids[n] for n in names])[3] == -1).all()
     assert sm.sets.evictions > 0 and sm.sets.loads > len(names)
     sm.close()
+
+
+def test_grouped_match_driver_with_empty_and_tiny_sets(tmp_path):
+    """Images without key points (n = 0) and with a handful, on either side of a pair: the grouped driver and the per-pair loop agree (all -1 /
+    empty rows), nothing is read out of bounds."""
+    from sfd2_amd import match_features as mf
+    sets = {"q/empty.jpg": np.zeros((0, 128), np.float32), "q/some.jpg": synth.make_descriptors(300, seed=41),
+            "db/empty.jpg": np.zeros((0, 128), np.float32), "db/one.jpg": synth.make_descriptors(1, seed=42),
+            "db/many.jpg": synth.make_descriptors(513, seed=43)}
+    _feature_store(str(tmp_path / "feats-e.h5"), sets)
+    pairs = [f"{q} {d}" for q in ("q/empty.jpg", "q/some.jpg") for d in ("db/empty.jpg", "db/one.jpg", "db/many.jpg")] + ["db/one.jpg db/many.jpg"]
+    a = mf.main(mf.confs["NNM"], pairs, "feats-e", tmp_path, pairs_name="serial", grouped=False)
+    b = mf.main(mf.confs["NNM"], pairs, "feats-e", tmp_path, pairs_name="grouped", grouped=True)
+    assert len(_stores_equal(b, a)) == 7
+    from sfd2_amd.feature_io import open_store
+    st = open_store(b, "r")
+    assert st[mf.names_to_pair("q/empty.jpg", "db/many.jpg")]["matches0"].shape == (0,)
+    assert (st[mf.names_to_pair("q/some.jpg", "db/empty.jpg")]["matches0"].__array__() == -1).all()
+    assert st[mf.names_to_pair("q/some.jpg", "db/empty.jpg")]["matches0"].shape == (300,)

@@ -199,3 +199,25 @@ def test_group_pairs_is_query_major_in_first_appearance_order():
     pairs = mf.unique_pairs(["q1 a", "q0 a", "q1 b", "a q1", "q0 c", "q1 c", "q0 a"])
     assert pairs == [("q1", "a"), ("q0", "a"), ("q1", "b"), ("q0", "c"), ("q1", "c")]
     assert mf.group_pairs(pairs) == [("q1", [(0, "a"), (2, "b"), (4, "c")]), ("q0", [(1, "a"), (3, "c")])]
+
+
+def test_pipelined_main_surfaces_decode_errors(tmp_path):
+    """An unreadable image raises in the pipelined loop as it does in the serial one (extract_localization.py:166-167), it does not hang
+    the pool; groups written before it stay readable."""
+    from sfd2_amd import extract_localization as el
+
+    class Items:
+        def __len__(self):
+            return 9
+
+        def __getitem__(self, idx):
+            if idx == 5:
+                raise ValueError("Cannot read image broken.jpg.")
+            return {"name": f"im{idx}.jpg", "image": np.full((3, 8, 8), idx, np.float32), "original_size": (8, 8)}
+
+    name, conf = next(iter(el.confs.items()))
+    for nw in (0, 3):
+        with pytest.raises(ValueError, match="Cannot read image"):
+            el.main(conf, Items(), tmp_path / f"o{nw}", model_and_extractor=(None, _stub_extractor), num_workers=nw)
+        st = fio.open_store(str(tmp_path / f"o{nw}" / (conf["output"] + ".h5")), "r")
+        assert set(st.keys()) <= {f"im{i}.jpg" for i in range(5)} and len(st.keys()) >= (5 if nw == 0 else 0)
