@@ -14,6 +14,7 @@
 //     (pixel & 31) on the copy's source address and on the read.
 #include "sfd2_internal.h"
 #include <stdlib.h>
+#include <algorithm>
 
 #define NT1 512
 #define GPX 64                      // pixels per group (stage)
@@ -213,6 +214,14 @@ void launch_conv1x1_c256(hipStream_t st, const half_t *in, int npix, const half_
 #ifndef SFD2_R1_VSCALE
 #define SFD2_R1_VSCALE 4.0f
 #endif
+// Ring depth of the residual-byte form (IN_C = 2, the default path's ResBlock.conv1): SFD2_C256_R1_STAGES stages of exactly 24 KB (16 KB of
+// hi records + 8 KB of residual bytes), filled (stages - 1) groups ahead.  Round 5 asked whether this kernel's 3.4 TB/s is the bytes it keeps in
+// flight (the fp16 kernel holds 3 x 32 KB ahead and reaches 4.0-4.4 TB/s; this form 3 x 24 KB): six stages = 120 KB in flight in 146 KB of LDS
+// measured conv1 44.5 / 43.6 / 43.4 us against 44.0 / 42.6 / 41.5 with four (same box, interleaved) -- it is not; four stages stay.
+#ifndef SFD2_C256_R1_STAGES
+#define SFD2_C256_R1_STAGES 4
+#endif
+#define STAGE_R1 (GPXC * 512 + GPXC * 256)
 template <bool HAS_RES, int IN_C, bool OUT_C>
 __global__ __launch_bounds__(NT1, 2)
 void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in_c, int npix,
@@ -226,9 +235,13 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
                            half_t *__restrict__ out, half_t *__restrict__ out_c, int groups_per_block,
                            const half_t *__restrict__ zero_page, int sa, unsigned int *__restrict__ range /* the output tensor's range-status slot */)
 {
+    constexpr int NSTC = IN_C == 2 ? SFD2_C256_R1_STAGES : NST;           // ring stages
+    constexpr int STB = IN_C == 2 ? STAGE_R1 : STAGE_C;                    // bytes per stage
+    constexpr int AHEAD = NSTC - 1;                                        // groups requested ahead of the one being computed
+    constexpr int CPG = IN_C == 1 ? 4 : IN_C == 2 ? 3 : 2;                 // copies per group and wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *Xs = smem;                                              // [NST][hi 32 x 512 B | corr 32 x 512 B (IN_C = 2: 32 x 256 B)]
-    float *SS = reinterpret_cast<float *>(smem + NST * STAGE_C);
+    unsigned char *Xs = smem;                                              // [NSTC][hi 32 x 512 B | corr 32 x 512 B (IN_C = 2: 32 x 256 B)]
+    float *SS = reinterpret_cast<float *>(smem + NSTC * STB);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -255,7 +268,7 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
     // group g -> ring stage: 16 + 16 one-KB chunks (2 pixel records each): 2 of each plane per wave
 #define ISSUE_GC(g_)                                                                                       \
     {                                                                                                      \
-        unsigned char *st = Xs + ((g_) & (NST - 1)) * STAGE_C;                                             \
+        unsigned char *st = Xs + (unsigned)((g_) - g0) % (unsigned)NSTC * STB;                             \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
             const int ch = wave * 2 + i;                                                                   \
             const int p = ch * 2 + lhi;                                                                    \
@@ -277,20 +290,20 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
         }                                                                                                  \
     }
 #define WAIT_GROUP_C()                                                                                     \
-    /* (N = the copies of the two younger groups, loads only: see WAIT_GROUP) */                          \
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (IN_C == 1 ? 4 : IN_C == 2 ? 3 : 2)) : "memory")
+    /* (N = the copies of the AHEAD - 1 younger groups, loads only: see WAIT_GROUP) */                    \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((AHEAD - 1) * CPG) : "memory")
 
-    ISSUE_GC(g0)
-    if (g0 + 1 < g1) { ISSUE_GC(g0 + 1) }
-    if (g0 + 2 < g1) { ISSUE_GC(g0 + 2) }
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+        if (g0 + a < g1) { ISSUE_GC(g0 + a) }
     SFD2_BARRIER_DRAIN();
 
     float mx = 0.0f;     // range status: the largest output value in front of the saturation
     for (int g = g0; g < g1; ++g) {
         if (g != g0) {
-            if (g + 2 < g1) WAIT_GROUP_C(); else SFD2_BARRIER_DRAIN();
+            if (g + AHEAD - 1 < g1) WAIT_GROUP_C(); else SFD2_BARRIER_DRAIN();
         }
-        const unsigned char *st = Xs + (g & (NST - 1)) * STAGE_C;
+        const unsigned char *st = Xs + (unsigned)(g - g0) % (unsigned)NSTC * STB;
         const int p = lrow;
         const long long gp = (long long)g * GPXC + p;
         const bool inb = gp < npix;
@@ -309,7 +322,7 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
             }
             asm volatile("" ::: "memory");       // keep the residual loads ahead of the copies below in program order
         }
-        if (g + 3 < g1) { ISSUE_GC(g + 3) }
+        if (g + AHEAD < g1) { ISSUE_GC(g + AHEAD) }
 
         f32x16_t acc;
 #pragma unroll
@@ -635,9 +648,10 @@ void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c,
 {
     static bool attr_done = false;
     static int slots = 256;
-    const size_t lds = (size_t)NST * STAGE_C + 512 * sizeof(float);
+    const size_t lds = in_r1 ? (size_t)SFD2_C256_R1_STAGES * STAGE_R1 + 512 * sizeof(float) : (size_t)NST * STAGE_C + 512 * sizeof(float);
     if (!attr_done) {
-#define C256C_ATTR(R_, I_, O_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_c256_c_kernel<R_, I_, O_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const size_t lds_max = std::max((size_t)SFD2_C256_R1_STAGES * STAGE_R1, (size_t)NST * STAGE_C) + 512 * sizeof(float);
+#define C256C_ATTR(R_, I_, O_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_c256_c_kernel<R_, I_, O_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         C256C_ATTR(true, 1, true) C256C_ATTR(false, 1, true) C256C_ATTR(false, 1, false) C256C_ATTR(true, 0, true) C256C_ATTR(false, 2, false)
 #undef C256C_ATTR
         int dev = 0, cus = 0;
