@@ -247,9 +247,20 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lhi = lane >> 5;
     const int ngroups = (npix + GPXC - 1) / GPXC;
+    // The block's groups, as ring positions g0 .. g1 - 1 -> group numbers GRP(g).  -DSFD2_C256_INTERLEAVE (experiment): block b takes groups b,
+    // b + grid, ... (at any moment the CUs work in one window of grid x 24 KB of the tensor) instead of a contiguous share of groups_per_block.
+    // Measured round 5, same box, interleaved: conv1 41.8 / 40.8 / 40.7 us contiguous, 41.7 / 41.4 / 42.0 interleaved -- the order the CUs walk
+    // the tensor in is not what holds this kernel at 3.5-3.7 TB/s either.
+#ifdef SFD2_C256_INTERLEAVE
+    const int g0 = 0;
+    const int g1 = ((int)blockIdx.x < ngroups) ? (ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+#define GRP(g_) ((int)blockIdx.x + (g_) * (int)gridDim.x)
+#else
     const int g0 = blockIdx.x * groups_per_block;
     int g1 = g0 + groups_per_block;
     if (g1 > ngroups) g1 = ngroups;
+#define GRP(g_) (g_)
+#endif
     if (g0 >= g1) return;
 
     h8_t ah[16];
@@ -272,7 +283,7 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
             const int ch = wave * 2 + i;                                                                   \
             const int p = ch * 2 + lhi;                                                                    \
-            const long long gp = (long long)(g_)*GPXC + p;                                                 \
+            const long long gp = (long long)GRP(g_)*GPXC + p;                                                 \
             const size_t so = (size_t)gp * 256 + ((lrow ^ (p & 31)) << 3);                                 \
             const half_t *s0 = gp < npix ? in + so : zero_page + (lrow << 3);                              \
             __builtin_amdgcn_global_load_lds((gbl_void_t *)s0, (lds_void_t *)(st + ch * 1024), 16, 0, 0);  \
@@ -283,7 +294,7 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
         }                                                                                                  \
         if (IN_C == 2) {   /* residual bytes: 256 B per pixel, ONE one-KB chunk (4 pixels) per wave, 16-byte slots XOR (pixel & 15) */ \
             const int p = wave * 4 + (lane >> 4);                                                          \
-            const long long gp = (long long)(g_)*GPXC + p;                                                 \
+            const long long gp = (long long)GRP(g_)*GPXC + p;                                                 \
             const unsigned char *s1 = gp < npix ? reinterpret_cast<const unsigned char *>(in_c) + (size_t)gp * 256 + (((lane & 15) ^ (p & 15)) << 4) \
                                                 : reinterpret_cast<const unsigned char *>(zero_page) + ((lane & 15) << 4); \
             __builtin_amdgcn_global_load_lds((gbl_void_t *)s1, (lds_void_t *)(st + GPXC * 512 + wave * 1024), 16, 0, 0); \
@@ -305,7 +316,7 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
         }
         const unsigned char *st = Xs + (unsigned)(g - g0) % (unsigned)NSTC * STB;
         const int p = lrow;
-        const long long gp = (long long)g * GPXC + p;
+        const long long gp = (long long)GRP(g) * GPXC + p;
         const bool inb = gp < npix;
         const size_t obase = (size_t)(inb ? gp : 0) * 256 + wave * 32;
 
@@ -433,6 +444,7 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
     }
     sfd2_range_commit(range, sfd2_wave_max_bits(mx));
 #undef ISSUE_GC
+#undef GRP
 #undef WAIT_GROUP_C
 }
 
