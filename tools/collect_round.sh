@@ -17,12 +17,12 @@ python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smo
 python tools/determinism_check.py 1500 f16c > $out/determinism.txt 2>&1
 python tools/determinism_check.py 500 f16 >> $out/determinism.txt 2>&1
 python bench.py > $out/bench.json 2> $out/bench.err
-python bench.py --steps 20 --warmup 5 --streams 1 --no-graphs --no-cpu-baseline --no-strict --dump-layers > $out/bench_streams1_eager.json 2> $out/layer_table.txt
+python bench.py --steps 20 --warmup 5 --streams 1 --no-graphs --no-cpu-baseline --no-strict --no-pipeline --dump-layers > $out/bench_streams1_eager.json 2> $out/layer_table.txt
 python bench.py --extract-only --no-cpu-baseline --no-strict > $out/bench_extract_only.json 2>/dev/null
-python bench.py --no-graphs --no-cpu-baseline --no-strict > $out/bench_eager.json 2>/dev/null
-python bench.py --comp-rb 0 --no-cpu-baseline --no-strict > $out/bench_comp_rb0.json 2>/dev/null
+python bench.py --no-graphs --no-cpu-baseline --no-strict --no-pipeline > $out/bench_eager.json 2>/dev/null
+python bench.py --comp-rb 0 --no-cpu-baseline --no-strict --no-pipeline > $out/bench_comp_rb0.json 2>/dev/null
 python bench.py --precision f16 --no-cpu-baseline --no-strict > $out/bench_f16.json 2>/dev/null
-python bench.py --mix --no-cpu-baseline --no-strict > $out/bench_mix.json 2>/dev/null
+python bench.py --mix --no-cpu-baseline --no-strict --no-pipeline > $out/bench_mix.json 2>/dev/null
 python bench.py --size 1024x1024 --no-cpu-baseline --no-strict > $out/bench_1024x1024.json 2>/dev/null
 python bench.py --size 1024x768 --no-cpu-baseline --no-strict > $out/bench_1024x768.json 2>/dev/null
 python bench.py --size 640x480 --no-cpu-baseline --no-strict --steps 20 --warmup 5 --streams 1 --no-graphs --dump-layers > $out/bench_640x480_streams1.json 2> $out/layer_table_640x480.txt
@@ -31,14 +31,14 @@ python tools/pipeline_bench.py > $out/pipeline_bench.json 2> $out/pipeline_bench
 python tools/pipeline_bench.py --workers 8 --precision f16c > $out/pipeline_bench_w8.json 2>> $out/pipeline_bench.err
 python tools/match_gap_stats.py > $out/match_gap_stats.json 2> $out/match_gap_stats.err
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strict --sustain 0"
+B="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strict --no-pipeline --sustain 0"
 rocprofv3 --kernel-trace --stats -d $out/prof -o $tag -- $B > $out/prof_bench.json 2> $out/prof.err
 python $R/tools/rocprof_summary.py $out/prof/*/${tag}_results.db > $out/rocprof_kernel_stats.txt 2>> $out/prof.err || python $R/tools/rocprof_summary.py $out/prof/${tag}_results.db > $out/rocprof_kernel_stats.txt 2>> $out/prof.err
-S1="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strict --sustain 0 --no-graphs --streams 1"
+S1="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strict --no-pipeline --sustain 0 --no-graphs --streams 1"
 rocprofv3 --kernel-trace --stats -d $out/prof1 -o ${tag}s1 -- $S1 > $out/prof_bench_streams1.json 2> $out/prof1.err
 python $R/tools/rocprof_summary.py $out/prof1/*/${tag}s1_results.db > $out/rocprof_kernel_stats_streams1.txt 2>> $out/prof1.err || python $R/tools/rocprof_summary.py $out/prof1/${tag}s1_results.db > $out/rocprof_kernel_stats_streams1.txt 2>> $out/prof1.err
 rm -rf $out/prof1/*/*.db $out/prof1/*.db
-S="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strict --sustain 0 --no-graphs --streams 1"
+S="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strict --no-pipeline --sustain 0 --no-graphs --streams 1"
 rocprofv3 --pmc FETCH_SIZE -d $out/pmc1 -o x --output-format csv -- $S > /dev/null 2> $out/pmc1.err
 rocprofv3 --pmc WRITE_SIZE -d $out/pmc2 -o x --output-format csv -- $S > /dev/null 2> $out/pmc2.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $out/pmc3 -o x --output-format csv -- $S > /dev/null 2> $out/pmc3.err
