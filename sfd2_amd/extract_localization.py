@@ -265,7 +265,7 @@ def _feed_of(model, data):
 
 
 def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precision="f16x3", world=1, rank=0,
-         barrier=None, model_and_extractor=None, num_workers=0, writers=2, depth=3, lanes=1):
+         barrier=None, model_and_extractor=None, num_workers=4, writers=2, depth=3, lanes=1):
     """extract_localization.py:221-279.  ``images``: an ImageDataset (decoded from files, resized per
     conf['preprocessing']) or any indexable / iterable of {'name', 'image': uint8 [H,W,3] RGB or float [3,H,W] in
     [0,1], 'original_size': (w, h)[, 'resize': (w, h)]}.  uint8 input is exact only together with the device resize
@@ -276,9 +276,9 @@ def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precisio
     is the loop that shards), writes them to its own part store and, after ``barrier()`` (torch.distributed.barrier
     or equivalent; one process per GPU), rank 0 merges the parts into the final store in item order.
 
-    num_workers > 0: the pipelined loop (_extract_pipelined: that many decoder threads -- the reference's DataLoader
-    uses 4 --, `depth` images in flight on the device over `lanes` contexts (HIP streams), `writers` writer threads); 0:
-    the reference's serial loop.
+    num_workers > 0 (default 4, the reference's DataLoader(num_workers=4), extract_localization.py:230-233): the pipelined
+    loop (_extract_pipelined: that many decoder threads, `depth` images in flight on the device over `lanes` contexts
+    (HIP streams), `writers` writer threads); 0: the reference's loop body strictly in turn per image.
     Both write the same groups.
     Returns the final store path (rank 0) or the part path (other ranks)."""
     from .feature_io import open_store, write_features

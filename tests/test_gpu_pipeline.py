@@ -74,7 +74,7 @@ def test_pipelined_extract_equals_serial_loop(tmp_path, synth_sd, precision):
     p_two = el.main(conf, ds, tmp_path / "two", model_and_extractor=(model, el.extract_resnet_return), num_workers=4, depth=4, lanes=2)
     _stores_equal(p_two, p_serial)
     # tag filter and the two-rank sharding go through the same loop
-    p_tag_s = el.main(conf, ds, tmp_path / "tag_s", model_and_extractor=(model, el.extract_resnet_return), tag="query")
+    p_tag_s = el.main(conf, ds, tmp_path / "tag_s", model_and_extractor=(model, el.extract_resnet_return), tag="query", num_workers=0)
     p_tag_p = el.main(conf, ds, tmp_path / "tag_p", model_and_extractor=(model, el.extract_resnet_return), tag="query", num_workers=2)
     assert all(n.startswith("query/") for n in _stores_equal(p_tag_p, p_tag_s))
     assert model.context.range_status()["fallbacks"] == 0
@@ -94,7 +94,7 @@ def test_pipelined_extract_in_memory_items_and_float_images(tmp_path, synth_sd):
             items.append({"name": f"m/{i}.png", "image": (f.transpose(1, 2, 0) * 255).astype(np.uint8), "original_size": (256, 192)})
     name, conf = next(iter(el.confs.items()))
     conf = {**conf, "model": {**conf["model"], "max_keypoints": 150}}
-    a = el.main(conf, items, tmp_path / "s", model_and_extractor=(model, el.extract_resnet_return))
+    a = el.main(conf, items, tmp_path / "s", model_and_extractor=(model, el.extract_resnet_return), num_workers=0)
     b = el.main(conf, items, tmp_path / "p", model_and_extractor=(model, el.extract_resnet_return), num_workers=2)
     assert _stores_equal(b, a) == sorted(it["name"] for it in items)
 
@@ -110,7 +110,7 @@ def test_pipelined_extract_repeats_saturated_images_in_strict_mode(tmp_path):
               "original_size": (128, 96)} for i in range(4)]
     name, conf = next(iter(el.confs.items()))
     conf = {**conf, "model": {**conf["model"], "max_keypoints": 100}}
-    a = el.main(conf, items, tmp_path / "s", model_and_extractor=(model, el.extract_resnet_return))
+    a = el.main(conf, items, tmp_path / "s", model_and_extractor=(model, el.extract_resnet_return), num_workers=0)
     n_serial = model.context.range_status(reset=True)["fallbacks"]
     b = el.main(conf, items, tmp_path / "p", model_and_extractor=(model, el.extract_resnet_return), num_workers=2)
     st = model.context.range_status()

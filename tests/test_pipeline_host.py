@@ -180,10 +180,10 @@ def test_pipelined_main_equals_serial_main_with_stub_extractor(tmp_path):
                 assert u.dtype == v.dtype and np.array_equal(u, v), (k, ds)
         return list(x.keys())
 
-    a = el.main(conf, items, tmp_path / "s", model_and_extractor=me)
+    a = el.main(conf, items, tmp_path / "s", model_and_extractor=me, num_workers=0)
     b = el.main(conf, items, tmp_path / "p", model_and_extractor=me, num_workers=3, writers=2)
     assert len(equal(b, a)) == 23
-    at = el.main(conf, items, tmp_path / "st", model_and_extractor=me, tag="query")
+    at = el.main(conf, items, tmp_path / "st", model_and_extractor=me, tag="query", num_workers=0)
     bt = el.main(conf, items, tmp_path / "pt", model_and_extractor=me, tag="query", num_workers=2)
     assert len(equal(bt, at)) == 6
     # two ranks in turn (no barrier needed in one process), pipelined, then rank 0's merge
