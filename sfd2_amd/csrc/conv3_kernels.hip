@@ -68,6 +68,13 @@ __device__ __forceinline__ h4_t cvt4c(float a, float b, float c, float d)
 #else
 #define PP_NO_CORR_MFMA 0
 #endif
+// -DSFD2_PP_ABL_BARRIER (timing only, WRONG results): the corr chunks skip both barriers of every stage's middle unit -- how much of a corr
+// chunk's time is the per-slot synchronisation rather than its MFMAs, LDS reads or copies?
+#ifdef SFD2_PP_ABL_BARRIER
+#define PP_ABL_BARRIER 1
+#else
+#define PP_ABL_BARRIER 0
+#endif
 #ifndef SFD2_PP_KXM
 #define SFD2_PP_KXM 1
 #endif
@@ -356,7 +363,7 @@ _Pragma("unroll") \
             if (RING3 && u3 == 0 && st + 2 < NST) { PP_ISSUE_F(st + 2, (sg + 2) % 3) } \
             if (u3 == 2) { PP_STAGE_WAIT(sg, "lgkmcnt(0)") } \
             __builtin_amdgcn_sched_barrier(0); \
-            asm volatile("s_barrier" ::: "memory"); \
+            if (!(PP_ABL_BARRIER && f8 && u3 == 1)) asm volatile("s_barrier" ::: "memory"); /* PP_ABL_BARRIER: timing experiment, wrong results */ \
             __builtin_amdgcn_sched_barrier(0); \
 /* ---------------- MFMA section */ \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
@@ -391,7 +398,7 @@ _Pragma("unroll") \
             __builtin_amdgcn_sched_barrier(0); \
             if (u3 == 2) { PP_STAGE_WAIT(sg, "") } \
 /* group 1's last MFMA section has nobody left to hand the pipe to */ \
-            if (!(STAGGER && grp == 1 && t9 == 8 && c + 1 == NCT)) asm volatile("s_barrier" ::: "memory"); \
+            if (!(STAGGER && grp == 1 && t9 == 8 && c + 1 == NCT) && !(PP_ABL_BARRIER && f8 && u3 == 1)) asm volatile("s_barrier" ::: "memory"); \
             __builtin_amdgcn_sched_barrier(0); \
         } \
     /* end of PP_CHUNK_BODY */
