@@ -112,9 +112,15 @@ __device__ unsigned long long g_pp_wall[1024][2];
 __device__ unsigned long long g_pp_cyc[2][8][4];
 #define PP_WALL(k_) if (tid == 0) g_pp_wall[blockIdx.x][k_] = __builtin_amdgcn_s_memrealtime();
 #define PP_CYC(k_) if (blockIdx.x == 3 && (wave == 0 || wave == 4) && lane == 0 && it < 8) g_pp_cyc[wave == 4][it][k_] = __builtin_readcyclecounter();
+// unit-level stamps of the second tile's chunk 1 (a hi chunk) and chunk NCH + 1 (a corr chunk): LOAD begin, LOAD end (in front of its barrier), MFMA
+// begin (behind it), MFMA end (in front of the second barrier)
+__device__ unsigned long long g_pp_unit[2][2][9][4];
+#define PP_UCYC(k_) if (blockIdx.x == 3 && it == 1 && (c == 1 || c == NCH + 1) && (wave == 0 || wave == 4) && lane == 0) \
+        g_pp_unit[wave == 4][c != 1][t9][k_] = __builtin_readcyclecounter();
 #else
 #define PP_WALL(k_)
 #define PP_CYC(k_)
+#define PP_UCYC(k_)
 #endif
 
 template <int STAGGER, int PRIO, int ABL = 0, int KXM = SFD2_PP_KXM, int COMP = 0>
@@ -134,7 +140,9 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     constexpr bool S2D = (COMP & 128) != 0;                // the OUTPUT is stored space-to-depth: [Ho / 2][Wo / 2][(y & 1) * 2 + (x & 1)][CoutP] (conv2b_s2d_kernel.hip; Ho, Wo even)
     static_assert(!B6 || F6, "fp6 pixel operands come with fp6 filter strings");
     constexpr int SSN = F6 ? 3 : 2;                        // arrays per tile parity in SSb: scale, shift (, the fp6 filters' scale bytes)
-    constexpr bool RING3 = SFD2_PP_RING3 && (COMP & 1) && !(COMP & 4) && KXM && !ABL;   // interleaved chunks, three filter buffers (above)
+    constexpr bool RING3 = (SFD2_PP_RING3 != 0) && (COMP & 1) && !(COMP & 4) && KXM && !ABL;   // three filter buffers, counted waits (above)
+    constexpr bool ILV = RING3 && (SFD2_PP_RING3 & 1);      // bit 0: hi and corr chunks interleaved
+    constexpr bool SPREAD = RING3 && (SFD2_PP_RING3 & 2);   // bit 1: a stage's three filter pieces are requested one per unit instead of all in its first unit
     constexpr int NFB = RING3 ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Xs = smem;                              // [2][PP_XBYTES]
@@ -208,33 +216,37 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
     do {                                                                                               \
         const int pc_ = (wave + 8 * (i_) < PP_XCH) ? wave + 8 * (i_) : PP_XCH - 1;                     \
         if constexpr (RING3) {   /* one 32-bit offset per piece and lane instead of a 64-bit address per piece, lane AND plane */ \
-            if ((chunk_) & 1)                                                                          \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_c, (lds_void3_t *)(Xs + (buf_)*PP_XBYTES + pc_ * 1024), 16, xoff[i_], ((chunk_) >> 1) * (PP_CC * 2), 0, 0); \
+            const bool corr_ = ILV ? (((chunk_) & 1) != 0) : ((chunk_) >= NCH);                        \
+            const int so_ = (ILV ? ((chunk_) >> 1) : (corr_ ? (chunk_) - NCH : (chunk_))) * (PP_CC * 2); \
+            if (corr_)                                                                                 \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_c, (lds_void3_t *)(Xs + (buf_)*PP_XBYTES + pc_ * 1024), 16, xoff[i_], so_, 0, 0); \
             else                                                                                       \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lds_void3_t *)(Xs + (buf_)*PP_XBYTES + pc_ * 1024), 16, xoff[i_], ((chunk_) >> 1) * (PP_CC * 2), 0, 0); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lds_void3_t *)(Xs + (buf_)*PP_XBYTES + pc_ * 1024), 16, xoff[i_], so_, 0, 0); \
             break;                                                                                     \
         }                                                                                              \
         /* X3: chunks [0, 2 NCH) read the hi plane (against the hi, then the lo' filters), [2 NCH, 3 NCH) the lo' plane */ \
         /* RING3: chunk 2 k = channels 32 k of the hi plane, 2 k + 1 = the same channels of the corr plane */ \
-        const int pch_ = RING3 ? ((chunk_) >> 1)                                                       \
+        const int pch_ = ILV ? ((chunk_) >> 1)                                                         \
                                : (COMP & 4) ? ((chunk_) >= NCH ? (chunk_) - NCH - ((chunk_) >= 2 * NCH ? NCH : 0) : (chunk_)) : (chunk_); \
-        const half_t *pl_ = RING3 ? (((chunk_) & 1) ? in_c : in)                                       \
+        const half_t *pl_ = ILV ? (((chunk_) & 1) ? in_c : in)                                         \
                           : (COMP & 4) ? ((chunk_) >= 2 * NCH ? in_c : in)                             \
                                        : (((COMP & 1) && (chunk_) >= NCH) ? in_c - (size_t)NCH * PP_CC : in); \
         const half_t *src_ = xoff[i_] >= 0 ? pl_ + (size_t)xoff[i_] + pch_ * PP_CC : zero_page + (lane & 3) * 8; \
         __builtin_amdgcn_global_load_lds((gbl_void3_t *)src_,                                          \
                                          (lds_void3_t *)(Xs + (buf_)*PP_XBYTES + pc_ * 1024), 16, 0, 0); \
     } while (0)
-#define PP_ISSUE_F(stage_, buf_)                                                                       \
-    _Pragma("unroll") for (int i_ = 0; i_ < PP_FPW; ++i_) {                                            \
+#define PP_ISSUE_F1(stage_, buf_, i_)                                                                  \
+    {                                                                                                  \
         /* X3: the filter array is [hi chunks][lo' chunks]; the K loop's chunk sequence uses hi, lo', hi */ \
-        /* RING3: the array stays [hi chunks][corr chunks]; K-loop chunk c is array chunk (c & 1) * NCH + (c >> 1) */ \
-        const int fst_ = RING3 ? ((((stage_) / 3) & 1) * NCH + (((stage_) / 3) >> 1)) * 3 + (stage_) % 3 \
-                               : (COMP & 4) ? ((stage_) >= 6 * NCH ? (stage_) - 6 * NCH : (stage_)) : (stage_); \
+        /* ILV: the array stays [hi chunks][corr chunks]; K-loop chunk c is array chunk (c & 1) * NCH + (c >> 1) */ \
+        const int fst_ = ILV ? ((((stage_) / 3) & 1) * NCH + (((stage_) / 3) >> 1)) * 3 + (stage_) % 3   \
+                             : (COMP & 4) ? ((stage_) >= 6 * NCH ? (stage_) - 6 * NCH : (stage_)) : (stage_); \
         const half_t *src_ = wpk + (size_t)(KXM ? (fst_ / 3) * 9 + fst_ % 3 : fst_ * 3) * CoutP * PP_CC + woff[i_]; \
         __builtin_amdgcn_global_load_lds((gbl_void3_t *)src_,                                          \
-                                         (lds_void3_t *)(Fs + (buf_)*PP_FBYTES + (wave * PP_FPW + i_) * 1024), 16, 0, 0); \
+                                         (lds_void3_t *)(Fs + (buf_)*PP_FBYTES + (wave * PP_FPW + (i_)) * 1024), 16, 0, 0); \
     }
+#define PP_ISSUE_F(stage_, buf_)                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < PP_FPW; ++i_) PP_ISSUE_F1(stage_, buf_, i_)
 
     const int NCT = ((COMP & 4) ? 3 : ((COMP & 1) ? 2 : 1)) * NCH;   // chunks of the K loop: the hi plane's, then the corr plane's (X3: three passes)
     const int NST = NCT * 3;
@@ -281,6 +293,7 @@ void conv3x3_pp_kernel(const half_t *__restrict__ in, int H, int W, int Cin,
 #define PP_STAGE_WAIT(sg_, extra_)                                                                     \
     if (RING3 && more_x) {                                                                             \
         if ((sg_) == 0) asm volatile("s_waitcnt vmcnt(5) " extra_ ::: "memory");                       \
+        else if ((sg_) == 1 && SPREAD) asm volatile("s_waitcnt vmcnt(5) " extra_ ::: "memory");        \
         else if ((sg_) == 1) asm volatile("s_waitcnt vmcnt(6) " extra_ ::: "memory");                  \
         else asm volatile("s_waitcnt vmcnt(3) " extra_ ::: "memory");                                  \
     } else asm volatile("s_waitcnt vmcnt(0) " extra_ ::: "memory");
@@ -299,6 +312,7 @@ _Pragma("unroll") \
             const int st = c * 3 + sg; \
             const unsigned char *fs = Fs + (RING3 ? sg : (st & 1)) * PP_FBYTES + u3 * (PP_BN * 64); /* RING3: st % 3 = sg */ \
 /* ---------------- LOAD section */ \
+            PP_UCYC(0) \
             h8_t fa[2][2], fb[2][4]; \
             if (ABL & 2) { /* timing ablation: no fragment reads */ \
 _Pragma("unroll") \
@@ -360,12 +374,15 @@ _Pragma("unroll") \
             } \
             /* RING3: stage st + 2 into the buffer stage st - 1 has just left, BEHIND this unit's patch piece in the wave's queue (the counted \
                waits below rely on the order  X0 F F F X1 | X2 F F F X3 | X4 F F F  per chunk) */ \
-            if (RING3 && u3 == 0 && st + 2 < NST) { PP_ISSUE_F(st + 2, (sg + 2) % 3) } \
+            if (RING3 && !SPREAD && u3 == 0 && st + 2 < NST) { PP_ISSUE_F(st + 2, (sg + 2) % 3) } \
+            if (SPREAD && st + 2 < NST) { PP_ISSUE_F1(st + 2, (sg + 2) % 3, u3) }   /* queue per chunk: X0 F | X1 F | F || X2 F | X3 F | F || X4 F | F | F */ \
             if (u3 == 2) { PP_STAGE_WAIT(sg, "lgkmcnt(0)") } \
+            PP_UCYC(1) \
             __builtin_amdgcn_sched_barrier(0); \
             if (!(PP_ABL_BARRIER && f8 && u3 == 1)) asm volatile("s_barrier" ::: "memory"); /* PP_ABL_BARRIER: timing experiment, wrong results */ \
             __builtin_amdgcn_sched_barrier(0); \
 /* ---------------- MFMA section */ \
+            PP_UCYC(2) \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
             if (PRIO) __builtin_amdgcn_s_setprio(1); \
             if (f8) { \
@@ -396,13 +413,14 @@ _Pragma("unroll") \
             } \
             if (PRIO) __builtin_amdgcn_s_setprio(0); \
             __builtin_amdgcn_sched_barrier(0); \
+            PP_UCYC(3) \
             if (u3 == 2) { PP_STAGE_WAIT(sg, "") } \
 /* group 1's last MFMA section has nobody left to hand the pipe to */ \
             if (!(STAGGER && grp == 1 && t9 == 8 && c + 1 == NCT) && !(PP_ABL_BARRIER && f8 && u3 == 1)) asm volatile("s_barrier" ::: "memory"); \
             __builtin_amdgcn_sched_barrier(0); \
         } \
     /* end of PP_CHUNK_BODY */
-    if constexpr (RING3) {
+    if constexpr (ILV) {
         if (F6) {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) sa6v[ct] = __float_as_int(SS[2 * PP_BN + wch + ct * 32 + lrow]);
@@ -566,7 +584,7 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
                         int Ho, int Wo, const half_t *zero_page, const half_t *in_c = nullptr, half_t *out_c = nullptr, int sa = 0,
                         unsigned int *range = nullptr)
 {
-    constexpr bool ring3 = SFD2_PP_RING3 && (COMP & 1) && !(COMP & 4) && SFD2_PP_KXM && !ABL;
+    constexpr bool ring3 = (SFD2_PP_RING3 != 0) && (COMP & 1) && !(COMP & 4) && SFD2_PP_KXM && !ABL;
     constexpr size_t lds = (size_t)2 * PP_XBYTES + (size_t)(ring3 ? 3 : 2) * PP_FBYTES + ((COMP & 16) ? 6 : 4) * PP_BN * sizeof(float);
     static bool attr_done = false;
     auto kern = conv3x3_pp_kernel<STAGGER, PRIO, ABL, SFD2_PP_KXM, COMP>;
@@ -593,6 +611,16 @@ static void launch_pp_t(hipStream_t st, const half_t *in, int H, int W, int Cin,
             static unsigned long long hw[1024][2], hc[2][8][4];
             (void)hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_pp_wall), sizeof(hw));
             (void)hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_pp_cyc), sizeof(hc));
+            static unsigned long long hu[2][2][9][4];
+            (void)hipMemcpyFromSymbol(hu, HIP_SYMBOL(g_pp_unit), sizeof(hu));
+            for (int w = 0; w < 2; ++w)
+                for (int k = 0; k < 2; ++k) {
+                    fprintf(stderr, "  wave %d %s chunk, per unit [LOAD, barrier wait, MFMA section, to next LOAD]:", w * 4, k ? "corr" : "hi  ");
+                    for (int u = 0; u < 9; ++u)
+                        fprintf(stderr, " [%lld %lld %lld %lld]", (long long)(hu[w][k][u][1] - hu[w][k][u][0]), (long long)(hu[w][k][u][2] - hu[w][k][u][1]),
+                                (long long)(hu[w][k][u][3] - hu[w][k][u][2]), u < 8 ? (long long)(hu[w][k][u + 1][0] - hu[w][k][u][3]) : 0ll);
+                    fprintf(stderr, "\n");
+                }
             unsigned long long t0 = ~0ull, e0 = ~0ull, e1 = 0; double es = 0;
             for (int b = 0; b < grid; ++b) t0 = hw[b][0] < t0 ? hw[b][0] : t0;
             for (int b = 0; b < grid; ++b) { const unsigned long long e = hw[b][1] - t0; e0 = e < e0 ? e : e0; e1 = e > e1 ? e : e1; es += (double)e; }
