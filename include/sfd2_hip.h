@@ -75,7 +75,7 @@ typedef struct {
     int64_t n_candidates; /* N0 after NMS + threshold + border of the last extract          */
 } sfd2_timings;
 
-int sfd2_version(void);
+int sfd2_version(void);   /* 100 = rounds 1-4; 105 adds sfd2_extract_record_async, sfd2_desc_pack and host outputs with SFD2_FLAG_ASYNC */
 const char *sfd2_last_error(void);
 
 int sfd2_ctx_create(int device, sfd2_ctx **out);

@@ -158,6 +158,8 @@ def load():
     lib.sfd2_desc_pack.argtypes = [vp, ctypes.POINTER(DescSet), ci, vp, ci]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the .so lacks a declared symbol
+    if lib.sfd2_version() < 105:
+        raise RuntimeError(f"{LIB_PATH} is version {lib.sfd2_version()}, this binding needs >= 105 (rebuild: __graft_entry__.build())")
     _lib = lib
     return lib
 

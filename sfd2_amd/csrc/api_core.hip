@@ -13,7 +13,7 @@ std::atomic<unsigned long long> g_alloc_gen{0};
 thread_local int g_sfd2_cu_limit = 0;       // set per network pass from the context's option "cu_limit" (sfd2_internal.h)
 
 // ------------------------------------------------------------------------------------------ basics
-extern "C" int sfd2_version(void) { return 100; }
+extern "C" int sfd2_version(void) { return 105; }   // 105: + sfd2_extract_record_async, sfd2_desc_pack, SFD2_FLAG_ASYNC with host outputs (round 5)
 extern "C" const char *sfd2_last_error(void) { return g_err.c_str(); }
 
 extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
