@@ -222,6 +222,36 @@ void launch_conv1x1_c256(hipStream_t st, const half_t *in, int npix, const half_
 #define SFD2_C256_R1_STAGES 4
 #endif
 #define STAGE_R1 (GPXC * 512 + GPXC * 256)
+// Round 5, what holds ResBlock.conv1 (IN_C = 2) at 42 us = 3.7 TB/s.  Ablations (timing only): without the output stores 38 us, without the
+// staging copies 38 us -- neither side of the memory traffic.  A section trace (-DSFD2_C256_TRACE) puts a group at ~4 300 cycles: wait + barrier
+// 170-1 200, fragment reads + value-byte rebuild + 24 MFMAs 2 300-3 500 (two waves per SIMD: 2 080 of MFMA issue), epilogue 540-660.  Tried, each
+// bit-compatible and measured on one box against the shipped form:
+//   SFD2_C256_STAGGER = 1  the waves as two groups one barrier apart (section A = reads + MFMAs + copies, section B = epilogue; conv3x3_pp's
+//                          schedule): 46.9-48.9 us against 42.6-43.1 -- the second barrier costs more than the overlap returns
+//   SFD2_C256_SPLIT_ACC = 1 the scaled MFMAs in an accumulator chain of their own (two chains of one MFMA type per wave): 44.7 / 44.1 / 44.3 against
+//                          45.0 / 44.5 / 44.2
+//   SFD2_C256_R1_STAGES = 6, SFD2_C256_INTERLEAVE: see below.  All off.
+#ifndef SFD2_C256_STAGGER
+#define SFD2_C256_STAGGER 0
+#endif
+#ifndef SFD2_C256_SPLIT_ACC
+#define SFD2_C256_SPLIT_ACC 0
+#endif
+// -DSFD2_C256_TRACE: cycle stamps of block 3's waves 0 and 4 around the sections of groups 4 .. 9 (top of the iteration, behind the wait + barrier,
+// behind the fragment reads + MFMAs, behind the epilogue), printed by the launcher of the residual-byte form after 40 launches
+#ifdef SFD2_C256_TRACE
+#include <stdio.h>
+__device__ unsigned long long g_c256_cyc[2][6][4];
+#define C256_CYC(k_) if (blockIdx.x == 3 && (wave == 0 || wave == 4) && lane == 0 && g - g0 >= 4 && g - g0 < 10) g_c256_cyc[wave == 4][g - g0 - 4][k_] = __builtin_readcyclecounter();
+#else
+#define C256_CYC(k_)
+#endif
+// -DSFD2_C256_ABL (timing only, wrong results): bit 0 = no output stores, bit 1 = no staging copies inside the group loop
+#ifdef SFD2_C256_ABL
+#define C256_ABL SFD2_C256_ABL
+#else
+#define C256_ABL 0
+#endif
 template <bool HAS_RES, int IN_C, bool OUT_C>
 __global__ __launch_bounds__(NT1, 2)
 void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restrict__ in_c, int npix,
@@ -310,10 +340,15 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
     SFD2_BARRIER_DRAIN();
 
     float mx = 0.0f;     // range status: the largest output value in front of the saturation
+    constexpr bool STG = SFD2_C256_STAGGER != 0;
+    const int grp = wave >> 2;                              // waves w and w + 4 share a SIMD
+    if (STG && grp == 1) asm volatile("s_barrier" ::: "memory");
     for (int g = g0; g < g1; ++g) {
-        if (g != g0) {
+        C256_CYC(0)
+        if (!STG && g != g0) {
             if (g + AHEAD - 1 < g1) WAIT_GROUP_C(); else SFD2_BARRIER_DRAIN();
         }
+        C256_CYC(1)
         const unsigned char *st = Xs + (unsigned)(g - g0) % (unsigned)NSTC * STB;
         const int p = lrow;
         const long long gp = (long long)GRP(g) * GPXC + p;
@@ -333,7 +368,7 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
             }
             asm volatile("" ::: "memory");       // keep the residual loads ahead of the copies below in program order
         }
-        if (g + AHEAD < g1) { ISSUE_GC(g + AHEAD) }
+        if (!(C256_ABL & 2) && g + AHEAD < g1) { ISSUE_GC(g + AHEAD) }
 
         f32x16_t acc;
 #pragma unroll
@@ -346,6 +381,11 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
             for (int r = 0; r < 16; ++r) acl[r] = 0.0f;
         }
         if (IN_C == 2) {
+#if SFD2_C256_SPLIT_ACC
+            f32x16_t acs;       // the scaled MFMAs' own chain: a wave then runs two independent accumulator chains of one MFMA type each
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acs[r] = 0.0f;
+#endif
             const unsigned char *xr = st + GPXC * 512 + p * 256 + 8 * lhi;
             const int sr = p & 15;
 #pragma unroll
@@ -379,8 +419,17 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
                         bu[4 + 2 * h + q] = (int)vb;
                     }
                 }
+#if SFD2_C256_SPLIT_ACC
+                acs = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ac[c], bu, acs, 0, 0, 0, sa, 0, 0x7f7f7f7f);
+#else
                 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ac[c], bu, acc, 0, 0, 0, sa, 0, 0x7f7f7f7f);
+#endif
             }
+#if SFD2_C256_SPLIT_ACC
+            asm volatile("" : "+v"(acs));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += acs[r];
+#endif
             asm volatile("" : "+v"(acc));
         } else
 #pragma unroll
@@ -403,6 +452,18 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
             for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(acl[r], 1.0f / 2048.0f, acc[r]);
         }
 
+        asm volatile("" : "+v"(acc));
+        C256_CYC(2)
+        if (STG) {
+            // end of section A: this wave's copies of group g + 1 have landed (the AHEAD - 1 younger groups may stay in flight; near the
+            // tail nothing younger exists: full wait), its fragment reads are done; the barrier hands the matrix pipe to the other group
+            asm volatile("" : "+v"(acc));
+            if (g + AHEAD < g1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((AHEAD - 1) * CPG) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const int cl = wave * 32 + 4 * lhi;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -434,12 +495,18 @@ void conv1x1_c256_c_kernel(const half_t *__restrict__ in, const half_t *__restri
             }
             const auto t0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
             const auto t1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
-            if (inb) *reinterpret_cast<uint4 *>(out + obase + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+            if (inb && (!(C256_ABL & 1) || t0[0] == 0x12345678u)) *reinterpret_cast<uint4 *>(out + obase + 8 * (2 * m + lhi)) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
             if (OUT_C) {
                 const auto u0 = __builtin_amdgcn_permlane32_swap(ck[0].x, ck[1].x, false, false);
                 const auto u1 = __builtin_amdgcn_permlane32_swap(ck[0].y, ck[1].y, false, false);
                 if (inb) *reinterpret_cast<uint4 *>(out_c + obase + 8 * (2 * m + lhi)) = make_uint4(u0[0], u1[0], u0[1], u1[1]);
             }
+        }
+        C256_CYC(3)
+        if (STG && !(grp == 1 && g + 1 == g1)) {            // end of section B (group 1's last one has nobody left to hand over to)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     sfd2_range_commit(range, sfd2_wave_max_bits(mx));
@@ -678,7 +745,22 @@ void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c,
     const int grid = (ngroups + gpb - 1) / gpb;
     const int sa = (sbyte & 255) * 0x01010101;
 #define C256C_GO(R_, I_, O_) hipLaunchKernelGGL((conv1x1_c256_c_kernel<R_, I_, O_>), dim3(grid), dim3(NT1), lds, st, in, in_c, npix, w_frag, wc_frag, scale, shift, relu, res, res_c, out, out_c, gpb, zero_page, sa, range)
-    if (in_r1) { if (in_c && !out_c && !res) C256C_GO(false, 2, false); else abort(); }   // ResBlock.conv1 over a residual-only input
+    if (in_r1) { if (in_c && !out_c && !res) C256C_GO(false, 2, false); else abort(); }
+#ifdef SFD2_C256_TRACE
+    if (in_r1) {
+        static int dumps = 0;
+        if (npix > 100000 && ++dumps == 40) {
+            (void)hipStreamSynchronize(st);
+            static unsigned long long hc[2][6][4];
+            (void)hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_c256_cyc), sizeof(hc));
+            for (int w = 0; w < 2; ++w)
+                for (int t = 0; t < 6; ++t)
+                    fprintf(stderr, "c256 trace wave %d group %d: wait+barrier %lld  reads+MFMAs %lld  epilogue %lld  to next top %lld\n", w * 4, t + 4,
+                            (long long)(hc[w][t][1] - hc[w][t][0]), (long long)(hc[w][t][2] - hc[w][t][1]), (long long)(hc[w][t][3] - hc[w][t][2]),
+                            t < 5 ? (long long)(hc[w][t + 1][0] - hc[w][t][3]) : 0ll);
+        }
+    }
+#endif   // ResBlock.conv1 over a residual-only input
     else if (in_c && out_c) { if (res) C256C_GO(true, 1, true); else C256C_GO(false, 1, true); }
     else if (in_c && !res) C256C_GO(false, 1, false);           // ResBlock.conv1 writing a plain t1
     else if (!in_c && out_c && res) C256C_GO(true, 0, true);   // ResBlock.conv3 reading a plain t2
