@@ -92,11 +92,21 @@ def test_pipelined_extract_in_memory_items_and_float_images(tmp_path, synth_sd):
             items.append({"name": f"m/{i}.png", "image": f, "original_size": (128, 96)})
         else:
             items.append({"name": f"m/{i}.png", "image": (f.transpose(1, 2, 0) * 255).astype(np.uint8), "original_size": (256, 192)})
+    # a constant image: whatever the detector makes of it (possibly no key point at all), both loops must store the same group
+    items.append({"name": "m/flat.png", "image": np.full((96, 128, 3), 128, dtype=np.uint8), "original_size": (128, 96)})
     name, conf = next(iter(el.confs.items()))
     conf = {**conf, "model": {**conf["model"], "max_keypoints": 150}}
     a = el.main(conf, items, tmp_path / "s", model_and_extractor=(model, el.extract_resnet_return), num_workers=0)
     b = el.main(conf, items, tmp_path / "p", model_and_extractor=(model, el.extract_resnet_return), num_workers=2)
     assert _stores_equal(b, a) == sorted(it["name"] for it in items)
+    # no key point anywhere (threshold above every score): empty groups from both loops (the reference raises in np.vstack here)
+    conf0 = {**conf, "model": {**conf["model"], "conf_th": 10.0}}
+    a0 = el.main(conf0, items, tmp_path / "s0", model_and_extractor=(model, el.extract_resnet_return), num_workers=0)
+    b0 = el.main(conf0, items, tmp_path / "p0", model_and_extractor=(model, el.extract_resnet_return), num_workers=2)
+    _stores_equal(b0, a0)
+    from sfd2_amd.feature_io import open_store
+    g = open_store(b0, "r")["m/0.png"]
+    assert g["keypoints"].shape == (0, 2) and g["descriptors"].shape == (128, 0) and g["scores"].shape == (0,)
 
 
 def test_pipelined_extract_repeats_saturated_images_in_strict_mode(tmp_path):
