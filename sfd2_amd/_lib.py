@@ -232,8 +232,10 @@ class Context:
                 "ms_match": t.ms_match, "n_candidates": t.n_candidates}
 
     def set_precision(self, mode):
-        """'f16' (throughput mode, default) or 'f32' (strict parity mode)."""
-        check(self.lib.sfd2_set_precision(self.h, {'f16': 0, 'f32': 1, 'f16x3': 2, 'f16c': 3}[mode]))
+        """'f16', 'f32', 'f16x3', 'f16c' (include/sfd2_hip.h SFD2_PREC_*), or 'f16x3d' = SFD2_PREC_F16X3 with option "x3_desc16": that mode's
+        key points, the descriptor branch in plain fp16 (descriptors within 1e-3 instead of 2e-5)."""
+        check(self.lib.sfd2_set_precision(self.h, {'f16': 0, 'f32': 1, 'f16x3': 2, 'f16c': 3, 'f16x3d': 2}[mode]))
+        check(self.lib.sfd2_set_option(self.h, b"x3_desc16", 1 if mode == 'f16x3d' else 0))
 
     def set_option(self, key, value):
         """'fuse', 'fuse_det', 'alias', 'graphs', 'fuse_post', 'sparse_desc', 'branches' (include/sfd2_hip.h sfd2_set_option)."""

@@ -107,6 +107,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "auto_range") c->opt_auto_range = value ? 1 : 0;
     else if (k == "range_fallback") c->opt_range_fallback = value ? 1 : 0;
     else if (k == "x3_pp") c->opt_x3_pp = value ? 1 : 0;
+    else if (k == "x3_desc16") c->opt_x3_desc16 = value ? 1 : 0;
     else if (k == "fp6_filters") c->opt_fp6_filters = value ? 1 : 0;
     else if (k == "fp6_acts") c->opt_fp6_acts = value ? 1 : 0;
     else if (k == "s2d") c->opt_s2d = value ? 1 : 0;

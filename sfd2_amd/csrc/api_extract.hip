@@ -213,7 +213,7 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
             HIPCHECK(c->kdesc.ensure((size_t)sel_cap * 128 * sizeof(float)));
             desc_dst = c->kdesc.as<float>();
         }
-        if (sparse_x3) {
+        if (sparse_x3 && !c->x3_desc16_now) {
             const size_t nin = (size_t)c->H4 * c->W4 * 256;
             const int rows32 = (sel_cap * 4 + 31) / 32;           // the compact pixels as a [rows32][32] image for the generic 1x1 kernel
             HIPCHECK(c->da3_sparse.ensure((size_t)rows32 * 32 * 256 * sizeof(float)));
@@ -235,7 +235,7 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
             ProfScope ps(c, "sample_desc", "sample_desc_kernel", 0.0, (double)sel_cap * 128 * 4 * 5);
             launch_sample_desc(c->stream, c->db_sparse.as<float>(), c->H4, c->W4, H, W, c->kpts_cur, c->counters.as<unsigned int>() + 1,
                                sel_cap, desc_dst, 1);
-        } else if (sparse_da3) {
+        } else if (sparse_da3 || (sparse_x3 && c->x3_desc16_now)) {      // (option "x3_desc16": f16x3's key points, the fp16 sparse head on convDa.0's fp16 output)
             HIPCHECK(c->da3_sparse.ensure((size_t)sel_cap * 4 * 256 * sizeof(half_t)));
             {
                 ProfScope ps(c, "convDa.3", "sparse_da3_kernel", 2.0 * 4 * sel_cap * 256.0 * 256.0 * 9, (double)sel_cap * (16 * 512 + 4 * 512) + 2.0 * 256 * 256 * 9);

@@ -148,9 +148,10 @@ int ensure_workspace(sfd2_ctx *c, int H, int W)
 }
 
 static void conv(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &in, int H, int W, const DevPtr &out,
-                 int Ho, int Wo, int relu, const half_t *res = nullptr, int out_f32 = 0)
+                 int Ho, int Wo, int relu, const half_t *res = nullptr, int out_f32 = 0, const float *scale_override = nullptr)
 {
     char kn[48];
+    const float *scale = scale_override ? scale_override : L.scale.as<float>();
     const int bn = (L.cout_pad % 256 == 0) ? 256 : (L.cout_pad % 128 == 0 ? 128 : 64);
     snprintf(kn, sizeof(kn), "conv_igemm<%d,%d,%d%s>", L.ks, L.stride, bn, out_f32 ? ",f32" : "");
     if (!res && !out_f32 && conv3x3_pp_serves(L.ks, L.stride, L.cout_pad, L.cin)) snprintf(kn, sizeof(kn), "conv3x3_pp");
@@ -163,12 +164,12 @@ static void conv(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &in
     if (L.wrm.p && !out_f32 && !no_c1) {
         snprintf(kn, sizeof(kn), "conv1x1_c256%s", res ? "+res" : "");
         ProfScope ps(c, name, kn, flops, bytes);
-        launch_conv1x1_c256(c->cur_stream, in.as<half_t>(), Ho * Wo, L.wrm.as<half_t>(), L.scale.as<float>(), L.shift.as<float>(),
+        launch_conv1x1_c256(c->cur_stream, in.as<half_t>(), Ho * Wo, L.wrm.as<half_t>(), scale, L.shift.as<float>(),
                             relu, res, reinterpret_cast<half_t *>(out.p), c->zero_page.as<half_t>());
         return;
     }
     ProfScope ps(c, name, kn, flops, bytes);
-    launch_conv_igemm(c->cur_stream, in.as<half_t>(), H, W, L.cin, L.w.as<half_t>(), L.scale.as<float>(),
+    launch_conv_igemm(c->cur_stream, in.as<half_t>(), H, W, L.cin, L.w.as<half_t>(), scale,
                       L.shift.as<float>(), L.cout_pad, L.ks, L.stride, relu, res, out.p, out_f32, Ho, Wo,
                       c->zero_page.as<half_t>());
 }
@@ -456,11 +457,28 @@ static int run_network_f32(sfd2_ctx *c, const float *img_dev, int normalise)
     if (convf(c, "convPb", c->fpb, c->gpa_o, H8, W8, c->logits, H8, W8, 0)) return -1;
     c->x3_pre_src = bb_src; c->x3_pre_hi = bb_hi; c->x3_pre_lo = bb_lo;      // convDa.0 takes the same planes
     const bool da0_planes = c->skip_da3_now && c->x3_fast_rb_now;
+    // Option "x3_desc16": the descriptor branch leaves this mode's arithmetic here -- convDa.0 as ONE fp16 pass (conv3x3_pp) over the backbone output's hi
+    // plane, at the network's own scale (scale_rawin), its output (times 2^act_exp[AE_DA0], what convDa.3's folded constants expect) in the buffer
+    // the planes would have taken; sfd2_extract then runs the fp16 sparse head on it.  The detector branch above is untouched.
+    c->x3_desc16_now = 0;
+    if (da0_planes && c->opt_x3_desc16 && bb_src == x->p && bb_hi && c->da0.w.p && c->da0.scale_rawin.p && c->da3.w.p && c->db.w.p) {
+        const size_t nin = (size_t)H4 * W4 * 256;
+        HIPCHECK(c->x3_da0_planes.ensure(nin * 2 * sizeof(half_t)));
+        DevPtr in, out;
+        in.p = const_cast<half_t *>(bb_hi);
+        out.p = c->x3_da0_planes.p;
+        conv(c, "convDa.0", c->da0, in, H4, W4, out, H4, W4, 1, nullptr, 0, c->da0.scale_rawin.as<float>());
+        c->da0_cur = c->x3_da0_planes.as<half_t>();
+        c->x3_desc16_now = 1;
+    } else {
     c->x3_planes_out_now = da0_planes ? 2 : 0;
     if (convf(c, "convDa.0", c->fda0, *x, H4, W4, c->gda0_o, H4, W4, 1)) return -1;
+    }
     c->x3_planes_out_now = 0;
     c->x3_pre_src = nullptr;
-    if (c->skip_da3_now) {      // sparse descriptor head of SFD2_PREC_F16X3 (sfd2_extract): convDa.3 and convDb run on the sampled corners only
+    if (c->x3_desc16_now) {
+        // (nothing: convDa.3 and convDb run on the sampled corners, in fp16)
+    } else if (c->skip_da3_now) {      // sparse descriptor head of SFD2_PREC_F16X3 (sfd2_extract): convDa.3 and convDb run on the sampled corners only
         const size_t nin = (size_t)H4 * W4 * 256;
         if (!da0_planes) {
             HIPCHECK(c->x3_da0_planes.ensure(nin * 2 * sizeof(half_t)));

@@ -627,6 +627,11 @@ int apply_act_exponents(sfd2_ctx *c)
             if (upload(L.sa66, sa.data(), sa.size() * sizeof(int), c->stream)) return -1;
         }
     }
+    if (!c->da0.h_scale.empty()) {                  // option "x3_desc16": convDa.0 in fp16 over an input that is NOT scaled by 2^e[AE_TRUNK]
+        sc = c->da0.h_scale;
+        for (float &v : sc) v = std::ldexp(v, e[AE_DA0]);
+        if (upload(c->da0.scale_rawin, sc.data(), sc.size() * sizeof(float), c->stream)) return -1;
+    }
     if (c->has_sta && !c->h_sta_w.empty()) {        // ConvSta reads the backbone output with fp32 filters of its own
         std::vector<float> w = c->h_sta_w;
         for (float &v : w) v = std::ldexp(v, -e[AE_TRUNK]);

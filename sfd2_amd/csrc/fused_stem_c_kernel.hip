@@ -34,6 +34,9 @@
 #define SC_IM (SC_IH * SC_IW * 8)      // bytes of one image plane ([px][4] fp16)
 #define SC_LDS (2 * SC_X1 + 2 * SC_IM + 1024)
 #define SC_NU 5                        // units per wave (the last two wave groups run four)
+#ifndef SFD2_STEMC_P1MODE
+#define SFD2_STEMC_P1MODE 0
+#endif
 
 __device__ __forceinline__ float sc_div_const(float a, float d, float r)   // see fused_stem_kernel.hip (exact for these constants)
 {
@@ -48,14 +51,14 @@ __device__ __forceinline__ float sc_div_const(float a, float d, float r)   // se
 
 #define SC_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-// -DSFD2_STEMC_TRACE: cycle stamps of one block's waves 0 and 7 at the section boundaries of its first tiles, printed by the
+// -DSFD2_STEMC_TRACE: cycle stamps of all eight waves of one block at the section boundaries of its first tiles, printed by the
 // launcher after a few launches
 #ifdef SFD2_STEMC_TRACE
 #include <stdio.h>
-__device__ unsigned long long g_stemc_trace[2][16][12];
+__device__ unsigned long long g_stemc_trace[8][16][12];
 #define SC_STAMP(k_)                                                                          \
-    if (blockIdx.x == 3 && (wave == 0 || wave == 7) && lane == 0 && tcount < 16)              \
-        g_stemc_trace[wave == 7][tcount][k_] = __builtin_readcyclecounter();
+    if (blockIdx.x == 3 && lane == 0 && tcount < 16)                                          \
+        g_stemc_trace[wave][tcount][k_] = __builtin_readcyclecounter();
 #else
 #define SC_STAMP(k_)
 #endif
@@ -71,6 +74,57 @@ __device__ __forceinline__ void sc_x3_epi4(float a0, float a1, float a2, float a
                     (half_t)((v2 - (float)h[2]) * 2048.0f), (half_t)((v3 - (float)h[3]) * 2048.0f)};
     __builtin_memcpy(&hv, &h, 8);
     __builtin_memcpy(&lv, &l, 8);
+}
+
+// sfd2_epi16_fp6's arithmetic (same operations in the same order: identical bits) cut into eight pieces of ~10 vector instructions with a slot
+// between them: the caller's slot(k), k = 0..8, issues one MFMA of the NEXT unit's chain; sched_barrier(0) pins the interleave (hipcc otherwise
+// keeps the chain in one run, and a wave stalls at its second MFMA until the pipe is free: the chain's 288 cycles are then exposed)
+template <class SLOT>
+__device__ __forceinline__ void sc_epi16_fp6_piped(const f32x16_t &acc, const float4 (&sc)[4], const float4 (&sh)[4], uint2 (&hv)[4], uint4 &rec0, uint4 &rec1,
+                                                   float &mx, bool counted, SLOT slot)
+{
+    f32x16v_t v, l;
+    float m = 0.0f;
+    slot(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x2_t v01 = f32x2_t{acc[4 * q], acc[4 * q + 1]} * f32x2_t{sc[q].x, sc[q].y} + f32x2_t{sh[q].x, sh[q].y};
+        f32x2_t v23 = f32x2_t{acc[4 * q + 2], acc[4 * q + 3]} * f32x2_t{sc[q].z, sc[q].w} + f32x2_t{sh[q].z, sh[q].w};
+        m = sfd2_max3(sfd2_max3(m, v01[0], v01[1]), v23[0], v23[1]);
+        v01[0] = __builtin_amdgcn_fmed3f(v01[0], 0.0f, SFD2_C_SAT); v01[1] = __builtin_amdgcn_fmed3f(v01[1], 0.0f, SFD2_C_SAT);
+        v23[0] = __builtin_amdgcn_fmed3f(v23[0], 0.0f, SFD2_C_SAT); v23[1] = __builtin_amdgcn_fmed3f(v23[1], 0.0f, SFD2_C_SAT);
+        __builtin_amdgcn_sched_barrier(0);
+        slot(2 * q + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const h2_t h01 = __builtin_convertvector(v01, h2_t), h23 = __builtin_convertvector(v23, h2_t);
+        __builtin_memcpy(&hv[q].x, &h01, 4);
+        __builtin_memcpy(&hv[q].y, &h23, 4);
+        const f32x2_t l01 = (v01 - f32x2_t{(float)h01[0], (float)h01[1]}) * 2048.0f, l23 = (v23 - f32x2_t{(float)h23[0], (float)h23[1]}) * 2048.0f;
+        v[4 * q] = v01[0]; v[4 * q + 1] = v01[1]; v[4 * q + 2] = v23[0]; v[4 * q + 3] = v23[1];
+        l[4 * q] = l01[0]; l[4 * q + 1] = l01[1]; l[4 * q + 2] = l23[0]; l[4 * q + 3] = l23[1];
+        __builtin_amdgcn_sched_barrier(0);
+        slot(2 * q + 2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#ifndef SFD2_NO_RANGE
+    mx = counted ? __builtin_fmaxf(mx, m) : mx;
+#endif
+    const unsigned int mb = __float_as_uint(__builtin_fminf(__builtin_fmaxf(m, 0.0f), SFD2_C_SAT));
+    v6i_t d;
+#if SFD2_PIX6_BF6
+    int e8 = (int)(mb >> 23) - 4 + ((mb & 0x7fffffu) > 0x600000u ? 1 : 0);
+    e8 = e8 < 1 ? 1 : e8;
+    const float scale = __uint_as_float((unsigned int)e8 << 23);
+    asm volatile("v_cvt_scalef32_2xpk16_bf6_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(l), "v"(v), "v"(scale));
+#else
+    int e8 = (int)(mb >> 23) - 2 + ((mb & 0x7fffffu) > 0x700000u ? 1 : 0);
+    e8 = e8 < 1 ? 1 : e8;
+    const float scale = __uint_as_float((unsigned int)e8 << 23);
+    asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(l), "v"(v), "v"(scale));
+#endif
+    rec0 = make_uint4((unsigned)d[0], (unsigned)d[1], (unsigned)d[2], (unsigned)d[3]);
+    rec1 = make_uint4((unsigned)d[4], (unsigned)d[5], (unsigned)e8 * 0x01010101u, 0u);
 }
 
 // X3 (SFD2_PREC_F16X3): the same kernel with conv1a's output and conv1b's filters / output as hi / lo' fp16 pairs instead of hi / corr
@@ -234,60 +288,85 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
 
         float mx1 = 0.0f, mx2 = 0.0f;
         // ---- phase 1: conv1a -> X1h / X1c
-        // conv1a's scale / shift of this wave's channels: read once per tile (they must not be live across phase 2)
-        float4 s1[4], h1[4];
-        {
-            int sso = cth * 32 + 4 * lhi;
-            asm volatile("" : "+v"(sso));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                s1[q] = sfd2_lds_f4(SS + sso + 8 * q);
-                h1[q] = sfd2_lds_f4(SS + 64 + sso + 8 * q);
-            }
+        // -DSFD2_STEMC_P1MODE (round 5 experiment): the two waves of a SIMD (w and w + 4) run phase 1's units in lockstep -- both in their MFMA chain, then both
+        // in their epilogue -- so a SIMD's time is MFMA time + VALU time.  1: priority 1 for a unit's MFMA chain; 2: waves 0..3 at priority 2 for the whole
+        // phase; 3: waves 4..7 start the phase ~320 cycles late
+#if SFD2_STEMC_P1MODE == 2
+        if (wave < 4) __builtin_amdgcn_s_setprio(2);
+#elif SFD2_STEMC_P1MODE == 3
+        if (wave >= 4) __builtin_amdgcn_s_sleep(5);
+#endif
+        // conv1a's scale / shift of this wave's channels: read once per tile (they must not be live across phase 2); PIPE: once per unit -- the
+        // second accumulator and the next unit's fragments need the 32 registers
+#define SC_LOAD_S1()                                                                                       \
+        {                                                                                                  \
+            int sso = cth * 32 + 4 * lhi;                                                                  \
+            asm volatile("" : "+v"(sso));                                                                  \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                \
+                s1[q] = sfd2_lds_f4(SS + sso + 8 * q);                                                     \
+                h1[q] = sfd2_lds_f4(SS + 64 + sso + 8 * q);                                                \
+            }                                                                                              \
         }
+        // -DSFD2_STEMC_P1PIPE (round 5, the fp6 instantiation): the MFMA chain of unit i + 1 is issued BETWEEN the pieces of unit i's epilogue (a second
+        // accumulator), so that a wave's own MFMAs run under its own ~115 epilogue instructions -- with two waves per SIMD a wave issues one vector
+        // instruction per ~7.5 cycles, a lone wave cannot fill the SIMD while its partner sits in an MFMA chain, and in practice both sit in their chains
+        // and then in their epilogues together (tools/probe/valu_cost.hip, profiles/r05j_*).  The last unit's chain is issued by every wave (the four-unit
+        // waves compute the region's last pixel block again and drop it).
+#ifdef SFD2_STEMC_P1PIPE
+        constexpr bool PIPE = O6 && !X3;
+#else
+        constexpr bool PIPE = false;
+#endif
+        float4 s1[4], h1[4];
+        if constexpr (!PIPE) SC_LOAD_S1()
+        // the image fragments of one kernel row of a unit (imo_: the unit's opaque offset register)
+#define SC_P1_FRAG(imo_, ky_, bh_, bl_)                                                                    \
+        {                                                                                                  \
+            const int o = (imo_) + (ky_) * (SC_IW * 4);                                                    \
+            {                                                                                              \
+                const h4_t lo = *reinterpret_cast<const h4_t *>(IMh + o);                                  \
+                const h4_t hi = *reinterpret_cast<const h4_t *>(IMh + o + 4);                              \
+                bh_[0] = lo[0]; bh_[1] = lo[1]; bh_[2] = lo[2]; bh_[3] = lo[3];                            \
+                bh_[4] = hi[0]; bh_[5] = hi[1]; bh_[6] = hi[2]; bh_[7] = hi[3];                            \
+            }                                                                                              \
+            {                                                                                              \
+                const h4_t lo = *reinterpret_cast<const h4_t *>(IMl + o);                                  \
+                const h4_t hi = *reinterpret_cast<const h4_t *>(IMl + o + 4);                              \
+                bl_[0] = lo[0]; bl_[1] = lo[1]; bl_[2] = lo[2]; bl_[3] = lo[3];                            \
+                bl_[4] = hi[0]; bl_[5] = hi[1]; bl_[6] = hi[2]; bl_[7] = hi[3];                            \
+            }                                                                                              \
+        }
+        // one unit's MFMA chain in one run
+#define SC_P1_CHAIN(i_, acc_)                                                                              \
+        {                                                                                                  \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc_[r] = 0.0f;                                 \
+            /* per-lane offsets are recomputed from one opaque register per unit: hoisted out of the tile loop (they are all */ \
+            /* tile-invariant) they are ~100 registers, spilled and reloaded behind s_waitcnt vmcnt(0) */  \
+            int imo = p1_im[i_];                                                                           \
+            asm volatile("" : "+v"(imo));                                                                  \
+            SC_P1_PRIO(1)                                                                                  \
+            _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                             \
+                h8_t bh, bl;                                                                               \
+                SC_P1_FRAG(imo, ky, bh, bl)                                                                \
+                acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l[ky], bh, acc_, 0, 0, 0);                 \
+                acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[ky], bl, acc_, 0, 0, 0);                 \
+                acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[ky], bh, acc_, 0, 0, 0);                 \
+            }                                                                                              \
+            SC_P1_PRIO(0)                                                                                  \
+        }
+#if SFD2_STEMC_P1MODE == 1
+#define SC_P1_PRIO(p_) __builtin_amdgcn_s_setprio(p_);
+#else
+#define SC_P1_PRIO(p_)
+#endif
+        f32x16_t accs[2];
+        h8_t fbh[2], fbl[2];                      // PIPE: the next unit's fragments, two kernel rows in flight
+        if constexpr (PIPE) SC_P1_CHAIN(0, accs[0])
 #pragma unroll
         for (int i = 0; i < P1_UNITS; ++i) {
-            if (i < p1_n) {
-                f32x16_t acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#ifdef SFD2_STEMC_ACC3
-                f32x16_t accb = acc, accc = acc;   // (experiment: one accumulator chain per pass)
-#endif
-                // per-lane offsets are recomputed from one opaque register per unit: hoisted out of the tile loop (they are all
-                // tile-invariant) they are ~100 registers, spilled and reloaded behind s_waitcnt vmcnt(0)
-                int imo = p1_im[i];
-                asm volatile("" : "+v"(imo));
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int o = imo + ky * (SC_IW * 4);
-                    h8_t bh, bl;
-                    {
-                        const h4_t lo = *reinterpret_cast<const h4_t *>(IMh + o);
-                        const h4_t hi = *reinterpret_cast<const h4_t *>(IMh + o + 4);
-                        bh[0] = lo[0]; bh[1] = lo[1]; bh[2] = lo[2]; bh[3] = lo[3];
-                        bh[4] = hi[0]; bh[5] = hi[1]; bh[6] = hi[2]; bh[7] = hi[3];
-                    }
-                    {
-                        const h4_t lo = *reinterpret_cast<const h4_t *>(IMl + o);
-                        const h4_t hi = *reinterpret_cast<const h4_t *>(IMl + o + 4);
-                        bl[0] = lo[0]; bl[1] = lo[1]; bl[2] = lo[2]; bl[3] = lo[3];
-                        bl[4] = hi[0]; bl[5] = hi[1]; bl[6] = hi[2]; bl[7] = hi[3];
-                    }
-#ifdef SFD2_STEMC_ACC3
-                    accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l[ky], bh, accb, 0, 0, 0);
-                    accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[ky], bl, accc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[ky], bh, acc, 0, 0, 0);
-#else
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l[ky], bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[ky], bl, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[ky], bh, acc, 0, 0, 0);
-#endif
-                }
-#ifdef SFD2_STEMC_ACC3
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] += accb[r] + accc[r];
-#endif
+            if (i + 1 < P1_UNITS || i < p1_n) {      // (every wave has P1_UNITS - 1 or P1_UNITS units: only the last one is behind a branch)
+                f32x16_t &acc = accs[PIPE ? (i & 1) : 0];
+                if constexpr (!PIPE) SC_P1_CHAIN(i, acc)
                 // conv1b zero-pads conv1a's OUTPUT: region pixels outside the image are zeros, not conv1a(0)
                 const int gy = ry0 + (p1_yx[i] >> 8), gx = rx0 + (p1_yx[i] & 255);
                 const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -298,7 +377,27 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                 if constexpr (O6 && !X3) {
                     uint2 hv4[4];
                     uint4 r0, r1;
-                    sfd2_epi16_fp6(acc, s1, h1, 0.0f, hv4, r0, r1, mx1, all_inside || inside);
+                    if constexpr (PIPE) {
+                        const bool more = i + 1 < P1_UNITS;       // (a constant once the unit loop is unrolled)
+                        f32x16_t &nacc = accs[(i + 1) & 1];
+                        int imo = p1_im[more ? i + 1 : i];
+                        asm volatile("" : "+v"(imo));
+                        if (more) SC_P1_FRAG(imo, 0, fbh[0], fbl[0])
+                        SC_LOAD_S1()
+                        sc_epi16_fp6_piped(acc, s1, h1, hv4, r0, r1, mx1, all_inside || inside, [&](const int k) {
+                            if (more) {
+                                const int ky = k / 3, j = k - 3 * ky;
+                                if (j == 0 && ky < 2) SC_P1_FRAG(imo, ky + 1, fbh[(ky + 1) & 1], fbl[(ky + 1) & 1])
+                                f32x16_t c = nacc;
+                                if (k == 0) {
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+                                }
+                                nacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(j == 0 ? a1l[ky] : a1h[ky], j == 1 ? fbl[ky & 1] : fbh[ky & 1], c, 0, 0, 0);
+                            }
+                        });
+                    } else
+                        sfd2_epi16_fp6(acc, s1, h1, 0.0f, hv4, r0, r1, mx1, all_inside || inside);
                     if (!all_inside && !inside) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) hv4[q] = make_uint2(0u, 0u);
@@ -327,6 +426,9 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
             __builtin_amdgcn_sched_barrier(0);   // (experiment: units not interleaved)
 #endif
         }
+#if SFD2_STEMC_P1MODE == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (!X3) { const unsigned int wb = sfd2_wave_max_bits(mx1); smax1 = wb > smax1 ? wb : smax1; }
         const int next = tile + (int)gridDim.x, next2 = next + (int)gridDim.x;
         const bool has_next = next < n_tiles;
@@ -510,6 +612,10 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
         sfd2_range_commit(range + SFD2_RS_CONV1B * SFD2_RANGE_SUB, smax2);
     }
 #undef SC_LOAD_A1
+#undef SC_P1_CHAIN
+#undef SC_P1_FRAG
+#undef SC_LOAD_S1
+#undef SC_P1_PRIO
 #undef SC_FETCH_IMG
 #undef SC_STORE_IMG
 }
@@ -550,12 +656,12 @@ void launch_fused_stem_c(hipStream_t st, const float *img, int H, int W, int nor
         static int dumps = 0;
         if (H >= 1000 && ++dumps == 40) {
             (void)hipStreamSynchronize(st);
-            static unsigned long long h[2][16][12];
+            static unsigned long long h[8][16][12];
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stemc_trace), sizeof(h));
             fprintf(stderr, "stemc columns: phase 1 | B1 wait | phase 2 (+A1 reload issue) | B2 wait | phase 3 partial writes | B3 wait | phase 4 sum | image -> LDS | epilogue + stores | fetch issue | B4 wait\n");
-            for (int w = 0; w < 2; ++w)
-                for (int t = 2; t < 10; ++t) {
-                    fprintf(stderr, "stemc wave %d tile %2d:", w * 7, t);
+            for (int w = 0; w < 8; ++w)
+                for (int t = 4; t < 8; ++t) {
+                    fprintf(stderr, "stemc wave %d tile %2d (phase 1 starts %5lld after wave 0's):", w, t, (long long)(h[w][t][0] - h[0][t][0]));
                     for (int k = 1; k < 12; ++k) fprintf(stderr, " %6lld", (long long)(h[w][t][k] - h[w][t][k - 1]));
                     fprintf(stderr, "  (tile %lld)\n", (long long)(h[w][t + 1][0] - h[w][t][0]));
                 }

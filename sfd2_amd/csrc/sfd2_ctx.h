@@ -71,6 +71,7 @@ struct DevBuf : DevPtr {
 struct ConvW {                 // one folded + packed layer
     int cin = 0, cout = 0, cout_pad = 0, ks = 0, stride = 1;
     DevBuf w, scale, shift;    // fp16 packed filters, fp32 [cout_pad]
+    DevBuf scale_rawin;        // convDa.0: scale for an input at the network's own scale (2^e_out only; option "x3_desc16" feeds it f16x3's hi plane)
     DevBuf wrm;                // 1x1 256 -> 256 layers: the same filters as plain [cout][cin] fp16 (conv1x1_c256_kernel)
     DevBuf wfh, wfc, wfl;      // conv1x1_c256_c_kernel: the same filters, their corr units and fp16 of (w - fp16(w)) * 2^11 (the second
                                // fp16 pass over a PLAIN input, option "rb_inner") in the kernel's fragment order [8 waves][8][64 lanes][16]
@@ -160,6 +161,10 @@ struct sfd2_ctx {
                                        // mixed-format MFMA's shorter issue time in the probe does not show in the layer; off by default, kept as the
                                        // packing / layout groundwork for fp6 on both sides
     int opt_x3_pp = 1;                 // sfd2_set_option "x3_pp": SFD2_PREC_F16X3 runs its 3x3 stride-1 layers on conv3x3_pp (pre-split planes, three passes)
+    int opt_x3_desc16 = 0;             // sfd2_set_option "x3_desc16": SFD2_PREC_F16X3 on sfd2_extract with the DESCRIPTOR branch (convDa.0, convDa.3 at the sampled corners,
+                                       // convDb) in plain fp16 on the backbone output's hi plane: the key points are this mode's own, the descriptors carry the
+                                       // fp16 head's error only (<= 1e-3: north_star's tolerance, not this mode's 2e-5)
+    int x3_desc16_now = 0;             // set per call by run_network: convDa.0's output is the fp16 tensor in x3_da0_planes (da0_cur)
     DevBuf x3_planes;                  // the input of such a layer as hi / lo' planes
     DevBuf x3_da0_planes;              // convDa.0's output as planes (sparse descriptor head of f16x3)
     DevBuf db_sparse;                  // [sel_cap][4][128] fp32: convDb on the sampled corners (f16x3)
