@@ -137,6 +137,11 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *   "x3_pp"     1 (default) / 0: SFD2_PREC_F16X3 on its throughput kernels -- 3x3 stride-1 layers on conv3x3_pp over pre-split hi / lo'
  *               planes, and on sfd2_extract (not sfd2_det) the fused three-pass stem, the streaming three-pass 1x1 kernel in the
  *               ResBlocks and the sparse descriptor head; 0 = the generic three-pass kernel everywhere (same tolerances, 1.6x slower).
+ *   "x3_desc16" 0 (default) / 1: SFD2_PREC_F16X3 on sfd2_extract with the DESCRIPTOR branch in plain fp16 -- convDa.0 as one fp16 pass over the
+ *               backbone output's hi plane, convDa.3 / convDb on the sampled corners on the fp16 kernels (wherever the sparse descriptor head
+ *               runs: 16 x top_k <= the 1/4-resolution map; elsewhere the option does nothing).  Key points and scores are this mode's own, bit for
+ *               bit; descriptors within 1e-3 of the reference (measured <= 2.9e-4) instead of 2e-5; 2.46 -> 2.18 ms per 1600x1200 extract.  This
+ *               is north_star's contract as written (key-point list equal up to near-ties, descriptors within 1e-3).  Python: precision "f16x3d".
  *   "fp6_filters" 0 (default) / 1: SFD2_PREC_F16C, conv2a / conv3a / conv3b: the correction filters as e2m3 (fp6) with one power-of-two
  *               scale per output channel instead of e4m3 (fp8 x fp6 scaled MFMA).  Same tolerance (descriptors <= 5.2e-4 measured),
  *               no measurable speed difference on MI355X: an experiment switch.

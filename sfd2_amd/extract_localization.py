@@ -34,7 +34,9 @@ def get_model(model_name, weight_path=None, use_stability=False, state_dict=None
     """extract_localization.py:208-218.  state_dict may be given directly (numpy / torch dict)
     when the checkpoint is not a file; otherwise weight_path is read with torch.load (the reference's
     {'model': state_dict, ...} checkpoint layout, :213-215).  precision: see ResSegNetV2 -- the drop-in default
-    is 'f16x3' (the strict mode's tolerances on the fp16 matrix path), 'f16c' the tolerance-conformant throughput mode, 'f16' an approximation."""
+    is 'f16x3' (the strict mode's tolerances on the fp16 matrix path: descriptors 2e-5); 'f16x3d' is north_star's contract as written (the
+    strict mode's key points -- 'f16x3''s, bit for bit -- and descriptors within 1e-3; 1.12x the speed of 'f16x3'), 'f16c' the
+    tolerance-conformant throughput mode (descriptors 1e-3, key-point SET IoU >= 0.985), 'f16' an approximation."""
     if model_name != 'ressegnetv2':
         raise NotImplementedError("only 'ressegnetv2' is on the hot path (SURVEY.md section 2 #1)")
     model = ResSegNetV2(outdim=128, require_stability=use_stability, precision=precision).eval()

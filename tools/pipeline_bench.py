@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """files -> feature store -> match store on one MI355X: the rate a user of the reference's two pipeline scripts sees.
 
-    python tools/pipeline_bench.py [--queries 256 --db 128 --k 50 --workers 16 --size 1600x1200 --precision f16c,f16x3]
+    python tools/pipeline_bench.py [--queries 256 --db 128 --k 50 --workers 16 --size 1600x1200 --precision f16c,f16x3d,f16x3]
 
 What it does (everything under a scratch directory, removed afterwards unless --keep):
   1. writes synthetic JPEGs (PIL encodes, quality 90, ~0.75 MB each -- the size of a real 1600x1200 photograph):
@@ -119,7 +119,7 @@ def parse_args(argv=None):
     ap.add_argument("--lanes", type=int, default=1, help="contexts (HIP streams) the pipelined extract loop alternates over")
     ap.add_argument("--size", default="1600x1200")
     ap.add_argument("--topk", type=int, default=4096)
-    ap.add_argument("--precision", default="f16c,f16x3")
+    ap.add_argument("--precision", default="f16c,f16x3d,f16x3")
     ap.add_argument("--serial-images", type=int, default=32)
     ap.add_argument("--serial-pairs", type=int, default=200)
     ap.add_argument("--scratch", default=None)
