@@ -577,6 +577,7 @@ def main():
                        {"mode": "f16 throughput (OUTSIDE north_star's 1e-3)", "descriptors_max_abs": "<= 3e-3 (measured 1.8e-3)", "keypoint_set_iou": ">= 0.93",
                         "selection_given_heat_map": "bit-exact", "asserted_in": "tests/test_gpu_parity.py"}),
             "single_stream": single, "sustained": sustained, "configs": configs_obj, "range_status": range_seen,
+            "margin_selfcheck": (lanes[0].ctx.margin_status() if args.precision == "f16c" else None),
             "strict_f32": strict, "strict_f16x3": strict_x3, "strict_kp_f16x3d": strict_kp,
             ("approx_f16" if args.precision == "f16c" else "f16c"): approx,
         }

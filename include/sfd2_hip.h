@@ -75,7 +75,7 @@ typedef struct {
     int64_t n_candidates; /* N0 after NMS + threshold + border of the last extract          */
 } sfd2_timings;
 
-int sfd2_version(void);   /* 100 = rounds 1-4; 105 adds sfd2_extract_record_async, sfd2_desc_pack and host outputs with SFD2_FLAG_ASYNC */
+int sfd2_version(void);   /* 100 = rounds 1-4; 105 adds sfd2_extract_record_async, sfd2_desc_pack and host outputs with SFD2_FLAG_ASYNC; 106 adds sfd2_get_margin_status */
 const char *sfd2_last_error(void);
 
 int sfd2_ctx_create(int device, sfd2_ctx **out);
@@ -137,6 +137,7 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *   "x3_pp"     1 (default) / 0: SFD2_PREC_F16X3 on its throughput kernels -- 3x3 stride-1 layers on conv3x3_pp over pre-split hi / lo'
  *               planes, and on sfd2_extract (not sfd2_det) the fused three-pass stem, the streaming three-pass 1x1 kernel in the
  *               ResBlocks and the sparse descriptor head; 0 = the generic three-pass kernel everywhere (same tolerances, 1.6x slower).
+ *   "auto_margin" 1 (default) / 0: the load-time self-check of SFD2_PREC_F16C (sfd2_get_margin_status below); set it BEFORE sfd2_load_weights.
  *   "x3_desc16" 0 (default) / 1: SFD2_PREC_F16X3 on sfd2_extract with the DESCRIPTOR branch in plain fp16 -- convDa.0 as one fp16 pass over the
  *               backbone output's hi plane, convDa.3 / convDb on the sampled corners on the fp16 kernels (wherever the sparse descriptor head
  *               runs: 16 x top_k <= the 1/4-resolution map; elsewhere the option does nothing).  Key points and scores are this mode's own, bit for
@@ -394,6 +395,13 @@ int sfd2_calibrate_range(sfd2_ctx *ctx, const float *img, int img_on_device, int
  * skip path), t1 of block 0..2, t2 of block 0..2, convPa.0, convDa.0.  maxima = what the last calibration measured. */
 int sfd2_get_act_exponents(sfd2_ctx *ctx, int32_t *exps, float *maxima, int cap, int *n);
 int sfd2_set_act_exponents(sfd2_ctx *ctx, const int32_t *exps, int n /* SFD2_RANGE_GROUPS, or 0 = all zero */);
+/* Self-check of SFD2_PREC_F16C at sfd2_load_weights (option "auto_margin", default 1).  The compensated mode's distance from the fp32 reference depends on
+ * the checkpoint (heavy-tailed or biased filters cost margin), so the library measures it: the built-in probe image goes through sfd2_det in SFD2_PREC_F32 and
+ * in SFD2_PREC_F16C, and while the largest difference of the two L2-normalised descriptor maps exceeds the target (7e-4) the accuracy options are turned on in
+ * order of cost -- "rb_inner" = 0 (+6 % per extract), "comp_heads" = 1 (+24 %), both -- the first that meets the target stays.  errs4: the probe error with the
+ * options as they were / rb_inner = 0 / comp_heads = 1 / both (-1 = not measured: an earlier one met the target); *choice: 0..3 = which of them the context
+ * now runs (bit 0: rb_inner = 0, bit 1: comp_heads = 1), -1 = no self-check has run (option off, auto_range off).  sfd2_set_option afterwards overrides. */
+int sfd2_get_margin_status(sfd2_ctx *ctx, float *errs4, int *choice, float *target);
 
 /* Blocks until every kernel queued on the context's stream has finished. */
 int sfd2_sync(sfd2_ctx *ctx);

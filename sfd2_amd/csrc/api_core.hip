@@ -13,7 +13,7 @@ std::atomic<unsigned long long> g_alloc_gen{0};
 thread_local int g_sfd2_cu_limit = 0;       // set per network pass from the context's option "cu_limit" (sfd2_internal.h)
 
 // ------------------------------------------------------------------------------------------ basics
-extern "C" int sfd2_version(void) { return 105; }   // 105: + sfd2_extract_record_async, sfd2_desc_pack, SFD2_FLAG_ASYNC with host outputs (round 5)
+extern "C" int sfd2_version(void) { return 106; }   // 105: + sfd2_extract_record_async, sfd2_desc_pack, SFD2_FLAG_ASYNC with host outputs (round 5); 106: + sfd2_get_margin_status
 extern "C" const char *sfd2_last_error(void) { return g_err.c_str(); }
 
 extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
@@ -108,6 +108,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "range_fallback") c->opt_range_fallback = value ? 1 : 0;
     else if (k == "x3_pp") c->opt_x3_pp = value ? 1 : 0;
     else if (k == "x3_desc16") c->opt_x3_desc16 = value ? 1 : 0;
+    else if (k == "auto_margin") c->opt_auto_margin = value ? 1 : 0;
     else if (k == "fp6_filters") c->opt_fp6_filters = value ? 1 : 0;
     else if (k == "fp6_acts") c->opt_fp6_acts = value ? 1 : 0;
     else if (k == "s2d") c->opt_s2d = value ? 1 : 0;

@@ -717,6 +717,79 @@ extern "C" int sfd2_set_act_exponents(sfd2_ctx *c, const int32_t *exps, int n)
     return apply_act_exponents(c);
 }
 
+// Self-check of SFD2_PREC_F16C (option "auto_margin", default 1; VERDICT r4 weak #3: the tolerance margin on heavy-tailed weights is thin).  How far the
+// compensated mode's descriptors sit from the fp32 reference depends on the CHECKPOINT: 4.5-5.3e-4 on the dense map of the probe for the well-conditioned
+// draw, 8-10e-4 for Student-t filters, 6.5-8.2e-4 for filters that do not sum to zero (profiles/r05j_probe_err.txt) -- and nobody has run the real
+// checkpoint (/root/reference/.MISSING_LARGE_BLOBS).  So the library measures it: the probe goes through sfd2_det once more in SFD2_PREC_F32 and in
+// SFD2_PREC_F16C, the L2-normalised descriptor maps are compared, and while the largest difference exceeds SFD2_MARGIN_TARGET the accuracy options are
+// tried in order of their cost -- "rb_inner" = 0 (the tensors inside the ResBlocks compensated too: +6 % per extract), "comp_heads" = 1 (+24 %), both
+// (+30 %) -- and the first one that meets the target stays on.  sfd2_get_margin_status reports the four errors and the choice; an option the caller sets
+// afterwards overrides it.  The dense map's maximum is a stricter measure than the error at key points (more samples, flat regions included).
+#define SFD2_MARGIN_TARGET 7.0e-4f
+static int probe_descriptors(sfd2_ctx *c, const float *img, int H, int W, int prec, std::vector<float> &out)
+{
+    const int p0 = c->precision, pm = c->prof_max_steps;
+    c->precision = prec;
+    c->prof_max_steps = 0;
+    int hc = 0, wc = 0;
+    out.assign((size_t)128 * ((H + 3) / 4 + 1) * ((W + 3) / 4 + 1), 0.0f);
+    const int rc = sfd2_det(c, img, 0, H, W, 0, nullptr, nullptr, out.data(), 0, nullptr, nullptr, &hc, &wc);
+    c->precision = p0;
+    c->prof_max_steps = pm;
+    if (rc) return -1;
+    out.resize((size_t)128 * hc * wc);
+    return 0;
+}
+
+static int margin_selfcheck(sfd2_ctx *c, const float *img, int H, int W)
+{
+    std::vector<float> ref, got;
+    if (probe_descriptors(c, img, H, W, SFD2_PREC_F32, ref)) return -1;
+    const int rb0 = c->opt_rb_inner, ch0 = c->opt_comp_heads;
+    auto run = [&](int rbi, int chd, float &err) -> int {
+        c->opt_rb_inner = rbi;
+        c->opt_comp_heads = chd;
+        if (probe_descriptors(c, img, H, W, SFD2_PREC_F16C, got)) return -1;
+        if (got.size() != ref.size()) return fail("auto_margin: descriptor maps of different size");
+        float m = 0.0f;
+        for (size_t i = 0; i < ref.size(); ++i) {
+            const float d = std::fabs(got[i] - ref[i]);
+            m = (d > m || !(d == d)) ? (d == d ? d : INFINITY) : m;      // (a NaN counts as infinitely wrong)
+        }
+        err = m;
+        return 0;
+    };
+    for (float &e : c->margin_err) e = -1.0f;
+    c->margin_choice = 0;
+    int rc = run(rb0, ch0, c->margin_err[0]);
+    if (rc == 0 && c->margin_err[0] > SFD2_MARGIN_TARGET) {
+        rc = run(0, ch0, c->margin_err[1]);
+        c->margin_choice = 1;
+        if (rc == 0 && c->margin_err[1] > SFD2_MARGIN_TARGET) {
+            rc = run(rb0, 1, c->margin_err[2]);
+            c->margin_choice = 2;
+            if (rc == 0 && c->margin_err[2] > SFD2_MARGIN_TARGET) {
+                rc = run(0, 1, c->margin_err[3]);
+                c->margin_choice = 3;
+            }
+        }
+    }
+    if (rc) { c->opt_rb_inner = rb0; c->opt_comp_heads = ch0; c->margin_choice = -1; return -1; }
+    c->opt_rb_inner = (c->margin_choice & 1) ? 0 : rb0;
+    c->opt_comp_heads = (c->margin_choice & 2) ? 1 : ch0;
+    graphs_release(c);
+    return reset_range_records(c);      // (the probe's maxima are not the caller's images')
+}
+
+extern "C" int sfd2_get_margin_status(sfd2_ctx *c, float *errs4, int *choice, float *target)
+{
+    if (!c) return fail("sfd2_get_margin_status: null argument");
+    if (errs4) for (int i = 0; i < 4; ++i) errs4[i] = c->margin_err[i];
+    if (choice) *choice = c->margin_choice;
+    if (target) *target = SFD2_MARGIN_TARGET;
+    return 0;
+}
+
 // The built-in probe: 192 x 256, half white noise and half a blocky low-frequency field (like the synthetic images of the tests), from
 // a fixed xorshift stream -- what sfd2_load_weights calibrates on when nothing better has been shown to the context yet.  A network
 // with BatchNorm after every conv keeps its activations at the same order of magnitude on any image; the envelope is 2^12 wide.
@@ -732,7 +805,8 @@ static int calibrate_on_probe(sfd2_ctx *c)
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x)
                 img[((size_t)ch * H + y) * W + x] = 0.5f * rnd() + 0.5f * coarse[((size_t)ch * (H / 16) + y / 16) * (W / 16) + x / 16];
-    const int rc = calibrate_impl(c, img.data(), 0, H, W, 0);
+    int rc = calibrate_impl(c, img.data(), 0, H, W, 0);
+    if (rc == 0 && c->opt_auto_margin) rc = margin_selfcheck(c, img.data(), H, W);
     // the probe's fp32 parity workspace (every activation in its own fp32 buffer) is of no use to a throughput context: give it back
     // (a context that runs SFD2_PREC_F32 / F16X3 allocates what its own geometry needs on its first call)
     DevBuf *f32ws[] = {&c->g1a, &c->g1b, &c->g2a, &c->g2b, &c->g3a, &c->g3b, &c->gpa0_o, &c->gpa_o, &c->gda0_o, &c->gda_o};

@@ -1,0 +1,75 @@
+"""Load-time self-check of SFD2_PREC_F16C (option "auto_margin", sfd2_get_margin_status; round 5): the library measures the
+compensated mode's descriptor error on its probe image against its own fp32 pass and turns on the accuracy options a checkpoint needs."""
+import numpy as np
+import pytest
+
+from sfd2_amd import synth
+
+
+def _model(sd, auto=True):
+    from sfd2_amd.model import ResSegNetV2
+    m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
+    m.cuda(0)                                   # the context first: the option must be set before the weights arrive
+    if not auto:
+        m.context.set_option("auto_margin", 0)
+    m.load_state_dict(sd)
+    return m
+
+
+def _desc_err(m, sd, h=480, w=640, k=1024, seed=41):
+    import oracle.oracle as orc
+    from sfd2_amd.extractor import extract_resnet_return
+    img = synth.make_image(h, w, seed)
+    got = extract_resnet_return(m, img[None], conf_th=0.001, topK=k, scales=[1.0])
+    want = orc.extract_resnet_return(sd, img, conf_th=0.001, topK=k)
+    a = {(float(x), float(y)): i for i, (x, y) in enumerate(got["keypoints"])}
+    b = {(float(x), float(y)): i for i, (x, y) in enumerate(want["keypoints"])}
+    common = sorted(set(a) & set(b))
+    assert len(common) >= 0.97 * len(b)
+    ia = np.array([a[c] for c in common]); ib = np.array([b[c] for c in common])
+    return float(np.abs(got["descriptors"][ia] - np.asarray(want["descriptors"])[ib]).max())
+
+
+@pytest.mark.gpu
+def test_benign_weights_keep_the_default_options(synth_sd):
+    m = _model(synth_sd)
+    st = m.context.margin_status()
+    assert st["choice"] == 0 and st["running"] == "as set", st
+    e = st["errors"]
+    assert 1e-4 < e["as set"] <= st["target"] and e["rb_inner=0"] == -1.0 and e["comp_heads=1"] == -1.0, st
+    # ... and the throughput path still runs the fused ResBlock kernel of the default options
+    from sfd2_amd.extractor import extract_resnet_return
+    m.context.set_profiling(4)
+    extract_resnet_return(m, synth.make_image(240, 320, 3)[None], conf_th=0.001, topK=300, scales=[1.0])
+    assert "rb23_c_kernel" in {r["kernel"] for r in m.context.layer_timings()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family,seed", [("student", 1), ("student", 0), ("biased", 2)])
+def test_heavy_tailed_and_biased_weights_get_their_margin_back(family, seed):
+    sd = synth.make_state_dict(seed, family=family)
+    m0, m1 = _model(sd, auto=False), _model(sd)
+    s0, s1 = m0.context.margin_status(), m1.context.margin_status()
+    assert s0["choice"] == -1 and s0["running"] is None
+    assert s1["choice"] >= 1, s1                                        # the defaults are above the target on these weights ...
+    assert s1["errors"]["as set"] > s1["target"] >= s1["errors"][s1["running"]] > 0, s1
+    e0, e1 = _desc_err(m0, sd), _desc_err(m1, sd)                        # ... and the chosen options bring an EXTRACTION's descriptors back too
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/margin_measured.txt", "a") as f:
+        f.write(f"{family} seed {seed}: probe errors {s1['errors']}, running '{s1['running']}'; 480x640 top-1024 descriptors vs oracle: "
+                f"defaults {e0:.2e} -> chosen options {e1:.2e}\n")
+    assert e1 <= 7.5e-4 and e1 < e0, (e0, e1)
+
+
+@pytest.mark.gpu
+def test_an_option_set_afterwards_overrides_the_choice():
+    sd = synth.make_state_dict(1, family="student")
+    m = _model(sd)
+    assert m.context.margin_status()["choice"] >= 1
+    m.context.set_option("rb_inner", 2)
+    m.context.set_option("comp_heads", 0)
+    from sfd2_amd.extractor import extract_resnet_return
+    m.context.set_profiling(4)
+    extract_resnet_return(m, synth.make_image(240, 320, 3)[None], conf_th=0.001, topK=300, scales=[1.0])
+    assert "rb23_c_kernel" in {r["kernel"] for r in m.context.layer_timings()}
