@@ -240,8 +240,9 @@ int sfd2_extract_count(sfd2_ctx *ctx, int *n_out);
  *   saturated    bit i: tensor i (sfd2_range_tensor_name) reached the saturation of SFD2_PREC_F16C ON THIS IMAGE -- the caller
  *                repeats such an image with a synchronous sfd2_extract (which falls back to SFD2_PREC_F16X3 by itself)
  *   flags        bit 0: candidate buffer overflow (the synchronous call's error)
- * and moves the image's range maxima into the context's history (sfd2_get_range_status still reports them), so the next
- * image's record speaks for that image alone.  One call per asynchronous extract, before the next extract is queued. */
+ * and folds the range maxima into the context's history (sfd2_get_range_status reports them); a tensor that saturated starts the next
+ * image with a clean record, so `saturated` speaks for this image alone (tensors below the saturation keep their running maxima: that
+ * is what spares the recording kernels their atomics).  One call per asynchronous extract, before the next extract is queued. */
 typedef struct {
     int32_t n;
     int32_t n_candidates;
