@@ -34,7 +34,7 @@ extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
     HIPCHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->cur_stream = c->stream;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < SFD2_IMG_SLOTS; ++i) {
         HIPCHECK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&c->ev_img_free[i], hipEventDisableTiming));
     }
@@ -60,7 +60,7 @@ extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
     graphs_release(c);
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < SFD2_IMG_SLOTS; ++i) {
         if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
         if (c->ev_img_free[i]) (void)hipEventDestroy(c->ev_img_free[i]);
     }

@@ -5,9 +5,9 @@ static int stage_image(sfd2_ctx *c, const void *x, int on_device, int H, int W, 
 {
     if (on_device) { *dev = static_cast<const float *>(x); return 0; }
     const size_t bytes = (size_t)3 * H * W * (u8 ? 1 : sizeof(float));
-    const int slot = (c->img_slot ^= 1);
+    const int slot = c->img_slot = (c->img_slot + 1) % SFD2_IMG_SLOTS;
     HIPCHECK(c->img2[slot].ensure(bytes));
-    // the slot's previous reader (the network two host images ago) must be done before the copy overwrites it
+    // the slot's previous reader (the network SFD2_IMG_SLOTS host images ago) must be done before the copy overwrites it
     HIPCHECK(hipStreamWaitEvent(c->copy_stream, c->ev_img_free[slot], 0));
     HIPCHECK(hipMemcpyAsync(c->img2[slot].p, x, bytes, hipMemcpyHostToDevice, c->copy_stream));
     HIPCHECK(hipEventRecord(c->ev_copied[slot], c->copy_stream));

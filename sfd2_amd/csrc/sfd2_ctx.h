@@ -111,8 +111,12 @@ struct sfd2_ctx {
     // host images go through a copy stream into one of two staging slots, so the upload of image i + 1 overlaps the
     // network of image i when the caller runs extracts back to back (SFD2_FLAG_ASYNC + pinned host memory)
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_img_free[2] = {nullptr, nullptr};
-    DevBuf img2[2];
+    // (SFD2_IMG_SLOTS slots, not two: an upload that has to WAIT for its slot's previous reader stalls the copy engine's queue in front of every other
+    //  context's uploads -- two pipelined contexts on one device then run at half the rate of one: profiles/r05l -- so the ring is longer than the images
+    //  a driver keeps in flight per context)
+#define SFD2_IMG_SLOTS 4
+    hipEvent_t ev_copied[SFD2_IMG_SLOTS] = {}, ev_img_free[SFD2_IMG_SLOTS] = {};
+    DevBuf img2[SFD2_IMG_SLOTS];
     int img_slot = 0, img_slot_used = -1;
     void *pin_jobs = nullptr;
     size_t pin_cap = 0;

@@ -105,6 +105,15 @@ class ResSegNetV2:
     def context(self):
         return self._ensure_ctx()
 
+    def lanes(self, n):
+        """[self, replica, ...]: n contexts for the pipelined driver, the replicas made once and kept (a replica costs a weight upload, the
+        packing kernels and the load-time probes: ~0.3 s, which a driver called per image directory must not pay every time)."""
+        have = getattr(self, "_lane_models", None) or []
+        while len(have) < n - 1:
+            have.append(self.replica())
+        self._lane_models = have
+        return [self] + have[:max(0, n - 1)]
+
     def replica(self):
         """A second context with the same weights, precision and activation exponents on the same device: another HIP stream
         for the pipelined driver (two images in flight fill the units one image's kernels leave idle).

@@ -90,11 +90,10 @@ class AsyncExtractor:
     finish(), as the float32 arrays the synchronous call fills."""
 
     def __init__(self, model, top_k, conf_th, depth=3, slots=8, lanes=1):
-        """lanes > 1: that many contexts (model.replica(): own HIP stream, workspace and staging slots) take the images
-        in turn; results do not depend on the lane.  Measured in THIS loop (eager launches, tools/pipeline_bench.py, f16c,
-        16 decoder threads): 547 images/s with one lane, 393 with two -- the +8 % bench.py gets from two streams comes with
-        one hipGraph replay per image; with ~35 eager launches per image from one host thread the second stream only adds
-        submission work.  Default 1."""
+        """lanes > 1: that many contexts (model.lanes(n): own HIP stream, workspace and staging slots; the replicas are made once per
+        model) take the images in turn; results do not depend on the lane.  Measured in THIS loop on pre-decoded images (f16c, 16 threads,
+        512 images, profiles/r05l): 678 images/s with one lane, 728-743 with two (4-6 images in flight).  (Rounds 4-5 had "two lanes are
+        slower, 393 against 547": that run created the replica -- weight upload, packing, probes: ~0.3 s -- inside its timed region.)"""
         import torch
         if top_k <= 0:
             raise ValueError("the pipelined extractor needs a key-point capacity (max_keypoints > 0)")
@@ -103,7 +102,8 @@ class AsyncExtractor:
         self.top_k, self.conf_th, self.depth = int(top_k), float(conf_th), int(depth)
         self.flags = 0 if getattr(model, "require_stability", True) else _lib.FLAG_NO_STABILITY
         self.device = torch.device("cuda", self.ctx.device)
-        self.models = [model] + [model.replica() for _ in range(max(1, int(lanes)) - 1)]
+        nl = max(1, int(lanes))
+        self.models = model.lanes(nl) if hasattr(model, "lanes") else [model] + [model.replica() for _ in range(nl - 1)]
         with torch.cuda.device(self.device):
             self._free = queue.Queue()
             for _ in range(max(slots, depth + 1)):

@@ -115,8 +115,8 @@ def parse_args(argv=None):
     ap.add_argument("--k", type=int, default=50)
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--writers", type=int, default=3)
-    ap.add_argument("--depth", type=int, default=3)
-    ap.add_argument("--lanes", type=int, default=1, help="contexts (HIP streams) the pipelined extract loop alternates over")
+    ap.add_argument("--depth", type=int, default=6)
+    ap.add_argument("--lanes", type=int, default=2, help="contexts (HIP streams) the pipelined extract loop alternates over")
     ap.add_argument("--size", default="1600x1200")
     ap.add_argument("--topk", type=int, default=4096)
     ap.add_argument("--precision", default="f16c,f16x3d,f16x3")
@@ -164,7 +164,8 @@ def run(args):
             model.load_state_dict(sd)
             model.cuda(0)
             me = (model, el.extract_resnet_return)
-            el.extract_resnet_return(model, ds[0]["image"], conf_th=0.001, topK=args.topk)        # workspace, first-use packing
+            for lm in model.lanes(args.lanes):                                                    # (the replicas of a multi-lane run: model construction, outside the timed region)
+                el.extract_resnet_return(lm, ds[0]["image"], conf_th=0.001, topK=args.topk)       # workspace, first-use packing
             d_pipe, d_ser = os.path.join(scratch, f"pipe_{prec}"), os.path.join(scratch, f"serial_{prec}")
             t0 = time.perf_counter()
             p_pipe = el.main(conf, ds, d_pipe, model_and_extractor=me, num_workers=args.workers, writers=args.writers, depth=args.depth, lanes=args.lanes)
