@@ -27,6 +27,8 @@ python bench.py --size 1024x1024 --no-cpu-baseline --no-strict > $out/bench_1024
 python bench.py --size 1024x768 --no-cpu-baseline --no-strict > $out/bench_1024x768.json 2>/dev/null
 python bench.py --size 640x480 --no-cpu-baseline --no-strict --steps 20 --warmup 5 --streams 1 --no-graphs --dump-layers > $out/bench_640x480_streams1.json 2> $out/layer_table_640x480.txt
 python tools/strict_layers.py f16x3 > $out/strict_layers_f16x3.txt 2>&1
+python tools/strict_layers.py f16x3d > $out/strict_layers_f16x3d.txt 2>&1
+[ -x build/probe/valu_cost ] && ./build/probe/valu_cost > $out/valu_cost.txt 2>&1
 python tools/pipeline_bench.py > $out/pipeline_bench.json 2> $out/pipeline_bench.err
 python tools/pipeline_bench.py --workers 8 --precision f16c > $out/pipeline_bench_w8.json 2>> $out/pipeline_bench.err
 python tools/match_gap_stats.py > $out/match_gap_stats.json 2> $out/match_gap_stats.err
