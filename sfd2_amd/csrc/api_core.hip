@@ -117,10 +117,10 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "generic_c") c->opt_generic_c = value ? 1 : 0;
     else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;
     else if (k == "no_rf_c") c->opt_no_rf_c = value ? 1 : 0;
-    else if (k == "comp_heads") c->opt_comp_heads = value ? 1 : 0;
+    else if (k == "comp_heads") c->opt_comp_heads = c->user_comp_heads = value ? 1 : 0;
     else if (k == "comp_det") c->opt_comp_det = value ? 1 : 0;
     else if (k == "fuse_rb23") c->opt_fuse_rb23 = value ? 1 : 0;
-    else if (k == "rb_inner") c->opt_rb_inner = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (k == "rb_inner") c->opt_rb_inner = c->user_rb_inner = value < 0 ? 0 : (value > 2 ? 2 : value);
     else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;
 }

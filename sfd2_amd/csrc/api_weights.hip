@@ -745,7 +745,7 @@ static int margin_selfcheck(sfd2_ctx *c, const float *img, int H, int W)
 {
     std::vector<float> ref, got;
     if (probe_descriptors(c, img, H, W, SFD2_PREC_F32, ref)) return -1;
-    const int rb0 = c->opt_rb_inner, ch0 = c->opt_comp_heads;
+    const int rb0 = c->user_rb_inner, ch0 = c->user_comp_heads;      // (not what an earlier load's self-check left behind)
     auto run = [&](int rbi, int chd, float &err) -> int {
         c->opt_rb_inner = rbi;
         c->opt_comp_heads = chd;

@@ -169,6 +169,7 @@ struct sfd2_ctx {
                                        // SFD2_PREC_F32 pass it runs anyway and, above SFD2_MARGIN_TARGET, turns on the accuracy options that bring it back (api_weights.hip)
     float margin_err[4] = {-1.0f, -1.0f, -1.0f, -1.0f};   // probe error with the options as set / rb_inner = 0 / comp_heads = 1 / both (-1: not measured)
     int margin_choice = -1;            // which of the four the context now runs (-1: no self-check has run)
+    int user_rb_inner = 2, user_comp_heads = 0;   // what sfd2_set_option last asked for: the self-check of a LATER sfd2_load_weights starts from these, not from its own earlier choice
     int opt_x3_desc16 = 0;             // sfd2_set_option "x3_desc16": SFD2_PREC_F16X3 on sfd2_extract with the DESCRIPTOR branch (convDa.0, convDa.3 at the sampled corners,
                                        // convDb) in plain fp16 on the backbone output's hi plane: the key points are this mode's own, the descriptors carry the
                                        // fp16 head's error only (<= 1e-3: north_star's tolerance, not this mode's 2e-5)

@@ -73,3 +73,17 @@ def test_an_option_set_afterwards_overrides_the_choice():
     m.context.set_profiling(4)
     extract_resnet_return(m, synth.make_image(240, 320, 3)[None], conf_th=0.001, topK=300, scales=[1.0])
     assert "rb23_c_kernel" in {r["kernel"] for r in m.context.layer_timings()}
+
+
+@pytest.mark.gpu
+def test_reload_starts_from_the_callers_options_not_from_the_last_choice(synth_sd):
+    """A context that needed `rb_inner = 0` for one checkpoint goes back to the default options when a benign one is loaded into it."""
+    from sfd2_amd.extractor import extract_resnet_return
+    m = _model(synth.make_state_dict(1, family="student"))
+    assert m.context.margin_status()["choice"] >= 1
+    m.load_state_dict(synth_sd)
+    st = m.context.margin_status()
+    assert st["choice"] == 0 and st["errors"]["as set"] <= st["target"], st
+    m.context.set_profiling(4)
+    extract_resnet_return(m, synth.make_image(240, 320, 3)[None], conf_th=0.001, topK=300, scales=[1.0])
+    assert "rb23_c_kernel" in {r["kernel"] for r in m.context.layer_timings()}
