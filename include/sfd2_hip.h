@@ -35,6 +35,9 @@ typedef struct sfd2_ctx sfd2_ctx;
 #define SFD2_FLAG_IMG_U8_HWC 8     /* sfd2_extract: img is uint8 [H][W][3]; the device does the
                                     * astype(float32) / 255. of extract_localization.py:168,186 */
 #define SFD2_FLAG_IMG_BGR 16       /* with IMG_U8_HWC: channel order is cv2's BGR (:162-165)    */
+#define SFD2_FLAG_IMG_U8_X 32      /* with IMG_U8_HWC (sfd2_extract, sfd2_preprocess): pixels are FOUR bytes, the fourth ignored
+                                    * (RGBX / BGRX: the in-memory layout of PIL's RGB images, which a decoder thread can hand
+                                    * over without the interpreter-locked repacking to three bytes); unpacked on the device */
 
 /* One named fp32 tensor of the reference state_dict (torch layout), host memory.
  * Replaces: model.load_state_dict(torch.load(p)['model'])  extract_localization.py:213-215 */

@@ -1,10 +1,22 @@
 // libsfd2hip: extraction entry points (sfd2_det, sfd2_extract, pyramids, spp variants, stage entry points).
 #include "sfd2_ctx.h"
 
+static int release_image_slot(sfd2_ctx *c);
+// u8: 0 = fp32 [3][H][W], 1 = uint8 [H][W][3], 2 = uint8 [H][W][4] (SFD2_FLAG_IMG_U8_X: unpacked to three bytes on the device)
 static int stage_image(sfd2_ctx *c, const void *x, int on_device, int H, int W, const float **dev, int u8 = 0)
 {
+    if (u8 == 2) {
+        const float *raw = nullptr;
+        if (on_device) raw = static_cast<const float *>(x);
+        else if (stage_image(c, x, 0, H, W, &raw, 3)) return -1;          // (3: four bytes per pixel, staged as they are)
+        HIPCHECK(c->img_u8_packed.ensure((size_t)3 * H * W + 16));
+        launch_unpack_rgbx(c->stream, reinterpret_cast<const unsigned char *>(raw), c->img_u8_packed.as<unsigned char>(), (size_t)H * W);
+        if (release_image_slot(c)) return -1;                             // the staged copy has been read once the unpack kernel is done
+        *dev = c->img_u8_packed.as<float>();
+        return 0;
+    }
     if (on_device) { *dev = static_cast<const float *>(x); return 0; }
-    const size_t bytes = (size_t)3 * H * W * (u8 ? 1 : sizeof(float));
+    const size_t bytes = u8 == 3 ? (size_t)4 * H * W : (size_t)3 * H * W * (u8 ? 1 : sizeof(float));
     const int slot = c->img_slot = (c->img_slot + 1) % SFD2_IMG_SLOTS;
     HIPCHECK(c->img2[slot].ensure(bytes));
     // the slot's previous reader (the network SFD2_IMG_SLOTS host images ago) must be done before the copy overwrites it
@@ -147,7 +159,8 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     const int u8 = (flags & SFD2_FLAG_IMG_U8_HWC) ? 1 : 0;
     if (u8 && (flags & SFD2_FLAG_IMG_NORMALISED)) return fail("sfd2_extract: a uint8 image cannot be pre-normalised");
     if ((flags & SFD2_FLAG_IMG_BGR) && !u8) return fail("sfd2_extract: SFD2_FLAG_IMG_BGR needs SFD2_FLAG_IMG_U8_HWC");
-    if (stage_image(c, img, img_on_device, H, W, &img_dev, u8)) return -1;
+    if ((flags & SFD2_FLAG_IMG_U8_X) && !u8) return fail("sfd2_extract: SFD2_FLAG_IMG_U8_X needs SFD2_FLAG_IMG_U8_HWC");
+    if (stage_image(c, img, img_on_device, H, W, &img_dev, u8 ? ((flags & SFD2_FLAG_IMG_U8_X) ? 2 : 1) : 0)) return -1;
     HIPCHECK(hipEventRecord(c->ev[0], c->stream));
     prof_step_begin(c);
     const int in_mode = ((flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1) | (u8 ? 2 : 0) | ((flags & SFD2_FLAG_IMG_BGR) ? 4 : 0);
@@ -299,7 +312,7 @@ extern "C" int sfd2_preprocess(sfd2_ctx *c, const unsigned char *img_hwc, int on
     if (H < 1 || W < 1 || new_h < 1 || new_w < 1) return fail("sfd2_preprocess: bad size");
     HIPCHECK(hipSetDevice(c->device));
     const float *staged = nullptr;
-    if (stage_image(c, img_hwc, on_device, H, W, &staged, 1)) return -1;
+    if (stage_image(c, img_hwc, on_device, H, W, &staged, (flags & SFD2_FLAG_IMG_U8_X) ? 2 : 1)) return -1;
     launch_ingest_u8(c->stream, reinterpret_cast<const unsigned char *>(staged), H, W, (flags & SFD2_FLAG_IMG_BGR) ? 1 : 0, new_h,
                      new_w, out_chw_dev);
     if (release_image_slot(c)) return -1;

@@ -230,6 +230,7 @@ struct sfd2_ctx {
     float *kpts_cur = nullptr, *kscores_cur = nullptr;   // where the last selection wrote its key points
     // scale pyramid staging (sfd2_extract_multiscale)
     DevBuf arena;   // aliased activation slots of the throughput path (run_network)
+    DevBuf img_u8_packed;              // SFD2_FLAG_IMG_U8_X: the image as three bytes per pixel (unpack_rgbx_kernel)
     DevBuf img_scaled, ms_kp, ms_sc, ms_de, ms_keys, ms_sorted, ms_cnt;
     unsigned int ms_cand_seen[8] = {};
     int ms_cand_cap[8] = {};

@@ -578,6 +578,7 @@ void launch_absmax_f32(hipStream_t st, const float *in, size_t n, unsigned int *
 
 // decoder-side ingest: uint8 HWC (RGB or BGR) -> float32 CHW in [0,1] at nh x nw (cv2 INTER_CUBIC when the size changes)
 void launch_ingest_u8(hipStream_t st, const unsigned char *src, int H, int W, int bgr, int nh, int nw, float *out);
+void launch_unpack_rgbx(hipStream_t st, const unsigned char *src, unsigned char *dst, size_t npix);   // SFD2_FLAG_IMG_U8_X
 void launch_extract_record(hipStream_t st, unsigned int *range_stat, unsigned int *hist, const unsigned int *counters, int sel_cap,
                            int cand_cap, unsigned int *rec /* 4 words, or null = fold the range words into hist only */);
 

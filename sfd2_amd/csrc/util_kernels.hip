@@ -155,6 +155,31 @@ void ingest_u8_kernel(const unsigned char *__restrict__ src, int H, int W, int b
     }
 }
 
+// SFD2_FLAG_IMG_U8_X: [n][4] bytes -> [n][3] bytes (the fourth byte of a pixel dropped); four pixels per thread
+__global__ __launch_bounds__(256)
+void unpack_rgbx_kernel(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, size_t npix)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;          // pixel quad
+    const size_t p0 = q * 4;
+    if (p0 + 4 <= npix && ((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) & 15) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + p0 * 4);
+        // bytes r0 g0 b0 x | r1 g1 b1 x | r2 g2 b2 x | r3 g3 b3 x  ->  r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+        const unsigned int a = (v.x & 0x00FFFFFFu) | (v.y << 24);
+        const unsigned int b = ((v.y >> 8) & 0x0000FFFFu) | (v.z << 16);
+        const unsigned int c = ((v.z >> 16) & 0x000000FFu) | (v.w << 8);
+        unsigned int *d = reinterpret_cast<unsigned int *>(dst + p0 * 3);
+        d[0] = a; d[1] = b; d[2] = c;
+    } else {
+        for (size_t p = p0; p < npix && p < p0 + 4; ++p)
+            for (int ch = 0; ch < 3; ++ch) dst[p * 3 + ch] = src[p * 4 + ch];
+    }
+}
+void launch_unpack_rgbx(hipStream_t st, const unsigned char *src, unsigned char *dst, size_t npix)
+{
+    const size_t quads = (npix + 3) / 4;
+    hipLaunchKernelGGL(unpack_rgbx_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, src, dst, npix);
+}
+
 void launch_ingest_u8(hipStream_t st, const unsigned char *src, int H, int W, int bgr, int nh, int nw, float *out)
 {
     // cv2.resize: inv_scale = dsize / ssize (double), scale = 1. / inv_scale

@@ -115,7 +115,7 @@ class AsyncExtractor:
         self.repeats = 0                # images re-run synchronously (range fallback)
 
     def submit(self, image_u8, H, W, resize, meta, inbuf=None):
-        """image_u8: uint8 [H,W,3] RGB view (pinned for a truly asynchronous upload); resize (w, h) or None."""
+        """image_u8: uint8 [H,W,3] RGB or [H,W,4] RGBX view (pinned for a truly asynchronous upload); resize (w, h) or None."""
         if not image_u8.flags.c_contiguous:
             image_u8 = np.ascontiguousarray(image_u8)      # (a transposed view multiplied / cast keeps its operand's layout)
         slot = self._free.get()         # blocks while the writers are behind: back-pressure
@@ -128,15 +128,16 @@ class AsyncExtractor:
         slot.image = image_u8           # kept for a synchronous repeat
         src, on_dev, h, w = image_u8.ctypes.data, 0, H, W
         flags = self.flags | _lib.FLAG_ASYNC
+        px4 = _lib.FLAG_IMG_U8_X if image_u8.shape[-1] == 4 else 0
         if resize is not None and tuple(resize) != (W, H):
             w, h = int(resize[0]), int(resize[1])
             if self._resized[lane] is None or self._resized[lane].numel() < 3 * h * w:
                 ctx.sync()              # nothing may still read the old buffer when it is replaced
                 self._resized[lane] = torch.empty(3 * h * w, dtype=torch.float32, device=self.device)
-            _lib.check(lib.sfd2_preprocess(ctx.h, src, 0, H, W, _lib.FLAG_ASYNC, h, w, self._resized[lane].data_ptr()))
+            _lib.check(lib.sfd2_preprocess(ctx.h, src, 0, H, W, _lib.FLAG_ASYNC | px4, h, w, self._resized[lane].data_ptr()))
             src, on_dev = self._resized[lane].data_ptr(), 1
         else:
-            flags |= _lib.FLAG_IMG_U8_HWC
+            flags |= _lib.FLAG_IMG_U8_HWC | px4
         slot.size = (w, h)
         slot.resize = None if on_dev == 0 else (w, h)
         n = ctypes.c_int(0)
@@ -157,9 +158,11 @@ class AsyncExtractor:
             # SFD2_PREC_F16C left its range on this image: the synchronous call repeats it in SFD2_PREC_F16X3 by itself
             from .extractor import extract_resnet_return
             img, model = slot.image, self.models[slot.lane]
+            if img.shape[-1] == 4:
+                img = np.ascontiguousarray(img[:, :, :3])
             if slot.resize is not None:
                 from .extract_localization import preprocess
-                img = preprocess(model, slot.image, slot.resize)
+                img = preprocess(model, img, slot.resize)
             slot.sync_result = extract_resnet_return(model, img=img, topK=self.top_k, conf_th=self.conf_th)
             self.repeats += 1
         slot.n = n

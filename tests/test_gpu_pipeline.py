@@ -428,3 +428,42 @@ def test_grouped_match_driver_with_empty_and_tiny_sets(tmp_path):
     assert st[mf.names_to_pair("q/empty.jpg", "db/many.jpg")]["matches0"].shape == (0,)
     assert (st[mf.names_to_pair("q/some.jpg", "db/empty.jpg")]["matches0"].__array__() == -1).all()
     assert st[mf.names_to_pair("q/some.jpg", "db/empty.jpg")]["matches0"].shape == (300,)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w", [(96, 128), (250, 333), (1200, 1600)])
+def test_rgbx_pixels_equal_rgb_pixels(synth_sd, h, w):
+    """SFD2_FLAG_IMG_U8_X (four bytes per pixel, PIL's in-memory layout, the fourth ignored) through sfd2_extract from host and from device memory,
+    and through sfd2_preprocess: the outputs of the three-byte form, bit for bit."""
+    import torch
+    from sfd2_amd.model import ResSegNetV2
+    m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
+    m.load_state_dict(synth_sd)
+    m.cuda(0)
+    ctx = m.context
+    rgb = (synth.make_image(h, w, 31).transpose(1, 2, 0) * 255).astype(np.uint8).copy()
+    rgbx = np.concatenate([rgb, np.full((h, w, 1), 0xA5, np.uint8)], axis=2).copy()
+    K = 300
+    def run(arr, flags, on_dev):
+        kp = np.zeros((K, 2), np.float32); sc = np.zeros((K,), np.float32); de = np.zeros((K, 128), np.float32)
+        n = ctypes.c_int(0)
+        src = torch.from_numpy(arr).cuda() if on_dev else None
+        ptr = src.data_ptr() if on_dev else arr.ctypes.data
+        _lib.check(ctx.lib.sfd2_extract(ctx.h, ptr, 1 if on_dev else 0, h, w, 0.001, K, _lib.FLAG_IMG_U8_HWC | flags, kp.ctypes.data, sc.ctypes.data,
+                                        de.ctypes.data, 0, K, ctypes.byref(n)))
+        return n.value, kp, sc, de
+    ref = run(rgb, 0, False)
+    assert ref[0] > 20
+    for on_dev in (False, True):
+        got = run(rgbx, _lib.FLAG_IMG_U8_X, on_dev)
+        assert got[0] == ref[0]
+        for a, b in zip(got[1:], ref[1:]):
+            np.testing.assert_array_equal(a, b)
+    # the resize path
+    nh, nw = max(8, h // 2), max(8, w // 2)
+    o3 = torch.empty((3, nh, nw), device="cuda"); o4 = torch.empty((3, nh, nw), device="cuda")
+    _lib.check(ctx.lib.sfd2_preprocess(ctx.h, rgb.ctypes.data, 0, h, w, 0, nh, nw, o3.data_ptr()))
+    _lib.check(ctx.lib.sfd2_preprocess(ctx.h, rgbx.ctypes.data, 0, h, w, _lib.FLAG_IMG_U8_X, nh, nw, o4.data_ptr()))
+    assert torch.equal(o3, o4)
+    # a float image cannot carry the flag
+    assert ctx.lib.sfd2_extract(ctx.h, rgbx.ctypes.data, 0, h, w, 0.001, K, _lib.FLAG_IMG_U8_X, None, None, None, 0, K, None) != 0

@@ -221,3 +221,26 @@ def test_pipelined_main_surfaces_decode_errors(tmp_path):
             el.main(conf, Items(), tmp_path / f"o{nw}", model_and_extractor=(None, _stub_extractor), num_workers=nw)
         st = fio.open_store(str(tmp_path / f"o{nw}" / (conf["output"] + ".h5")), "r")
         assert set(st.keys()) <= {f"im{i}.jpg" for i in range(5)} and len(st.keys()) >= (5 if nw == 0 else 0)
+
+
+def test_decoder_rgbx_paste_equals_repacked_pixels(tmp_path):
+    """_read_rgb_u8(rgbx=True): PIL's four-byte pixels pasted into the caller's buffer with the interpreter lock released -- the first three bytes of every
+    pixel are what np.asarray(im) gives (the path the serial loop takes); odd sizes and a non-RGB file included."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    from sfd2_amd import extract_localization as el
+    rs = np.random.RandomState(3)
+    for i, (h, w, mode) in enumerate([(48, 64, "RGB"), (37, 53, "RGB"), (40, 40, "L")]):
+        arr = rs.randint(0, 256, (h, w, 3) if mode == "RGB" else (h, w), dtype=np.uint8)
+        p = tmp_path / f"im{i}.png"
+        Image.fromarray(arr, mode).save(p)
+        want = el._read_rgb_u8(p)
+        store = {}
+        def reserve(n):
+            store["b"] = np.zeros(n + 7, np.uint8)[:n]
+            return store["b"]
+        got = el._read_rgb_u8(p, reserve, rgbx=True)
+        assert got.dtype == np.uint8 and got.shape[:2] == (h, w) and got.shape[2] in (3, 4)
+        np.testing.assert_array_equal(got[:, :, :3], want)
+        assert got.base is not None and np.shares_memory(got, store["b"])          # the pixels are in the caller's buffer
+    assert el._RGBX_OK in (True, False)
