@@ -54,8 +54,9 @@ def write_images(root, n_query, n_db, H, W, quality=90, bases=4, seed=0):
     return names, float(np.mean(sizes))
 
 
-def decode_only_rate(ds, workers):
-    """The decoder pool alone (PIL decode + copy into a reusable buffer), no device: the ceiling files -> features can reach."""
+def decode_only_rate(ds, workers, rgbx=True):
+    """The decoder pool alone (PIL decode + copy into a reusable buffer), no device: the ceiling files -> features can reach.
+    rgbx: the pipelined loader's form (four-byte pixels pasted with the interpreter lock released); False: repacked to three bytes."""
     from sfd2_amd.pipeline import OrderedPrefetch
     class Buf:
         def __init__(self):
@@ -78,7 +79,7 @@ def decode_only_rate(ds, workers):
             return None
 
     def load(idx, buf):
-        return ds.load(idx, buf.reserve), buf
+        return ds.load(idx, buf.reserve, rgbx=rgbx), buf
 
     pf = OrderedPrefetch(load, range(len(ds)), workers, window=workers + 2, claim=claim)
     t0 = time.perf_counter()
@@ -153,6 +154,7 @@ def run(args):
         ds = el.ImageDataset(os.path.join(scratch, "images"), conf["preprocessing"])
         assert len(ds) == len(names)
         out["decode_only_images_per_s"] = round(decode_only_rate(ds, args.workers), 1)
+        out["decode_only_repacked_rgb_images_per_s"] = round(decode_only_rate(ds, args.workers, rgbx=False), 1)
         sd = synth.make_state_dict(0)
         sub_list = os.path.join(scratch, "subset.txt")
         with open(sub_list, "w") as f:
