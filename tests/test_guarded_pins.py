@@ -71,7 +71,7 @@ def test_real_checkpoint_every_precision_vs_fp32_twin():
     want = tt.extract(tt.Twin(sd), img, conf_th=0.001, topK=1024)
     ib = {(float(x), float(y)): i for i, (x, y) in enumerate(want["keypoints"])}
     report = []
-    for prec, tol in (("f32", 2e-5), ("f16x3", 2e-5), ("f16c", 1e-3), ("f16", None)):
+    for prec, tol in (("f32", 2e-5), ("f16x3", 2e-5), ("f16x3d", 1e-3), ("f16c", 1e-3), ("f16", None)):
         m = ResSegNetV2(outdim=128, require_stability=stab, precision=prec).eval()
         m.load_state_dict(sd, strict=False)
         m.cuda(0)
