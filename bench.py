@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--graphs", action="store_true", help="(default since round 2; kept for old command lines) sfd2_extract_match with the per-context hipGraph cache (configs[4]); "
                                                           "per-kernel events are not available then")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-f32 leg")
+    ap.add_argument("--strict-graphs", action="store_true", help="the parity legs (strict_f32, strict_f16x3, strict_kp_f16x3d, approx) in the headline's launch mode "
+                                                                 "(sfd2_extract_match, one hipGraph replay per image) instead of eager launches")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the files -> feature store -> match store leg (the `pipeline` object: tools/pipeline_bench.py "
                     "on a reduced workload, N = 1 only)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configs (the 'configs' object)")
@@ -451,13 +453,15 @@ def main():
         n_st = max(4, min(args.steps, 10))
 
         def sstep(i):
+            if use_graphs and args.strict_graphs:      # the headline's launch mode (one hipGraph replay per image) for this precision too
+                return step(i)
             sl = lanes[i % len(lanes)]
             _lib.check(lib.sfd2_extract(sl.ctx.h, imgs[i % n_img].data_ptr(), 1, geo[i % n_img][0], geo[i % n_img][1], 0.001, TOPK, _lib.FLAG_ASYNC,
                                         sl.kpts.data_ptr(), sl.scores.data_ptr(), sl.desc.data_ptr(), 1, TOPK, ctypes.byref(sl.n_out)))
             if not args.extract_only:
                 _lib.check(lib.sfd2_match_batch(sl.ctx.h, ctypes.byref(sl.q), dbs, K_DB, 128, ctypes.byref(mconf),
                                                 sl.matches.data_ptr(), sl.mscores.data_ptr(), 1, _lib.FLAG_ASYNC))
-        for i in range(2 * len(lanes)):
+        for i in range((4 if (use_graphs and args.strict_graphs) else 2) * len(lanes)):      # (a geometry is captured the second time a context sees it)
             sstep(i)
         sync_all()
         barrier()
@@ -476,7 +480,8 @@ def main():
                "f16": "OUTSIDE north_star's tolerance: descriptors <= 3e-3 (measured 1.8e-3), key-point set IoU >= 0.93 (tests/test_gpu_parity.py)",
                "f16c": "descriptors <= 1e-3 asserted (measured <= 3.5e-4), key-point set IoU >= 0.985 (tests/test_gpu_f16c.py)"}[mode]
         return {"value": round(n_st * world / dst, 3), "unit": "images/sec", "ms_per_step": round(dst / n_st * 1e3, 3),
-                "steps": n_st, "dtype": mode, "streams_per_gpu": len(lanes), "launch": "eager", "parity": par}
+                "steps": n_st, "dtype": mode, "streams_per_gpu": len(lanes),
+                "launch": "hipGraph replay per image (sfd2_extract_match)" if (use_graphs and args.strict_graphs) else "eager", "parity": par}
 
     strict = strict_x3 = strict_kp = approx = None
     if not args.no_strict:
