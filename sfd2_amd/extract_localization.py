@@ -312,9 +312,9 @@ def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precisio
     or equivalent; one process per GPU), rank 0 merges the parts into the final store in item order.
 
     num_workers > 0 (default 4, the reference's DataLoader(num_workers=4), extract_localization.py:230-233): the pipelined
-    loop (_extract_pipelined: that many decoder threads, `depth` images in flight on the device over `lanes` contexts
-    (HIP streams), `writers` writer threads); 0: the reference's loop body strictly in turn per image.
-    Both write the same groups.
+    loop (_extract_pipelined: that many decoder threads, `depth` images in flight on the device (default: three per lane) over `lanes`
+    contexts (HIP streams; default 2 from 64 images on -- the second context is made once per model, model.lanes), `writers` writer
+    threads); 0: the reference's loop body strictly in turn per image.  Both write the same groups.
     Returns the final store path (rank 0) or the part path (other ranks)."""
     from .feature_io import open_store, write_features
     from .sharding import shard_indices
