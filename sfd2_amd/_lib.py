@@ -191,6 +191,7 @@ class Context:
         check(self.lib.sfd2_ctx_create(int(device), ctypes.byref(h)))
         self.h = h
         self.device = int(device)
+        self.options = {}           # what set_option was asked for, in order (ResSegNetV2.replica replays it on the other lanes of a pipelined driver)
 
     def close(self):
         if getattr(self, "h", None):
@@ -242,6 +243,8 @@ class Context:
     def set_option(self, key, value):
         """'fuse', 'fuse_det', 'alias', 'graphs', 'fuse_post', 'sparse_desc', 'branches' (include/sfd2_hip.h sfd2_set_option)."""
         check(self.lib.sfd2_set_option(self.h, key.encode(), int(value)))
+        self.options.pop(key, None)
+        self.options[key] = int(value)
 
     def sync(self):
         check(self.lib.sfd2_sync(self.h))

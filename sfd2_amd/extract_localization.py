@@ -300,7 +300,7 @@ def _feed_of(model, data):
 
 
 def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precision="f16x3", world=1, rank=0,
-         barrier=None, model_and_extractor=None, num_workers=4, writers=2, depth=None, lanes=2):
+         barrier=None, model_and_extractor=None, num_workers=4, writers=2, depth=None, lanes=None):
     """extract_localization.py:221-279.  ``images``: an ImageDataset (decoded from files, resized per
     conf['preprocessing']) or any indexable / iterable of {'name', 'image': uint8 [H,W,3] RGB or float [3,H,W] in
     [0,1], 'original_size': (w, h)[, 'resize': (w, h)]}.  uint8 input is exact only together with the device resize
@@ -313,7 +313,7 @@ def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precisio
 
     num_workers > 0 (default 4, the reference's DataLoader(num_workers=4), extract_localization.py:230-233): the pipelined
     loop (_extract_pipelined: that many decoder threads, `depth` images in flight on the device (default: three per lane) over `lanes`
-    contexts (HIP streams; default 2 from 64 images on -- the second context is made once per model, model.lanes), `writers` writer
+    contexts (HIP streams; default: 2 from 64 images on, else 1 -- the second context is made once per model, model.lanes), `writers` writer
     threads); 0: the reference's loop body strictly in turn per image.  Both write the same groups.
     Returns the final store path (rank 0) or the part path (other ranks)."""
     from .feature_io import open_store, write_features
@@ -336,7 +336,7 @@ def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precisio
             # two contexts (HIP streams) taking the images in turn: +7-9 % on the device (tile tails and small launches of one image filled by the
             # other's kernels); the second context costs a weight upload once per model (model.lanes), so short jobs stay on one
             idx_list = list(shard_indices(n_items, rank, world))
-            n_lanes = max(1, int(lanes)) if len(idx_list) >= 64 else 1
+            n_lanes = max(1, int(lanes)) if lanes is not None else (2 if len(idx_list) >= 64 else 1)
             n_depth = max(1, int(depth)) if depth is not None else 3 * n_lanes
             _extract_pipelined(model, extractor, conf, images, idx_list, tag, store, names,
                                int(num_workers), max(1, int(writers)), n_depth, n_lanes)

@@ -112,20 +112,35 @@ class ResSegNetV2:
         while len(have) < n - 1:
             have.append(self.replica())
         self._lane_models = have
+        mine = self._ensure_ctx().options
+        for r in have:                              # options set on this context since the replica was made
+            theirs = r._ctx.options
+            for k, v in mine.items():
+                if theirs.get(k) != v:
+                    r._ctx.set_option(k, v)
         return [self] + have[:max(0, n - 1)]
 
     def replica(self):
         """A second context with the same weights, precision and activation exponents on the same device: another HIP stream
         for the pipelined driver (two images in flight fill the units one image's kernels leave idle).
-        Options set on this model's context with set_option are NOT copied."""
+        The options set on this model's context so far are replayed on the replica BEFORE its weights are loaded (so that "auto_margin" / "auto_range"
+        act there as they did here) -- results do not depend on the lane; lanes() re-synchronises options set later."""
         if self._sd is None:
             raise RuntimeError("load_state_dict() first")
         m = ResSegNetV2(outdim=self.outdim, require_feature=self.require_feature, require_stability=self.require_stability,
                         ms_detector=self.ms_detector, precision=self.precision)
         m._device = self._device
+        src = self._ensure_ctx()
+        m._ctx = _lib.Context(self._device)
+        m._ctx.set_precision(self.precision)
+        for k, v in src.options.items():
+            m._ctx.set_option(k, v)
         m._sd = self._sd
-        m._ensure_ctx()
-        exps, _ = self._ensure_ctx().act_exponents()
+        m._ctx.load_weights(self._sd)
+        for k, v in src.options.items():        # (the load-time self-check may have moved rb_inner / comp_heads: what the caller asked for wins, as on the source)
+            if k in ("rb_inner", "comp_heads"):
+                m._ctx.set_option(k, v)
+        exps, _ = src.act_exponents()
         m._ctx.set_act_exponents(exps)          # the same scaling of every stored tensor: bit-identical results on either context
         return m
 

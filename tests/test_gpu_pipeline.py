@@ -467,3 +467,31 @@ def test_rgbx_pixels_equal_rgb_pixels(synth_sd, h, w):
     assert torch.equal(o3, o4)
     # a float image cannot carry the flag
     assert ctx.lib.sfd2_extract(ctx.h, rgbx.ctypes.data, 0, h, w, 0.001, K, _lib.FLAG_IMG_U8_X, None, None, None, 0, K, None) != 0
+
+
+def test_replica_lanes_carry_the_options_of_the_model(tmp_path, synth_sd):
+    """Two lanes with an option that CHANGES the descriptors set on the model's context (comp_heads = 1), before and after the replica exists: every
+    image gets the same result whichever context it lands on, i.e. the pipelined store equals the serial loop's."""
+    from sfd2_amd import extract_localization as el
+    model = _model(synth_sd, "f16c")
+    items = [{"name": f"m/{i:02d}.png", "image": (synth.make_image(96, 128, 500 + i).transpose(1, 2, 0) * 255).astype(np.uint8), "original_size": (128, 96)}
+             for i in range(10)]
+    name, conf = next(iter(el.confs.items()))
+    conf = {**conf, "model": {**conf["model"], "max_keypoints": 120}}
+    me = (model, el.extract_resnet_return)
+    model.context.set_option("comp_heads", 1)
+    a = el.main(conf, items, tmp_path / "s1", model_and_extractor=me, num_workers=0)
+    b = el.main(conf, items, tmp_path / "p1", model_and_extractor=me, num_workers=2, lanes=2)      # the replica is made here, with the option
+    _stores_equal(b, a)
+    assert model.lanes(2)[1].context.options.get("comp_heads") == 1
+    model.context.set_option("comp_heads", 0)                                                            # ... and changed after it exists
+    c = el.main(conf, items, tmp_path / "s0", model_and_extractor=me, num_workers=0)
+    d = el.main(conf, items, tmp_path / "p0", model_and_extractor=me, num_workers=2, lanes=2)
+    _stores_equal(d, c)
+    fa, fc = fio_open(a), fio_open(c)
+    assert not np.array_equal(fa["m/00.png"]["descriptors"].__array__(), fc["m/00.png"]["descriptors"].__array__())   # (the option does change descriptors)
+
+
+def fio_open(path):
+    from sfd2_amd import feature_io as fio
+    return fio.open_store(path, "r")
