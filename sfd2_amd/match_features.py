@@ -116,14 +116,17 @@ def _match_grouped(model, feats, store, pairs, rank, world, done, device=0, max_
         ring.event.synchronize()
         m16, s16 = cast_for_storage(m, s)          # the whole [k, n0] block at once: int16 / fp16 as stored (:114,118)
         free.put(ring)
-        for i, (idx, name1) in enumerate(members):
-            pair = names_to_pair(name0, name1)
-            if hasattr(store, "write_group"):
-                store.write_group(pair, {"matches0": m16[i], "matching_scores0": s16[i]})
-            else:
-                write_matches(store, pair, m16[i], s16[i])
-            with lock:
-                done.append((idx, pair))
+        pairs = [names_to_pair(name0, name1) for _, name1 in members]
+        if hasattr(store, "write_rows"):
+            store.write_rows(pairs, {"matches0": m16[:len(pairs)], "matching_scores0": s16[:len(pairs)]})      # the query's pair groups as ONE append
+        else:
+            for i, pair in enumerate(pairs):
+                if hasattr(store, "write_group"):
+                    store.write_group(pair, {"matches0": m16[i], "matching_scores0": s16[i]})
+                else:
+                    write_matches(store, pair, m16[i], s16[i])
+        with lock:
+            done.extend((idx, pair) for (idx, _), pair in zip(members, pairs))
 
     wp = WriterPool(write, workers=1, maxsize=2, name="sfd2-match-writer")
     try:

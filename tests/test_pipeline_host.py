@@ -244,3 +244,31 @@ def test_decoder_rgbx_paste_equals_repacked_pixels(tmp_path):
         np.testing.assert_array_equal(got[:, :, :3], want)
         assert got.base is not None and np.shares_memory(got, store["b"])          # the pixels are in the caller's buffer
     assert el._RGBX_OK in (True, False)
+
+
+def test_packstore_write_rows_equals_single_appends(tmp_path):
+    """PackStore.write_rows (a query's pair groups as ONE append) against write_group per pair: the same groups, dtypes, shapes and bytes; rows whose
+    size is not a multiple of 64 bytes take the per-row path; existing / duplicate names are refused before anything is written."""
+    from sfd2_amd import feature_io as fio
+    rs = np.random.RandomState(5)
+    for n in (4096, 100):                  # 8 KB rows (aligned) / 200-byte rows (not)
+        m = rs.randint(-1, n, (7, n)).astype(np.int16); s = rs.rand(7, n).astype(np.float16)
+        a = fio.open_store(str(tmp_path / f"a{n}.h5"), "w"); b = fio.open_store(str(tmp_path / f"b{n}.h5"), "w")
+        names = [f"q_d{i}" for i in range(7)]
+        a.write_rows(names, {"matches0": m, "matching_scores0": s})
+        for i, nm in enumerate(names):
+            b.write_group(nm, {"matches0": m[i], "matching_scores0": s[i]})
+        with pytest.raises(ValueError):
+            a.write_rows(["q_d3", "new"], {"matches0": m[:2], "matching_scores0": s[:2]})
+        if n == 4096:
+            with pytest.raises(ValueError):
+                a.write_rows(["x", "x"], {"matches0": m[:2], "matching_scores0": s[:2]})
+        assert "new" not in a and "x" not in a
+        a.close(); b.close()
+        ra, rb = fio.open_store(a.path, "r"), fio.open_store(b.path, "r")
+        assert list(ra.keys()) == list(rb.keys()) == names
+        for nm in names:
+            for k in ("matches0", "matching_scores0"):
+                x, y = ra[nm][k], rb[nm][k]
+                assert x.dtype == y.dtype and x.shape == y.shape
+                np.testing.assert_array_equal(x[()], y[()])
