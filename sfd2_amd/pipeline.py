@@ -268,6 +268,23 @@ class WriterPool:
 
 
 # ----------------------------------------------------------------------------------------------- match
+class _PinnedStage:
+    """One pinned host buffer of the descriptor reads + the event behind its last asynchronous use."""
+
+    def __init__(self, torch):
+        self._torch, self.t, self.np = torch, None, None
+        self.event, self.busy = torch.cuda.Event(), False
+
+    def reserve(self, nbytes):
+        if self.busy:
+            self.event.synchronize()
+            self.busy = False
+        if self.t is None or self.t.numel() < nbytes:
+            self.t = self._torch.empty(int(max(nbytes, 1)), dtype=self._torch.uint8, pin_memory=True)
+            self.np = self.t.numpy()
+        return self.np[:nbytes]
+
+
 class ResidentSets:
     """Descriptor sets of a feature store as fp16 [n][128] in HBM, least recently used evicted.  `budget` bytes
     (default: 60 % of the device memory free at construction).  get(name) -> (device pointer, n); a set is converted
@@ -290,12 +307,26 @@ class ResidentSets:
         self._rlock = None if safe else threading.Lock()
         self.loads = self.hits = self.evictions = 0
         self.completed_seq = -1                     # last query whose device work is known to be finished
+        # pinned staging for the reads: a set read into pageable memory cost its query ~0.4 ms of synchronous upload (4 MB of float64) on the
+        # driver's thread; read into a pinned buffer by the reader thread, the conversion kernel's upload is asynchronous.  A buffer is reused once
+        # the event recorded behind its conversion has passed.
+        self._stage_free = queue.Queue()
+        for _ in range(max(1, readers) + 12):
+            self._stage_free.put(_PinnedStage(torch))
+        self._stream = torch.cuda.ExternalStream(ctx.stream, device=self.device)
 
     def _read(self, name):
         if self._rlock is not None:
             with self._rlock:
-                return np.ascontiguousarray(self.feats[name]['descriptors'].__array__())
-        return np.ascontiguousarray(self.feats[name]['descriptors'].__array__())
+                src = self.feats[name]['descriptors'].__array__()
+        else:
+            src = self.feats[name]['descriptors'].__array__()
+        if src.dtype not in (np.float64, np.float32, np.float16) or src.ndim != 2:
+            return np.ascontiguousarray(src), None
+        st = self._stage_free.get()
+        dst = st.reserve(src.nbytes).view(src.dtype).reshape(src.shape)       # (waits for the buffer's previous conversion)
+        np.copyto(dst, src)
+        return dst, st
 
     def prefetch(self, names):
         for name in names:
@@ -311,19 +342,27 @@ class ResidentSets:
             self.hits += 1
             return ent[0].data_ptr(), ent[1]
         fut = self._pending.pop(name, None)
-        d = fut.result() if fut is not None else self._read(name)
+        d, stage = fut.result() if fut is not None else self._read(name)
         if d.ndim != 2:
             raise ValueError(f"descriptors of {name!r}: expected [dim, n]")
         dim, n = d.shape
         dt = {np.dtype(np.float64): _lib.DT_F64, np.dtype(np.float32): _lib.DT_F32, np.dtype(np.float16): _lib.DT_F16}.get(d.dtype)
         if dt is None:
             d, dt = d.astype(np.float32), _lib.DT_F32
+            if stage is not None:
+                self._stage_free.put(stage)
+                stage = None
         nbytes = max(n, 1) * 128 * 2
         self._make_room(nbytes, seq)
         t = self.torch.empty(max(n, 1) * 128, dtype=self.torch.float16, device=self.device)
         src = _lib.DescSet(d.ctypes.data, n, dt, _lib.LAYOUT_DN, 0, None, 0, 0)
-        # synchronous: `d` is a temporary; ~0.1 ms of device time, off the steady state (every set is packed once)
-        _lib.check(self.ctx.lib.sfd2_desc_pack(self.ctx.h, ctypes.byref(src), dim, t.data_ptr(), 0))
+        if stage is not None:       # pinned source: the upload rides on the stream; the buffer goes back behind an event
+            _lib.check(self.ctx.lib.sfd2_desc_pack(self.ctx.h, ctypes.byref(src), dim, t.data_ptr(), _lib.FLAG_ASYNC))
+            stage.event.record(self._stream)
+            stage.busy = True
+            self._stage_free.put(stage)
+        else:                       # synchronous: `d` is a temporary
+            _lib.check(self.ctx.lib.sfd2_desc_pack(self.ctx.h, ctypes.byref(src), dim, t.data_ptr(), 0))
         self._sets[name] = (t, n, seq)
         self.used += nbytes
         self.loads += 1
