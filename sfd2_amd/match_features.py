@@ -131,7 +131,8 @@ def _match_grouped(model, feats, store, pairs, rank, world, done, device=0, max_
     wp = WriterPool(write, workers=1, maxsize=2, name="sfd2-match-writer")
     try:
         for u, (name0, members) in enumerate(units):
-            for name0_next, members_next in units[u:u + 1 + lookahead]:
+            # reads of the units ahead: the whole window once, then only the unit that enters it (a set evicted in between is read again by get())
+            for name0_next, members_next in (units[:1 + lookahead] if u == 0 else units[u + lookahead:u + lookahead + 1]):
                 sets.prefetch([name0_next] + [n1 for _, n1 in members_next])
             q_ptr, n0 = sets.get(name0, u)
             k = len(members)

@@ -315,7 +315,7 @@ class ResidentSets:
             self._stage_free.put(_PinnedStage(torch))
         self._stream = torch.cuda.ExternalStream(ctx.stream, device=self.device)
 
-    def _read(self, name):
+    def _read(self, name, wait_for_stage=True):
         if self._rlock is not None:
             with self._rlock:
                 src = self.feats[name]['descriptors'].__array__()
@@ -323,7 +323,13 @@ class ResidentSets:
             src = self.feats[name]['descriptors'].__array__()
         if src.dtype not in (np.float64, np.float32, np.float16) or src.ndim != 2:
             return np.ascontiguousarray(src), None
-        st = self._stage_free.get()
+        if wait_for_stage:
+            st = self._stage_free.get()
+        else:                                   # the driver's own thread (a set that was not prefetched): it is the one that gives stages back
+            try:
+                st = self._stage_free.get_nowait()
+            except queue.Empty:
+                return np.ascontiguousarray(src), None
         dst = st.reserve(src.nbytes).view(src.dtype).reshape(src.shape)       # (waits for the buffer's previous conversion)
         np.copyto(dst, src)
         return dst, st
@@ -342,7 +348,7 @@ class ResidentSets:
             self.hits += 1
             return ent[0].data_ptr(), ent[1]
         fut = self._pending.pop(name, None)
-        d, stage = fut.result() if fut is not None else self._read(name)
+        d, stage = fut.result() if fut is not None else self._read(name, wait_for_stage=False)
         if d.ndim != 2:
             raise ValueError(f"descriptors of {name!r}: expected [dim, n]")
         dim, n = d.shape
