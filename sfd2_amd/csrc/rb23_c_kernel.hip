@@ -341,6 +341,11 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
             int sw = lrow;
             asm volatile("" : "+v"(sw));   // (the 16 fragment addresses: per row, not hoisted)
             const unsigned char *xp = T2 + (r4 * 32 + sw) * 512;
+            // -DSFD2_RB23_PRIO (round 5 experiment): priority 1 for a row's MFMA burst -- the rows have no barriers between them, so the two waves of a SIMD could
+            // drift half a row apart (one in its MFMAs, one in its epilogue) as the matcher's do with the same switch
+#ifdef SFD2_RB23_PRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
             if constexpr (L8) {
                 typedef short s2v_t __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -364,6 +369,9 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
                     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al[j], vb, acc, 0, 0, 0, sa3, 0, 0x7f7f7f7f);
                 }
                 asm volatile("" : "+v"(acc));
+#ifdef SFD2_RB23_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             } else
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
