@@ -35,6 +35,9 @@ typedef struct sfd2_ctx sfd2_ctx;
 #define SFD2_FLAG_IMG_U8_HWC 8     /* sfd2_extract: img is uint8 [H][W][3]; the device does the
                                     * astype(float32) / 255. of extract_localization.py:168,186 */
 #define SFD2_FLAG_IMG_BGR 16       /* with IMG_U8_HWC: channel order is cv2's BGR (:162-165)    */
+#define SFD2_FLAG_MATCH_OUT16 64    /* sfd2_match_batch: matches0 is int16 [k][n], scores0 IEEE half [k][n] -- the types the reference STORES (.short() /
+                                    * .half(): hloc/match_features.py:114,118), converted on the device: a third of the bytes to the host and no
+                                    * host-side cast of the [k][n] blocks in the batch driver's writer */
 #define SFD2_FLAG_IMG_U8_X 32      /* with IMG_U8_HWC (sfd2_extract, sfd2_preprocess): pixels are FOUR bytes, the fourth ignored
                                     * (RGBX / BGRX: the in-memory layout of PIL's RGB images, which a decoder thread can hand
                                     * over without the interpreter-locked repacking to three bytes); unpacked on the device */

@@ -90,6 +90,8 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     if (!q->data) return fail("sfd2_match_batch: null query descriptors");
     HIPCHECK(hipSetDevice(c->device));
     const int need_lo = conf->sim_mode == SFD2_SIM_F16X2;
+    const bool o16 = (flags & SFD2_FLAG_MATCH_OUT16) != 0;       // outputs as int16 / fp16 (converted by match_decide_kernel)
+    const size_t msz = o16 ? sizeof(short) : sizeof(long long), ssz = o16 ? sizeof(half_t) : sizeof(float);
     int max_n1 = 0;
     size_t tot_n1 = 0, stage_bytes = 0;
     if (q->rows) return fail("sfd2_match_batch: row selection applies to database sets only");
@@ -217,9 +219,10 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
         }
         off1 += (size_t)n1;
         fn.n0 = n0; fn.n1 = n1;
+        fn.out16 = o16 ? 1 : 0; fn.pad_ = 0;
         const bool direct_out = out_on_device && matches0 && scores0;
-        fn.matches0 = (direct_out ? reinterpret_cast<long long *>(matches0) : c->m_out_m.as<long long>()) + (size_t)i * n0;
-        fn.scores0 = (direct_out ? scores0 : c->m_out_s.as<float>()) + (size_t)i * n0;
+        fn.matches0 = reinterpret_cast<long long *>((direct_out ? reinterpret_cast<char *>(matches0) : c->m_out_m.as<char>()) + (size_t)i * n0 * msz);
+        fn.scores0 = reinterpret_cast<float *>((direct_out ? reinterpret_cast<char *>(scores0) : c->m_out_s.as<char>()) + (size_t)i * n0 * ssz);
         fn.red_f = red + 3 * roff; roff += (size_t)n0;
         fn.red_r = red + 3 * roff; roff += (size_t)n1;
     }
@@ -257,8 +260,8 @@ extern "C" int sfd2_match_batch(sfd2_ctx *c, const sfd2_desc_set *q, const sfd2_
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventRecord(c->ev[3], c->stream));
     if (!(out_on_device && matches0 && scores0)) {
-        if (copy_out(c, matches0, c->m_out_m.p, (size_t)k * n0 * sizeof(long long), out_on_device)) return -1;
-        if (copy_out(c, scores0, c->m_out_s.p, (size_t)k * n0 * sizeof(float), out_on_device)) return -1;
+        if (copy_out(c, matches0, c->m_out_m.p, (size_t)k * n0 * msz, out_on_device)) return -1;
+        if (copy_out(c, scores0, c->m_out_s.p, (size_t)k * n0 * ssz, out_on_device)) return -1;
     }
     if (!(flags & SFD2_FLAG_ASYNC)) {
         HIPCHECK(hipStreamSynchronize(c->stream));
@@ -355,6 +358,7 @@ extern "C" int sfd2_match_segments(sfd2_ctx *c, const void *d0, int n0, const vo
         for (int j = 0; j < k; ++j) {
             const int sg = live[j], a0 = seg0[sg], na = seg0[sg + 1] - a0, b0 = seg1[sg], nb = seg1[sg + 1] - b0;
             MatchFinal &fn = fins[j];
+            fn.out16 = 0; fn.pad_ = 0;
             fn.remap = iota_dev + b0;
             if (single_gemm) {
                 MatchJob2 &j2 = jobs2[j];

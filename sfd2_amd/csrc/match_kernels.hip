@@ -526,8 +526,14 @@ void match_decide_kernel(const MatchFinal *__restrict__ fins, int flavour, int m
             m = ok ? j : -1;
         }
     }
-    f.matches0[i] = (m >= 0 && f.remap) ? (long long)f.remap[m] : m;   // back to unmasked indexing (localize_cv2.py:557-559)
-    f.scores0[i] = score;
+    const long long mm = (m >= 0 && f.remap) ? (long long)f.remap[m] : m;   // back to unmasked indexing (localize_cv2.py:557-559)
+    if (f.out16) {      // the casts of hloc/match_features.py:114,118 on the device: .short() (wraps) and .half() (round to nearest even)
+        reinterpret_cast<short *>(f.matches0)[i] = (short)mm;
+        reinterpret_cast<half_t *>(f.scores0)[i] = (half_t)score;
+    } else {
+        f.matches0[i] = mm;
+        f.scores0[i] = score;
+    }
 }
 
 void launch_match_decide(hipStream_t st, const MatchFinal *fin_dev, int npairs, int max_n, int flavour, int mutual,

@@ -619,6 +619,7 @@ struct MatchFinal {
     const float *f_v1, *f_v2; const int *f_i1;   // forward partials [splits][n0]
     const float *r_v1, *r_v2; const int *r_i1;   // reverse partials [splits][n1]
     int n0, n1;
+    int out16, pad_;                             // SFD2_FLAG_MATCH_OUT16: matches0 / scores0 point to int16 / fp16 arrays (the stored types of hloc/match_features.py:114,118)
     long long *matches0; float *scores0;
     float *red_f;  // scratch [3*n0]
     float *red_r;  // scratch [3*n1]

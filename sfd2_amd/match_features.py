@@ -100,9 +100,10 @@ def _match_grouped(model, feats, store, pairs, rank, world, done, device=0, max_
             self.event = torch.cuda.Event()
 
         def reserve(self, k, n0):
+            # int16 / fp16: the stored types, written by the matcher itself (SFD2_FLAG_MATCH_OUT16)
             if self.m is None or self.m.numel() < k * n0:
-                self.m = torch.empty(max(k * n0, 1), dtype=torch.int64, pin_memory=True)
-                self.s = torch.empty(max(k * n0, 1), dtype=torch.float32, pin_memory=True)
+                self.m = torch.empty(max(k * n0, 1), dtype=torch.int16, pin_memory=True)
+                self.s = torch.empty(max(k * n0, 1), dtype=torch.float16, pin_memory=True)
             return self.m.numpy()[:k * n0].reshape(k, n0), self.s.numpy()[:k * n0].reshape(k, n0)
 
     import queue
@@ -114,8 +115,7 @@ def _match_grouped(model, feats, store, pairs, rank, world, done, device=0, max_
     def write(job):
         ring, m, s, name0, members = job
         ring.event.synchronize()
-        m16, s16 = cast_for_storage(m, s)          # the whole [k, n0] block at once: int16 / fp16 as stored (:114,118)
-        free.put(ring)
+        m16, s16 = m, s                            # already int16 / fp16 as stored (:114,118): the device did the casts
         pairs = [names_to_pair(name0, name1) for _, name1 in members]
         if hasattr(store, "write_rows"):
             store.write_rows(pairs, {"matches0": m16[:len(pairs)], "matching_scores0": s16[:len(pairs)]})      # the query's pair groups as ONE append
@@ -125,6 +125,7 @@ def _match_grouped(model, feats, store, pairs, rank, world, done, device=0, max_
                     store.write_group(pair, {"matches0": m16[i], "matching_scores0": s16[i]})
                 else:
                     write_matches(store, pair, m16[i], s16[i])
+        free.put(ring)                             # (the store has copied the rows: the pinned buffers may be overwritten)
         with lock:
             done.extend((idx, pair) for (idx, _), pair in zip(members, pairs))
 
@@ -147,7 +148,7 @@ def _match_grouped(model, feats, store, pairs, rank, world, done, device=0, max_
                 pass                                 # nothing to match: empty rows, as the per-pair call returns
             else:
                 _lib.check(ctx.lib.sfd2_match_batch(ctx.h, ctypes.byref(q), db, k, 128, ctypes.byref(conf), m.ctypes.data,
-                                                    s.ctypes.data, 0, _lib.FLAG_ASYNC))
+                                                    s.ctypes.data, 0, _lib.FLAG_ASYNC | _lib.FLAG_MATCH_OUT16))
             ring.event.record(stream)
             wp.put((ring, m, s, name0, members))
             sets.completed_seq = u - 3               # three rings: a unit's buffers are reused only after its event was awaited

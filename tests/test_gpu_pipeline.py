@@ -495,3 +495,35 @@ def test_replica_lanes_carry_the_options_of_the_model(tmp_path, synth_sd):
 def fio_open(path):
     from sfd2_amd import feature_io as fio
     return fio.open_store(path, "r")
+
+
+@pytest.mark.parametrize("flavour,mutual,ratio", [(0, 1, 0.0), (0, 0, 0.0), (0, 1, 0.9), (2, 1, 0.95)])
+def test_match_batch_out16_equals_the_host_casts(flavour, mutual, ratio):
+    """SFD2_FLAG_MATCH_OUT16: the matcher writes matches0 as int16 and scores0 as fp16 itself -- bit for bit what hloc/match_features.py:114,118's
+    .short() / .half() make of the int64 / fp32 outputs (host and device outputs, a database set given by row selection)."""
+    import torch
+    ctx = _lib.default_context(0)
+    rs = np.random.RandomState(7)
+    def unit(n):
+        d = rs.standard_normal((n, 128)).astype(np.float32)
+        return d / np.linalg.norm(d, axis=1, keepdims=True)
+    q = unit(700)
+    dbs = [unit(n) for n in (512, 700, 33)]
+    dbs[1][:50] = q[100:150] + 0.01 * rs.standard_normal((50, 128)).astype(np.float32)      # some real matches
+    rows = np.arange(0, 700, 2, dtype=np.int32)
+    qd = _lib.DescSet(q.ctypes.data, 700, _lib.DT_F32, _lib.LAYOUT_ND, 0, None, 0, 0)
+    arr = (_lib.DescSet * 3)(_lib.DescSet(dbs[0].ctypes.data, 512, _lib.DT_F32, _lib.LAYOUT_ND, 0, None, 0, 0),
+                             _lib.DescSet(dbs[1].ctypes.data, 700, _lib.DT_F32, _lib.LAYOUT_ND, 0, rows.ctypes.data, len(rows), 0),
+                             _lib.DescSet(dbs[2].ctypes.data, 33, _lib.DT_F32, _lib.LAYOUT_ND, 0, None, 0, 0))
+    conf = _lib.MatchConf(flavour, mutual, ratio, 0.0, _lib.SIM_F16)
+    m64 = np.empty((3, 700), np.int64); s32 = np.empty((3, 700), np.float32)
+    _lib.check(ctx.lib.sfd2_match_batch(ctx.h, ctypes.byref(qd), arr, 3, 128, ctypes.byref(conf), m64.ctypes.data, s32.ctypes.data, 0, 0))
+    m16 = np.empty((3, 700), np.int16); s16 = np.empty((3, 700), np.float16)
+    _lib.check(ctx.lib.sfd2_match_batch(ctx.h, ctypes.byref(qd), arr, 3, 128, ctypes.byref(conf), m16.ctypes.data, s16.ctypes.data, 0, _lib.FLAG_MATCH_OUT16))
+    np.testing.assert_array_equal(m16, m64.astype(np.int16))
+    np.testing.assert_array_equal(s16.view(np.uint16), s32.astype(np.float16).view(np.uint16))
+    assert (m64 >= 0).sum() > 20
+    md = torch.empty((3, 700), dtype=torch.int16, device="cuda"); sd = torch.empty((3, 700), dtype=torch.float16, device="cuda")
+    _lib.check(ctx.lib.sfd2_match_batch(ctx.h, ctypes.byref(qd), arr, 3, 128, ctypes.byref(conf), md.data_ptr(), sd.data_ptr(), 1, _lib.FLAG_MATCH_OUT16))
+    np.testing.assert_array_equal(md.cpu().numpy(), m16)
+    np.testing.assert_array_equal(sd.cpu().numpy().view(np.uint16), s16.view(np.uint16))
