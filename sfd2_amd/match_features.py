@@ -130,6 +130,7 @@ def _match_grouped(model, feats, store, pairs, rank, world, done, device=0, max_
             done.extend((idx, pair) for (idx, _), pair in zip(members, pairs))
 
     wp = WriterPool(write, workers=1, maxsize=2, name="sfd2-match-writer")
+    db_arrays = {}
     try:
         for u, (name0, members) in enumerate(units):
             # reads of the units ahead: the whole window once, then only the unit that enters it (a set evicted in between is read again by get())
@@ -137,10 +138,13 @@ def _match_grouped(model, feats, store, pairs, rank, world, done, device=0, max_
                 sets.prefetch([name0_next] + [n1 for _, n1 in members_next])
             q_ptr, n0 = sets.get(name0, u)
             k = len(members)
-            db = (_lib.DescSet * k)()
+            db = db_arrays.get(k)             # (the library reads the array during the call: reusable afterwards)
+            if db is None:
+                db = db_arrays[k] = (_lib.DescSet * k)(*[_lib.DescSet(None, 0, _lib.DT_F16, _lib.LAYOUT_ND, 1, None, 0, 0) for _ in range(k)])
+            get = sets.get
             for i, (_, name1) in enumerate(members):
-                p1, n1 = sets.get(name1, u)
-                db[i] = _lib.DescSet(p1, n1, _lib.DT_F16, _lib.LAYOUT_ND, 1, None, 0, 0)
+                e = db[i]
+                e.data, e.n = get(name1, u)
             q = _lib.DescSet(q_ptr, n0, _lib.DT_F16, _lib.LAYOUT_ND, 1, None, 0, 0)
             ring = free.get()
             m, s = ring.reserve(k, n0)

@@ -342,11 +342,11 @@ class ResidentSets:
     def get(self, name, seq):
         """seq: number of the query group being assembled (sets it uses are not evicted while it is)."""
         ent = self._sets.get(name)
-        if ent is not None:
+        if ent is not None:                 # (the hit path runs ~50 times per query group on the driver's thread: no tensor calls, no tuple rebuild)
             self._sets.move_to_end(name)
-            self._sets[name] = (ent[0], ent[1], seq)
+            ent[2] = seq
             self.hits += 1
-            return ent[0].data_ptr(), ent[1]
+            return ent[3], ent[1]
         fut = self._pending.pop(name, None)
         d, stage = fut.result() if fut is not None else self._read(name, wait_for_stage=False)
         if d.ndim != 2:
@@ -369,10 +369,10 @@ class ResidentSets:
             self._stage_free.put(stage)
         else:                       # synchronous: `d` is a temporary
             _lib.check(self.ctx.lib.sfd2_desc_pack(self.ctx.h, ctypes.byref(src), dim, t.data_ptr(), 0))
-        self._sets[name] = (t, n, seq)
+        self._sets[name] = [t, n, seq, t.data_ptr()]
         self.used += nbytes
         self.loads += 1
-        return t.data_ptr(), n
+        return self._sets[name][3], n
 
     def _make_room(self, nbytes, cur_seq):
         synced = False
@@ -380,7 +380,7 @@ class ResidentSets:
             victim = next((k for k, v in self._sets.items() if v[2] != cur_seq), None)   # oldest first; never the group in assembly
             if victim is None:
                 return                      # one group needs more than the budget: over it for this group
-            t, n, seq = self._sets[victim]
+            t, n, seq, _ = self._sets[victim]
             if seq > self.completed_seq and not synced:
                 self.ctx.sync()             # the victim may still be read by a queued batch
                 synced = True
