@@ -311,11 +311,11 @@ class ResidentSets:
         # driver's thread; read into a pinned buffer by the reader thread, the conversion kernel's upload is asynchronous.  A buffer is reused once
         # the event recorded behind its conversion has passed.
         self._stage_free = queue.Queue()
-        for _ in range(max(1, readers) + 12):
+        for _ in range(max(64, 4 * max(1, readers))):       # (buffers are allocated on first use: a driver that keeps few reads pending touches few)
             self._stage_free.put(_PinnedStage(torch))
         self._stream = torch.cuda.ExternalStream(ctx.stream, device=self.device)
 
-    def _read(self, name, wait_for_stage=True):
+    def _read(self, name):
         if self._rlock is not None:
             with self._rlock:
                 src = self.feats[name]['descriptors'].__array__()
@@ -323,13 +323,12 @@ class ResidentSets:
             src = self.feats[name]['descriptors'].__array__()
         if src.dtype not in (np.float64, np.float32, np.float16) or src.ndim != 2:
             return np.ascontiguousarray(src), None
-        if wait_for_stage:
-            st = self._stage_free.get()
-        else:                                   # the driver's own thread (a set that was not prefetched): it is the one that gives stages back
-            try:
-                st = self._stage_free.get_nowait()
-            except queue.Empty:
-                return np.ascontiguousarray(src), None
+        # never WAIT for a stage: the driver's thread is the one that gives stages back, and it may be waiting for this very read (a caller is free to
+        # prefetch in one order and consume in another).  With none free the set goes through pageable memory (a synchronous upload: slower, never stuck).
+        try:
+            st = self._stage_free.get_nowait()
+        except queue.Empty:
+            return np.ascontiguousarray(src), None
         dst = st.reserve(src.nbytes).view(src.dtype).reshape(src.shape)       # (waits for the buffer's previous conversion)
         np.copyto(dst, src)
         return dst, st
@@ -348,7 +347,7 @@ class ResidentSets:
             self.hits += 1
             return ent[3], ent[1]
         fut = self._pending.pop(name, None)
-        d, stage = fut.result() if fut is not None else self._read(name, wait_for_stage=False)
+        d, stage = fut.result() if fut is not None else self._read(name)
         if d.ndim != 2:
             raise ValueError(f"descriptors of {name!r}: expected [dim, n]")
         dim, n = d.shape

@@ -527,3 +527,31 @@ def test_match_batch_out16_equals_the_host_casts(flavour, mutual, ratio):
     _lib.check(ctx.lib.sfd2_match_batch(ctx.h, ctypes.byref(qd), arr, 3, 128, ctypes.byref(conf), md.data_ptr(), sd.data_ptr(), 1, _lib.FLAG_MATCH_OUT16))
     np.testing.assert_array_equal(md.cpu().numpy(), m16)
     np.testing.assert_array_equal(sd.cpu().numpy().view(np.uint16), s16.view(np.uint16))
+
+
+def test_resident_sets_prefetch_order_is_free(tmp_path):
+    """ResidentSets with far more reads pending than pinned staging buffers, consumed in the REVERSE of the prefetch order: every set arrives
+    (a read that finds no staging buffer goes through pageable memory; nothing waits for a buffer only the consumer can give back)."""
+    import torch
+    from sfd2_amd import feature_io as fio
+    from sfd2_amd.pipeline import ResidentSets
+    rs = np.random.RandomState(11)
+    st = fio.open_store(str(tmp_path / "f.h5"), "w")
+    names = [f"db/{i:03d}.jpg" for i in range(150)]
+    ref = {}
+    for nm in names:
+        d = rs.standard_normal((128, 40)).astype(np.float64)
+        ref[nm] = d
+        st.write_group(nm, {"descriptors": d})
+    st.close()
+    feats = fio.open_store(st.path, "r")
+    sets = ResidentSets(_lib.default_context(0), feats, readers=4)
+    sets.prefetch(names)
+    for nm in reversed(names):
+        p, n = sets.get(nm, 0)
+        assert n == 40 and p != 0
+    _lib.default_context(0).sync()
+    got = sets._sets[names[7]][0].cpu().numpy().reshape(40, 128)
+    np.testing.assert_allclose(got.astype(np.float32), ref[names[7]].T.astype(np.float32), rtol=1e-3, atol=1e-6)      # (fp16 of the stored float64 set)
+    assert sets.loads == 150
+    sets.close()
