@@ -342,6 +342,7 @@ extern "C" int sfd2_extract_multiscale(sfd2_ctx *c, const void *img, int img_on_
     const int u8 = (flags & SFD2_FLAG_IMG_U8_HWC) ? 1 : 0;
     if (u8 && (flags & SFD2_FLAG_IMG_NORMALISED)) return fail("sfd2_extract_multiscale: a uint8 image cannot be pre-normalised");
     if ((flags & SFD2_FLAG_IMG_BGR) && !u8) return fail("sfd2_extract_multiscale: SFD2_FLAG_IMG_BGR needs SFD2_FLAG_IMG_U8_HWC");
+    if (flags & SFD2_FLAG_IMG_U8_X) return fail("sfd2_extract_multiscale: SFD2_FLAG_IMG_U8_X is taken by sfd2_extract and sfd2_preprocess only");
     const int in_mode = ((flags & SFD2_FLAG_IMG_NORMALISED) ? 0 : 1) | (u8 ? 2 : 0) | ((flags & SFD2_FLAG_IMG_BGR) ? 4 : 0);
     int nh[8], nw[8], cap[8], off[8];
     int cap_total = 0;

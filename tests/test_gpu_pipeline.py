@@ -465,8 +465,13 @@ def test_rgbx_pixels_equal_rgb_pixels(synth_sd, h, w):
     _lib.check(ctx.lib.sfd2_preprocess(ctx.h, rgb.ctypes.data, 0, h, w, 0, nh, nw, o3.data_ptr()))
     _lib.check(ctx.lib.sfd2_preprocess(ctx.h, rgbx.ctypes.data, 0, h, w, _lib.FLAG_IMG_U8_X, nh, nw, o4.data_ptr()))
     assert torch.equal(o3, o4)
-    # a float image cannot carry the flag
+    # a float image cannot carry the flag, and the pyramid entry point does not take four-byte pixels
     assert ctx.lib.sfd2_extract(ctx.h, rgbx.ctypes.data, 0, h, w, 0.001, K, _lib.FLAG_IMG_U8_X, None, None, None, 0, K, None) != 0
+    sc = (ctypes.c_double * 1)(1.0)
+    kp = np.zeros((K, 2), np.float32); scr = np.zeros((K,), np.float32)
+    rc = ctx.lib.sfd2_extract_multiscale(ctx.h, rgbx.ctypes.data, 0, h, w, sc, 1, ctypes.c_float(0.001), K, _lib.FLAG_IMG_U8_HWC | _lib.FLAG_IMG_U8_X,
+                                         kp.ctypes.data, scr.ctypes.data, None, 0, K, None)
+    assert rc != 0 and b"SFD2_FLAG_IMG_U8_X" in ctx.lib.sfd2_last_error()
 
 
 def test_replica_lanes_carry_the_options_of_the_model(tmp_path, synth_sd):
