@@ -391,3 +391,55 @@ def merge_parts(export_dir, conf, world):
         for p in parts:
             p.close()
     return actual
+
+
+def _dist_env():
+    """(world, rank, local_rank, barrier) of a `python -m torch.distributed.run --nproc-per-node N -m sfd2_amd....` launch (one process per GPU), or a
+    single process.  The drivers have no data-path collective: the process group (gloo: a barrier is all it carries) only lines the ranks up before rank 0
+    merges their part stores."""
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world <= 1:
+        return 1, 0, local, None
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    return world, rank, local, dist.barrier
+
+
+def cli(argv=None):
+    """The reference script's command line (extract_localization.py:281-291: --image_dir, --image_list, --tag, --mask_dir, --export_dir, --conf) plus what this
+    path adds (--weights overriding the conf's model_fn, --precision, --num_workers, --device).  Under torchrun every rank takes its share of the images on
+    its own GPU (LOCAL_RANK) and rank 0 merges."""
+    import argparse
+    from pathlib import Path
+    ap = argparse.ArgumentParser(description="SFD2 feature extraction on MI355X (drop-in for the reference's extract_localization.py)")
+    ap.add_argument('--image_dir', type=Path, required=True)
+    ap.add_argument('--image_list', type=str, default=None)
+    ap.add_argument('--tag', type=str, default=None)
+    ap.add_argument('--mask_dir', type=Path, default=None, help="accepted for compatibility (the reference passes mask_root=None as well)")
+    ap.add_argument('--export_dir', type=Path, required=True)
+    ap.add_argument('--conf', type=str, default=next(iter(confs)), choices=list(confs.keys()))
+    ap.add_argument('--weights', type=str, default=None, help="checkpoint file (default: the conf's model_fn, " + _W + ")")
+    ap.add_argument('--precision', type=str, default="f16x3", choices=["f32", "f16x3", "f16x3d", "f16c", "f16"])
+    ap.add_argument('--num_workers', type=int, default=4, help="decoder threads (the reference's DataLoader(num_workers=4)); 0 = the serial loop")
+    ap.add_argument('--device', type=int, default=None, help="GPU index (default: LOCAL_RANK modulo the visible GPUs)")
+    args = ap.parse_args(argv)
+    conf = confs[args.conf]
+    if args.weights:
+        conf = {**conf, 'model': {**conf['model'], 'model_fn': args.weights}}
+    world, rank, local, barrier = _dist_env()
+    device = args.device
+    if device is None:
+        import torch
+        device = local % max(1, torch.cuda.device_count())
+    ds = ImageDataset(args.image_dir, conf['preprocessing'], image_list=args.image_list, mask_root=None)
+    path = main(conf, ds, args.export_dir, device=device, tag=args.tag, precision=args.precision, world=world, rank=rank, barrier=barrier,
+                num_workers=args.num_workers)
+    if rank == 0:
+        print(path)
+    return path
+
+
+if __name__ == '__main__':
+    cli()

@@ -241,3 +241,47 @@ def main(conf, pair_list, features, export_dir, pairs_name='pairs', world=1, ran
         for p in parts:
             p.close()
     return actual
+
+
+def cli(argv=None):
+    """The reference script's command line (hloc/match_features.py:129-142: --export_dir, --features, --pairs, --conf, --exhaustive).  --exhaustive writes
+    every unordered pair of the feature store's images to --pairs first (:61-74; image names in sorted order here, where the reference takes them out of a
+    set).  Under torchrun every rank matches its share of the query groups on its own GPU and rank 0 merges."""
+    import argparse
+    from pathlib import Path
+    from .extract_localization import _dist_env
+    from .feature_io import open_store
+    ap = argparse.ArgumentParser(description="SFD2 descriptor matching on MI355X (drop-in for the reference's hloc/match_features.py)")
+    ap.add_argument('--export_dir', type=Path, required=True)
+    ap.add_argument('--features', type=str, default='feats-ressegnetv2-20220810-wapv2-sd2mfsf-uspg-0001-n4096-r1600')
+    ap.add_argument('--pairs', type=Path, required=True)
+    ap.add_argument('--conf', type=str, default='NNM', choices=list(confs.keys()))
+    ap.add_argument('--exhaustive', action='store_true')
+    ap.add_argument('--device', type=int, default=None)
+    args = ap.parse_args(argv)
+    world, rank, local, barrier = _dist_env()
+    device = args.device
+    if device is None:
+        import torch
+        device = local % max(1, torch.cuda.device_count())
+    if args.exhaustive:
+        if rank == 0:
+            assert not args.pairs.exists(), args.pairs
+            feats = open_store(os.path.join(str(args.export_dir), args.features + '.h5'), 'r')
+            images = sorted(feats.keys())
+            feats.close()
+            with open(str(args.pairs), 'w') as f:
+                f.write('\n'.join(' '.join((images[i], images[j])) for i in range(len(images)) for j in range(i)))
+        if barrier is not None:
+            barrier()
+    assert args.pairs.exists(), args.pairs
+    with open(args.pairs, 'r') as f:
+        pair_list = f.read().rstrip('\n').split('\n')
+    path = main(confs[args.conf], pair_list, args.features, args.export_dir, pairs_name=args.pairs.stem, world=world, rank=rank, barrier=barrier, device=device)
+    if rank == 0:
+        print(path)
+    return path
+
+
+if __name__ == '__main__':
+    cli()

@@ -111,3 +111,55 @@ def test_sharded_drivers_two_processes_one_device(tmp_path):
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GPU_DRIVERS_OK" in outs[0]
+
+
+def test_reference_shaped_command_lines_single_and_torchrun(tmp_path):
+    """`python -m sfd2_amd.extract_localization --image_dir .. --export_dir .. --conf ..` and `python -m sfd2_amd.match_features --export_dir .. --features ..
+    --pairs .. --conf NNM` -- the reference scripts' own arguments (extract_localization.py:281-291, hloc/match_features.py:129-142) -- alone and as two
+    ranks under torch.distributed.run sharing the one GPU: the same stores either way, and --exhaustive writes its pairs file."""
+    pytest.importorskip("PIL")
+    import numpy as np
+    import torch
+    from PIL import Image
+    from sfd2_amd import synth, feature_io as fio
+    root = tmp_path / "images"
+    (root / "db").mkdir(parents=True)
+    (root / "query").mkdir(parents=True)
+    for i in range(7):
+        u8 = (synth.make_image(96 + 8 * (i % 3), 128, 700 + i).transpose(1, 2, 0) * 255).astype(np.uint8)
+        Image.fromarray(u8).save(root / ("query" if i < 2 else "db") / f"im{i}.png")
+    ck = tmp_path / "ck.pth"
+    torch.save({"model": {k: torch.from_numpy(v) for k, v in synth.make_state_dict(0).items()}}, ck)
+    conf = "ressegnetv2-20220810-wapv2-sd2mfsf-uspg-0001-n2000-r1024"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    def run(cmd):
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        return r.stdout.decode()
+    tr = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    ex = ["-m", "sfd2_amd.extract_localization", "--image_dir", str(root), "--conf", conf, "--weights", str(ck), "--precision", "f16c", "--num_workers", "2"]
+    out1, out2 = tmp_path / "one", tmp_path / "two"
+    p1 = run([sys.executable] + ex + ["--export_dir", str(out1)]).strip().splitlines()[-1]
+    run(tr + ["--master-port", str(_free_port())] + ex + ["--export_dir", str(out2)])
+    feats = "feats-" + conf
+    def same(a, b):
+        x, y = fio.open_store(str(a), "r"), fio.open_store(str(b), "r")
+        assert list(x.keys()) == list(y.keys()) and len(list(x.keys())) > 0
+        for k in x.keys():
+            for d in x[k].keys():
+                u, v = np.asarray(x[k][d].__array__()), np.asarray(y[k][d].__array__())
+                assert u.dtype == v.dtype and np.array_equal(u, v), (k, d)
+        return list(x.keys())
+    names = same(os.path.join(out1, feats + ".h5"), os.path.join(out2, feats + ".h5"))
+    assert len(names) == 7 and os.path.basename(p1).startswith(feats)
+    pairs = tmp_path / "pairs-q.txt"
+    pairs.write_text("\n".join(f"query/im{q}.png db/im{d}.png" for q in range(2) for d in range(2, 7)))
+    mt = ["-m", "sfd2_amd.match_features", "--features", feats, "--conf", "NNM"]
+    run([sys.executable] + mt + ["--export_dir", str(out1), "--pairs", str(pairs)])
+    run(tr + ["--master-port", str(_free_port())] + mt + ["--export_dir", str(out2), "--pairs", str(pairs)])
+    mname = f"{feats}-NNM-pairs-q.h5"
+    got = same(os.path.join(out1, mname), os.path.join(out2, mname))
+    assert len(got) == 10
+    ex_pairs = tmp_path / "pairs-all.txt"
+    run([sys.executable] + mt + ["--export_dir", str(out1), "--pairs", str(ex_pairs), "--exhaustive"])
+    assert len(ex_pairs.read_text().split("\n")) == 7 * 6 // 2
