@@ -252,7 +252,7 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
             HIPCHECK(c->da3_sparse.ensure((size_t)sel_cap * 4 * 256 * sizeof(half_t)));
             {
                 ProfScope ps(c, "convDa.3", "sparse_da3_kernel", 2.0 * 4 * sel_cap * 256.0 * 256.0 * 9, (double)sel_cap * (16 * 512 + 4 * 512) + 2.0 * 256 * 256 * 9);
-                launch_sparse_da3(c->stream, c->da0_cur, c->H4, c->W4, H, W, c->da3.w.as<half_t>(), c->da3.cout_pad, c->da3.scale.as<float>(),
+                launch_sparse_da3(c->stream, c->da0_cur, c->H4, c->W4, H, W, c->da3.w.as<half_t>(), c->da3.wsl.as<half_t>(), c->da3.cout_pad, c->da3.scale.as<float>(),
                                   c->da3.shift.as<float>(), 0, c->kpts_cur, c->counters.as<unsigned int>() + 1, sel_cap,
                                   c->da3_sparse.as<half_t>(), c->zero_page.as<half_t>());
             }

@@ -569,6 +569,8 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
     if (pack_igemm(c, m, c->pa3, "convPa.3", "", 256, 256, 3, 1)) return -1;
     if (pack_igemm(c, m, c->da0, "convDa.0", "convDa.1", 256, 256, 3, 1)) return -1;
     if (pack_igemm(c, m, c->da3, "convDa.3", "", 256, 256, 3, 1)) return -1;
+    HIPCHECK(c->da3.wsl.ensure((size_t)(256 / 32) * 9 * c->da3.cout_pad * 32 * sizeof(half_t)));     // the same filters in sparse_da3_kernel's fragment order
+    launch_sparse_da3_repack(c->stream, c->da3.w.as<half_t>(), c->da3.wsl.as<half_t>(), c->da3.cout_pad, 256);
     if (pack_igemm(c, m, c->pb, "convPb", "", 256, 65, 1, 1)) return -1;
     if (pack_igemm(c, m, c->db, "convDb", "", 256, 128, 1, 1)) return -1;
     // ConvSta exists only in models built with require_stability=True (nets/sfd2.py:302-303); the reference loads

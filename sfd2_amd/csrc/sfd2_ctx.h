@@ -72,6 +72,7 @@ struct ConvW {                 // one folded + packed layer
     int cin = 0, cout = 0, cout_pad = 0, ks = 0, stride = 1;
     DevBuf w, scale, shift;    // fp16 packed filters, fp32 [cout_pad]
     DevBuf scale_rawin;        // convDa.0: scale for an input at the network's own scale (2^e_out only; option "x3_desc16" feeds it f16x3's hi plane)
+    DevBuf wsl;                // convDa.3: w in sparse_da3_kernel's fragment order -- [chunk][tap][cout_pad / 32][2][64 lanes][8]: a fragment load reads one contiguous kilobyte
     DevBuf wrm;                // 1x1 256 -> 256 layers: the same filters as plain [cout][cin] fp16 (conv1x1_c256_kernel)
     DevBuf wfh, wfc, wfl;      // conv1x1_c256_c_kernel: the same filters, their corr units and fp16 of (w - fp16(w)) * 2^11 (the second
                                // fp16 pass over a PLAIN input, option "rb_inner") in the kernel's fragment order [8 waves][8][64 lanes][16]

@@ -405,9 +405,10 @@ void launch_conv1x1_c256_c(hipStream_t st, const half_t *in, const half_t *in_c,
                            const half_t *res_c, half_t *out, half_t *out_c, const half_t *zero_page, int sbyte, unsigned int *range = nullptr,
                            int in_r1 = 0 /* in_c = residual bytes only (256 B per pixel): option "trunk_r1" */);
 // sparse_da3_kernel.hip: convDa.3 on the four bilinear corner pixels of every selected key point only -> out [n_max][4][256] fp16
-void launch_sparse_da3(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, int CoutP,
+void launch_sparse_da3(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, const half_t *wsl, int CoutP,
                        const float *scale, const float *shift, int relu, const float *kpts, const unsigned int *count, int n_max,
                        half_t *out, const half_t *zero_page);
+void launch_sparse_da3_repack(hipStream_t st, const half_t *w, half_t *dst, int CoutP, int cin);
 void launch_sparse_da3_x3(hipStream_t st, const half_t *fmap_hi, const half_t *fmap_lo, int hc, int wc, int nh, int nw, const half_t *wpk,
                           int CoutP, const float *scale, const float *shift, int relu, const float *kpts, const unsigned int *count,
                           int n_max, float *out, const half_t *zero_page);

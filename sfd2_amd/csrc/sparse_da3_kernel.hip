@@ -8,7 +8,10 @@
 //   block   16 key points (64 output pixels = two 32-pixel MFMA tiles) x 128 output channels (grid.y = 2); 4 waves, a wave owns
 //           32 channels; up to four blocks per CU, which is what hides the gather round trips
 //   K loop  four 64-channel chunks: the 16 patches' records (16 x 16 pixels x 128 B = 32 KB) are copied global -> LDS
-//           (a record's eight 16-byte parts at slot part ^ (record & 7): conflict-free fragment reads without padding), then
+//           (a record's eight 16-byte parts at slot part ^ (record & 7) ^ (key point & 3): ds_read_b128 serves a wave in four groups of sixteen
+//           lanes = four key points x four corners, whose sixteen 16-byte slots must differ across the 256-byte bank row -- the corners differ through
+//           the record term, the group's key points {0, 3, 5, 6} / {1, 2, 4, 7} through theirs; without the second term every read was four-way
+//           conflicted: SQ_LDS_BANK_CONFLICT 73 % of SQ_LDS_IDX_ACTIVE, profiles/r05s_pmc_summary.txt), then
 //           9 taps x 4 K-slices of v_mfma_f32_32x32x16_f16 per tile, filter fragments straight from the packed filters in L2
 //   output  compact [key point][corner][256] fp16 = what desc_head_kernel gathers from the dense map otherwise
 //
@@ -18,6 +21,15 @@
 
 #define SD_KP 16
 #define SD_NT 256
+// -DSFD2_SD_PF=0: the filter fragments as first written (requested per tap, three blocks per CU) -- the A side of profiles/r05v_sparse_da3_ab.txt
+#ifndef SFD2_SD_PF
+#define SFD2_SD_PF 1
+#endif
+// fragment sets in the prefetch ring (SD_RING - 1 taps in flight behind the one in use); must divide the 36 taps of the four chunks, whose
+// loop is unrolled so that the ring index stays a constant (6: seven spilled registers, slower)
+#ifndef SFD2_SD_RING
+#define SFD2_SD_RING 4
+#endif
 #define SD_XB (SD_KP * 16 * 128)
 
 typedef __attribute__((address_space(3))) void sd_lds_t;
@@ -37,8 +49,9 @@ __device__ __forceinline__ void sd_corner(float kx, float ky, float half_w, floa
 
 // X3 (SFD2_PREC_F16X3): fmap / fmap_lo = convDa.0's output as hi / lo' planes, wpk = [hi chunks][lo' chunks], three MFMAs per K
 // slice into two accumulators (hi x hi; hi x lo' + lo' x hi, weighted 2^-11), fp32 output [n_max][4][256]
-template <bool X3>
-__global__ __launch_bounds__(SD_NT, X3 ? 2 : 3)
+// LINA: wpk is the repacked array (sparse_da3_repack_kernel below)
+template <bool X3, bool LINA = false>
+__global__ __launch_bounds__(SD_NT, (X3 || SFD2_SD_PF) ? 2 : 3)
 void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][wc][256]*/, const half_t *__restrict__ fmap_lo, int hc, int wc,
                        float half_w, float half_h,
                        const half_t *__restrict__ wpk /*[8 chunks of 32][9 taps][CoutP][32]*/, int CoutP,
@@ -52,15 +65,42 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lhi = lane >> 5;
     int n = n_max;
-    if (count) { const unsigned int c = *count; if ((unsigned int)n > c) n = (int)c; }
     const int k0 = blockIdx.x * SD_KP;
-    if (k0 >= n) return;
+    // the key points are requested BEFORE the count is known (two round trips to memory side by side instead of one behind the other): rows of
+    // the list beyond the count hold whatever they hold -- such a row's patch addresses are bounds-checked like any other and its outputs are
+    // not stored
+    float kpx = 0.0f, kpy = 0.0f;
+    if (tid < SD_KP) {
+        const int kp = k0 + tid < n_max ? k0 + tid : n_max - 1;
+        kpx = kpts[2 * kp];
+        kpy = kpts[2 * kp + 1];
+    }
     const int n0 = blockIdx.y * 128 + wave * 32;            // this wave's output channels
+    // Filter fragments of one tap: four K slices of 16 channels, straight from the packed filters in L2.  Plain fp16: the fragments of tap
+    // t + DIST (running on across the chunks) are requested BEFORE the MFMAs of tap t, the first DIST before the set-up -- as first written (load, wait, eight
+    // MFMAs per tap) every tap paid an L2 round trip that only the other resident block could hide: 36 round trips per block, 84 k cycles for
+    // 9.2 k cycles of MFMA issue per wave (profiles/r05v_sparse_da3_ab.txt).
+    // LINA: in the layers' common packing ([chunk of 32][tap][CoutP][32]) a fragment load touches sixteen 128-byte lines and uses half of each (the
+    // odd K slice the other half); the kernel is bound by what its waves pull through the CU's vector L1 -- 1.18 MB of fragments per CU and launch,
+    // ~40 B/clk while the taps run (a trace with producer waves had the patch copies crawl at 3 B/clk beside them) -- so the repacked array, one
+    // contiguous kilobyte per load, is worth 3.5 us
+#define SD_LOAD_A(dst_, c_, tap_)                                                                                          \
+    _Pragma("unroll") for (int k16 = 0; k16 < 4; ++k16)                                                                   \
+        dst_[k16] = LINA ? *reinterpret_cast<const h8_t *>(wpk + ((size_t)(((c_)*2 + (k16 >> 1)) * 9 + (tap_)) * CoutP + n0) * 32 + (k16 & 1) * 512 + lane * 8) \
+                         : *reinterpret_cast<const h8_t *>(wpk + ((size_t)(((c_)*2 + (k16 >> 1)) * 9 + (tap_)) * CoutP + n0 + lrow) * 32 + (k16 & 1) * 16 + lhi * 8);
+    constexpr int RING = SFD2_SD_RING, DIST = RING - 1;
+    h8_t an[RING][4];                                         // ring: DIST taps in flight behind the one in use
+    constexpr bool PF = !X3 && SFD2_SD_PF;
+    if (PF) {
+#pragma unroll
+        for (int i = 0; i < DIST; ++i) { SD_LOAD_A(an[i], 0, i) }
+    }
+    if (count) { const unsigned int c = *count; if ((unsigned int)n > c) n = (int)c; }
+    if (k0 >= n) return;
 
     if (tid < SD_KP) {
-        const int kp = k0 + tid < n ? k0 + tid : n - 1;
         int x0, y0;
-        sd_corner(kpts[2 * kp], kpts[2 * kp + 1], half_w, half_h, hc, wc, x0, y0);
+        sd_corner(kpx, kpy, half_w, half_h, hc, wc, x0, y0);
         geo[2 * tid] = x0;
         geo[2 * tid + 1] = y0;
     }
@@ -76,8 +116,9 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
     int recb[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) recb[t] = (t * 8 + (lrow >> 2)) * 16 + ((lrow >> 1) & 1) * 4 + (lrow & 1);
+    const int kcode = (lrow >> 2) & 3;                     // the key point's part of the slot swizzle (header)
 
-#pragma unroll 1
+#pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (c) __syncthreads();                               // every wave is past its reads of the previous chunk
         // copies: instruction j = wave + 4 * i moves records 8 j .. 8 j + 7 (half a key point's patch), lane -> (record, slot)
@@ -87,7 +128,7 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
             const int kpl = j >> 1, ppix = (j & 1) * 8 + (lane >> 3), slot = lane & 7;
             const int x0 = geo[2 * kpl], y0 = geo[2 * kpl + 1];
             const int iy = y0 - 1 + (ppix >> 2), ix = x0 - 1 + (ppix & 3);
-            const int part = slot ^ (ppix & 7);
+            const int part = slot ^ (ppix & 7) ^ (kpl & 3);
             const bool ok = iy >= 0 && iy < hc && ix >= 0 && ix < wc;
             const half_t *src = ok ? fmap + ((size_t)iy * wc + ix) * 256 + c * 64 + part * 8 : zero_page + slot * 8;
             __builtin_amdgcn_global_load_lds((sd_gbl_t *)src, (sd_lds_t *)(X + j * 1024), 16, 0, 0);
@@ -102,21 +143,30 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
             h8_t a[4], al[4];
+            if (!PF) {
 #pragma unroll
-            for (int k16 = 0; k16 < 4; ++k16) {
-                const size_t ao = ((size_t)((c * 2 + (k16 >> 1)) * 9 + tap) * CoutP + n0 + lrow) * 32 + (k16 & 1) * 16 + lhi * 8;
-                a[k16] = *reinterpret_cast<const h8_t *>(wpk + ao);
-                if (X3) al[k16] = *reinterpret_cast<const h8_t *>(wpk + (size_t)8 * 9 * CoutP * 32 + ao);   // the lo' plane of the filters
+                for (int k16 = 0; k16 < 4; ++k16) {
+                    const size_t ao = ((size_t)((c * 2 + (k16 >> 1)) * 9 + tap) * CoutP + n0 + lrow) * 32 + (k16 & 1) * 16 + lhi * 8;
+                    a[k16] = *reinterpret_cast<const h8_t *>(wpk + ao);
+                    if (X3) al[k16] = *reinterpret_cast<const h8_t *>(wpk + (size_t)8 * 9 * CoutP * 32 + ao);   // the lo' plane of the filters
+                }
+            } else {
+#pragma unroll
+                for (int k16 = 0; k16 < 4; ++k16) a[k16] = an[(c * 9 + tap) % RING][k16];
+                // the fragments DIST taps on (the last chunk's last taps re-read the last tap's: no branch, the values are not used)
+                const int gn = c * 9 + tap + DIST < 36 ? c * 9 + tap + DIST : 35;
+                SD_LOAD_A(an[(c * 9 + tap + DIST) % RING], gn / 9, gn % 9)
+                __builtin_amdgcn_sched_barrier(0);            // the requests stay in front of this tap's MFMAs
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int rec = recb[t] + ky * 4 + kx;
 #pragma unroll
                 for (int k16 = 0; k16 < 4; ++k16) {
-                    const h8_t b = *reinterpret_cast<const h8_t *>(X + rec * 128 + (((k16 * 2 + lhi) ^ (rec & 7)) << 4));
+                    const h8_t b = *reinterpret_cast<const h8_t *>(X + rec * 128 + (((k16 * 2 + lhi) ^ (rec & 7) ^ kcode) << 4));
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k16], b, acc[t], 0, 0, 0);
                     if (X3) {
-                        const h8_t bl = *reinterpret_cast<const h8_t *>(X + SD_XB + rec * 128 + (((k16 * 2 + lhi) ^ (rec & 7)) << 4));
+                        const h8_t bl = *reinterpret_cast<const h8_t *>(X + SD_XB + rec * 128 + (((k16 * 2 + lhi) ^ (rec & 7) ^ kcode) << 4));
                         acl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[k16], b, acl[t], 0, 0, 0);
                         acl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k16], bl, acl[t], 0, 0, 0);
                     }
@@ -124,6 +174,7 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
             }
         }
     }
+#undef SD_LOAD_A
 
     // C layout: lane owns pixel (t * 32 + lrow), channels n0 + 8 q + 4 lhi + j
 #pragma unroll
@@ -152,13 +203,39 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
     }
 }
 
-void launch_sparse_da3(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, int CoutP,
+// [chunk of 32][tap][CoutP][32] -> [chunk][tap][CoutP / 32][K half][lane = lhi * 32 + row][8]: element (row r of group g, K half h, lane half lhi, e)
+// comes from channel h * 16 + lhi * 8 + e of filter g * 32 + r
+__global__ void sparse_da3_repack_kernel(const half_t *__restrict__ src, half_t *__restrict__ dst, int CoutP, int n_ct /* chunks x taps */)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte piece
+    if (i >= (size_t)n_ct * CoutP * 4) return;
+    const int lane = (int)(i & 63), h = (int)((i >> 6) & 1);
+    const size_t grp = i >> 7;                                           // (chunk-tap) * (CoutP / 32) + group
+    const size_t ct = grp / (CoutP / 32), g = grp % (CoutP / 32);
+    const int r = lane & 31, lhi = lane >> 5;
+    *reinterpret_cast<h8_t *>(dst + i * 8) = *reinterpret_cast<const h8_t *>(src + (ct * CoutP + g * 32 + r) * 32 + h * 16 + lhi * 8);
+}
+
+void launch_sparse_da3_repack(hipStream_t st, const half_t *w, half_t *dst, int CoutP, int cin)
+{
+    const int n_ct = cin / 32 * 9;
+    const size_t pieces = (size_t)n_ct * CoutP * 4;
+    hipLaunchKernelGGL(sparse_da3_repack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, w, dst, CoutP, n_ct);
+}
+
+// wsl: the repacked filters (ConvW::wsl); -DSFD2_EXPERIMENTS builds: SFD2_SD_LINA=0 reads the common packing (the A side of the A/B)
+void launch_sparse_da3(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, const half_t *wsl, int CoutP,
                        const float *scale, const float *shift, int relu, const float *kpts, const unsigned int *count, int n_max,
                        half_t *out, const half_t *zero_page)
 {
     if (n_max <= 0) return;
-    hipLaunchKernelGGL(sparse_da3_kernel<false>, dim3((n_max + SD_KP - 1) / SD_KP, 2), dim3(SD_NT), 0, st, fmap, nullptr, hc, wc, (float)nw / 2.0f,
-                       (float)nh / 2.0f, wpk, CoutP, scale, shift, relu, kpts, count, n_max, out, zero_page);
+    static const char *force = sfd2_env("SFD2_SD_LINA");
+    if (wsl && !(force && force[0] == '0'))
+        hipLaunchKernelGGL((sparse_da3_kernel<false, true>), dim3((n_max + SD_KP - 1) / SD_KP, 2), dim3(SD_NT), 0, st, fmap, nullptr, hc, wc, (float)nw / 2.0f,
+                           (float)nh / 2.0f, wsl, CoutP, scale, shift, relu, kpts, count, n_max, out, zero_page);
+    else
+        hipLaunchKernelGGL((sparse_da3_kernel<false, false>), dim3((n_max + SD_KP - 1) / SD_KP, 2), dim3(SD_NT), 0, st, fmap, nullptr, hc, wc, (float)nw / 2.0f,
+                           (float)nh / 2.0f, wpk, CoutP, scale, shift, relu, kpts, count, n_max, out, zero_page);
 }
 
 // SFD2_PREC_F16X3: planes in, [hi][lo'] filters, fp32 out
@@ -167,6 +244,6 @@ void launch_sparse_da3_x3(hipStream_t st, const half_t *fmap_hi, const half_t *f
                           int n_max, float *out, const half_t *zero_page)
 {
     if (n_max <= 0) return;
-    hipLaunchKernelGGL(sparse_da3_kernel<true>, dim3((n_max + SD_KP - 1) / SD_KP, 2), dim3(SD_NT), 0, st, fmap_hi, fmap_lo, hc, wc,
+    hipLaunchKernelGGL((sparse_da3_kernel<true, false>), dim3((n_max + SD_KP - 1) / SD_KP, 2), dim3(SD_NT), 0, st, fmap_hi, fmap_lo, hc, wc,
                        (float)nw / 2.0f, (float)nh / 2.0f, wpk, CoutP, scale, shift, relu, kpts, count, n_max, out, zero_page);
 }
