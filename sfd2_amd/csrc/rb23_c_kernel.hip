@@ -25,6 +25,11 @@
 #define R23_NPIX (R23_PH * R23_PW)                  // 204 patch pixels x 128 B (one 64-channel chunk) = 25.5 KB
 #define R23_XB (26 * 1024)                          // a patch buffer: 26 copy instructions of 1 KB (the last one half used)
 #define R23_T2B (R23_TH * R23_TW * 512)
+#ifdef SFD2_RB23_OLDSWZ
+#define R23_SWZ(c_) (((c_) >> 1) & 7)
+#else
+#define R23_SWZ(c_) ((((c_) >> 1) & 3) << 1)
+#endif
 
 typedef float r23_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void r23_lds_t;
@@ -52,8 +57,13 @@ __device__ unsigned long long g_r23_wall[1024][2];
 
 // Pipeline.  Patch chunks travel global -> LDS by direct copies (global_load_lds), TWO chunks ahead of their use, into a ring of
 // three buffers (a chunk's compute, ~1.5k cycles, is shorter than an HBM round trip); a 128-byte pixel record's eight 16-byte
-// parts sit at slot part ^ ((patch column >> 1) & 7), so the 16 pixels a fragment read touches fall into 16 different bank
-// groups without padding -- and, the row not entering the swizzle, a lane's 20 fragment addresses of a chunk are five per-lane
+// parts sit at slot part ^ R23_SWZ(patch column), R23_SWZ(c) = ((c >> 1) & 3) << 1.  What has to differ: one LDS cycle of a `ds_read_b128`
+// serves sixteen lanes (MI355X_MICROARCH.md: {0-3, 12-15, 20-27}, ...) = columns {0-3, 12-15} of the lanes with g = 0 and columns 4-11 of
+// those with g = 1 (the pair's other group: part + 1), shifted by the tap's kx.  Two columns of one parity share their ((c >> 1) & 3) term
+// exactly when they are 8 apart -- one of them is then a g = 0 lane and the other a g = 1 lane whatever kx is, and the part bit keeps them
+// apart; bit 0 of the slot is the part's, never the swizzle's.  (Until the end of round 5 the term was (c >> 1) & 7: conflict-free for
+// kx = 0 only, 1.7 LDS cycles per lane group on average over a chunk's reads -- 26 % of the kernel's LDS cycles were conflicts,
+// profiles/r05s_pmc_summary.txt; -DSFD2_RB23_OLDSWZ builds it.)  The row not entering the swizzle, a lane's 20 fragment addresses of a chunk are five per-lane
 // offsets (one per K step: the tap differs between lane groups) plus compile-time (row, pixel half) offsets that fit the
 // ds_read immediate.  A chunk is bound by VALU issue (16-wide SIMDs: a wave64 instruction takes four cycles, 40 MFMAs per chunk
 // take 640), so what is computed per chunk is kept to the accumulator fold, the BN epilogue and a few adds.  The grouped conv's filter fragments of the NEXT chunk are loaded into the registers of the step that has
@@ -139,7 +149,7 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
         const int q = piece >> 3;                                                                         \
         const int py = (q * 241) >> 13, px = q - py * R23_PW;                                             \
         const int iy = (oy0_)-1 + py, ix = (ox0_)-1 + px;                                                  \
-        const int part = (piece & 7) ^ ((px >> 1) & 7);   /* slot = part ^ ((column >> 1) & 7) */          \
+        const int part = (piece & 7) ^ R23_SWZ(px);       /* slot = part ^ R23_SWZ(column) */                  \
         const bool ok = j < 26 && q < R23_NPIX && iy >= 0 && iy < H && ix >= 0 && ix < W;                  \
         xoff[i] = ok ? ((iy * W + ix) * 256 + part * 8) * (int)sizeof(half_t) : (int)0x80000000;           \
     }
@@ -165,7 +175,7 @@ void rb23_c_kernel(const half_t *__restrict__ t1, int H, int W,
         if (tap > 8) tap = 8;                               // zero-weight slot: read any valid location
         const int ky = tap / 3, kx = tap - ky * 3;
         const int col = lcol + kx;                          // (+ 16 for the second pixel half: the swizzle term does not change)
-        boff[s] = ((rh * 2 + ky) * R23_PW + col) * 128 + (((pw * 2 + (g & 1)) ^ ((col >> 1) & 7)) << 4);
+        boff[s] = ((rh * 2 + ky) * R23_PW + col) * 128 + (((pw * 2 + (g & 1)) ^ R23_SWZ(col)) << 4);
     }
     // T2 store of (tile row rh * 2, pixel half h): pixel pl = rh * 64 + 16 h + lcol, slot (pair * 2 + (g >> 1)) ^ (pl & 31) -- the
     // pair's chunk bits (chunk * 8) and the half's bit 4 enter by XOR
