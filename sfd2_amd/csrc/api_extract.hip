@@ -237,10 +237,16 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
                 HIPCHECK(L3.wx3p.ensure(nfl * 2 * sizeof(half_t)));
                 launch_x3_split_planes(c->stream, L3.w.as<float>(), nfl, L3.wx3p.p, L3.wx3p.as<half_t>() + nfl);
             }
+            if (!L3.wsl.p && L3.cin == 256) {                     // both planes in sparse_da3_kernel's fragment order (ConvW::wsl)
+                const size_t nfl = (size_t)9 * L3.cout_pad * L3.cin;
+                HIPCHECK(L3.wsl.ensure(nfl * 2 * sizeof(half_t)));
+                launch_sparse_da3_repack(c->stream, L3.wx3p.as<half_t>(), L3.wsl.as<half_t>(), L3.cout_pad, L3.cin);
+                launch_sparse_da3_repack(c->stream, L3.wx3p.as<half_t>() + nfl, L3.wsl.as<half_t>() + nfl, L3.cout_pad, L3.cin);
+            }
             {
                 ProfScope ps(c, "convDa.3", "sparse_da3_kernel<x3>", 2.0 * 4 * sel_cap * 256.0 * 256.0 * 9, (double)sel_cap * (16 * 1024 + 4 * 1024));
                 launch_sparse_da3_x3(c->stream, c->x3_da0_planes.as<half_t>(), c->x3_da0_planes.as<half_t>() + nin, c->H4, c->W4, H, W,
-                                     L3.wx3p.as<half_t>(), L3.cout_pad, L3.scale.as<float>(), L3.shift.as<float>(), 0, c->kpts_cur,
+                                     L3.wx3p.as<half_t>(), L3.wsl.as<half_t>(), L3.cout_pad, L3.scale.as<float>(), L3.shift.as<float>(), 0, c->kpts_cur,
                                      c->counters.as<unsigned int>() + 1, sel_cap, c->da3_sparse.as<float>(), c->zero_page.as<half_t>());
             }
             // convDb (1x1) on the compact [sel_cap x 4] "image" with the mode's generic kernel, then the sampler on its compact output

@@ -462,7 +462,7 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
         ConvW *fl[] = {&c->f1a, &c->f1b, &c->f2a, &c->f2b, &c->f3a, &c->f3b, &c->frb1[0], &c->frb1[1], &c->frb1[2], &c->frb2[0],
                        &c->frb2[1], &c->frb2[2], &c->frb3[0], &c->frb3[1], &c->frb3[2], &c->fpa0, &c->fpa3, &c->fda0, &c->fda3,
                        &c->fpb, &c->fdb};
-        for (ConvW *L : fl) { L->wx3.release(); L->wx3p.release(); }
+        for (ConvW *L : fl) { L->wx3.release(); L->wx3p.release(); L->wsl.release(); }
     }
     TMap m;
     for (int i = 0; i < n; ++i) {

@@ -409,7 +409,7 @@ void launch_sparse_da3(hipStream_t st, const half_t *fmap, int hc, int wc, int n
                        const float *scale, const float *shift, int relu, const float *kpts, const unsigned int *count, int n_max,
                        half_t *out, const half_t *zero_page);
 void launch_sparse_da3_repack(hipStream_t st, const half_t *w, half_t *dst, int CoutP, int cin);
-void launch_sparse_da3_x3(hipStream_t st, const half_t *fmap_hi, const half_t *fmap_lo, int hc, int wc, int nh, int nw, const half_t *wpk,
+void launch_sparse_da3_x3(hipStream_t st, const half_t *fmap_hi, const half_t *fmap_lo, int hc, int wc, int nh, int nw, const half_t *wpk, const half_t *wsl,
                           int CoutP, const float *scale, const float *shift, int relu, const float *kpts, const unsigned int *count,
                           int n_max, float *out, const half_t *zero_page);
 // rb23_c_kernel.hip: ResBlock.conv2 + conv3 + residual in one kernel (SFD2_PREC_F16C, option "rb_inner" = 2: t1 plain fp16 in, t2 in LDS)

@@ -30,6 +30,9 @@
 #ifndef SFD2_SD_RING
 #define SFD2_SD_RING 4
 #endif
+#ifndef SFD2_SD_RING_X3      // the three-pass form holds twice the fragments per tap and twice the accumulators (1 = no prefetch)
+#define SFD2_SD_RING_X3 2
+#endif
 #define SD_XB (SD_KP * 16 * 128)
 
 typedef __attribute__((address_space(3))) void sd_lds_t;
@@ -88,12 +91,21 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
     _Pragma("unroll") for (int k16 = 0; k16 < 4; ++k16)                                                                   \
         dst_[k16] = LINA ? *reinterpret_cast<const h8_t *>(wpk + ((size_t)(((c_)*2 + (k16 >> 1)) * 9 + (tap_)) * CoutP + n0) * 32 + (k16 & 1) * 512 + lane * 8) \
                          : *reinterpret_cast<const h8_t *>(wpk + ((size_t)(((c_)*2 + (k16 >> 1)) * 9 + (tap_)) * CoutP + n0 + lrow) * 32 + (k16 & 1) * 16 + lhi * 8);
-    constexpr int RING = SFD2_SD_RING, DIST = RING - 1;
-    h8_t an[RING][4];                                         // ring: DIST taps in flight behind the one in use
-    constexpr bool PF = !X3 && SFD2_SD_PF;
+    constexpr int RING = X3 ? SFD2_SD_RING_X3 : SFD2_SD_RING, DIST = RING - 1;
+    h8_t an[RING][4], aln[X3 ? RING : 1][4];                  // ring: DIST taps in flight behind the one in use (X3: the hi and the lo' fragments)
+    constexpr bool PF = SFD2_SD_PF && RING > 1;
+    static_assert(PF || !LINA, "the repacked filters are read by the prefetching form");
+    const half_t *wpl = wpk + (size_t)8 * 9 * CoutP * 32;     // X3: the lo' plane of the filters
+#define SD_LOAD_AL(dst_, c_, tap_)                                                                                         \
+    _Pragma("unroll") for (int k16 = 0; k16 < 4; ++k16)                                                                   \
+        dst_[k16] = LINA ? *reinterpret_cast<const h8_t *>(wpl + ((size_t)(((c_)*2 + (k16 >> 1)) * 9 + (tap_)) * CoutP + n0) * 32 + (k16 & 1) * 512 + lane * 8) \
+                         : *reinterpret_cast<const h8_t *>(wpl + ((size_t)(((c_)*2 + (k16 >> 1)) * 9 + (tap_)) * CoutP + n0 + lrow) * 32 + (k16 & 1) * 16 + lhi * 8);
     if (PF) {
 #pragma unroll
-        for (int i = 0; i < DIST; ++i) { SD_LOAD_A(an[i], 0, i) }
+        for (int i = 0; i < DIST; ++i) {
+            SD_LOAD_A(an[i], 0, i)
+            if (X3) { SD_LOAD_AL(aln[i], 0, i) }
+        }
     }
     if (count) { const unsigned int c = *count; if ((unsigned int)n > c) n = (int)c; }
     if (k0 >= n) return;
@@ -152,10 +164,14 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
                 }
             } else {
 #pragma unroll
-                for (int k16 = 0; k16 < 4; ++k16) a[k16] = an[(c * 9 + tap) % RING][k16];
+                for (int k16 = 0; k16 < 4; ++k16) {
+                    a[k16] = an[(c * 9 + tap) % RING][k16];
+                    if (X3) al[k16] = aln[(c * 9 + tap) % RING][k16];
+                }
                 // the fragments DIST taps on (the last chunk's last taps re-read the last tap's: no branch, the values are not used)
                 const int gn = c * 9 + tap + DIST < 36 ? c * 9 + tap + DIST : 35;
                 SD_LOAD_A(an[(c * 9 + tap + DIST) % RING], gn / 9, gn % 9)
+                if (X3) { SD_LOAD_AL(aln[(c * 9 + tap + DIST) % RING], gn / 9, gn % 9) }
                 __builtin_amdgcn_sched_barrier(0);            // the requests stay in front of this tap's MFMAs
             }
 #pragma unroll
@@ -175,6 +191,7 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
         }
     }
 #undef SD_LOAD_A
+#undef SD_LOAD_AL
 
     // C layout: lane owns pixel (t * 32 + lrow), channels n0 + 8 q + 4 lhi + j
 #pragma unroll
@@ -238,12 +255,21 @@ void launch_sparse_da3(hipStream_t st, const half_t *fmap, int hc, int wc, int n
                            (float)nh / 2.0f, wpk, CoutP, scale, shift, relu, kpts, count, n_max, out, zero_page);
 }
 
-// SFD2_PREC_F16X3: planes in, [hi][lo'] filters, fp32 out
-void launch_sparse_da3_x3(hipStream_t st, const half_t *fmap_hi, const half_t *fmap_lo, int hc, int wc, int nh, int nw, const half_t *wpk,
+// SFD2_PREC_F16X3: planes in, [hi][lo'] filters (wsl: both planes repacked, or null), fp32 out
+void launch_sparse_da3_x3(hipStream_t st, const half_t *fmap_hi, const half_t *fmap_lo, int hc, int wc, int nh, int nw, const half_t *wpk, const half_t *wsl,
                           int CoutP, const float *scale, const float *shift, int relu, const float *kpts, const unsigned int *count,
                           int n_max, float *out, const half_t *zero_page)
 {
     if (n_max <= 0) return;
+    static const char *force = sfd2_env("SFD2_SD_LINA");
+#if SFD2_SD_PF && SFD2_SD_RING_X3 > 1
+    if (wsl && !(force && force[0] == '0')) {
+        hipLaunchKernelGGL((sparse_da3_kernel<true, true>), dim3((n_max + SD_KP - 1) / SD_KP, 2), dim3(SD_NT), 0, st, fmap_hi, fmap_lo, hc, wc,
+                           (float)nw / 2.0f, (float)nh / 2.0f, wsl, CoutP, scale, shift, relu, kpts, count, n_max, out, zero_page);
+        return;
+    }
+#endif
+    (void)force;
     hipLaunchKernelGGL((sparse_da3_kernel<true, false>), dim3((n_max + SD_KP - 1) / SD_KP, 2), dim3(SD_NT), 0, st, fmap_hi, fmap_lo, hc, wc,
                        (float)nw / 2.0f, (float)nh / 2.0f, wpk, CoutP, scale, shift, relu, kpts, count, n_max, out, zero_page);
 }
