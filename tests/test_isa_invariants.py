@@ -173,6 +173,24 @@ def test_matcher_valu_budget(asm):
         assert _count(k["body"], r"v_max_f32_e32 (v\d+), \1, \1") == 0
 
 
+def test_sparse_da3_fragments_stay_in_flight(asm):
+    """Round 5: the kernel was 41 us with its filter fragments loaded and waited for tap by tap; the prefetch ring is only worth anything while
+    the waits between the MFMAs are COUNTED (a `vmcnt(0)` there is the old tap-by-tap round trip again)."""
+    ks = {n: k for n, k in asm("sparse_da3_kernel.hip").items() if "sparse_da3_kernel" in n}
+    assert len(ks) == 4                                  # <plain | x3> x <common packing | repacked filters>
+    for name, k in ks.items():
+        meta = k["meta"]
+        x3 = "ILb1E" in name
+        assert meta["vgpr_count"] <= 256, (name, meta)   # two blocks per CU
+        assert meta["vgpr_spill_count"] <= (8 if x3 else 0), (name, meta)   # (x3 parks seven address registers: measured faster than no ring)
+        span = _mfma_span(k["body"])
+        assert _count(span, r"v_mfma") == 36 * 8 * (3 if x3 else 1), name
+        drains = _count(span, r"s_waitcnt vmcnt\(0\)")
+        # per chunk the written drain in front of its barrier (the patch copies) and the compiler's own beside it; x3's spilled reloads add a few; never one per tap (36)
+        assert drains <= (16 if x3 else 8), (name, drains)
+        assert _count(span, r"s_waitcnt vmcnt\((?:[4-9]|\d\d)\)") >= 30, name      # the counted waits of the ring
+
+
 def test_pmc_families_name_the_headline_kernels(asm):
     """tools/pmc_to_json.py picks kernels by regex on their mangled names; a renamed template parameter silently drops a family from
     profiles/pmc_traffic.json (it happened twice in round 4: bench.py's roofline.traffic went null).  Every family of the default f16c path
