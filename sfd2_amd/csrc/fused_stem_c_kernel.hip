@@ -34,6 +34,17 @@
 #define SC_IM (SC_IH * SC_IW * 8)      // bytes of one image plane ([px][4] fp16)
 #define SC_LDS (2 * SC_X1 + 2 * SC_IM + 1024)
 #define SC_NU 5                        // units per wave (the last two wave groups run four)
+// slot term of a region pixel's record.  (pixel >> 1) & 7 is what phase 2's stride-2 fragment reads need (sixteen lanes = sixteen pixels two apart); the
+// parity bit on top changes nothing for them (a read's pixels share their parity: one constant XOR) and separates pixels 2 m and 2 m + 1 in
+// phase 1's 16-byte corr stores, whose eight-lane groups are eight CONSECUTIVE pixels: two-way conflicted until the end of round 5
+// (-DSFD2_STEMC_OLDSWZ).  The 8-byte hi stores stay two-way (CHANGELOG round 5).
+#ifdef SFD2_STEMC_OLDSWZ
+#define SC_SWZ(q_) (((q_) >> 1) & 7)
+#define SC_SWZ_PAR(c_) 0
+#else
+#define SC_SWZ(q_) ((((q_) >> 1) & 7) ^ (((q_) & 1) << 2))
+#define SC_SWZ_PAR(c_) (((c_) & 1) << 2)      // the parity part alone, of a pixel index known up to an even offset
+#endif
 #ifndef SFD2_STEMC_P1MODE
 #define SFD2_STEMC_P1MODE 0
 #endif
@@ -147,7 +158,7 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
 {
     unsigned int smax1 = 0, smax2 = 0;     // range status of conv1a's (LDS-resident) and conv1b's output: wave-uniform across the tiles
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *X1h = smem;                                   // [SC_RP][128 B], 16-B slots swizzled with (rec >> 1) & 7, records pair-swapped
+    unsigned char *X1h = smem;                                   // [SC_RP][128 B], 16-B slots swizzled with SC_SWZ(rec), records pair-swapped
     unsigned char *X1c = smem + SC_X1;                           // the corr plane, same addressing
     half_t *IMh = reinterpret_cast<half_t *>(smem + 2 * SC_X1);  // [SC_IH][SC_IW][4]
     half_t *IMl = IMh + SC_IH * SC_IW * 4;
@@ -264,7 +275,7 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
         p1_yx[i] = (ry << 8) | rx;
         p1_im[i] = (ry * SC_IW + rx + 2 * lhi) * 4;                      // halfs
         // byte offset of this lane's 8 bytes of channel quad 0 in the pixel's record, swizzle of the record folded in per quad below
-        p1_x[i] = ((pc ^ ((pc >> 4) & 1)) * 128 + 8 * lhi) | (((pc >> 1) & 7) << 20);
+        p1_x[i] = ((pc ^ ((pc >> 4) & 1)) * 128 + 8 * lhi) | (SC_SWZ(pc) << 20);
     }
 
     int tile = blockIdx.x;
@@ -453,8 +464,9 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                 for (int r = 0; r < SC_TH; ++r) {
                     const int q = (2 * r + ky) * SC_RW + l2 + kx;
                     const int ro = (q ^ ((q >> 4) & 1)) * 128;
-                    const int bsw = (q >> 1) & 7;
-                    const int o0 = ro + (((ih * 4 + lhi) ^ bsw) << 4), o1 = ro + (((ih * 4 + 2 + lhi) ^ bsw) << 4);
+                    // (the pixel's parity is the tap's: a constant, folded into the slot constants -- as `SC_SWZ(q)` it was two more vector instructions per read)
+                    const int bsw = (q >> 1) & 7, par = SC_SWZ_PAR((2 * r + ky) * SC_RW + kx);
+                    const int o0 = ro + (((((ih * 4) ^ par) + lhi) ^ bsw) << 4), o1 = ro + (((((ih * 4 + 2) ^ par) + lhi) ^ bsw) << 4);
                     const h8_t b0 = *reinterpret_cast<const h8_t *>(X1h + o0);
                     const h8_t b1 = *reinterpret_cast<const h8_t *>(X1h + o1);
                     acc2[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[i][0], b0, acc2[r], 0, 0, 0);
@@ -484,8 +496,8 @@ void fused_stem_c_kernel(const float *__restrict__ img, int H, int W, int normal
                     for (int r = 0; r < SC_TH; ++r) {
                         const int q = (2 * r + ky) * SC_RW + l2b + kx;
                         const int ro = (q ^ ((q >> 4) & 1)) * 128;
-                        const int bsw = (q >> 1) & 7;
-                        const int o0 = ro + (((ih * 4 + lhi) ^ bsw) << 4), o1 = ro + (((ih * 4 + 2 + lhi) ^ bsw) << 4);
+                        const int bsw = (q >> 1) & 7, par = SC_SWZ_PAR((2 * r + ky) * SC_RW + kx);
+                        const int o0 = ro + (((((ih * 4) ^ par) + lhi) ^ bsw) << 4), o1 = ro + (((((ih * 4 + 2) ^ par) + lhi) ^ bsw) << 4);
                         const h8_t b0 = *reinterpret_cast<const h8_t *>(X1h + o0);
                         const h8_t b1 = *reinterpret_cast<const h8_t *>(X1h + o1);
                         const h8_t l0 = *reinterpret_cast<const h8_t *>(X1c + o0);
