@@ -81,7 +81,7 @@ typedef struct {
     int64_t n_candidates; /* N0 after NMS + threshold + border of the last extract          */
 } sfd2_timings;
 
-int sfd2_version(void);   /* 100 = rounds 1-4; 105 adds sfd2_extract_record_async, sfd2_desc_pack and host outputs with SFD2_FLAG_ASYNC; 106 adds sfd2_get_margin_status */
+int sfd2_version(void);   /* 100 = rounds 1-4; 105 adds sfd2_extract_record_async, sfd2_desc_pack and host outputs with SFD2_FLAG_ASYNC; 106 adds sfd2_get_margin_status; 107 adds sfd2_get_relax_status (option "c3b_plain") */
 const char *sfd2_last_error(void);
 
 int sfd2_ctx_create(int device, sfd2_ctx **out);
@@ -143,7 +143,9 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *   "x3_pp"     1 (default) / 0: SFD2_PREC_F16X3 on its throughput kernels -- 3x3 stride-1 layers on conv3x3_pp over pre-split hi / lo'
  *               planes, and on sfd2_extract (not sfd2_det) the fused three-pass stem, the streaming three-pass 1x1 kernel in the
  *               ResBlocks and the sparse descriptor head; 0 = the generic three-pass kernel everywhere (same tolerances, 1.6x slower).
- *   "auto_margin" 1 (default) / 0: the load-time self-check of SFD2_PREC_F16C (sfd2_get_margin_status below); set it BEFORE sfd2_load_weights.
+ *   "auto_margin" 1 (default) / 0: the load-time self-check of SFD2_PREC_F16C (sfd2_get_margin_status below); set it BEFORE sfd2_load_weights.  It runs when
+ *               the context is in SFD2_PREC_F16C at the load (or the first time it enters that precision afterwards) and leaves alone a key the caller set.
+ *   "c3b_plain" -1 (default) / 0 / 1: conv3b without its correction chunks when the self-check finds the room (sfd2_get_relax_status below).
  *   "x3_desc16" 0 (default) / 1: SFD2_PREC_F16X3 on sfd2_extract with the DESCRIPTOR branch in plain fp16 -- convDa.0 as one fp16 pass over the
  *               backbone output's hi plane, convDa.3 / convDb on the sampled corners on the fp16 kernels (wherever the sparse descriptor head
  *               runs: 16 x top_k <= the 1/4-resolution map; elsewhere the option does nothing).  Key points and scores are this mode's own, bit for
@@ -409,6 +411,13 @@ int sfd2_set_act_exponents(sfd2_ctx *ctx, const int32_t *exps, int n /* SFD2_RAN
  * options as they were / rb_inner = 0 / comp_heads = 1 / both (-1 = not measured: an earlier one met the target); *choice: 0..3 = which of them the context
  * now runs (bit 0: rb_inner = 0, bit 1: comp_heads = 1), -1 = no self-check has run (option off, auto_range off).  sfd2_set_option afterwards overrides. */
 int sfd2_get_margin_status(sfd2_ctx *ctx, float *errs4, int *choice, float *target);
+/* Option "c3b_plain" (version 107).  conv3b (nets/sfd2.py:276-278: 256 -> 256 channels at 1/4 resolution, the largest layer of the backbone) can run its
+ * K loop over the fp16 plane of conv3a's output alone -- no correction chunks, the output's correction bytes still come from the fp32 accumulators, and
+ * conv3a then writes no correction plane: -62 us of that layer's 184 at 1600x1200 for ~1.4x the descriptor error (tools/relax_study.py).  It is never on
+ * unverified: with the default -1 the self-check above also measures the probe WITH it and keeps it only when the options as set met the target and still
+ * meet it with it; 1 forces it (the self-check then runs every candidate with it), 0 forbids it.  *err_plain: the probe error with it (-1 = not measured),
+ * *c3b_plain: whether the context now runs it.  A rounds-1..5 caller sees the same entry points; the descriptor tolerance (1e-3) is unchanged. */
+int sfd2_get_relax_status(sfd2_ctx *ctx, float *err_plain, int *c3b_plain);
 
 /* Blocks until every kernel queued on the context's stream has finished. */
 int sfd2_sync(sfd2_ctx *ctx);

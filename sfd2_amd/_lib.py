@@ -82,7 +82,7 @@ EXPORTS = [
     "sfd2_get_layer_timings", "sfd2_set_precision", "sfd2_extract_spp", "sfd2_nms_fast",
     "sfd2_set_profile_filter", "sfd2_extract_multiscale", "sfd2_set_option", "sfd2_extract_match", "sfd2_preprocess", "sfd2_extract_spp_levels", "sfd2_match_segments",
     "sfd2_get_range_status", "sfd2_range_tensor_name", "sfd2_calibrate_range", "sfd2_get_act_exponents", "sfd2_set_act_exponents",
-    "sfd2_extract_record_async", "sfd2_desc_pack", "sfd2_get_margin_status",
+    "sfd2_extract_record_async", "sfd2_desc_pack", "sfd2_get_margin_status", "sfd2_get_relax_status",
 ]
 
 _lib = None
@@ -156,13 +156,15 @@ def load():
     lib.sfd2_calibrate_range.argtypes = [vp, vp, ci, ci, ci, ci]
     lib.sfd2_get_act_exponents.argtypes = [vp, vp, vp, ci, pi]
     lib.sfd2_get_margin_status.argtypes = [vp, vp, pi, ctypes.POINTER(ctypes.c_float)]
+    lib.sfd2_get_relax_status.restype = ci
+    lib.sfd2_get_relax_status.argtypes = [vp, ctypes.POINTER(ctypes.c_float), pi]
     lib.sfd2_set_act_exponents.argtypes = [vp, vp, ci]
     lib.sfd2_extract_record_async.argtypes = [vp, vp, ci]
     lib.sfd2_desc_pack.argtypes = [vp, ctypes.POINTER(DescSet), ci, vp, ci]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the .so lacks a declared symbol
-    if lib.sfd2_version() < 106:
-        raise RuntimeError(f"{LIB_PATH} is version {lib.sfd2_version()}, this binding needs >= 106 (rebuild: __graft_entry__.build())")
+    if lib.sfd2_version() < 107:
+        raise RuntimeError(f"{LIB_PATH} is version {lib.sfd2_version()}, this binding needs >= 107 (rebuild: __graft_entry__.build())")
     _lib = lib
     return lib
 
@@ -298,8 +300,11 @@ class Context:
         ch, tg = ctypes.c_int(0), ctypes.c_float(0)
         check(self.lib.sfd2_get_margin_status(self.h, e.ctypes.data, ctypes.byref(ch), ctypes.byref(tg)))
         names = ["as set", "rb_inner=0", "comp_heads=1", "rb_inner=0 comp_heads=1"]
+        ep, on = ctypes.c_float(0), ctypes.c_int(0)
+        check(self.lib.sfd2_get_relax_status(self.h, ctypes.byref(ep), ctypes.byref(on)))
         return {"errors": {n: float(v) for n, v in zip(names, e)}, "choice": int(ch.value),
-                "running": names[ch.value] if ch.value >= 0 else None, "target": float(tg.value)}
+                "running": names[ch.value] if ch.value >= 0 else None, "target": float(tg.value),
+                "c3b_plain": bool(on.value), "error_with_c3b_plain": float(ep.value)}
 
     def set_act_exponents(self, exps=None):
         if exps is None:

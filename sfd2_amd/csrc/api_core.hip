@@ -13,7 +13,7 @@ std::atomic<unsigned long long> g_alloc_gen{0};
 thread_local int g_sfd2_cu_limit = 0;       // set per network pass from the context's option "cu_limit" (sfd2_internal.h)
 
 // ------------------------------------------------------------------------------------------ basics
-extern "C" int sfd2_version(void) { return 106; }   // 105: + sfd2_extract_record_async, sfd2_desc_pack, SFD2_FLAG_ASYNC with host outputs (round 5); 106: + sfd2_get_margin_status
+extern "C" int sfd2_version(void) { return 107; }   // 107: + sfd2_get_relax_status (option c3b_plain); 105: + sfd2_extract_record_async, sfd2_desc_pack, SFD2_FLAG_ASYNC with host outputs (round 5); 106: + sfd2_get_margin_status
 extern "C" const char *sfd2_last_error(void) { return g_err.c_str(); }
 
 extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
@@ -85,7 +85,7 @@ extern "C" int sfd2_set_precision(sfd2_ctx *c, int mode)
     HIPCHECK(hipStreamSynchronize(c->stream));
     if (mode != c->precision) graphs_release(c);   // a captured unit holds the kernels of the precision it was captured in
     c->precision = mode;
-    return 0;
+    return sfd2_margin_selfcheck_if_pending(c);     // (a context that was loaded in another precision: the F16C self-check runs now)
 }
 
 extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
@@ -117,10 +117,11 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "generic_c") c->opt_generic_c = value ? 1 : 0;
     else if (k == "comp_rb") c->opt_comp_rb = value ? 1 : 0;
     else if (k == "no_rf_c") c->opt_no_rf_c = value ? 1 : 0;
-    else if (k == "comp_heads") c->opt_comp_heads = c->user_comp_heads = value ? 1 : 0;
+    else if (k == "comp_heads") { c->opt_comp_heads = c->user_comp_heads = value ? 1 : 0; c->user_set_comp_heads = true; }
+    else if (k == "c3b_plain") { c->user_c3b_plain = value < 0 ? -1 : (value ? 1 : 0); c->opt_c3b_plain = value > 0 ? 1 : 0; }
     else if (k == "comp_det") c->opt_comp_det = value ? 1 : 0;
     else if (k == "fuse_rb23") c->opt_fuse_rb23 = value ? 1 : 0;
-    else if (k == "rb_inner") c->opt_rb_inner = c->user_rb_inner = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (k == "rb_inner") { c->opt_rb_inner = c->user_rb_inner = value < 0 ? 0 : (value > 2 ? 2 : value); c->user_set_rb_inner = true; }
     else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;
 }

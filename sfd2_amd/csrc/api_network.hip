@@ -197,7 +197,15 @@ static void convc(sfd2_ctx *c, const char *name, const ConvW &L, const DevPtr &i
     half_t *out_c = out_comp ? corr_of(out, (size_t)Ho * Wo, L.cout_pad) : nullptr;
     // conv3x3_pp's tile is 128 channels wide: in its compensated form it also takes conv2a (64 -> 128 channels, four chunks)
     if (!res && !c->opt_generic_c && L.ks == 3 && L.stride == 1 && L.cout_pad % 128 == 0 && L.cin % 64 == 0) {
-        ProfScope ps(c, name, "conv3x3_pp<comp>", flops, bytes);
+        ProfScope ps(c, name, (in_c && out_c) ? "conv3x3_pp<comp>" : (in_c ? "conv3x3_pp<comp,plain out>" : "conv3x3_pp<comp out>"), flops, bytes);
+        if (relu && ((!in_c && out_c) || (in_c && !out_c && (fmt6 & 1) && L.wc66.p && L.sa66.p))) {
+            // option "c3b_plain": conv3b over the hi plane of its input alone (the hi chunks at the start of any of the layer's arrays; the output's corr
+            // bytes from the fp32 accumulators as ever: fmt6 bit 3 = the three-byte trunk form), and conv3a, whose corr plane then has no reader
+            launch_conv3x3_pp_c(c->cur_stream, in.as<half_t>(), in_c, H, W, L.cin, in_c ? L.wc66.as<half_t>() : L.wc.as<half_t>(), L.scale.as<float>(),
+                                in_c ? L.shift.as<float>() : L.shift.as<float>(), L.cout_pad, relu, out.as<half_t>(), out_c, Ho, Wo, c->zero_page.as<half_t>(), L.sbyte,
+                                in_c ? L.sa66.as<float>() : nullptr, rs, fmt6);
+            return;
+        }
         if (fmt6 && in_c && out_c && relu && L.wc66.p && L.sa66.p && L.wc6.p && L.sa6.p) {
             // fp6 pixel records on either side: the filter strings in the input records' format (fp6 x fp6 when the input's are fp6)
             const bool i6 = (fmt6 & 1) != 0;
@@ -626,7 +634,19 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                               a2b.as<half_t>(), corr_of(a2b, (size_t)H4 * W4, L.cout_pad), c->zero_page.as<half_t>(), L.sbyte, range_slot(c, SFD2_RS_CONV2B), b6 ? 2 : 0);
         } else
         convc(c, "conv2b", c->c2b, a2a, H2, W2, a2b, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV2B, b6 ? 2 : 0);
-        convc(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV3A, (b6 ? 1 : 0) | (a6 ? 2 : 0));
+        // Option "c3b_plain" (the load-time self-check decides, api_weights.hip): conv3b takes the hi plane of conv3a's output only; conv3a keeps writing
+        // its records unless SFD2_C3A_PLAIN_OUT says otherwise (experiment switch until measured)
+        const bool p3b = c->opt_c3b_plain && a6 && b6 && !c->opt_generic_c;
+        static const bool c3a_plain_out = sfd2_env("SFD2_C3A_KEEP_CORR") == nullptr;
+        const bool p3a = p3b && c3a_plain_out;
+        {
+            auto it = c->acts.find("conv3a");
+            if (it != c->acts.end() && it->second.p == a3a.p) {      // (sfd2_debug_activation: the tensor has no corr plane then)
+                it->second.pc = p3a ? nullptr : corr_of(a3a, (size_t)H4 * W4, 256);
+                it->second.fmt6 = a6 && !p3a;
+            }
+        }
+        convc(c, "conv3a", c->c3a, a2b, H4, W4, a3a, H4, W4, 1, true, !p3a, nullptr, SFD2_RS_CONV3A, (b6 ? 1 : 0) | ((a6 && !p3a) ? 2 : 0));
         // Option "trunk_r1": the three tensors the ResBlocks read as block input (conv3b's output, the outputs of blocks 0 and 1) with the residual
         // byte only -- their readers are conv1x1_c256_c<.., 2, ..> (value bytes rebuilt from the hi plane) and rb23_c_kernel's skip path
         const bool tr1 = c->opt_trunk_r1 && a6 && !c->opt_generic_c && c->opt_comp_rb && c->opt_rb_inner >= 2 && c->opt_fuse_rb23 &&
@@ -638,7 +658,7 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
                 if (it != c->acts.end()) it->second.r1 = tr1;
             }
         }
-        convc(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1, true, true, nullptr, SFD2_RS_CONV3B, (a6 ? 1 : 0) | (tr1 ? 8 : 0));
+        convc(c, "conv3b", c->c3b, a3a, H4, W4, a3b, H4, W4, 1, !p3b, true, nullptr, SFD2_RS_CONV3B, ((a6 && !p3b) ? 1 : 0) | (tr1 ? 8 : 0));
         for (int b = 0; b < 3; ++b) {  // ResBlock (nets/sfd2.py:25-55)
             if (!c->opt_comp_rb) { rb_f16(b); continue; }   // option "comp_rb" = 0: this block in plain fp16 on the hi planes
             DevPtr &t1 = t1v[b], &t2 = t2v[b], &ob = rov[b];

@@ -590,6 +590,12 @@ extern "C" int sfd2_load_weights(sfd2_ctx *c, const sfd2_tensor *tensors, int n)
     for (int g = 0; g < AE_COUNT; ++g) { c->act_exp[g] = 0; c->act_max[g] = 0.0f; }
     c->weights_loaded = true;
     if (apply_act_exponents(c)) { c->weights_loaded = false; return -1; }
+    c->margin_done = false;        // the self-check's findings belong to the weights it ran on
+    c->margin_pending = false;
+    c->margin_choice = -1;
+    for (float &e : c->margin_err) e = -1.0f;
+    c->relax_err = -1.0f;
+    c->opt_c3b_plain = c->user_c3b_plain == 1 ? 1 : 0;     // (never on unverified: -1 waits for the self-check)
     if (c->opt_auto_range && calibrate_on_probe(c)) { c->weights_loaded = false; return -1; }
     return 0;
 }
@@ -748,7 +754,10 @@ static int margin_selfcheck(sfd2_ctx *c, const float *img, int H, int W)
     std::vector<float> ref, got;
     if (probe_descriptors(c, img, H, W, SFD2_PREC_F32, ref)) return -1;
     const int rb0 = c->user_rb_inner, ch0 = c->user_comp_heads;      // (not what an earlier load's self-check left behind)
-    auto run = [&](int rbi, int chd, float &err) -> int {
+    // "c3b_plain" (round 6): -1 = try it and keep it when the probe stays inside the target with it, 1 = the caller wants it (every run below has it), 0 = off
+    const int forced_plain = c->user_c3b_plain == 1 ? 1 : 0;
+    auto run = [&](int plain, int rbi, int chd, float &err) -> int {
+        c->opt_c3b_plain = plain;
         c->opt_rb_inner = rbi;
         c->opt_comp_heads = chd;
         if (probe_descriptors(c, img, H, W, SFD2_PREC_F16C, got)) return -1;
@@ -762,23 +771,30 @@ static int margin_selfcheck(sfd2_ctx *c, const float *img, int H, int W)
         return 0;
     };
     for (float &e : c->margin_err) e = -1.0f;
+    c->relax_err = -1.0f;
     c->margin_choice = 0;
-    int rc = run(rb0, ch0, c->margin_err[0]);
+    int rc = 0;
+    if (c->user_c3b_plain == -1) rc = run(1, rb0, ch0, c->relax_err);
+    if (rc == 0) rc = run(forced_plain, rb0, ch0, c->margin_err[0]);
+    if (forced_plain) c->relax_err = c->margin_err[0];
+    // the accuracy options in order of their cost; a key the caller set explicitly is reported, not overridden
+    const bool may_rb = !c->user_set_rb_inner && rb0 != 0, may_ch = !c->user_set_comp_heads && ch0 != 1;
     if (rc == 0 && c->margin_err[0] > SFD2_MARGIN_TARGET) {
-        rc = run(0, ch0, c->margin_err[1]);
-        c->margin_choice = 1;
-        if (rc == 0 && c->margin_err[1] > SFD2_MARGIN_TARGET) {
-            rc = run(rb0, 1, c->margin_err[2]);
-            c->margin_choice = 2;
-            if (rc == 0 && c->margin_err[2] > SFD2_MARGIN_TARGET) {
-                rc = run(0, 1, c->margin_err[3]);
-                c->margin_choice = 3;
-            }
-        }
+        bool ok = false;
+        if (may_rb) { rc = run(forced_plain, 0, ch0, c->margin_err[1]); c->margin_choice = 1; ok = rc == 0 && c->margin_err[1] <= SFD2_MARGIN_TARGET; }
+        if (rc == 0 && !ok && may_ch) { rc = run(forced_plain, rb0, 1, c->margin_err[2]); c->margin_choice = 2; ok = rc == 0 && c->margin_err[2] <= SFD2_MARGIN_TARGET; }
+        if (rc == 0 && !ok && may_rb && may_ch) { rc = run(forced_plain, 0, 1, c->margin_err[3]); c->margin_choice = 3; }
     }
-    if (rc) { c->opt_rb_inner = rb0; c->opt_comp_heads = ch0; c->margin_choice = -1; return -1; }
+    if (rc) { c->opt_rb_inner = rb0; c->opt_comp_heads = ch0; c->opt_c3b_plain = forced_plain; c->margin_choice = -1; return -1; }
     c->opt_rb_inner = (c->margin_choice & 1) ? 0 : rb0;
     c->opt_comp_heads = (c->margin_choice & 2) ? 1 : ch0;
+    // conv3b without its correction chunks only where the probe says the checkpoint has the room: the options as set are inside the target AND stay inside with it
+    c->opt_c3b_plain = (forced_plain || (c->user_c3b_plain == -1 && c->margin_choice == 0 && c->relax_err >= 0.0f && c->relax_err <= SFD2_MARGIN_TARGET)) ? 1 : 0;
+    c->margin_done = true;
+    static const bool verbose = sfd2_env("SFD2_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "sfd2: f16c self-check: probe error %.2e (with c3b_plain %.2e, target %.1e) -> rb_inner %d, comp_heads %d, c3b_plain %d\n",
+                c->margin_err[0], c->relax_err, SFD2_MARGIN_TARGET, c->opt_rb_inner, c->opt_comp_heads, c->opt_c3b_plain);
     graphs_release(c);
     return reset_range_records(c);      // (the probe's maxima are not the caller's images')
 }
@@ -792,13 +808,21 @@ extern "C" int sfd2_get_margin_status(sfd2_ctx *c, float *errs4, int *choice, fl
     return 0;
 }
 
+extern "C" int sfd2_get_relax_status(sfd2_ctx *c, float *err_plain, int *c3b_plain)
+{
+    if (!c) return fail("sfd2_get_relax_status: null argument");
+    if (err_plain) *err_plain = c->relax_err;
+    if (c3b_plain) *c3b_plain = c->opt_c3b_plain;
+    return 0;
+}
+
 // The built-in probe: 192 x 256, half white noise and half a blocky low-frequency field (like the synthetic images of the tests), from
 // a fixed xorshift stream -- what sfd2_load_weights calibrates on when nothing better has been shown to the context yet.  A network
 // with BatchNorm after every conv keeps its activations at the same order of magnitude on any image; the envelope is 2^12 wide.
-static int calibrate_on_probe(sfd2_ctx *c)
+static void probe_image(std::vector<float> &img, int &H, int &W)
 {
-    const int H = 192, W = 256;
-    std::vector<float> img((size_t)3 * H * W);
+    H = 192; W = 256;
+    img.resize((size_t)3 * H * W);
     unsigned int s = 0x9E3779B9u;
     auto rnd = [&]() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return (float)(s >> 8) * (1.0f / 16777216.0f); };
     std::vector<float> coarse((size_t)3 * (H / 16) * (W / 16));
@@ -807,8 +831,10 @@ static int calibrate_on_probe(sfd2_ctx *c)
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x)
                 img[((size_t)ch * H + y) * W + x] = 0.5f * rnd() + 0.5f * coarse[((size_t)ch * (H / 16) + y / 16) * (W / 16) + x / 16];
-    int rc = calibrate_impl(c, img.data(), 0, H, W, 0);
-    if (rc == 0 && c->opt_auto_margin) rc = margin_selfcheck(c, img.data(), H, W);
+}
+
+static void release_probe_workspace(sfd2_ctx *c)
+{
     // the probe's fp32 parity workspace (every activation in its own fp32 buffer) is of no use to a throughput context: give it back
     // (a context that runs SFD2_PREC_F32 / F16X3 allocates what its own geometry needs on its first call)
     DevBuf *f32ws[] = {&c->g1a, &c->g1b, &c->g2a, &c->g2b, &c->g3a, &c->g3b, &c->gpa0_o, &c->gpa_o, &c->gda0_o, &c->gda_o};
@@ -816,5 +842,32 @@ static int calibrate_on_probe(sfd2_ctx *c)
     for (DevBuf *b : f32ws) b->release();
     for (int b = 0; b < 3; ++b) { c->grt1[b].release(); c->grt2[b].release(); c->gro[b].release(); }
     c->acts.clear();            // (they named those buffers)
+}
+
+// The self-check belongs to SFD2_PREC_F16C: a context in another precision does not pay for it at load -- it runs when the
+// precision is switched to F16C later (sfd2_set_precision), on the same probe
+int sfd2_margin_selfcheck_if_pending(sfd2_ctx *c)
+{
+    if (!c->weights_loaded || !c->opt_auto_margin || !c->margin_pending || c->precision != SFD2_PREC_F16C) return 0;
+    c->margin_pending = false;
+    std::vector<float> img;
+    int H, W;
+    probe_image(img, H, W);
+    const int rc = margin_selfcheck(c, img.data(), H, W);
+    release_probe_workspace(c);
+    return rc;
+}
+
+static int calibrate_on_probe(sfd2_ctx *c)
+{
+    int H, W;
+    std::vector<float> img;
+    probe_image(img, H, W);
+    int rc = calibrate_impl(c, img.data(), 0, H, W, 0);
+    if (rc == 0 && c->opt_auto_margin) {
+        if (c->precision == SFD2_PREC_F16C) rc = margin_selfcheck(c, img.data(), H, W);
+        else c->margin_pending = true;
+    }
+    release_probe_workspace(c);
     return rc;
 }

@@ -640,6 +640,17 @@ void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, i
                          int Ho, int Wo, const half_t *zero_page, int sbyte, const float *shift_sa6, unsigned int *range, int fmt6)
 {
     const int sa = (sbyte & 255) * 0x01010101;
+    // option "c3b_plain": no corr plane on one side.  Plain input (conv3b): the K loop ends with the hi chunks, the epilogue still writes the output's corr
+    // bytes (fmt6 bit 3: the three-byte trunk form).  Plain output (conv3a, its corr plane having no reader): fp6 x fp6 correction chunks, fp16 epilogue.
+    if (!in_c && out_c) {
+        if (fmt6 & 8) launch_pp_t<1, 1, 0, 2 | 256>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
+        else launch_pp_t<1, 1, 0, 2>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
+        return;
+    }
+    if (in_c && !out_c && shift_sa6 && (fmt6 & 1)) {
+        launch_pp_t<1, 1, 0, 1 | 16 | 32>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
+        return;
+    }
     // shift_sa6 != null: wpk's corr rows are fp6 strings and shift_sa6 = [shift[CoutP] | the rows' scale bytes as ints [CoutP]]
     if (in_c && out_c && shift_sa6 && fmt6 != 0) {      // fp6 corr records: bit 0 of fmt6 = the input's, bit 1 = the output's (filters: the (w, lo'_w) strings)
         if ((fmt6 & 3) == 3) launch_pp_t<1, 1, 0, 3 | 16 | 32 | 64>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
@@ -661,7 +672,6 @@ void launch_conv3x3_pp_c(hipStream_t st, const half_t *in, const half_t *in_c, i
     if (in_c && out_c && shift_sa6) launch_pp_t<1, 1, 0, 19>(st, in, H, W, Cin, wpk, scale, shift_sa6, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
     else if (in_c && out_c) launch_pp_t<1, 1, 0, 3>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
     else if (in_c) launch_pp_t<1, 1, 0, 1>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa);
-    else launch_pp_t<1, 1, 0, 2>(st, in, H, W, Cin, wpk, scale, shift, CoutP, relu, out, Ho, Wo, zero_page, in_c, out_c, sa, range);
 }
 
 // SFD2_PREC_F16X3 on pre-split planes (hi = fp16(x), lo' = fp16((x - hi) * 2^11), x3_split's arithmetic): in / in_lo = the input's

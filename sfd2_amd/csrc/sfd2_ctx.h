@@ -170,6 +170,14 @@ struct sfd2_ctx {
                                        // SFD2_PREC_F32 pass it runs anyway and, above SFD2_MARGIN_TARGET, turns on the accuracy options that bring it back (api_weights.hip)
     float margin_err[4] = {-1.0f, -1.0f, -1.0f, -1.0f};   // probe error with the options as set / rb_inner = 0 / comp_heads = 1 / both (-1: not measured)
     int margin_choice = -1;            // which of the four the context now runs (-1: no self-check has run)
+    int opt_c3b_plain = 0;             // effective: conv3b (SFD2_PREC_F16C) runs its K loop over the hi plane of conv3a's output only -- no correction chunks (the
+                                       // output's corr bytes still come from the fp32 accumulators) -- and conv3a then writes no corr plane.  -62 us of 184 at 1600x1200
+                                       // for ~ x 1.4 on the descriptor error (tools/relax_study.py), so it is never on unverified:
+    int user_c3b_plain = -1;           // sfd2_set_option "c3b_plain": -1 (default) = on only when the load-time self-check measured the probe inside SFD2_MARGIN_TARGET
+                                       // WITH it (option "auto_margin"; off otherwise), 1 = on, 0 = off
+    bool margin_done = false, margin_pending = false;   // the self-check ran on the loaded weights / waits for the context to enter SFD2_PREC_F16C
+    float relax_err = -1.0f;           // the probe's error with "c3b_plain" on and the other options as set (-1: not measured)
+    bool user_set_rb_inner = false, user_set_comp_heads = false;   // the caller set the key explicitly: the self-check reports, but does not override it
     int user_rb_inner = 2, user_comp_heads = 0;   // what sfd2_set_option last asked for: the self-check of a LATER sfd2_load_weights starts from these, not from its own earlier choice
     int opt_x3_desc16 = 0;             // sfd2_set_option "x3_desc16": SFD2_PREC_F16X3 on sfd2_extract with the DESCRIPTOR branch (convDa.0, convDa.3 at the sampled corners,
                                        // convDb) in plain fp16 on the backbone output's hi plane: the key points are this mode's own, the descriptors carry the
@@ -298,6 +306,7 @@ int read_range_status(sfd2_ctx *c, sfd2_range_status *out, int reset);
 // (the device words are folded into the context's history and cleared), 0 = fine / not applicable, -1 = error
 int range_wants_fallback(sfd2_ctx *c);
 int range_fold_before_sync_extract(sfd2_ctx *c);        // earlier asynchronous calls' maxima -> device-side history, running words cleared (no host sync)
+int sfd2_margin_selfcheck_if_pending(sfd2_ctx *c);    // api_weights.hip: the F16C self-check of a context loaded in another precision
 int reset_range_records(sfd2_ctx *c);                   // the exponents changed: running words, device and host history cleared
 struct FallbackScope {      // the repeat: strict arithmetic, no recursion
     sfd2_ctx *c; int prec;
