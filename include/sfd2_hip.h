@@ -81,7 +81,7 @@ typedef struct {
     int64_t n_candidates; /* N0 after NMS + threshold + border of the last extract          */
 } sfd2_timings;
 
-int sfd2_version(void);   /* 100 = rounds 1-4; 105 adds sfd2_extract_record_async, sfd2_desc_pack and host outputs with SFD2_FLAG_ASYNC; 106 adds sfd2_get_margin_status; 107 adds sfd2_get_relax_status (option "c3b_plain") */
+int sfd2_version(void);   /* 100 = rounds 1-4; 105 adds sfd2_extract_record_async, sfd2_desc_pack and host outputs with SFD2_FLAG_ASYNC; 106 adds sfd2_get_margin_status; 107 adds sfd2_get_relax_status (option "c3b_plain"); 108 adds sfd2_get_option */
 const char *sfd2_last_error(void);
 
 int sfd2_ctx_create(int device, sfd2_ctx **out);
@@ -194,6 +194,10 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *               differ by fp32 summation order only.
  * Unknown keys are an error. */
 int sfd2_set_option(sfd2_ctx *ctx, const char *key, int value);
+/* (version 108) What the context runs with for a key of sfd2_set_option: the value last set, or, for the keys the load-time self-check decides
+ * ("rb_inner", "comp_heads", "c3b_plain"), its choice.  The reference has no counterpart (one fp32 arithmetic, nets/sfd2.py:313-326); a caller that keeps
+ * several contexts per GPU copies these from the first so that all of them compute the same bits (sfd2_amd/model.py replica()). */
+int sfd2_get_option(sfd2_ctx *ctx, const char *key, int *value);
 
 /* ResSegNetV2.det (nets/sfd2.py:313-354).  x: [3][H][W] fp32, normalised image
  * (pass SFD2_FLAG_IMG_NORMALISED) or raw [0,1] RGB (normalised on the fly).

@@ -82,7 +82,7 @@ EXPORTS = [
     "sfd2_get_layer_timings", "sfd2_set_precision", "sfd2_extract_spp", "sfd2_nms_fast",
     "sfd2_set_profile_filter", "sfd2_extract_multiscale", "sfd2_set_option", "sfd2_extract_match", "sfd2_preprocess", "sfd2_extract_spp_levels", "sfd2_match_segments",
     "sfd2_get_range_status", "sfd2_range_tensor_name", "sfd2_calibrate_range", "sfd2_get_act_exponents", "sfd2_set_act_exponents",
-    "sfd2_extract_record_async", "sfd2_desc_pack", "sfd2_get_margin_status", "sfd2_get_relax_status",
+    "sfd2_extract_record_async", "sfd2_desc_pack", "sfd2_get_margin_status", "sfd2_get_relax_status", "sfd2_get_option",
 ]
 
 _lib = None
@@ -144,6 +144,7 @@ def load():
     lib.sfd2_sync.argtypes = [vp]
     lib.sfd2_set_precision.argtypes = [vp, ci]
     lib.sfd2_set_option.argtypes = [vp, ctypes.c_char_p, ci]
+    lib.sfd2_get_option.argtypes = [vp, ctypes.c_char_p, pi]
     lib.sfd2_preprocess.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.sfd2_extract_match.argtypes = [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, ctypes.POINTER(DescSet), ci, ci,
                                        ctypes.POINTER(MatchConf), vp, vp]
@@ -163,8 +164,8 @@ def load():
     lib.sfd2_desc_pack.argtypes = [vp, ctypes.POINTER(DescSet), ci, vp, ci]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the .so lacks a declared symbol
-    if lib.sfd2_version() < 107:
-        raise RuntimeError(f"{LIB_PATH} is version {lib.sfd2_version()}, this binding needs >= 107 (rebuild: __graft_entry__.build())")
+    if lib.sfd2_version() < 108:
+        raise RuntimeError(f"{LIB_PATH} is version {lib.sfd2_version()}, this binding needs >= 108 (rebuild: __graft_entry__.build())")
     _lib = lib
     return lib
 
@@ -248,6 +249,12 @@ class Context:
         check(self.lib.sfd2_set_option(self.h, key.encode(), int(value)))
         self.options.pop(key, None)
         self.options[key] = int(value)
+
+    def get_option(self, key):
+        """What the context runs with (sfd2_get_option): the value last set or, for rb_inner / comp_heads / c3b_plain, the load-time self-check's choice."""
+        v = ctypes.c_int(0)
+        check(self.lib.sfd2_get_option(self.h, key.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def sync(self):
         check(self.lib.sfd2_sync(self.h))

@@ -13,7 +13,7 @@ std::atomic<unsigned long long> g_alloc_gen{0};
 thread_local int g_sfd2_cu_limit = 0;       // set per network pass from the context's option "cu_limit" (sfd2_internal.h)
 
 // ------------------------------------------------------------------------------------------ basics
-extern "C" int sfd2_version(void) { return 107; }   // 107: + sfd2_get_relax_status (option c3b_plain); 105: + sfd2_extract_record_async, sfd2_desc_pack, SFD2_FLAG_ASYNC with host outputs (round 5); 106: + sfd2_get_margin_status
+extern "C" int sfd2_version(void) { return 108; }   // 108: + sfd2_get_option; 107: + sfd2_get_relax_status (option c3b_plain); 105: + sfd2_extract_record_async, sfd2_desc_pack, SFD2_FLAG_ASYNC with host outputs (round 5); 106: + sfd2_get_margin_status
 extern "C" const char *sfd2_last_error(void) { return g_err.c_str(); }
 
 extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
@@ -124,6 +124,27 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "rb_inner") { c->opt_rb_inner = c->user_rb_inner = value < 0 ? 0 : (value > 2 ? 2 : value); c->user_set_rb_inner = true; }
     else return fail("sfd2_set_option: unknown key '" + k + "'");
     return 0;
+}
+
+// What the context RUNS with for a key of sfd2_set_option (version 108): the value last set, or -- for the keys the load-time self-check of
+// SFD2_PREC_F16C decides ("rb_inner", "comp_heads", "c3b_plain") -- its choice.  A second context that is to compute the same bits as this one copies
+// these instead of replaying what the caller asked for (sfd2_amd/model.py replica()).
+extern "C" int sfd2_get_option(sfd2_ctx *c, const char *key, int *value)
+{
+    if (!c || !key || !value) return fail("sfd2_get_option: null argument");
+    const std::string k(key);
+    const struct { const char *name; int v; } tab[] = {
+        {"fuse", c->fuse}, {"fuse_det", c->fuse_det}, {"alias", c->opt_alias}, {"graphs", c->use_graphs}, {"branches", c->opt_branches},
+        {"fuse_post", c->opt_fuse_post}, {"sparse_desc", c->opt_sparse_desc}, {"sparse_da3", c->opt_sparse_da3}, {"cu_limit", c->opt_cu_limit},
+        {"auto_range", c->opt_auto_range}, {"range_fallback", c->opt_range_fallback}, {"x3_pp", c->opt_x3_pp}, {"x3_desc16", c->opt_x3_desc16},
+        {"auto_margin", c->opt_auto_margin}, {"fp6_filters", c->opt_fp6_filters}, {"fp6_acts", c->opt_fp6_acts}, {"s2d", c->opt_s2d},
+        {"trunk_r1", c->opt_trunk_r1}, {"fuse_pb", c->opt_fuse_pb}, {"generic_c", c->opt_generic_c}, {"comp_rb", c->opt_comp_rb},
+        {"no_rf_c", c->opt_no_rf_c}, {"comp_heads", c->opt_comp_heads}, {"c3b_plain", c->opt_c3b_plain}, {"comp_det", c->opt_comp_det},
+        {"fuse_rb23", c->opt_fuse_rb23}, {"rb_inner", c->opt_rb_inner},
+    };
+    for (const auto &e : tab)
+        if (k == e.name) { *value = e.v; return 0; }
+    return fail("sfd2_get_option: unknown key '" + k + "'");
 }
 
 extern "C" int sfd2_sync(sfd2_ctx *c)

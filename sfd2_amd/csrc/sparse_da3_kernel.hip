@@ -112,6 +112,7 @@ void sparse_da3_kernel(const half_t *__restrict__ fmap /*convDa.0's output [hc][
 
     if (tid < SD_KP) {
         int x0, y0;
+        if (k0 + tid >= n) kpx = kpy = 0.0f;        // a row beyond the count holds stale or uninitialised bits: no float -> int conversion of those
         sd_corner(kpx, kpy, half_w, half_h, hc, wc, x0, y0);
         geo[2 * tid] = x0;
         geo[2 * tid + 1] = y0;

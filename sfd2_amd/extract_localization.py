@@ -230,8 +230,10 @@ def _extract_pipelined(model, extractor, conf, images, indices, tag, store, name
     def write(job):
         idx, name, original_size, size, arrays, slot = job
         if slot is not None:
-            arrays = slot_arrays(slot)
-            ax.release(slot)
+            try:
+                arrays = slot_arrays(slot)
+            finally:
+                ax.release(slot)
         kp, sc, de = arrays
         pred = {'keypoints': rescale_keypoints(kp, original_size, size), 'descriptors': de.transpose(), 'scores': sc,
                 'image_size': original_size}
@@ -243,7 +245,11 @@ def _extract_pipelined(model, extractor, conf, images, indices, tag, store, name
         indices = [i for i in indices if str(images.paths[i]).find(tag) >= 0]
     pf = OrderedPrefetch(load, indices, num_workers, window=num_workers + 2,
                          claim=(lambda: pool.acquire(block=False)) if pool is not None else None)
-    wp = WriterPool(write, workers=writers, maxsize=4 * writers)
+    def drop(job):                  # a job queued behind a failed write: its slot still goes back (the producer may be waiting for one)
+        if job[5] is not None:
+            ax.release(job[5])
+
+    wp = WriterPool(write, workers=writers, maxsize=4 * writers, on_drop=drop)
 
     def drain_one():
         slot = ax.finish()

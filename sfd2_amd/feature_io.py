@@ -154,8 +154,9 @@ class _PackGroup:
 
 class PackStore:
     """``<path>/data.bin`` (every dataset's bytes, 64-byte aligned, append-only) + ``<path>/index.jsonl`` (one line per
-    write: group name and its datasets' dtype / shape / offset).  A group exists once its index line is on disk, so a
-    killed writer leaves a readable store (trailing data without a line is ignored).  The h5py.File subset the pipelines
+    write: group name and its datasets' dtype / shape / offset).  A group exists once its index line is on disk, and the data
+    file is flushed before a line is written, so a killed writer leaves a readable store: trailing data without a line is ignored,
+    and on open the index ends at the first line that is torn or names bytes beyond the end of data.bin (later lines are dropped with it).  The h5py.File subset the pipelines
     use -- create_group / __getitem__ / __contains__ / keys / close / context manager -- plus write_group(name, {key:
     array}) (one lock round, one write() per dataset, one index line): what the writer threads of the pipelined drivers
     call.  Thread-safe; reads go through ONE shared read-only memory map (remapped when the file has grown)."""
@@ -180,12 +181,20 @@ class PackStore:
         self._map_len = 0
         good = 0
         if os.path.exists(self._index_path):
+            data_size = os.path.getsize(self._data_path) if os.path.exists(self._data_path) else 0
             with open(self._index_path, "r") as fh:
                 for line in fh:
                     if not line.endswith("\n"):
                         break      # a torn last line: the write never completed
+                    try:
+                        rec = json.loads(line)
+                        ends = [int(off) + int(np.prod(shape, dtype=np.int64)) * np.dtype(dt).itemsize for dt, shape, off in rec["d"].values()]
+                    except (ValueError, KeyError, TypeError):
+                        break      # not a record: everything from here on is dropped
+                    if ends and max(ends) > data_size:
+                        break      # the line names bytes data.bin does not hold (a writer killed between the two files): appends are
+                                   # sequential, so every later line is beyond the end as well -- the store ends at the last whole group
                     good += len(line.encode())
-                    rec = json.loads(line)
                     g = self._groups.setdefault(rec["g"], {})
                     for key, (dt, shape, off) in rec["d"].items():
                         g[key] = (dt, tuple(shape), int(off))
@@ -224,6 +233,7 @@ class PackStore:
                 self._end += a.nbytes + pad
                 rec[k] = (a.dtype.str, list(a.shape), off)
                 g[k] = (a.dtype.str, tuple(a.shape), off)
+            self._fd.flush()    # data first: an index line never reaches the OS ahead of the bytes it names
             self._fi.write(json.dumps({"g": name, "d": rec}, separators=(",", ":")) + "\n")
 
     def write_group(self, name, datasets):
@@ -265,6 +275,7 @@ class PackStore:
                     g[key] = (a.dtype.str, (int(a.shape[1]),), off)
                 self._groups[nm] = g
                 lines.append(json.dumps({"g": nm, "d": rec}, separators=(",", ":")))
+            self._fd.flush()    # data first, as in _append
             self._fi.write("\n".join(lines) + "\n")
 
     def create_group(self, name):

@@ -114,22 +114,28 @@ def _match_grouped(model, feats, store, pairs, rank, world, done, device=0, max_
 
     def write(job):
         ring, m, s, name0, members = job
-        ring.event.synchronize()
-        m16, s16 = m, s                            # already int16 / fp16 as stored (:114,118): the device did the casts
-        pairs = [names_to_pair(name0, name1) for _, name1 in members]
-        if hasattr(store, "write_rows"):
-            store.write_rows(pairs, {"matches0": m16[:len(pairs)], "matching_scores0": s16[:len(pairs)]})      # the query's pair groups as ONE append
-        else:
-            for i, pair in enumerate(pairs):
-                if hasattr(store, "write_group"):
-                    store.write_group(pair, {"matches0": m16[i], "matching_scores0": s16[i]})
-                else:
-                    write_matches(store, pair, m16[i], s16[i])
-        free.put(ring)                             # (the store has copied the rows: the pinned buffers may be overwritten)
+        try:
+            ring.event.synchronize()
+            m16, s16 = m, s                            # already int16 / fp16 as stored (:114,118): the device did the casts
+            pairs = [names_to_pair(name0, name1) for _, name1 in members]
+            if hasattr(store, "write_rows"):
+                store.write_rows(pairs, {"matches0": m16[:len(pairs)], "matching_scores0": s16[:len(pairs)]})      # the query's pair groups as ONE append
+            else:
+                for i, pair in enumerate(pairs):
+                    if hasattr(store, "write_group"):
+                        store.write_group(pair, {"matches0": m16[i], "matching_scores0": s16[i]})
+                    else:
+                        write_matches(store, pair, m16[i], s16[i])
+        finally:
+            free.put(ring)                             # (the store has copied the rows -- or failed: either way the producer must not wait for this ring for ever)
         with lock:
             done.extend((idx, pair) for (idx, _), pair in zip(members, pairs))
 
-    wp = WriterPool(write, workers=1, maxsize=2, name="sfd2-match-writer")
+    def drop(job):                                     # queued behind a failed write: not written, its ring still goes back
+        job[0].event.synchronize()
+        free.put(job[0])
+
+    wp = WriterPool(write, workers=1, maxsize=2, name="sfd2-match-writer", on_drop=drop)
     db_arrays = {}
     try:
         for u, (name0, members) in enumerate(units):

@@ -17,6 +17,9 @@ except Exception:  # pragma: no cover
     torch = None
 
 
+_SELFCHECK_KEYS = ("rb_inner", "comp_heads", "c3b_plain")     # decided by the load-time self-check of 'f16c' unless the caller set them
+
+
 def _is_torch(x):
     return torch is not None and isinstance(x, torch.Tensor)
 
@@ -58,6 +61,7 @@ class ResSegNetV2:
         self._sd = None
         self._ctx = None
         self._device = 0
+        self._weights_gen = 0
 
     # -- nn.Module-like plumbing the reference drivers call (extract_localization.py:208-226)
     def eval(self):
@@ -86,6 +90,7 @@ class ResSegNetV2:
         if isinstance(sd, dict) and isinstance(sd.get("model"), dict):  # whole checkpoint {'model': sd, 'epoch': ..}
             sd = sd["model"]
         self._sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
+        self._weights_gen += 1          # lanes() rebuilds its replicas for new weights
         if self._ctx is not None:
             self._ctx.load_weights(self._sd)
         return self
@@ -106,25 +111,40 @@ class ResSegNetV2:
         return self._ensure_ctx()
 
     def lanes(self, n):
-        """[self, replica, ...]: n contexts for the pipelined driver, the replicas made once and kept (a replica costs a weight upload, the
-        packing kernels and the load-time probes: ~0.3 s, which a driver called per image directory must not pay every time)."""
+        """[self, replica, ...]: n contexts for the pipelined driver, the replicas made once and kept (a replica costs a weight upload and the
+        packing kernels: ~0.3 s, which a driver called per image directory must not pay every time).  Kept replicas are checked on every call:
+        new weights on this model (load_state_dict) rebuild them; options set and activation exponents changed since (set_option, calibrate_range,
+        set_act_exponents on the context) are copied over, so that results never depend on the lane."""
         have = getattr(self, "_lane_models", None) or []
+        src = self._ensure_ctx()
+        if have and getattr(self, "_lane_gen", None) != self._weights_gen:
+            for r in have:                          # replicas of the previous weights
+                r._ctx.close()
+            have = []
         while len(have) < n - 1:
             have.append(self.replica())
-        self._lane_models = have
-        mine = self._ensure_ctx().options
-        for r in have:                              # options set on this context since the replica was made
+        self._lane_models, self._lane_gen = have, self._weights_gen
+        mine = src.options
+        exps, _ = src.act_exponents()
+        for r in have:
             theirs = r._ctx.options
-            for k, v in mine.items():
-                if theirs.get(k) != v:
+            for k, v in mine.items():               # options set on this context since the replica was made
+                if theirs.get(k) != v and k != "auto_margin":
                     r._ctx.set_option(k, v)
+            for k in _SELFCHECK_KEYS:               # what the source RUNS with (its load-time self-check's choice, or a later set_option)
+                v = src.get_option(k)
+                if r._ctx.get_option(k) != v:
+                    r._ctx.set_option(k, v)
+            if not np.array_equal(r._ctx.act_exponents()[0], exps):
+                r._ctx.set_act_exponents(exps)
         return [self] + have[:max(0, n - 1)]
 
     def replica(self):
         """A second context with the same weights, precision and activation exponents on the same device: another HIP stream
         for the pipelined driver (two images in flight fill the units one image's kernels leave idle).
-        The options set on this model's context so far are replayed on the replica BEFORE its weights are loaded (so that "auto_margin" / "auto_range"
-        act there as they did here) -- results do not depend on the lane; lanes() re-synchronises options set later."""
+        The options set on this model's context so far are replayed on the replica; the keys the load-time self-check of 'f16c' decides
+        (rb_inner, comp_heads, c3b_plain) are COPIED from what this context runs with (sfd2_get_option), not decided again: the replica skips
+        the self-check (auto_margin off for its load) -- results do not depend on the lane; lanes() re-synchronises what changes later."""
         if self._sd is None:
             raise RuntimeError("load_state_dict() first")
         m = ResSegNetV2(outdim=self.outdim, require_feature=self.require_feature, require_stability=self.require_stability,
@@ -134,12 +154,13 @@ class ResSegNetV2:
         m._ctx = _lib.Context(self._device)
         m._ctx.set_precision(self.precision)
         for k, v in src.options.items():
-            m._ctx.set_option(k, v)
+            if k not in _SELFCHECK_KEYS:
+                m._ctx.set_option(k, v)
+        m._ctx.set_option("auto_margin", 0)
         m._sd = self._sd
         m._ctx.load_weights(self._sd)
-        for k, v in src.options.items():        # (the load-time self-check may have moved rb_inner / comp_heads: what the caller asked for wins, as on the source)
-            if k in ("rb_inner", "comp_heads"):
-                m._ctx.set_option(k, v)
+        for k in _SELFCHECK_KEYS:
+            m._ctx.set_option(k, src.get_option(k))
         exps, _ = src.act_exponents()
         m._ctx.set_act_exponents(exps)          # the same scaling of every stored tensor: bit-identical results on either context
         return m
@@ -163,7 +184,19 @@ class ResSegNetV2:
         return self
 
     def range_status(self, reset=False):
-        return self._ensure_ctx().range_status(reset)
+        """The context's range status; with lanes (pipelined driver) the union over all of them: per tensor the largest value any lane stored,
+        'saturated' / 'low' if any lane saw it, fallbacks summed."""
+        st = self._ensure_ctx().range_status(reset)
+        for r in getattr(self, "_lane_models", None) or []:
+            o = r._ctx.range_status(reset)
+            for name, t in o["tensors"].items():
+                mine = st["tensors"].setdefault(name, dict(t))
+                if t["max_stored"] > mine["max_stored"]:
+                    mine.update(max_stored=t["max_stored"], max_value=t["max_value"])
+            for key in ("saturated", "low"):
+                st[key] = [n for n in st["tensors"] if n in st[key] or n in o[key]]
+            st["fallbacks"] += o["fallbacks"]
+        return st
 
     # -- the operator (nets/sfd2.py:313-354)
     def det(self, x):

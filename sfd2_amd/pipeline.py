@@ -234,10 +234,13 @@ class OrderedPrefetch:
 
 
 class WriterPool:
-    """`workers` threads calling fn(job) for queued jobs; errors surface on the producer's next put() / on close()."""
+    """`workers` threads calling fn(job) for queued jobs; errors surface on the producer's next put() / on close().  After an error the
+    remaining jobs are not written but still handed to `on_drop(job)` (optional), which must give back whatever the job carries (an
+    extractor slot, a ring of pinned buffers): a producer waiting for one of those then wakes up and meets the error in its next put()
+    instead of waiting for ever."""
 
-    def __init__(self, fn, workers=1, maxsize=0, name="sfd2-writer"):
-        self._fn, self._q, self._err = fn, queue.Queue(maxsize), None
+    def __init__(self, fn, workers=1, maxsize=0, name="sfd2-writer", on_drop=None):
+        self._fn, self._q, self._err, self._on_drop = fn, queue.Queue(maxsize), None, on_drop
         self._threads = [threading.Thread(target=self._run, name=f"{name}-{i}", daemon=True) for i in range(max(1, workers))]
         for t in self._threads:
             t.start()
@@ -251,7 +254,13 @@ class WriterPool:
                 try:
                     self._fn(job)
                 except BaseException as e:      # noqa: BLE001 - handed to the producer
-                    self._err = e
+                    if self._err is None:
+                        self._err = e
+            elif self._on_drop is not None:
+                try:
+                    self._on_drop(job)
+                except BaseException:           # noqa: BLE001 - the first error is the one reported
+                    pass
 
     def put(self, job):
         if self._err is not None:

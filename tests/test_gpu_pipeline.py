@@ -497,6 +497,41 @@ def test_replica_lanes_carry_the_options_of_the_model(tmp_path, synth_sd):
     assert not np.array_equal(fa["m/00.png"]["descriptors"].__array__(), fc["m/00.png"]["descriptors"].__array__())   # (the option does change descriptors)
 
 
+def test_replica_lanes_follow_new_weights_exponents_and_the_selfcheck(tmp_path, synth_sd):
+    """cached replicas must not go stale.  (1) load_state_dict with other weights on a model whose lanes exist: the pipelined store (two lanes) still
+    equals the serial loop's.  (2) calibrate_range on the model afterwards: the replica takes the new exponents.  (3) The replica RUNS with what the source's
+    load-time self-check chose (sfd2_get_option), whatever the caller asked for before the load; range_status() covers every lane."""
+    from sfd2_amd import extract_localization as el
+    model = _model(synth_sd, "f16c")
+    items = [{"name": f"m/{i:02d}.png", "image": (synth.make_image(96, 128, 700 + i).transpose(1, 2, 0) * 255).astype(np.uint8), "original_size": (128, 96)}
+             for i in range(8)]
+    name, conf = next(iter(el.confs.items()))
+    conf = {**conf, "model": {**conf["model"], "max_keypoints": 120}}
+    me = (model, el.extract_resnet_return)
+    el.main(conf, items, tmp_path / "p0", model_and_extractor=me, num_workers=2, lanes=2)          # lanes exist now
+    old_replica = model.lanes(2)[1]
+    sd2 = synth.make_state_dict(3, family="student")                                                # (1) other weights (a family whose self-check moves options)
+    model.load_state_dict(sd2)
+    a = el.main(conf, items, tmp_path / "s1", model_and_extractor=me, num_workers=0)
+    b = el.main(conf, items, tmp_path / "p1", model_and_extractor=me, num_workers=2, lanes=2)
+    _stores_equal(b, a)
+    rep = model.lanes(2)[1]
+    assert rep is not old_replica
+    for k in ("rb_inner", "comp_heads", "c3b_plain"):                                               # (3)
+        assert rep.context.get_option(k) == model.context.get_option(k), k
+    model.calibrate_range(synth.make_image(96, 128, 3) * 4.0)                                       # (2) other exponents
+    e_src = model.context.act_exponents()[0]
+    assert not np.array_equal(e_src, rep.context.act_exponents()[0])
+    assert np.array_equal(model.lanes(2)[1].context.act_exponents()[0], e_src)
+    c = el.main(conf, items, tmp_path / "s2", model_and_extractor=me, num_workers=0)
+    d = el.main(conf, items, tmp_path / "p2", model_and_extractor=me, num_workers=2, lanes=2)
+    _stores_equal(d, c)
+    st = model.range_status()
+    assert set(st["tensors"]) == set(rep.context.range_status()["tensors"]) and st["saturated"] == []
+    for n, t in rep.context.range_status()["tensors"].items():
+        assert st["tensors"][n]["max_stored"] >= t["max_stored"]
+
+
 def fio_open(path):
     from sfd2_amd import feature_io as fio
     return fio.open_store(path, "r")

@@ -153,6 +153,50 @@ def test_writer_pool_surfaces_errors():
     assert 3 not in seen
 
 
+def test_writer_pool_error_does_not_strand_a_producer_waiting_for_its_resources():
+    """the producers of both drivers wait for a RESOURCE the writer gives back (an extractor slot, a ring of pinned buffers), not for the
+    queue.  After a failed write the queued jobs are dropped through on_drop, which returns what they carry: the producer wakes up and meets the
+    error in its next put() instead of hanging."""
+    import queue
+    from sfd2_amd.pipeline import WriterPool
+    free = queue.Queue()
+    for r in range(3):
+        free.put(r)
+    gate = threading.Event()
+
+    def fn(job):
+        gate.wait(5)                    # a slow writer: the producer gets ahead and runs out of rings
+        try:
+            if job[1] == 0:
+                raise OSError("No space left on device")
+        finally:
+            free.put(job[0])
+
+    wp = WriterPool(fn, workers=1, maxsize=2, on_drop=lambda job: free.put(job[0]))
+    out = {}
+
+    def producer():
+        try:
+            for j in range(50):
+                ring = free.get(timeout=10)         # (the drivers wait without a timeout; the test must not hang if the fix regresses)
+                if j == 2:
+                    gate.set()
+                out["held"] = ring
+                wp.put((ring, j))
+            out["err"] = None
+        except BaseException as e:                  # noqa: BLE001
+            out["err"] = e
+            free.put(out["held"])                   # the ring in the producer's hand when put() raised was never queued
+    t = threading.Thread(target=producer)
+    t.start()
+    t.join(20)
+    assert not t.is_alive(), "producer stranded"
+    assert isinstance(out["err"], OSError), out["err"]
+    with pytest.raises(OSError):
+        wp.close()
+    assert sorted(free.queue) == [0, 1, 2]          # every ring came back exactly once
+
+
 def _stub_extractor(model, img, topK, mask, conf_th, scales):
     a = np.asarray(img, dtype=np.float64).reshape(-1)
     n = 5 + int(a[:7].sum()) % 11
@@ -272,3 +316,40 @@ def test_packstore_write_rows_equals_single_appends(tmp_path):
                 x, y = ra[nm][k], rb[nm][k]
                 assert x.dtype == y.dtype and x.shape == y.shape
                 np.testing.assert_array_equal(x[()], y[()])
+
+
+def test_packstore_survives_a_writer_killed_mid_run(tmp_path):
+    """the data file is flushed before an index line is written, so a snapshot of the two files taken while a writer runs (= what a
+    killed process leaves) never holds a line whose bytes are missing; and a store whose index DOES run ahead of its data (written here by hand: the
+    state the unflushed writer could leave) is cut at the first such line on open -- those groups read as absent, not as later appends' bytes."""
+    import shutil
+    if fio.h5py is not None:
+        pytest.skip("h5py present: the stand-in is not used")
+    p = str(tmp_path / "k.h5")
+    st = fio.open_store(p, "w")
+    snaps = []
+    for i in range(400):
+        st.write_group(f"g{i}", {"v": np.full(5, i, dtype=np.int16)})
+        if i % 57 == 56:                       # what is on disk NOW, without a flush() or close() by the writer
+            d = str(tmp_path / f"snap{i}.pack"); os.makedirs(d)
+            # index first: a line on disk must name bytes that are on disk already
+            shutil.copy(os.path.join(st.path, "index.jsonl"), d); shutil.copy(os.path.join(st.path, "data.bin"), d)
+            snaps.append(d)
+    st.close()
+    for d in snaps:
+        rd = fio.PackStore(d, "r")
+        for nm in rd.keys():
+            assert rd[nm]["v"][()].tolist() == [int(nm[1:])] * 5
+        rd.close()
+    # an index that runs ahead of the data: cut, then appended to -- the dropped names stay absent
+    d = str(tmp_path / "ahead.pack"); shutil.copytree(st.path, d)
+    with open(os.path.join(d, "data.bin"), "r+b") as f:
+        f.truncate(64 * 388 + 3)               # group 388's bytes are torn, 389.. are gone
+    ap = fio.PackStore(d, "a")
+    assert "g387" in ap and "g388" not in ap and "g399" not in ap and len(ap.keys()) == 388
+    ap.write_group("new", {"v": np.full(5, -7, dtype=np.int16)})
+    ap.close()
+    rd = fio.PackStore(d, "r")
+    assert rd["new"]["v"][()].tolist() == [-7] * 5 and rd["g387"]["v"][()].tolist() == [387] * 5 and "g390" not in rd
+    with open(os.path.join(d, "index.jsonl")) as f:
+        assert len(f.readlines()) == 389
