@@ -241,6 +241,9 @@ def main():
     from sfd2_amd import _lib, synth
     if args.lib:
         _lib.use_library(args.lib)
+    # one process per GPU: the rank's threads (the pipeline leg's decoders / writers, torch's pools) stay on the socket its GPU hangs off
+    from sfd2_amd.sharding import pin_to_gpu_socket
+    placement = pin_to_gpu_socket(local_rank, local_world=world) if world > 1 else {"pinned": False, "why": "one rank: not pinned", "cpus": []}
     from sfd2_amd.model import ResSegNetV2
 
     sd = synth.make_state_dict(0)
@@ -379,6 +382,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_ranks(x):
+        """x of every rank, in rank order (the max is what `value` uses; min / max side by side show an imbalance at once)."""
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = x
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    dt_ranks = all_ranks(dt)
     dt = max_over_ranks(dt)
     n_matched = int((matches >= 0).sum().item()) if not args.extract_only else 0
 
@@ -477,13 +489,16 @@ def main():
     # parity modes, same workload, same bracket: precision 'f32' (exact fp32 on the f32-input MFMA) and 'f16x3' (the same
     # buffers and layer sequence with the convolutions on the fp16 matrix path in three passes); the matcher is unchanged:
     # its fp16 GEMM already meets the 1e-3 similarity tolerance
-    def parity_leg(mode):
+    def parity_leg(mode, headline_launch=False):
         for ln in lanes:
             ln.ctx.set_precision(mode)
         n_st = max(4, min(args.steps, 10))
+        replay = use_graphs and (args.strict_graphs or headline_launch)
+        if headline_launch:
+            n_st = max(n_st, min(args.steps, 40))
 
         def sstep(i):
-            if use_graphs and args.strict_graphs:      # the headline's launch mode (one hipGraph replay per image) for this precision too
+            if replay:      # the headline's launch mode (one hipGraph replay per image) for this precision too
                 return step(i)
             sl = lanes[i % len(lanes)]
             _lib.check(lib.sfd2_extract(sl.ctx.h, imgs[i % n_img].data_ptr(), 1, geo[i % n_img][0], geo[i % n_img][1], 0.001, TOPK, _lib.FLAG_ASYNC,
@@ -491,7 +506,7 @@ def main():
             if not args.extract_only:
                 _lib.check(lib.sfd2_match_batch(sl.ctx.h, ctypes.byref(sl.q), dbs, K_DB, 128, ctypes.byref(mconf),
                                                 sl.matches.data_ptr(), sl.mscores.data_ptr(), 1, _lib.FLAG_ASYNC))
-        for i in range((4 if (use_graphs and args.strict_graphs) else 2) * len(lanes)):      # (a geometry is captured the second time a context sees it)
+        for i in range((4 if replay else 2) * max(len(lanes), n_img)):      # (a geometry is captured the second time a context sees it)
             sstep(i)
         sync_all()
         barrier()
@@ -511,13 +526,18 @@ def main():
                "f16c": "descriptors <= 1e-3 asserted (measured <= 3.5e-4), key-point set IoU >= 0.985 (tests/test_gpu_f16c.py)"}[mode]
         return {"value": round(n_st * world / dst, 3), "unit": "images/sec", "ms_per_step": round(dst / n_st * 1e3, 3),
                 "steps": n_st, "dtype": mode, "streams_per_gpu": len(lanes),
-                "launch": "hipGraph replay per image (sfd2_extract_match)" if (use_graphs and args.strict_graphs) else "eager", "parity": par}
+                "launch": "hipGraph replay per image (sfd2_extract_match)" if replay else "eager", "parity": par}
 
-    strict = strict_x3 = strict_kp = approx = None
+    strict = strict_x3 = strict_kp = approx = north_star_strict = None
     if not args.no_strict:
         strict = parity_leg("f32")
         strict_x3 = parity_leg("f16x3")
         strict_kp = parity_leg("f16x3d")
+        # north_star read to the letter -- the reference's ordered key-point list (up to fp32 near-ties) AND descriptors within 1e-3 -- in the HEADLINE's
+        # launch mode (the same lanes, one hipGraph replay per image): what `value` would be if list-level parity were demanded of it
+        north_star_strict = parity_leg("f16x3d", headline_launch=True)
+        north_star_strict["contract"] = ("north_star as written: key-point list = the fp32 reference's up to near-ties (bit-identical to f16x3's), descriptors <= 1e-3; "
+                                         "`value` (f16c) meets the descriptor tolerance and the key-point SET (IoU >= 0.985, rank order asserted statistically)")
         approx = parity_leg("f16" if args.precision == "f16c" else "f16c")
 
     if rank == 0:
@@ -613,7 +633,9 @@ def main():
                         "selection_given_heat_map": "bit-exact", "asserted_in": "tests/test_gpu_parity.py"}),
             "single_stream": single, "sustained": sustained, "configs": configs_obj, "range_status": range_seen,
             "margin_selfcheck": (lanes[0].ctx.margin_status() if args.precision == "f16c" else None),
-            "strict_f32": strict, "strict_f16x3": strict_x3, "strict_kp_f16x3d": strict_kp,
+            "strict_f32": strict, "strict_f16x3": strict_x3, "strict_kp_f16x3d": strict_kp, "north_star_strict": north_star_strict,
+            "per_rank": {"ms_per_step": [round(d / args.steps * 1e3, 4) for d in dt_ranks], "min": round(min(dt_ranks) / args.steps * 1e3, 4),
+                         "max": round(max(dt_ranks) / args.steps * 1e3, 4), "cpu_placement_rank0": {k: placement[k] for k in ("pinned", "why")}},
             ("approx_f16" if args.precision == "f16c" else "f16c"): approx,
         }
         if world == 1 and not args.no_pipeline and not args.extract_only and not args.size and args.precision == "f16c":

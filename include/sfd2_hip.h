@@ -81,10 +81,14 @@ typedef struct {
     int64_t n_candidates; /* N0 after NMS + threshold + border of the last extract          */
 } sfd2_timings;
 
-int sfd2_version(void);   /* 100 = rounds 1-4; 105 adds sfd2_extract_record_async, sfd2_desc_pack and host outputs with SFD2_FLAG_ASYNC; 106 adds sfd2_get_margin_status; 107 adds sfd2_get_relax_status (option "c3b_plain"); 108 adds sfd2_get_option */
+int sfd2_version(void);   /* 100 = rounds 1-4; 105 adds sfd2_extract_record_async, sfd2_desc_pack and host outputs with SFD2_FLAG_ASYNC; 106 adds sfd2_get_margin_status; 107 adds sfd2_get_relax_status (option "c3b_plain"); 108 adds sfd2_get_option, sfd2_device_pci_bus_id */
 const char *sfd2_last_error(void);
 
 int sfd2_ctx_create(int device, sfd2_ctx **out);
+/* (version 108) PCI address "dddd:bb:dd.f" of a device and HIP's device count: what a one-process-per-GPU launcher needs to place a rank's decoder and writer
+ * threads on the socket its GPU hangs off (/sys/bus/pci/devices/<address>/local_cpulist; sfd2_amd/sharding.py).  The reference leaves CPU placement to its
+ * DataLoader worker processes (extract_localization.py:230-233).  out: at least 13 bytes; n_devices may be null. */
+int sfd2_device_pci_bus_id(int device, char *out, int len, int *n_devices);
 void sfd2_ctx_destroy(sfd2_ctx *ctx);
 /* HIP stream (hipStream_t) all of this context's kernels are launched on. */
 void *sfd2_get_stream(sfd2_ctx *ctx);

@@ -82,7 +82,7 @@ EXPORTS = [
     "sfd2_get_layer_timings", "sfd2_set_precision", "sfd2_extract_spp", "sfd2_nms_fast",
     "sfd2_set_profile_filter", "sfd2_extract_multiscale", "sfd2_set_option", "sfd2_extract_match", "sfd2_preprocess", "sfd2_extract_spp_levels", "sfd2_match_segments",
     "sfd2_get_range_status", "sfd2_range_tensor_name", "sfd2_calibrate_range", "sfd2_get_act_exponents", "sfd2_set_act_exponents",
-    "sfd2_extract_record_async", "sfd2_desc_pack", "sfd2_get_margin_status", "sfd2_get_relax_status", "sfd2_get_option",
+    "sfd2_extract_record_async", "sfd2_desc_pack", "sfd2_get_margin_status", "sfd2_get_relax_status", "sfd2_get_option", "sfd2_device_pci_bus_id",
 ]
 
 _lib = None
@@ -145,6 +145,7 @@ def load():
     lib.sfd2_set_precision.argtypes = [vp, ci]
     lib.sfd2_set_option.argtypes = [vp, ctypes.c_char_p, ci]
     lib.sfd2_get_option.argtypes = [vp, ctypes.c_char_p, pi]
+    lib.sfd2_device_pci_bus_id.argtypes = [ci, ctypes.c_char_p, ci, pi]
     lib.sfd2_preprocess.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.sfd2_extract_match.argtypes = [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, ctypes.POINTER(DescSet), ci, ci,
                                        ctypes.POINTER(MatchConf), vp, vp]

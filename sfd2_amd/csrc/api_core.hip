@@ -52,6 +52,21 @@ extern "C" int sfd2_ctx_create(int device, sfd2_ctx **out)
     return 0;
 }
 
+// Where a device sits on the host (version 108): its PCI address "dddd:bb:dd.f" (hipDeviceGetPCIBusId), *n_devices = HIP's device count.  What a one-process-
+// per-GPU launcher needs to keep a rank's decoder / writer threads on the socket its GPU hangs off (sfd2_amd/sharding.py pin_to_gpu_socket reads
+// /sys/bus/pci/devices/<address>/local_cpulist); the reference leaves placement to the DataLoader's worker processes (extract_localization.py:230-233).
+extern "C" int sfd2_device_pci_bus_id(int device, char *out, int len, int *n_devices)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail("sfd2_device_pci_bus_id: no HIP device available");
+    if (n_devices) *n_devices = ndev;
+    if (device < 0 || device >= ndev) return fail("sfd2_device_pci_bus_id: bad device index");
+    if (!out || len < 13) return fail("sfd2_device_pci_bus_id: buffer of at least 13 bytes needed");
+    HIPCHECK(hipDeviceGetPCIBusId(out, len, device));
+    return 0;
+}
+
 extern "C" void sfd2_ctx_destroy(sfd2_ctx *c)
 {
     if (!c) return;

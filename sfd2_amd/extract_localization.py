@@ -92,14 +92,58 @@ def _paste_rgbx(im, reserve):
         return None
 
 
+_CV2 = False         # not looked for yet
+
+
+def _cv2():
+    """The reference's decoder (cv2.imread, extract_localization.py:162-165) when it is importable; None -> PIL.  SFD2_DECODER = "pil" / "cv2" forces one
+    ("cv2" raises when the import fails); default "auto".  Both sit on libjpeg(-turbo); where the two builds differ in their IDCT / chroma upsampling the
+    pixels differ by a count or two, which is why the reference's own decoder is preferred wherever it exists."""
+    global _CV2
+    if _CV2 is False:
+        want = os.environ.get("SFD2_DECODER", "auto").lower()
+        _CV2 = None
+        if want != "pil":
+            try:
+                import cv2
+                _CV2 = cv2
+            except Exception as e:
+                if want == "cv2":
+                    raise RuntimeError("SFD2_DECODER=cv2 but cv2 is not importable") from e
+    return _CV2
+
+
+def _read_rgb_u8_cv2(cv2, path, reserve, rgbx):
+    """cv2.imread(path, IMREAD_COLOR) -> BGR; the channel reversal of :165 is a cvtColor straight into the caller's buffer (three- or four-byte pixels; cv2
+    releases the interpreter lock for both calls)."""
+    img = cv2.imread(str(path), cv2.IMREAD_COLOR)
+    if img is None:
+        raise ValueError(f'Cannot read image {str(path)}.')            # extract_localization.py:166-167
+    h, w = img.shape[:2]
+    if reserve is None:
+        return np.ascontiguousarray(img[:, :, ::-1])
+    if rgbx:
+        out = reserve(h * w * 4).reshape(h, w, 4)
+        res = cv2.cvtColor(img, cv2.COLOR_BGR2RGBA, dst=out)           # (the fourth byte is not read: SFD2_FLAG_IMG_U8_X)
+    else:
+        out = reserve(h * w * 3).reshape(h, w, 3)
+        res = cv2.cvtColor(img, cv2.COLOR_BGR2RGB, dst=out)
+    if res is not out and not np.shares_memory(res, out):              # (a cv2 that did not take dst)
+        np.copyto(out, res)
+    return out
+
+
 def _read_rgb_u8(path, reserve=None, rgbx=False):
     """The decoder: uint8 [H,W,3] RGB (the reference: cv2.imread(..., IMREAD_COLOR)[:, :, ::-1], :162-165).
     reserve(nbytes) -> writable uint8 buffer: the pixels are put there (the pipelined driver's pinned buffers).
     rgbx (with reserve): [H,W,4] RGBX when PIL allows it (_paste_rgbx), else [H,W,3]."""
+    cv2 = _cv2()
+    if cv2 is not None:
+        return _read_rgb_u8_cv2(cv2, path, reserve, rgbx)
     try:
         from PIL import Image
     except Exception as e:  # pragma: no cover
-        raise RuntimeError("no image decoder importable (PIL); pass decoded uint8 arrays instead of paths") from e
+        raise RuntimeError("no image decoder importable (cv2, PIL); pass decoded uint8 arrays instead of paths") from e
     try:
         with Image.open(path) as im:
             if im.mode != "RGB":
@@ -306,7 +350,7 @@ def _feed_of(model, data):
 
 
 def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precision="f16x3", world=1, rank=0,
-         barrier=None, model_and_extractor=None, num_workers=4, writers=2, depth=None, lanes=None):
+         barrier=None, model_and_extractor=None, num_workers=4, writers=2, depth=None, lanes=None, affinity=None):
     """extract_localization.py:221-279.  ``images``: an ImageDataset (decoded from files, resized per
     conf['preprocessing']) or any indexable / iterable of {'name', 'image': uint8 [H,W,3] RGB or float [3,H,W] in
     [0,1], 'original_size': (w, h)[, 'resize': (w, h)]}.  uint8 input is exact only together with the device resize
@@ -321,9 +365,13 @@ def main(conf, images, export_dir, state_dict=None, device=0, tag=None, precisio
     loop (_extract_pipelined: that many decoder threads, `depth` images in flight on the device (default: three per lane) over `lanes`
     contexts (HIP streams; default: 2 from 64 images on, else 1 -- the second context is made once per model, model.lanes), `writers` writer
     threads); 0: the reference's loop body strictly in turn per image.  Both write the same groups.
+    affinity: None (default) = with world > 1 the process pins itself, before its decoder / writer threads exist, to its share of the CPUs of the socket
+    GPU `device` hangs off (sharding.pin_to_gpu_socket; SFD2_CPU_AFFINITY=0 disables); True / False force it on / off.
     Returns the final store path (rank 0) or the part path (other ranks)."""
     from .feature_io import open_store, write_features
-    from .sharding import shard_indices
+    from .sharding import pin_to_gpu_socket, shard_indices
+    if affinity or (affinity is None and world > 1):
+        pin_to_gpu_socket(device, local_world=world if world > 1 else None, enable=True if affinity else None)
     if model_and_extractor is None:
         model, extractor = get_model(conf['model']['name'], weight_path=conf['model']['model_fn'],
                                      use_stability=conf['model']['use_stability'], state_dict=state_dict, device=device,

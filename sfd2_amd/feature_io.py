@@ -4,15 +4,20 @@ The reference writes one HDF5 group per image (extract_localization.py:266-270: 
 (N,2) f64, descriptors (128,N) f64, scores (N,) f64, image_size (2,)) and one group per pair
 (hloc/match_features.py:99-119: matches0 int16 (N,), matching_scores0 fp16 (N,)), and reads
 them back as ``f[name]['keypoints'].__array__()`` (it_loc/localize_cv2.py:571-574,
-hloc/triangulation.py:57-111).  h5py is a third-party dependency that this image does not
-carry: when it imports, the stores below ARE h5py files with exactly that layout; when it does
-not, the same names and arrays go behind the same mapping interface into a stand-in, so callers
-are written once.  Two stand-ins:
+hloc/triangulation.py:57-111).  The stores below ARE HDF5 files with exactly that layout wherever an HDF5 library
+exists: through h5py when it imports, otherwise through the HDF5 C library itself (h5lite.py: libhdf5 over ctypes -- this image
+carries the C library but not the binding).  ``open_store`` wraps either in H5Store, whose one addition to the h5py.File subset the
+pipelines use is that keys() lists the image / pair names (every group holding datasets, full path) instead of the top-level links.
+Where no HDF5 library exists, or on request (``standin=`` / SFD2_STORE=pack), the same names and arrays go behind the same mapping
+interface into a stand-in, so callers are written once.  Two stand-ins:
 
-  PackStore (default, ``<name>.pack/``)  one append-only data file + a text index, read back through
+  PackStore (``<name>.pack/``)  one append-only data file + a text index, read back through
       one memory map.  Written for the pipelined drivers: a 4 MB feature group is one write(), a
       pair's two small datasets cost microseconds instead of a zip archive each, and readers on
       several threads share the map (no per-group open / CRC pass).
+      HDF5 costs ~250 us per pair group in the library itself (one group + two datasets: ~4 k pairs/s, h5py or not), the pipelined
+      match driver produces 50-80 k pairs/s: a run that must not wait for its store writes a PackStore and converts afterwards
+      (tools/pack_to_h5.py, ``pack_to_h5`` below).
   NpzStore (``<name>.npzdir/``)  one ``.npz`` shard per group; what rounds 2-4 wrote, still read.
 """
 import json
@@ -334,30 +339,161 @@ class PackStore:
         self.close()
 
 
-STANDIN = "pack"     # what a '.h5' path becomes when h5py is not importable: "pack" (PackStore) or "npz" (NpzStore)
+class H5Store:
+    """An HDF5 file behind the stores' interface.  backend: the h5py module, or sfd2_amd.h5lite (same File / group / dataset surface).
+    create_group / write_group / write_rows / __getitem__ / __contains__ / close / context manager as the stand-ins; keys() = the names the
+    groups were written with (full paths of every group that holds datasets -- 'db/1.jpg' is HDF5 group '1.jpg' inside group 'db'), in
+    name order.  Thread-safe (one lock: neither libhdf5 nor an h5py.File is safe for concurrent use)."""
+    threadsafe_reads = True
+
+    def __init__(self, path, mode, backend):
+        self.path, self.mode, self._backend = str(path), mode, backend
+        self._lock = threading.RLock()
+        self._f = backend.File(self.path, mode)
+        self._names = None          # filled by the first keys()
+
+    def _walk(self):
+        if hasattr(self._f, "leaf_groups"):
+            return list(self._f.leaf_groups())
+        out = []
+
+        def visit(name, obj):
+            if hasattr(obj, "keys"):                      # a group
+                kids = list(obj.keys())
+                if not kids or any(not hasattr(obj[k], "keys") for k in kids):
+                    out.append(name)
+        self._f.visititems(visit)
+        return sorted(out)
+
+    def keys(self):
+        with self._lock:
+            if self._names is None:
+                self._names = set(self._walk())
+            return sorted(self._names)
+
+    def __contains__(self, name):
+        with self._lock:
+            return name in self._f
+
+    def __getitem__(self, name):
+        with self._lock:
+            if name not in self._f:
+                raise KeyError(name)
+            return self._f[name]
+
+    def create_group(self, name):
+        with self._lock:
+            if self.mode == "r":
+                raise IOError("store opened read-only")
+            g = self._f.create_group(name)
+            if self._names is not None:
+                self._names.add(name)
+            return g
+
+    def write_group(self, name, datasets):
+        with self._lock:
+            if hasattr(self._f, "write_group"):
+                if self.mode == "r":
+                    raise IOError("store opened read-only")
+                self._f.write_group(name, datasets)
+                if self._names is not None:
+                    self._names.add(name)
+                return
+            g = self.create_group(name)
+            for k, v in datasets.items():
+                g.create_dataset(k, data=v)
+
+    def write_rows(self, names, blocks):
+        """Row i of every [k, n] block becomes dataset `key` of group names[i] (PackStore.write_rows' contract; here one group at a time -- the format's cost)."""
+        arrs = {k: np.asarray(v) for k, v in blocks.items()}
+        if any(a.ndim != 2 or a.shape[0] != len(names) for a in arrs.values()):
+            raise ValueError("write_rows: every block must be [len(names), n]")
+        with self._lock:
+            for nm in names:
+                if nm in self._f:
+                    raise ValueError(f"Unable to create group (name already exists): {nm}")
+            if len(set(names)) != len(names):
+                raise ValueError("write_rows: duplicate group names")
+            for i, nm in enumerate(names):
+                self.write_group(nm, {k: a[i] for k, a in arrs.items()})
+
+    def flush(self):
+        with self._lock:
+            self._f.flush()
+
+    def close(self):
+        with self._lock:
+            self._f.close()
+            self.mode = "r"
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+STANDIN = "pack"     # the stand-in a '.h5' path becomes when no HDF5 library exists or one is asked for: "pack" (PackStore) or "npz" (NpzStore)
+STORE = os.environ.get("SFD2_STORE", "auto")     # "auto": HDF5 when a library exists, else STANDIN; "h5" (required); "pack" / "npz": that stand-in
+
+
+def hdf5_backend():
+    """h5py when it imports, else h5lite when the HDF5 C library loads, else None."""
+    if h5py is not None:
+        return h5py
+    from . import h5lite
+    return h5lite if h5lite.available() else None
 
 
 def open_store(path, mode="a", standin=None):
-    """``path`` ending in .h5 with h5py importable -> h5py.File (the reference's format).  Otherwise a stand-in at
-    ``path`` with the trailing .h5 replaced: a PackStore (<name>.pack, the default) or an NpzStore (<name>.npzdir,
-    ``standin="npz"``); reading picks whichever of the two exists."""
+    """``path`` ending in .h5 -> an HDF5 file (the reference's format) through h5py or, without it, the HDF5 C library (H5Store).  With no HDF5
+    library on the host, or with ``standin="pack"`` / ``"npz"`` (module default STORE, environment SFD2_STORE), a stand-in at ``path`` with the trailing
+    .h5 replaced: a PackStore (<name>.pack) or an NpzStore (<name>.npzdir).  Reading (mode "r") without an explicit choice picks whichever of the three
+    exists, the HDF5 file first.  A path ending in .pack / .npzdir names a stand-in directly."""
     path = str(path)
-    if h5py is not None and path.endswith(".h5"):
-        return h5py.File(path, mode)
     base = path[:-3] if path.endswith(".h5") else None
     if base is None:
         if path.endswith(".npzdir"):
             return NpzStore(path, mode)
         return PackStore(path, mode)
-    kind = standin or STANDIN
-    if mode == "r" and standin is None:
-        if not os.path.exists(base + ".pack") and os.path.isdir(base + ".npzdir"):
-            kind = "npz"
+    kind = standin or (STORE if STORE != "auto" else None)
+    backend = hdf5_backend() if kind in (None, "h5") else None
+    if kind == "h5" and backend is None:
+        raise RuntimeError("SFD2_STORE=h5 but neither h5py nor the HDF5 C library (sfd2_amd/h5lite.py) is available")
+    if mode == "r" and kind is None:
+        if backend is not None and os.path.isfile(path):
+            return H5Store(path, mode, backend)
+        if os.path.exists(base + ".pack"):
+            return PackStore(base + ".pack", mode)
+        if os.path.isdir(base + ".npzdir"):
+            return NpzStore(base + ".npzdir", mode)
+    if backend is not None:
+        return H5Store(path, mode, backend)
+    kind = kind or STANDIN
     if kind == "npz":
         return NpzStore(base + ".npzdir", mode)
     if kind != "pack":
         raise ValueError(f"unknown stand-in store {kind!r}")
     return PackStore(base + ".pack", mode)
+
+
+def pack_to_h5(src, dst, backend=None, progress=None):
+    """Every group of a stand-in store (PackStore / NpzStore directory) into an HDF5 file with the reference's layout: the hand-over of a fast run's
+    output to the reference's consumers (hloc/triangulation.py:57-111, it_loc/localize_cv2.py:677-680).  Returns the number of groups written."""
+    backend = backend or hdf5_backend()
+    if backend is None:
+        raise RuntimeError("no HDF5 library (h5py or libhdf5) on this host")
+    rd = NpzStore(src, "r") if str(src).endswith(".npzdir") else PackStore(src, "r")
+    n = 0
+    with H5Store(dst, "w", backend) as out:
+        for name in rd.keys():
+            g = rd[name]
+            out.write_group(name, {k: g[k].__array__() for k in g.keys()})
+            n += 1
+            if progress is not None and n % 1000 == 0:
+                progress(n)
+    rd.close()
+    return n
 
 
 def write_features(store, name, pred):

@@ -176,7 +176,7 @@ def _out_path(export_dir, features, conf, pairs_name, rank, world):
 
 
 def main(conf, pair_list, features, export_dir, pairs_name='pairs', world=1, rank=0, barrier=None, model=None,
-         grouped=None, device=0, cache_bytes=None, readers=4):
+         grouped=None, device=0, cache_bytes=None, readers=4, affinity=None):
     """hloc/match_features.py:48-123: ``pair_list`` holds the pairs file's lines ("name0 name1"),
     ``features`` the feature store's name inside export_dir (:52-54).  Skips pairs already matched in
     either order or already stored (:88-97), writes matches0 int16 / matching_scores0 fp16 per pair
@@ -191,7 +191,9 @@ def main(conf, pair_list, features, export_dir, pairs_name='pairs', world=1, ran
     launch per pair; shards by query group instead of by pair.  grouped=False is the reference's loop.  Same store."""
     import json
     from .feature_io import open_store, write_matches
-    from .sharding import shard_indices
+    from .sharding import pin_to_gpu_socket, shard_indices
+    if affinity or (affinity is None and world > 1):     # before the reader / writer threads exist (extract_localization.main has the same switch)
+        pin_to_gpu_socket(device, local_world=world if world > 1 else None, enable=True if affinity else None)
     if grouped is None:
         grouped = model is None and conf['model']['name'] == 'nearest_neighbor'
     if model is None:

@@ -71,6 +71,19 @@ def _compare(got, want, min_iou):
     assert dd <= DESC_TOL, dd
     assert iou >= min_iou, iou
     assert bad.mean() <= 0.005, bad.mean()
+    # ORDER of the list (asserted, not only recorded).  A stability-class flip multiplies one score by a class ratio and moves that point by
+    # thousands of ranks -- those points are the `bad` ones above, bounded at 0.5 %.  Among the others the two lists must agree as ordered lists: ranks taken
+    # among the common, un-flipped points; Spearman correlation >= 0.999 and no point further than max(8, n / 32) ranks from its place (measured at 4096 key
+    # points: <= 47; the score error of ~1e-2 relative against a score spacing of ~2e-4 relative per rank).
+    good = ~bad
+    if good.sum() >= 8:
+        ra = np.argsort(np.argsort(ia[good])).astype(np.float64)
+        rb = np.argsort(np.argsort(ib[good])).astype(np.float64)
+        n = ra.size
+        rho = 1.0 - 6.0 * float(((ra - rb) ** 2).sum()) / (n * (n * n - 1.0))
+        worst = int(np.abs(ra - rb).max())
+        assert rho >= 0.999, rho
+        assert worst <= max(8, n // 32), (worst, n)
     return iou, dd, shift, same_rank, len(common)
 
 

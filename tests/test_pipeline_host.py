@@ -11,11 +11,10 @@ import pytest
 from sfd2_amd import feature_io as fio
 
 
-def test_pack_store_layout_roundtrip_and_reopen(tmp_path):
+def test_pack_store_layout_roundtrip_and_reopen(tmp_path, monkeypatch):
     p = str(tmp_path / "feats-x.h5")
+    monkeypatch.setattr(fio, "STORE", "pack")          # the stand-in (the default is a real HDF5 file wherever an HDF5 library exists: test_h5_store_* below)
     st = fio.open_store(p, "a")
-    if fio.h5py is not None:
-        pytest.skip("h5py present: the stand-in is not used")
     assert isinstance(st, fio.PackStore) and st.path.endswith("feats-x.pack")
     g = st.create_group("db/1.jpg")
     g.create_dataset("keypoints", data=np.arange(8.).reshape(4, 2))
@@ -56,10 +55,12 @@ def test_pack_store_layout_roundtrip_and_reopen(tmp_path):
     assert fio.open_store(p, "w").keys() == []
 
 
-def test_pack_store_concurrent_writers_and_readers(tmp_path):
-    if fio.h5py is not None:
-        pytest.skip("h5py present")
-    st = fio.open_store(str(tmp_path / "m.h5"), "w")
+@pytest.mark.parametrize("kind", ["pack", "h5"])
+def test_store_concurrent_writers_and_readers(tmp_path, kind):
+    if kind == "h5" and fio.hdf5_backend() is None:
+        pytest.skip("no HDF5 library on this host")
+    st = fio.open_store(str(tmp_path / "m.h5"), "w", standin=kind)
+    assert isinstance(st, fio.PackStore if kind == "pack" else fio.H5Store)
 
     def work(t):
         for i in range(200):
@@ -78,8 +79,6 @@ def test_pack_store_concurrent_writers_and_readers(tmp_path):
 
 
 def test_open_store_reads_round4_npz_shards(tmp_path):
-    if fio.h5py is not None:
-        pytest.skip("h5py present")
     old = fio.open_store(str(tmp_path / "f.h5"), "w", standin="npz")
     fio.write_features(old, "a/b.jpg", {"keypoints": np.zeros((2, 2)), "image_size": np.array([3, 4])})
     old.close()
@@ -323,10 +322,8 @@ def test_packstore_survives_a_writer_killed_mid_run(tmp_path):
     killed process leaves) never holds a line whose bytes are missing; and a store whose index DOES run ahead of its data (written here by hand: the
     state the unflushed writer could leave) is cut at the first such line on open -- those groups read as absent, not as later appends' bytes."""
     import shutil
-    if fio.h5py is not None:
-        pytest.skip("h5py present: the stand-in is not used")
     p = str(tmp_path / "k.h5")
-    st = fio.open_store(p, "w")
+    st = fio.open_store(p, "w", standin="pack")
     snaps = []
     for i in range(400):
         st.write_group(f"g{i}", {"v": np.full(5, i, dtype=np.int16)})
@@ -353,3 +350,152 @@ def test_packstore_survives_a_writer_killed_mid_run(tmp_path):
     assert rd["new"]["v"][()].tolist() == [-7] * 5 and rd["g387"]["v"][()].tolist() == [387] * 5 and "g390" not in rd
     with open(os.path.join(d, "index.jsonl")) as f:
         assert len(f.readlines()) == 389
+
+
+def test_decoder_prefers_cv2_when_importable(tmp_path, monkeypatch):
+    """The reference decodes with cv2.imread (extract_localization.py:162-165); _read_rgb_u8 takes that decoder wherever it is importable and PIL otherwise
+    (VERDICT r5 #7).  cv2 is not in this image: a stand-in module with the three entry points used (imread / cvtColor / the constants) checks the branch --
+    same pixels, three- and four-byte forms, the caller's buffer, the ValueError of :166-167."""
+    import sys
+    import types
+    from PIL import Image
+    from sfd2_amd import extract_localization as el
+    rs = np.random.RandomState(3)
+    rgb = rs.randint(0, 256, (20, 30, 3)).astype(np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "a.png")
+    calls = []
+    fake = types.ModuleType("cv2")
+    fake.IMREAD_COLOR, fake.COLOR_BGR2RGB, fake.COLOR_BGR2RGBA = 1, 4, 2
+
+    def imread(path, flag):
+        calls.append(path)
+        try:
+            return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+        except OSError:
+            return None
+
+    def cvt(img, code, dst=None):
+        res = img[:, :, ::-1] if code == 4 else np.concatenate([img[:, :, ::-1], np.full(img.shape[:2] + (1,), 255, np.uint8)], axis=2)
+        if dst is not None and code == 4:
+            np.copyto(dst, res)
+            return dst
+        return np.ascontiguousarray(res)                                # (the four-byte form ignores dst: the copy path)
+    fake.imread, fake.cvtColor = imread, cvt
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    monkeypatch.setattr(el, "_CV2", False)
+    monkeypatch.delenv("SFD2_DECODER", raising=False)
+    try:
+        np.testing.assert_array_equal(el._read_rgb_u8(tmp_path / "a.png"), rgb)
+        buf = np.zeros(20 * 30 * 4, np.uint8)
+        out = el._read_rgb_u8(tmp_path / "a.png", reserve=lambda n: buf[:n])
+        assert np.shares_memory(out, buf) and out.shape == (20, 30, 3)
+        np.testing.assert_array_equal(out, rgb)
+        out4 = el._read_rgb_u8(tmp_path / "a.png", reserve=lambda n: buf[:n], rgbx=True)
+        assert np.shares_memory(out4, buf) and out4.shape == (20, 30, 4)
+        np.testing.assert_array_equal(out4[:, :, :3], rgb)
+        assert len(calls) == 3
+        (tmp_path / "bad.jpg").write_bytes(b"not an image")
+        with pytest.raises(ValueError, match="Cannot read image"):
+            el._read_rgb_u8(tmp_path / "bad.jpg")
+        monkeypatch.setattr(el, "_CV2", False)
+        monkeypatch.setenv("SFD2_DECODER", "pil")                       # forced back to PIL
+        np.testing.assert_array_equal(el._read_rgb_u8(tmp_path / "a.png"), rgb)
+        assert len(calls) == 4
+    finally:
+        el._CV2 = False
+
+
+def test_h5_store_is_a_real_hdf5_file_with_the_reference_layout(tmp_path):
+    """VERDICT r5 'what's missing' 2 / SURVEY 8f1: the stores ARE HDF5 files wherever an HDF5 library exists -- h5py, or the C library itself through
+    sfd2_amd/h5lite.py (this image has libhdf5 and no h5py).  Written through the stores' interface, then checked THREE ways: read back through the store,
+    through a second independent open of the file, and by HDF5's own h5dump (group nesting along '/', dataset names, shapes and types of
+    extract_localization.py:266-272 and hloc/match_features.py:108-119)."""
+    import shutil
+    import subprocess
+    backend = fio.hdf5_backend()
+    if backend is None:
+        pytest.skip("no HDF5 library on this host")
+    rs = np.random.RandomState(0)
+    pred = {"keypoints": rs.random_sample((17, 2)), "descriptors": rs.random_sample((128, 17)), "scores": rs.random_sample(17),
+            "image_size": np.array([160, 120])}
+    p = str(tmp_path / "feats.h5")
+    with fio.open_store(p, "w") as st:
+        assert isinstance(st, fio.H5Store)
+        fio.write_features(st, "db/1.jpg", pred)
+        fio.write_features(st, "query/day/2.jpg", {**pred, "scores": np.zeros((0,))})
+        with pytest.raises(ValueError, match="already exists"):
+            st.create_group("db/1.jpg")
+        assert "db/1.jpg" in st and "db/9.jpg" not in st and "nope/x" not in st
+        assert st.keys() == ["db/1.jpg", "query/day/2.jpg"]
+    assert os.path.isfile(p)
+    with open(p, "rb") as f:
+        assert f.read(8) == b"\x89HDF\r\n\x1a\n"                               # the HDF5 signature
+    rd = fio.open_store(p, "r")
+    assert isinstance(rd, fio.H5Store) and rd.keys() == ["db/1.jpg", "query/day/2.jpg"]
+    for k, v in pred.items():
+        got = rd["db/1.jpg"][k].__array__()
+        assert got.dtype == np.asarray(v).dtype and np.array_equal(got, v), k
+    assert rd["query/day/2.jpg"]["scores"].shape == (0,)
+    with pytest.raises(KeyError):
+        rd["db/2.jpg"]
+    with pytest.raises(IOError):
+        rd.write_group("x", {"v": np.zeros(2)})
+    rd.close()
+    # matches: int16 / fp16 as stored by the reference (hloc/match_features.py:114,118)
+    m = np.arange(-1, 16).astype(np.int64)
+    sc = rs.random_sample(17).astype(np.float32)
+    q = str(tmp_path / "matches.h5")
+    with fio.open_store(q, "w") as st:
+        fio.write_matches(st, "query-q1.jpg_db-1.jpg", m, sc)
+        st.write_rows(["a_b", "c_d"], {"matches0": np.full((2, 64), 7, np.int16), "matching_scores0": np.full((2, 64), 0.5, np.float16)})
+    with fio.open_store(q, "a") as st:                                          # append to an existing file
+        st.write_group("e_f", {"matches0": np.zeros(3, np.int16), "matching_scores0": np.zeros(3, np.float16)})
+        g = st["query-q1.jpg_db-1.jpg"]
+        assert g["matches0"].dtype == np.int16 and g["matching_scores0"].dtype == np.float16
+        np.testing.assert_array_equal(g["matches0"][()], m.astype(np.int16))
+        np.testing.assert_array_equal(g["matching_scores0"][()], sc.astype(np.float16))
+        assert st.keys() == ["a_b", "c_d", "e_f", "query-q1.jpg_db-1.jpg"] and st["c_d"]["matches0"][5] == 7
+    h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if os.path.exists("/opt/conda/bin/h5dump") else None)
+    if h5dump:
+        out = subprocess.run([h5dump, "-H", p], capture_output=True, text=True, check=True).stdout
+        flat = " ".join(out.split())
+        assert 'GROUP "db" { GROUP "1.jpg" {' in flat and 'GROUP "query" { GROUP "day" { GROUP "2.jpg" {' in flat
+        assert 'DATASET "descriptors" { DATATYPE H5T_IEEE_F64LE DATASPACE SIMPLE { ( 128, 17 ) / ( 128, 17 ) }' in flat
+        assert 'DATASET "keypoints" { DATATYPE H5T_IEEE_F64LE DATASPACE SIMPLE { ( 17, 2 ) / ( 17, 2 ) }' in flat
+        assert 'DATASET "image_size" { DATATYPE H5T_STD_I64LE DATASPACE SIMPLE { ( 2 ) / ( 2 ) }' in flat
+        out = " ".join(subprocess.run([h5dump, "-H", q], capture_output=True, text=True, check=True).stdout.split())
+        assert 'DATASET "matches0" { DATATYPE H5T_STD_I16LE DATASPACE SIMPLE { ( 17 ) / ( 17 ) }' in out
+        assert 'DATASET "matching_scores0" { DATATYPE 16-bit little-endian floating-point' in out
+        data = subprocess.run([h5dump, "-d", "/query-q1.jpg_db-1.jpg/matches0", q], capture_output=True, text=True, check=True).stdout
+        assert "-1, 0, 1, 2, 3" in data
+
+
+def test_pack_to_h5_hands_a_fast_store_over_to_the_reference_format(tmp_path):
+    """A run that wrote the PackStore stand-in (SFD2_STORE=pack: the pipelined match driver outruns HDF5's ~4 k pair groups/s) is converted afterwards --
+    feature_io.pack_to_h5 / tools/pack_to_h5.py: every group, dataset, dtype and byte; reading prefers the HDF5 file once it exists."""
+    import subprocess
+    import sys
+    if fio.hdf5_backend() is None:
+        pytest.skip("no HDF5 library on this host")
+    rs = np.random.RandomState(1)
+    src = fio.open_store(str(tmp_path / "feats.h5"), "w", standin="pack")
+    want = {}
+    for i in range(20):
+        n = int(rs.randint(0, 40))
+        want[f"db/seq{i % 3}/{i}.jpg"] = {"keypoints": rs.rand(n, 2), "descriptors": rs.rand(128, n), "scores": rs.rand(n), "image_size": np.array([640 + i, 480])}
+        src.write_group(f"db/seq{i % 3}/{i}.jpg", want[f"db/seq{i % 3}/{i}.jpg"])
+    src.write_rows([f"q_{j}" for j in range(4)], {"matches0": rs.randint(-1, 99, (4, 64)).astype(np.int16), "matching_scores0": rs.rand(4, 64).astype(np.float16)})
+    src.close()
+    assert isinstance(fio.open_store(str(tmp_path / "feats.h5"), "r"), fio.PackStore)          # only the stand-in exists so far
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pack_to_h5.py")
+    r = subprocess.run([sys.executable, tool, src.path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "24 groups" in r.stdout
+    rd = fio.open_store(str(tmp_path / "feats.h5"), "r")
+    assert isinstance(rd, fio.H5Store) and len(rd.keys()) == 24
+    pk = fio.PackStore(src.path, "r")
+    for name in pk.keys():
+        assert sorted(pk[name].keys()) == sorted(rd[name].keys())
+        for k in pk[name].keys():
+            a, b = pk[name][k].__array__(), rd[name][k].__array__()
+            assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), (name, k)
