@@ -17,12 +17,14 @@ import ctypes
 import ctypes.util
 import os
 import threading
+import weakref
 
 import numpy as np
 
 _lock = threading.RLock()
 _lib = None
 _ids = {}
+_open_files = {}        # realpath -> WeakSet of open File objects
 
 H5F_ACC_RDONLY, H5F_ACC_RDWR, H5F_ACC_TRUNC, H5F_ACC_EXCL = 0, 1, 2, 4
 H5P_DEFAULT = 0
@@ -301,15 +303,27 @@ class File(Group):
         if mode not in ("r", "a", "w", "r+"):
             raise ValueError(mode)
         self.path, self.mode = str(path), mode
-        with _lock:
+        self._id = 0
+        key = os.path.realpath(self.path)
+
+        def attempt():
             if mode == "w" or (mode == "a" and not os.path.exists(self.path)):
-                fid = lib.H5Fcreate(self.path.encode(), H5F_ACC_TRUNC, H5P_DEFAULT, _ids["FAPL_STRONG"])
-            else:
-                if not os.path.exists(self.path):
-                    raise FileNotFoundError(self.path)
-                fid = lib.H5Fopen(self.path.encode(), H5F_ACC_RDONLY if mode == "r" else H5F_ACC_RDWR, _ids["FAPL_STRONG"])
+                return lib.H5Fcreate(self.path.encode(), H5F_ACC_TRUNC, H5P_DEFAULT, _ids["FAPL_STRONG"])
+            if not os.path.exists(self.path):
+                raise FileNotFoundError(self.path)
+            return lib.H5Fopen(self.path.encode(), H5F_ACC_RDONLY if mode == "r" else H5F_ACC_RDWR, _ids["FAPL_STRONG"])
+        with _lock:
+            fid = attempt()
+            if fid < 0 and mode != "r":
+                # libhdf5 refuses a second open of one file with other access flags inside a process.  A READ handle somebody forgot (datasets handed
+                # out are arrays in memory already) must not block the writer: read-only handles of this path are closed, then once more
+                for other in list(_open_files.get(key, ())):
+                    if other.mode == "r":
+                        other.close()
+                fid = attempt()
             if fid < 0:
-                raise OSError(f"libhdf5: cannot open {self.path} (mode {mode})")
+                raise OSError(f"libhdf5: cannot open {self.path} (mode {mode})" + (": open for writing elsewhere in this process" if _open_files.get(key) else ""))
+            _open_files.setdefault(key, weakref.WeakSet()).add(self)
         Group.__init__(self, self, fid, "/")
 
     def _writable(self):
@@ -365,7 +379,9 @@ class File(Group):
             if self._id:
                 load().H5Fclose(self._id)
                 self._id = 0
-                self.mode = "r"
+                ws = _open_files.get(os.path.realpath(self.path))
+                if ws is not None:
+                    ws.discard(self)
 
     def __del__(self):
         try:

@@ -7,7 +7,13 @@ Asserted here (measured values are printed and appended to gpurun_out/f16c_parit
   * dense and sampled descriptors within 1e-3 absolute on unit vectors (north_star), norms 1 +- 1e-5
   * detector score within 2e-2 relative (plain fp16: 8e-2)
   * key-point set IoU >= 0.985 against the fp32 oracle / the reference goldens (selection stages themselves are
-    bit-exact given the heat map: tests/test_gpu_parity.py)
+    bit-exact given the heat map: tests/test_gpu_parity.py), and since round 6 the ORDER of the list (Spearman >= 0.999, bounded rank shift: _compare)
+
+Two option sets (round 6).  `model_c` is the mode AS SHIPPED: on these weights the load-time self-check turns "c3b_plain" on (conv3b without its correction
+chunks: include/sfd2_hip.h, sfd2_get_relax_status) -- every end-to-end assertion (descriptors <= 1e-3, IoU, order, goldens, every BASELINE geometry) runs on
+it, and its activations behind conv3b are held to 2e-3 of max instead of 1e-3.  Tests of the compensated ARITHMETIC itself (per-activation tolerances, tuned
+against generic kernels, the rb_inner / fp6 / trunk_r1 / s2d option tables with their own tighter numbers) pin "c3b_plain" = 0: `model_c_full` and every model
+built inside a test.
 """
 import os
 
@@ -51,6 +57,17 @@ def model_c(synth_sd):
     return m
 
 
+@pytest.fixture(scope="module")
+def model_c_full(synth_sd):
+    """The fully compensated backbone: option c3b_plain = 0 (module docstring)."""
+    from sfd2_amd.model import ResSegNetV2
+    m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
+    m.context.set_option("c3b_plain", 0)
+    m.load_state_dict(synth_sd)
+    m.cuda(0)
+    return m
+
+
 def _kp_index(kp):
     out = {}
     for i, (x, y) in enumerate(kp):
@@ -87,8 +104,12 @@ def _compare(got, want, min_iou):
     return iou, dd, shift, same_rank, len(common)
 
 
+@pytest.mark.parametrize("shipped", [False, True])
 @pytest.mark.parametrize("h,w,seed", [(64, 96, 11), (100, 130, 12), (37, 53, 13)])
-def test_f16c_det_vs_oracle(model_c, synth_sd, h, w, seed):
+def test_f16c_det_vs_oracle(model_c, model_c_full, synth_sd, h, w, seed, shipped):
+    model_c = model_c if shipped else model_c_full
+    plain3b = bool(model_c.context.get_option("c3b_plain"))
+    assert plain3b == shipped, model_c.context.margin_status()       # (on these weights the self-check finds the room: 6.0-6.4e-4 on the probe against 7e-4)
     img = synth.make_image(h, w, seed)
     x = orc.norm_rgb(img)
     taps = {}
@@ -105,14 +126,15 @@ def test_f16c_det_vs_oracle(model_c, synth_sd, h, w, seed):
             worst = (name, float(err))
         # (the two head branches are plain fp16 layers whose outputs are stored as fp16 -- half an ulp alone is up to 4.9e-4 of
         #  max: 2e-3 there, plain fp16 asserts 1.5e-2)
-        assert err <= (2 * ACT_TOL if name.startswith(("convP", "convD")) else ACT_TOL), (name, err)
+        behind_3b = plain3b and (name == "bn3b" or name.startswith(("conv4", "ConvSta")))      # conv3b in plain fp16: its own rounding rides on the trunk
+        assert err <= (2 * ACT_TOL if (behind_3b or name.startswith(("convP", "convD"))) else ACT_TOL), (name, err)
     rel = np.abs(score[0, 0] - o_score) / (o_score + 1e-4 / SCORE_TOL)
     assert rel.max() <= SCORE_TOL, rel.max()
     dd = np.abs(desc[0] - o_desc).max()
     assert dd <= DESC_TOL, dd
     np.testing.assert_allclose(np.linalg.norm(desc[0], axis=0), 1.0, atol=1e-5)
     assert (stab[0, 0] != o_stab).mean() < 0.002
-    _record(f"f16c det {h}x{w}: worst activation {worst[0]} {worst[1]:.2e} of max, score rel {rel.max():.2e}, dense desc {dd:.2e}, "
+    _record(f"f16c det {h}x{w} ({'as shipped: c3b_plain' if shipped else 'fully compensated'}): worst activation {worst[0]} {worst[1]:.2e} of max, score rel {rel.max():.2e}, dense desc {dd:.2e}, "
             f"stability flips {(stab[0, 0] != o_stab).mean():.2e}")
 
 
@@ -190,6 +212,7 @@ def test_f16c_tuned_kernels_vs_generic_kernel(synth_sd, h, w, seed, fp6):
         m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
         m.load_state_dict(synth_sd)
         m.cuda(0)
+        m.context.set_option("c3b_plain", 0)      # the arithmetic under test is the fully compensated backbone (module docstring)
         m.context.set_option("generic_c", generic)
         m.context.set_option("rb_inner", 0)      # (the generic kernel only has the fully compensated ResBlock)
         m.context.set_option("fuse_det", 0 if generic else 1)
@@ -216,6 +239,7 @@ def model_c_rb16(synth_sd):
     m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
     m.load_state_dict(synth_sd)
     m.cuda(0)
+    m.context.set_option("c3b_plain", 0)      # the arithmetic under test is the fully compensated backbone (module docstring)
     m.context.set_option("comp_rb", 0)
     return m
 
@@ -330,6 +354,7 @@ def model_c_heads(synth_sd):
     m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
     m.load_state_dict(synth_sd)
     m.cuda(0)
+    m.context.set_option("c3b_plain", 0)      # the arithmetic under test is the fully compensated backbone (module docstring)
     m.context.set_option("comp_heads", 1)
     m.context.set_option("rb_inner", 0)
     return m
@@ -373,6 +398,7 @@ def test_f16c_fp6_filters_extract_vs_oracle(synth_sd, h, w, seed, topk):
     m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
     m.load_state_dict(synth_sd)
     m.cuda(0)
+    m.context.set_option("c3b_plain", 0)      # the arithmetic under test is the fully compensated backbone (module docstring)
     m.context.set_option("fp6_filters", 1)
     img = synth.make_image(h, w, seed)
     want = orc.extract_resnet_return(synth_sd, img, conf_th=0.001, topK=topk)
@@ -390,6 +416,7 @@ def model_c_fp6(synth_sd):
     m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
     m.load_state_dict(synth_sd)
     m.cuda(0)
+    m.context.set_option("c3b_plain", 0)      # the arithmetic under test is the fully compensated backbone (module docstring)
     m.context.set_option("fp6_acts", 1)
     return m
 
@@ -454,6 +481,7 @@ def test_f16c_fp6_acts_per_tensor_fallbacks(synth_sd):
         m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
         m.load_state_dict(synth_sd)
         m.cuda(0)
+        m.context.set_option("c3b_plain", 0)      # the arithmetic under test is the fully compensated backbone (module docstring)
         m.context.set_option("fp6_acts", 1)
         for k, v in opts.items():
             m.context.set_option(k, v)
@@ -479,6 +507,7 @@ def test_f16c_conv2b_space_to_depth_vs_oracle_and_strided_kernel(synth_sd, h, w,
         m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
         m.load_state_dict(synth_sd)
         m.cuda(0)
+        m.context.set_option("c3b_plain", 0)      # the arithmetic under test is the fully compensated backbone (module docstring)
         m.context.set_option("s2d", s2d)
         got = extract_resnet_return(m, torch.from_numpy(img)[None].cuda(), conf_th=0.001, topK=topk, scales=[1.0])
         iou, dd, shift, same, n = _compare(got, want, 0.985 if topk > 0 else 0.97)      # (every point above the threshold: a few sit on it)
@@ -511,6 +540,7 @@ def test_f16c_trunk_residual_only_tensors(synth_sd, h, w, seed):
         m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
         m.load_state_dict(synth_sd)
         m.cuda(0)
+        m.context.set_option("c3b_plain", 0)      # the arithmetic under test is the fully compensated backbone (module docstring)
         m.context.set_option("trunk_r1", r1)
         m.det(x[None])
         got = {n: m.context.debug_activation(n) for n in names}
@@ -532,6 +562,7 @@ def model_c_inner(request, synth_sd):
     m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
     m.load_state_dict(synth_sd)
     m.cuda(0)
+    m.context.set_option("c3b_plain", 0)      # the arithmetic under test is the fully compensated backbone (module docstring)
     m.context.set_option("rb_inner", request.param)
     m.rb_inner = request.param
     return m
@@ -582,6 +613,7 @@ def test_f16c_fused_conv2_conv3_bit_identical(synth_sd, h, w, topk):
         m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
         m.load_state_dict(synth_sd)
         m.cuda(0)
+        m.context.set_option("c3b_plain", 0)      # the arithmetic under test is the fully compensated backbone (module docstring)
         m.context.set_option("fuse_rb23", fuse)
         m.context.set_option("trunk_r1", 0)      # (the same tensor format on both sides: the residual-only trunk tensors need the fused kernel)
         o = extract_resnet_return(m, img[None], conf_th=0.001, topK=topk, scales=[1.0])
@@ -655,6 +687,7 @@ def test_f16c_detector_branch_compensation_table(synth_sd):
         m = ResSegNetV2(outdim=128, require_stability=True, precision="f16c").eval()
         m.load_state_dict(synth_sd)
         m.cuda(0)
+        m.context.set_option("c3b_plain", 0)      # the arithmetic under test is the fully compensated backbone (module docstring)
         for k, v in opts.items():
             m.context.set_option(k, v)
         score, _, _ = m.det(x[None])
