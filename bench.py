@@ -77,6 +77,17 @@ def _cpu_info():
     return model, physical, logical
 
 
+def _cpu_quota():
+    """CPUs' worth of time the container's cgroup allows (cpu.max), or None: on a box with a quota every thread count above it is throttled -- the GPU boxes
+    of this pool: 2 x 64 cores visible, cpu.max = 1600000 100000 = 16 CPUs (tools/diag/cpu_quota_probe.py, profiles/r06e_cpu_quota_probe.json)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(sd, n_match_sample=10):
     """The reference's CPU path, timed on this host beside the GPU number (warm-up 2,
     median of >= 5, core count and CPU model stated).  Two CPU implementations of the same unit (one 1600x1200
@@ -144,6 +155,7 @@ def cpu_baseline(sd, n_match_sample=10):
     #  twin, a single unwarmed sample; it is a checker, not a baseline, and is no longer in the line)
     return {"value": torch_entry["value"], "unit": "images/sec", "cores": physical, "kind": "port", "model": model, "logical_cpus": logical,
             "threads": best_t, "median_of": 5, "warmup": 2, "all_cores": all_cores,
+            "container_cpu_quota_cpus": _cpu_quota(),      # (the probe's best thread count follows this, not the host's core count)
             "sample": f"1 image {W}x{H} top-{TOPK} extract + {n_match_sample} of {K_DB} NNM matches 4096x4096x128 scaled x{K_DB // n_match_sample}; "
                       f"torch-CPU twin (stock torch ops, oneDNN convolutions; {best_t} threads = best of a probe over 8..{physical}): "
                       f"extract {te:.2f}s + match {tm:.2f}s",

@@ -38,6 +38,10 @@ typedef struct sfd2_ctx sfd2_ctx;
 #define SFD2_FLAG_MATCH_OUT16 64    /* sfd2_match_batch: matches0 is int16 [k][n], scores0 IEEE half [k][n] -- the types the reference STORES (.short() /
                                     * .half(): hloc/match_features.py:114,118), converted on the device: a third of the bytes to the host and no
                                     * host-side cast of the [k][n] blocks in the batch driver's writer */
+#define SFD2_FLAG_DESC_STORE64 128 /* sfd2_extract: `desc` is double [128][cap_out] -- the descriptors as the reference STORES them (transposed,
+                                    * extract_localization.py:253, and float64, :269-272), columns >= the key-point count zero.  The cast is exact and the
+                                    * values are those of the float [n][128] form; what moves to the device is the writer threads' cast + transposing
+                                    * copy (4 MB per image: the host is the scarce side of an 8-GPU node, tools/host_soak.py).  cap_out >= 1 required. */
 #define SFD2_FLAG_IMG_U8_X 32      /* with IMG_U8_HWC (sfd2_extract, sfd2_preprocess): pixels are FOUR bytes, the fourth ignored
                                     * (RGBX / BGRX: the in-memory layout of PIL's RGB images, which a decoder thread can hand
                                     * over without the interpreter-locked repacking to three bytes); unpacked on the device */
@@ -81,7 +85,7 @@ typedef struct {
     int64_t n_candidates; /* N0 after NMS + threshold + border of the last extract          */
 } sfd2_timings;
 
-int sfd2_version(void);   /* 100 = rounds 1-4; 105 adds sfd2_extract_record_async, sfd2_desc_pack and host outputs with SFD2_FLAG_ASYNC; 106 adds sfd2_get_margin_status; 107 adds sfd2_get_relax_status (option "c3b_plain"); 108 adds sfd2_get_option, sfd2_device_pci_bus_id */
+int sfd2_version(void);   /* 100 = rounds 1-4; 105 adds sfd2_extract_record_async, sfd2_desc_pack and host outputs with SFD2_FLAG_ASYNC; 106 adds sfd2_get_margin_status; 107 adds sfd2_get_relax_status (option "c3b_plain"); 108 adds sfd2_get_option, sfd2_device_pci_bus_id, SFD2_FLAG_DESC_STORE64 */
 const char *sfd2_last_error(void);
 
 int sfd2_ctx_create(int device, sfd2_ctx **out);

@@ -27,6 +27,7 @@ FLAG_IMG_U8_HWC = 8
 FLAG_IMG_BGR = 16
 FLAG_IMG_U8_X = 32
 FLAG_MATCH_OUT16 = 64
+FLAG_DESC_STORE64 = 128
 MATCH_HLOC, MATCH_ITLOC_NNM, MATCH_ITLOC_NNR = 0, 1, 2
 DT_F32, DT_F64, DT_F16 = 0, 1, 2
 LAYOUT_ND, LAYOUT_DN = 0, 1

@@ -218,9 +218,11 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     const int sel_cap = c->last_sel_cap;
     int64_t ncopy = sel_cap;
     if (cap_out >= 0 && ncopy > cap_out) ncopy = cap_out;
+    const bool store64 = desc && (flags & SFD2_FLAG_DESC_STORE64);
+    if (store64 && cap_out < 1) return fail("sfd2_extract: SFD2_FLAG_DESC_STORE64 needs cap_out >= 1 (desc is double [128][cap_out])");
     float *desc_dst = nullptr;
     if (desc) {
-        if (out_on_device && cap_out >= sel_cap) {
+        if (out_on_device && cap_out >= sel_cap && !store64) {
             desc_dst = desc;  // sample straight into the caller's buffer
         } else {
             HIPCHECK(c->kdesc.ensure((size_t)sel_cap * 128 * sizeof(float)));
@@ -275,6 +277,18 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
                                c->counters.as<unsigned int>() + 1, sel_cap, desc_dst);
         }
     }
+    size_t desc_bytes_fixed = 0;          // store64: the copy has one size whatever the count is
+    if (store64) {
+        float *d64_dst = out_on_device ? desc : nullptr;
+        if (!out_on_device) {
+            HIPCHECK(c->kdesc64.ensure((size_t)128 * cap_out * sizeof(double)));
+            d64_dst = c->kdesc64.as<float>();
+        }
+        ProfScope ps(c, "desc_store64", "desc_store64_kernel", 0.0, (double)sel_cap * 128 * 4 + (double)cap_out * 128 * 8);
+        launch_desc_store64(c->stream, desc_dst, c->counters.as<unsigned int>() + 1, sel_cap, reinterpret_cast<double *>(d64_dst), (int)cap_out);
+        desc_dst = d64_dst;
+        desc_bytes_fixed = (size_t)128 * cap_out * sizeof(double);
+    }
     prof_step_end(c);
     HIPCHECK(hipEventRecord(c->ev[2], c->stream));
     HIPCHECK(hipGetLastError());
@@ -283,7 +297,7 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
         // Host output buffers (pinned, or the copies are not asynchronous) hold the result once the stream has been synchronised.
         if (!direct && copy_out(c, kpts_xy, c->kpts.p, (size_t)ncopy * 2 * sizeof(float), out_on_device)) return -1;
         if (!direct && copy_out(c, scores, c->kscores.p, (size_t)ncopy * sizeof(float), out_on_device)) return -1;
-        if (desc && desc_dst != desc && copy_out(c, desc, desc_dst, (size_t)ncopy * 128 * sizeof(float), out_on_device)) return -1;
+        if (desc && desc_dst != desc && copy_out(c, desc, desc_dst, desc_bytes_fixed ? desc_bytes_fixed : (size_t)ncopy * 128 * sizeof(float), out_on_device)) return -1;
         if (n_out) *n_out = -1;
         return 0;
     }
@@ -299,7 +313,7 @@ extern "C" int sfd2_extract(sfd2_ctx *c, const void *img, int img_on_device, int
     }
     if (!direct && copy_out(c, kpts_xy, c->kpts.p, (size_t)n * 2 * sizeof(float), out_on_device)) return -1;
     if (!direct && copy_out(c, scores, c->kscores.p, (size_t)n * sizeof(float), out_on_device)) return -1;
-    if (desc && desc_dst != desc && copy_out(c, desc, desc_dst, (size_t)n * 128 * sizeof(float), out_on_device)) return -1;
+    if (desc && desc_dst != desc && copy_out(c, desc, desc_dst, desc_bytes_fixed ? desc_bytes_fixed : (size_t)n * 128 * sizeof(float), out_on_device)) return -1;
     HIPCHECK(hipStreamSynchronize(c->stream));
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev[0], c->ev[2]) == hipSuccess) c->tim.ms_total = ms;
@@ -342,6 +356,7 @@ extern "C" int sfd2_extract_multiscale(sfd2_ctx *c, const void *img, int img_on_
     if (!(flags & SFD2_FLAG_NO_STABILITY) && !c->has_sta)
         return fail("sfd2_extract_multiscale: the loaded state_dict has no ConvSta; pass SFD2_FLAG_NO_STABILITY");
     if (flags & SFD2_FLAG_ASYNC) return fail("sfd2_extract_multiscale: SFD2_FLAG_ASYNC is not supported");
+    if (flags & SFD2_FLAG_DESC_STORE64) return fail("sfd2_extract_multiscale: SFD2_FLAG_DESC_STORE64 is not supported (single-scale sfd2_extract only)");
     if (!kpts_xy || !scores) return fail("sfd2_extract_multiscale: kpts_xy and scores are required");
     HIPCHECK(hipSetDevice(c->device));
     if (extract_begin(c, 0)) return -1;

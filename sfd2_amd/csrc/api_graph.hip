@@ -64,6 +64,7 @@ extern "C" int sfd2_extract_match(sfd2_ctx *c, const void *img_dev, int H, int W
 {
     if (!c || !img_dev || !kpts_xy || !scores || !desc) return fail("sfd2_extract_match: null argument");
     if (top_k <= 0) return fail("sfd2_extract_match: top_k must be positive (fixed-capacity device outputs)");
+    if (flags & SFD2_FLAG_DESC_STORE64) return fail("sfd2_extract_match: SFD2_FLAG_DESC_STORE64 is for stores; the matcher reads the float [n][128] descriptors");
     if (k < 0 || (k > 0 && (!db || !conf || !matches0 || !scores0))) return fail("sfd2_extract_match: null matcher argument");
     for (int i = 0; i < k; ++i)
         if (!db[i].on_device || db[i].rows) return fail("sfd2_extract_match: database sets must be device resident, without row selection");

@@ -827,6 +827,34 @@ void launch_desc_head(hipStream_t st, const half_t *fmap, int hc, int wc, int nh
                        (float)nh / 2.0f, wpk, CoutP, scale, shift, kpts, count, n_max, out, compact);
 }
 
+// ---------------------------------------------------------------- descriptors as the reference STORES them (SFD2_FLAG_DESC_STORE64)
+// extract_localization.py:253 transposes the [N,128] descriptors to [128,N] and :269-272 writes them as float64: on a host that feeds several GPUs the
+// cast + transposing copy of 4096 x 128 values per image is the writer threads' largest cost (tools/host_soak.py).  Here the device does both while the
+// descriptors are still in HBM: in [n_max][128] fp32 -> out [128][pitch] fp64 (exact: every fp32 is an fp64), columns >= count zero.
+__global__ __launch_bounds__(NT)
+void desc_store64_kernel(const float *__restrict__ in, const unsigned int *__restrict__ count, int n_max, double *__restrict__ out, int pitch)
+{
+    __shared__ float tile[64][129];
+    int n = n_max;
+    if (count) { const unsigned int c = *count; if ((unsigned int)n > c) n = (int)c; }
+    const int k0 = blockIdx.x * 64, tid = threadIdx.x;
+    for (int i = tid; i < 64 * 128; i += NT) {
+        const int r = i >> 7, ch = i & 127;
+        tile[r][ch] = (k0 + r < n) ? in[(size_t)(k0 + r) * 128 + ch] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 128; i += NT) {
+        const int ch = i >> 6, r = i & 63;
+        if (k0 + r < pitch) out[(size_t)ch * pitch + k0 + r] = (double)tile[r][ch];
+    }
+}
+
+void launch_desc_store64(hipStream_t st, const float *in, const unsigned int *count, int n_max, double *out, int pitch)
+{
+    if (pitch <= 0) return;
+    hipLaunchKernelGGL(desc_store64_kernel, dim3((pitch + 63) / 64), dim3(NT), 0, st, in, count, n_max, out, pitch);
+}
+
 // ---------------------------------------------------------------- dense descriptor normalise + NHWC -> NCHW
 __global__ __launch_bounds__(NT)
 void desc_normalise_nchw_kernel(const float *__restrict__ in, int npix, float *__restrict__ out)

@@ -233,6 +233,7 @@ struct sfd2_ctx {
     DevBuf stab /*f32 [H][W]*/, desc_nchw, tmp_f32;
     // selection
     DevBuf cand, bnd, sel, sorted, counters, kpts, kscores, kdesc;
+    DevBuf kdesc64;                    // SFD2_FLAG_DESC_STORE64: the descriptors as float64 [128][capacity] on their way to a host buffer
     DevBuf g_keys, g_state0, g_state1, g_kept;   // greedy NMS (extract.py variant)
     int cand_cap = 0;
     int last_sel_cap = 0;

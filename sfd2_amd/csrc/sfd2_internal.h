@@ -564,6 +564,7 @@ void launch_pb_heads_heat(hipStream_t st, const half_t *fmap, int hc8, int wc8, 
                           const float *shift, const float *sta, int hc, int wc, int H, int W, float *heat,
                           unsigned int *zero_words /*nullable: n_zero words cleared if the grid covers them*/, int n_zero);
 bool pb_heads_heat_clears(int hc8, int wc8, int n_zero);
+void launch_desc_store64(hipStream_t st, const float *in /*[n_max][128]*/, const unsigned int *count, int n_max, double *out /*[128][pitch]*/, int pitch);
 void launch_desc_head(hipStream_t st, const half_t *fmap, int hc, int wc, int nh, int nw, const half_t *wpk, int CoutP,
                       const float *scale, const float *shift, const float *kpts, const unsigned int *count, int n_max, float *out, int compact = 0);
 // desc_raw NHWC [P][128] -> normalised NCHW [128][P]

@@ -273,15 +273,16 @@ def _extract_pipelined(model, extractor, conf, images, indices, tag, store, name
 
     def write(job):
         idx, name, original_size, size, arrays, slot = job
-        if slot is not None:
-            try:
+        try:
+            if slot is not None:
                 arrays = slot_arrays(slot)
-            finally:
-                ax.release(slot)
-        kp, sc, de = arrays
-        pred = {'keypoints': rescale_keypoints(kp, original_size, size), 'descriptors': de.transpose(), 'scores': sc,
-                'image_size': original_size}
-        write_features(store, name, pred)
+            kp, sc, de = arrays
+            pred = {'keypoints': rescale_keypoints(kp, original_size, size), 'descriptors': de.transpose(), 'scores': sc,
+                    'image_size': original_size}
+            write_features(store, name, pred)
+        finally:
+            if slot is not None:
+                ax.release(slot)        # (the descriptors are a VIEW of the slot's pinned block until the store has copied them)
         with lock:
             names.append((idx, name))
 

@@ -457,23 +457,26 @@ def open_store(path, mode="a", standin=None):
             return NpzStore(path, mode)
         return PackStore(path, mode)
     kind = standin or (STORE if STORE != "auto" else None)
-    backend = hdf5_backend() if kind in (None, "h5") else None
+    if kind not in (None, "h5", "pack", "npz"):
+        raise ValueError(f"unknown stand-in store {kind!r}")
+    backend = hdf5_backend() if kind in (None, "h5") or mode == "r" else None
     if kind == "h5" and backend is None:
         raise RuntimeError("SFD2_STORE=h5 but neither h5py nor the HDF5 C library (sfd2_amd/h5lite.py) is available")
-    if mode == "r" and kind is None:
-        if backend is not None and os.path.isfile(path):
-            return H5Store(path, mode, backend)
-        if os.path.exists(base + ".pack"):
-            return PackStore(base + ".pack", mode)
-        if os.path.isdir(base + ".npzdir"):
-            return NpzStore(base + ".npzdir", mode)
+    if mode == "r":
+        # whatever exists, the asked-for kind first, then HDF5, PackStore, NpzStore
+        for k in ([kind] if kind else []) + ["h5", "pack", "npz"]:
+            if k == "h5" and backend is not None and os.path.isfile(path):
+                return H5Store(path, mode, backend)
+            if k == "pack" and os.path.exists(os.path.join(base + ".pack", "index.jsonl")):
+                return PackStore(base + ".pack", mode)
+            if k == "npz" and os.path.isdir(base + ".npzdir"):
+                return NpzStore(base + ".npzdir", mode)
+        raise FileNotFoundError(path)
     if backend is not None:
         return H5Store(path, mode, backend)
     kind = kind or STANDIN
     if kind == "npz":
         return NpzStore(base + ".npzdir", mode)
-    if kind != "pack":
-        raise ValueError(f"unknown stand-in store {kind!r}")
     return PackStore(base + ".pack", mode)
 
 

@@ -75,9 +75,11 @@ class _Slot:
         pin = dict(pin_memory=True)
         self.kp_t = torch.empty((cap, 2), dtype=torch.float32, **pin)
         self.sc_t = torch.empty((cap,), dtype=torch.float32, **pin)
-        self.de_t = torch.empty((cap, 128), dtype=torch.float32, **pin)
+        # descriptors as the reference STORES them: float64 [128][cap] (SFD2_FLAG_DESC_STORE64: the device does the cast and the transposition that
+        # extract_localization.py:253,269-272 do on the host -- the writer threads' largest cost, tools/host_soak.py)
+        self.de_t = torch.empty((128, cap), dtype=torch.float64, **pin)
         self.rec_t = torch.zeros((4,), dtype=torch.int32, **pin)
-        self.kp, self.sc, self.de, self.rec = self.kp_t.numpy(), self.sc_t.numpy(), self.de_t.numpy(), self.rec_t.numpy()
+        self.kp, self.sc, self.de64, self.rec = self.kp_t.numpy(), self.sc_t.numpy(), self.de_t.numpy(), self.rec_t.numpy()
         self.event = torch.cuda.Event()
         self.meta = None
         self.inbuf = None
@@ -141,8 +143,8 @@ class AsyncExtractor:
         slot.size = (w, h)
         slot.resize = None if on_dev == 0 else (w, h)
         n = ctypes.c_int(0)
-        _lib.check(lib.sfd2_extract(ctx.h, src, on_dev, h, w, self.conf_th, self.top_k, flags, slot.kp.ctypes.data,
-                                    slot.sc.ctypes.data, slot.de.ctypes.data, 0, slot.cap, ctypes.byref(n)))
+        _lib.check(lib.sfd2_extract(ctx.h, src, on_dev, h, w, self.conf_th, self.top_k, flags | _lib.FLAG_DESC_STORE64, slot.kp.ctypes.data,
+                                    slot.sc.ctypes.data, slot.de64.ctypes.data, 0, slot.cap, ctypes.byref(n)))
         _lib.check(lib.sfd2_extract_record_async(ctx.h, slot.rec.ctypes.data, 0))
         slot.event.record(self.streams[lane])
         self.inflight.append(slot)
@@ -180,7 +182,9 @@ def slot_arrays(slot):
         r = slot.sync_result
         return r["keypoints"], r["scores"], r["descriptors"]
     n = slot.n
-    return slot.kp[:n].astype(np.float64), slot.sc[:n].astype(np.float64), slot.de[:n].astype(np.float64)
+    # descriptors: the transposed VIEW of the slot's float64 [128][cap] block -- the caller's .transpose() (extract_localization.py:253) gives the stored
+    # [128, n] array back without a copy when the image filled its capacity (n == cap: every BASELINE workload); the store copies it out before the slot is reused
+    return slot.kp[:n].astype(np.float64), slot.sc[:n].astype(np.float64), slot.de64[:, :n].T
 
 
 class OrderedPrefetch:

@@ -431,6 +431,50 @@ def test_grouped_match_driver_with_empty_and_tiny_sets(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f16c", "f16x3"])
+@pytest.mark.parametrize("h,w,K,cap", [(96, 128, 200, 200), (250, 333, 4096, 4096), (480, 640, 1024, 1500)])
+def test_desc_store64_is_the_float_descriptors_cast_and_transposed(synth_sd, precision, h, w, K, cap):
+    """SFD2_FLAG_DESC_STORE64: `desc` comes back as double [128][cap_out] -- what extract_localization.py:253,269-272 store (transpose, float64) -- with exactly the
+    values of the float [n][128] form (an fp32 is an fp64) and zero columns behind the count; host and device destinations, synchronous and asynchronous; an image
+    with fewer key points than the capacity (250x333: ~1400 of 4096) and a capacity above top_k.  The matcher unit and the pyramid refuse the flag."""
+    import torch
+    m = _model(synth_sd, precision)
+    ctx = m.context
+    img = synth.make_image(h, w, 77)
+
+    def run(flags, on_dev, async_):
+        kp = np.zeros((cap, 2), np.float32); sc = np.zeros((cap,), np.float32)
+        de = np.full((128, cap), -7.0, np.float64) if flags & _lib.FLAG_DESC_STORE64 else np.zeros((cap, 128), np.float32)
+        n = ctypes.c_int(0)
+        if on_dev:
+            tk, ts, td = torch.from_numpy(kp).cuda(), torch.from_numpy(sc).cuda(), torch.from_numpy(de).cuda()
+            ptrs = (tk.data_ptr(), ts.data_ptr(), td.data_ptr())
+        else:
+            ptrs = (kp.ctypes.data, sc.ctypes.data, de.ctypes.data)
+        _lib.check(ctx.lib.sfd2_extract(ctx.h, img.ctypes.data, 0, h, w, 0.001, K, flags | (_lib.FLAG_ASYNC if async_ else 0), ptrs[0], ptrs[1], ptrs[2],
+                                        1 if on_dev else 0, cap, ctypes.byref(n)))
+        ctx.sync()
+        if async_:
+            _lib.check(ctx.lib.sfd2_extract_count(ctx.h, ctypes.byref(n)))
+        if on_dev:
+            kp, sc, de = tk.cpu().numpy(), ts.cpu().numpy(), td.cpu().numpy()
+        return n.value, kp, sc, de
+    n, kp, sc, de = run(0, False, False)
+    assert 20 < n <= K
+    for on_dev in (False, True):
+        for async_ in (False, True):
+            n2, kp2, sc2, d64 = run(_lib.FLAG_DESC_STORE64, on_dev, async_)
+            assert n2 == n
+            np.testing.assert_array_equal(kp2[:n], kp[:n]); np.testing.assert_array_equal(sc2[:n], sc[:n])
+            assert d64.dtype == np.float64 and d64.shape == (128, cap)
+            np.testing.assert_array_equal(d64[:, :n], de[:n].T.astype(np.float64))
+            assert not d64[:, n:].any()
+    sc1 = (ctypes.c_double * 1)(1.0)
+    rc = ctx.lib.sfd2_extract_multiscale(ctx.h, img.ctypes.data, 0, h, w, sc1, 1, ctypes.c_float(0.001), K, _lib.FLAG_DESC_STORE64, kp.ctypes.data, sc.ctypes.data, None, 0, cap, None)
+    assert rc != 0 and b"SFD2_FLAG_DESC_STORE64" in ctx.lib.sfd2_last_error()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("h,w", [(96, 128), (250, 333), (1200, 1600)])
 def test_rgbx_pixels_equal_rgb_pixels(synth_sd, h, w):
     """SFD2_FLAG_IMG_U8_X (four bytes per pixel, PIL's in-memory layout, the fourth ignored) through sfd2_extract from host and from device memory,

@@ -7,8 +7,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd $R
-rm -f gpurun_out/f16c_parity_measured.txt gpurun_out/strict_parity_measured.txt gpurun_out/f16c_conditioning_measured.txt
-python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/pytest_gpu.txt
+rm -f gpurun_out/f16c_parity_measured.txt gpurun_out/strict_parity_measured.txt gpurun_out/f16c_conditioning_measured.txt gpurun_out/margin_measured.txt
+python -m pytest tests -m gpu -q 2>&1 | tail -60 > $out/pytest_gpu.txt
+cp gpurun_out/margin_measured.txt $out/margin_measured.txt 2>/dev/null
 cp gpurun_out/f16c_parity_measured.txt $out/f16c_parity_measured.txt 2>/dev/null
 cp gpurun_out/strict_parity_measured.txt $out/strict_parity_measured.txt 2>/dev/null
 cp gpurun_out/f16c_conditioning_measured.txt $out/f16c_conditioning_measured.txt 2>/dev/null
@@ -32,6 +33,8 @@ python tools/strict_layers.py f16x3d > $out/strict_layers_f16x3d.txt 2>&1
 python tools/pipeline_bench.py > $out/pipeline_bench.json 2> $out/pipeline_bench.err
 python tools/pipeline_bench.py --workers 8 --precision f16c > $out/pipeline_bench_w8.json 2>> $out/pipeline_bench.err
 python tools/match_gap_stats.py > $out/match_gap_stats.json 2> $out/match_gap_stats.err
+python tools/host_soak.py --ranks 8 > $out/host_soak_8ranks.json 2> $out/host_soak.err
+python tools/relax_probe.py 3 > $out/relax_probe.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strict --no-pipeline --sustain 0"
 rocprofv3 --kernel-trace --stats -d $out/prof -o $tag -- $B > $out/prof_bench.json 2> $out/prof.err

@@ -73,6 +73,7 @@ def child(args):
     t_kp = (rs.rand(TOPK, 2) * 1600).astype(np.float32)
     t_sc = np.sort(rs.rand(TOPK).astype(np.float32))[::-1].copy()
     t_de = rs.randn(TOPK, 128).astype(np.float32)
+    t_de64 = np.ascontiguousarray(t_de.T, dtype=np.float64)
     scratch = os.path.join(args.scratch, f"rank{r}")
     os.makedirs(scratch, exist_ok=True)
     # Bounded footprint: at the device rate a rank writes 3 GB/s of float64 feature groups -- 15 s of eight ranks would be 360 GB.  Every writer thread
@@ -122,7 +123,10 @@ def child(args):
 
     def write(job):
         i, data = job
-        kp, sc, de = t_kp.astype(np.float64), t_sc.astype(np.float64), t_de.astype(np.float64)       # slot_arrays
+        if args.host_cast:       # rounds 1-5: the writer casts float32 [n][128] to float64 and the store's copy transposes it
+            kp, sc, de = t_kp.astype(np.float64), t_sc.astype(np.float64), t_de.astype(np.float64)
+        else:                    # round 6 (SFD2_FLAG_DESC_STORE64): the slot already holds float64 [128][n]; slot_arrays hands out its transposed view
+            kp, sc, de = t_kp.astype(np.float64), t_sc.astype(np.float64), t_de64.T
         pred = {"keypoints": rescale_keypoints(kp, data["original_size"], np.array((1600, 1200))), "descriptors": de.transpose(), "scores": sc,
                 "image_size": data["original_size"]}
         fio.write_features(my_store("feats", 48), f"query/r{r}_{i:07d}.jpg", pred)
@@ -146,7 +150,11 @@ def child(args):
                     # (the device stage would read the pixels here: upload + extract; the buffer goes back as the real loop returns it after the upload)
                     meta = {"original_size": data["original_size"]}
                     free.put(buf)
-                    wp.put((k, meta))
+                    if args.half == "decode":          # the decoder pool alone: no float64 groups, no store
+                        with lock:
+                            counts["images"] += 1
+                    else:
+                        wp.put((k, meta))
                     k += 1
                 elif pf.exhausted:
                     break
@@ -201,9 +209,10 @@ def child(args):
     if delay > 0:
         time.sleep(delay)
     t0 = time.perf_counter()
+    cpu0 = time.process_time()              # CPU time of every thread of this process: what the rank COSTS, whatever share of the host it was given
     stop_at[0] = t0 + args.seconds
     threads = []
-    if args.half in ("both", "extract"):
+    if args.half in ("both", "extract", "decode"):
         threads.append(threading.Thread(target=extract_half))
     if args.half in ("both", "match"):
         threads.append(threading.Thread(target=match_half))
@@ -213,10 +222,12 @@ def child(args):
     for t in threads:
         t.join()
     dt = time.perf_counter() - t0
+    cpu = time.process_time() - cpu0
     for st in all_stores:
         st.close()
     print(json.dumps({"rank": r, "seconds": round(dt, 3), "images_per_s": round(counts["images"] / dt, 1), "pairs_per_s": round(counts["pairs"] / dt, 1),
-                      "descriptor_sets_read_per_s": round(counts["sets_read"] / dt, 1), "placement": placement}), flush=True)
+                      "descriptor_sets_read_per_s": round(counts["sets_read"] / dt, 1), "cpu_seconds": round(cpu, 3), "images": counts["images"],
+                      "pairs": counts["pairs"], "placement": placement}), flush=True)
 
 
 def main():
@@ -230,7 +241,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=15.0)
     ap.add_argument("--store", default="pack", choices=["pack", "h5", "auto"])
     ap.add_argument("--no-affinity", action="store_true")
-    ap.add_argument("--half", default="both", choices=["both", "extract", "match"])
+    ap.add_argument("--half", default="both", choices=["both", "extract", "match", "decode"])
+    ap.add_argument("--host-cast", action="store_true", help="the writers cast and transpose the descriptors on the host (the drivers until round 5)")
+    ap.add_argument("--breakdown", action="store_true", help="besides the full legs: decode only, extract half only, match half only (pinned), and one rank alone")
     ap.add_argument("--files", type=int, default=96, help="distinct JPEG files (1600x1200, quality 90) the ranks cycle over")
     ap.add_argument("--per-rank-device-rate", type=float, default=715.0, help="images/s one GPU extracts + matches (bench.py's value)")
     ap.add_argument("--scratch", default=None)
@@ -248,14 +261,13 @@ def main():
     images = os.path.join(scratch, "images")
     names, mean_bytes = pb.write_images(images, args.files, 0, 1200, 1600)
     legs = {}
-    for label, extra in (("pinned", []), ("floating", ["--no-affinity"])):
-        if args.no_affinity and label == "pinned":
-            continue
-        start_at = time.time() + 6.0 + 0.5 * args.ranks          # (interpreter + numpy import of every child)
+
+    def leg(label, half, ranks, extra):
+        start_at = time.time() + 6.0 + 0.5 * ranks          # (interpreter + numpy import of every child)
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", str(r), "--ranks", str(args.ranks), "--workers", str(args.workers),
-                                   "--writers", str(args.writers), "--readers", str(args.readers), "--k", str(args.k), "--read-rate", str(args.read_rate), "--seconds", str(args.seconds),
-                                   "--store", args.store, "--half", args.half, "--scratch", os.path.join(scratch, label), "--images", images,
-                                   "--start-at", repr(start_at)] + extra, stdout=subprocess.PIPE, text=True) for r in range(args.ranks)]
+                                   "--writers", str(args.writers), "--readers", str(args.readers), "--k", str(args.k), "--read-rate", str(args.read_rate),
+                                   "--seconds", str(args.seconds), "--store", args.store, "--half", half, "--scratch", os.path.join(scratch, label),
+                                   "--images", images, "--start-at", repr(start_at)] + (["--host-cast"] if args.host_cast else []) + extra, stdout=subprocess.PIPE, text=True) for r in range(ranks)]
         per = []
         for p in procs:
             out, _ = p.communicate()
@@ -264,12 +276,40 @@ def main():
             per.append(json.loads(out.strip().splitlines()[-1]))
         import shutil
         shutil.rmtree(os.path.join(scratch, label), ignore_errors=True)
-        legs[label] = {"images_per_s": round(sum(c["images_per_s"] for c in per), 1), "pairs_per_s": round(sum(c["pairs_per_s"] for c in per), 1),
+        legs[label] = {"half": half, "ranks_running": ranks, "images_per_s": round(sum(c["images_per_s"] for c in per), 1),
+                       "pairs_per_s": round(sum(c["pairs_per_s"] for c in per), 1),
                        "descriptor_sets_read_per_s": round(sum(c["descriptor_sets_read_per_s"] for c in per), 1),
                        "per_rank_images_per_s": [c["images_per_s"] for c in per], "per_rank_pairs_per_s": [c["pairs_per_s"] for c in per],
-                       "placement": [c["placement"] for c in per]}
+                       "placement": per[0]["placement"]}
+        cpu, ni, npairs = sum(c["cpu_seconds"] for c in per), sum(c["images"] for c in per), sum(c["pairs"] for c in per)
+        legs[label]["cpus_busy"] = round(cpu / max(per[0]["seconds"], 1e-9), 1)
+        if half in ("decode", "extract") and ni:
+            legs[label]["cpu_ms_per_image"] = round(cpu * 1e3 / ni, 2)
+        if half == "match" and npairs:
+            legs[label]["cpu_us_per_pair"] = round(cpu * 1e6 / npairs, 2)
+
+    if not args.no_affinity:
+        leg("pinned", args.half, args.ranks, [])
+    leg("floating", args.half, args.ranks, ["--no-affinity"])
+    if args.breakdown:
+        pin = [] if not args.no_affinity else ["--no-affinity"]
+        leg("decode_only", "decode", args.ranks, pin)
+        leg("extract_half_only", "extract", args.ranks, pin)
+        leg("match_half_only", "match", args.ranks, pin)
+        leg("one_rank_alone_decode_only", "decode", 1, pin)
+        leg("one_rank_alone", args.half, 1, pin)
     import shutil
     shutil.rmtree(scratch, ignore_errors=True)
+    def read(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+    cpu_max = read("/sys/fs/cgroup/cpu.max")
+    quota = None
+    if cpu_max and cpu_max.split()[0] != "max":
+        quota = float(cpu_max.split()[0]) / float(cpu_max.split()[1])
     need_img = args.ranks * args.per_rank_device_rate
     need_pairs = need_img * args.k
     best = legs.get("pinned") or legs["floating"]
@@ -277,10 +317,24 @@ def main():
            "ranks": args.ranks, "decoder_threads_per_rank": args.workers, "writer_threads_per_rank": args.writers, "reader_threads_per_rank": args.readers,
            "store": args.store, "seconds": args.seconds, "jpeg_mean_bytes": round(mean_bytes), "logical_cpus": os.cpu_count(), "numa_nodes": len(node_cpulists()),
            "needed": {"images_per_s": need_img, "pairs_per_s": need_pairs, "from": f"{args.ranks} x {args.per_rank_device_rate} images/s per GPU x K = {args.k}"},
-           "legs": legs,
+           "legs": legs, "scratch": ("tmpfs (/dev/shm): the disk is not part of this measurement" if scratch.startswith("/dev/shm") else scratch),
+           "container_cpu_quota": {"cgroup_cpu_max": cpu_max, "cpus": quota,
+                                   "note": ("every aggregate above is capped by this quota, not by the host: read the per-unit CPU costs" if quota else "no CPU quota on this container")},
+           "cpu_budget": None,
            "verdict": {"images": "host sustains the device rate" if best["images_per_s"] >= need_img else "HOST-BOUND: decode + feature-store side is the bottleneck",
                        "pairs": "host sustains the device rate" if best["pairs_per_s"] >= need_pairs else "HOST-BOUND: match-store side is the bottleneck",
                        "images_ratio": round(best["images_per_s"] / need_img, 3), "pairs_ratio": round(best["pairs_per_s"] / need_pairs, 3)}}
+    ex, ma = legs.get("extract_half_only"), legs.get("match_half_only")
+    if ex and ma and "cpu_ms_per_image" in ex and "cpu_us_per_pair" in ma:
+        cpus_needed = need_img * ex["cpu_ms_per_image"] * 1e-3 + need_pairs * ma["cpu_us_per_pair"] * 1e-6
+        res["cpu_budget"] = {"cpu_ms_per_image_decode_to_stored_group": ex["cpu_ms_per_image"], "cpu_ms_per_image_decode_only": legs.get("decode_only", {}).get("cpu_ms_per_image"),
+                             "cpu_us_per_stored_pair": ma["cpu_us_per_pair"], "cpus_needed_for_all_ranks_at_device_rate": round(cpus_needed, 1),
+                             "host_logical_cpus": os.cpu_count(), "container_quota_cpus": quota,
+                             "reading": (f"{args.ranks} ranks at {args.per_rank_device_rate} images/s each cost {cpus_needed:.0f} CPUs of host work "
+                                         f"({os.cpu_count()} logical CPUs on this host" + (f"; this container may use {quota:.0f}" if quota else "") + ")")}
+        if quota and cpus_needed > quota:
+            res["verdict"]["named_bottleneck"] = (f"the container's CPU quota ({quota:.0f} CPUs, cgroup cpu.max {cpu_max}): {args.ranks} ranks need {cpus_needed:.0f}; "
+                                                  f"one rank needs {cpus_needed / args.ranks:.1f}")
     print(json.dumps(res))
 
 

@@ -140,6 +140,9 @@ def run(args):
 
     scratch = args.scratch or tempfile.mkdtemp(prefix="sfd2_pipe_")
     os.makedirs(scratch, exist_ok=True)
+    from sfd2_amd import feature_io as fio
+    store0 = fio.STORE
+    fio.STORE = "pack"       # the timed legs below write the fast stand-in store (as every round's numbers did); the `hdf5` object at the end is the same run into HDF5 files
     out = {"workload": f"{args.queries} query + {args.db} db JPEG files {W}x{H} -> top-{args.topk} features -> NNM matches, {args.k} db images per query",
            "decode_workers": args.workers, "writer_threads": args.writers, "extracts_in_flight": args.depth, "lanes": args.lanes,
            "host_logical_cpus": len(os.sched_getaffinity(0)), "host_cpu_count": os.cpu_count()}
@@ -212,7 +215,41 @@ def run(args):
                         "per_pair_loop_pairs_per_s": round(len(sub_pairs) / dtp, 1), "per_pair_pairs": len(sub_pairs),
                         "equal_to_per_pair_on_subset": bool(stores_equal(m_grp, m_ser, list(open_store(m_ser, "r").keys()))),
                         "k": k, "features": os.path.basename(feats_path)}
+        # ---- the same two drivers writing HDF5 files directly (the reference's format; the default of open_store wherever an HDF5 library exists), and the
+        # conversion of the stand-in stores afterwards (tools/pack_to_h5.py).  HDF5 costs ~250 us per pair group inside the library: the match store is format-bound.
+        backend = fio.hdf5_backend()
+        if backend is not None:
+            fio.STORE = "h5"
+            prec = args.precision.split(",")[0]
+            model = ResSegNetV2(outdim=128, require_stability=True, precision=prec).eval()
+            model.load_state_dict(sd)
+            model.cuda(0)
+            me = (model, el.extract_resnet_return)
+            for lm in model.lanes(args.lanes):
+                el.extract_resnet_return(lm, ds[0]["image"], conf_th=0.001, topK=args.topk)
+            d_h5 = os.path.join(scratch, "h5")
+            t0 = time.perf_counter()
+            p_h5 = el.main(conf, ds, d_h5, model_and_extractor=me, num_workers=args.workers, writers=args.writers, depth=args.depth, lanes=args.lanes)
+            dth = time.perf_counter() - t0
+            n_pairs_h5 = min(len(pairs), 40 * k)
+            t0 = time.perf_counter()
+            m_h5 = mf.main(mconf, pairs[:n_pairs_h5], conf["output"], d_h5, pairs_name="grouped", model=matcher, grouped=True)
+            dtm = time.perf_counter() - t0
+            eq_f = bool(stores_equal(p_h5, feats_path, list(fio.open_store(feats_path, "r").keys())[:16]))
+            fio.STORE = "pack"
+            t0 = time.perf_counter()
+            n_f = fio.pack_to_h5(fio.open_store(feats_path, "r").path, os.path.join(scratch, "conv_feats.h5"), backend)
+            dcf = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            n_m = fio.pack_to_h5(fio.open_store(m_grp, "r").path, os.path.join(scratch, "conv_matches.h5"), backend)
+            dcm = time.perf_counter() - t0
+            out["hdf5"] = {"backend": backend.__name__, "files_to_features_images_per_s": round(len(ds) / dth, 1), "precision": prec,
+                           "store_to_store_pairs_per_s": round(n_pairs_h5 / dtm, 1), "pairs": n_pairs_h5,
+                           "features_equal_to_the_pack_run": eq_f, "is_hdf5": bool(open(p_h5, "rb").read(8) == b"\x89HDF\r\n\x1a\n"),
+                           "pack_to_h5_feature_groups_per_s": round(n_f / dcf, 1), "pack_to_h5_pair_groups_per_s": round(n_m / dcm, 1)}
+            del model
     finally:
+        fio.STORE = store0
         if not args.keep:
             shutil.rmtree(scratch, ignore_errors=True)
     return out
