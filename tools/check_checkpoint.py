@@ -82,7 +82,8 @@ def main():
         m = model_of(prec)
         if prec == "f16c":
             st = m.context.margin_status()
-            print(f"f16c self-check: probe error {st['errors']}, running '{st['running']}' (target {st['target']:.1e})")
+            print(f"f16c self-check: probe error {st['errors']}, running '{st['running']}' (target {st['target']:.1e}); conv3b without correction chunks "
+                  f"(c3b_plain): probe with it {st['error_with_c3b_plain']:.2e} -> {'on' if st['c3b_plain'] else 'off'}")
         worst_d, worst_iou, same_rank = 0.0, 1.0, []
         for (name, u8, rs), ref in zip(imgs, refs):
             got = extract_resnet_return(m, feed(m, u8, rs), conf_th=0.001, topK=args.topk, scales=[1.0])
