@@ -17,7 +17,7 @@ Multi-GPU: one process per GPU, images sharded, no collective on the data path
 `value` is the fastest mode whose tests assert BASELINE.json north_star's tolerance (descriptors within 1e-3 of the fp32
 reference): precision 'f16c', compensated fp16 -- fp16 MFMA operands plus one block-scaled MFMA per 32 channels that adds the
 two first-order rounding terms (fp6 x fp6 records on conv2a / conv3a / conv3b, option fp6_acts, the default; fp8 elsewhere;
-tests/test_gpu_f16c.py asserts 1e-3 at every BASELINE geometry; measured <= 5e-4: profiles/r05n_f16c_parity_measured.txt).  Other modes of the same workload, same bracket, in the same line: `approx_f16` (plain fp16, descriptors within
+tests/test_gpu_f16c.py asserts 1e-3 at every BASELINE geometry; measured <= 6.2e-4 as shipped -- conv3b without its correction chunks where the load-time self-check finds the room: profiles/r06g_f16c_parity_measured.txt).  Other modes of the same workload, same bracket, in the same line: `approx_f16` (plain fp16, descriptors within
 3e-3: OUTSIDE the tolerance, reported for reference only), `strict_f32` (fp32 on the f32-input MFMA: descriptors within
 2e-5, key-point list equal up to near-ties), `strict_f16x3` (three hi / lo fp16 passes, same tolerances as f32) and
 `strict_kp_f16x3d` (f16x3's backbone and detector branch -- its key points bit for bit -- with the descriptor branch in plain fp16:
@@ -535,7 +535,7 @@ def main():
                "f16x3d": "key points and scores bit-identical to f16x3's (ordered list equal to the reference's up to near-ties), descriptors <= 1e-3 "
                          "(descriptor branch in plain fp16: tests/test_gpu_x3_desc16.py)",
                "f16": "OUTSIDE north_star's tolerance: descriptors <= 3e-3 (measured 1.8e-3), key-point set IoU >= 0.93 (tests/test_gpu_parity.py)",
-               "f16c": "descriptors <= 1e-3 asserted (measured <= 3.5e-4), key-point set IoU >= 0.985 (tests/test_gpu_f16c.py)"}[mode]
+               "f16c": "descriptors <= 1e-3 asserted (measured <= 6.2e-4), key-point set IoU >= 0.985 (tests/test_gpu_f16c.py)"}[mode]
         return {"value": round(n_st * world / dst, 3), "unit": "images/sec", "ms_per_step": round(dst / n_st * 1e3, 3),
                 "steps": n_st, "dtype": mode, "streams_per_gpu": len(lanes),
                 "launch": "hipGraph replay per image (sfd2_extract_match)" if replay else "eager", "parity": par}
@@ -637,10 +637,11 @@ def main():
                                 + ("fp6 x fp6 on conv2a / conv3a / conv3b (option fp6_acts), fp8 elsewhere" if args.fp6_acts else "fp8 operands") + " -- fp32 accumulate)"
                                 + (f"; backbone compensated, tensors inside the ResBlocks per option rb_inner = {args.rb_inner}" if args.comp_rb else "; option comp_rb = 0 (ResBlocks plain fp16)"),
                         "descriptors_max_abs": "<= 1e-3 asserted = north_star's tolerance (measured "
-                                               + (("<= 4.9e-4", "<= 3.8e-4", "<= 3.5e-4")[2 - max(0, min(2, args.rb_inner))] if args.comp_rb else "<= 8.1e-4") + " at 480x640 .. 2048x1536)",
-                        "keypoint_set_iou": ">= 0.985 asserted (measured 0.997 - 1.0)" if args.comp_rb else ">= 0.97 asserted (measured 0.991 - 0.996)",
+                                               + (("<= 6.2e-4 as shipped (option c3b_plain on where the self-check allows: margin_selfcheck.c3b_plain; 4.9e-4 with it off)", "<= 3.8e-4", "<= 3.5e-4")[2 - max(0, min(2, args.rb_inner))] if args.comp_rb else "<= 8.5e-4") + " at 480x640 .. 2048x1536)",
+                        "keypoint_set_iou": ">= 0.985 asserted (measured 0.992 - 1.0)" if args.comp_rb else ">= 0.97 asserted (measured 0.991 - 0.996)",
+                        "keypoint_order": "asserted among the points whose stability class did not flip: Spearman >= 0.999, rank shift <= n / 32 (measured <= 90 of 4096); the ordered LIST of the reference is `north_star_strict`'s contract",
                         "selection_given_heat_map": "bit-exact", "asserted_in": "tests/test_gpu_f16c.py",
-                        "measured_in": "profiles/r05n_f16c_parity_measured.txt"} if args.precision == "f16c" else
+                        "measured_in": "profiles/r06g_f16c_parity_measured.txt"} if args.precision == "f16c" else
                        {"mode": "f16 throughput (OUTSIDE north_star's 1e-3)", "descriptors_max_abs": "<= 3e-3 (measured 1.8e-3)", "keypoint_set_iou": ">= 0.93",
                         "selection_given_heat_map": "bit-exact", "asserted_in": "tests/test_gpu_parity.py"}),
             "single_stream": single, "sustained": sustained, "configs": configs_obj, "range_status": range_seen,
