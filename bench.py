@@ -153,7 +153,7 @@ def cpu_baseline(sd, n_match_sample=10):
         torch.set_num_threads(best_t)
     # (the C oracle -- the naive OpenMP loop nest the parity tests check against -- was timed here too until round 3: 4-6x slower than the
     #  twin, a single unwarmed sample; it is a checker, not a baseline, and is no longer in the line)
-    return {"value": torch_entry["value"], "unit": "images/sec", "cores": physical, "kind": "port", "model": model, "logical_cpus": logical,
+    return {"value": torch_entry["value"], "unit": "images/sec", "cores": best_t, "kind": "port", "model": model, "host_physical_cores": physical, "logical_cpus": logical,
             "threads": best_t, "median_of": 5, "warmup": 2, "all_cores": all_cores,
             "container_cpu_quota_cpus": _cpu_quota(),      # (the probe's best thread count follows this, not the host's core count)
             "sample": f"1 image {W}x{H} top-{TOPK} extract + {n_match_sample} of {K_DB} NNM matches 4096x4096x128 scaled x{K_DB // n_match_sample}; "
