@@ -113,7 +113,7 @@ struct sfd2_ctx {
     // network of image i when the caller runs extracts back to back (SFD2_FLAG_ASYNC + pinned host memory)
     hipStream_t copy_stream = nullptr;
     // (SFD2_IMG_SLOTS slots, not two: an upload that has to WAIT for its slot's previous reader stalls the copy engine's queue in front of every other
-    //  context's uploads -- two pipelined contexts on one device then run at half the rate of one: profiles/r05l -- so the ring is longer than the images
+    //  context's uploads -- two pipelined contexts on one device then run at half the rate of one (CHANGELOG round 5) -- so the ring is longer than the images
     //  a driver keeps in flight per context)
 #define SFD2_IMG_SLOTS 4
     hipEvent_t ev_copied[SFD2_IMG_SLOTS] = {}, ev_img_free[SFD2_IMG_SLOTS] = {};

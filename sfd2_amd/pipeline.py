@@ -94,7 +94,7 @@ class AsyncExtractor:
     def __init__(self, model, top_k, conf_th, depth=3, slots=8, lanes=1):
         """lanes > 1: that many contexts (model.lanes(n): own HIP stream, workspace and staging slots; the replicas are made once per
         model) take the images in turn; results do not depend on the lane.  Measured in THIS loop on pre-decoded images (f16c, 16 threads,
-        512 images, profiles/r05l): 678 images/s with one lane, 728-743 with two (4-6 images in flight).  (Rounds 4-5 had "two lanes are
+        512 images; CHANGELOG round 5): 678 images/s with one lane, 728-743 with two (4-6 images in flight).  (Rounds 4-5 had "two lanes are
         slower, 393 against 547": that run created the replica -- weight upload, packing, probes: ~0.3 s -- inside its timed region.)"""
         import torch
         if top_k <= 0:

@@ -696,7 +696,7 @@ def test_f16c_detector_branch_compensation_table(synth_sd):
         iou, dd, shift, same, n = _compare(got, want, 0.985)
         rows[name] = (rel, iou, same, n, dd)
         _record(f"f16c head compensation [{name}]: score rel {rel:.2e}, 1600x1200 IoU {iou:.4f}, same rank {same}/{n}, max rank shift {shift}, desc {dd:.2e}")
-    # Measured (profiles/r04_f16c_parity_measured.txt) and predicted by the CPU twin (profiles/r04_detector_budget.txt): the score error
+    # Measured (round 4; CHANGELOG) and predicted by the CPU twin (profiles/r04_detector_budget.txt): the score error
     # (1.2-1.3e-2 relative) is the BACKBONE's f16c-level error carried through the detector branch into logits of magnitude ~18 and
     # through exp() -- compensating convPa.0 / convPa.3, even with convPb in three passes, moves it by a quarter at most.  The option is
     # therefore off by default; what is asserted is that it does no harm.
