@@ -93,7 +93,7 @@ def _bind(lib):
         "H5Gcreate2": (hid_t, [hid_t, S, hid_t, hid_t, hid_t]), "H5Gopen2": (hid_t, [hid_t, S, hid_t]), "H5Gclose": (I, [hid_t]),
         "H5Pcreate": (hid_t, [hid_t]), "H5Pset_create_intermediate_group": (I, [hid_t, U]), "H5Pclose": (I, [hid_t]),
         "H5Pset_fclose_degree": (I, [hid_t, I]),
-        "H5Screate_simple": (hid_t, [I, P, P]), "H5Sclose": (I, [hid_t]), "H5Sget_simple_extent_ndims": (I, [hid_t]),
+        "H5Screate_simple": (hid_t, [I, P, P]), "H5Screate": (hid_t, [I]), "H5Sclose": (I, [hid_t]), "H5Sget_simple_extent_ndims": (I, [hid_t]),
         "H5Sget_simple_extent_dims": (I, [hid_t, P, P]),
         "H5Dcreate2": (hid_t, [hid_t, S, hid_t, hid_t, hid_t, hid_t, hid_t]), "H5Dopen2": (hid_t, [hid_t, S, hid_t]), "H5Dclose": (I, [hid_t]),
         "H5Dwrite": (I, [hid_t, hid_t, hid_t, hid_t, hid_t, P]), "H5Dread": (I, [hid_t, hid_t, hid_t, hid_t, hid_t, P]),
@@ -219,8 +219,11 @@ class Group:
             self._file._writable()
             if lib.H5Lexists(self._id, key.encode(), H5P_DEFAULT) > 0:
                 raise ValueError(f"Unable to create dataset (name already exists): {self._full(key)}")      # h5py's message
-            dims = (hsize_t * max(a.ndim, 1))(*a.shape)
-            sp = _chk(lib.H5Screate_simple(a.ndim, dims if a.ndim else None, None), "dataspace")
+            if a.ndim:
+                dims = (hsize_t * a.ndim)(*a.shape)
+                sp = _chk(lib.H5Screate_simple(a.ndim, dims, None), "dataspace")
+            else:
+                sp = _chk(lib.H5Screate(0), "scalar dataspace")        # H5S_SCALAR
             try:
                 d = _chk(lib.H5Dcreate2(self._id, key.encode(), t, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT), f"create dataset {self._full(key)}")
                 try:
