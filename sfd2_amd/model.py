@@ -93,7 +93,24 @@ class ResSegNetV2:
         self._weights_gen += 1          # lanes() rebuilds its replicas for new weights
         if self._ctx is not None:
             self._ctx.load_weights(self._sd)
+            self._log_selfcheck()
         return self
+
+    def _log_selfcheck(self):
+        """One INFO line (logger "sfd2_amd") saying what the load-time self-check of 'f16c' made of this checkpoint: the speed and the numerics of the mode
+        depend on it, and a caller should not have to ask sfd2_get_margin_status to find out."""
+        if self.precision != "f16c" or self._ctx is None:
+            return
+        try:
+            st = self._ctx.margin_status()
+        except Exception:      # noqa: BLE001 -- informative only
+            return
+        if st["choice"] < 0:
+            return
+        import logging
+        logging.getLogger("sfd2_amd").info(
+            "f16c self-check: probe error %.2e (target %.1e) -> running '%s'; conv3b without correction chunks (c3b_plain): probe with it %.2e -> %s",
+            st["errors"]["as set"], st["target"], st["running"], st["error_with_c3b_plain"], "on" if st["c3b_plain"] else "off")
 
     def state_dict(self):
         return dict(self._sd or {})
@@ -104,6 +121,7 @@ class ResSegNetV2:
             self._ctx.set_precision(self.precision)
             if self._sd is not None:
                 self._ctx.load_weights(self._sd)
+                self._log_selfcheck()
         return self._ctx
 
     @property
