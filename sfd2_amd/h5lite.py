@@ -136,12 +136,18 @@ _FILE_TYPES = {"f8": "H5T_IEEE_F64LE_g", "f4": "H5T_IEEE_F32LE_g", "f2": "F16LE"
                "i8": "H5T_STD_I64LE_g", "u1": "H5T_STD_U8LE_g", "u2": "H5T_STD_U16LE_g", "u4": "H5T_STD_U32LE_g", "u8": "H5T_STD_U64LE_g"}
 
 
+_type_cache = {}
+
+
 def _h5type(dtype):
-    dt = np.dtype(dtype)
-    key = dt.kind + str(dt.itemsize)
-    if key not in _FILE_TYPES or dt.byteorder == ">":
-        raise TypeError(f"h5lite: dtype {dt} is not one the stores hold")
-    return _ids[_FILE_TYPES[key]]
+    t = _type_cache.get(dtype)
+    if t is None:
+        dt = np.dtype(dtype)
+        key = dt.kind + str(dt.itemsize)
+        if key not in _FILE_TYPES or dt.byteorder == ">":
+            raise TypeError(f"h5lite: dtype {dt} is not one the stores hold")
+        t = _type_cache[dtype] = _ids[_FILE_TYPES[key]]
+    return t
 
 
 def _chk(rc, what):
@@ -346,7 +352,7 @@ class File(Group):
         lib = load()
         arrs = {}
         for k, v in datasets.items():
-            a = np.ascontiguousarray(v)
+            a = v if (type(v) is np.ndarray and v.flags.c_contiguous) else np.ascontiguousarray(v)
             if a.dtype.byteorder == ">":
                 a = a.astype(a.dtype.newbyteorder("<"))
             if a.dtype == np.bool_:
