@@ -231,7 +231,7 @@ def run(args):
             t0 = time.perf_counter()
             p_h5 = el.main(conf, ds, d_h5, model_and_extractor=me, num_workers=args.workers, writers=args.writers, depth=args.depth, lanes=args.lanes)
             dth = time.perf_counter() - t0
-            n_pairs_h5 = min(len(pairs), 40 * k)
+            n_pairs_h5 = min(len(pairs), 200 * k)      # (long enough to amortise the first read of every database set through HDF5)
             t0 = time.perf_counter()
             m_h5 = mf.main(mconf, pairs[:n_pairs_h5], conf["output"], d_h5, pairs_name="grouped", model=matcher, grouped=True)
             dtm = time.perf_counter() - t0
