@@ -103,7 +103,7 @@ def _bind(lib):
         "H5Tget_sign": (I, [hid_t]), "H5Tset_fields": (I, [hid_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t]),
         "H5Tset_size": (I, [hid_t, ctypes.c_size_t]), "H5Tset_ebias": (I, [hid_t, ctypes.c_size_t]), "H5Tset_precision": (I, [hid_t, ctypes.c_size_t]),
         "H5Tset_offset": (I, [hid_t, ctypes.c_size_t]), "H5Tget_order": (I, [hid_t]),
-        "H5Lexists": (I, [hid_t, S, hid_t]),
+        "H5Lexists": (I, [hid_t, S, hid_t]), "H5Oopen": (hid_t, [hid_t, S, hid_t]), "H5Oclose": (I, [hid_t]), "H5Iget_type": (I, [hid_t]),
         "H5Lget_name_by_idx": (ctypes.c_ssize_t, [hid_t, S, I, I, hsize_t, P, ctypes.c_size_t, hid_t]),
         "H5Gget_info": (I, [hid_t, P]), "H5Oget_info_by_name": (I, [hid_t, S, P, hid_t]),
         "H5Eset_auto2": (I, [hid_t, P, P]),
@@ -150,6 +150,16 @@ def _h5type(dtype):
     return t
 
 
+_tls = threading.local()
+
+
+def _quiet():
+    """A thread-safe libhdf5 keeps an error stack PER THREAD, each with automatic printing on: switch it off once per thread (errors are return codes here)."""
+    if not getattr(_tls, "quiet", False):
+        load().H5Eset_auto2(hid_t(0), None, None)
+        _tls.quiet = True
+
+
 def _chk(rc, what):
     if rc < 0:
         raise OSError(f"libhdf5: {what} failed")
@@ -159,11 +169,11 @@ def _chk(rc, what):
 class Dataset:
     """f[group][key]: shape, dtype, __array__(), [()] / [...] (the whole dataset is read on first use and kept)."""
 
-    def __init__(self, parent_id, name, full):
+    def __init__(self, parent_id, name, full, open_id=None):
         lib = load()
         self.name = full
         with _lock:
-            d = _chk(lib.H5Dopen2(parent_id, name.encode(), H5P_DEFAULT), f"open dataset {full}")
+            d = open_id if open_id is not None else _chk(lib.H5Dopen2(parent_id, name.encode(), H5P_DEFAULT), f"open dataset {full}")
             try:
                 sp = lib.H5Dget_space(d)
                 nd = lib.H5Sget_simple_extent_ndims(sp)
@@ -205,7 +215,7 @@ class Group:
     def _close(self):
         if self._id:
             with _lock:
-                load().H5Gclose(self._id)
+                load().H5Oclose(self._id)
             self._id = 0
 
     def __del__(self):
@@ -264,20 +274,26 @@ class Group:
     def keys(self):
         return self._names()
 
+    def _open_any(self, gid, key):
+        """(id, is_group) of a child that exists -- H5Oopen + H5Iget_type: no call that fails on purpose (a thread-safe libhdf5 keeps an error stack per thread and
+        prints it unless every thread has switched that off)."""
+        lib = load()
+        oid = _chk(lib.H5Oopen(gid, key.encode(), H5P_DEFAULT), f"open {key}")
+        return oid, lib.H5Iget_type(oid) == 2        # H5I_GROUP
+
     def _kind(self, key):
         """'group' / 'dataset' / None of a direct child."""
         lib = load()
         with _lock:
             if lib.H5Lexists(self._id, key.encode(), H5P_DEFAULT) <= 0:
                 return None
-            g = lib.H5Gopen2(self._id, key.encode(), H5P_DEFAULT)
-            if g >= 0:
-                lib.H5Gclose(g)
-                return "group"
-            return "dataset"
+            oid, is_group = self._open_any(self._id, key)
+            lib.H5Oclose(oid)
+            return "group" if is_group else "dataset"
 
     def __contains__(self, name):
         lib = load()
+        _quiet()
         with _lock:
             cur = ""
             for part in [p for p in name.split("/") if p]:          # H5Lexists wants every intermediate link to exist
@@ -291,10 +307,10 @@ class Group:
         if name not in self:
             raise KeyError(name)
         with _lock:
-            g = lib.H5Gopen2(self._id, name.encode(), H5P_DEFAULT)
-            if g >= 0:
-                return Group(self._file, g, self._full(name))
-        return Dataset(self._id, name, self._full(name))
+            oid, is_group = self._open_any(self._id, name)
+            if is_group:
+                return Group(self._file, oid, self._full(name))
+            return Dataset(self._id, name, self._full(name), open_id=oid)      # (closes the id)
 
     def create_group(self, name):
         lib = load()
@@ -318,6 +334,7 @@ class File(Group):
             raise ValueError(mode)
         self.path, self.mode = str(path), mode
         self._id = 0
+        _quiet()
         key = os.path.realpath(self.path)
 
         def attempt():
@@ -350,6 +367,7 @@ class File(Group):
         """create_group + one create_dataset per item under one lock round (what the pipelined drivers' writer threads call).  The group is new, so no dataset
         name can be taken: no existence checks; dataspaces of the shapes seen so far are kept (a match store writes two shapes 200 000 times)."""
         lib = load()
+        _quiet()
         arrs = {}
         for k, v in datasets.items():
             a = v if (type(v) is np.ndarray and v.flags.c_contiguous) else np.ascontiguousarray(v)
@@ -393,21 +411,21 @@ class File(Group):
 
         def walk(gid, prefix):
             names = self._names(gid)
-            kinds = {}
+            groups, has_dataset = [], False
             for n in names:
-                g = lib.H5Gopen2(gid, n.encode(), H5P_DEFAULT)
-                kinds[n] = g
-            if names and any(g < 0 for g in kinds.values()) and prefix:
-                out.append(prefix)
-            elif not names and prefix:
-                out.append(prefix)               # an empty group is still a name somebody wrote
-            for n in names:
-                g = kinds[n]
-                if g >= 0:
-                    try:
-                        walk(g, n if not prefix else prefix + "/" + n)
-                    finally:
-                        lib.H5Gclose(g)
+                oid, is_group = self._open_any(gid, n)
+                if is_group:
+                    groups.append((n, oid))
+                else:
+                    has_dataset = True
+                    lib.H5Oclose(oid)
+            if prefix and (has_dataset or not names):
+                out.append(prefix)               # (an empty group is still a name somebody wrote)
+            for n, g in groups:
+                try:
+                    walk(g, n if not prefix else prefix + "/" + n)
+                finally:
+                    lib.H5Oclose(g)
         with _lock:
             walk(self._id, "")
         return out
