@@ -426,8 +426,9 @@ int sfd2_get_margin_status(sfd2_ctx *ctx, float *errs4, int *choice, float *targ
 /* Option "c3b_plain" (version 107).  conv3b (nets/sfd2.py:276-278: 256 -> 256 channels at 1/4 resolution, the largest layer of the backbone) can run its
  * K loop over the fp16 plane of conv3a's output alone -- no correction chunks, the output's correction bytes still come from the fp32 accumulators, and
  * conv3a then writes no correction plane: -62 us of that layer's 184 at 1600x1200 for ~1.4x the descriptor error (tools/relax_study.py).  It is never on
- * unverified: with the default -1 the self-check above also measures the probe WITH it and keeps it only when the options as set met the target and still
- * meet it with it; 1 forces it (the self-check then runs every candidate with it), 0 forbids it.  *err_plain: the probe error with it (-1 = not measured),
+ * unverified: with the default -1 the self-check above also measures the probe WITH it and keeps it only when the options as set met the target and the probe
+ * with it stays inside 6.5e-4 (tighter than the 7e-4 that buys margin back: an extraction's error is up to 1.1x the probe's, profiles/r06p_relax_probe_8seeds.txt);
+ * 1 forces it (the self-check then runs every candidate with it), 0 forbids it.  *err_plain: the probe error with it (-1 = not measured),
  * *c3b_plain: whether the context now runs it.  A rounds-1..5 caller sees the same entry points; the descriptor tolerance (1e-3) is unchanged. */
 int sfd2_get_relax_status(sfd2_ctx *ctx, float *err_plain, int *c3b_plain);
 
