@@ -142,6 +142,8 @@ int sfd2_set_precision(sfd2_ctx *ctx, int mode);
  *               0: dense map, then sampling.  Bit-identical descriptors either way.
  *   "branches"  0 (default) / 1: the detector branch (convPa, convPb, soft-max) runs on a second HIP stream beside
  *               the descriptor branch (convDa, convDb) -- they share only the backbone output (-1.7 % per extract).
+ *   "sta_side"  0 (default) / 1: on the throughput path ConvSta (nets/sfd2.py:344: 256 -> 3 channels, a 63 MB read) runs on the context's side stream beside
+ *               convPa.0 / convPa.3 / convDa.0 and joins in front of the heat-map kernel; a fork inside a captured hipGraph.  Bit-identical.  Not together with "branches".
  *   "comp_rb"   1 (default) / 0: SFD2_PREC_F16C compensates the three ResBlocks as well (descriptors within ~3e-4 of
  *               the fp32 reference); 0 runs them on the fused fp16 ResBlock kernel (~7e-4, still inside 1e-3, and faster).
  *   "rb_inner"  2 (default) / 1 / 0: SFD2_PREC_F16C stores the tensors INSIDE the ResBlocks as plain fp16 (1: the grouped

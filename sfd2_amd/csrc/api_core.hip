@@ -115,6 +115,7 @@ extern "C" int sfd2_set_option(sfd2_ctx *c, const char *key, int value)
     else if (k == "alias") c->opt_alias = value ? 1 : 0;
     else if (k == "graphs") c->use_graphs = value ? 1 : 0;
     else if (k == "branches") c->opt_branches = value ? 1 : 0;
+    else if (k == "sta_side") c->opt_sta_side = value ? 1 : 0;
     else if (k == "fuse_post") c->opt_fuse_post = value ? 1 : 0;
     else if (k == "sparse_desc") c->opt_sparse_desc = value ? 1 : 0;
     else if (k == "sparse_da3") c->opt_sparse_da3 = value ? 1 : 0;
@@ -149,7 +150,7 @@ extern "C" int sfd2_get_option(sfd2_ctx *c, const char *key, int *value)
     if (!c || !key || !value) return fail("sfd2_get_option: null argument");
     const std::string k(key);
     const struct { const char *name; int v; } tab[] = {
-        {"fuse", c->fuse}, {"fuse_det", c->fuse_det}, {"alias", c->opt_alias}, {"graphs", c->use_graphs}, {"branches", c->opt_branches},
+        {"fuse", c->fuse}, {"fuse_det", c->fuse_det}, {"alias", c->opt_alias}, {"graphs", c->use_graphs}, {"branches", c->opt_branches}, {"sta_side", c->opt_sta_side},
         {"fuse_post", c->opt_fuse_post}, {"sparse_desc", c->opt_sparse_desc}, {"sparse_da3", c->opt_sparse_da3}, {"cu_limit", c->opt_cu_limit},
         {"auto_range", c->opt_auto_range}, {"range_fallback", c->opt_range_fallback}, {"x3_pp", c->opt_x3_pp}, {"x3_desc16", c->opt_x3_desc16},
         {"auto_margin", c->opt_auto_margin}, {"fp6_filters", c->opt_fp6_filters}, {"fp6_acts", c->opt_fp6_acts}, {"s2d", c->opt_s2d},

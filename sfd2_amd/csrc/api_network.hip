@@ -753,9 +753,24 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
     // 1600x1200): 1.260 -> 1.238 ms per extract (-1.7 %), outputs bit-identical.  Off by default: overlapped launches
     // stretch each other's event-timed durations, and bench.py's per-kernel roofline wants uncontended ones.
     const bool sta_early = alias && c->skip_pb_now;
+    // Option "sta_side" (round 6): ConvSta -- 63 MB read at HBM speed, 16 us -- on the side stream beside convPa.0 / convPa.3 / convDa.0 (matrix-bound, another part of
+    // the chip's budget); fork here, join at the end of this function (the heat-map kernel behind it is the first reader of its output).  Inside a captured hipGraph: a
+    // fork in the graph.  Same kernel, same bits.  Not with "branches" (that option owns the side stream).
+    const bool sta_side = c->has_sta && sta_early && c->opt_sta_side && !c->opt_branches;
     if (c->has_sta && sta_early) {
-        ProfScope ps(c, "ConvSta", "convsta_kernel", 2.0 * P4 * 3 * 256, P4 * (512 + 12));
-        launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w16.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
+        if (sta_side) {
+            HIPCHECK(hipEventRecord(c->ev_fork, st));
+            HIPCHECK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+            c->cur_stream = c->side_stream;
+        }
+        {
+            ProfScope ps(c, "ConvSta", "convsta_kernel", 2.0 * P4 * 3 * 256, P4 * (512 + 12));
+            launch_convsta(c->cur_stream, x->as<half_t>(), H4 * W4, c->sta_w16.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
+        }
+        if (sta_side) {
+            HIPCHECK(hipEventRecord(c->ev_join, c->side_stream));
+            c->cur_stream = st;
+        }
     }
     const bool fork = c->opt_branches != 0;
     if (fork) {
@@ -799,7 +814,7 @@ int run_network(sfd2_ctx *c, const float *img_dev, int normalise)
         ProfScope ps(c, "ConvSta", "convsta_kernel", 2.0 * P4 * 3 * 256, P4 * (512 + 12));
         launch_convsta(st, x->as<half_t>(), H4 * W4, c->sta_w16.as<float>(), c->sta_b.as<float>(), c->sta.as<float>());
     }
-    if (fork) HIPCHECK(hipStreamWaitEvent(st, c->ev_join, 0));
+    if (fork || sta_side) HIPCHECK(hipStreamWaitEvent(st, c->ev_join, 0));
     HIPCHECK(hipGetLastError());
     if (c->net_error) { c->net_error = 0; return -1; }      // (a layer helper recorded an error: sfd2_last_error has its text)
     return 0;

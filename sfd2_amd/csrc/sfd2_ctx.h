@@ -202,6 +202,7 @@ struct sfd2_ctx {
     int opt_no_rf_c = 0;               // sfd2_set_option "no_rf_c": conv2b on conv_igemm2<comp> instead of conv3x3_rf<comp> (A/B switch)
     int opt_generic_c = 0;             // sfd2_set_option "generic_c": SFD2_PREC_F16C layers on the generic reference kernel (tests)
     int opt_branches = 0;              // sfd2_set_option "branches": detector branch on a second stream beside the descriptor branch
+    int opt_sta_side = 0;              // sfd2_set_option "sta_side": ConvSta on the side stream beside the head branches' 3x3 layers (throughput path)
     hipStream_t side_stream = nullptr; // the detector branch (convPa.0 -> convPa.3 -> convPb -> detector_head)
     hipStream_t cur_stream = nullptr;  // stream the conv()/ProfScope helpers launch on (main or side)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

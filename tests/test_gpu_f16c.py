@@ -341,8 +341,19 @@ def test_f16c_hipgraph_cache_equals_eager(model_c):
         ctx.set_precision("f16c")
         got = unit(0)
         assert all(torch.equal(g, w) for g, w in zip(got, want[0]))
+        # option "sta_side" (round 6): ConvSta as a fork inside the captured graph -- the same bits, eager and replayed, images alternating
+        ctx.set_option("sta_side", 1)
+        for rnd in range(3):
+            for i in (0, 1):
+                got = unit(i)
+                assert all(torch.equal(g, w) for g, w in zip(got, want[i])), ("sta_side", rnd, i)
+        ctx.set_option("graphs", 0)
+        for i in (0, 1):
+            got = unit(i)
+            assert all(torch.equal(g, w) for g, w in zip(got, want[i])), ("sta_side eager", i)
     finally:
         ctx.set_option("graphs", 0)
+        ctx.set_option("sta_side", 0)
         ctx.set_precision("f16c")
 
 

@@ -33,6 +33,8 @@ ROWS = [
     ({"branches": 1}, F16S, False),      # (no sparse convDa.3 beside a side stream: another fp32 summation order)
     ({"branches": 1, "sparse_desc": 0}, F16S, False),
     ({"cu_limit": 64}, ALL, True),
+    ({"sta_side": 1}, F16S, True),           # (round 6: ConvSta on the side stream: the same kernel, the same bits)
+    ({"sta_side": 1, "branches": 1}, F16S, False),      # ("branches" owns the side stream: sta_side steps back)
     ({"cu_limit": 7, "fuse": 0}, F16S, False),
     ({"x3_pp": 0}, ("f16x3",), False),
     ({"auto_range": 0}, F16S, False),
